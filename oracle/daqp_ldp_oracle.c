@@ -1,0 +1,409 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU parity oracle for the batched condensed-MPC QP path.
+ *
+ * Nothing in the shipped package may include, link or call this file; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it (as the checker /
+ * the reported CPU baseline, never as the product).
+ *
+ * What it restates
+ * ----------------
+ * The reference's online path is compute_control -> solve -> DAQP.update + DAQP.solve
+ * (/root/reference/src/utils.jl:43-51, :268-283) and, in its generated-C form,
+ * mpc_compute_control (/root/reference/codegen/mpc_update_qp.c:29-54):
+ *
+ *     dupper/dlower = du/dl + Dth*theta            mpc_update_qp.c:1-10
+ *     cold start (empty working set)               mpc_update_qp.c:44-47
+ *     daqp_ldp                                     [EXT] libdaqp, called at mpc_update_qp.c:48
+ *     control = R^-1 u* + u_offset + Uth_offset*theta   mpc_update_qp.c:14-22
+ *
+ * The solver itself (libdaqp, DAQPBase ~0.4.4, /root/reference/Project.toml:9,30) is a
+ * third-party dependency that is NOT vendored under /root/reference and is not installed in
+ * the build image.  daqp_ldp below is therefore a restatement of the PUBLISHED algorithm:
+ * Arnstrom, Bemporad, Axehill, "A Dual Active-Set Solver for Embedded Quadratic Programming
+ * Using Recursive LDL' Updates", IEEE TAC 2022 (cited at /root/reference/README.md:74-83):
+ * dual active-set iterations on the least-distance problem
+ *
+ *     min 1/2 |u|^2   s.t.  dlower <= M u <= dupper
+ *
+ * with a recursively updated LDL' factorisation of M_W M_W', most-violated-constraint
+ * selection with primal_tol, dual ratio test with dual_tol, a singular-direction branch when
+ * the new row is linearly dependent (D < zero_tol), and progress/cycle/iteration guards.
+ * Tolerances follow /root/reference/docs/src/manual/solver.md:49-56.  libdaqp's pivoting
+ * heuristic (reordering of the last two working-set entries for conditioning) is not part of
+ * the published algorithm and is not restated.
+ *
+ * Parity pinning: the reference's own known answers that any correct strictly-convex QP
+ * solver must reproduce (K1 u = 1.7612519326 at
+ * /root/reference/test/runtests.jl:62-66, K4 :1306-1318) are checked in
+ * tests/test_oracle.py; iteration counts and working sets of libdaqp itself are not pinned
+ * by any reference test ("parity vs DAQP internals: unpinned").
+ *
+ * Arithmetic contract (shared with the HIP kernels so that results are bit-comparable):
+ * IEEE binary64, every multiply-add written as an explicit fma(), sums accumulated in
+ * index order, correctly rounded division; build with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SENSE_ACTIVE 1
+#define SENSE_LOWER 2
+#define SENSE_IMMUTABLE 4
+#define SENSE_SOFT 8
+#define SENSE_BINARY 16
+
+#define EXIT_SOFT_OPTIMAL 2
+#define EXIT_OPTIMAL 1
+#define EXIT_INFEASIBLE (-1)
+#define EXIT_CYCLE (-2)
+#define EXIT_UNBOUNDED (-3)
+#define EXIT_ITERLIMIT (-4)
+#define EXIT_NONCONVEX (-5)
+#define EXIT_OVERDETERMINED_INITIAL (-6)
+
+#define TRI(i) (((i) * ((i) + 1)) / 2)
+
+typedef struct {
+    int32_t n, m, ms, nth, nout;
+    const double *M;     /* m x n   row-major, rows normalised                 */
+    const double *du0;   /* m                                                   */
+    const double *dl0;   /* m                                                   */
+    const double *Dth;   /* m x nth row-major                                   */
+    const double *Rout;  /* nout x n row-major: first rows of R^-1              */
+    const double *x0;    /* nout                                                */
+    const double *Xth;   /* nout x nth row-major                                */
+    const int32_t *sense;/* m                                                   */
+} oracle_ldp;
+
+typedef struct {
+    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
+    int32_t cycle_tol, iter_limit;
+} oracle_settings;
+
+typedef struct {
+    int n, m, cap, na, sing, reuse, nsoft_act;
+    double *L, *D, *lam, *lam_star, *xl, *zl, *u, *dupper, *dlower, *w;
+    int *WS;
+    int32_t *sense;
+    double fval, soft_slack;
+} work_t;
+
+static work_t *work_new(int n, int m, int nsoft) {
+    work_t *w = (work_t *)calloc(1, sizeof(work_t));
+    int cap = n + 1 + nsoft;                /* hard rows <= n (+1 singular), soft rows extra */
+    w->n = n; w->m = m; w->cap = cap;
+    w->L = (double *)calloc((size_t)TRI(cap + 1), sizeof(double));
+    w->D = (double *)calloc(cap + 1, sizeof(double));
+    w->lam = (double *)calloc(cap + 1, sizeof(double));
+    w->lam_star = (double *)calloc(cap + 1, sizeof(double));
+    w->xl = (double *)calloc(cap + 1, sizeof(double));
+    w->zl = (double *)calloc(cap + 1, sizeof(double));
+    w->w = (double *)calloc(cap + 1, sizeof(double));
+    w->u = (double *)calloc(n > 0 ? n : 1, sizeof(double));
+    w->dupper = (double *)calloc(m > 0 ? m : 1, sizeof(double));
+    w->dlower = (double *)calloc(m > 0 ? m : 1, sizeof(double));
+    w->WS = (int *)calloc(cap + 1, sizeof(int));
+    w->sense = (int32_t *)calloc(m > 0 ? m : 1, sizeof(int32_t));
+    return w;
+}
+
+static void work_free(work_t *w) {
+    free(w->L); free(w->D); free(w->lam); free(w->lam_star); free(w->xl); free(w->zl);
+    free(w->w); free(w->u); free(w->dupper); free(w->dlower); free(w->WS); free(w->sense);
+    free(w);
+}
+
+/* Append constraint j to the working set: new row of L, new pivot of D (paper sec. IV-A). */
+static void ldl_add(work_t *w, const oracle_ldp *p, const oracle_settings *s, int j) {
+    const int n = w->n, na = w->na;
+    double *row = &w->L[TRI(na)];
+    const double *mj = &p->M[(size_t)j * n];
+    double dnew = 0.0;
+    for (int i = 0; i < na; i++) {
+        const double *mi = &p->M[(size_t)w->WS[i] * n];
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc = fma(mi[k], mj[k], acc);
+        row[i] = acc;
+    }
+    for (int k = 0; k < n; k++) dnew = fma(mj[k], mj[k], dnew);
+    /* soft rows: slack measured in the normalised row's units, weight 1/rho_soft -- the
+     * convention /root/reference/src/utils.jl:329-364 (make_singlesided) spells out */
+    if (w->sense[j] & SENSE_SOFT) dnew += s->rho_soft;
+    for (int i = 0; i < na; i++) {          /* q = L \ (M_W m_j) */
+        double acc = row[i];
+        const double *li = &w->L[TRI(i)];
+        for (int t = 0; t < i; t++) acc = fma(-li[t], row[t], acc);
+        row[i] = acc;
+    }
+    for (int i = 0; i < na; i++) {          /* l = D \ q ; d_new = m_j'm_j - sum l_i q_i */
+        double q = row[i];
+        double l = q / w->D[i];
+        row[i] = l;
+        dnew = fma(-l, q, dnew);
+    }
+    row[na] = 1.0;
+    const int is_soft = (w->sense[j] & SENSE_SOFT) != 0;
+    /* n+1 hard rows in R^n are always dependent, whatever rounding says */
+    if (dnew < s->zero_tol || (!is_soft && na - w->nsoft_act >= n)) {
+        w->D[na] = 0.0;
+        w->sing = na;
+    } else {
+        w->D[na] = dnew;
+    }
+    w->WS[na] = j;
+    w->lam[na] = 0.0;
+    w->lam_star[na] = 0.0;
+    w->sense[j] |= SENSE_ACTIVE;
+    w->nsoft_act += is_soft;
+    w->na = na + 1;
+}
+
+/* Drop working-set position r: compact L and apply the rank-one update
+ * L~ D~ L~' = L D L' + D_r w w' to the trailing block (paper sec. IV-B). */
+static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
+    const int na = w->na, nup = na - r - 1;
+    double *wv = w->w;
+    double alpha = w->D[r];
+    for (int t = 0; t < nup; t++) wv[t] = w->L[TRI(r + 1 + t) + r];
+    for (int i = r; i < na - 1; i++) {      /* new row i = old row i+1 without column r */
+        double *dst = &w->L[TRI(i)];
+        const double *src = &w->L[TRI(i + 1)];
+        for (int c = 0; c < r; c++) dst[c] = src[c];
+        for (int c = r; c < i; c++) dst[c] = src[c + 1];
+        dst[i] = 1.0;
+    }
+    w->sing = -1;
+    for (int t = 0; t < nup; t++) {
+        const int i = r + t;
+        const double pt = wv[t];
+        const double dold = w->D[i + 1];
+        const double dbar = fma(alpha * pt, pt, dold);
+        if (dbar < s->zero_tol) {
+            w->D[i] = 0.0;
+            w->sing = i;
+            break;
+        }
+        const double beta = (pt * alpha) / dbar;
+        alpha = (dold * alpha) / dbar;
+        w->D[i] = dbar;
+        for (int q = t + 1; q < nup; q++) {
+            double *lqi = &w->L[TRI(r + q) + i];
+            wv[q] = fma(-pt, *lqi, wv[q]);
+            *lqi = fma(beta, wv[q], *lqi);
+        }
+    }
+    if (w->sense[w->WS[r]] & SENSE_SOFT) w->nsoft_act--;
+    w->sense[w->WS[r]] &= ~(SENSE_ACTIVE | SENSE_LOWER);
+    for (int i = r; i < na - 1; i++) {
+        w->WS[i] = w->WS[i + 1];
+        w->lam[i] = w->lam[i + 1];
+    }
+    w->na = na - 1;
+    if (r < w->reuse) w->reuse = r;
+}
+
+/* Constrained stationary point: solve (L D L') lam* = -d_W. */
+static void compute_csp(work_t *w) {
+    const int na = w->na;
+    for (int i = w->reuse; i < na; i++) {
+        const int j = w->WS[i];
+        double acc = (w->sense[j] & SENSE_LOWER) ? -w->dlower[j] : -w->dupper[j];
+        const double *li = &w->L[TRI(i)];
+        for (int t = 0; t < i; t++) acc = fma(-li[t], w->xl[t], acc);
+        w->xl[i] = acc;
+    }
+    for (int i = w->reuse; i < na; i++) w->zl[i] = w->xl[i] / w->D[i];
+    for (int i = na - 1; i >= 0; i--) {
+        double acc = w->zl[i];
+        for (int t = na - 1; t > i; t--) acc = fma(-w->L[TRI(t) + i], w->lam_star[t], acc);
+        w->lam_star[i] = acc;
+    }
+    w->reuse = na;
+}
+
+/* Direction p with M_W' p = 0 and p_sing = +-1, stored in lam_star. */
+static void singular_direction(work_t *w) {
+    const int sg = w->sing;
+    const double *ls = &w->L[TRI(sg)];
+    for (int i = sg - 1; i >= 0; i--) {
+        double acc = -ls[i];
+        for (int t = sg - 1; t > i; t--) acc = fma(-w->L[TRI(t) + i], w->lam_star[t], acc);
+        w->lam_star[i] = acc;
+    }
+    w->lam_star[sg] = 1.0;
+    if (w->sense[w->WS[sg]] & SENSE_LOWER)
+        for (int i = 0; i <= sg; i++) w->lam_star[i] = -w->lam_star[i];
+}
+
+static void primal_and_fval(work_t *w, const oracle_ldp *p, const oracle_settings *s) {
+    const int n = w->n;
+    double soft = 0.0;
+    for (int k = 0; k < n; k++) w->u[k] = 0.0;
+    for (int i = 0; i < w->na; i++) {
+        const int j = w->WS[i];
+        const double *mi = &p->M[(size_t)j * n];
+        const double l = w->lam_star[i];
+        for (int k = 0; k < n; k++) w->u[k] = fma(-mi[k], l, w->u[k]);
+        if (w->sense[j] & SENSE_SOFT) soft = fma(l * l, s->rho_soft, soft);
+    }
+    double fv = 0.0;
+    for (int k = 0; k < n; k++) fv = fma(w->u[k], w->u[k], fv);
+    w->soft_slack = soft;
+    w->fval = fv + soft;
+}
+
+static void write_outputs(const work_t *w, const oracle_ldp *p, const double *theta,
+                          double *xout, uint64_t *active, int nwords) {
+    const int n = p->n, nth = p->nth;
+    for (int k = 0; k < p->nout; k++) {
+        double xs = 0.0, sh = p->x0[k];
+        for (int c = 0; c < n; c++) xs = fma(p->Rout[(size_t)k * n + c], w->u[c], xs);
+        for (int t = 0; t < nth; t++) sh = fma(p->Xth[(size_t)k * nth + t], theta[t], sh);
+        xout[k] = xs + sh;
+    }
+    if (active) {
+        for (int q = 0; q < nwords; q++) active[q] = 0;
+        for (int i = 0; i < w->na; i++) {
+            const int j = w->WS[i];
+            const int bit = (w->sense[j] & SENSE_LOWER) ? p->m + j : j;
+            active[bit >> 6] |= (uint64_t)1 << (bit & 63);
+        }
+    }
+}
+
+/* One cold- (warm == NULL) or warm-started solve.  Returns the DAQP-style exit flag. */
+static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
+                     const double *theta, const uint64_t *warm, double *xout,
+                     int32_t *iters, uint64_t *active, int nwords) {
+    const int n = p->n, m = p->m, nth = p->nth;
+    int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
+    double best_fval = -1.0;
+
+    /* mpc_update_qp.c:1-10 */
+    for (int j = 0; j < m; j++) {
+        double sh = 0.0;
+        for (int t = 0; t < nth; t++) sh = fma(p->Dth[(size_t)j * nth + t], theta[t], sh);
+        w->dupper[j] = p->du0[j] + sh;
+        w->dlower[j] = p->dl0[j] + sh;
+        w->sense[j] = p->sense[j] & ~SENSE_LOWER;
+    }
+    w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
+    for (int k = 0; k < n; k++) w->u[k] = 0.0;
+
+    /* initial working set: equality rows (ACTIVE|IMMUTABLE) and, if warm, the given mask */
+    for (int j = 0; j < m; j++) {
+        int want = (p->sense[j] & SENSE_ACTIVE) != 0, lower = 0;
+        if (warm && !(p->sense[j] & SENSE_IMMUTABLE)) {
+            if ((warm[j >> 6] >> (j & 63)) & 1) want = 1;
+            else if ((warm[(m + j) >> 6] >> ((m + j) & 63)) & 1) { want = 1; lower = 1; }
+        }
+        if (!want) { w->sense[j] &= ~SENSE_ACTIVE; continue; }
+        if (lower) w->sense[j] |= SENSE_LOWER;
+        ldl_add(w, p, s, j);
+        if (w->sing >= 0) {
+            if (p->sense[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
+            /* dependent warm-start row: drop it again */
+            w->na--; w->sing = -1;
+            if (w->sense[j] & SENSE_SOFT) w->nsoft_act--;
+            w->sense[j] &= ~(SENSE_ACTIVE | SENSE_LOWER);
+        }
+    }
+
+    for (; iter < s->iter_limit; iter++) {
+        if (w->sing < 0) {
+            compute_csp(w);
+            int nblock = 0, rm = -1;
+            double alpha = 0.0;
+            for (int i = 0; i < w->na; i++) {
+                const int j = w->WS[i];
+                if (w->sense[j] & SENSE_IMMUTABLE) continue;
+                if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
+                else if (w->lam_star[i] > -s->dual_tol) continue;
+                const double cand = -w->lam[i] / (w->lam_star[i] - w->lam[i]);
+                if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
+                nblock++;
+            }
+            if (nblock == 0) {
+                primal_and_fval(w, p, s);
+                if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
+                /* most violated constraint, primal_tol margin */
+                double min_val = -s->primal_tol;
+                int add = -1, isupper = 0;
+                for (int j = 0; j < m; j++) {
+                    if (w->sense[j] & (SENSE_ACTIVE | SENSE_IMMUTABLE)) continue;
+                    const double *mj = &p->M[(size_t)j * n];
+                    double Mu = 0.0;
+                    for (int k = 0; k < n; k++) Mu = fma(mj[k], w->u[k], Mu);
+                    const double vu = w->dupper[j] - Mu;
+                    if (vu < min_val) { add = j; isupper = 1; min_val = vu; }
+                    else {
+                        const double vl = -(w->dlower[j] - Mu);
+                        if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
+                    }
+                }
+                if (add < 0) {
+                    exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
+                    break;
+                }
+                for (int i = 0; i < w->na; i++) w->lam[i] = w->lam_star[i];
+                if (!isupper) w->sense[add] |= SENSE_LOWER;
+                ldl_add(w, p, s, add);
+                if (w->fval - best_fval < s->progress_tol) {
+                    if (++cycle > s->cycle_tol) { exitflag = EXIT_CYCLE; break; }
+                } else { best_fval = w->fval; cycle = 0; }
+            } else {
+                for (int i = 0; i < w->na; i++)
+                    w->lam[i] = fma(alpha, w->lam_star[i] - w->lam[i], w->lam[i]);
+                ldl_remove(w, s, rm);
+            }
+        } else {
+            singular_direction(w);
+            int nblock = 0, rm = -1;
+            double alpha = 0.0;
+            for (int i = 0; i < w->na; i++) {
+                const int j = w->WS[i];
+                if (w->sense[j] & SENSE_IMMUTABLE) continue;
+                if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
+                else if (w->lam_star[i] > -s->dual_tol) continue;
+                const double cand = -w->lam[i] / w->lam_star[i];
+                if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
+                nblock++;
+            }
+            if (nblock == 0) { exitflag = EXIT_INFEASIBLE; break; }
+            for (int i = 0; i < w->na; i++) w->lam[i] = fma(alpha, w->lam_star[i], w->lam[i]);
+            ldl_remove(w, s, rm);
+        }
+    }
+done:
+    write_outputs(w, p, theta, xout, active, nwords);
+    if (iters) *iters = iter;
+    return exitflag;
+}
+
+/* ---------------------------------------------------------------- exported entry points */
+int oracle_active_words(int m) { return (2 * m + 63) / 64; }
+
+void oracle_default_settings(oracle_settings *s) {
+    s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
+    s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+}
+
+/* theta: N rows of nth; X: N rows of nout; active: N rows of nwords (may be NULL);
+ * warm: N rows of nwords initial working sets (may be NULL = cold start). */
+void oracle_solve_batch(const oracle_ldp *p, const oracle_settings *s, int64_t N,
+                        const double *theta, const uint64_t *warm, double *X,
+                        int32_t *exitflag, int32_t *iters, uint64_t *active) {
+    const int nw = oracle_active_words(p->m);
+    int nsoft = 0;
+    for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
+    work_t *w = work_new(p->n, p->m, nsoft);
+    for (int64_t i = 0; i < N; i++) {
+        int32_t it = 0;
+        int ef = solve_one(w, p, s, theta + i * p->nth, warm ? warm + i * nw : NULL,
+                           X + i * p->nout, &it, active ? active + i * nw : NULL, nw);
+        exitflag[i] = ef;
+        if (iters) iters[i] = it;
+    }
+    work_free(w);
+}

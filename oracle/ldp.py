@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the QP -> LDP transform and a ctypes
+front end to the C oracle solver (oracle/daqp_ldp_oracle.c).
+
+Nothing in the shipped package may import this; only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg do.
+
+`qp2ldp` follows /root/reference/src/codegen.jl:239-280 (`qp2ldp`) line by line:
+
+    R      = chol((H+H')/2)                         :242   (upper factor, H = R'R)
+    Mext   = [I_nb ; A] / R.U                        :243
+    Vth    = R.L \\ f_theta ;  v = R.L \\ f           :244-245
+    Dth    = W + Mext*Vth ;  du/dl = bu/bl + Mext*v  :246-249
+    rows of Mext, Dth, du, dl divided by |Mext_i|    :252-264
+    Uth_offset = -(H \\ f_theta)[1:nout,:]            :269-270
+    u_offset   = -(H \\ f)[1:nout]                    :272-273
+
+and adds what the batched backend needs on top: the first `nout` rows of R^-1 (un-normalised)
+so that the primal solution is recovered as  x = R^-1 u + u_offset + Uth_offset*theta
+(codegen/mpc_update_qp.c:14-22, where `uscaling[i]*xstar[i]` is the same product), and the
+prestabilising-feedback correction `Uth_offset[:, :nx] -= K` (codegen.jl:157, utils.jl:48-49).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+@dataclass
+class LDP:
+    n: int
+    m: int
+    ms: int
+    nth: int
+    nout: int
+    M: np.ndarray       # m x n  normalised rows
+    du0: np.ndarray     # m
+    dl0: np.ndarray     # m
+    Dth: np.ndarray     # m x nth
+    Rout: np.ndarray    # nout x n
+    x0: np.ndarray      # nout
+    Xth: np.ndarray     # nout x nth
+    sense: np.ndarray   # m int32
+    scale: np.ndarray   # m row norms before normalisation
+
+    def contiguous(self):
+        for name in ("M", "du0", "dl0", "Dth", "Rout", "x0", "Xth", "scale"):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=np.float64))
+        self.sense = np.ascontiguousarray(self.sense, dtype=np.int32)
+        return self
+
+
+def qp2ldp(H, f, f_theta, A, bu, bl, W, sense, nout, K=None) -> LDP:
+    H = np.asarray(H, float)
+    n = H.shape[0]
+    f = np.asarray(f, float).reshape(n)
+    f_theta = np.asarray(f_theta, float).reshape(n, -1)
+    nth = f_theta.shape[1]
+    bu = np.asarray(bu, float).reshape(-1)
+    bl = np.asarray(bl, float).reshape(-1)
+    m = bu.size
+    A = np.asarray(A, float).reshape(-1, n)
+    ms = m - A.shape[0]
+    W = np.asarray(W, float).reshape(m, nth)
+    Rl = np.linalg.cholesky((H + H.T) / 2)          # lower; R.U = Rl.T
+    Rinv = np.linalg.solve(Rl.T, np.eye(n))         # R^-1 (upper triangular)
+    Mext = np.vstack([np.eye(n)[:ms], A]) @ Rinv
+    Vth = np.linalg.solve(Rl, f_theta)
+    v = np.linalg.solve(Rl, f)
+    Dth = W + Mext @ Vth
+    shift = Mext @ v
+    du, dl = bu + shift, bl + shift
+    scale = np.linalg.norm(Mext, axis=1)
+    nzr = scale > 0
+    Mext[nzr] /= scale[nzr, None]
+    Dth[nzr] /= scale[nzr, None]
+    du[nzr] /= scale[nzr]
+    dl[nzr] /= scale[nzr]
+    Xth = -np.linalg.solve(H, f_theta)[:nout]
+    x0 = -np.linalg.solve(H, f)[:nout]
+    if K is not None:
+        K = np.atleast_2d(np.asarray(K, float))
+        Xth = Xth.copy()
+        Xth[:K.shape[0], :K.shape[1]] -= K
+    return LDP(n, m, ms, nth, nout, Mext, du, dl, Dth, Rinv[:nout].copy(), x0, Xth,
+               np.asarray(sense, np.int32).reshape(m), scale).contiguous()
+
+
+# ---------------------------------------------------------------- ctypes front end
+class _CLdp(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("m", ctypes.c_int32), ("ms", ctypes.c_int32),
+                ("nth", ctypes.c_int32), ("nout", ctypes.c_int32),
+                ("M", ctypes.c_void_p), ("du0", ctypes.c_void_p), ("dl0", ctypes.c_void_p),
+                ("Dth", ctypes.c_void_p), ("Rout", ctypes.c_void_p), ("x0", ctypes.c_void_p),
+                ("Xth", ctypes.c_void_p), ("sense", ctypes.c_void_p)]
+
+
+class Settings(ctypes.Structure):
+    """Field order = oracle_settings in daqp_ldp_oracle.c; defaults = solver.md:49-56."""
+    _fields_ = [("primal_tol", ctypes.c_double), ("dual_tol", ctypes.c_double),
+                ("zero_tol", ctypes.c_double), ("progress_tol", ctypes.c_double),
+                ("fval_bound", ctypes.c_double), ("rho_soft", ctypes.c_double),
+                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "daqp_ldp_oracle.c")):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_active_words.restype = ctypes.c_int
+        _lib.oracle_solve_batch.restype = None
+    return _lib
+
+
+def default_settings() -> Settings:
+    s = Settings()
+    lib().oracle_default_settings(ctypes.byref(s))
+    return s
+
+
+def active_words(m):
+    return (2 * m + 63) // 64
+
+
+def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None):
+    """Solve every row of theta (N x nth).  Returns X (N x nout), exitflag, iters, active."""
+    L = lib()
+    ldp.contiguous()
+    theta = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, ldp.nth))
+    N = theta.shape[0]
+    nw = active_words(ldp.m)
+    X = np.empty((N, ldp.nout))
+    ef = np.empty(N, np.int32)
+    it = np.empty(N, np.int32)
+    act = np.zeros((N, nw), np.uint64)
+    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout,
+              *(a.ctypes.data for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0,
+                                        ldp.Xth, ldp.sense)))
+    s = settings if settings is not None else default_settings()
+    wptr = None
+    if warm is not None:
+        warm = np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, nw))
+        wptr = ctypes.c_void_p(warm.ctypes.data)
+    L.oracle_solve_batch(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N),
+                         ctypes.c_void_p(theta.ctypes.data), wptr,
+                         ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(ef.ctypes.data),
+                         ctypes.c_void_p(it.ctypes.data), ctypes.c_void_p(act.ctypes.data))
+    return X, ef, it, act

@@ -1,0 +1,443 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of LinearMPC.jl's condensing step.
+
+This module is part of the parity oracle.  Nothing in the shipped package may
+import it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+
+It turns a linear MPC description (model, weights, bounds, general constraints)
+into the dense multi-parametric QP
+
+    min_U  1/2 U'HU + (f + f_theta th)'U    s.t.  bl + W th <= [I_ms 0; A] U <= bu + W th
+
+exactly the way the reference builds it on the Julia host, so that the fixtures
+fed to the HIP path are the matrices a LinearMPC.jl user would hand over.  Only
+the features the benchmark/known-answer problems exercise are restated (no
+preview modes, no move blocking, no prestabilising feedback K, no binaries,
+no operating-point offsets).  Reference lines followed, all under
+/root/reference/src/:
+
+    zoh                     utils.jl:291-295
+    Model(A,B,Ts)           model.jl:78-90
+    get_parameter_dims      mpc2mpqp.jl:147-164
+    create_extended_system  mpc2mpqp.jl:649-690
+    create_extended_cost    mpc2mpqp.jl:692-731
+    state_predictor         mpc2mpqp.jl:20-46
+    create_objective        mpc2mpqp.jl:407-533
+    create_controlbounds    mpc2mpqp.jl:206-245
+    create_general_constraints mpc2mpqp.jl:249-354
+    create_constraints      mpc2mpqp.jl:358-402
+    remove_redundant        mpc2mpqp.jl:733-773
+    remove_duplicate        mpc2mpqp.jl:775-828
+    MPQP(obj,constraints)   mpc2mpqp.jl:868-899
+    example problems        mpc_examples.jl:104-141 (invpend), :241-286 (mass_spring),
+                            README.md:39-52 (pendulum on a cart)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+from scipy.linalg import expm, block_diag
+
+# DAQP constraint-sense bit flags ([EXT] DAQPBase constants used at mpc2mpqp.jl:875-884)
+ACTIVE, LOWER, IMMUTABLE, SOFT, BINARY = 1, 2, 4, 8, 16
+EQUALITY = ACTIVE + IMMUTABLE
+
+
+def zoh(A, B, Ts):
+    """utils.jl:291-295 -- exact zero-order-hold discretisation via one matrix exponential."""
+    A = np.atleast_2d(np.asarray(A, float))
+    B = np.asarray(B, float).reshape(A.shape[0], -1)
+    nx, nu = B.shape
+    blk = np.zeros((nx + nu, nx + nu))
+    blk[:nx, :nx] = A * Ts
+    blk[:nx, nx:] = B * Ts
+    E = expm(blk)
+    return E[:nx, :nx].copy(), E[:nx, nx:].copy()
+
+
+def _as_weight(w, n):
+    """utils.jl:297-299 matrixify: scalar -> w*I, vector -> diag, matrix -> itself."""
+    w = np.asarray(w, float)
+    if w.ndim == 0:
+        return np.eye(n) * float(w)
+    if w.ndim == 1:
+        return np.diag(w)
+    return w.copy()
+
+
+@dataclass
+class GeneralConstraint:
+    """types.jl:4-18 -- lb <= Ax x_k + Au u_k <= ub for the (1-based) time steps in ks."""
+    Ax: np.ndarray
+    Au: np.ndarray
+    lb: np.ndarray
+    ub: np.ndarray
+    ks: Sequence[int]
+    soft: bool = False
+    prio: int = 0
+
+
+@dataclass
+class MPCProblem:
+    """The subset of `mutable struct MPC` (types.jl:108-157) that the restated path reads."""
+    F: np.ndarray
+    G: np.ndarray
+    C: np.ndarray
+    Np: int
+    Nc: int
+    Q: np.ndarray
+    R: np.ndarray
+    Rr: np.ndarray
+    umin: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    umax: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    constraints: List[GeneralConstraint] = field(default_factory=list)
+    reference_tracking: bool = True
+    preprocess: bool = True
+    Ts: float = -1.0
+
+    @property
+    def nx(self):
+        return self.F.shape[0]
+
+    @property
+    def nu(self):
+        return self.G.shape[1]
+
+    @property
+    def ny(self):
+        return self.C.shape[0]
+
+    # mpc2mpqp.jl:147-164
+    def parameter_dims(self):
+        nr = self.ny if self.reference_tracking else 0
+        nuprev = self.nu if np.any(self.Rr != 0) else 0
+        return self.nx, nr, 0, nuprev, 0
+
+    def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0):
+        """setup.jl:57-79 add_constraint! (default ks = 2:Np, missing side = +-1e30)."""
+        lb = np.atleast_1d(np.asarray(lb, float))
+        ub = np.atleast_1d(np.asarray(ub, float))
+        m = max(lb.size, ub.size)
+        if m == 0 or (Ax is None and Au is None):
+            return
+        ub = np.concatenate([ub, 1e30 * np.ones(m - ub.size)])
+        lb = np.concatenate([lb, -1e30 * np.ones(m - lb.size)])
+        Ax = np.zeros((m, self.nx)) if Ax is None else np.atleast_2d(np.asarray(Ax, float))
+        Au = np.zeros((m, self.nu)) if Au is None else np.atleast_2d(np.asarray(Au, float))
+        ks = list(range(2, self.Np + 1)) if ks is None else list(ks)
+        self.constraints.append(GeneralConstraint(Ax, Au, lb, ub, ks, soft, prio))
+
+
+def make_mpc(F, G, C=None, Np=10, Nc=None, Q=None, R=None, Rr=None, umin=(), umax=(),
+             reference_tracking=True, Ts=-1.0):
+    """MPC(F,G;...) + set_objective! + set_bounds! (types.jl:159-172, setup.jl:36-46,:136-150).
+
+    Default weights follow MPCWeights(nu,nx,nr) (types.jl:34-37): Q=I_ny, R=I_nu, Rr=0.
+    """
+    F = np.atleast_2d(np.asarray(F, float))
+    G = np.asarray(G, float).reshape(F.shape[0], -1)
+    nx, nu = G.shape
+    C = np.eye(nx) if C is None else np.atleast_2d(np.asarray(C, float))
+    ny = C.shape[0]
+    Nc = Np if Nc is None else Nc
+    Q = np.eye(ny) if Q is None else _as_weight(Q, ny)
+    R = np.eye(nu) if R is None else _as_weight(R, nu)
+    Rr = np.zeros((nu, nu)) if Rr is None else _as_weight(Rr, nu)
+    return MPCProblem(F, G, C, Np, Nc, Q, R, Rr,
+                      np.atleast_1d(np.asarray(umin, float)), np.atleast_1d(np.asarray(umax, float)),
+                      [], reference_tracking, True, Ts)
+
+
+# --------------------------------------------------------------------------- prediction
+def state_predictor(F, G, Np, Nc):
+    """mpc2mpqp.jl:20-46.  X = Phi x0 + Gam U with u_k = u_Nc held for k > Nc."""
+    nx, nu = G.shape
+    Gam = np.zeros(((Np + 1) * nx, Nc * nu))
+    Phi = np.zeros(((Np + 1) * nx, nx))
+    Phi[:nx] = np.eye(nx)
+    Fpow, FG = F.copy(), G.copy()
+    for i in range(1, Nc + 1):
+        for j in range(0, Nc - i + 1):
+            Gam[(i + j) * nx:(i + j + 1) * nx, j * nu:(j + 1) * nu] = FG
+        Phi[i * nx:(i + 1) * nx] = Fpow
+        if i == Nc:
+            break
+        Fpow = Fpow @ F
+        FG = F @ FG
+    for i in range(Nc + 1, Np + 1):
+        Gam[i * nx:(i + 1) * nx] = F @ Gam[(i - 1) * nx:i * nx]
+        Gam[i * nx:(i + 1) * nx, -nu:] += G
+        Phi[i * nx:(i + 1) * nx] = F @ Phi[(i - 1) * nx:i * nx]
+    return Phi, Gam
+
+
+def extended_system(p: MPCProblem):
+    """mpc2mpqp.jl:649-690 with K = 0, no disturbance, no offsets."""
+    nx, nr, _, nuprev, _ = p.parameter_dims()
+    nu, ny = p.nu, p.ny
+    F, G, C = p.F.copy(), p.G.copy(), p.C.copy()
+    if nr > 0:                                   # reference rides along as constant states
+        F = block_diag(F, np.eye(ny))
+        G = np.vstack([G, np.zeros((ny, nu))])
+        C = np.hstack([C, -np.eye(ny)])
+    if nuprev > 0:                               # previous input as a state, du as an output
+        F = block_diag(F, np.zeros((nu, nu)))
+        G = np.vstack([G, np.eye(nu)])
+        nye, nxe = C.shape
+        C = np.vstack([np.hstack([C, np.zeros((nye, nu))]),
+                       np.hstack([np.zeros((nu, nxe)), np.eye(nu)])])
+    return F, G, C
+
+
+def extended_cost(p: MPCProblem):
+    """mpc2mpqp.jl:692-731 with K = 0.  Returns Q, R, S, Qf of the extended system."""
+    nx, nr, _, nuprev, _ = p.parameter_dims()
+    nu, ny = p.nu, p.ny
+    Q, R, Rr = p.Q.copy(), p.R.copy(), p.Rr.copy()
+    Qf = Q.copy()                                # Qf, Qfx unset => terminal weight = Q (:694)
+    S = np.zeros((nx, nu))
+    if nr > 0:
+        S = np.vstack([S, np.zeros((ny, nu))])
+    if nuprev > 0:
+        Q = block_diag(Q, Rr)
+        Qf = block_diag(Qf, np.zeros((nu, nu)))
+        S = np.vstack([S, -Rr])
+        R = R + Rr
+    return Q, R, S, Qf
+
+
+def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
+    """mpc2mpqp.jl:407-533 (branches for preview / offsets / binaries / affine params unused)."""
+    N, Nc = p.Np, p.Nc
+    nxe, nue = Gam.shape[0] // (N + 1), R.shape[0]
+    posQ = np.flatnonzero(np.diag(Q) > 0)
+    Qp, Cp = Q[np.ix_(posQ, posQ)], C[posQ]
+    posQf = np.flatnonzero(np.diag(Qf) > 0)
+    Qfp, Cf = Qf[np.ix_(posQf, posQf)], C[posQf]
+
+    H = np.kron(np.eye(Nc), R)
+    H[-nue:, -nue:] += (N - Nc) * R              # held input after the control horizon
+    CQC = np.kron(np.eye(N + 1), Cp.T @ Qp @ Cp)
+    CQC[-nxe:, -nxe:] = Cf.T @ Qfp @ Cf
+    H = H + Gam.T @ CQC @ Gam
+    f_theta = Gam.T @ CQC @ Phi
+    H_theta = Phi.T @ CQC @ Phi
+    if np.any(S != 0):
+        Stot = np.vstack([np.kron(np.eye(Nc), S), np.zeros(((N - Nc + 1) * nxe, Nc * nue))])
+        Stot[Nc * nxe:N * nxe, -nue:] = np.tile(S, (N - Nc, 1))
+        GS = Gam.T @ Stot
+        H = H + GS + GS.T
+        f_theta = f_theta + Stot.T @ Phi
+    f = np.zeros(H.shape[0])
+    return (H + H.T) / 2, f, f_theta, H_theta
+
+
+def dense_constraints(p: MPCProblem, Phi, Gam):
+    """mpc2mpqp.jl:358-402 -> (A, bu, bl, W, issoft, prio); simple bounds first."""
+    nx, nr, nd, nuprev, _ = p.parameter_dims()
+    nu, Np, Nc = p.nu, p.Np, p.Nc
+    nxe = nx + nr + nd + nuprev
+    n = Gam.shape[1]
+    if p.umax.size:
+        # create_controlbounds, K = 0 branch (:220-226)
+        A = np.zeros((0, n))
+        bu, bl = np.tile(p.umax, Nc), np.tile(p.umin, Nc)
+        W = np.zeros((Nc * nu, nxe))
+        soft = np.zeros(n, bool)
+        prio = np.zeros(n, int)
+    else:
+        A, bu, bl = np.zeros((0, n)), np.zeros(0), np.zeros(0)
+        W, soft, prio = np.zeros((0, nxe)), np.zeros(0, bool), np.zeros(0, int)
+    if p.constraints:
+        eyeX = np.eye(Np + 1)
+        eyeU = np.vstack([np.eye(Nc), np.zeros((1 + Np - Nc, Nc))])
+        Ax_rows, Au_rows, ubs, lbs, softs, prios = [], [], [], [], [], []
+        for c in p.constraints:
+            mi = c.Au.shape[0]
+            kmax = Np + 1 if not np.any(c.Au) else Np
+            ks = [k for k in c.ks if k <= kmax]
+            sel = [k - 1 for k in ks]
+            pad = np.zeros((mi, nxe - nx))
+            Au_rows.append(np.kron(eyeU[sel], c.Au))
+            Ax_rows.append(np.kron(eyeX[sel], np.hstack([c.Ax, pad])))
+            ubs.append(np.tile(c.ub, len(ks)))
+            lbs.append(np.tile(c.lb, len(ks)))
+            softs.append(np.full(mi * len(ks), c.soft))
+            prios.append(np.full(mi * len(ks), c.prio, int))
+        Axt, Aut = np.vstack(Ax_rows), np.vstack(Au_rows)
+        A = np.vstack([A, Axt @ Gam + Aut])
+        W = np.vstack([W, -Axt @ Phi])
+        bu = np.concatenate([bu] + ubs)
+        bl = np.concatenate([bl] + lbs)
+        soft = np.concatenate([soft] + softs)
+        prio = np.concatenate([prio] + prios)
+    return A, bu, bl, W, soft, prio
+
+
+def sort_by_priority(A, bu, bl, W, soft, prio):
+    """mpc2mpqp.jl:859-866 (stable sort of the general rows by prio)."""
+    ns = bu.size - A.shape[0]
+    order = np.argsort(prio[ns:], kind="stable")
+    full = np.concatenate([np.arange(ns), order + ns])
+    return A[order], bu[full], bl[full], W[full], soft[full], prio[full]
+
+
+def remove_redundant(A, bu, bl, W, soft, prio):
+    """mpc2mpqp.jl:733-773: drop ~zero rows, fold single-entry rows into simple bounds."""
+    A, bu, bl, W = A.copy(), bu.copy(), bl.copy(), W.copy()
+    ns = bu.size - A.shape[0]
+    keep = list(range(ns))
+    scale = [1.0] * ns
+    for i in range(A.shape[0]):
+        a = A[i]
+        idx = ns + i
+        nrm = np.linalg.norm(a)
+        if nrm <= 1e-10:
+            continue
+        nz = np.flatnonzero(np.abs(a) > 1e-12)
+        first = nz[0]
+        if a[first] < 0:                         # unique half-plane orientation
+            A[i] = -a + 0.0
+            a = A[i]
+            bu[idx], bl[idx] = -bl[idx], -bu[idx]
+            W[idx] = -W[idx] + 0.0
+        if nz.size == 1 and first < ns and prio[first] == prio[idx] and soft[first] == soft[idx] \
+                and not np.any(W[idx] - W[first]):
+            bu[first] = min(bu[first], bu[idx] / nrm)
+            bl[first] = max(bl[first], bl[idx] / nrm)
+            continue
+        keep.append(idx)
+        scale.append(1.0 / nrm)
+    if len(keep) < bu.size:
+        keep = np.asarray(keep, int)
+        scale = np.asarray(scale)
+        A = A[keep[ns:] - ns] * scale[ns:, None]
+        bu, bl, W = bu[keep] * scale, bl[keep] * scale, W[keep] * scale[:, None]
+        soft, prio = soft[keep], prio[keep]
+    return A, bu, bl, W, soft, prio
+
+
+def remove_duplicate(A, bu, bl, W, soft, prio):
+    """mpc2mpqp.jl:775-828: merge general rows equal to 6 decimals (tightest bounds win)."""
+    ns = bu.size - A.shape[0]
+    ext = np.hstack([A, W[ns:], soft[ns:, None].astype(float), prio[ns:, None].astype(float)])
+    groups, order = {}, []
+    for i in range(ext.shape[0]):
+        key = tuple(np.round(ext[i], 6) + 0.0)
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(i)
+    if len(order) == A.shape[0]:
+        return A, bu, bl, W, soft, prio
+    firsts = np.array([groups[k][0] for k in order], int)
+    A2 = A[firsts]
+    bu2 = np.concatenate([bu[:ns], [bu[ns + np.array(groups[k])].min() for k in order]])
+    bl2 = np.concatenate([bl[:ns], [bl[ns + np.array(groups[k])].max() for k in order]])
+    full = np.concatenate([np.arange(ns), firsts + ns])
+    return A2, bu2, bl2, W[full], soft[full], prio[full]
+
+
+@dataclass
+class MPQP:
+    """types.jl:75-98 data contract (column-major Float64 on the Julia side; C-order here)."""
+    H: np.ndarray
+    f: np.ndarray
+    H_theta: np.ndarray
+    f_theta: np.ndarray
+    A: np.ndarray
+    bu: np.ndarray
+    bl: np.ndarray
+    W: np.ndarray
+    senses: np.ndarray
+    prio: np.ndarray
+    nu: int = 1
+    nx: int = 0
+
+    @property
+    def n(self):
+        return self.H.shape[0]
+
+    @property
+    def m(self):
+        return self.bu.size
+
+    @property
+    def ms(self):
+        return self.bu.size - self.A.shape[0]
+
+    @property
+    def nth(self):
+        return self.f_theta.shape[1]
+
+
+def mpc2mpqp(p: MPCProblem) -> MPQP:
+    """mpc2mpqp.jl:612-647."""
+    F, G, C = extended_system(p)
+    Phi, Gam = state_predictor(F, G, p.Np, p.Nc)
+    Q, R, S, Qf = extended_cost(p)
+    H, f, f_theta, H_theta = dense_objective(p, F, Phi, Gam, C, Q, R, S, Qf)
+    cons = dense_constraints(p, Phi, Gam)
+    cons = sort_by_priority(*cons)
+    if p.preprocess:
+        cons = remove_redundant(*cons)
+        cons = remove_duplicate(*cons)
+    A, bu, bl, W, soft, prio = cons
+    senses = np.zeros(bu.size, np.int32)         # mpc2mpqp.jl:868-885
+    for i in range(bu.size):
+        if bu[i] > 1e20 and bl[i] < -1e20:
+            senses[i] = IMMUTABLE
+        elif abs(bu[i] - bl[i]) < 1e-12:
+            senses[i] = EQUALITY
+    senses[soft.astype(bool)] += SOFT
+    bu = np.clip(bu, -1e30, 1e30)
+    bl = np.clip(bl, -1e30, 1e30)
+    return MPQP(H, f, H_theta, f_theta, A, bu, bl, W, senses, prio.astype(np.int32), p.nu, p.nx)
+
+
+# --------------------------------------------------------------------------- named problems
+def pendulum(Np=50, Nc=5) -> MPCProblem:
+    """README.md:39-52 == mpc_examples.jl:104-141 linearised at the origin (M=m=1, l=.5, damp=10)."""
+    A = np.array([[0, 1, 0, 0], [0, -10, 9.81, 0], [0, 0, 0, 1], [0, -20, 39.24, 0.0]])
+    B = 100 * np.array([[0.0], [1.0], [0.0], [2.0]])
+    C = np.array([[1.0, 0, 0, 0], [0, 0, 1.0, 0]])
+    Ts = 0.01
+    F, G = zoh(A, B, Ts)
+    return make_mpc(F, G, C, Np=Np, Nc=Nc, Q=[1.2 ** 2, 1.0], R=[0.0], Rr=[1.0],
+                    umin=[-2.0], umax=[2.0], Ts=Ts)
+
+
+def mass_spring(nm=6, Np=10, Nc=10, kappa=1.0, lam=0.0) -> MPCProblem:
+    """mpc_examples.jl:241-286: chain of nm masses, force on mass 1, |pos| <= 4 for k = 2..Nc."""
+    nx = 2 * nm
+    off = np.ones(nm - 1)
+    Fx = np.diag(kappa * off, 1) + np.diag(kappa * off, -1) - 2 * kappa * np.eye(nm)
+    Fv = np.diag(lam * off, 1) + np.diag(lam * off, -1) - 2 * lam * np.eye(nm)
+    A = np.block([[np.zeros((nm, nm)), np.eye(nm)], [Fx, Fv]])
+    B = np.zeros((nx, 1))
+    B[nm, 0] = 1.0
+    F, G = zoh(A, B, 0.5)
+    p = make_mpc(F, G, np.eye(nx), Np=Np, Nc=Nc, Q=100 * np.ones(nx), R=[1.0], Rr=[0.0],
+                 umin=[-0.5], umax=[0.5], reference_tracking=False, Ts=0.5)
+    p.add_constraint(Ax=np.hstack([np.eye(nm), np.zeros((nm, nm))]), lb=-4 * np.ones(nm),
+                     ub=4 * np.ones(nm), ks=range(2, Nc + 1))
+    return p
+
+
+def preprocessing_kat() -> MPCProblem:
+    """test/runtests.jl:1306-1318 (K4): two Au-only constraints fold into the simple bounds."""
+    F, G = zoh(np.array([[0, 1.0], [10, 0]]), np.array([[0.0], [1.0]]), 0.1)
+    p = make_mpc(F, G, np.eye(2), Np=10, umin=[-1.0], umax=[1.0], Ts=0.1)
+    p.add_constraint(Au=[[-1.0]], lb=[-0.9], ub=[1.5], ks=range(1, 11))
+    p.add_constraint(Au=[[1.0]], lb=[-0.5], ub=[2.0], ks=range(1, 11))
+    return p
+
+
+def form_parameter(p: MPCProblem, x, r=None, uprev=None):
+    """explicit.jl:54-63: theta = [x; r; d; uprev; p] (d, p empty here; r, uprev default 0)."""
+    nx, nr, _, nuprev, _ = p.parameter_dims()
+    x = np.asarray(x, float).reshape(nx)
+    r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
+    u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
+    return np.concatenate([x, r, u])
