@@ -1,0 +1,173 @@
+/*
+ * lmpc_hip.h -- C ABI of the MI355X (gfx950) batched QP backend for LinearMPC.jl's online path.
+ *
+ * Drop-in boundary: everything LinearMPC.jl does between "theta is formed" and "x*, exitflag
+ * come back from DAQP" (reference /root/reference/src/utils.jl:268-283 `solve`, with the
+ * one-time half at /root/reference/src/setup.jl:7-29 `setup!`), for N parameter points at once.
+ * The reference-side binding a maintainer would add (Julia `ccall`) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, opaque handle, no exceptions; every entry point returns an int status.
+ *  - "QP" arrays arrive exactly as Julia stores mpc.mpQP (COLUMN-major Float64, Cint senses),
+ *    so the ccall passes the struct fields without copies or transposes.
+ *  - batched arrays are "one problem per contiguous record": theta is nth x N column-major on
+ *    the Julia side == N records of nth doubles; x is nout x N == N records of nout doubles.
+ *  - exit flags per problem use DAQP's sign convention (reference asserts exitflag >= 1,
+ *    utils.jl:46):  1 optimal, 2 soft-optimal, -1 infeasible, -2 cycle, -3 unbounded,
+ *    -4 iteration limit, -5 non-convex, -6 over-determined initial working set.
+ *  - sense bit flags are DAQP's (reference mpc2mpqp.jl:868-885): 1 ACTIVE, 2 LOWER,
+ *    4 IMMUTABLE, 5 EQUALITY (=ACTIVE|IMMUTABLE), 8 SOFT, 16 BINARY.
+ *  - active-set masks: lmpc_active_words(h) 64-bit words per problem; bit j (0 <= j < m) set
+ *    = constraint j active at its UPPER bound, bit m+j set = active at its LOWER bound.
+ *  - a handle is bound to one GPU (the `device` given at setup); calls on one handle must not
+ *    overlap in time, different handles are independent (the reference's DAQP workspace is
+ *    one-per-MPC and not thread-safe either: types.jl:93-97,141).
+ */
+#ifndef LMPC_HIP_H
+#define LMPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmpc_handle lmpc_handle;
+
+/* Solver settings == the DAQP settings LinearMPC.jl documents
+ * (/root/reference/docs/src/manual/solver.md:49-56) plus the two DAQP-internal tolerances the
+ * algorithm needs (zero_tol for singular pivots, fval_bound). rho_soft = 1/soft_weight
+ * (setup.jl:26).  Replaces DAQP.settings(model, Dict(...)). */
+typedef struct lmpc_settings {
+    double primal_tol;   /* 1e-6  */
+    double dual_tol;     /* 1e-12 */
+    double zero_tol;     /* 1e-11 */
+    double progress_tol; /* 1e-6  */
+    double fval_bound;   /* 1e30  */
+    double rho_soft;     /* 1e-6  */
+    int32_t cycle_tol;   /* 10    */
+    int32_t iter_limit;  /* 10000 */
+} lmpc_settings;
+
+/* status codes of the API itself (solver outcomes are the per-problem exit flags) */
+#define LMPC_OK 1
+#define LMPC_ERR_INFEASIBLE (-1)      /* setup: bl > bu somewhere (DAQP.setup flag -1)        */
+#define LMPC_ERR_NONCONVEX (-5)       /* setup: H not positive definite (DAQP.setup flag -5)  */
+#define LMPC_ERR_OVERDETERMINED (-6)  /* setup: equality rows linearly dependent (flag -6)    */
+#define LMPC_ERR_BADARG (-100)
+#define LMPC_ERR_NOGPU (-101)         /* no usable HIP device: there is NO CPU fallback       */
+#define LMPC_ERR_HIP (-102)           /* a HIP runtime call failed, see lmpc_last_error       */
+#define LMPC_ERR_UNSUPPORTED (-103)   /* problem shape outside what the kernels cover         */
+
+/* Fills *s with the defaults listed above. */
+void lmpc_default_settings(lmpc_settings *s);
+
+/*
+ * One-time setup from the mpQP, replacing DAQP.setup + DAQP.settings (setup.jl:11-13,26) and
+ * doing what DAQP.update / qp2ldp precompute (utils.jl:272-281, codegen.jl:239-280):
+ * Cholesky H = R'R, LDP rows M = [I_ms;A] R^-1 (normalised), Dth = W + M R^-T f_theta,
+ * du/dl, the output maps, and the upload of that constant pack to GPU `device`.
+ *
+ *   n      decision variables (Nc*nu)            m     two-sided constraints (ms simple first)
+ *   ms     leading simple bounds  bl<=U[i]<=bu   nth   length of theta = [x; r; d; uprev; p]
+ *   nout   leading entries of U* returned per problem (nu for compute_control, n for
+ *          compute_control_trajectory)
+ *   H[n*n] f[n] f_theta[n*nth] A[(m-ms)*n] bu[m] bl[m] W[m*nth]   column-major, as in mpc.mpQP
+ *   sense[m]  Cint flags        Kfb[nout*nx] or NULL  prestabilising feedback mpc.K
+ *          (column-major): output k gets  - Kfb[k,:]*theta[0:nx]  (utils.jl:48-49)
+ *   s      settings or NULL for defaults          device  HIP device ordinal
+ *
+ * Returns LMPC_OK (1) or a negative code; *out is NULL on failure.
+ */
+int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
+               const double *H, const double *f, const double *f_theta,
+               const double *A, const double *bu, const double *bl, const double *W,
+               const int32_t *sense, const double *Kfb, int nx,
+               const lmpc_settings *s, int device);
+
+/*
+ * Setup from an already-transformed least-distance problem -- the data the reference's code
+ * generator writes into C arrays (codegen.jl:183-189: Dth, du, dl, Uth_offset, u_offset, plus
+ * DAQP's M) -- all ROW-major:
+ *   M[m*n] normalised rows, du[m], dl[m], Dth[m*nth], Rout[nout*n] (rows of R^-1),
+ *   x0[nout] (= u_offset), Xth[nout*nth] (= Uth_offset incl. -K), sense[m].
+ * Replaces the static workspace of generated mpc_workspace.c / mpc_compute_control
+ * (codegen/mpc_update_qp.c:29-54).
+ */
+int lmpc_setup_ldp(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
+                   const double *M, const double *du, const double *dl, const double *Dth,
+                   const double *Rout, const double *x0, const double *Xth,
+                   const int32_t *sense, const lmpc_settings *s, int device);
+
+/*
+ * Host-only half of lmpc_setup: the QP -> LDP transform (reference codegen.jl:239-280 `qp2ldp`,
+ * i.e. what LinearMPC.codegen writes into the generated C arrays) without touching a GPU.
+ * Inputs as lmpc_setup, outputs row-major as lmpc_setup_ldp takes them; any output may be NULL.
+ */
+int lmpc_transform(int n, int m, int ms, int nth, int nout,
+                   const double *H, const double *f, const double *f_theta,
+                   const double *A, const double *bu, const double *bl, const double *W,
+                   const int32_t *sense, const double *Kfb, int nx,
+                   double *M, double *du, double *dl, double *Dth,
+                   double *Rout, double *x0, double *Xth);
+
+/* Copies the constant pack held by the handle back to the caller (row-major, sizes as in
+ * lmpc_setup_ldp); any pointer may be NULL.  Lets a test feed the SAME pack to the oracle. */
+int lmpc_get_ldp(const lmpc_handle *h, double *M, double *du, double *dl, double *Dth,
+                 double *Rout, double *x0, double *Xth, int32_t *sense);
+
+/* dims[0..5] = n, m, ms, nth, nout, active words per problem */
+int lmpc_get_dims(const lmpc_handle *h, int32_t dims[6]);
+int lmpc_active_words(const lmpc_handle *h);
+
+/* Replaces DAQP.settings on a live model. */
+int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
+
+/*
+ * THE hot path.  Replaces, for N parameter points at once, the body of `solve`
+ * (utils.jl:272-282: bu/bl/f update, DAQP.update, DAQP.solve) and the primal recovery
+ * x = R^-1 u + offsets (codegen/mpc_update_qp.c:14-22).  Cold start per problem
+ * (mpc_update_qp.c:44-47) unless `warm` is given.
+ *
+ *   theta     N records of nth doubles        x        N records of nout doubles (out)
+ *   exitflag  N int32 (out)                   iters    N int32 (out) or NULL
+ *   active    N records of lmpc_active_words words (out) or NULL
+ *   warm      N records of the same layout: initial working sets (in) or NULL = cold
+ *
+ * lmpc_solve_batch: HOST pointers; copies in, launches, copies out, synchronises.
+ * lmpc_solve_batch_device: DEVICE pointers on the handle's GPU; enqueues the kernels on
+ * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns without
+ * synchronising -- this is what bench.py times with inputs resident in HBM.
+ */
+int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x,
+                     int32_t *exitflag, int32_t *iters, uint64_t *active,
+                     const uint64_t *warm);
+int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, double *x,
+                            int32_t *exitflag, int32_t *iters, uint64_t *active,
+                            const uint64_t *warm, void *stream);
+
+/* N = 1 convenience with DAQP.solve's shape: returns the exit flag (or an LMPC_ERR_* <= -100),
+ * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call. */
+int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
+
+/* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
+const char *lmpc_kernel_name(const lmpc_handle *h);
+
+/* Average device time in ms of the dominant solve kernel over the launches made since the
+ * last call (HIP events recorded on the launch stream when profiling is switched on with
+ * lmpc_profile(h, 1)); returns the number of launches averaged, <0 on error. */
+int lmpc_profile(lmpc_handle *h, int enable);
+int lmpc_profile_read(lmpc_handle *h, double *avg_ms);
+
+void lmpc_free(lmpc_handle *h);
+
+/* Last error text of this handle (or of the failed setup call when h == NULL). */
+const char *lmpc_last_error(const lmpc_handle *h);
+
+/* Library/ABI version, bumped on any signature change. */
+int lmpc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMPC_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of liblmpc_hip.so -- the same entry points a Julia `ccall` would bind
+(include/lmpc_hip.h; Julia stub in INTEGRATION.md).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing the import
+fails loudly, and if no HIP device is present every setup/solve call raises `LmpcError`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "liblmpc_hip.so")
+
+LMPC_OK = 1
+ERR_NAMES = {-1: "INFEASIBLE", -5: "NONCONVEX", -6: "OVERDETERMINED", -100: "BADARG",
+             -101: "NOGPU", -102: "HIP", -103: "UNSUPPORTED"}
+
+# every symbol include/lmpc_hip.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "lmpc_abi_version", "lmpc_default_settings", "lmpc_setup", "lmpc_setup_ldp", "lmpc_transform",
+    "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
+    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one", "lmpc_kernel_name",
+    "lmpc_profile", "lmpc_profile_read", "lmpc_free", "lmpc_last_error",
+)
+
+
+class LmpcError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"lmpc error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+
+
+class Settings(ctypes.Structure):
+    """`lmpc_settings`; defaults are DAQP's as documented in reference docs/src/manual/solver.md:49-56."""
+    _fields_ = [("primal_tol", ctypes.c_double), ("dual_tol", ctypes.c_double),
+                ("zero_tol", ctypes.c_double), ("progress_tol", ctypes.c_double),
+                ("fval_bound", ctypes.c_double), ("rho_soft", ctypes.c_double),
+                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C linearmpc.jl_amd/csrc)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    L.lmpc_abi_version.restype = i32
+    L.lmpc_default_settings.argtypes = [ctypes.POINTER(Settings)]
+    L.lmpc_default_settings.restype = None
+    L.lmpc_setup.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32, vp, i32]
+    L.lmpc_setup.restype = i32
+    L.lmpc_setup_ldp.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32]
+    L.lmpc_setup_ldp.restype = i32
+    L.lmpc_transform.argtypes = [i32] * 5 + [vp] * 9 + [i32] + [vp] * 7
+    L.lmpc_transform.restype = i32
+    L.lmpc_get_ldp.argtypes = [vp] * 9
+    L.lmpc_get_ldp.restype = i32
+    L.lmpc_get_dims.argtypes = [vp, ctypes.POINTER(ctypes.c_int32 * 6)]
+    L.lmpc_get_dims.restype = i32
+    L.lmpc_active_words.argtypes = [vp]
+    L.lmpc_active_words.restype = i32
+    L.lmpc_set_settings.argtypes = [vp, ctypes.POINTER(Settings)]
+    L.lmpc_set_settings.restype = i32
+    L.lmpc_solve_batch.argtypes = [vp, i64] + [vp] * 6
+    L.lmpc_solve_batch.restype = i32
+    L.lmpc_solve_batch_device.argtypes = [vp, i64] + [vp] * 7
+    L.lmpc_solve_batch_device.restype = i32
+    L.lmpc_solve_one.argtypes = [vp, vp, vp]
+    L.lmpc_solve_one.restype = i32
+    L.lmpc_kernel_name.argtypes = [vp]
+    L.lmpc_kernel_name.restype = ctypes.c_char_p
+    L.lmpc_profile.argtypes = [vp, i32]
+    L.lmpc_profile.restype = i32
+    L.lmpc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    L.lmpc_profile_read.restype = i32
+    L.lmpc_free.argtypes = [vp]
+    L.lmpc_free.restype = None
+    L.lmpc_last_error.argtypes = [vp]
+    L.lmpc_last_error.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def default_settings() -> Settings:
+    s = Settings()
+    lib().lmpc_default_settings(ctypes.byref(s))
+    return s
+
+
+def last_error(handle=None) -> str:
+    return (lib().lmpc_last_error(handle) or b"").decode()
+
+
+def check(rc, handle=None):
+    if rc != LMPC_OK:
+        raise LmpcError(rc, last_error(handle))

@@ -1,0 +1,371 @@
+// C ABI of liblmpc_hip.so (see include/lmpc_hip.h) and kernel dispatch.
+// There is deliberately no CPU fallback: without a HIP device every solve entry point fails
+// with LMPC_ERR_NOGPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lmpc_lane_kernel.hpp"
+#include "lmpc_pack.hpp"
+
+using namespace lmpc;
+
+namespace {
+
+thread_local std::string g_setup_err;
+
+constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
+constexpr int kLaneMaxN = 12;
+constexpr int kLaneMaxM = 64;
+constexpr size_t kLdsMax = 160 * 1024;
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct lmpc_handle {
+    HostPack P;
+    lmpc_settings S;
+    int device = 0;
+    int laneN = 0;              // lane-kernel instantiation (row stride of M/Rout on the device)
+    PackLayout L{};
+    double *dC = nullptr;       // constant pack on the GPU
+    size_t nC = 0;
+    std::string err, kname;
+    // staging for the host-pointer entry point
+    double *sTheta = nullptr, *sX = nullptr;
+    int32_t *sFlag = nullptr, *sIter = nullptr;
+    uint64_t *sAct = nullptr, *sWarm = nullptr;
+    int64_t sCap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> events;
+};
+
+namespace {
+
+int fail(lmpc_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_setup_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+void fill_layout(lmpc_handle *h) {
+    const HostPack &P = h->P;
+    PackLayout &L = h->L;
+    const int N = h->laneN;
+    L.n = P.n; L.m = P.m; L.ms = P.ms; L.nth = P.nth; L.nout = P.nout; L.words = P.words();
+    int o = 0;
+    L.oM = o; o += P.m * N;
+    L.oG = o; o += lmpc_tri(P.m);
+    L.odu = o; o += P.m;
+    L.odl = o; o += P.m;
+    L.oDth = o; o += P.m * P.nth;
+    L.oRout = o; o += P.nout * N;
+    L.ox0 = o; o += P.nout;
+    L.oXth = o; o += P.nout * P.nth;
+    h->nC = (size_t)o;
+    L.imm_mask = 0; L.eq_mask = 0;
+    for (int j = 0; j < P.m && j < 64; j++) {
+        if (P.sense[j] & SENSE_IMMUTABLE) L.imm_mask |= 1ull << j;
+        if (P.sense[j] & SENSE_ACTIVE) L.eq_mask |= 1ull << j;
+    }
+    const lmpc_settings &S = h->S;
+    L.primal_tol = S.primal_tol; L.dual_tol = S.dual_tol; L.zero_tol = S.zero_tol;
+    L.progress_tol = S.progress_tol; L.fval_bound = S.fval_bound; L.rho_soft = S.rho_soft;
+    L.cycle_tol = S.cycle_tol; L.iter_limit = S.iter_limit;
+}
+
+// choose the kernel variant and upload the constant pack
+int finalize_handle(lmpc_handle *h) {
+    const HostPack &P = h->P;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    if (h->device < 0 || h->device >= ndev) return fail(h, LMPC_ERR_BADARG, "lmpc: bad device ordinal");
+    if (P.n > kLaneMaxN || P.m > kLaneMaxM)
+        return fail(h, LMPC_ERR_UNSUPPORTED,
+                    "lmpc: problem larger than the lane kernel covers (n <= 12, m <= 64)");
+    if (P.nsoft > 0)
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: soft constraints are not supported by the lane kernel yet");
+    h->laneN = 0;
+    for (int s : kLaneSizes) if (s >= P.n) { h->laneN = s; break; }
+    h->kname = "lane<" + std::to_string(h->laneN) + ">";
+    fill_layout(h);
+    const int N = h->laneN;
+    std::vector<double> buf(h->nC, 0.0);
+    const PackLayout &L = h->L;
+    for (int j = 0; j < P.m; j++)
+        for (int k = 0; k < P.n; k++) buf[L.oM + j * N + k] = P.M[(size_t)j * P.n + k];
+    std::memcpy(&buf[L.oG], P.G.data(), sizeof(double) * P.G.size());
+    for (int j = 0; j < P.m; j++) { buf[L.odu + j] = P.du0[j]; buf[L.odl + j] = P.dl0[j]; }
+    if (P.m * P.nth) std::memcpy(&buf[L.oDth], P.Dth.data(), sizeof(double) * P.Dth.size());
+    for (int k = 0; k < P.nout; k++)
+        for (int c = 0; c < P.n; c++) buf[L.oRout + k * N + c] = P.Rout[(size_t)k * P.n + c];
+    for (int k = 0; k < P.nout; k++) buf[L.ox0 + k] = P.x0[k];
+    if (P.nout * P.nth) std::memcpy(&buf[L.oXth], P.Xth.data(), sizeof(double) * P.Xth.size());
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMalloc(&h->dC, sizeof(double) * (h->nC ? h->nC : 1)));
+    HIP_TRY(h, hipMemcpy(h->dC, buf.data(), sizeof(double) * h->nC, hipMemcpyHostToDevice));
+    return LMPC_OK;
+}
+
+size_t lane_lds_bytes(const HostPack &P, int N, int B) {
+    return sizeof(double) * ((size_t)P.m * N + lmpc_tri(P.m) + 2 * (size_t)P.m + (size_t)P.m * B);
+}
+
+template <int N>
+int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
+                int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
+                hipStream_t st) {
+    auto kern = lane_kernel<N>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)((nprob + B - 1) / B);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag, iters, active,
+                       warm, (long long)nprob);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+           int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    // block size: the one that keeps most wavefronts resident per CU under the 160 KiB LDS cap
+    int bestB = 0, bestWaves = -1;
+    size_t bestLds = 0;
+    for (int B : {256, 128, 64}) {
+        const size_t lds = lane_lds_bytes(h->P, h->laneN, B);
+        if (lds > kLdsMax) continue;
+        int blocks = (int)(kLdsMax / lds);
+        int waves = blocks * (B / 64);
+        if (waves > 32) waves = 32;
+        if (waves > bestWaves) { bestWaves = waves; bestB = B; bestLds = lds; }
+    }
+    if (!bestB) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: constant pack does not fit in LDS");
+    EventPair ev{};
+    if (h->prof) {
+        HIP_TRY(h, hipEventCreate(&ev.a));
+        HIP_TRY(h, hipEventCreate(&ev.b));
+        HIP_TRY(h, hipEventRecord(ev.a, st));
+    }
+    int rc;
+    switch (h->laneN) {
+#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, st); break;
+        LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
+#undef LMPC_CASE
+        default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
+    }
+    if (h->prof) {
+        if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    }
+    return rc;
+}
+
+int ensure_staging(lmpc_handle *h, int64_t N, bool warm) {
+    if (N <= h->sCap && (!warm || h->sWarm)) return LMPC_OK;
+    if (N > h->sCap) {
+        hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter); hipFree(h->sAct); hipFree(h->sWarm);
+        h->sTheta = h->sX = nullptr; h->sFlag = h->sIter = nullptr; h->sAct = h->sWarm = nullptr;
+        h->sCap = 0;
+        const size_t w = (size_t)h->P.words();
+        HIP_TRY(h, hipMalloc(&h->sTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
+        HIP_TRY(h, hipMalloc(&h->sX, sizeof(double) * (size_t)N * h->P.nout));
+        HIP_TRY(h, hipMalloc(&h->sFlag, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->sIter, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->sAct, sizeof(uint64_t) * (size_t)N * w));
+        h->sCap = N;
+    }
+    if (warm && !h->sWarm)
+        HIP_TRY(h, hipMalloc(&h->sWarm, sizeof(uint64_t) * (size_t)h->sCap * h->P.words()));
+    return LMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmpc_abi_version(void) { return 1; }
+
+void lmpc_default_settings(lmpc_settings *s) {
+    if (!s) return;
+    s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
+    s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+}
+
+int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
+               const double *f, const double *f_theta, const double *A, const double *bu,
+               const double *bl, const double *W, const int32_t *sense, const double *Kfb, int nx,
+               const lmpc_settings *s, int device) {
+    if (!out) return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup: out is NULL");
+    *out = nullptr;
+    lmpc_handle *h = new lmpc_handle();
+    if (s) h->S = *s; else lmpc_default_settings(&h->S);
+    h->device = device;
+    int rc = qp_to_ldp(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->err);
+    if (rc == LMPC_OK) rc = finalize_handle(h);
+    if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
+    *out = h;
+    return LMPC_OK;
+}
+
+int lmpc_setup_ldp(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *M,
+                   const double *du, const double *dl, const double *Dth, const double *Rout,
+                   const double *x0, const double *Xth, const int32_t *sense,
+                   const lmpc_settings *s, int device) {
+    if (!out) return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_ldp: out is NULL");
+    *out = nullptr;
+    if (n <= 0 || m < 0 || nth < 0 || nout <= 0 || nout > n || ms < 0 || ms > m ||
+        (m > 0 && (!M || !du || !dl)) || (m * nth > 0 && !Dth) || !Rout || !x0 || (nth > 0 && !Xth))
+        return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_ldp: bad dimensions or NULL array");
+    lmpc_handle *h = new lmpc_handle();
+    if (s) h->S = *s; else lmpc_default_settings(&h->S);
+    h->device = device;
+    HostPack &P = h->P;
+    P.n = n; P.m = m; P.ms = ms; P.nth = nth; P.nout = nout;
+    P.M.assign(M, M + (size_t)m * n);
+    P.du0.assign(du, du + m);
+    P.dl0.assign(dl, dl + m);
+    P.Dth.assign(Dth, Dth + (size_t)m * nth);
+    P.Rout.assign(Rout, Rout + (size_t)nout * n);
+    P.x0.assign(x0, x0 + nout);
+    P.Xth.assign(Xth, Xth + (size_t)nout * nth);
+    P.sense.assign(m, 0);
+    if (sense) P.sense.assign(sense, sense + m);
+    int rc = finish_pack(P, h->err);
+    if (rc == LMPC_OK) rc = finalize_handle(h);
+    if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
+    *out = h;
+    return LMPC_OK;
+}
+
+int lmpc_transform(int n, int m, int ms, int nth, int nout, const double *H, const double *f,
+                   const double *f_theta, const double *A, const double *bu, const double *bl,
+                   const double *W, const int32_t *sense, const double *Kfb, int nx, double *M,
+                   double *du, double *dl, double *Dth, double *Rout, double *x0, double *Xth) {
+    HostPack P;
+    std::string err;
+    int rc = qp_to_ldp(P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, err);
+    if (rc != LMPC_OK) return fail(nullptr, rc, err);
+    auto cp = [](double *dst, const std::vector<double> &src) {
+        if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size());
+    };
+    cp(M, P.M); cp(du, P.du0); cp(dl, P.dl0); cp(Dth, P.Dth); cp(Rout, P.Rout); cp(x0, P.x0); cp(Xth, P.Xth);
+    return LMPC_OK;
+}
+
+int lmpc_get_ldp(const lmpc_handle *h, double *M, double *du, double *dl, double *Dth, double *Rout,
+                 double *x0, double *Xth, int32_t *sense) {
+    if (!h) return LMPC_ERR_BADARG;
+    const HostPack &P = h->P;
+    auto cp = [](double *dst, const std::vector<double> &src) {
+        if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size());
+    };
+    cp(M, P.M); cp(du, P.du0); cp(dl, P.dl0); cp(Dth, P.Dth); cp(Rout, P.Rout); cp(x0, P.x0); cp(Xth, P.Xth);
+    if (sense && !P.sense.empty()) std::memcpy(sense, P.sense.data(), sizeof(int32_t) * P.sense.size());
+    return LMPC_OK;
+}
+
+int lmpc_get_dims(const lmpc_handle *h, int32_t dims[6]) {
+    if (!h || !dims) return LMPC_ERR_BADARG;
+    dims[0] = h->P.n; dims[1] = h->P.m; dims[2] = h->P.ms; dims[3] = h->P.nth; dims[4] = h->P.nout;
+    dims[5] = h->P.words();
+    return LMPC_OK;
+}
+
+int lmpc_active_words(const lmpc_handle *h) { return h ? h->P.words() : LMPC_ERR_BADARG; }
+
+int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s) {
+    if (!h || !s) return LMPC_ERR_BADARG;
+    h->S = *s;
+    fill_layout(h);
+    return LMPC_OK;
+}
+
+int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, double *x,
+                            int32_t *exitflag, int32_t *iters, uint64_t *active,
+                            const uint64_t *warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch_device: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    if (N > (int64_t)0x7fffffff * 64) return fail(h, LMPC_ERR_BADARG, "lmpc: batch too large for one launch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch(h, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
+}
+
+int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x, int32_t *exitflag,
+                     int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_staging(h, N, warm != nullptr);
+    if (rc != LMPC_OK) return rc;
+    const size_t w = (size_t)h->P.words();
+    if (h->P.nth > 0)
+        HIP_TRY(h, hipMemcpy(h->sTheta, theta, sizeof(double) * (size_t)N * h->P.nth, hipMemcpyHostToDevice));
+    if (warm) HIP_TRY(h, hipMemcpy(h->sWarm, warm, sizeof(uint64_t) * (size_t)N * w, hipMemcpyHostToDevice));
+    rc = launch(h, N, h->sTheta, h->sX, h->sFlag, h->sIter, h->sAct, warm ? h->sWarm : nullptr, nullptr);
+    if (rc != LMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpy(x, h->sX, sizeof(double) * (size_t)N * h->P.nout, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(exitflag, h->sFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(h, hipMemcpy(iters, h->sIter, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    if (active) HIP_TRY(h, hipMemcpy(active, h->sAct, sizeof(uint64_t) * (size_t)N * w, hipMemcpyDeviceToHost));
+    return LMPC_OK;
+}
+
+int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
+    int32_t flag = 0;
+    int rc = lmpc_solve_batch(h, 1, theta, x, &flag, nullptr, nullptr, nullptr);
+    return rc == LMPC_OK ? flag : rc;
+}
+
+const char *lmpc_kernel_name(const lmpc_handle *h) { return h ? h->kname.c_str() : ""; }
+
+int lmpc_profile(lmpc_handle *h, int enable) {
+    if (!h) return LMPC_ERR_BADARG;
+    h->prof = enable != 0;
+    return LMPC_OK;
+}
+
+int lmpc_profile_read(lmpc_handle *h, double *avg_ms) {
+    if (!h || !avg_ms) return LMPC_ERR_BADARG;
+    double tot = 0.0;
+    int cnt = 0;
+    for (auto &ev : h->events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            tot += ms;
+            cnt++;
+        }
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    h->events.clear();
+    *avg_ms = cnt ? tot / cnt : 0.0;
+    return cnt;
+}
+
+void lmpc_free(lmpc_handle *h) {
+    if (!h) return;
+    if (h->dC || h->sTheta) hipSetDevice(h->device);
+    for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
+    hipFree(h->sAct); hipFree(h->sWarm);
+    delete h;
+}
+
+const char *lmpc_last_error(const lmpc_handle *h) { return h ? h->err.c_str() : g_setup_err.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// One-QP-per-lane dual active-set kernel for small condensed-MPC problems (n <= 12, m <= 64).
+//
+// Mapping (gfx950): every lane of a 64-wide wavefront owns one parameter point theta and runs the
+// whole dual active-set iteration on it.  The LDL' factor, multipliers and working set of that
+// lane live in VGPRs: every loop over working-set positions is fully unrolled against the
+// compile-time capacity MA = N+1, so all register-array indices are static and positions beyond
+// the lane's current |W| are kept at exact zeros (they then drop out of every fma chain).  What is
+// shared by all problems is read uniformly: rows of M / Dth / bounds through the scalar cache
+// (s_load, one SGPR operand per v_fma_f64), and the rows a lane needs by *its own* constraint
+// index (M_W rows for the primal step, Gram entries for the new L row) from an LDS copy.
+// The per-lane constraint shift b_j = Dth_j . theta is kept in LDS as [j][lane] (conflict-free for
+// ds_read_b64: consecutive lanes hit consecutive bank pairs).  There is no cross-lane arithmetic,
+// so the summation order is exactly the sequential order of the CPU oracle: results are
+// bit-comparable, not just close.
+//
+// Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp
+// ([EXT] libdaqp, called at mpc_update_qp.c:48 / utils.jl:282) and mpc_get_solution
+// (mpc_update_qp.c:14-22).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lmpc_pack.hpp"
+
+namespace lmpc {
+
+// Offsets (in doubles) of the constant arrays inside the single device buffer.
+struct PackLayout {
+    int n, m, ms, nth, nout, words;
+    int oM, oG, odu, odl, oDth, oRout, ox0, oXth;   // offsets into the double buffer
+    unsigned long long imm_mask, eq_mask;           // m <= 64: IMMUTABLE rows / rows flagged ACTIVE
+    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
+    int cycle_tol, iter_limit;
+};
+
+__host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
+// strict lower triangle, row i > col t
+__host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
+
+template <int N>
+__global__ __launch_bounds__(256) void lane_kernel(
+    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
+    double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
+    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, long long nprob) {
+    constexpr int MA = N + 1;
+    constexpr int NSL = MA * (MA - 1) / 2;
+    extern __shared__ __align__(16) double lds[];
+
+    const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
+    double *sM = lds;                    // m x N   rows by per-lane constraint index
+    double *sG = sM + m * N;             // packed lower triangle of M M'
+    double *sdu = sG + lmpc_tri(m);      // du0
+    double *sdl = sdu + m;               // dl0
+    double *sB = sdl + m;                // b[j][lane]
+    for (int i = tid; i < m * N; i += B) sM[i] = C[P.oM + i];
+    for (int i = tid; i < lmpc_tri(m); i += B) sG[i] = C[P.oG + i];
+    for (int i = tid; i < m; i += B) { sdu[i] = C[P.odu + i]; sdl[i] = C[P.odl + i]; }
+    __syncthreads();
+
+    const long long pid = (long long)blockIdx.x * B + tid;
+    if (pid >= nprob) return;
+    const double *th = theta + pid * nth;
+
+    // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
+    for (int j = 0; j < m; j++) {
+        double acc = 0.0;
+        for (int t = 0; t < nth; t++) acc = __builtin_fma(C[P.oDth + j * nth + t], th[t], acc);
+        sB[j * B + tid] = acc;
+    }
+
+    double SL[NSL > 0 ? NSL : 1];
+    double D[MA], Dinv[MA], lam[MA], ls[MA], rhs[MA], u[N];
+    int WS[MA];
+#pragma unroll
+    for (int i = 0; i < NSL; i++) SL[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < MA; i++) { D[i] = 0.0; Dinv[i] = 0.0; lam[i] = 0.0; ls[i] = 0.0; rhs[i] = 0.0; WS[i] = 0; }
+#pragma unroll
+    for (int k = 0; k < N; k++) u[k] = 0.0;
+    unsigned long long act = 0ull, low = 0ull;
+    int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT;
+    double best = -1.0, fval = 0.0;
+    bool done = false;
+
+    // ---- append constraint j (at its lower bound if `lower`) to the working set
+    auto ldl_add = [&](int j, bool lower) {
+        double row[MA > 1 ? MA - 1 : 1];
+#pragma unroll
+        for (int t = 0; t < MA - 1; t++) {
+            row[t] = 0.0;
+            if (t < na) {
+                const int a = WS[t];
+                row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
+            }
+        }
+        double dnew = sG[lmpc_tri(j) + j];
+#pragma unroll
+        for (int i = 1; i < MA - 1; i++) {
+            double acc = row[i];
+#pragma unroll
+            for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], row[t], acc);
+            row[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < MA - 1; i++) {
+            const double q = row[i];
+            const double l = q * Dinv[i];
+            row[i] = l;
+            dnew = __builtin_fma(-l, q, dnew);
+        }
+        const bool singular = (dnew < P.zero_tol) || (na >= P.n);
+        const double b = sB[j * B + tid];
+        const double r = lower ? -(sdl[j] + b) : -(sdu[j] + b);
+        const double dval = singular ? 0.0 : dnew;
+        const double dinv = singular ? 0.0 : 1.0 / dnew;
+#pragma unroll
+        for (int i = 0; i < MA; i++) {
+            if (i == na) {
+                WS[i] = j; rhs[i] = r; lam[i] = 0.0; ls[i] = 0.0; D[i] = dval; Dinv[i] = dinv;
+#pragma unroll
+                for (int t = 0; t < i; t++) SL[lmpc_sl(i, t)] = row[t];
+            }
+        }
+        if (singular) sing = na;
+        act |= 1ull << j;
+        if (lower) low |= 1ull << j;
+        na++;
+    };
+
+    // ---- drop working-set position r (rank-one update of the trailing block)
+    auto ldl_remove = [&](int r) {
+        double wv[MA];
+        double alpha = 0.0;
+        int jrem = 0;
+#pragma unroll
+        for (int i = 0; i < MA; i++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < i; c++) s = (c == r) ? SL[lmpc_sl(i, c)] : s;
+            wv[i] = s;
+            if (i == r) { alpha = D[i]; jrem = WS[i]; }
+        }
+#pragma unroll
+        for (int i = 1; i < MA - 1; i++) {
+#pragma unroll
+            for (int c = 0; c < i; c++) {
+                // read all three unconditionally: a select of VALUES keeps SL in registers, a
+                // select of addresses (what phi-of-loads folds to) would push it to scratch
+                const double va = SL[lmpc_sl(i + 1, c)], vb = SL[lmpc_sl(i + 1, c + 1)];
+                const double keep = SL[lmpc_sl(i, c)];
+                const double sh = (c < r) ? va : vb;
+                SL[lmpc_sl(i, c)] = (i >= r) ? sh : keep;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MA - 1; c++) SL[lmpc_sl(MA - 1, c)] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MA - 1; i++) {
+            if (i >= r) {
+                WS[i] = WS[i + 1]; lam[i] = lam[i + 1]; rhs[i] = rhs[i + 1];
+                D[i] = D[i + 1]; Dinv[i] = Dinv[i + 1];
+            }
+        }
+        WS[MA - 1] = 0; lam[MA - 1] = 0.0; rhs[MA - 1] = 0.0; D[MA - 1] = 0.0; Dinv[MA - 1] = 0.0;
+        na--;
+        sing = -1;
+        bool stop = false;
+#pragma unroll
+        for (int i = 0; i < MA - 1; i++) {
+            if (i >= r && i < na && !stop) {
+                const double pt = wv[i + 1];
+                const double dold = D[i];
+                const double dbar = __builtin_fma(alpha * pt, pt, dold);
+                if (dbar < P.zero_tol) {
+                    D[i] = 0.0; Dinv[i] = 0.0; sing = i; stop = true;
+                } else {
+                    const double rinv = 1.0 / dbar;
+                    const double beta = (pt * alpha) * rinv;
+                    alpha = (dold * alpha) * rinv;
+                    D[i] = dbar; Dinv[i] = rinv;
+#pragma unroll
+                    for (int q = i + 1; q < MA - 1; q++) {
+                        wv[q + 1] = __builtin_fma(-pt, SL[lmpc_sl(q, i)], wv[q + 1]);
+                        SL[lmpc_sl(q, i)] = __builtin_fma(beta, wv[q + 1], SL[lmpc_sl(q, i)]);
+                    }
+                }
+            }
+        }
+        act &= ~(1ull << jrem);
+        low &= ~(1ull << jrem);
+    };
+
+    // ---- initial working set: equality rows, then the caller's warm-start mask
+    if (P.eq_mask != 0ull || warm != nullptr) {
+        unsigned long long wup = 0ull, wlo = 0ull;
+        if (warm != nullptr) {
+            const uint64_t *wp = warm + pid * P.words;
+            const unsigned long long w0 = wp[0], w1 = P.words > 1 ? wp[1] : 0ull;
+            const unsigned long long mm = m >= 64 ? ~0ull : ((1ull << m) - 1ull);
+            wup = w0 & mm;
+            wlo = (m >= 64 ? w1 : ((w0 >> m) | (m > 0 ? (w1 << (64 - m)) : 0ull))) & mm;
+            wup &= ~P.imm_mask; wlo &= ~P.imm_mask;
+        }
+        for (int j = 0; j < m && !done; j++) {
+            const bool iseq = (P.eq_mask >> j) & 1ull;
+            const bool up = (wup >> j) & 1ull, lo = ((wlo >> j) & 1ull) && !up;
+            if (iseq || up || lo) {
+                ldl_add(j, lo);
+                if (sing >= 0) {
+                    if ((P.imm_mask >> j) & 1ull) { flag = EXIT_OVERDETERMINED; done = true; }
+                    else {      // dependent warm-start row: take it out again
+                        na--;
+                        sing = -1;
+#pragma unroll
+                        for (int i = 0; i < MA; i++) {
+                            if (i == na) {
+                                WS[i] = 0; rhs[i] = 0.0; D[i] = 0.0; Dinv[i] = 0.0;
+#pragma unroll
+                                for (int t = 0; t < i; t++) SL[lmpc_sl(i, t)] = 0.0;
+                            }
+                        }
+                        act &= ~(1ull << j);
+                        low &= ~(1ull << j);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- dual active-set iterations
+    while (!done) {
+        if (iter >= P.iter_limit) { flag = EXIT_ITERLIMIT; break; }
+        int rm = -1;
+        double alpha = 0.0;
+        if (sing < 0) {
+            // constrained stationary point: (L D L') lam* = rhs
+            double xl[MA];
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                double acc = rhs[i];
+#pragma unroll
+                for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], xl[t], acc);
+                xl[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < MA; i++) xl[i] = xl[i] * Dinv[i];
+#pragma unroll
+            for (int i = MA - 1; i >= 0; i--) {
+                double acc = xl[i];
+#pragma unroll
+                for (int t = MA - 1; t > i; t--) acc = __builtin_fma(-SL[lmpc_sl(t, i)], ls[t], acc);
+                ls[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                if (i < na) {
+                    const int j = WS[i];
+                    const bool imm = (P.imm_mask >> j) & 1ull;
+                    const bool isl = (low >> j) & 1ull;
+                    const bool ok = isl ? (ls[i] < P.dual_tol) : (ls[i] > -P.dual_tol);
+                    if (!imm && !ok) {
+                        const double cand = -lam[i] / (ls[i] - lam[i]);
+                        if (rm < 0 || cand < alpha) { alpha = cand; rm = i; }
+                    }
+                }
+            }
+            if (rm < 0) {
+                // primal iterate u = -M_W' lam*, then the most violated inactive constraint
+#pragma unroll
+                for (int k = 0; k < N; k++) u[k] = 0.0;
+#pragma unroll
+                for (int i = 0; i < MA; i++) {
+                    if (i < na) {
+                        const double *mi = sM + WS[i] * N;
+                        const double l = ls[i];
+#pragma unroll
+                        for (int k = 0; k < N; k++) u[k] = __builtin_fma(-mi[k], l, u[k]);
+                    }
+                }
+                fval = 0.0;
+#pragma unroll
+                for (int k = 0; k < N; k++) fval = __builtin_fma(u[k], u[k], fval);
+                if (fval > P.fval_bound) { flag = EXIT_INFEASIBLE; break; }
+                double min_val = -P.primal_tol;
+                int add = -1;
+                bool addlow = false;
+                for (int j = 0; j < m; j++) {
+                    if ((P.imm_mask >> j) & 1ull) continue;
+                    double Mu = 0.0;
+#pragma unroll
+                    for (int k = 0; k < N; k++) Mu = __builtin_fma(C[P.oM + j * N + k], u[k], Mu);
+                    const double b = sB[j * B + tid];
+                    const double vu = (C[P.odu + j] + b) - Mu;
+                    const double vl = -((C[P.odl + j] + b) - Mu);
+                    if (!((act >> j) & 1ull)) {
+                        if (vu < min_val) { add = j; addlow = false; min_val = vu; }
+                        else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+                    }
+                }
+                if (add < 0) { flag = EXIT_OPTIMAL; break; }
+#pragma unroll
+                for (int i = 0; i < MA; i++) lam[i] = ls[i];
+                ldl_add(add, addlow);
+                if (fval - best < P.progress_tol) {
+                    if (++cyc > P.cycle_tol) { flag = EXIT_CYCLE; break; }
+                } else { best = fval; cyc = 0; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MA; i++) lam[i] = __builtin_fma(alpha, ls[i] - lam[i], lam[i]);
+                ldl_remove(rm);
+            }
+        } else {
+            // singular working set: direction p with M_W' p = 0, p_sing = +-1
+            double lrow[MA], p[MA];
+            int js = 0;
+#pragma unroll
+            for (int c = 0; c < MA; c++) { lrow[c] = 0.0; p[c] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                if (i == sing) {
+                    js = WS[i];
+#pragma unroll
+                    for (int c = 0; c < i; c++) lrow[c] = SL[lmpc_sl(i, c)];
+                }
+            }
+#pragma unroll
+            for (int i = MA - 2; i >= 0; i--) {
+                if (i < sing) {
+                    double acc = -lrow[i];
+#pragma unroll
+                    for (int t = MA - 2; t > i; t--) acc = __builtin_fma(-SL[lmpc_sl(t, i)], p[t], acc);
+                    p[i] = acc;
+                }
+            }
+            const bool slow = (low >> js) & 1ull;
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                if (i == sing) p[i] = 1.0;
+                if (slow) p[i] = -p[i];
+                ls[i] = p[i];
+            }
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                if (i < na) {
+                    const int j = WS[i];
+                    const bool imm = (P.imm_mask >> j) & 1ull;
+                    const bool isl = (low >> j) & 1ull;
+                    const bool ok = isl ? (ls[i] < P.dual_tol) : (ls[i] > -P.dual_tol);
+                    if (!imm && !ok) {
+                        const double cand = -lam[i] / ls[i];
+                        if (rm < 0 || cand < alpha) { alpha = cand; rm = i; }
+                    }
+                }
+            }
+            if (rm < 0) { flag = EXIT_INFEASIBLE; break; }
+#pragma unroll
+            for (int i = 0; i < MA; i++) lam[i] = __builtin_fma(alpha, ls[i], lam[i]);
+            ldl_remove(rm);
+        }
+        iter++;
+    }
+
+    // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22)
+    for (int k = 0; k < P.nout; k++) {
+        double xs = 0.0, sh = C[P.ox0 + k];
+#pragma unroll
+        for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
+        for (int t = 0; t < nth; t++) sh = __builtin_fma(C[P.oXth + k * nth + t], th[t], sh);
+        X[pid * P.nout + k] = xs + sh;
+    }
+    exitflag[pid] = flag;
+    if (iters) iters[pid] = iter;
+    if (active) {
+        const unsigned long long up = act & ~low, lo = act & low;
+        unsigned long long w0 = up, w1 = 0ull;
+        if (m < 64) { w0 |= lo << m; if (m > 0) w1 = lo >> (64 - m); }
+        else w1 = lo;
+        active[pid * P.words] = w0;
+        if (P.words > 1) active[pid * P.words + 1] = w1;
+    }
+}
+
+}  // namespace lmpc

@@ -1,0 +1,51 @@
+// Host-side constant pack of one condensed-MPC least-distance problem and the device view of it.
+// Internal to liblmpc_hip.so (the public surface is include/lmpc_hip.h).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/lmpc_hip.h"
+
+namespace lmpc {
+
+// DAQP sense flags (reference mpc2mpqp.jl:868-885 uses DAQP.IMMUTABLE/EQUALITY/SOFT/BINARY)
+enum : int32_t { SENSE_ACTIVE = 1, SENSE_LOWER = 2, SENSE_IMMUTABLE = 4, SENSE_SOFT = 8, SENSE_BINARY = 16 };
+
+// DAQP exit flags
+enum : int32_t {
+    EXIT_SOFT_OPTIMAL = 2, EXIT_OPTIMAL = 1, EXIT_INFEASIBLE = -1, EXIT_CYCLE = -2,
+    EXIT_UNBOUNDED = -3, EXIT_ITERLIMIT = -4, EXIT_NONCONVEX = -5, EXIT_OVERDETERMINED = -6
+};
+
+// All matrices row-major.  G is the packed lower triangle of M M' (index a>=b: a(a+1)/2+b),
+// accumulated with the same fma chain the solver would use at run time, so looking a product up
+// is bit-identical to recomputing it.
+struct HostPack {
+    int n = 0, m = 0, ms = 0, nth = 0, nout = 0, nsoft = 0;
+    std::vector<double> M, G, du0, dl0, Dth, Rout, x0, Xth;
+    std::vector<int32_t> sense;
+    int words() const { return (2 * m + 63) / 64; }
+};
+
+// QP -> LDP transform of reference codegen.jl:239-280 (qp2ldp) on column-major Julia arrays.
+// Returns LMPC_OK or LMPC_ERR_NONCONVEX / LMPC_ERR_INFEASIBLE / LMPC_ERR_BADARG.
+int qp_to_ldp(HostPack &P, int n, int m, int ms, int nth, int nout,
+              const double *H, const double *f, const double *f_theta, const double *A,
+              const double *bu, const double *bl, const double *W, const int32_t *sense,
+              const double *Kfb, int nx, std::string &err);
+
+// Fills P.G and P.nsoft from P.M / P.sense; validates shapes.
+int finish_pack(HostPack &P, std::string &err);
+
+// What the kernels receive by value.
+struct DevPack {
+    int n, m, ms, nth, nout, words;
+    const double *M, *G, *du0, *dl0, *Dth, *Rout, *x0, *Xth;
+    const int32_t *sense;
+    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
+    int cycle_tol, iter_limit;
+};
+
+}  // namespace lmpc

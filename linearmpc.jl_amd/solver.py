@@ -1,0 +1,202 @@
+"""`BatchedQP`: Python face of one `lmpc_handle` (include/lmpc_hip.h).
+
+It stands where `mpc.opt_model` (a DAQPBase.Model) stands in the reference
+(/root/reference/src/types.jl:141, setup.jl:11-13): set up once from the mpQP, then solved for
+many parameter points.  All arithmetic happens in the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _cabi
+from ._cabi import LmpcError, Settings, check, lib
+
+_vp = ctypes.c_void_p
+
+
+def _f64(a, order="C"):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["A", "O", order[0]])
+
+
+def _ptr(a):
+    return _vp(a.ctypes.data) if a is not None and a.size else None
+
+
+def transform(H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0):
+    """Host-only QP -> LDP transform (`lmpc_transform`; reference codegen.jl:239-280 `qp2ldp`).
+
+    Returns a dict with row-major M, du, dl, Dth, Rout, x0, Xth (+ dims)."""
+    H = _f64(H, "F")
+    n = H.shape[0]
+    f_theta = _f64(np.asarray(f_theta, float).reshape(n, -1), "F")
+    nth = f_theta.shape[1]
+    bu = _f64(np.asarray(bu, float).reshape(-1))
+    bl = _f64(np.asarray(bl, float).reshape(-1))
+    m = bu.size
+    A = _f64(np.asarray(A, float).reshape(-1, n), "F")
+    ms = m - A.shape[0]
+    W = _f64(np.asarray(W, float).reshape(m, nth), "F")
+    f = _f64(np.zeros(n) if f is None else np.asarray(f, float).reshape(n))
+    nout = n if nout is None else int(nout)
+    sense = np.ascontiguousarray(np.zeros(m, np.int32) if senses is None else senses, dtype=np.int32)
+    Kf = None if K is None else _f64(np.asarray(K, float).reshape(nout, -1), "F")
+    out = dict(M=np.empty((m, n)), du=np.empty(m), dl=np.empty(m), Dth=np.empty((m, nth)),
+               Rout=np.empty((nout, n)), x0=np.empty(nout), Xth=np.empty((nout, nth)))
+    rc = lib().lmpc_transform(n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta), _ptr(A),
+                              _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense), _ptr(Kf) if Kf is not None else None,
+                              int(nx if K is not None else 0),
+                              *[_ptr(out[k]) for k in ("M", "du", "dl", "Dth", "Rout", "x0", "Xth")])
+    check(rc)
+    out.update(n=n, m=m, ms=ms, nth=nth, nout=nout, sense=sense)
+    return out
+
+
+class BatchedQP:
+    """One condensed-MPC QP structure resident on one GPU, solved for batches of theta."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+        dims = (ctypes.c_int32 * 6)()
+        check(lib().lmpc_get_dims(self._h, ctypes.byref(dims)), self._h)
+        self.n, self.m, self.ms, self.nth, self.nout, self.words = (int(v) for v in dims)
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_mpqp(cls, H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0,
+                  settings: Settings | None = None, device=0):
+        """DAQP.setup + DAQP.settings equivalent (reference setup.jl:11-13,26)."""
+        H = _f64(H, "F")
+        n = H.shape[0]
+        f_theta = _f64(np.asarray(f_theta, float).reshape(n, -1), "F")
+        nth = f_theta.shape[1]
+        bu = _f64(np.asarray(bu, float).reshape(-1))
+        bl = _f64(np.asarray(bl, float).reshape(-1))
+        m = bu.size
+        A = _f64(np.asarray(A, float).reshape(-1, n), "F")
+        ms = m - A.shape[0]
+        W = _f64(np.asarray(W, float).reshape(m, nth), "F")
+        f = _f64(np.zeros(n) if f is None else np.asarray(f, float).reshape(n))
+        nout = n if nout is None else int(nout)
+        sense = np.ascontiguousarray(np.zeros(m, np.int32) if senses is None else senses, dtype=np.int32)
+        Kf = None if K is None else _f64(np.asarray(K, float).reshape(nout, -1), "F")
+        h = _vp()
+        rc = lib().lmpc_setup(ctypes.byref(h), n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta),
+                              _ptr(A), _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense),
+                              _ptr(Kf) if Kf is not None else None, int(nx if K is not None else 0),
+                              ctypes.cast(ctypes.pointer(settings), _vp) if settings is not None else None,
+                              int(device))
+        check(rc)
+        return cls(h, device)
+
+    @classmethod
+    def from_ldp(cls, M, du, dl, Dth, Rout, x0, Xth, sense=None, ms=0,
+                 settings: Settings | None = None, device=0):
+        """Setup from the arrays the reference's code generator emits (codegen.jl:183-189)."""
+        M = _f64(M)
+        m, n = M.shape
+        Dth = _f64(np.asarray(Dth, float).reshape(m, -1))
+        nth = Dth.shape[1]
+        Rout = _f64(np.asarray(Rout, float).reshape(-1, n))
+        nout = Rout.shape[0]
+        du, dl, x0 = _f64(du), _f64(dl), _f64(x0)
+        Xth = _f64(np.asarray(Xth, float).reshape(nout, nth))
+        sense = np.ascontiguousarray(np.zeros(m, np.int32) if sense is None else sense, dtype=np.int32)
+        h = _vp()
+        rc = lib().lmpc_setup_ldp(ctypes.byref(h), n, m, int(ms), nth, nout, _ptr(M), _ptr(du), _ptr(dl),
+                                  _ptr(Dth), _ptr(Rout), _ptr(x0), _ptr(Xth), _ptr(sense),
+                                  ctypes.cast(ctypes.pointer(settings), _vp) if settings is not None else None,
+                                  int(device))
+        check(rc)
+        return cls(h, device)
+
+    # ------------------------------------------------------------------ inspection
+    @property
+    def kernel_name(self) -> str:
+        return lib().lmpc_kernel_name(self._h).decode()
+
+    def ldp(self):
+        """The constant pack the kernels use (row-major) -- what tests hand to the oracle."""
+        out = dict(M=np.empty((self.m, self.n)), du=np.empty(self.m), dl=np.empty(self.m),
+                   Dth=np.empty((self.m, self.nth)), Rout=np.empty((self.nout, self.n)),
+                   x0=np.empty(self.nout), Xth=np.empty((self.nout, self.nth)))
+        sense = np.zeros(self.m, np.int32)
+        check(lib().lmpc_get_ldp(self._h, *[_ptr(out[k]) for k in ("M", "du", "dl", "Dth", "Rout", "x0", "Xth")],
+                                 _ptr(sense)), self._h)
+        out.update(sense=sense, n=self.n, m=self.m, ms=self.ms, nth=self.nth, nout=self.nout)
+        return out
+
+    def set_settings(self, settings: Settings):
+        check(lib().lmpc_set_settings(self._h, ctypes.byref(settings)), self._h)
+
+    # ------------------------------------------------------------------ solving
+    def solve(self, theta, warm=None, want_iters=True, want_active=True):
+        """Host arrays in, host arrays out (`lmpc_solve_batch`)."""
+        theta = _f64(np.asarray(theta, float).reshape(-1, self.nth) if self.nth else np.zeros((len(theta), 0)))
+        N = theta.shape[0]
+        x = np.empty((N, self.nout))
+        ef = np.empty(N, np.int32)
+        it = np.empty(N, np.int32) if want_iters else None
+        act = np.zeros((N, self.words), np.uint64) if want_active else None
+        w = None
+        if warm is not None:
+            w = np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, self.words))
+        check(lib().lmpc_solve_batch(self._h, N, _ptr(theta), _ptr(x), _ptr(ef),
+                                     _ptr(it) if it is not None else None,
+                                     _ptr(act) if act is not None else None,
+                                     _ptr(w) if w is not None else None), self._h)
+        return x, ef, it, act
+
+    def solve_one(self, theta):
+        """DAQP.solve shape for one theta: (x*, exitflag) (`lmpc_solve_one`)."""
+        theta = _f64(np.asarray(theta, float).reshape(self.nth))
+        x = np.empty(self.nout)
+        rc = lib().lmpc_solve_one(self._h, _ptr(theta), _ptr(x))
+        if rc <= -100:
+            raise LmpcError(rc, _cabi.last_error(self._h))
+        return x, rc
+
+    def solve_device(self, theta, x=None, exitflag=None, iters=None, active=None, warm=None, stream=None):
+        """Device-resident batch (`lmpc_solve_batch_device`): torch CUDA tensors in and out, the
+        launch is enqueued on `stream` (default: torch's current stream) and NOT synchronised."""
+        import torch
+        if not theta.is_cuda or theta.dtype != torch.float64 or not theta.is_contiguous():
+            raise ValueError("theta must be a contiguous float64 CUDA tensor of shape (N, nth)")
+        if theta.device.index != self.device:
+            raise ValueError("theta lives on a different GPU than this handle")
+        N = theta.shape[0]
+        dev = theta.device
+        if x is None:
+            x = torch.empty((N, self.nout), dtype=torch.float64, device=dev)
+        if exitflag is None:
+            exitflag = torch.empty(N, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        check(lib().lmpc_solve_batch_device(
+            self._h, N, _vp(theta.data_ptr()), _vp(x.data_ptr()), _vp(exitflag.data_ptr()),
+            _vp(iters.data_ptr()) if iters is not None else None,
+            _vp(active.data_ptr()) if active is not None else None,
+            _vp(warm.data_ptr()) if warm is not None else None, _vp(st)), self._h)
+        return x, exitflag
+
+    # ------------------------------------------------------------------ profiling
+    def profile(self, enable=True):
+        check(lib().lmpc_profile(self._h, int(bool(enable))), self._h)
+
+    def profile_read(self):
+        """(number of launches, average kernel ms) since the last read; HIP events on the launch stream."""
+        ms = ctypes.c_double(0.0)
+        cnt = lib().lmpc_profile_read(self._h, ctypes.byref(ms))
+        return cnt, ms.value
+
+    def close(self):
+        if self._h:
+            lib().lmpc_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

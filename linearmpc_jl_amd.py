@@ -1,0 +1,12 @@
+"""Importable alias of the package that lives in `linearmpc.jl_amd/` (a dotted directory name
+cannot be written in an import statement): `import linearmpc_jl_amd as lmpc`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "linearmpc.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

@@ -40,7 +40,8 @@
  *
  * Arithmetic contract (shared with the HIP kernels so that results are bit-comparable):
  * IEEE binary64, every multiply-add written as an explicit fma(), sums accumulated in
- * index order, correctly rounded division; build with -ffp-contract=off.
+ * index order, correctly rounded division, pivots applied through their stored reciprocal
+ * 1/D_i (one division per new pivot instead of one per use); build with -ffp-contract=off.
  */
 #include <math.h>
 #include <stdint.h>
@@ -83,7 +84,7 @@ typedef struct {
 
 typedef struct {
     int n, m, cap, na, sing, reuse, nsoft_act;
-    double *L, *D, *lam, *lam_star, *xl, *zl, *u, *dupper, *dlower, *w;
+    double *L, *D, *Dinv, *lam, *lam_star, *xl, *zl, *u, *dupper, *dlower, *w;
     int *WS;
     int32_t *sense;
     double fval, soft_slack;
@@ -95,6 +96,7 @@ static work_t *work_new(int n, int m, int nsoft) {
     w->n = n; w->m = m; w->cap = cap;
     w->L = (double *)calloc((size_t)TRI(cap + 1), sizeof(double));
     w->D = (double *)calloc(cap + 1, sizeof(double));
+    w->Dinv = (double *)calloc(cap + 1, sizeof(double));
     w->lam = (double *)calloc(cap + 1, sizeof(double));
     w->lam_star = (double *)calloc(cap + 1, sizeof(double));
     w->xl = (double *)calloc(cap + 1, sizeof(double));
@@ -109,7 +111,7 @@ static work_t *work_new(int n, int m, int nsoft) {
 }
 
 static void work_free(work_t *w) {
-    free(w->L); free(w->D); free(w->lam); free(w->lam_star); free(w->xl); free(w->zl);
+    free(w->L); free(w->D); free(w->Dinv); free(w->lam); free(w->lam_star); free(w->xl); free(w->zl);
     free(w->w); free(w->u); free(w->dupper); free(w->dlower); free(w->WS); free(w->sense);
     free(w);
 }
@@ -138,7 +140,7 @@ static void ldl_add(work_t *w, const oracle_ldp *p, const oracle_settings *s, in
     }
     for (int i = 0; i < na; i++) {          /* l = D \ q ; d_new = m_j'm_j - sum l_i q_i */
         double q = row[i];
-        double l = q / w->D[i];
+        double l = q * w->Dinv[i];
         row[i] = l;
         dnew = fma(-l, q, dnew);
     }
@@ -147,9 +149,11 @@ static void ldl_add(work_t *w, const oracle_ldp *p, const oracle_settings *s, in
     /* n+1 hard rows in R^n are always dependent, whatever rounding says */
     if (dnew < s->zero_tol || (!is_soft && na - w->nsoft_act >= n)) {
         w->D[na] = 0.0;
+        w->Dinv[na] = 0.0;
         w->sing = na;
     } else {
         w->D[na] = dnew;
+        w->Dinv[na] = 1.0 / dnew;
     }
     w->WS[na] = j;
     w->lam[na] = 0.0;
@@ -180,13 +184,18 @@ static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
         const double dold = w->D[i + 1];
         const double dbar = fma(alpha * pt, pt, dold);
         if (dbar < s->zero_tol) {
+            /* only the last pivot can vanish in exact arithmetic; keep the tail shifted */
             w->D[i] = 0.0;
+            w->Dinv[i] = 0.0;
             w->sing = i;
+            for (int q = i + 1; q < na - 1; q++) { w->D[q] = w->D[q + 1]; w->Dinv[q] = w->Dinv[q + 1]; }
             break;
         }
-        const double beta = (pt * alpha) / dbar;
-        alpha = (dold * alpha) / dbar;
+        const double rinv = 1.0 / dbar;
+        const double beta = (pt * alpha) * rinv;
+        alpha = (dold * alpha) * rinv;
         w->D[i] = dbar;
+        w->Dinv[i] = rinv;
         for (int q = t + 1; q < nup; q++) {
             double *lqi = &w->L[TRI(r + q) + i];
             wv[q] = fma(-pt, *lqi, wv[q]);
@@ -213,7 +222,7 @@ static void compute_csp(work_t *w) {
         for (int t = 0; t < i; t++) acc = fma(-li[t], w->xl[t], acc);
         w->xl[i] = acc;
     }
-    for (int i = w->reuse; i < na; i++) w->zl[i] = w->xl[i] / w->D[i];
+    for (int i = w->reuse; i < na; i++) w->zl[i] = w->xl[i] * w->Dinv[i];
     for (int i = na - 1; i >= 0; i--) {
         double acc = w->zl[i];
         for (int t = na - 1; t > i; t--) acc = fma(-w->L[TRI(t) + i], w->lam_star[t], acc);

@@ -1,0 +1,143 @@
+"""Generates the committed golden fixtures (tests/golden/*.npz).
+
+Run from the repo root:  python tests/golden/make_golden.py
+
+Each fixture holds (a) the mpQP a LinearMPC.jl user would hand over for one of the benchmark
+problems (built by oracle/mpc2mpqp.py, the restatement of /root/reference/src/mpc2mpqp.jl),
+(b) the LDP pack (oracle/ldp.py restating /root/reference/src/codegen.jl:239-280), (c) seeded
+parameter points and (d) the oracle's answers for them: X*, exit flag, iterations, active-set
+mask.  Before anything is written the answers are cross-checked by independent means:
+
+  * pendulum: brute-force KKT enumeration over all 3^5 active-set patterns (unique optimum of a
+    strictly convex QP), and the reference's own known answer u = 1.7612519326
+    (/root/reference/test/runtests.jl:62-66);
+  * mass-spring: KKT residuals of every "optimal" answer and an LP feasibility check
+    (scipy.optimize.linprog) of every "infeasible" answer;
+  * preprocessing: the reference's K4 known answer (/root/reference/test/runtests.jl:1306-1318).
+
+Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
+the oracle against regressions and carry the reference's known answers.
+"""
+import itertools
+import os
+import sys
+
+import numpy as np
+from scipy.optimize import linprog
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+from oracle import ldp as oldp  # noqa: E402
+from oracle import mpc2mpqp as omm  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def kkt_enumerate_box(q, theta):
+    """Exact solution of a box-constrained strictly convex QP by enumerating active sets."""
+    n = q.n
+    f = q.f + q.f_theta @ theta
+    for pat in itertools.product((0, 1, -1), repeat=n):
+        act = [i for i in range(n) if pat[i]]
+        free = [i for i in range(n) if not pat[i]]
+        x = np.zeros(n)
+        for i in act:
+            x[i] = q.bu[i] if pat[i] == 1 else q.bl[i]
+        if free:
+            x[free] = np.linalg.solve(q.H[np.ix_(free, free)], -(f[free] + q.H[np.ix_(free, act)] @ x[act]))
+        g = q.H @ x + f
+        if np.any(x > q.bu + 1e-9) or np.any(x < q.bl - 1e-9):
+            continue
+        if all((-g[i] >= -1e-9) if pat[i] == 1 else (-g[i] <= 1e-9) for i in act):
+            return x
+    raise RuntimeError("no KKT point found")
+
+
+def kkt_residuals(q, theta, x, act_words):
+    m = q.m
+    Afull = np.vstack([np.eye(q.n)[:q.ms], q.A])
+    up = [j for j in range(m) if (int(act_words[j >> 6]) >> (j & 63)) & 1]
+    lo = [j for j in range(m) if (int(act_words[(m + j) >> 6]) >> ((m + j) & 63)) & 1]
+    bu, bl = q.bu + q.W @ theta, q.bl + q.W @ theta
+    g = q.H @ x + q.f + q.f_theta @ theta
+    E = Afull[up + lo]
+    lam = np.linalg.lstsq(E.T, -g, rcond=None)[0] if len(up + lo) else np.zeros(0)
+    stat = np.abs(g + E.T @ lam).max() if lam.size else np.abs(g).max()
+    pfeas = max((Afull @ x - bu).max(), (bl - Afull @ x).max())
+    sign = min([lam[i] for i in range(len(up))] + [-lam[len(up) + i] for i in range(len(lo))] + [0.0])
+    return stat, pfeas, sign
+
+
+def lp_feasible(q, theta):
+    Afull = np.vstack([np.eye(q.n)[:q.ms], q.A])
+    bu, bl = q.bu + q.W @ theta, q.bl + q.W @ theta
+    res = linprog(np.zeros(q.n), A_ub=np.vstack([Afull, -Afull]), b_ub=np.concatenate([bu, -bl]),
+                  bounds=[(None, None)] * q.n, method="highs")
+    return res.status == 0
+
+
+def save(name, q, L, theta, X, ef, it, act, extra=None):
+    d = dict(H=q.H, f=q.f, f_theta=q.f_theta, A=q.A, bu=q.bu, bl=q.bl, W=q.W, senses=q.senses,
+             nu=q.nu, nx=q.nx, M=L.M, du=L.du0, dl=L.dl0, Dth=L.Dth, Rout=L.Rout, x0=L.x0, Xth=L.Xth,
+             theta=theta, X=X, exitflag=ef, iters=it, active=act)
+    d.update(extra or {})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: N={theta.shape[0]} flags={dict(zip(*np.unique(ef, return_counts=True)))} "
+          f"max iters={it.max()}")
+
+
+def pendulum_theta(rng, N, hard=False):
+    """SURVEY.md 8(d) sampling; `hard` draws from the example's +-20 ParameterRange
+    (/root/reference/src/mpc_examples.jl:128-134)."""
+    if hard:
+        x = rng.uniform(-20, 20, (N, 4))
+        r = np.stack([rng.uniform(-20, 20, N), np.zeros(N)], 1)
+    else:
+        x = rng.uniform([-5, -5, -0.3, -2], [5, 5, 0.3, 2], (N, 4))
+        r = np.stack([rng.uniform(-5, 5, N), np.zeros(N)], 1)
+    return np.hstack([x, r, rng.uniform(-2, 2, (N, 1))])
+
+
+def main():
+    rng = np.random.default_rng(1234)   # seed mirrors /root/reference/test/runtests.jl:8
+
+    # ---- pendulum (BASELINE configs 1-2)
+    prob = omm.pendulum()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = np.vstack([pendulum_theta(rng, 1536), pendulum_theta(rng, 512, hard=True)])
+    theta[0] = omm.form_parameter(prob, [5.0, 5.0, 0.0, 0.0])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert abs(X[0, 0] - 1.7612519326) < 1e-9, X[0]
+    assert np.all(ef == 1)
+    for i in range(0, theta.shape[0], 8):
+        xe = kkt_enumerate_box(q, theta[i])
+        assert np.abs(xe - X[i]).max() < 2e-6, (i, xe, X[i])   # DAQP stops within primal_tol 1e-6
+    save("pendulum", q, L, theta, X, ef, it, act, dict(K1_x=[5.0, 5.0, 0, 0], K1_u=1.7612519326))
+
+    # ---- mass-spring chain nm=6 (BASELINE config 3; reference example has one input)
+    prob = omm.mass_spring()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = np.vstack([rng.uniform(-4, 4, (384, 12)), rng.uniform(-2, 2, (384, 12)),
+                       rng.uniform(-1, 1, (256, 12))])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    for i in range(theta.shape[0]):
+        if ef[i] == 1:
+            stat, pf, sg = kkt_residuals(q, theta[i], X[i], act[i])
+            assert stat < 1e-8 and pf < 2e-6 and sg > -1e-9, (i, stat, pf, sg)
+        elif i % 4 == 0:
+            assert not lp_feasible(q, theta[i]), i
+    save("mass_spring", q, L, theta, X, ef, it, act)
+
+    # ---- K4: preprocessing folds Au-only rows into the simple bounds
+    q = omm.mpc2mpqp(omm.preprocessing_kat())
+    assert q.A.shape[0] == 0 and np.all(q.bu == 0.9) and np.all(q.bl == -0.5)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = rng.uniform(-1, 1, (256, q.nth))
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("preprocessing_kat", q, L, theta, X, ef, it, act)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""CPU tests of the parity oracle against the reference's known answers and the committed
+golden vectors."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_ldp_from
+from oracle import ldp as oldp
+from oracle import mpc2mpqp as omm
+
+
+def test_K1_invpend_known_answer():
+    # /root/reference/test/runtests.jl:62-66: compute_control(invpend, [5,5,0,0]) = 1.7612519326 (tol 1e-6)
+    prob = omm.pendulum()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=prob.nu)
+    X, ef, it, act = oldp.solve_batch(L, omm.form_parameter(prob, [5.0, 5, 0, 0])[None])
+    assert ef[0] == 1
+    assert abs(X[0, 0] - 1.7612519326) < 1e-6
+    assert int(act[0, 0]) == 0b00010            # U_2 at its upper bound, nothing else
+
+
+def test_pendulum_problem_shape():
+    # n=5, m=5 simple bounds, theta=[x(4); r(2); u_prev(1)]
+    q = omm.mpc2mpqp(omm.pendulum())
+    assert (q.n, q.m, q.ms, q.nth) == (5, 5, 5, 7)
+    assert np.allclose(q.H, q.H.T) and np.all(np.linalg.eigvalsh(q.H) > 0)
+    assert not np.any(q.W) and not np.any(q.senses)
+    assert np.all(q.bu == 2.0) and np.all(q.bl == -2.0)
+
+
+def test_mass_spring_problem_shape():
+    # 54 state-constraint rows generated, one dropped by remove_redundant (mpc2mpqp.jl:742)
+    q = omm.mpc2mpqp(omm.mass_spring())
+    assert (q.n, q.m, q.ms, q.nth) == (10, 63, 10, 12)
+
+
+def test_K4_preprocessing_folds_bounds():
+    # /root/reference/test/runtests.jl:1306-1318
+    q = omm.mpc2mpqp(omm.preprocessing_kat())
+    assert q.A.shape[0] == 0
+    assert np.all(q.bu == 0.9 * np.ones(10))
+    assert np.all(q.bl == -0.5 * np.ones(10))
+
+
+def _enumerate_box(q, theta):
+    n = q.n
+    f = q.f + q.f_theta @ theta
+    for pat in itertools.product((0, 1, -1), repeat=n):
+        act = [i for i in range(n) if pat[i]]
+        free = [i for i in range(n) if not pat[i]]
+        x = np.zeros(n)
+        for i in act:
+            x[i] = q.bu[i] if pat[i] == 1 else q.bl[i]
+        if free:
+            x[free] = np.linalg.solve(q.H[np.ix_(free, free)], -(f[free] + q.H[np.ix_(free, act)] @ x[act]))
+        g = q.H @ x + f
+        if np.any(x > q.bu + 1e-9) or np.any(x < q.bl - 1e-9):
+            continue
+        if all((-g[i] >= -1e-9) if pat[i] == 1 else (-g[i] <= 1e-9) for i in act):
+            return x, pat
+    raise AssertionError("no KKT point")
+
+
+def test_oracle_vs_kkt_enumeration_pendulum():
+    prob = omm.pendulum()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    rng = np.random.default_rng(7)
+    theta = np.hstack([rng.uniform(-20, 20, (60, 4)), rng.uniform(-20, 20, (60, 1)), np.zeros((60, 1)),
+                       rng.uniform(-2, 2, (60, 1))])
+    X, ef, _, act = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1)
+    for i in range(theta.shape[0]):
+        xe, pat = _enumerate_box(q, theta[i])
+        assert np.abs(xe - X[i]).max() < 2e-6          # the solver stops within primal_tol = 1e-6
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+def test_oracle_reproduces_golden(name):
+    g = load_golden(name)
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    X, ef, it, act = oldp.solve_batch(L, g["theta"])
+    assert np.array_equal(ef, g["exitflag"])
+    assert np.array_equal(it, g["iters"])
+    assert np.array_equal(act, g["active"])
+    ok = ef >= 1
+    assert np.abs(X[ok] - g["X"][ok]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+def test_golden_pack_matches_restated_transform(name):
+    g = load_golden(name)
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
+    for k, a in (("M", L.M), ("du", L.du0), ("dl", L.dl0), ("Dth", L.Dth), ("Rout", L.Rout), ("Xth", L.Xth)):
+        assert np.allclose(a, g[k], rtol=0, atol=1e-12), k
+
+
+def test_golden_solutions_satisfy_kkt_mass_spring():
+    g = load_golden("mass_spring")
+    H, A, n = g["H"], g["A"], g["H"].shape[0]
+    ms = g["bu"].size - A.shape[0]
+    Afull = np.vstack([np.eye(n)[:ms], A])
+    m = g["bu"].size
+    checked = 0
+    for i in np.flatnonzero(g["exitflag"] == 1)[:200]:
+        th, x, a = g["theta"][i], g["X"][i], g["active"][i]
+        up = [j for j in range(m) if (int(a[j >> 6]) >> (j & 63)) & 1]
+        lo = [j for j in range(m) if (int(a[(m + j) >> 6]) >> ((m + j) & 63)) & 1]
+        bu, bl = g["bu"] + g["W"] @ th, g["bl"] + g["W"] @ th
+        grad = H @ x + g["f"] + g["f_theta"] @ th
+        E = Afull[up + lo]
+        lam = np.linalg.lstsq(E.T, -grad, rcond=None)[0] if len(up + lo) else np.zeros(0)
+        assert (np.abs(grad + E.T @ lam).max() if lam.size else np.abs(grad).max()) < 1e-8
+        assert max((Afull @ x - bu).max(), (bl - Afull @ x).max()) < 2e-6
+        assert all(lam[k] > -1e-9 for k in range(len(up))) and all(lam[len(up) + k] < 1e-9 for k in range(len(lo)))
+        checked += 1
+    assert checked > 50
+
+
+def test_warm_start_reaches_same_solution():
+    # K6 (/root/reference/test/runtests.jl:85-117): cold vs warm start agree (|du| < 1e-9)
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    Xw, efw, itw, actw = oldp.solve_batch(L, g["theta"], warm=g["active"])
+    assert np.array_equal(efw, g["exitflag"])
+    assert np.abs(Xw - g["X"]).max() < 1e-9
+    assert np.array_equal(actw, g["active"])
+    assert itw.max() <= 2 and itw.mean() < g["iters"].mean()
+
+
+def test_equality_and_immutable_rows():
+    # sense flags of mpc2mpqp.jl:868-885: an EQUALITY row is active from the start and never leaves,
+    # an IMMUTABLE (both bounds infinite) row is never looked at
+    rng = np.random.default_rng(3)
+    n, nth = 4, 3
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + n * np.eye(n)
+    A = rng.standard_normal((3, n))
+    bu = np.array([1.0, 1.0, 1e30, 1e30, 0.3, 1e30, 0.5])
+    bl = np.array([-1.0, -1.0, -1e30, -1e30, 0.3, -1e30, -0.5])
+    sense = np.array([0, 0, 4, 4, 5, 4, 0], np.int32)
+    W = np.zeros((7, nth)); W[4] = [0.1, 0, 0]
+    f_theta = rng.standard_normal((n, nth))
+    L = oldp.qp2ldp(H, np.zeros(n), f_theta, A, bu, bl, W, sense, nout=n)
+    theta = rng.uniform(-1, 1, (50, nth))
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1)
+    for i in range(50):
+        assert abs(A[0] @ X[i] - (0.3 + 0.1 * theta[i, 0])) < 1e-9          # equality holds
+        assert (int(act[i, 0]) >> 4) & 1                                   # and is in the working set
+        assert np.all(X[i, :2] <= 1 + 1e-6) and np.all(X[i, :2] >= -1 - 1e-6)
+        assert abs(A[2] @ X[i]) <= 0.5 + 1e-6
