@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: condensed-MPC QP solves per second, pendulum Nc=5, batch 1e6 (f64).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (lmpc_solve_batch_device: constraint shift, dual
+active-set solve, primal recovery) over one batch of 1e6 synthetic parameter points per GPU,
+already resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 1e6-point
+shard (weak scaling) and the per-shard solutions + exit flags are all-gathered over RCCL/xGMI;
+the gather of step k runs on RCCL's stream underneath the solve of step k+1.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 1_000_000
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_problem(name):
+    """mpQP of the benchmark problem.  The condensing step is not part of the timed path (it stays
+    on the LinearMPC.jl host); the committed golden fixture carries the matrices."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz")))
+    return g
+
+
+def make_theta(name, n, seed, hard=False):
+    """Synthetic parameter points, SURVEY.md section 8(d) / BASELINE.md sampling."""
+    rng = np.random.default_rng(seed)
+    if name == "pendulum":
+        if hard:      # the example's +-20 ParameterRange (reference mpc_examples.jl:128-134)
+            x = rng.uniform(-20, 20, (n, 4))
+            r = rng.uniform(-20, 20, (n, 1))
+        else:
+            x = rng.uniform([-5, -5, -0.3, -2], [5, 5, 0.3, 2], (n, 4))
+            r = rng.uniform(-5, 5, (n, 1))
+        return np.ascontiguousarray(np.hstack([x, r, np.zeros((n, 1)), rng.uniform(-2, 2, (n, 1))]))
+    if name == "mass_spring":
+        return np.ascontiguousarray(rng.uniform(-4, 4, (n, 12)))
+    raise ValueError(name)
+
+
+def algorithmic_bytes(nth, nout):
+    # read theta (8*nth) + write x (8*nout) + write exit flag (4); SURVEY.md section 8(d)
+    return 8 * nth + 8 * nout + 4
+
+
+def cpu_baseline(g, theta, nout, min_seconds=10.0):
+    """Single-thread CPU oracle (the restated DAQP algorithm) on the same batch; a reported
+    baseline, not the product path."""
+    from oracle import ldp as oldp
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+    oldp.solve_batch(L, theta[:1000])
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        oldp.solve_batch(L, theta)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or passes >= 200:
+            break
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": passes * theta.shape[0] / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} passes over the same {theta.shape[0]}-point batch, 1 thread of "
+                      f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c built -O2 -mfma"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring"])
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import linearmpc_jl_amd as lmpc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    name = "pendulum" if args.workload.startswith("pendulum") else args.workload
+    hard = args.workload == "pendulum_hard"
+    g = make_problem(name)
+    nout = int(g["nu"])
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
+                                  g["senses"], nout=nout, device=local_rank)
+    n_local = args.batch
+    theta_h = make_theta(name, n_local, 1234 + rank, hard)
+    theta = torch.from_numpy(theta_h).to(dev)
+
+    # double-buffered outputs so the gather of step k overlaps the solve of step k+1
+    xbuf = [torch.empty((n_local, nout), dtype=torch.float64, device=dev) for _ in range(2)]
+    fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(2)]
+    do_gather = world > 1 and not args.no_gather
+    if do_gather:
+        xall = [torch.empty((world * n_local, nout), dtype=torch.float64, device=dev) for _ in range(2)]
+        fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(2)]
+    pending = [None, None]
+
+    def step(k):
+        b = k & 1
+        if pending[b] is not None:               # buffer b is free once its gather has finished
+            for w in pending[b]:
+                w.wait()
+            pending[b] = None
+        qp.solve_device(theta, x=xbuf[b], exitflag=fbuf[b])
+        if do_gather:
+            pending[b] = (dist.all_gather_into_tensor(xall[b], xbuf[b], async_op=True),
+                          dist.all_gather_into_tensor(fall[b], fbuf[b], async_op=True))
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    fence()
+    qp.profile(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    nlaunch, kern_ms = qp.profile_read()
+    qp.profile(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    flags = fbuf[(args.steps - 1) & 1].cpu().numpy() if args.steps else np.zeros(0, np.int32)
+    if rank == 0:
+        total = world * n_local * args.steps
+        value = total / elapsed
+        bytes_per = algorithmic_bytes(qp.nth, nout)
+        achieved = (bytes_per * n_local) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "condensed-MPC QP solves/sec (batch 1e6 params), pendulum Nc=5"
+                      if args.workload == "pendulum" else f"condensed-MPC QP solves/sec ({args.workload})",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: "
+                       + ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 "
+                          "(n=5 vars, 5 two-sided input bounds, theta=[x;r;u_prev] nth=7), "
+                          if name == "pendulum" else "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), ")
+                       + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
+                       "batch_per_gpu": n_local, "kernel": qp.kernel_name,
+                       "gather": "all_gather(x, exitflag) over RCCL, overlapped" if do_gather else "none",
+                       "solved_fraction": float((flags >= 1).mean()) if flags.size else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "launches_timed": nlaunch,
+                         "algorithmic_bytes_per_solve": bytes_per},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(g, theta_h, nout)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,60 @@
+"""world_size-2 gloo tests of the sharding / gather layer (the N>1 path of bench.py).
+
+The per-shard solutions are produced by the CPU oracle here (no GPU in this container); what is
+under test is the partition + exchange: contiguous shards, ragged remainder, all-gather and
+gather-to-root, and that the gathered result equals the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden, oracle_ldp_from
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    import sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import linearmpc_jl_amd as lmpc
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    theta = g["theta"][:n_total]
+    lo, hi = lmpc.shard_bounds(n_total, world, rank)
+    X, ef, _, _ = oldp.solve_batch(L, theta[lo:hi])
+    Xl, efl = torch.from_numpy(X), torch.from_numpy(ef)
+    Xall = lmpc.gather_shards(Xl, n_total)                     # all-gather
+    efall = lmpc.gather_shards(efl, n_total)
+    Xroot = lmpc.gather_shards(Xl, n_total, dst=0)             # gather to rank 0
+    assert (Xroot is None) == (rank != 0)
+    np.save(os.path.join(out_dir, f"X{rank}.npy"), Xall.numpy())
+    np.save(os.path.join(out_dir, f"ef{rank}.npy"), efall.numpy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "Xroot.npy"), Xroot.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [512, 333, 1])
+def test_sharded_gather_equals_single_process(tmp_path, n_total):
+    from oracle import ldp as oldp
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_total, str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    X, ef, _, _ = oldp.solve_batch(oracle_ldp_from(pk), g["theta"][:n_total])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"X{r}.npy"), X)
+        assert np.array_equal(np.load(tmp_path / f"ef{r}.npy"), ef)
+    assert np.array_equal(np.load(tmp_path / "Xroot.npy"), X)

@@ -1,0 +1,118 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls: no GPU here)."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from oracle import ldp as oldp
+
+
+@pytest.fixture(scope="module")
+def lmpc():
+    import linearmpc_jl_amd as mod
+    return mod
+
+
+def test_library_exports_every_declared_symbol(lmpc):
+    hdr = open(os.path.join(ROOT, "include", "lmpc_hip.h")).read()
+    declared = set(re.findall(r"\b(lmpc_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"lmpc_handle", "lmpc_settings"}
+    assert declared == set(lmpc.SYMBOLS), declared ^ set(lmpc.SYMBOLS)
+    L = lmpc.lib()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.lmpc_abi_version() == 1
+
+
+def test_default_settings_match_reference_docs(lmpc):
+    # /root/reference/docs/src/manual/solver.md:49-56
+    s = lmpc.default_settings()
+    assert (s.primal_tol, s.dual_tol, s.progress_tol, s.cycle_tol, s.iter_limit, s.rho_soft) == \
+        (1e-6, 1e-12, 1e-6, 10, 10000, 1e-6)
+    so = oldp.default_settings()
+    for name, _ in lmpc.Settings._fields_:
+        assert getattr(s, name) == getattr(so, name), name
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+def test_host_transform_matches_oracle_qp2ldp(lmpc, name):
+    # library's C++ QP->LDP (lmpc_transform) vs the numpy restatement of codegen.jl:239-280
+    g = load_golden(name)
+    n = g["H"].shape[0]
+    for nout in (1, n):
+        t = lmpc.transform(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+        L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+        for k, ref in (("M", L.M), ("du", L.du0), ("dl", L.dl0), ("Dth", L.Dth), ("Rout", L.Rout),
+                       ("x0", L.x0), ("Xth", L.Xth)):
+            assert np.allclose(t[k], ref, rtol=1e-12, atol=1e-12), (name, k)
+        assert np.allclose(np.linalg.norm(t["M"], axis=1), 1.0)
+
+
+def test_transform_with_prestabilising_feedback_and_linear_term(lmpc):
+    rng = np.random.default_rng(0)
+    n, nth, nx, nout = 4, 5, 3, 2
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + np.eye(n)
+    f = rng.standard_normal(n); f_theta = rng.standard_normal((n, nth))
+    A = rng.standard_normal((3, n)); bu = np.ones(5); bl = -np.ones(5); W = rng.standard_normal((5, nth))
+    K = rng.standard_normal((nout, nx))
+    t = lmpc.transform(H, f, f_theta, A, bu, bl, W, None, nout=nout, K=K, nx=nx)
+    L = oldp.qp2ldp(H, f, f_theta, A, bu, bl, W, np.zeros(5, np.int32), nout=nout, K=K)
+    for k, ref in (("M", L.M), ("du", L.du0), ("dl", L.dl0), ("Dth", L.Dth), ("Rout", L.Rout), ("x0", L.x0), ("Xth", L.Xth)):
+        assert np.allclose(t[k], ref, rtol=1e-11, atol=1e-11), k
+
+
+def test_transform_error_codes(lmpc):
+    g = load_golden("pendulum")
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.transform(-g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"])
+    assert e.value.code == -5 and "positive definite" in str(e.value)
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.transform(g["H"], g["f"], g["f_theta"], g["A"], g["bl"], g["bu"], g["W"], g["senses"])
+    assert e.value.code == -1
+
+
+def test_no_cpu_fallback(lmpc, has_gpu):
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    g = load_golden("pendulum")
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"])
+    assert e.value.code == -101
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "linearmpc.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")) or fn == "Makefile":
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle/" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_form_parameter_layout(lmpc):
+    # /root/reference/src/explicit.jl:54-63: theta = [x; r; d; uprev; p]
+    g = load_golden("pendulum")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                   nx=4, nu=1, nr=2, nuprev=1)
+    assert mpc.get_parameter_dims() == (4, 2, 0, 1, 0)
+    th = mpc.form_parameter([1, 2, 3, 4], r=[5, 6], uprev=[7])
+    assert np.array_equal(th, [1, 2, 3, 4, 5, 6, 7])
+    assert np.array_equal(mpc.form_parameter([1, 2, 3, 4]), [1, 2, 3, 4, 0, 0, 0])   # r, uprev default 0
+    with pytest.raises(ValueError):
+        mpc.form_parameter([1, 2, 3])
+    with pytest.raises(ValueError):
+        mpc.form_parameter([1, 2, 3, 4], r=[1.0])
+    TH = mpc.form_parameter_batch(np.ones((3, 4)), R=[5, 6], Uprev=np.arange(3)[:, None])
+    assert TH.shape == (3, 7) and np.array_equal(TH[:, 4:6], [[5, 6]] * 3) and np.array_equal(TH[:, 6], [0, 1, 2])
+
+
+def test_shard_bounds(lmpc):
+    for n, w in [(10, 3), (1_000_000, 8), (5, 8), (0, 2), (64, 1)]:
+        spans = [lmpc.shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == lmpc.shard_counts(n, w)
