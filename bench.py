@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
+    ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +122,8 @@ def main():
     nout = int(g["nu"])
     qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
                                   g["senses"], nout=nout, device=local_rank)
+    if args.no_screen:
+        qp.set_option("screen", 0)
     n_local = args.batch
     theta_h = make_theta(name, n_local, 1234 + rank, hard)
     theta = torch.from_numpy(theta_h).to(dev)
@@ -168,7 +171,7 @@ def main():
     drain()
     fence()
     elapsed = time.perf_counter() - t0
-    nlaunch, kern_ms = qp.profile_read()
+    nlaunch, kern_ms, screen_ms, iterate_ms = qp.profile_read()
     qp.profile(False)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -206,7 +209,8 @@ def main():
                        "solved_fraction": float((flags >= 1).mean()) if flags.size else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "launches_timed": nlaunch,
+                         "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
+                         "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
                          "algorithmic_bytes_per_solve": bytes_per},
         }
         if world == 1 and not args.no_cpu_baseline:

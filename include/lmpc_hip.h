@@ -153,11 +153,18 @@ int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 
-/* Average device time in ms of the dominant solve kernel over the launches made since the
- * last call (HIP events recorded on the launch stream when profiling is switched on with
- * lmpc_profile(h, 1)); returns the number of launches averaged, <0 on error. */
+/* Device time per lmpc_solve_batch* call, measured with HIP events recorded on the launch
+ * stream (switch on with lmpc_profile(h, 1)).  lmpc_profile_read waits for the recorded calls,
+ * averages over the calls made since the last read and returns how many there were (<0: error):
+ *   avg_ms[0] whole call (screening pass + iterating pass), avg_ms[1] screening kernel,
+ *   avg_ms[2] iterating kernel. */
 int lmpc_profile(lmpc_handle *h, int enable);
-int lmpc_profile_read(lmpc_handle *h, double *avg_ms);
+int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
+
+/* Tuning switches: "screen" (default 1) = run cold-start batches through the streaming
+ * screening pass before the iterating kernel; 0 = iterating kernel only.  Results are
+ * bit-identical either way. */
+int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
 void lmpc_free(lmpc_handle *h);
 

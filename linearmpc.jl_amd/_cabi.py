@@ -21,7 +21,7 @@ SYMBOLS = (
     "lmpc_abi_version", "lmpc_default_settings", "lmpc_setup", "lmpc_setup_ldp", "lmpc_transform",
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
     "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one", "lmpc_kernel_name",
-    "lmpc_profile", "lmpc_profile_read", "lmpc_free", "lmpc_last_error",
+    "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
 
@@ -79,8 +79,10 @@ def lib():
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]
     L.lmpc_profile.restype = i32
-    L.lmpc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
+    L.lmpc_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double * 3)]
     L.lmpc_profile_read.restype = i32
+    L.lmpc_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    L.lmpc_set_option.restype = i32
     L.lmpc_free.argtypes = [vp]
     L.lmpc_free.restype = None
     L.lmpc_last_error.argtypes = [vp]

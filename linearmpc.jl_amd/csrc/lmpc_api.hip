@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "lmpc_lane_kernel.hpp"
+#include "lmpc_screen_kernel.hpp"
 #include "lmpc_pack.hpp"
 
 using namespace lmpc;
@@ -21,8 +22,9 @@ constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
 constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
-struct EventPair { hipEvent_t a, b; };
+struct EventTriple { hipEvent_t a, mid, b; bool screened; };
 
 }  // namespace
 
@@ -40,9 +42,13 @@ struct lmpc_handle {
     int32_t *sFlag = nullptr, *sIter = nullptr;
     uint64_t *sAct = nullptr, *sWarm = nullptr;
     int64_t sCap = 0;
+    // work list of the problems the screening pass leaves for the iterating kernel
+    int32_t *dList = nullptr, *dCount = nullptr;
+    int64_t listCap = 0;        // batch size the list buffer was sized for
+    bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // profiling
     bool prof = false;
-    std::vector<EventPair> events;
+    std::vector<EventTriple> events;
 };
 
 namespace {
@@ -99,7 +105,7 @@ int finalize_handle(lmpc_handle *h) {
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: soft constraints are not supported by the lane kernel yet");
     h->laneN = 0;
     for (int s : kLaneSizes) if (s >= P.n) { h->laneN = s; break; }
-    h->kname = "lane<" + std::to_string(h->laneN) + ">";
+    h->kname = "screen+lane<" + std::to_string(h->laneN) + ">";
     fill_layout(h);
     const int N = h->laneN;
     std::vector<double> buf(h->nC, 0.0);
@@ -126,13 +132,36 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
 template <int N>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
-                hipStream_t st) {
+                const int32_t *list, const int32_t *count, hipStream_t st) {
     auto kern = lane_kernel<N>;
+    const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned grid = (unsigned)((nprob + B - 1) / B);
+    unsigned grid = (unsigned)((nprob + B - 1) / B);
+    // with a work list the counts are only known on the device: a fixed grid (a multiple of the
+    // shard count) strides over each segment
+    if (list) {
+        unsigned per = (unsigned)((segCap + B - 1) / B);
+        if (per > 32u) per = 32u;
+        if (per < 1u) per = 1u;
+        grid = per * (unsigned)kShards;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag, iters, active,
-                       warm, (long long)nprob);
+                       warm, list, count, segCap, kShards, (long long)nprob);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+template <int NTHMAX>
+int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+                  int32_t *iters, uint64_t *active, hipStream_t st) {
+    const int B = 256;
+    const size_t lds = sizeof(double) * (size_t)B * (h->P.nth ? h->P.nth : 1);
+    const unsigned grid = (unsigned)((nprob + B - 1) / B);
+    const int vec16 = ((uintptr_t)theta % 16u) == 0;
+    const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
+    hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
+                       iters, active, h->dList, h->dCount, segCap, kShards, (long long)nprob, vec16);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -151,22 +180,44 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         if (waves > bestWaves) { bestWaves = waves; bestB = B; bestLds = lds; }
     }
     if (!bestB) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: constant pack does not fit in LDS");
-    EventPair ev{};
+    // Cold starts without initially-active rows go through the screening pass first.
+    const bool screened = h->screen && !warm && h->L.eq_mask == 0ull && h->S.iter_limit > 1 &&
+                          h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
+    if (screened && nprob > h->listCap) {
+        hipFree(h->dList); hipFree(h->dCount);
+        h->dList = h->dCount = nullptr; h->listCap = 0;
+        const size_t segCap = (size_t)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
+        HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
+        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * kShards * kCountStride));
+        h->listCap = nprob;
+    }
+    EventTriple ev{};
+    ev.screened = screened;
     if (h->prof) {
         HIP_TRY(h, hipEventCreate(&ev.a));
+        HIP_TRY(h, hipEventCreate(&ev.mid));
         HIP_TRY(h, hipEventCreate(&ev.b));
         HIP_TRY(h, hipEventRecord(ev.a, st));
     }
-    int rc;
-    switch (h->laneN) {
-#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, st); break;
+    int rc = LMPC_OK;
+    if (screened) {
+        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * kShards * kCountStride, st));
+        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, st);
+        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, st);
+        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, st);
+    }
+    if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
+    const int32_t *list = screened ? h->dList : nullptr;
+    const int32_t *count = screened ? h->dCount : nullptr;
+    if (rc == LMPC_OK) switch (h->laneN) {
+#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, st); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
     }
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
-        else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     }
     return rc;
 }
@@ -339,30 +390,41 @@ int lmpc_profile(lmpc_handle *h, int enable) {
     return LMPC_OK;
 }
 
-int lmpc_profile_read(lmpc_handle *h, double *avg_ms) {
+int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
     if (!h || !avg_ms) return LMPC_ERR_BADARG;
-    double tot = 0.0;
+    double tot = 0.0, scr = 0.0, itr = 0.0;
     int cnt = 0;
     for (auto &ev : h->events) {
-        float ms = 0.f;
-        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
-            tot += ms;
+        float ms = 0.f, ms1 = 0.f, ms2 = 0.f;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess &&
+            hipEventElapsedTime(&ms1, ev.a, ev.mid) == hipSuccess &&
+            hipEventElapsedTime(&ms2, ev.mid, ev.b) == hipSuccess) {
+            tot += ms; scr += ms1; itr += ms2;
             cnt++;
         }
         hipEventDestroy(ev.a);
+        hipEventDestroy(ev.mid);
         hipEventDestroy(ev.b);
     }
     h->events.clear();
-    *avg_ms = cnt ? tot / cnt : 0.0;
+    avg_ms[0] = cnt ? tot / cnt : 0.0;
+    avg_ms[1] = cnt ? scr / cnt : 0.0;
+    avg_ms[2] = cnt ? itr / cnt : 0.0;
     return cnt;
+}
+
+int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
+    if (!h || !name) return LMPC_ERR_BADARG;
+    if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
+    return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
 }
 
 void lmpc_free(lmpc_handle *h) {
     if (!h) return;
     if (h->dC || h->sTheta) hipSetDevice(h->device);
-    for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+    for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
-    hipFree(h->sAct); hipFree(h->sWarm);
+    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount);
     delete h;
 }
 

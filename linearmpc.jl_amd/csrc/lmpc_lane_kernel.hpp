@@ -34,20 +34,34 @@ struct PackLayout {
     int cycle_tol, iter_limit;
 };
 
+// work-list counters sit one per 128-byte line
+constexpr int kCountStride = 32;
+
 __host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
 // strict lower triangle, row i > col t
 __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
 template <int N>
-__global__ __launch_bounds__(256) void lane_kernel(
+__global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, long long nprob) {
+    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ count, long long seg_cap,
+    int nshards, long long nprob) {
     constexpr int MA = N + 1;
     constexpr int NSL = MA * (MA - 1) / 2;
     extern __shared__ __align__(16) double lds[];
 
     const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
+    // `list` (from screen_kernel) holds the problems that need iterations, in `nshards` segments of
+    // capacity seg_cap with one counter each; block b works on segment b % nshards.  Without a list
+    // the kernel walks the whole batch.  Blocks stride over the work so a fixed grid covers any count.
+    const int shard = list ? (int)(blockIdx.x % nshards) : 0;
+    const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
+    const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;
+    const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
+    if (first >= cnt) return;
+    if (list) list += (long long)shard * seg_cap;
     double *sM = lds;                    // m x N   rows by per-lane constraint index
     double *sG = sM + m * N;             // packed lower triangle of M M'
     double *sdu = sG + lmpc_tri(m);      // du0
@@ -58,16 +72,30 @@ __global__ __launch_bounds__(256) void lane_kernel(
     for (int i = tid; i < m; i += B) { sdu[i] = C[P.odu + i]; sdl[i] = C[P.odl + i]; }
     __syncthreads();
 
-    const long long pid = (long long)blockIdx.x * B + tid;
-    if (pid >= nprob) return;
+  for (long long base = first; base < cnt; base += stride) {
+    const long long idx = base + tid;
+    if (idx >= cnt) continue;
+    const long long pid = list ? (long long)list[idx] : idx;
     const double *th = theta + pid * nth;
 
-    // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
-    for (int j = 0; j < m; j++) {
-        double acc = 0.0;
-        for (int t = 0; t < nth; t++) acc = __builtin_fma(C[P.oDth + j * nth + t], th[t], acc);
-        sB[j * B + tid] = acc;
+    // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
+    // (loads issued back to back), the running sums live in this lane's LDS column; per row the
+    // products are still added in ascending t, as the oracle does
+    for (int t0 = 0; t0 < nth; t0 += 4) {
+        double tv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) tv[q] = (t0 + q < nth) ? th[t0 + q] : 0.0;
+        for (int j = 0; j < m; j++) {
+            double acc = t0 ? sB[j * B + tid] : 0.0;
+            const double *dj = C + P.oDth + j * nth + t0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t0 + q < nth) acc = __builtin_fma(dj[q], tv[q], acc);
+            sB[j * B + tid] = acc;
+        }
     }
+    if (nth == 0)
+        for (int j = 0; j < m; j++) sB[j * B + tid] = 0.0;
 
     double SL[NSL > 0 ? NSL : 1];
     double D[MA], Dinv[MA], lam[MA], ls[MA], rhs[MA], u[N];
@@ -379,6 +407,7 @@ __global__ __launch_bounds__(256) void lane_kernel(
         active[pid * P.words] = w0;
         if (P.words > 1) active[pid * P.words + 1] = w1;
     }
+  }   // chunk loop
 }
 
 }  // namespace lmpc

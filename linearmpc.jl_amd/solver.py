@@ -185,10 +185,14 @@ class BatchedQP:
         check(lib().lmpc_profile(self._h, int(bool(enable))), self._h)
 
     def profile_read(self):
-        """(number of launches, average kernel ms) since the last read; HIP events on the launch stream."""
-        ms = ctypes.c_double(0.0)
+        """(launches, avg ms whole call, avg ms screening kernel, avg ms iterating kernel) since the
+        last read; HIP events recorded on the launch stream."""
+        ms = (ctypes.c_double * 3)()
         cnt = lib().lmpc_profile_read(self._h, ctypes.byref(ms))
-        return cnt, ms.value
+        return cnt, ms[0], ms[1], ms[2]
+
+    def set_option(self, name: str, value: int):
+        check(lib().lmpc_set_option(self._h, name.encode(), int(value)), self._h)
 
     def close(self):
         if self._h:
