@@ -45,6 +45,7 @@ struct lmpc_handle {
     // work list of the problems the screening pass leaves for the iterating kernel
     int32_t *dList = nullptr, *dCount = nullptr;
     int64_t listCap = 0;        // batch size the list buffer was sized for
+    int countSet = 0;           // which of the two counter sets the next call uses
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // profiling
     bool prof = false;
@@ -132,7 +133,7 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
 template <int N>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
-                const int32_t *list, const int32_t *count, hipStream_t st) {
+                const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
     auto kern = lane_kernel<N>;
     const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
     if (lds > 48 * 1024)
@@ -147,21 +148,21 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
         grid = per * (unsigned)kShards;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag, iters, active,
-                       warm, list, count, segCap, kShards, (long long)nprob);
+                       warm, list, count, count_next, segCap, kShards, (long long)nprob);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
 
 template <int NTHMAX>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
-                  int32_t *iters, uint64_t *active, hipStream_t st) {
+                  int32_t *iters, uint64_t *active, int32_t *count, hipStream_t st) {
     const int B = 256;
     const size_t lds = sizeof(double) * (size_t)B * (h->P.nth ? h->P.nth : 1);
     const unsigned grid = (unsigned)((nprob + B - 1) / B);
     const int vec16 = ((uintptr_t)theta % 16u) == 0;
     const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
     hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
-                       iters, active, h->dList, h->dCount, segCap, kShards, (long long)nprob, vec16);
+                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, vec16);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -188,8 +189,10 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         h->dList = h->dCount = nullptr; h->listCap = 0;
         const size_t segCap = (size_t)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
         HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
-        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * kShards * kCountStride));
+        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 2 * kShards * kCountStride));
+        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 2 * kShards * kCountStride, st));
         h->listCap = nprob;
+        h->countSet = 0;
     }
     EventTriple ev{};
     ev.screened = screened;
@@ -200,17 +203,21 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         HIP_TRY(h, hipEventRecord(ev.a, st));
     }
     int rc = LMPC_OK;
+    // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
+    int32_t *cnt_now = nullptr, *cnt_next = nullptr;
     if (screened) {
-        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * kShards * kCountStride, st));
-        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, st);
-        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, st);
-        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, st);
+        cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+        cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+        h->countSet ^= 1;
+        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
+        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
+        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
     const int32_t *list = screened ? h->dList : nullptr;
-    const int32_t *count = screened ? h->dCount : nullptr;
+    const int32_t *count = cnt_now;
     if (rc == LMPC_OK) switch (h->laneN) {
-#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, st); break;
+#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;

@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
-    const int32_t *__restrict__ list, const int32_t *__restrict__ count, long long seg_cap,
-    int nshards, long long nprob) {
+    const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
+    long long seg_cap, int nshards, long long nprob) {
     constexpr int MA = N + 1;
     constexpr int NSL = MA * (MA - 1) / 2;
     extern __shared__ __align__(16) double lds[];
@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
     // `list` (from screen_kernel) holds the problems that need iterations, in `nshards` segments of
     // capacity seg_cap with one counter each; block b works on segment b % nshards.  Without a list
     // the kernel walks the whole batch.  Blocks stride over the work so a fixed grid covers any count.
+    // the counter set the next call's screening pass will use is cleared here (saves a memset
+    // node per call; this call's screening pass finished before this kernel started)
+    if (count_next && blockIdx.x == 0 && (int)threadIdx.x < nshards) count_next[threadIdx.x * kCountStride] = 0;
     const int shard = list ? (int)(blockIdx.x % nshards) : 0;
     const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
     const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;

@@ -26,8 +26,6 @@ __global__ __launch_bounds__(256) void screen_kernel(
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, int32_t *__restrict__ list, int32_t *__restrict__ count,
     long long seg_cap, int nshards, long long nprob, int vec16) {
-    __shared__ int s_wave_cnt[4];
-    __shared__ int s_base;
     extern __shared__ __align__(16) double tile[];     // B records of nth doubles, as in HBM
     const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
     const long long bp = (long long)blockIdx.x * B;
@@ -65,6 +63,16 @@ __global__ __launch_bounds__(256) void screen_kernel(
     }
     hard = hard && valid;
 
+    // Append the problems that need iterations to the work list: one atomic per wavefront, issued
+    // before the outputs are formed so that its round trip overlaps them.  The list is cut into
+    // `nshards` segments with their own counters (128 B apart): a single counter word saturates
+    // near 90 atomics/us, which 15k wavefronts would turn into the bottleneck of the whole pass.
+    const unsigned long long mask = __ballot(hard);
+    const int lane = tid & 63;
+    const int shard = blockIdx.x % nshards;
+    int basei = 0;
+    if (mask != 0ull && lane == 0) basei = atomicAdd(&count[shard * kCountStride], __popcll(mask));
+
     if (valid && !hard) {
         for (int k = 0; k < P.nout; k++) {
             double sh = C[P.ox0 + k];
@@ -80,28 +88,10 @@ __global__ __launch_bounds__(256) void screen_kernel(
             for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;
     }
 
-    // Append the problems that need iterations to the work list.  One global atomic per BLOCK,
-    // and the list is cut into `nshards` segments with their own counters (128 B apart): a single
-    // counter word saturates near 90 atomics/us, which 15k wavefronts would turn into the
-    // bottleneck of the whole pass.
-    const unsigned long long mask = __ballot(hard);
-    const int lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) s_wave_cnt[wave] = __popcll(mask);
-    __syncthreads();
-    const int nw = B >> 6;
-    if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < nw; w++) tot += s_wave_cnt[w];
-        const int shard = blockIdx.x % nshards;
-        s_base = tot ? atomicAdd(&count[shard * kCountStride], tot) : 0;
-    }
-    __syncthreads();
-    if (hard) {
-        int off = s_base;
-        for (int w = 0; w < wave; w++) off += s_wave_cnt[w];
-        off += __popcll(mask & ((1ull << lane) - 1ull));
-        const long long seg = (long long)(blockIdx.x % nshards) * seg_cap;
-        list[seg + off] = (int32_t)pid;
+    if (mask != 0ull) {
+        basei = __shfl(basei, 0);
+        if (hard)
+            list[(long long)shard * seg_cap + basei + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)pid;
     }
 }
 
