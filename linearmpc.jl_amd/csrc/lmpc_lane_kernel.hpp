@@ -41,44 +41,17 @@ __host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
 // strict lower triangle, row i > col t
 __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
+// Whole dual active-set solve of problem `pid` on this lane (no barriers inside).
+// sM/sG/sdu/sdl: LDS copies of the constant pack; sB: this block's b[j][lane] columns.
 template <int N>
-__global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
-    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
-    double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
-    const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
-    long long seg_cap, int nshards, long long nprob) {
+__device__ __forceinline__ void lane_solve(
+    const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
+    const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
+    const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
+    int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm) {
     constexpr int MA = N + 1;
     constexpr int NSL = MA * (MA - 1) / 2;
-    extern __shared__ __align__(16) double lds[];
-
-    const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
-    // `list` (from screen_kernel) holds the problems that need iterations, in `nshards` segments of
-    // capacity seg_cap with one counter each; block b works on segment b % nshards.  Without a list
-    // the kernel walks the whole batch.  Blocks stride over the work so a fixed grid covers any count.
-    // the counter set the next call's screening pass will use is cleared here (saves a memset
-    // node per call; this call's screening pass finished before this kernel started)
-    if (count_next && blockIdx.x == 0 && (int)threadIdx.x < nshards) count_next[threadIdx.x * kCountStride] = 0;
-    const int shard = list ? (int)(blockIdx.x % nshards) : 0;
-    const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
-    const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;
-    const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
-    if (first >= cnt) return;
-    if (list) list += (long long)shard * seg_cap;
-    double *sM = lds;                    // m x N   rows by per-lane constraint index
-    double *sG = sM + m * N;             // packed lower triangle of M M'
-    double *sdu = sG + lmpc_tri(m);      // du0
-    double *sdl = sdu + m;               // dl0
-    double *sB = sdl + m;                // b[j][lane]
-    for (int i = tid; i < m * N; i += B) sM[i] = C[P.oM + i];
-    for (int i = tid; i < lmpc_tri(m); i += B) sG[i] = C[P.oG + i];
-    for (int i = tid; i < m; i += B) { sdu[i] = C[P.odu + i]; sdl[i] = C[P.odl + i]; }
-    __syncthreads();
-
-  for (long long base = first; base < cnt; base += stride) {
-    const long long idx = base + tid;
-    if (idx >= cnt) continue;
-    const long long pid = list ? (long long)list[idx] : idx;
+    const int m = P.m, nth = P.nth;
     const double *th = theta + pid * nth;
 
     // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
@@ -410,6 +383,45 @@ __global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
         active[pid * P.words] = w0;
         if (P.words > 1) active[pid * P.words + 1] = w1;
     }
+}
+
+template <int N>
+__global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
+    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
+    double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
+    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
+    long long seg_cap, int nshards, long long nprob) {
+    extern __shared__ __align__(16) double lds[];
+
+    const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
+    // `list` (from screen_kernel) holds the problems that need iterations, in `nshards` segments of
+    // capacity seg_cap with one counter each; block b works on segment b % nshards.  Without a list
+    // the kernel walks the whole batch.  Blocks stride over the work so a fixed grid covers any count.
+    // the counter set the next call's screening pass will use is cleared here (saves a memset
+    // node per call; this call's screening pass finished before this kernel started)
+    if (count_next && blockIdx.x == 0 && (int)threadIdx.x < nshards) count_next[threadIdx.x * kCountStride] = 0;
+    const int shard = list ? (int)(blockIdx.x % nshards) : 0;
+    const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
+    const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;
+    const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
+    if (first >= cnt) return;
+    if (list) list += (long long)shard * seg_cap;
+    double *sM = lds;                    // m x N   rows by per-lane constraint index
+    double *sG = sM + m * N;             // packed lower triangle of M M'
+    double *sdu = sG + lmpc_tri(m);      // du0
+    double *sdl = sdu + m;               // dl0
+    double *sB = sdl + m;                // b[j][lane]
+    for (int i = tid; i < m * N; i += B) sM[i] = C[P.oM + i];
+    for (int i = tid; i < lmpc_tri(m); i += B) sG[i] = C[P.oG + i];
+    for (int i = tid; i < m; i += B) { sdu[i] = C[P.odu + i]; sdl[i] = C[P.odl + i]; }
+    __syncthreads();
+
+  for (long long base = first; base < cnt; base += stride) {
+    const long long idx = base + tid;
+    if (idx >= cnt) continue;
+    const long long pid = list ? (long long)list[idx] : idx;
+    lane_solve<N>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm);
   }   // chunk loop
 }
 
