@@ -10,6 +10,7 @@
 
 #include "lmpc_lane_kernel.hpp"
 #include "lmpc_screen_kernel.hpp"
+#include "lmpc_wave_kernel.hpp"
 #include "lmpc_pack.hpp"
 
 using namespace lmpc;
@@ -22,6 +23,7 @@ constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
 constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
+constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 256;
 constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
 struct EventTriple { hipEvent_t a, mid, b; bool screened; };
@@ -47,6 +49,12 @@ struct lmpc_handle {
     int64_t listCap = 0;        // batch size the list buffer was sized for
     int countSet = 0;           // which of the two counter sets the next call uses
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
+    // general path: one QP per wavefront
+    bool useWave = false, forceWave = false;
+    WaveLayout W{};
+    double *dCw = nullptr;
+    int32_t *dSw = nullptr;
+    int numCU = 256;
     // profiling
     bool prof = false;
     std::vector<EventTriple> events;
@@ -90,6 +98,10 @@ void fill_layout(lmpc_handle *h) {
     L.primal_tol = S.primal_tol; L.dual_tol = S.dual_tol; L.zero_tol = S.zero_tol;
     L.progress_tol = S.progress_tol; L.fval_bound = S.fval_bound; L.rho_soft = S.rho_soft;
     L.cycle_tol = S.cycle_tol; L.iter_limit = S.iter_limit;
+    WaveLayout &Wl = h->W;
+    Wl.primal_tol = S.primal_tol; Wl.dual_tol = S.dual_tol; Wl.zero_tol = S.zero_tol;
+    Wl.progress_tol = S.progress_tol; Wl.fval_bound = S.fval_bound; Wl.rho_soft = S.rho_soft;
+    Wl.cycle_tol = S.cycle_tol; Wl.iter_limit = S.iter_limit;
 }
 
 // choose the kernel variant and upload the constant pack
@@ -99,14 +111,56 @@ int finalize_handle(lmpc_handle *h) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
     if (h->device < 0 || h->device >= ndev) return fail(h, LMPC_ERR_BADARG, "lmpc: bad device ordinal");
-    if (P.n > kLaneMaxN || P.m > kLaneMaxM)
+    const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0;
+    const int cap = P.n + 1 + P.nsoft;
+    const bool waveOk = P.n <= kWaveMaxN && cap <= kWaveMaxCap && P.m <= kWaveMaxM && P.m >= 1;
+    if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,
-                    "lmpc: problem larger than the lane kernel covers (n <= 12, m <= 64)");
-    if (P.nsoft > 0)
-        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: soft constraints are not supported by the lane kernel yet");
+                    "lmpc: problem outside what the kernels cover (lane: n<=12, m<=64, hard rows; "
+                    "wave: n<=63, n+1+#soft<=64, m<=256)");
+    h->useWave = !laneOk || (h->forceWave && waveOk);
+    HIP_TRY(h, hipSetDevice(h->device));
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->numCU = prop.multiProcessorCount;
+    }
+    if (waveOk) {
+        // constant pack of the wavefront kernel: M, M transposed, Gram, bounds, maps (stride n)
+        WaveLayout &Wl = h->W;
+        Wl.n = P.n; Wl.m = P.m; Wl.ms = P.ms; Wl.nth = P.nth; Wl.nout = P.nout; Wl.words = P.words();
+        Wl.cap = cap; Wl.ldc = cap | 1;
+        int o = 0;
+        Wl.oM = o; o += P.m * P.n;
+        Wl.oMt = o; o += P.m * P.n;
+        Wl.oG = o; o += lmpc_tri(P.m);
+        Wl.odu = o; o += P.m;
+        Wl.odl = o; o += P.m;
+        Wl.oDth = o; o += P.m * P.nth;
+        Wl.oRout = o; o += P.nout * P.n;
+        Wl.ox0 = o; o += P.nout;
+        Wl.oXth = o; o += P.nout * P.nth;
+        std::vector<double> wb((size_t)o, 0.0);
+        std::memcpy(&wb[Wl.oM], P.M.data(), sizeof(double) * P.M.size());
+        for (int j = 0; j < P.m; j++)
+            for (int k = 0; k < P.n; k++) wb[Wl.oMt + (size_t)k * P.m + j] = P.M[(size_t)j * P.n + k];
+        std::memcpy(&wb[Wl.oG], P.G.data(), sizeof(double) * P.G.size());
+        std::memcpy(&wb[Wl.odu], P.du0.data(), sizeof(double) * P.m);
+        std::memcpy(&wb[Wl.odl], P.dl0.data(), sizeof(double) * P.m);
+        if (P.m * P.nth) std::memcpy(&wb[Wl.oDth], P.Dth.data(), sizeof(double) * P.Dth.size());
+        std::memcpy(&wb[Wl.oRout], P.Rout.data(), sizeof(double) * P.Rout.size());
+        std::memcpy(&wb[Wl.ox0], P.x0.data(), sizeof(double) * P.x0.size());
+        if (P.nout * P.nth) std::memcpy(&wb[Wl.oXth], P.Xth.data(), sizeof(double) * P.Xth.size());
+        HIP_TRY(h, hipMalloc(&h->dCw, sizeof(double) * wb.size()));
+        HIP_TRY(h, hipMemcpy(h->dCw, wb.data(), sizeof(double) * wb.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMalloc(&h->dSw, sizeof(int32_t) * P.m));
+        HIP_TRY(h, hipMemcpy(h->dSw, P.sense.data(), sizeof(int32_t) * P.m, hipMemcpyHostToDevice));
+    }
+    fill_layout(h);
+    if (!laneOk) { h->kname = "wave"; return LMPC_OK; }
     h->laneN = 0;
     for (int s : kLaneSizes) if (s >= P.n) { h->laneN = s; break; }
-    h->kname = "screen+lane<" + std::to_string(h->laneN) + ">";
+    h->kname = h->useWave ? "wave" : "screen+lane<" + std::to_string(h->laneN) + ">";
     fill_layout(h);
     const int N = h->laneN;
     std::vector<double> buf(h->nC, 0.0);
@@ -167,8 +221,54 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     return LMPC_OK;
 }
 
+template <int MR>
+int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+                   int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const WaveLayout &Wl = h->W;
+    const size_t perWave = sizeof(double) * (size_t)Wl.cap * Wl.ldc;
+    const int nwv = perWave > 40 * 1024 ? 1 : 4;        // wavefronts (problems in flight) per workgroup
+    const size_t lds = perWave * nwv;
+    auto kern = wave_kernel<MR>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int wavesPerCU = (int)(kLdsMax / (perWave ? perWave : 1));
+    if (wavesPerCU > 16) wavesPerCU = 16;
+    if (wavesPerCU < 1) wavesPerCU = 1;
+    long long grid = (long long)h->numCU * ((wavesPerCU + nwv - 1) / nwv);
+    const long long need = (nprob + nwv - 1) / nwv;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nwv), lds, st, Wl, h->dCw, h->dSw, theta, x, flag,
+                       iters, active, warm, (long long)nprob);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+                int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    EventTriple ev{};
+    ev.screened = false;
+    if (h->prof) {
+        HIP_TRY(h, hipEventCreate(&ev.a));
+        HIP_TRY(h, hipEventCreate(&ev.mid));
+        HIP_TRY(h, hipEventCreate(&ev.b));
+        HIP_TRY(h, hipEventRecord(ev.a, st));
+        HIP_TRY(h, hipEventRecord(ev.mid, st));
+    }
+    int rc;
+    const int mr = (h->P.m + 63) / 64;
+    if (mr <= 1) rc = launch_wave_mr<1>(h, nprob, theta, x, flag, iters, active, warm, st);
+    else if (mr == 2) rc = launch_wave_mr<2>(h, nprob, theta, x, flag, iters, active, warm, st);
+    else rc = launch_wave_mr<4>(h, nprob, theta, x, flag, iters, active, warm, st);
+    if (h->prof) {
+        if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    }
+    return rc;
+}
+
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    if (h->useWave) return launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
     // block size: the one that keeps most wavefronts resident per CU under the 160 KiB LDS cap
     int bestB = 0, bestWaves = -1;
     size_t bestLds = 0;
@@ -389,7 +489,10 @@ int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
     return rc == LMPC_OK ? flag : rc;
 }
 
-const char *lmpc_kernel_name(const lmpc_handle *h) { return h ? h->kname.c_str() : ""; }
+const char *lmpc_kernel_name(const lmpc_handle *h) {
+    if (!h) return "";
+    return h->useWave ? "wave" : h->kname.c_str();
+}
 
 int lmpc_profile(lmpc_handle *h, int enable) {
     if (!h) return LMPC_ERR_BADARG;
@@ -423,6 +526,12 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
 int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "wave") == 0) {
+        if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
+        if (!value && h->laneN == 0) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
+        h->useWave = value != 0;
+        return LMPC_OK;
+    }
     return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
 }
 
@@ -431,7 +540,7 @@ void lmpc_free(lmpc_handle *h) {
     if (h->dC || h->sTheta) hipSetDevice(h->device);
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
-    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount);
+    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw);
     delete h;
 }
 

@@ -29,7 +29,7 @@ no operating-point offsets).  Reference lines followed, all under
     remove_duplicate        mpc2mpqp.jl:775-828
     MPQP(obj,constraints)   mpc2mpqp.jl:868-899
     example problems        mpc_examples.jl:104-141 (invpend), :241-286 (mass_spring),
-                            README.md:39-52 (pendulum on a cart)
+                            README.md:39-52 (pendulum on a cart), docs/src/manual/simple.md:60-83
 """
 from __future__ import annotations
 
@@ -431,6 +431,18 @@ def preprocessing_kat() -> MPCProblem:
     p = make_mpc(F, G, np.eye(2), Np=10, umin=[-1.0], umax=[1.0], Ts=0.1)
     p.add_constraint(Au=[[-1.0]], lb=[-0.9], ub=[1.5], ks=range(1, 11))
     p.add_constraint(Au=[[1.0]], lb=[-0.5], ub=[2.0], ks=range(1, 11))
+    return p
+
+
+def doc_simple_soft() -> MPCProblem:
+    """docs/src/manual/simple.md:60-83 (K8): soft output bounds (set_bounds! ymin/ymax defaults to
+    soft=true, ks=2:Np, setup.jl:94) plus one hard general constraint; u = -1 at x=[0.5,1], r=0."""
+    F = np.array([[1.0, 0.5], [0.0, 1.0]])
+    G = np.array([[0.0], [1.0]])
+    C = np.array([[1.0, 0.0], [1.0, 1.0]])
+    p = make_mpc(F, G, C, Np=10, Nc=10, Q=[1.0, 1.0], R=[0.0], Rr=[1.0], umin=[-3.0], umax=[3.0])
+    p.add_constraint(Ax=C, lb=[0.0, 0.0], ub=[1.0, 2.0], ks=range(2, 11), soft=True)
+    p.add_constraint(Ax=[[2.0, -1.0]], lb=[-1.0], ub=[2.0], ks=range(2, 11))
     return p
 
 

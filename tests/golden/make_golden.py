@@ -13,6 +13,8 @@ mask.  Before anything is written the answers are cross-checked by independent m
     (/root/reference/test/runtests.jl:62-66);
   * mass-spring: KKT residuals of every "optimal" answer and an LP feasibility check
     (scipy.optimize.linprog) of every "infeasible" answer;
+  * soft_doc: the documentation's worked example with soft output bounds, known answer u = -1
+    (/root/reference/docs/src/manual/simple.md:98-107);
   * preprocessing: the reference's K4 known answer (/root/reference/test/runtests.jl:1306-1318).
 
 Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
@@ -129,6 +131,18 @@ def main():
         elif i % 4 == 0:
             assert not lp_feasible(q, theta[i]), i
     save("mass_spring", q, L, theta, X, ef, it, act)
+
+    # ---- K8: documentation example with SOFT output bounds (docs/src/manual/simple.md:60-107)
+    prob = omm.doc_simple_soft()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = np.hstack([rng.uniform(-1, 2, (768, 2)), rng.uniform(0, 1, (768, 2)), rng.uniform(-3, 3, (768, 1))])
+    theta[0] = omm.form_parameter(prob, [0.5, 1.0], r=[0.0, 0.0])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert ef[0] >= 1 and abs(X[0, 0] + 1.0) < 1e-6, (ef[0], X[0])      # "u = -1", simple.md:107
+    nsoft = int(np.sum((q.senses & 8) != 0))
+    assert nsoft > 0 and np.any(ef == 2)
+    save("soft_doc", q, L, theta, X, ef, it, act, dict(K8_x=[0.5, 1.0], K8_u=-1.0))
 
     # ---- K4: preprocessing folds Au-only rows into the simple bounds
     q = omm.mpc2mpqp(omm.preprocessing_kat())

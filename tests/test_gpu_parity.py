@@ -235,3 +235,71 @@ def test_device_resident_path_and_full_size_properties(lmpc):
     xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(pk), theta[idx])
     assert np.array_equal(efo, ef[idx]) and np.array_equal(ito, it[idx]) and np.array_equal(acto, act[idx])
     assert np.abs(xo - x[idx]).max() <= TOL
+
+
+# ------------------------------------------------------------------ wavefront-per-QP kernel
+def _random_qp(rng, n, mg, nth, nsoft=0, ms=None):
+    ms = n if ms is None else ms
+    Hh = rng.standard_normal((n, n))
+    H = Hh @ Hh.T + n * np.eye(n)
+    A = rng.standard_normal((mg, n))
+    m = ms + mg
+    bu = rng.uniform(0.5, 2.0, m)
+    bl = -rng.uniform(0.5, 2.0, m)
+    W = 0.3 * rng.standard_normal((m, nth))
+    W[:ms] = 0.0
+    f_theta = rng.standard_normal((n, nth))
+    sense = np.zeros(m, np.int32)
+    if nsoft:
+        sense[ms + rng.choice(mg, nsoft, replace=False)] = 8
+    return H, np.zeros(n), f_theta, A, bu, bl, W, sense
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+def test_wave_kernel_matches_oracle_and_lane_kernel(lmpc, name):
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    xl, efl, itl, actl = qp.solve(g["theta"])
+    assert "lane" in qp.kernel_name
+    qp.set_option("wave", 1)
+    assert qp.kernel_name == "wave"
+    xw, efw, itw, actw = _compare(qp, g["theta"])
+    assert np.array_equal(xw, xl) and np.array_equal(efw, efl) and np.array_equal(itw, itl)
+    assert np.array_equal(actw, actl)
+    ok = g["exitflag"] >= 1
+    _compare(qp, g["theta"][ok], warm=g["active"][ok])
+
+
+def test_K8_soft_constraints_through_c_abi(lmpc):
+    # /root/reference/docs/src/manual/simple.md:98-107: u = -1 at x = [0.5, 1], r = [0, 0]
+    g = load_golden("soft_doc")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                   nx=2, nu=1, nr=2, nuprev=1)
+    u = mpc.compute_control([0.5, 1.0], r=[0.0, 0.0])
+    assert abs(u[0] + 1.0) < 1e-6
+    assert mpc.opt_model.kernel_name == "wave"
+    x, ef, it, act = _compare(mpc.opt_model, g["theta"])
+    assert (ef == 2).any() and (ef == 1).any() and (ef == -1).any()
+    ok = g["exitflag"] >= 1
+    assert np.array_equal(ef >= 1, ok)
+    assert np.array_equal(act[ok], g["active"][ok])
+    # golden X came from the numpy-transformed pack; with soft rows the KKT system carries the
+    # 1/rho_soft = 1e6 penalty, so 1e-16 differences between the two packs grow to ~1e-5 in x on
+    # the soft-optimal problems (same active set, same iteration count).  The bit-level check on
+    # ONE pack is the _compare call above.
+    assert np.abs(x[ok] - g["X"][ok]).max() <= 1e-3
+    hard_only = ok & (g["exitflag"] == 1)
+    assert np.abs(x[hard_only] - g["X"][hard_only]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("n,mg,nth,nsoft,seed", [(20, 30, 6, 0, 0), (30, 90, 8, 10, 1), (63, 100, 5, 0, 2),
+                                                 (12, 200, 4, 40, 3), (3, 5, 2, 2, 4)])
+def test_wave_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
+    rng = np.random.default_rng(seed)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=min(n, 4))
+    assert qp.kernel_name == "wave"
+    theta = rng.uniform(-2, 2, (600, nth))
+    x, ef, it, act = _compare(qp, theta)
+    assert (ef >= 1).mean() > 0.05
+    _compare(qp, theta[:65], warm=act[:65])

@@ -77,7 +77,24 @@ def test_oracle_vs_kkt_enumeration_pendulum():
         assert np.abs(xe - X[i]).max() < 2e-6          # the solver stops within primal_tol = 1e-6
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+def test_K8_doc_example_with_soft_output_bounds():
+    # /root/reference/docs/src/manual/simple.md:60-107: "the optimal control action at x=[0.5,1] with
+    # r=[0,0] is u=-1"; output bounds are SOFT (setup.jl:94), rho_soft = 1/soft_weight (setup.jl:26)
+    prob = omm.doc_simple_soft()
+    q = omm.mpc2mpqp(prob)
+    assert np.sum((q.senses & omm.SOFT) != 0) == 17 and q.n == 10
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    X, ef, _, _ = oldp.solve_batch(L, omm.form_parameter(prob, [0.5, 1.0], r=[0.0, 0.0])[None])
+    assert ef[0] >= 1 and abs(X[0, 0] + 1.0) < 1e-6
+    # states that cannot keep the soft output bounds are still solved (exit flag 2 = soft optimal),
+    # and the violation stays small: y1 = x1 after one step exceeds its bound by O(rho_soft * lam)
+    g = load_golden("soft_doc")
+    i = int(np.flatnonzero(g["exitflag"] == 2)[0])
+    X, ef, _, _ = oldp.solve_batch(L, g["theta"][i][None])
+    assert ef[0] == 2
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -90,7 +107,7 @@ def test_oracle_reproduces_golden(name):
     assert np.abs(X[ok] - g["X"][ok]).max() <= 1e-12
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc"])
 def test_golden_pack_matches_restated_transform(name):
     g = load_golden(name)
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
