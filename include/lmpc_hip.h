@@ -150,6 +150,30 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
  * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call. */
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
 
+/*
+ * Batched closed-loop simulation: N independent scenarios advanced T steps in lock-step on the GPU.
+ * Per step and scenario it does what one pass of the reference's Simulation loop does
+ * (src/simulation.jl:93-113 without observer): theta = [x; r; uprev] (src/explicit.jl:54-63),
+ * u = compute_control (the batched solve of this handle, which must have been set up with
+ * nout = nu and, if used, the prestabilising feedback folded in), x <- F x + G u, uprev <- u.
+ * warm != 0 starts each solve from the previous step's final working set (the reference's
+ * DAQP_WARMSTART build, codegen/mpc_update_qp.c:44-47); the first step is cold.
+ *
+ *   nx + nr + nuprev must equal nth.  F[nx*nx], G[nx*nu] row-major HOST arrays (the plant).
+ *   x      N records of nx: in = initial states, out = states after T steps
+ *   r      N records of nr (constant reference per scenario) or NULL = 0
+ *   uprev  N records of nuprev, in/out (NULL allowed when nuprev == 0)
+ *   U_traj T*N*nu (step-major) or NULL;  X_traj (T+1)*N*nx or NULL
+ *   flag_min N int32: smallest exit flag seen over the T steps (>= 1 means every solve succeeded) or NULL
+ * lmpc_simulate takes HOST pointers; lmpc_simulate_device DEVICE pointers (except F, G) and a stream.
+ */
+int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev,
+                  const double *F, const double *G, double *x, const double *r, double *uprev,
+                  double *U_traj, double *X_traj, int32_t *flag_min, int warm);
+int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev,
+                         const double *F, const double *G, double *x, const double *r, double *uprev,
+                         double *U_traj, double *X_traj, int32_t *flag_min, int warm, void *stream);
+
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 

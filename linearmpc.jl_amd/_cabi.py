@@ -20,7 +20,8 @@ ERR_NAMES = {-1: "INFEASIBLE", -5: "NONCONVEX", -6: "OVERDETERMINED", -100: "BAD
 SYMBOLS = (
     "lmpc_abi_version", "lmpc_default_settings", "lmpc_setup", "lmpc_setup_ldp", "lmpc_transform",
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
-    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one", "lmpc_kernel_name",
+    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one", "lmpc_simulate",
+    "lmpc_simulate_device", "lmpc_kernel_name",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
@@ -75,6 +76,10 @@ def lib():
     L.lmpc_solve_batch_device.restype = i32
     L.lmpc_solve_one.argtypes = [vp, vp, vp]
     L.lmpc_solve_one.restype = i32
+    L.lmpc_simulate.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32]
+    L.lmpc_simulate.restype = i32
+    L.lmpc_simulate_device.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32, vp]
+    L.lmpc_simulate_device.restype = i32
     L.lmpc_kernel_name.argtypes = [vp]
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]

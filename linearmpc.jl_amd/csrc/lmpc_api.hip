@@ -11,6 +11,7 @@
 #include "lmpc_lane_kernel.hpp"
 #include "lmpc_screen_kernel.hpp"
 #include "lmpc_wave_kernel.hpp"
+#include "lmpc_sim_kernels.hpp"
 #include "lmpc_pack.hpp"
 
 using namespace lmpc;
@@ -55,6 +56,11 @@ struct lmpc_handle {
     double *dCw = nullptr;
     int32_t *dSw = nullptr;
     int numCU = 256;
+    // closed-loop simulation scratch
+    double *simTheta = nullptr, *simU = nullptr, *simFG = nullptr;
+    int32_t *simFlag = nullptr;
+    uint64_t *simAct = nullptr;
+    int64_t simCap = 0;
     // profiling
     bool prof = false;
     std::vector<EventTriple> events;
@@ -489,6 +495,89 @@ int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
     return rc == LMPC_OK ? flag : rc;
 }
 
+int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F,
+                         const double *G, double *x, const double *r, double *uprev, double *U_traj,
+                         double *X_traj, int32_t *flag_min, int warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    const int nu = h->P.nout;
+    if (N < 0 || T < 0 || nx <= 0 || nx > 32 || nr < 0 || nuprev < 0 || nuprev > nu || !F || !G || (N > 0 && !x) ||
+        (nuprev > 0 && N > 0 && !uprev) || nx + nr + nuprev != h->P.nth)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_simulate_device: theta = [x; r; uprev] must match the handle "
+                                        "(nx + nr + nuprev == nth, nout == nu, nx <= 32)");
+    if (N == 0 || T == 0) return LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w = (size_t)h->P.words();
+    if (N > h->simCap) {
+        hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+        h->simTheta = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
+        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
+        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
+        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
+        h->simCap = N;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
+    if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    for (int k = 0; k < T; k++) {
+        hipLaunchKernelGGL(form_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
+                           nuprev, (long long)N);
+        // warm start = previous step's final working set (reference codegen DAQP_WARMSTART,
+        // codegen/mpc_update_qp.c:44-47); the first step is always cold
+        const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
+        int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
+        if (rc != LMPC_OK) return rc;
+        hipLaunchKernelGGL(plant_kernel, dim3(grid), dim3(256), 0, st, x, uprev, h->simU, h->simFlag, h->simFG, nx,
+                           nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return LMPC_OK;
+}
+
+int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F, const double *G,
+                  double *x, const double *r, double *uprev, double *U_traj, double *X_traj, int32_t *flag_min,
+                  int warm) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N <= 0 || T <= 0) return N < 0 || T < 0 ? LMPC_ERR_BADARG : LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nu = h->P.nout;
+    double *dx = nullptr, *dr = nullptr, *du = nullptr, *dU = nullptr, *dX = nullptr;
+    int32_t *df = nullptr;
+    auto cleanup = [&]() { hipFree(dx); hipFree(dr); hipFree(du); hipFree(dU); hipFree(dX); hipFree(df); };
+#define SIM_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
+        return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    SIM_TRY(hipMalloc(&dx, sizeof(double) * (size_t)N * nx));
+    SIM_TRY(hipMemcpy(dx, x, sizeof(double) * (size_t)N * nx, hipMemcpyHostToDevice));
+    if (r && nr > 0) {
+        SIM_TRY(hipMalloc(&dr, sizeof(double) * (size_t)N * nr));
+        SIM_TRY(hipMemcpy(dr, r, sizeof(double) * (size_t)N * nr, hipMemcpyHostToDevice));
+    }
+    if (nuprev > 0) {
+        SIM_TRY(hipMalloc(&du, sizeof(double) * (size_t)N * nuprev));
+        if (uprev) SIM_TRY(hipMemcpy(du, uprev, sizeof(double) * (size_t)N * nuprev, hipMemcpyHostToDevice));
+        else SIM_TRY(hipMemset(du, 0, sizeof(double) * (size_t)N * nuprev));
+    }
+    if (U_traj) SIM_TRY(hipMalloc(&dU, sizeof(double) * (size_t)T * N * nu));
+    if (X_traj) SIM_TRY(hipMalloc(&dX, sizeof(double) * (size_t)(T + 1) * N * nx));
+    if (flag_min) SIM_TRY(hipMalloc(&df, sizeof(int32_t) * (size_t)N));
+    int rc = lmpc_simulate_device(h, N, T, nx, nr, nuprev, F, G, dx, dr, du, dU, dX, df, warm, nullptr);
+    if (rc == LMPC_OK) {
+        SIM_TRY(hipDeviceSynchronize());
+        SIM_TRY(hipMemcpy(x, dx, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToHost));
+        if (uprev && nuprev > 0) SIM_TRY(hipMemcpy(uprev, du, sizeof(double) * (size_t)N * nuprev, hipMemcpyDeviceToHost));
+        if (U_traj) SIM_TRY(hipMemcpy(U_traj, dU, sizeof(double) * (size_t)T * N * nu, hipMemcpyDeviceToHost));
+        if (X_traj) SIM_TRY(hipMemcpy(X_traj, dX, sizeof(double) * (size_t)(T + 1) * N * nx, hipMemcpyDeviceToHost));
+        if (flag_min) SIM_TRY(hipMemcpy(flag_min, df, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    }
+#undef SIM_TRY
+    cleanup();
+    return rc;
+}
+
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
     return h->useWave ? "wave" : h->kname.c_str();
@@ -541,6 +630,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw);
+    hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     delete h;
 }
 

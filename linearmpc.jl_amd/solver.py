@@ -180,6 +180,32 @@ class BatchedQP:
             _vp(warm.data_ptr()) if warm is not None else None, _vp(st)), self._h)
         return x, exitflag
 
+    def simulate(self, x0, T, F, G, r=None, uprev=None, warm=True, want_x=True):
+        """Batched closed loop (`lmpc_simulate`): N scenarios, T steps of solve + x <- F x + G u.
+
+        Returns dict(x=final states, U=(T,N,nu), X=(T+1,N,nx) or None, uprev, flag_min)."""
+        F = _f64(np.atleast_2d(F))
+        nx = F.shape[0]
+        nu = self.nout
+        G = _f64(np.asarray(G, float).reshape(nx, nu))
+        x = _f64(np.array(np.asarray(x0, float).reshape(-1, nx), copy=True))
+        N = x.shape[0]
+        nr = 0 if r is None else np.asarray(r).reshape(N, -1).shape[1]
+        nup = self.nth - nx - nr
+        if nup < 0 or nup > nu:
+            raise ValueError("theta = [x; r; uprev] does not match this handle")
+        rr = None if nr == 0 else _f64(np.asarray(r, float).reshape(N, nr))
+        up = None
+        if nup:
+            up = _f64(np.zeros((N, nup)) if uprev is None else np.array(np.asarray(uprev, float).reshape(N, nup), copy=True))
+        U = np.empty((T, N, nu))
+        X = np.empty((T + 1, N, nx)) if want_x else None
+        fm = np.empty(N, np.int32)
+        check(lib().lmpc_simulate(self._h, N, int(T), nx, nr, nup, _ptr(F), _ptr(G), _ptr(x), _ptr(rr) if rr is not None else None,
+                                  _ptr(up) if up is not None else None, _ptr(U), _ptr(X) if X is not None else None,
+                                  _ptr(fm), int(bool(warm))), self._h)
+        return dict(x=x, U=U, X=X, uprev=up, flag_min=fm)
+
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):
         check(lib().lmpc_profile(self._h, int(bool(enable))), self._h)

@@ -416,3 +416,50 @@ void oracle_solve_batch(const oracle_ldp *p, const oracle_settings *s, int64_t N
     }
     work_free(w);
 }
+
+/* Closed loop, one scenario after the other: the reference's Simulation loop without observer
+ * (/root/reference/src/simulation.jl:93-113): theta = [x; r; uprev] (src/explicit.jl:54-63),
+ * u = compute_control, x <- F x + G u (sums in index order, F then G), uprev <- u.
+ * warm != 0 reuses the previous step's final working set (generated-C DAQP_WARMSTART,
+ * /root/reference/codegen/mpc_update_qp.c:44-47); the first step is cold.  nout must equal nu. */
+void oracle_simulate(const oracle_ldp *p, const oracle_settings *s, int64_t N, int32_t T, int32_t nx,
+                     int32_t nr, int32_t nup, const double *F, const double *G, double *x,
+                     const double *r, double *uprev, double *U, double *X, int32_t *flag_min,
+                     int32_t warm) {
+    const int nw = oracle_active_words(p->m), nu = p->nout, nth = p->nth;
+    int nsoft = 0;
+    for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
+    work_t *w = work_new(p->n, p->m, nsoft);
+    double *th = (double *)calloc(nth > 0 ? nth : 1, sizeof(double));
+    double *u = (double *)calloc(nu, sizeof(double));
+    double *xn = (double *)calloc(nx, sizeof(double));
+    uint64_t *act = (uint64_t *)calloc(nw, sizeof(uint64_t));
+    for (int64_t i = 0; i < N; i++) {
+        double *xi = x + i * nx;
+        if (X) for (int a = 0; a < nx; a++) X[(size_t)i * nx + a] = xi[a];
+        for (int k = 0; k < T; k++) {
+            for (int a = 0; a < nx; a++) th[a] = xi[a];
+            for (int a = 0; a < nr; a++) th[nx + a] = r ? r[i * nr + a] : 0.0;
+            for (int a = 0; a < nup; a++) th[nx + nr + a] = uprev ? uprev[i * nup + a] : 0.0;
+            int32_t it = 0;
+            int ef = solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
+            for (int a = 0; a < nx; a++) {
+                double acc = 0.0;
+                for (int c = 0; c < nx; c++) acc = fma(F[a * nx + c], xi[c], acc);
+                for (int l = 0; l < nu; l++) acc = fma(G[a * nu + l], u[l], acc);
+                xn[a] = acc;
+            }
+            for (int a = 0; a < nx; a++) {
+                xi[a] = xn[a];
+                if (X) X[((size_t)(k + 1) * N + i) * nx + a] = xn[a];
+            }
+            for (int l = 0; l < nu; l++) {
+                if (l < nup) uprev[i * nup + l] = u[l];
+                if (U) U[((size_t)k * N + i) * nu + l] = u[l];
+            }
+            if (flag_min) flag_min[i] = (k == 0 || ef < flag_min[i]) ? ef : flag_min[i];
+        }
+    }
+    free(th); free(u); free(xn); free(act);
+    work_free(w);
+}

@@ -303,3 +303,46 @@ def test_wave_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
     x, ef, it, act = _compare(qp, theta)
     assert (ef >= 1).mean() > 0.05
     _compare(qp, theta[:65], warm=act[:65])
+
+
+# ------------------------------------------------------------------ closed-loop batch simulation
+@pytest.mark.parametrize("warm", [False, True])
+def test_closed_loop_simulation_matches_oracle(lmpc, warm):
+    # reference src/simulation.jl:93-113 for N scenarios at once; K6 (test/runtests.jl:85-117)
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    prob = omm.pendulum()
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(8)
+    N, T = 3000, 40
+    x0 = rng.uniform([-5, -5, -.3, -2], [5, 5, .3, 2], (N, 4))
+    x0[0] = [5.0, 5.0, 0.0, 0.0]
+    r = np.stack([rng.uniform(-2, 2, N), np.zeros(N)], 1)
+    r[0] = 0.0
+    ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=warm)
+    out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
+    assert np.array_equal(out["flag_min"], ref["flag_min"]) and np.all(out["flag_min"] >= 1)
+    assert np.abs(out["U"] - ref["U"]).max() <= TOL
+    assert np.abs(out["X"] - ref["X"]).max() <= TOL
+    assert np.abs(out["x"] - ref["x"]).max() <= TOL and np.abs(out["uprev"] - ref["uprev"]).max() <= TOL
+    assert abs(out["U"][0, 0, 0] - 1.7612519326) < 1e-6
+
+
+def test_closed_loop_simulation_soft_problem_wave_kernel(lmpc):
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    prob = omm.doc_simple_soft()
+    g = load_golden("soft_doc")
+    qp = _qp_from_golden(lmpc, g, 1)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(9)
+    N, T = 400, 10                       # docs/src/manual/simple.md:112-119: x0 = [0,0], r = [1,0], N = 10
+    x0 = rng.uniform(0, 0.5, (N, 2)); x0[0] = 0.0
+    r = np.tile([1.0, 0.0], (N, 1))
+    for warm in (False, True):
+        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=warm)
+        out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
+        assert np.array_equal(out["flag_min"], ref["flag_min"])
+        assert np.abs(out["U"] - ref["U"]).max() <= TOL and np.abs(out["X"] - ref["X"]).max() <= TOL

@@ -170,3 +170,20 @@ def test_equality_and_immutable_rows():
         assert (int(act[i, 0]) >> 4) & 1                                   # and is in the working set
         assert np.all(X[i, :2] <= 1 + 1e-6) and np.all(X[i, :2] >= -1 - 1e-6)
         assert abs(A[2] @ X[i]) <= 0.5 + 1e-6
+
+
+def test_K6_closed_loop_cold_equals_warm():
+    # /root/reference/test/runtests.jl:85-117: 100 closed-loop steps from x = [5,5,0,0], cold vs warm
+    # started solves give the same inputs (|du| < 1e-9); plant here = the linear prediction model
+    prob = omm.pendulum()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=prob.nu)
+    x0 = np.array([[5.0, 5.0, 0.0, 0.0], [0.0, 0.0, 0.15, 0.0], [-3.0, 2.0, 0.1, -1.0]])
+    r = np.zeros((3, 2))
+    cold = oldp.simulate(L, x0, 100, prob.F, prob.G, r=r, warm=False)
+    wrm = oldp.simulate(L, x0, 100, prob.F, prob.G, r=r, warm=True)
+    assert np.all(cold["flag_min"] >= 1) and np.all(wrm["flag_min"] >= 1)
+    assert np.abs(cold["U"] - wrm["U"]).max() < 1e-9
+    assert abs(cold["U"][0, 0, 0] - 1.7612519326) < 1e-6          # first move of scenario 0 is K1
+    assert np.abs(cold["U"]).max() <= 2 + 1e-6                     # |u| <= 2 along the whole run
+    assert abs(cold["x"][0, 1]) < 0.5 * abs(x0[0, 1])              # the cart is being braked
