@@ -9,7 +9,10 @@ One "step" = one pass of the hot path (lmpc_solve_batch_device: constraint shift
 active-set solve, primal recovery) over one batch of 1e6 synthetic parameter points per GPU,
 already resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 1e6-point
 shard (weak scaling) and the per-shard solutions + exit flags are all-gathered over RCCL/xGMI;
-the gather of step k runs on RCCL's stream underneath the solve of step k+1.
+the gather of step k runs on RCCL's stream underneath the solve of step k+1.  Consecutive steps are
+independent batches; by default three of them are kept in flight on three HIP streams (each with
+its own solver handle), which lets the streaming pass of one batch overlap the latency-bound
+iterating pass of another (--streams 1 serialises them).
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
 """
@@ -95,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
 
     import torch
@@ -120,36 +125,50 @@ def main():
     hard = args.workload == "pendulum_hard"
     g = make_problem(name)
     nout = int(g["nu"])
-    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
-                                  g["senses"], nout=nout, device=local_rank)
+    nstreams = max(1, min(8, args.streams))
+    qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
+                                    g["senses"], nout=nout, device=local_rank) for _ in range(nstreams)]
+    qp = qps[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    stream_handles = [s_.cuda_stream for s_ in streams]
     if args.no_screen:
-        qp.set_option("screen", 0)
+        for q_ in qps:
+            q_.set_option("screen", 0)
     n_local = args.batch
     theta_h = make_theta(name, n_local, 1234 + rank, hard)
     theta = torch.from_numpy(theta_h).to(dev)
 
     # double-buffered outputs so the gather of step k overlaps the solve of step k+1
-    xbuf = [torch.empty((n_local, nout), dtype=torch.float64, device=dev) for _ in range(2)]
-    fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(2)]
+    nbuf = max(2, nstreams)
+    xbuf = [torch.empty((n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and not args.no_gather
     if do_gather:
-        xall = [torch.empty((world * n_local, nout), dtype=torch.float64, device=dev) for _ in range(2)]
-        fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(2)]
-    pending = [None, None]
+        xall = [torch.empty((world * n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    pending = [None] * nbuf
 
     def step(k):
-        b = k & 1
-        if pending[b] is not None:               # buffer b is free once its gather has finished
-            for w in pending[b]:
-                w.wait()
-            pending[b] = None
-        qp.solve_device(theta, x=xbuf[b], exitflag=fbuf[b])
-        if do_gather:
-            pending[b] = (dist.all_gather_into_tensor(xall[b], xbuf[b], async_op=True),
-                          dist.all_gather_into_tensor(fall[b], fbuf[b], async_op=True))
+        b = k % nbuf
+        # step k runs on stream k % nstreams with that stream's own handle (work list, counters):
+        # consecutive steps are independent batches, so the streaming pass of one overlaps the
+        # latency-bound iterating pass of the other
+        sidx = k % nstreams
+        if not do_gather:                        # single GPU: raw stream handle, no context switch
+            qps[sidx].solve_device(theta, x=xbuf[b], exitflag=fbuf[b], stream=stream_handles[sidx])
+            return
+        with torch.cuda.stream(streams[sidx]):
+            if pending[b] is not None:           # buffer b is free once its gather has finished
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+            qps[sidx].solve_device(theta, x=xbuf[b], exitflag=fbuf[b])
+            if do_gather:
+                pending[b] = (dist.all_gather_into_tensor(xall[b], xbuf[b], async_op=True),
+                              dist.all_gather_into_tensor(fall[b], fbuf[b], async_op=True))
 
     def drain():
-        for b in (0, 1):
+        for b in range(nbuf):
             if pending[b] is not None:
                 for w in pending[b]:
                     w.wait()
@@ -164,27 +183,37 @@ def main():
         step(k)
     drain()
     fence()
-    qp.profile(True)
+    for q_ in qps:
+        q_.profile(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
-    nlaunch, kern_ms, screen_ms, iterate_ms = qp.profile_read()
-    qp.profile(False)
+    prof = [q_.profile_read() for q_ in qps]
+    for q_ in qps:
+        q_.profile(False)
+    nlaunch = sum(p_[0] for p_ in prof)
+    kern_ms, screen_ms, iterate_ms = (sum(p_[0] * p_[i] for p_ in prof) / max(nlaunch, 1) for i in (1, 2, 3))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    flags = fbuf[(args.steps - 1) & 1].cpu().numpy() if args.steps else np.zeros(0, np.int32)
+    flags = fbuf[(args.steps - 1) % nbuf].cpu().numpy() if args.steps else np.zeros(0, np.int32)
     if rank == 0:
         total = world * n_local * args.steps
         value = total / elapsed
         bytes_per = algorithmic_bytes(qp.nth, nout)
-        achieved = (bytes_per * n_local) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # One batch in flight: algorithmic bytes of a call / its device time (HIP events on the launch
+        # stream).  Several batches in flight: their launches overlap on the chip, a single launch no
+        # longer owns it, so the bytes one step moves are divided by the wall time one step takes
+        # (about kernel_ms / batches_in_flight; kernel_ms stays in the record for the rocprof check).
+        step_ms = 1e3 * elapsed / max(args.steps, 1)
+        dur_ms = kern_ms if nstreams == 1 else step_ms
+        achieved = (bytes_per * n_local) / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
         if os.path.exists(pmc):
@@ -204,13 +233,14 @@ def main():
                           "(n=5 vars, 5 two-sided input bounds, theta=[x;r;u_prev] nth=7), "
                           if name == "pendulum" else "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), ")
                        + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
-                       "batch_per_gpu": n_local, "kernel": qp.kernel_name,
+                       "batch_per_gpu": n_local, "kernel": qp.kernel_name, "batches_in_flight": nstreams,
                        "gather": "all_gather(x, exitflag) over RCCL, overlapped" if do_gather else "none",
                        "solved_fraction": float((flags >= 1).mean()) if flags.size else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
                          "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
+                         "duration_used_ms": dur_ms,
                          "algorithmic_bytes_per_solve": bytes_per},
         }
         if world == 1 and not args.no_cpu_baseline:

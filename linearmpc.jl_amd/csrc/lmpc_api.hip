@@ -64,9 +64,15 @@ struct lmpc_handle {
     // profiling
     bool prof = false;
     std::vector<EventTriple> events;
+    std::vector<hipEvent_t> eventPool;   // recycled by lmpc_profile_read
 };
 
 namespace {
+
+hipError_t pool_event(lmpc_handle *h, hipEvent_t *e) {
+    if (!h->eventPool.empty()) { *e = h->eventPool.back(); h->eventPool.pop_back(); return hipSuccess; }
+    return hipEventCreate(e);
+}
 
 int fail(lmpc_handle *h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_setup_err = msg;
@@ -190,11 +196,11 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
     return sizeof(double) * ((size_t)P.m * N + lmpc_tri(P.m) + 2 * (size_t)P.m + (size_t)P.m * B);
 }
 
-template <int N>
+template <int N, int MS>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
                 const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
-    auto kern = lane_kernel<N>;
+    auto kern = lane_kernel<N, MS>;
     const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -254,9 +260,9 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     EventTriple ev{};
     ev.screened = false;
     if (h->prof) {
-        HIP_TRY(h, hipEventCreate(&ev.a));
-        HIP_TRY(h, hipEventCreate(&ev.mid));
-        HIP_TRY(h, hipEventCreate(&ev.b));
+        HIP_TRY(h, pool_event(h, &ev.a));
+        HIP_TRY(h, pool_event(h, &ev.mid));
+        HIP_TRY(h, pool_event(h, &ev.b));
         HIP_TRY(h, hipEventRecord(ev.a, st));
         HIP_TRY(h, hipEventRecord(ev.mid, st));
     }
@@ -303,9 +309,9 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     EventTriple ev{};
     ev.screened = screened;
     if (h->prof) {
-        HIP_TRY(h, hipEventCreate(&ev.a));
-        HIP_TRY(h, hipEventCreate(&ev.mid));
-        HIP_TRY(h, hipEventCreate(&ev.b));
+        HIP_TRY(h, pool_event(h, &ev.a));
+        HIP_TRY(h, pool_event(h, &ev.mid));
+        HIP_TRY(h, pool_event(h, &ev.b));
         HIP_TRY(h, hipEventRecord(ev.a, st));
     }
     int rc = LMPC_OK;
@@ -322,8 +328,11 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
     const int32_t *list = screened ? h->dList : nullptr;
     const int32_t *count = cnt_now;
+    // box-constrained problems (m == n == N) get the instantiation with the row scans unrolled
+    const bool boxed = h->P.m == h->laneN && h->P.n == h->laneN;
     if (rc == LMPC_OK) switch (h->laneN) {
-#define LMPC_CASE(NN) case NN: rc = launch_lane<NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
+#define LMPC_CASE(NN) case NN: rc = boxed ? launch_lane<NN, NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
+                                          : launch_lane<NN, 0>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
@@ -601,9 +610,9 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
             tot += ms; scr += ms1; itr += ms2;
             cnt++;
         }
-        hipEventDestroy(ev.a);
-        hipEventDestroy(ev.mid);
-        hipEventDestroy(ev.b);
+        h->eventPool.push_back(ev.a);
+        h->eventPool.push_back(ev.mid);
+        h->eventPool.push_back(ev.b);
     }
     h->events.clear();
     avg_ms[0] = cnt ? tot / cnt : 0.0;
@@ -628,6 +637,7 @@ void lmpc_free(lmpc_handle *h) {
     if (!h) return;
     if (h->dC || h->sTheta) hipSetDevice(h->device);
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw);
     hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);

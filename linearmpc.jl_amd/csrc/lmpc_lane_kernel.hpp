@@ -43,7 +43,10 @@ __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2
 
 // Whole dual active-set solve of problem `pid` on this lane (no barriers inside).
 // sM/sG/sdu/sdl: LDS copies of the constant pack; sB: this block's b[j][lane] columns.
-template <int N>
+// MS > 0: the number of constraints is the compile-time constant MS (the common box-constrained
+// MPC, m == n): the scans over rows are fully unrolled, so all their scalar loads are issued in one
+// batch instead of one round trip per row.  MS == 0: m is a run-time value.
+template <int N, int MS>
 __device__ __forceinline__ void lane_solve(
     const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
     const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
@@ -51,7 +54,9 @@ __device__ __forceinline__ void lane_solve(
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm) {
     constexpr int MA = N + 1;
     constexpr int NSL = MA * (MA - 1) / 2;
-    const int m = P.m, nth = P.nth;
+    const int m = MS > 0 ? MS : P.m, nth = P.nth;
+    const bool one_out = P.nout == 1;
+    double sh0 = one_out ? C[P.ox0] : 0.0;      // x0 + Xth theta of the first output, built on the fly
     const double *th = theta + pid * nth;
 
     // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
@@ -61,13 +66,24 @@ __device__ __forceinline__ void lane_solve(
         double tv[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) tv[q] = (t0 + q < nth) ? th[t0 + q] : 0.0;
-        for (int j = 0; j < m; j++) {
+        auto brow = [&](int j) {
             double acc = t0 ? sB[j * B + tid] : 0.0;
             const double *dj = C + P.oDth + j * nth + t0;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (t0 + q < nth) acc = __builtin_fma(dj[q], tv[q], acc);
             sB[j * B + tid] = acc;
+        };
+        if constexpr (MS > 0) {
+#pragma unroll
+            for (int j = 0; j < MS; j++) brow(j);
+        } else {
+            for (int j = 0; j < m; j++) brow(j);
+        }
+        if (one_out) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t0 + q < nth) sh0 = __builtin_fma(C[P.oXth + t0 + q], tv[q], sh0);
         }
     }
     if (nth == 0)
@@ -289,18 +305,25 @@ __device__ __forceinline__ void lane_solve(
                 double min_val = -P.primal_tol;
                 int add = -1;
                 bool addlow = false;
-                for (int j = 0; j < m; j++) {
-                    if ((P.imm_mask >> j) & 1ull) continue;
-                    double Mu = 0.0;
+                auto scan_row = [&](int j) {
+                    if (!((P.imm_mask >> j) & 1ull)) {
+                        double Mu = 0.0;
 #pragma unroll
-                    for (int k = 0; k < N; k++) Mu = __builtin_fma(C[P.oM + j * N + k], u[k], Mu);
-                    const double b = sB[j * B + tid];
-                    const double vu = (C[P.odu + j] + b) - Mu;
-                    const double vl = -((C[P.odl + j] + b) - Mu);
-                    if (!((act >> j) & 1ull)) {
-                        if (vu < min_val) { add = j; addlow = false; min_val = vu; }
-                        else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+                        for (int k = 0; k < N; k++) Mu = __builtin_fma(C[P.oM + j * N + k], u[k], Mu);
+                        const double b = sB[j * B + tid];
+                        const double vu = (C[P.odu + j] + b) - Mu;
+                        const double vl = -((C[P.odl + j] + b) - Mu);
+                        if (!((act >> j) & 1ull)) {
+                            if (vu < min_val) { add = j; addlow = false; min_val = vu; }
+                            else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+                        }
                     }
+                };
+                if constexpr (MS > 0) {
+#pragma unroll
+                    for (int j = 0; j < MS; j++) scan_row(j);
+                } else {
+                    for (int j = 0; j < m; j++) scan_row(j);
                 }
                 if (add < 0) { flag = EXIT_OPTIMAL; break; }
 #pragma unroll
@@ -366,12 +389,19 @@ __device__ __forceinline__ void lane_solve(
     }
 
     // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22)
-    for (int k = 0; k < P.nout; k++) {
-        double xs = 0.0, sh = C[P.ox0 + k];
+    if (one_out) {
+        double xs = 0.0;
 #pragma unroll
-        for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
-        for (int t = 0; t < nth; t++) sh = __builtin_fma(C[P.oXth + k * nth + t], th[t], sh);
-        X[pid * P.nout + k] = xs + sh;
+        for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + c], u[c], xs);
+        X[pid] = xs + sh0;
+    } else {
+        for (int k = 0; k < P.nout; k++) {
+            double xs = 0.0, sh = C[P.ox0 + k];
+#pragma unroll
+            for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
+            for (int t = 0; t < nth; t++) sh = __builtin_fma(C[P.oXth + k * nth + t], th[t], sh);
+            X[pid * P.nout + k] = xs + sh;
+        }
     }
     exitflag[pid] = flag;
     if (iters) iters[pid] = iter;
@@ -385,7 +415,7 @@ __device__ __forceinline__ void lane_solve(
     }
 }
 
-template <int N>
+template <int N, int MS>
 __global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
     const long long idx = base + tid;
     if (idx >= cnt) continue;
     const long long pid = list ? (long long)list[idx] : idx;
-    lane_solve<N>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm);
+    lane_solve<N, MS>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm);
   }   // chunk loop
 }
 
