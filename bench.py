@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
+    ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
@@ -134,6 +135,9 @@ def main():
     if args.no_screen:
         for q_ in qps:
             q_.set_option("screen", 0)
+    if args.ablate:
+        for q_ in qps:
+            q_.set_option("ablate", args.ablate)
     n_local = args.batch
     theta_h = make_theta(name, n_local, 1234 + rank, hard)
     theta = torch.from_numpy(theta_h).to(dev)

@@ -52,6 +52,7 @@ struct lmpc_handle {
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
     bool useWave = false, forceWave = false;
+    int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     WaveLayout W{};
     double *dCw = nullptr;
     int32_t *dSw = nullptr;
@@ -100,6 +101,13 @@ void fill_layout(lmpc_handle *h) {
     L.oRout = o; o += P.nout * N;
     L.ox0 = o; o += P.nout;
     L.oXth = o; o += P.nout * P.nth;
+    L.nthp = P.nth <= 8 ? 8 : (P.nth <= 16 ? 16 : 32);
+    o = (o + 7) & ~7;                                  // 64-byte aligned rows for wide scalar loads
+    const int mp = (P.m + 3) & ~3;                     // rows padded to a multiple of four
+    L.oDthP = o; o += mp * L.nthp;
+    L.oBnd = o; o += 2 * mp;
+    o = (o + 7) & ~7;
+    L.oXthP = o; o += P.nout * L.nthp;
     h->nC = (size_t)o;
     L.imm_mask = 0; L.eq_mask = 0;
     for (int j = 0; j < P.m && j < 64; j++) {
@@ -186,6 +194,19 @@ int finalize_handle(lmpc_handle *h) {
         for (int c = 0; c < P.n; c++) buf[L.oRout + k * N + c] = P.Rout[(size_t)k * P.n + c];
     for (int k = 0; k < P.nout; k++) buf[L.ox0 + k] = P.x0[k];
     if (P.nout * P.nth) std::memcpy(&buf[L.oXth], P.Xth.data(), sizeof(double) * P.Xth.size());
+    if (P.nth <= 32) {
+        for (int j = 0; j < P.m; j++) {
+            for (int t = 0; t < P.nth; t++) buf[L.oDthP + j * L.nthp + t] = P.Dth[(size_t)j * P.nth + t];
+            buf[L.oBnd + 2 * j] = P.du0[j];
+            buf[L.oBnd + 2 * j + 1] = P.dl0[j];
+        }
+        for (int j = P.m; j < ((P.m + 3) & ~3); j++) {  // padding rows: never violated
+            buf[L.oBnd + 2 * j] = 1e300;
+            buf[L.oBnd + 2 * j + 1] = -1e300;
+        }
+        for (int k = 0; k < P.nout; k++)
+            for (int t = 0; t < P.nth; t++) buf[L.oXthP + k * L.nthp + t] = P.Xth[(size_t)k * P.nth + t];
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMalloc(&h->dC, sizeof(double) * (h->nC ? h->nC : 1)));
     HIP_TRY(h, hipMemcpy(h->dC, buf.data(), sizeof(double) * h->nC, hipMemcpyHostToDevice));
@@ -196,12 +217,20 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
     return sizeof(double) * ((size_t)P.m * N + lmpc_tri(P.m) + 2 * (size_t)P.m + (size_t)P.m * B);
 }
 
+// capacity of one work-list segment: the problems of all screening workgroups with the same
+// (blockIdx % kShards), each covering kScreenTPB tiles of 256
+long long lane_seg_cap(long long nprob) {
+    const long long ntiles = (nprob + 255) / 256;
+    const long long nblocks = (ntiles + kScreenTPB - 1) / kScreenTPB;
+    return (nblocks + kShards - 1) / kShards * kScreenTPB * 256;
+}
+
 template <int N, int MS>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
                 const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
     auto kern = lane_kernel<N, MS>;
-    const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
+    const long long segCap = lane_seg_cap(nprob);
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     unsigned grid = (unsigned)((nprob + B - 1) / B);
@@ -224,11 +253,12 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
                   int32_t *iters, uint64_t *active, int32_t *count, hipStream_t st) {
     const int B = 256;
     const size_t lds = sizeof(double) * (size_t)B * (h->P.nth ? h->P.nth : 1);
-    const unsigned grid = (unsigned)((nprob + B - 1) / B);
+    const long long ntiles = (nprob + B - 1) / B;
+    const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const int vec16 = ((uintptr_t)theta % 16u) == 0;
-    const long long segCap = (long long)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
+    const long long segCap = lane_seg_cap(nprob);
     hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
-                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, vec16);
+                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, vec16, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -299,7 +329,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     if (screened && nprob > h->listCap) {
         hipFree(h->dList); hipFree(h->dCount);
         h->dList = h->dCount = nullptr; h->listCap = 0;
-        const size_t segCap = (size_t)((nprob + 255) / 256 + kShards - 1) / kShards * 256;
+        const size_t segCap = (size_t)lane_seg_cap(nprob);
         HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
         HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 2 * kShards * kCountStride));
         HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 2 * kShards * kCountStride, st));
@@ -624,6 +654,7 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
 int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "wave") == 0) {
         if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
         if (!value && h->laneN == 0) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
