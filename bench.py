@@ -52,6 +52,9 @@ def make_theta(name, n, seed, hard=False):
         return np.ascontiguousarray(np.hstack([x, r, np.zeros((n, 1)), rng.uniform(-2, 2, (n, 1))]))
     if name == "mass_spring":
         return np.ascontiguousarray(rng.uniform(-4, 4, (n, 12)))
+    if name == "soft_doc":      # docs example with soft output bounds (reference docs/src/manual/simple.md:60-83)
+        return np.ascontiguousarray(np.hstack([rng.uniform(-1, 2, (n, 2)), rng.uniform(0, 1, (n, 2)),
+                                               rng.uniform(-3, 3, (n, 1))]))
     raise ValueError(name)
 
 
@@ -93,7 +96,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring"])
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "soft_doc"])
+    ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
@@ -135,6 +139,9 @@ def main():
     if args.no_screen:
         for q_ in qps:
             q_.set_option("screen", 0)
+    if args.wave:
+        for q_ in qps:
+            q_.set_option("wave", 1)
     if args.ablate:
         for q_ in qps:
             q_.set_option("ablate", args.ablate)
@@ -235,7 +242,8 @@ def main():
             "config": {"workload": f"{args.workload}: "
                        + ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 "
                           "(n=5 vars, 5 two-sided input bounds, theta=[x;r;u_prev] nth=7), "
-                          if name == "pendulum" else "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), ")
+                          if name == "pendulum" else ("mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), "
+                                                      if name == "mass_spring" else f"{name} (n={qp.n}, m={qp.m}, nth={qp.nth}), "))
                        + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
                        "batch_per_gpu": n_local, "kernel": qp.kernel_name, "batches_in_flight": nstreams,
                        "gather": "all_gather(x, exitflag) over RCCL, overlapped" if do_gather else "none",

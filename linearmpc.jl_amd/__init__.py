@@ -13,6 +13,8 @@ from ._cabi import LIB_PATH, SYMBOLS, LmpcError, Settings, default_settings, lib
 from .solver import BatchedQP, transform  # noqa: F401
 from .mpc import MPC, MPQP  # noqa: F401
 from .shard import gather_shards, shard_bounds, shard_counts, solve_sharded  # noqa: F401
+from . import explicit  # noqa: F401
 
 __all__ = ["BatchedQP", "transform", "MPC", "MPQP", "Settings", "default_settings", "LmpcError",
-           "gather_shards", "shard_bounds", "shard_counts", "solve_sharded", "lib", "LIB_PATH", "SYMBOLS"]
+           "gather_shards", "shard_bounds", "shard_counts", "solve_sharded", "explicit", "lib", "LIB_PATH",
+           "SYMBOLS"]

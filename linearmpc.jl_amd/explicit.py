@@ -1,0 +1,102 @@
+"""Sampling-based discovery of explicit-MPC critical regions on top of the batched solve.
+
+The reference builds explicit controllers with ParametricDAQP's exact region enumeration
+(/root/reference/src/explicit.jl:23-48, a third-party solver that never calls `solve`).  What the
+batched backend can contribute is the data-parallel part: solve the condensed QP on a large sample
+of the parameter range (`ParameterRange`, /root/reference/src/types.jl:184-224 ->
+`range2region` utils.jl:285-289), collect the distinct optimal active sets (one per critical
+region that the sample hit) and derive each region's affine control law from the KKT system of
+that active set.  This is a candidate generator, NOT a replacement for exact enumeration: regions
+the sample misses are not found, and no region boundaries are certified.
+
+Everything here is host-side bookkeeping around `BatchedQP.solve`; the solve itself is the HIP path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def sample_range(lb, ub, n, seed=0):
+    """Uniform sample of the box [lb, ub] (zero-width coordinates stay fixed)."""
+    lb = np.asarray(lb, float).reshape(-1)
+    ub = np.asarray(ub, float).reshape(-1)
+    rng = np.random.default_rng(seed)
+    return np.ascontiguousarray(lb + (ub - lb) * rng.random((int(n), lb.size)))
+
+
+def unique_active_sets(active, exitflag=None):
+    """Distinct active-set masks among the solved problems.
+
+    Returns (masks (R x words uint64), counts (R), first_index (R)) sorted by decreasing count."""
+    active = np.ascontiguousarray(np.asarray(active, np.uint64).reshape(len(active), -1))
+    idx = np.arange(active.shape[0])
+    if exitflag is not None:
+        idx = idx[np.asarray(exitflag) >= 1]
+    if idx.size == 0:
+        return np.zeros((0, active.shape[1]), np.uint64), np.zeros(0, int), np.zeros(0, int)
+    masks, first, counts = np.unique(active[idx], axis=0, return_index=True, return_counts=True)
+    order = np.argsort(-counts, kind="stable")
+    return masks[order], counts[order], idx[first[order]]
+
+
+def mask_to_sets(mask, m):
+    """(upper-active rows, lower-active rows) of one mask (bit j upper, bit m+j lower)."""
+    mask = np.asarray(mask, np.uint64).reshape(-1)
+    bit = lambda b: (int(mask[b >> 6]) >> (b & 63)) & 1
+    return [j for j in range(m) if bit(j)], [j for j in range(m) if bit(m + j)]
+
+
+def affine_law(H, f, f_theta, A, bu, bl, W, mask, nout=None):
+    """U*(theta) = Fz theta + gz on the critical region whose active set is `mask`.
+
+    KKT of  min 1/2 U'HU + (f + f_theta th)'U  s.t.  E U = e + Wa th  (active rows at their bound):
+        [H E'; E 0] [U; lam] = [-(f + f_theta th); e + Wa th]."""
+    H = np.asarray(H, float)
+    n = H.shape[0]
+    f_theta = np.asarray(f_theta, float).reshape(n, -1)
+    nth = f_theta.shape[1]
+    bu = np.asarray(bu, float).reshape(-1)
+    bl = np.asarray(bl, float).reshape(-1)
+    m = bu.size
+    A = np.asarray(A, float).reshape(-1, n)
+    ms = m - A.shape[0]
+    Afull = np.vstack([np.eye(n)[:ms], A])
+    W = np.asarray(W, float).reshape(m, nth)
+    up, lo = mask_to_sets(mask, m)
+    rows = up + lo
+    E = Afull[rows]
+    e = np.concatenate([bu[up], bl[lo]])
+    Wa = W[rows]
+    k = len(rows)
+    KKT = np.block([[H, E.T], [E, np.zeros((k, k))]])
+    rhs_th = np.vstack([-f_theta, Wa])
+    rhs_0 = np.concatenate([-np.asarray(f, float).reshape(n), e])
+    sol_th = np.linalg.solve(KKT, rhs_th)
+    sol_0 = np.linalg.solve(KKT, rhs_0)
+    nout = n if nout is None else nout
+    return sol_th[:nout], sol_0[:nout]
+
+
+def discover_regions(solve_fn, theta, group=None):
+    """Distinct optimal active sets over a parameter sample, optionally merged across ranks.
+
+    solve_fn(theta) -> (x, exitflag, iters, active) is `BatchedQP.solve` of a handle on this rank's
+    GPU; with `group` given (torch.distributed) every rank passes ITS shard of the sample, the
+    per-rank unique masks are all-gathered (a few kB) and de-duplicated on every rank -- the sample
+    grid shards across the GPUs of a node exactly like any other batch."""
+    x, ef, it, act = solve_fn(theta)
+    masks, counts, first = unique_active_sets(act, ef)
+    solved = int(np.sum(np.asarray(ef) >= 1))
+    if group is not None:
+        import torch.distributed as dist
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, (masks, counts, solved), group=group)
+        allm = np.concatenate([g[0] for g in gathered if len(g[0])], 0) if any(len(g[0]) for g in gathered) \
+            else masks
+        allc = np.concatenate([g[1] for g in gathered if len(g[0])]) if any(len(g[0]) for g in gathered) else counts
+        um, inv = np.unique(allm, axis=0, return_inverse=True)
+        uc = np.bincount(inv.reshape(-1), weights=allc, minlength=len(um)).astype(int)
+        order = np.argsort(-uc, kind="stable")
+        masks, counts, first = um[order], uc[order], None
+        solved = sum(g[2] for g in gathered)
+    return {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved}

@@ -58,3 +58,40 @@ def test_sharded_gather_equals_single_process(tmp_path, n_total):
         assert np.array_equal(np.load(tmp_path / f"X{r}.npy"), X)
         assert np.array_equal(np.load(tmp_path / f"ef{r}.npy"), ef)
     assert np.array_equal(np.load(tmp_path / "Xroot.npy"), X)
+
+
+def _region_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import linearmpc_jl_amd as lmpc
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
+    theta = lmpc.explicit.sample_range(lb, ub, 20000, seed=3)
+    lo, hi = lmpc.shard_bounds(len(theta), world, rank)
+    out = lmpc.explicit.discover_regions(lambda th: oldp.solve_batch(L, th), theta[lo:hi], group=dist.group.WORLD)
+    np.save(os.path.join(out_dir, f"masks{rank}.npy"), out["masks"])
+    np.save(os.path.join(out_dir, f"counts{rank}.npy"), out["counts"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_region_discovery_equals_single_process(tmp_path):
+    import linearmpc_jl_amd as lmpc
+    from oracle import ldp as oldp
+    world = 2
+    mp.spawn(_region_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
+    theta = lmpc.explicit.sample_range(lb, ub, 20000, seed=3)
+    ref = lmpc.explicit.discover_regions(lambda th: oldp.solve_batch(L, th), theta)
+    key = lambda M, c: sorted((tuple(r), int(k)) for r, k in zip(M.tolist(), c.tolist()))
+    for r in range(world):
+        assert key(np.load(tmp_path / f"masks{r}.npy"), np.load(tmp_path / f"counts{r}.npy")) == \
+            key(ref["masks"], ref["counts"])

@@ -346,3 +346,19 @@ def test_closed_loop_simulation_soft_problem_wave_kernel(lmpc):
         out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
         assert np.array_equal(out["flag_min"], ref["flag_min"])
         assert np.abs(out["U"] - ref["U"]).max() <= TOL and np.abs(out["X"] - ref["X"]).max() <= TOL
+
+
+def test_region_discovery_on_gpu(lmpc):
+    # config 4 of BASELINE.json on one GPU: sample the example's +-20 ParameterRange
+    # (/root/reference/src/mpc_examples.jl:128-134), batched solve, distinct active sets
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0])
+    ub = np.array([20.0] * 4 + [20.0, 0.0] + [2.0])
+    theta = lmpc.explicit.sample_range(lb, ub, 500000, seed=1)
+    out = lmpc.explicit.discover_regions(qp.solve, theta)
+    assert out["n_solved"] == 500000 and 44 <= len(out["masks"]) <= 243
+    i = int(out["first_index"][3])
+    Fz, gz = lmpc.explicit.affine_law(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], out["masks"][3])
+    x, ef, _, act = qp.solve(theta[i][None])
+    assert np.array_equal(act[0], out["masks"][3]) and np.abs(Fz @ theta[i] + gz - x[0]).max() < 1e-8

@@ -116,3 +116,30 @@ def test_shard_bounds(lmpc):
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1 and sizes == lmpc.shard_counts(n, w)
+
+
+def test_region_discovery_bookkeeping(lmpc):
+    # sampling-based critical-region discovery, host logic driven by the oracle here.
+    # With 5 box-constrained moves there are at most 3^5 optimal active sets; on the example's +-20
+    # range ~48 of them are ever optimal (the count saturates: 43 @6e4, 45 @5e5, 48 @3e6 samples).
+    # (The "> 100" of /root/reference/test/runtests.jl:199-204 counts ASCertain's partition by
+    # active-set SEQUENCE, a different object.)
+    from conftest import oracle_ldp_from
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0])
+    ub = np.array([20.0] * 4 + [20.0, 0.0] + [2.0])
+    theta = lmpc.explicit.sample_range(lb, ub, 60000, seed=1)
+    assert theta.shape == (60000, 7) and np.all(theta[:, 5] == 0.0)
+    out = lmpc.explicit.discover_regions(lambda th: oldp.solve_batch(L, th), theta)
+    assert 40 <= len(out["masks"]) <= 243 and out["counts"].sum() == out["n_solved"] == 60000
+    assert out["counts"][0] >= out["counts"][-1]
+    # the affine law of a region reproduces the implicit solution inside it
+    # (explicit == implicit, /root/reference/test/runtests.jl:178-183, :319, :381 to 1e-10)
+    X, ef, it, act = oldp.solve_batch(L, theta[:400])
+    for i in range(0, 400, 7):
+        Fz, gz = lmpc.explicit.affine_law(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], act[i])
+        assert np.abs(Fz @ theta[i] + gz - X[i]).max() < 1e-8
+    up, lo = lmpc.explicit.mask_to_sets(np.array([0b0000100010], np.uint64), 5)
+    assert up == [1] and lo == [0]
