@@ -120,11 +120,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # test hooks (single-GPU box): LMPC_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # LMPC_BENCH_BACKEND=gloo swaps RCCL for gloo so the N > 1 control flow can be exercised there
+    if os.environ.get("LMPC_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("LMPC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     name = "pendulum" if args.workload.startswith("pendulum") else args.workload
     hard = args.workload == "pendulum_hard"
