@@ -11,8 +11,7 @@ into the dense multi-parametric QP
 exactly the way the reference builds it on the Julia host, so that the fixtures
 fed to the HIP path are the matrices a LinearMPC.jl user would hand over.  Only
 the features the benchmark/known-answer problems exercise are restated (no
-preview modes, no move blocking, no prestabilising feedback K, no binaries,
-no operating-point offsets).  Reference lines followed, all under
+preview modes, no move blocking, no binaries, no operating-point offsets).  Reference lines followed, all under
 /root/reference/src/:
 
     zoh                     utils.jl:291-295
@@ -95,6 +94,22 @@ class MPCProblem:
     reference_tracking: bool = True
     preprocess: bool = True
     Ts: float = -1.0
+    K: Optional[np.ndarray] = None          # prestabilising feedback u = v - K x (setup.jl:186-199)
+
+    def gain(self):
+        return np.zeros((self.nu, self.nx)) if self.K is None else np.asarray(self.K, float).reshape(self.nu, self.nx)
+
+    def set_prestabilizing_feedback(self, K=None):
+        """setup.jl:186-199: given K, or the infinite-horizon LQR gain from the discrete Riccati
+        equation with weights C'QC and R+Rr (`ared`)."""
+        if K is None:
+            from scipy.linalg import solve_discrete_are
+            Qx = self.C.T @ self.Q @ self.C
+            Ru = self.R + self.Rr
+            Pm = solve_discrete_are(self.F, self.G, Qx, Ru)
+            K = np.linalg.solve(Ru + self.G.T @ Pm @ self.G, self.G.T @ Pm @ self.F)
+        self.K = np.asarray(K, float).reshape(self.nu, self.nx)
+        return self
 
     @property
     def nx(self):
@@ -173,27 +188,32 @@ def state_predictor(F, G, Np, Nc):
 
 
 def extended_system(p: MPCProblem):
-    """mpc2mpqp.jl:649-690 with K = 0, no disturbance, no offsets."""
+    """mpc2mpqp.jl:649-690, no disturbance, no offsets."""
     nx, nr, _, nuprev, _ = p.parameter_dims()
     nu, ny = p.nu, p.ny
-    F, G, C = p.F.copy(), p.G.copy(), p.C.copy()
+    K = p.gain()
+    F, G, C = p.F - p.G @ K, p.G.copy(), p.C.copy()
     if nr > 0:                                   # reference rides along as constant states
         F = block_diag(F, np.eye(ny))
         G = np.vstack([G, np.zeros((ny, nu))])
         C = np.hstack([C, -np.eye(ny)])
     if nuprev > 0:                               # previous input as a state, du as an output
         F = block_diag(F, np.zeros((nu, nu)))
+        F[-nu:, :nx] = -K
         G = np.vstack([G, np.eye(nu)])
         nye, nxe = C.shape
         C = np.vstack([np.hstack([C, np.zeros((nye, nu))]),
-                       np.hstack([np.zeros((nu, nxe)), np.eye(nu)])])
+                       np.hstack([K, np.zeros((nu, nxe - nx)), np.eye(nu)])])
+    if np.any(p.R != 0) and np.any(K != 0):      # u'Ru with u = v - Kx: K x becomes an output (:679-681)
+        C = np.vstack([C, np.hstack([K, np.zeros((nu, C.shape[1] - nx))])])
     return F, G, C
 
 
 def extended_cost(p: MPCProblem):
-    """mpc2mpqp.jl:692-731 with K = 0.  Returns Q, R, S, Qf of the extended system."""
+    """mpc2mpqp.jl:692-731.  Returns Q, R, S, Qf of the extended system."""
     nx, nr, _, nuprev, _ = p.parameter_dims()
     nu, ny = p.nu, p.ny
+    K = p.gain()
     Q, R, Rr = p.Q.copy(), p.R.copy(), p.Rr.copy()
     Qf = Q.copy()                                # Qf, Qfx unset => terminal weight = Q (:694)
     S = np.zeros((nx, nu))
@@ -203,7 +223,12 @@ def extended_cost(p: MPCProblem):
         Q = block_diag(Q, Rr)
         Qf = block_diag(Qf, np.zeros((nu, nu)))
         S = np.vstack([S, -Rr])
+        S[:nx] -= K.T @ Rr
         R = R + Rr
+    if np.any(R != 0) and np.any(K != 0):        # :718-724
+        Q = block_diag(Q, p.R)
+        Qf = block_diag(Qf, np.zeros((nu, nu)))
+        S[:nx] -= K.T @ p.R
     return Q, R, S, Qf
 
 
@@ -240,10 +265,17 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
     nxe = nx + nr + nd + nuprev
     n = Gam.shape[1]
     if p.umax.size:
-        # create_controlbounds, K = 0 branch (:220-226)
-        A = np.zeros((0, n))
+        # create_controlbounds (:206-245): with K = 0 simple bounds on U, otherwise general rows
+        # (I - Kfull Gam) V <= b + Kfull Phi x0  for u_k = v_k - K x_k
+        K = p.gain()
         bu, bl = np.tile(p.umax, Nc), np.tile(p.umin, Nc)
-        W = np.zeros((Nc * nu, nxe))
+        if np.any(K != 0):
+            Kfull = np.kron(np.eye(Nc), np.hstack([K, np.zeros((nu, nxe - nx))]))
+            A = np.eye(Nc * nu) - Kfull @ Gam[:Nc * nxe, :Nc * nu]
+            W = Kfull @ Phi[:Nc * nxe]
+        else:
+            A = np.zeros((0, n))
+            W = np.zeros((Nc * nu, nxe))
         soft = np.zeros(n, bool)
         prio = np.zeros(n, int)
     else:
@@ -260,7 +292,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             sel = [k - 1 for k in ks]
             pad = np.zeros((mi, nxe - nx))
             Au_rows.append(np.kron(eyeU[sel], c.Au))
-            Ax_rows.append(np.kron(eyeX[sel], np.hstack([c.Ax, pad])))
+            Ax_rows.append(np.kron(eyeX[sel], np.hstack([c.Ax - c.Au @ p.gain(), pad])))
             ubs.append(np.tile(c.ub, len(ks)))
             lbs.append(np.tile(c.lb, len(ks)))
             softs.append(np.full(mi * len(ks), c.soft))
@@ -431,6 +463,16 @@ def preprocessing_kat() -> MPCProblem:
     p = make_mpc(F, G, np.eye(2), Np=10, umin=[-1.0], umax=[1.0], Ts=0.1)
     p.add_constraint(Au=[[-1.0]], lb=[-0.9], ub=[1.5], ks=range(1, 11))
     p.add_constraint(Au=[[1.0]], lb=[-0.5], ub=[2.0], ks=range(1, 11))
+    return p
+
+
+def prestab_kat(prestabilize: bool) -> MPCProblem:
+    """test/runtests.jl:119-136 (K2): unstable double-integrator-like plant, |u| <= 1, Np = 30; the
+    nominal controller and the one with LQR prestabilising feedback give the same input."""
+    F, G = zoh(np.array([[0, 1.0], [10, 0]]), np.array([[0.0], [1.0]]), 0.1)
+    p = make_mpc(F, G, np.eye(2), Np=30, umin=[-1.0], umax=[1.0], Ts=0.1)
+    if prestabilize:
+        p.set_prestabilizing_feedback()
     return p
 
 

@@ -15,6 +15,8 @@ mask.  Before anything is written the answers are cross-checked by independent m
     (scipy.optimize.linprog) of every "infeasible" answer;
   * soft_doc: the documentation's worked example with soft output bounds, known answer u = -1
     (/root/reference/docs/src/manual/simple.md:98-107);
+  * prestab: K2, nominal and LQR-prestabilised controllers give the same input
+    (/root/reference/test/runtests.jl:119-136);
   * preprocessing: the reference's K4 known answer (/root/reference/test/runtests.jl:1306-1318).
 
 Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
@@ -143,6 +145,21 @@ def main():
     nsoft = int(np.sum((q.senses & 8) != 0))
     assert nsoft > 0 and np.any(ef == 2)
     save("soft_doc", q, L, theta, X, ef, it, act, dict(K8_x=[0.5, 1.0], K8_u=-1.0))
+
+    # ---- K2: prestabilising feedback (test/runtests.jl:119-136): same input as the nominal controller
+    pn, pp = omm.prestab_kat(False), omm.prestab_kat(True)
+    qn, qq = omm.mpc2mpqp(pn), omm.mpc2mpqp(pp)
+    Ln = oldp.qp2ldp(qn.H, qn.f, qn.f_theta, qn.A, qn.bu, qn.bl, qn.W, qn.senses, nout=1)
+    Lp = oldp.qp2ldp(qq.H, qq.f, qq.f_theta, qq.A, qq.bu, qq.bl, qq.W, qq.senses, nout=1, K=pp.gain())
+    theta = np.hstack([rng.uniform(-0.2, 0.2, (255, 2)), rng.uniform(-1, 1, (255, 1)), np.zeros((255, 1))])
+    theta = np.vstack([omm.form_parameter(pn, [0.0, 0.0], r=[1.0, 0.0])[None], theta])
+    Xn, efn, _, _ = oldp.solve_batch(Ln, theta)
+    X, ef, it, act = oldp.solve_batch(Lp, theta)
+    assert efn[0] == 1 and ef[0] == 1 and abs(Xn[0, 0] - X[0, 0]) < 1e-10          # runtests.jl:134
+    assert np.linalg.cond(qq.H) < np.linalg.cond(qn.H)                             # runtests.jl:135
+    both = (efn >= 1) & (ef >= 1)
+    assert np.abs(Xn[both] - X[both]).max() < 1e-8
+    save("prestab", qq, Lp, theta, X, ef, it, act, dict(K=pp.gain(), u_nominal=Xn[:, 0], ef_nominal=efn))
 
     # ---- K4: preprocessing folds Au-only rows into the simple bounds
     q = omm.mpc2mpqp(omm.preprocessing_kat())

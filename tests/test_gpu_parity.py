@@ -362,3 +362,26 @@ def test_region_discovery_on_gpu(lmpc):
     Fz, gz = lmpc.explicit.affine_law(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], out["masks"][3])
     x, ef, _, act = qp.solve(theta[i][None])
     assert np.array_equal(act[0], out["masks"][3]) and np.abs(Fz @ theta[i] + gz - x[0]).max() < 1e-8
+
+
+def test_K2_prestabilising_feedback_through_c_abi(lmpc):
+    # /root/reference/test/runtests.jl:119-136; u = U*[1:nu] - K x (reference src/utils.jl:48-49)
+    from oracle import mpc2mpqp as omm
+    g = load_golden("prestab")
+    K = g["K"]
+    pn = omm.prestab_kat(False)
+    qn = omm.mpc2mpqp(pn)
+    nominal = lmpc.MPC(lmpc.MPQP(qn.H, qn.f, qn.f_theta, qn.A, qn.bu, qn.bl, qn.W, qn.senses), nx=2, nu=1, nr=2)
+    prestab = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                       nx=2, nu=1, nr=2, K=K)
+    unom = nominal.compute_control([0.0, 0.0], r=[1.0, 0.0])
+    upre = prestab.compute_control([0.0, 0.0], r=[1.0, 0.0])
+    assert np.linalg.norm(unom - upre) < 1e-10
+    assert prestab.opt_model.kernel_name == "wave" and prestab.opt_model.ms == 0      # bounds are general rows
+    # batched path with K folded into the output map, against the oracle on the same pack
+    cm = prestab.control_model()
+    x, ef, it, act = _compare(cm, g["theta"])
+    ok = (ef >= 1) & (g["ef_nominal"] >= 1)
+    assert np.abs(x[ok, 0] - g["u_nominal"][ok]).max() < 1e-8
+    U, efb = prestab.compute_control_batch(g["theta"][:, :2], R=g["theta"][:, 2:4], check=False)
+    assert np.array_equal(U, x) and np.array_equal(efb, ef)

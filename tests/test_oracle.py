@@ -94,7 +94,7 @@ def test_K8_doc_example_with_soft_output_bounds():
     assert ef[0] == 2
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc", "prestab"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -187,3 +187,18 @@ def test_K6_closed_loop_cold_equals_warm():
     assert abs(cold["U"][0, 0, 0] - 1.7612519326) < 1e-6          # first move of scenario 0 is K1
     assert np.abs(cold["U"]).max() <= 2 + 1e-6                     # |u| <= 2 along the whole run
     assert abs(cold["x"][0, 1]) < 0.5 * abs(x0[0, 1])              # the cart is being braked
+
+
+def test_K2_prestabilising_feedback_equals_nominal():
+    # /root/reference/test/runtests.jl:119-136: |u_nom - u_prestab| < 1e-10 at x = 0, r = [1, 0] and the
+    # prestabilised Hessian is better conditioned; with K != 0 the input bounds become general rows
+    pn, pp = omm.prestab_kat(False), omm.prestab_kat(True)
+    qn, qq = omm.mpc2mpqp(pn), omm.mpc2mpqp(pp)
+    assert (qn.ms, qq.ms, qq.m, qq.n) == (30, 0, 30, 30)
+    assert np.linalg.cond(qq.H) < np.linalg.cond(qn.H)
+    Ln = oldp.qp2ldp(qn.H, qn.f, qn.f_theta, qn.A, qn.bu, qn.bl, qn.W, qn.senses, nout=1)
+    Lp = oldp.qp2ldp(qq.H, qq.f, qq.f_theta, qq.A, qq.bu, qq.bl, qq.W, qq.senses, nout=1, K=pp.gain())
+    th = omm.form_parameter(pn, [0.0, 0.0], r=[1.0, 0.0])[None]
+    un, efn, _, _ = oldp.solve_batch(Ln, th)
+    up, efp, _, _ = oldp.solve_batch(Lp, th)
+    assert efn[0] == 1 and efp[0] == 1 and abs(un[0, 0] - up[0, 0]) < 1e-10
