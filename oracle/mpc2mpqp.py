@@ -75,6 +75,7 @@ class GeneralConstraint:
     ks: Sequence[int]
     soft: bool = False
     prio: int = 0
+    Ap: Optional[np.ndarray] = None      # generalised-parameter term  + Ap p_k  (types.jl:11)
 
 
 @dataclass
@@ -95,6 +96,14 @@ class MPCProblem:
     preprocess: bool = True
     Ts: float = -1.0
     K: Optional[np.ndarray] = None          # prestabilising feedback u = v - K x (setup.jl:186-199)
+    Eu: Optional[np.ndarray] = None         # affine input cost (Eu p + eu)'u_k  (setup.jl:136-150)
+    eu: Optional[np.ndarray] = None
+
+    def np_base(self):
+        """utils.jl:207-216 get_affine_parameter_base_dim (largest column count among Eu / Ap)."""
+        dims = [0 if self.Eu is None else np.atleast_2d(self.Eu).shape[1]]
+        dims += [0 if c.Ap is None else np.atleast_2d(c.Ap).shape[1] for c in self.constraints]
+        return max(dims)
 
     def gain(self):
         return np.zeros((self.nu, self.nx)) if self.K is None else np.asarray(self.K, float).reshape(self.nu, self.nx)
@@ -127,9 +136,9 @@ class MPCProblem:
     def parameter_dims(self):
         nr = self.ny if self.reference_tracking else 0
         nuprev = self.nu if np.any(self.Rr != 0) else 0
-        return self.nx, nr, 0, nuprev, 0
+        return self.nx, nr, 0, nuprev, self.np_base()
 
-    def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0):
+    def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0, Ap=None):
         """setup.jl:57-79 add_constraint! (default ks = 2:Np, missing side = +-1e30)."""
         lb = np.atleast_1d(np.asarray(lb, float))
         ub = np.atleast_1d(np.asarray(ub, float))
@@ -141,7 +150,8 @@ class MPCProblem:
         Ax = np.zeros((m, self.nx)) if Ax is None else np.atleast_2d(np.asarray(Ax, float))
         Au = np.zeros((m, self.nu)) if Au is None else np.atleast_2d(np.asarray(Au, float))
         ks = list(range(2, self.Np + 1)) if ks is None else list(ks)
-        self.constraints.append(GeneralConstraint(Ax, Au, lb, ub, ks, soft, prio))
+        Ap = None if Ap is None else np.atleast_2d(np.asarray(Ap, float))
+        self.constraints.append(GeneralConstraint(Ax, Au, lb, ub, ks, soft, prio, Ap))
 
 
 def make_mpc(F, G, C=None, Np=10, Nc=None, Q=None, R=None, Rr=None, umin=(), umax=(),
@@ -255,12 +265,24 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         H = H + GS + GS.T
         f_theta = f_theta + Stot.T @ Phi
     f = np.zeros(H.shape[0])
+    # generalised-parameter cost on the inputs (mpc2mpqp.jl:478-508): f += Umap' eu, f_theta gets
+    # one column block Umap' (Eu stacked) for p (constant over the horizon, no preview)
+    npb = p.np_base()
+    Umap = np.kron(np.vstack([np.eye(Nc), np.zeros((N - Nc, Nc))]), np.eye(p.nu))
+    if p.eu is not None:
+        f = f + Umap.T @ np.tile(np.asarray(p.eu, float).reshape(p.nu), N)
+    if npb > 0:
+        Eu = np.zeros((p.nu, npb)) if p.Eu is None else np.atleast_2d(np.asarray(p.Eu, float))
+        Fp = Umap.T @ np.tile(Eu, (N, 1))
+        f_theta = np.hstack([f_theta, Fp])
+        nthc = H_theta.shape[0]
+        H_theta = np.block([[H_theta, np.zeros((nthc, npb))], [np.zeros((npb, nthc)), np.zeros((npb, npb))]])
     return (H + H.T) / 2, f, f_theta, H_theta
 
 
 def dense_constraints(p: MPCProblem, Phi, Gam):
     """mpc2mpqp.jl:358-402 -> (A, bu, bl, W, issoft, prio); simple bounds first."""
-    nx, nr, nd, nuprev, _ = p.parameter_dims()
+    nx, nr, nd, nuprev, npb = p.parameter_dims()
     nu, Np, Nc = p.nu, p.Np, p.Nc
     nxe = nx + nr + nd + nuprev
     n = Gam.shape[1]
@@ -278,13 +300,15 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             W = np.zeros((Nc * nu, nxe))
         soft = np.zeros(n, bool)
         prio = np.zeros(n, int)
+        if npb > 0:
+            W = np.hstack([W, np.zeros((W.shape[0], npb))])
     else:
         A, bu, bl = np.zeros((0, n)), np.zeros(0), np.zeros(0)
-        W, soft, prio = np.zeros((0, nxe)), np.zeros(0, bool), np.zeros(0, int)
+        W, soft, prio = np.zeros((0, nxe + npb)), np.zeros(0, bool), np.zeros(0, int)
     if p.constraints:
         eyeX = np.eye(Np + 1)
         eyeU = np.vstack([np.eye(Nc), np.zeros((1 + Np - Nc, Nc))])
-        Ax_rows, Au_rows, ubs, lbs, softs, prios = [], [], [], [], [], []
+        Ax_rows, Au_rows, ubs, lbs, softs, prios, Wp_rows = [], [], [], [], [], [], []
         for c in p.constraints:
             mi = c.Au.shape[0]
             kmax = Np + 1 if not np.any(c.Au) else Np
@@ -295,11 +319,17 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             Ax_rows.append(np.kron(eyeX[sel], np.hstack([c.Ax - c.Au @ p.gain(), pad])))
             ubs.append(np.tile(c.ub, len(ks)))
             lbs.append(np.tile(c.lb, len(ks)))
+            if npb > 0:                          # parameter_preview_direct (:125-143): W[:, p] = -Ap
+                Ap = np.zeros((mi, npb)) if c.Ap is None else c.Ap
+                Wp_rows.append(np.tile(-Ap, (len(ks), 1)))
             softs.append(np.full(mi * len(ks), c.soft))
             prios.append(np.full(mi * len(ks), c.prio, int))
         Axt, Aut = np.vstack(Ax_rows), np.vstack(Au_rows)
         A = np.vstack([A, Axt @ Gam + Aut])
-        W = np.vstack([W, -Axt @ Phi])
+        Wg = -Axt @ Phi
+        if npb > 0:
+            Wg = np.hstack([Wg, np.vstack(Wp_rows)])
+        W = np.vstack([W, Wg])
         bu = np.concatenate([bu] + ubs)
         bl = np.concatenate([bl] + lbs)
         soft = np.concatenate([soft] + softs)
@@ -488,10 +518,21 @@ def doc_simple_soft() -> MPCProblem:
     return p
 
 
-def form_parameter(p: MPCProblem, x, r=None, uprev=None):
-    """explicit.jl:54-63: theta = [x; r; d; uprev; p] (d, p empty here; r, uprev default 0)."""
-    nx, nr, _, nuprev, _ = p.parameter_dims()
+def generalized_parameter_kat() -> MPCProblem:
+    """test/runtests.jl:1250-1268 (K3): scalar integrator, cost (Eu p + eu)'u with Eu = -1, eu = -0.1,
+    constraint u + p <= 1 at every step: u = 1.0 for p = 0, u = 0.25 for p = 0.75."""
+    p = make_mpc([[1.0]], [[1.0]], [[1.0]], Np=4, Nc=4, Q=[0.0], R=[1e-6], umin=[0.0], umax=[2.0])
+    p.Eu = np.array([[-1.0]])
+    p.eu = np.array([-0.1])
+    p.add_constraint(Au=[[1.0]], Ap=[[1.0]], ub=[1.0], ks=range(1, 5))
+    return p
+
+
+def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):
+    """explicit.jl:54-63: theta = [x; r; d; uprev; p] (d empty here; r, uprev, p default 0)."""
+    nx, nr, _, nuprev, npb = p.parameter_dims()
     x = np.asarray(x, float).reshape(nx)
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
-    return np.concatenate([x, r, u])
+    pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]
+    return np.concatenate([x, r, u, pp])

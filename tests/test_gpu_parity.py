@@ -385,3 +385,18 @@ def test_K2_prestabilising_feedback_through_c_abi(lmpc):
     assert np.abs(x[ok, 0] - g["u_nominal"][ok]).max() < 1e-8
     U, efb = prestab.compute_control_batch(g["theta"][:, :2], R=g["theta"][:, 2:4], check=False)
     assert np.array_equal(U, x) and np.array_equal(efb, ef)
+
+
+def test_K3_generalized_parameters_through_c_abi(lmpc):
+    # /root/reference/test/runtests.jl:1250-1268: theta = [x; r; p]; u_nom = 1.0 (p = 0), u_tight = 0.25 (p = 0.75)
+    from oracle import mpc2mpqp as omm
+    prob = omm.generalized_parameter_kat()
+    q = omm.mpc2mpqp(prob)
+    mpc = lmpc.MPC(lmpc.MPQP(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses), nx=1, nu=1, nr=1, np_=1)
+    assert mpc.get_parameter_dims() == (1, 1, 0, 0, 1)
+    u_nom = mpc.compute_control([0.0], r=[0.0], p=[0.0])
+    u_tight = mpc.compute_control([0.0], r=[0.0], p=[0.75])
+    assert abs(u_nom[0] - 1.0) < 1e-6 and abs(u_tight[0] - 0.25) < 1e-6
+    rng = np.random.default_rng(2)
+    theta = np.hstack([rng.uniform(-1, 1, (500, 1)), np.zeros((500, 1)), rng.uniform(-0.5, 1.5, (500, 1))])
+    _compare(mpc.opt_model, theta)

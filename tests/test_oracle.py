@@ -202,3 +202,14 @@ def test_K2_prestabilising_feedback_equals_nominal():
     un, efn, _, _ = oldp.solve_batch(Ln, th)
     up, efp, _, _ = oldp.solve_batch(Lp, th)
     assert efn[0] == 1 and efp[0] == 1 and abs(un[0, 0] - up[0, 0]) < 1e-10
+
+
+def test_K3_generalized_parameters_in_constraints():
+    # /root/reference/test/runtests.jl:1250-1268: parameter dims (1,1,0,0,1); u = 1.0 at p = 0, 0.25 at p = 0.75
+    prob = omm.generalized_parameter_kat()
+    assert prob.parameter_dims() == (1, 1, 0, 0, 1)
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    for par, expect in ((0.0, 1.0), (0.75, 0.25)):
+        X, ef, _, _ = oldp.solve_batch(L, omm.form_parameter(prob, [0.0], r=[0.0], par=[par])[None])
+        assert ef[0] == 1 and abs(X[0, 0] - expect) < 1e-6
