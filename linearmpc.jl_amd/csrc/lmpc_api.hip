@@ -263,20 +263,25 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     return LMPC_OK;
 }
 
-template <int MR>
+size_t wave_const_bytes(const HostPack &P) {
+    return sizeof(double) * (2 * (size_t)P.m * P.n + (size_t)P.m * (P.m + 1) / 2);
+}
+
+template <int MR, bool LDSC>
 int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                    int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;
     const size_t perWave = sizeof(double) * (size_t)Wl.cap * Wl.ldc;
     const int nwv = perWave > 40 * 1024 ? 1 : 4;        // wavefronts (problems in flight) per workgroup
-    const size_t lds = perWave * nwv;
-    auto kern = wave_kernel<MR>;
+    const size_t shared = LDSC ? wave_const_bytes(h->P) : 0;
+    const size_t lds = perWave * nwv + shared;
+    auto kern = wave_kernel<MR, LDSC>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int wavesPerCU = (int)(kLdsMax / (perWave ? perWave : 1));
-    if (wavesPerCU > 16) wavesPerCU = 16;
-    if (wavesPerCU < 1) wavesPerCU = 1;
-    long long grid = (long long)h->numCU * ((wavesPerCU + nwv - 1) / nwv);
+    int blocksPerCU = (int)(kLdsMax / (lds ? lds : 1));
+    if (blocksPerCU * nwv > 16) blocksPerCU = 16 / nwv;
+    if (blocksPerCU < 1) blocksPerCU = 1;
+    long long grid = (long long)h->numCU * blocksPerCU;
     const long long need = (nprob + nwv - 1) / nwv;
     if (grid > need) grid = need;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nwv), lds, st, Wl, h->dCw, h->dSw, theta, x, flag,
@@ -298,9 +303,16 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     }
     int rc;
     const int mr = (h->P.m + 63) / 64;
-    if (mr <= 1) rc = launch_wave_mr<1>(h, nprob, theta, x, flag, iters, active, warm, st);
-    else if (mr == 2) rc = launch_wave_mr<2>(h, nprob, theta, x, flag, iters, active, warm, st);
-    else rc = launch_wave_mr<4>(h, nprob, theta, x, flag, iters, active, warm, st);
+    // shared data in LDS when it leaves room for at least two workgroups per CU
+    const size_t perWave = sizeof(double) * (size_t)h->W.cap * h->W.ldc;
+    const int nwv0 = perWave > 40 * 1024 ? 1 : 4;
+    const bool inLds = perWave * nwv0 + wave_const_bytes(h->P) <= kLdsMax / 2;
+#define LMPC_WV(MRR) (inLds ? launch_wave_mr<MRR, true>(h, nprob, theta, x, flag, iters, active, warm, st) \
+                            : launch_wave_mr<MRR, false>(h, nprob, theta, x, flag, iters, active, warm, st))
+    if (mr <= 1) rc = LMPC_WV(1);
+    else if (mr == 2) rc = LMPC_WV(2);
+    else rc = LMPC_WV(4);
+#undef LMPC_WV
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
