@@ -12,6 +12,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # build the native pieces if this checkout has not been built yet (hipcc cross-compiles here)
+    import subprocess
+    lib = os.path.join(ROOT, "linearmpc.jl_amd", "lib", "liblmpc_hip.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "linearmpc.jl_amd", "csrc")], check=True)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
 def load_golden(name):
