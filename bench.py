@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
+    ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
@@ -150,6 +151,9 @@ def main():
     if args.wave:
         for q_ in qps:
             q_.set_option("wave", 1)
+    if args.lane_per:
+        for q_ in qps:
+            q_.set_option("lane_per", args.lane_per)
     if args.ablate:
         for q_ in qps:
             q_.set_option("ablate", args.ablate)
@@ -207,6 +211,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    enqueue_s = time.perf_counter() - t0          # host time to issue all steps (diagnostic)
     drain()
     fence()
     elapsed = time.perf_counter() - t0
@@ -260,7 +265,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
                          "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
-                         "duration_used_ms": dur_ms,
+                         "duration_used_ms": dur_ms, "host_enqueue_ms_per_step": 1e3 * enqueue_s / max(args.steps, 1),
                          "algorithmic_bytes_per_solve": bytes_per},
         }
         if world == 1 and not args.no_cpu_baseline:

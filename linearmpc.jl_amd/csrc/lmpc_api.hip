@@ -52,6 +52,7 @@ struct lmpc_handle {
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
     bool useWave = false, forceWave = false;
+    int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     WaveLayout W{};
     double *dCw = nullptr;
@@ -237,8 +238,15 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
     // with a work list the counts are only known on the device: a fixed grid (a multiple of the
     // shard count) strides over each segment
     if (list) {
+        // ... sized to ONE resident round (workgroups with nothing to do still cost a count load
+        // before they can exit): what the register budget keeps on the chip, spread over the shards
+        const unsigned wavesPerSimd = (N <= 5) ? 3u : 1u;
+        const unsigned resident = (unsigned)h->numCU * (wavesPerSimd * 4u * 64u / (unsigned)B);
         unsigned per = (unsigned)((segCap + B - 1) / B);
-        if (per > 32u) per = 32u;
+        unsigned cap = resident / (unsigned)kShards;
+        if (h->lanePer > 0) cap = (unsigned)h->lanePer;
+        if (cap < 1u) cap = 1u;
+        if (per > cap) per = cap;
         if (per < 1u) per = 1u;
         grid = per * (unsigned)kShards;
     }
@@ -667,6 +675,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
+    if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "wave") == 0) {
         if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
         if (!value && h->laneN == 0) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
