@@ -240,7 +240,7 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
     if (list) {
         // ... sized to ONE resident round (workgroups with nothing to do still cost a count load
         // before they can exit): what the register budget keeps on the chip, spread over the shards
-        const unsigned wavesPerSimd = (N <= 5) ? 3u : 1u;
+        const unsigned wavesPerSimd = (N <= 5) ? (unsigned)LMPC_LANE_WAVES : 1u;
         const unsigned resident = (unsigned)h->numCU * (wavesPerSimd * 4u * 64u / (unsigned)B);
         unsigned per = (unsigned)((segCap + B - 1) / B);
         unsigned cap = resident / (unsigned)kShards;
@@ -337,7 +337,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     for (int B : {256, 128, 64}) {
         const size_t lds = lane_lds_bytes(h->P, h->laneN, B);
         if (lds > kLdsMax) continue;
-        int blocks = (int)(kLdsMax / lds);
+        int blocks = (int)(kLdsMax / (lds ? lds : 1));
         int waves = blocks * (B / 64);
         if (waves > 32) waves = 32;
         if (waves > bestWaves) { bestWaves = waves; bestB = B; bestLds = lds; }

@@ -23,6 +23,10 @@
 
 #include "lmpc_pack.hpp"
 
+#ifndef LMPC_LANE_WAVES
+#define LMPC_LANE_WAVES 3   // wavefronts per SIMD the small lane kernels are register-budgeted for
+#endif
+
 namespace lmpc {
 
 // Offsets (in doubles) of the constant arrays inside the single device buffer.
@@ -418,7 +422,7 @@ __device__ __forceinline__ void lane_solve(
 }
 
 template <int N, int MS>
-__global__ __launch_bounds__(256, (N <= 5 ? 3 : 1)) void lane_kernel(
+__global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,

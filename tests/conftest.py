@@ -30,11 +30,12 @@ def oracle_ldp_from(pk):
     from oracle import ldp as oldp
     M = np.asarray(pk["M"], float)
     m, n = M.shape
-    Dth = np.asarray(pk["Dth"], float).reshape(m, -1)
+    nth = int(pk["nth"]) if "nth" in pk else (np.asarray(pk["Dth"]).size // m if m else np.asarray(pk["Xth"]).shape[-1])
+    Dth = np.asarray(pk["Dth"], float).reshape(m, nth)
     Rout = np.asarray(pk["Rout"], float).reshape(-1, n)
     sense = np.asarray(pk["sense"] if "sense" in pk else pk["senses"], np.int32)
     ms = int(pk["ms"]) if "ms" in pk else 0
-    return oldp.LDP(n, m, ms, Dth.shape[1], Rout.shape[0], M, np.asarray(pk["du"], float),
+    return oldp.LDP(n, m, ms, nth, Rout.shape[0], M, np.asarray(pk["du"], float),
                     np.asarray(pk["dl"], float), Dth, Rout, np.asarray(pk["x0"], float),
                     np.asarray(pk["Xth"], float).reshape(Rout.shape[0], -1), sense, np.ones(m)).contiguous()
 

@@ -400,3 +400,48 @@ def test_K3_generalized_parameters_through_c_abi(lmpc):
     rng = np.random.default_rng(2)
     theta = np.hstack([rng.uniform(-1, 1, (500, 1)), np.zeros((500, 1)), rng.uniform(-0.5, 1.5, (500, 1))])
     _compare(mpc.opt_model, theta)
+
+
+def test_unconstrained_and_wide_parameter_problems(lmpc):
+    rng = np.random.default_rng(21)
+    # (a) no constraints at all (reference "Unconstrained" testset, test/runtests.jl:1327-1335):
+    #     every problem is optimal after one iteration, x = -H^-1 f_theta theta
+    n, nth = 4, 3
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + n * np.eye(n)
+    f_theta = rng.standard_normal((n, nth))
+    qp = lmpc.BatchedQP.from_mpqp(H, np.zeros(n), f_theta, np.zeros((0, n)), np.zeros(0), np.zeros(0),
+                                  np.zeros((0, nth)), None)
+    theta = rng.uniform(-3, 3, (700, nth))
+    x, ef, it, act = _compare(qp, theta)
+    assert np.all(ef == 1) and np.all(it == 1)
+    assert np.abs(x + theta @ np.linalg.solve(H, f_theta).T).max() < 1e-10
+    # (b) a parameter vector longer than the screening pass covers (nth > 32, e.g. reference preview
+    #     over the horizon): the iterating kernel alone handles the batch
+    n, mg, nth = 6, 10, 40
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, 0.2 * f_theta, A, bu, bl, 0.1 * W, sense, nout=2)
+    assert "lane" in qp.kernel_name
+    theta = rng.uniform(-1, 1, (900, nth))
+    x, ef, it, act = _compare(qp, theta)
+    assert (ef == 1).mean() > 0.5 and it.max() > 1
+    # (c) outputs that are not requested may be NULL
+    x2, ef2, it2, act2 = qp.solve(theta, want_iters=False, want_active=False)
+    assert it2 is None and act2 is None and np.array_equal(x2, x) and np.array_equal(ef2, ef)
+    # (d) kernel-selection switches do not change a bit
+    qp.set_option("screen", 0)
+    x3, ef3, _, _ = qp.solve(theta)
+    assert np.array_equal(x3, x) and np.array_equal(ef3, ef)
+    with pytest.raises(lmpc.LmpcError):
+        qp.set_option("no_such_option", 1)
+
+
+def test_unsupported_shapes_are_refused_loudly(lmpc):
+    rng = np.random.default_rng(22)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 70, 10, 3)       # n > 63
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
+    assert e.value.code == -103
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 8, 300, 3)       # m > 256
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
+    assert e.value.code == -103
