@@ -143,7 +143,8 @@ def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None):
     """Solve every row of theta (N x nth).  Returns X (N x nout), exitflag, iters, active."""
     L = lib()
     ldp.contiguous()
-    theta = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, ldp.nth))
+    theta = np.asarray(theta, np.float64)
+    theta = np.ascontiguousarray(theta.reshape(-1, ldp.nth) if ldp.nth else theta.reshape(len(theta), 0))
     N = theta.shape[0]
     nw = active_words(ldp.m)
     X = np.empty((N, ldp.nout))

@@ -445,3 +445,30 @@ def test_unsupported_shapes_are_refused_loudly(lmpc):
     with pytest.raises(lmpc.LmpcError) as e:
         lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
     assert e.value.code == -103
+
+
+@pytest.mark.parametrize("n,mg,kernel", [(6, 58, "lane"), (6, 59, "wave"), (12, 52, "lane"), (13, 3, "wave"),
+                                         (20, 236, "wave"), (2, 1, "lane")])
+def test_size_boundaries_between_kernels(lmpc, n, mg, kernel):
+    # m = 64 is the last size the lane kernel's one-word masks cover, n = 12 its largest instantiation,
+    # m = 256 the wavefront kernel's limit
+    rng = np.random.default_rng(100 + n + mg)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, 4)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 3 * bu, 3 * bl, 0.2 * W, sense, nout=min(n, 3))
+    assert kernel in qp.kernel_name and qp.m == n + mg
+    theta = rng.uniform(-2, 2, (300, 4))
+    x, ef, it, act = _compare(qp, theta)
+    ok = ef >= 1
+    if ok.sum() > 4:
+        _compare(qp, theta[ok][:64], warm=act[ok][:64])
+
+
+def test_problem_without_parameters(lmpc):
+    # nth = 0: a plain QP solved N times (theta has no columns)
+    rng = np.random.default_rng(31)
+    n, mg = 5, 4
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, 0)
+    f = rng.standard_normal(n) * 3
+    qp = lmpc.BatchedQP.from_mpqp(H, f, np.zeros((n, 0)), A, bu, bl, np.zeros((n + mg, 0)), sense)
+    x, ef, it, act = _compare(qp, np.zeros((130, 0)))
+    assert np.all(ef == ef[0]) and np.all(x == x[0])
