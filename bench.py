@@ -8,8 +8,11 @@
 One "step" = one pass of the hot path (lmpc_solve_batch_device: constraint shift, dual
 active-set solve, primal recovery) over one batch of 1e6 synthetic parameter points per GPU,
 already resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 1e6-point
-shard (weak scaling) and the per-shard solutions + exit flags are all-gathered over RCCL/xGMI;
-the gather of step k runs on RCCL's stream underneath the solve of step k+1.  Consecutive steps are
+shard (weak scaling).  The solve needs no data-path collective: shards are independent and their
+results stay on the GPU that produced them; the one exchange step -- an RCCL all-gather of the
+solutions and exit flags over xGMI -- happens once, after the last step, inside the timed region
+(--gather step does it after every step, overlapped with the next solve; at 12 MB per rank and
+step that exchange is ~10x longer than the 30 us solve it follows, so it is not the default).  Consecutive steps are
 independent batches; by default three of them are kept in flight on three HIP streams (each with
 its own solver handle), which lets the streaming pass of one batch overlap the latency-bound
 iterating pass of another (--streams 1 serialises them).
@@ -100,7 +103,9 @@ def main():
     ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather (diagnostic)")
+    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
+                    help="N > 1: RCCL all-gather of x and exit flags once after the last step (default), "
+                         "after every step (overlapped with the next solve), or never")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
@@ -165,7 +170,11 @@ def main():
     nbuf = max(2, nstreams)
     xbuf = [torch.empty((n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
     fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    do_gather = world > 1 and not args.no_gather
+    do_gather = world > 1 and args.gather == "step"
+    final_gather = world > 1 and args.gather == "final"
+    if final_gather:
+        xfin = torch.empty((world * n_local, nout), dtype=torch.float64, device=dev)
+        ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev)
     if do_gather:
         xall = [torch.empty((world * n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
         fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
@@ -213,6 +222,12 @@ def main():
         step(k)
     enqueue_s = time.perf_counter() - t0          # host time to issue all steps (diagnostic)
     drain()
+    if final_gather and args.steps:
+        # the one exchange step of the sharded job: every rank receives all shards' solutions
+        torch.cuda.synchronize(dev)
+        lastb = (args.steps - 1) % nbuf
+        dist.all_gather_into_tensor(xfin, xbuf[lastb])
+        dist.all_gather_into_tensor(ffin, fbuf[lastb])
     fence()
     elapsed = time.perf_counter() - t0
     prof = [q_.profile_read() for q_ in qps]
@@ -259,7 +274,9 @@ def main():
                                                       if name == "mass_spring" else f"{name} (n={qp.n}, m={qp.m}, nth={qp.nth}), "))
                        + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
                        "batch_per_gpu": n_local, "kernel": qp.kernel_name, "batches_in_flight": nstreams,
-                       "gather": "all_gather(x, exitflag) over RCCL, overlapped" if do_gather else "none",
+                       "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
+                                  else "all_gather(x, exitflag) over RCCL once, after the last step" if final_gather
+                                  else "none"),
                        "solved_fraction": float((flags >= 1).mean()) if flags.size else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
