@@ -226,11 +226,11 @@ long long lane_seg_cap(long long nprob) {
     return (nblocks + kShards - 1) / kShards * kScreenTPB * 256;
 }
 
-template <int N, int MS>
+template <int N, int MS, int MA>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
                 const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
-    auto kern = lane_kernel<N, MS>;
+    auto kern = lane_kernel<N, MS, MA>;
     const long long segCap = lane_seg_cap(nprob);
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -378,11 +378,12 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
     const int32_t *list = screened ? h->dList : nullptr;
     const int32_t *count = cnt_now;
-    // box-constrained problems (m == n == N) get the instantiation with the row scans unrolled
-    const bool boxed = h->P.m == h->laneN && h->P.n == h->laneN;
+    // problems whose constraints are exactly the n simple bounds (ms == m == n == N) get the
+    // instantiation with the row scans unrolled and the working-set capacity cut to N
+    const bool boxed = h->P.m == h->laneN && h->P.n == h->laneN && h->P.ms == h->P.m;
     if (rc == LMPC_OK) switch (h->laneN) {
-#define LMPC_CASE(NN) case NN: rc = boxed ? launch_lane<NN, NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
-                                          : launch_lane<NN, 0>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
+#define LMPC_CASE(NN) case NN: rc = boxed ? launch_lane<NN, NN, NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
+                                          : launch_lane<NN, 0, NN + 1>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
