@@ -260,13 +260,12 @@ template <int NTHMAX>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, int32_t *count, hipStream_t st) {
     const int B = 256;
-    const size_t lds = sizeof(double) * (size_t)B * (h->P.nth ? h->P.nth : 1);
+    const size_t lds = 0;
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
-    const int vec16 = ((uintptr_t)theta % 16u) == 0;
     const long long segCap = lane_seg_cap(nprob);
     hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
-                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, vec16, h->ablate);
+                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }

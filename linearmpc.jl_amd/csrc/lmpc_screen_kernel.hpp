@@ -5,9 +5,9 @@
 // thing it does is look for a violated row of  dl + b <= 0 <= du + b  (b = Dth theta).  If there is
 // none the problem is optimal after that one iteration and x = x0 + Xth theta.  In MPC batches
 // this is the common case (a controller near its set-point), so it gets its own kernel: a few
-// dozen VGPRs, full occupancy, theta tiles staged through LDS with 16-byte coalesced loads, every
-// constant read through the scalar cache -- it runs at HBM speed and leaves the register-heavy
-// iterating kernel a dense list of the problems that actually need iterations.
+// dozen VGPRs, high occupancy, every constant read through the scalar cache -- it streams theta
+// once and leaves the register-heavy iterating kernel a dense list of the problems that actually
+// need iterations.
 //
 // The arithmetic is the same as the first iteration of lane_kernel / the CPU oracle (same fma
 // chains, same comparisons), so which kernel finishes a problem does not change a single bit.
@@ -20,81 +20,58 @@
 
 namespace lmpc {
 
-// TPB consecutive tiles per workgroup: the loads of tile t+1 are issued (into registers) before tile
-// t is screened, so a workgroup's HBM round trips overlap its own arithmetic instead of every
-// resident workgroup alternating between "all loading" and "all computing" in lock-step.
-constexpr int kScreenTPB = 4;
+// Each lane walks kScreenTPB problems (strided by the workgroup size; the record of the next one is
+// loaded into registers before the current one is screened).  Records are read straight from HBM,
+// one 8-byte load per parameter: lane i reads record i, so the 64 lanes of a load touch 64*8*nth
+// contiguous bytes over the nth loads -- every fetched line is used completely.  Measured at 10^6
+// pendulum points: kScreenTPB = 1 / 2 / 4 / 8 -> 18.1 / 19.3 / 20.5 / 24.4 us, and a variant that
+// staged 16-byte coalesced tiles through LDS (two barriers per tile) 22.9 us: at this batch size
+// the pass is two rounds of resident wavefronts, more wavefronts in flight beat fewer, longer ones.
+#ifndef LMPC_SCREEN_TPB
+#define LMPC_SCREEN_TPB 1
+#endif
+constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 
 template <int NTHMAX>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, int32_t *__restrict__ list, int32_t *__restrict__ count,
-    long long seg_cap, int nshards, long long nprob, int vec16, int ablate) {
-    constexpr int R2 = NTHMAX / 2;                     // 16-byte pieces of a tile per thread
-    extern __shared__ __align__(16) double tile[];     // B records of nth doubles, as in HBM
+    long long seg_cap, int nshards, long long nprob, int ablate) {
     const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
-    const long long ntiles = (nprob + B - 1) / B;
-    const long long tile0 = (long long)blockIdx.x * kScreenTPB;
+    const long long first = (long long)blockIdx.x * kScreenTPB * B + tid;
     const double ntol = -P.primal_tol;
     const int lane = tid & 63;
     const int shard = blockIdx.x % nshards;
 
-    double2 pf[R2];
-#define LMPC_PREFETCH_TILE(TIX)                                                                  \
-    {                                                                                             \
-        const long long bp_ = (TIX) * B;                                                          \
-        const int nv_ = (nprob - bp_) < (long long)B ? (int)(nprob - bp_) : B;                    \
-        const int n2_ = (nv_ * nth) >> 1;                                                         \
-        const double2 *s2_ = reinterpret_cast<const double2 *>(theta + bp_ * nth);                \
-        _Pragma("unroll") for (int r = 0; r < R2; r++) {                                          \
-            const int i_ = tid + r * B;                                                           \
-            pf[r] = (i_ < n2_) ? s2_[i_] : make_double2(0.0, 0.0);                                \
-        }                                                                                         \
-    }
-    if (vec16 && tile0 < ntiles && !(ablate & 8)) LMPC_PREFETCH_TILE(tile0)
-    else {
+    double nx[NTHMAX];                                 // record of the problem after the current one
+    auto load_record = [&](long long pid, double *dst) {
+        const double *src = theta + pid * nth;
+        const bool ok = pid < nprob;
 #pragma unroll
-        for (int r = 0; r < R2; r++) pf[r] = make_double2(0.0, 0.0);
-    }
+        for (int t = 0; t < NTHMAX; t++) dst[t] = (ok && t < nth) ? src[t] : 0.0;
+    };
+    load_record(first, nx);
 
-    // list write of the previous tile, held back so that its atomic's round trip (the longest single
-    // latency in a wave's life) runs underneath the next tile's screening
+    // list write of the previous problem, held back so that its atomic's round trip runs underneath
+    // the next problem's screening
     unsigned long long pmask = 0ull;
     int pbase = 0;
     long long ppid = 0;
     bool phard = false;
 
     for (int it = 0; it < kScreenTPB; it++) {
-        const long long tix = tile0 + it;
-        if (tix >= ntiles) break;                      // uniform over the workgroup
-        const long long bp = tix * B;
-        const int nvalid = (nprob - bp) < (long long)B ? (int)(nprob - bp) : B;
-        const int elems = nvalid * nth;
-        const double *src = theta + bp * nth;
-        if (vec16) {
-            double2 *t2 = reinterpret_cast<double2 *>(tile);
-#pragma unroll
-            for (int r = 0; r < R2; r++) {
-                const int i = tid + r * B;
-                if (i < (elems >> 1)) t2[i] = pf[r];
-            }
-            if ((elems & 1) && tid == 0) tile[elems - 1] = src[elems - 1];
-        } else {
-            for (int i = tid; i < elems; i += B) tile[i] = src[i];
-        }
-        __syncthreads();
-        if (vec16 && it + 1 < kScreenTPB && tix + 1 < ntiles && !(ablate & 8)) LMPC_PREFETCH_TILE(tix + 1)
-
-        const bool valid = tid < nvalid;
-        const long long pid = bp + tid;
+        const long long pid = first + (long long)it * B;
+        if (pid - tid >= nprob) break;                 // uniform over the workgroup
+        const bool valid = pid < nprob;
         double th[NTHMAX];
 #pragma unroll
-        for (int t = 0; t < NTHMAX; t++) th[t] = (valid && t < nth) ? tile[tid * nth + t] : 0.0;
+        for (int t = 0; t < NTHMAX; t++) th[t] = nx[t];
+        if (it + 1 < kScreenTPB) load_record(pid + B, nx);
 
         bool hard = false;
         // rows of Dth zero-padded to NTHMAX columns (theta is zero-padded in registers): a fixed,
-        // guard-free fma chain per row and one wide scalar load; the padded terms add +0 exactly
+        // guard-free fma chain per row and one wide scalar load; the padded terms add +0 exactly.
         // Four rows per trip (the row count is padded to a multiple of four with rows that can never
         // be violated), so four independent fma chains are in flight instead of one.
         const double *dj = C + P.oDthP;
@@ -145,8 +122,6 @@ __global__ __launch_bounds__(256) void screen_kernel(
             if (active)
                 for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;
         }
-
-        __syncthreads();                               // tile is rewritten by the next round
     }
     if (pmask != 0ull) {
         const int pb = __shfl(pbase, 0);
@@ -154,7 +129,5 @@ __global__ __launch_bounds__(256) void screen_kernel(
             list[(long long)shard * seg_cap + pb + __popcll(pmask & ((1ull << lane) - 1ull))] = (int32_t)ppid;
     }
 }
-
-#undef LMPC_PREFETCH_TILE
 
 }  // namespace lmpc
