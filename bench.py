@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
+    ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
@@ -159,6 +160,9 @@ def main():
     if args.lane_per:
         for q_ in qps:
             q_.set_option("lane_per", args.lane_per)
+    if args.lane_block:
+        for q_ in qps:
+            q_.set_option("lane_block", args.lane_block)
     if args.ablate:
         for q_ in qps:
             q_.set_option("ablate", args.ablate)

@@ -52,6 +52,7 @@ struct lmpc_handle {
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
     bool useWave = false, forceWave = false;
+    int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     WaveLayout W{};
@@ -340,6 +341,10 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         int waves = blocks * (B / 64);
         if (waves > 32) waves = 32;
         if (waves > bestWaves) { bestWaves = waves; bestB = B; bestLds = lds; }
+    }
+    if (h->laneBlock > 0 && lane_lds_bytes(h->P, h->laneN, h->laneBlock) <= kLdsMax) {
+        bestB = h->laneBlock;
+        bestLds = lane_lds_bytes(h->P, h->laneN, h->laneBlock);
     }
     if (!bestB) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: constant pack does not fit in LDS");
     // Cold starts without initially-active rows go through the screening pass first.
@@ -676,6 +681,12 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
+    if (std::strcmp(name, "lane_block") == 0) {
+        if (value != 0 && value != 64 && value != 128 && value != 256)
+            return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");
+        h->laneBlock = value;
+        return LMPC_OK;
+    }
     if (std::strcmp(name, "wave") == 0) {
         if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
         if (!value && h->laneN == 0) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
