@@ -53,7 +53,7 @@ def make_theta(name, n, seed, hard=False):
             x = rng.uniform([-5, -5, -0.3, -2], [5, 5, 0.3, 2], (n, 4))
             r = rng.uniform(-5, 5, (n, 1))
         return np.ascontiguousarray(np.hstack([x, r, np.zeros((n, 1)), rng.uniform(-2, 2, (n, 1))]))
-    if name == "mass_spring":
+    if name in ("mass_spring", "mass_spring_3in"):
         return np.ascontiguousarray(rng.uniform(-4, 4, (n, 12)))
     if name == "soft_doc":      # docs example with soft output bounds (reference docs/src/manual/simple.md:60-83)
         return np.ascontiguousarray(np.hstack([rng.uniform(-1, 2, (n, 2)), rng.uniform(0, 1, (n, 2)),
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "soft_doc"])
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc"])
     ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -314,7 +314,7 @@ __device__ __forceinline__ void lane_solve(
                 if (fval > P.fval_bound) { flag = EXIT_INFEASIBLE; break; }
                 double min_val = -P.primal_tol;
                 int add = -1;
-                bool addlow = false;
+                bool addlow = false, broken = false;
                 auto scan_row = [&](int j) {
                     if (!((P.imm_mask >> j) & 1ull)) {
                         double Mu = 0.0;
@@ -326,6 +326,8 @@ __device__ __forceinline__ void lane_solve(
                         if (!((act >> j) & 1ull)) {
                             if (vu < min_val) { add = j; addlow = false; min_val = vu; }
                             else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+                        } else if (vu < -P.primal_tol || vl < -P.primal_tol) {
+                            broken = true;      // the iterate violates a row of its own working set
                         }
                     }
                 };
@@ -335,7 +337,7 @@ __device__ __forceinline__ void lane_solve(
                 } else {
                     for (int j = 0; j < m; j++) scan_row(j);
                 }
-                if (add < 0) { flag = EXIT_OPTIMAL; break; }
+                if (add < 0) { flag = broken ? EXIT_CYCLE : EXIT_OPTIMAL; break; }
                 if (MA < N + 1 && na >= MA) { flag = EXIT_CYCLE; break; }   // cannot happen for pure bounds
 #pragma unroll
                 for (int i = 0; i < MA; i++) lam[i] = ls[i];

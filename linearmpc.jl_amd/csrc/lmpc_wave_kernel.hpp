@@ -308,20 +308,26 @@ __global__ __launch_bounds__(256) void wave_kernel(
                     }
                     double mval = -P.primal_tol;
                     int midx = -1;
+                    bool broken = false;
 #pragma unroll
                     for (int r = 0; r < MR; r++) {
                         const int j = lane + 64 * r;
-                        if (j < m && !(sense[r] & SENSE_IMMUTABLE) && !((actb >> r) & 1u)) {
+                        if (j < m && !(sense[r] & SENSE_IMMUTABLE)) {
                             const double vu = (C[P.odu + j] + b[r]) - Mu[r];
                             const double vl = -((C[P.odl + j] + b[r]) - Mu[r]);
-                            if (vu < mval) { mval = vu; midx = 2 * j; }
-                            else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
+                            if (!((actb >> r) & 1u)) {
+                                if (vu < mval) { mval = vu; midx = 2 * j; }
+                                else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
+                            } else if (!(sense[r] & SENSE_SOFT) && (vu < -P.primal_tol || vl < -P.primal_tol)) {
+                                broken = true;  // the iterate violates a hard row of its own working set
+                            }
                         }
                     }
                     wv_argmin(mval, midx);
                     midx = __builtin_amdgcn_readfirstlane(midx);
                     if (midx < 0) {
-                        flag = (soft_slack > P.primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
+                        if (__ballot(broken) != 0ull) flag = EXIT_CYCLE;
+                        else flag = (soft_slack > P.primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
                         break;
                     }
                     lam = ls;

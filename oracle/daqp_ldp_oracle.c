@@ -338,21 +338,28 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
                 if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
                 /* most violated constraint, primal_tol margin */
                 double min_val = -s->primal_tol;
-                int add = -1, isupper = 0;
+                int add = -1, isupper = 0, broken = 0;
                 for (int j = 0; j < m; j++) {
-                    if (w->sense[j] & (SENSE_ACTIVE | SENSE_IMMUTABLE)) continue;
+                    if (w->sense[j] & SENSE_IMMUTABLE) continue;
                     const double *mj = &p->M[(size_t)j * n];
                     double Mu = 0.0;
                     for (int k = 0; k < n; k++) Mu = fma(mj[k], w->u[k], Mu);
                     const double vu = w->dupper[j] - Mu;
-                    if (vu < min_val) { add = j; isupper = 1; min_val = vu; }
-                    else {
-                        const double vl = -(w->dlower[j] - Mu);
-                        if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
+                    const double vl = -(w->dlower[j] - Mu);
+                    if (w->sense[j] & SENSE_ACTIVE) {
+                        /* a hard row of the working set sits ON its bound in exact arithmetic; if the
+                         * iterate violates it by more than primal_tol the factorisation has broken
+                         * down (typically an infeasible problem with a nearly dependent working set,
+                         * multipliers ~1e15): never report that as optimal */
+                        if (!(w->sense[j] & SENSE_SOFT) && (vu < -s->primal_tol || vl < -s->primal_tol)) broken = 1;
+                        continue;
                     }
+                    if (vu < min_val) { add = j; isupper = 1; min_val = vu; }
+                    else if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
                 }
                 if (add < 0) {
-                    exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
+                    if (broken) exitflag = EXIT_CYCLE;
+                    else exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
                     break;
                 }
                 for (int i = 0; i < w->na; i++) w->lam[i] = w->lam_star[i];

@@ -487,6 +487,26 @@ def mass_spring(nm=6, Np=10, Nc=10, kappa=1.0, lam=0.0) -> MPCProblem:
     return p
 
 
+def mass_spring_3in(nm=6, Np=10, Nc=10) -> MPCProblem:
+    """BASELINE.json config 3 as worded ("12 states / 3 inputs, Nc=10, ~60 ineq"): the reference's
+    mass_spring example (mpc_examples.jl:241-286) has ONE input, so this is a SYNTHETIC variant of it
+    with forces on masses 1, 3 and 5 (B defined here, everything else as in the example)."""
+    p = mass_spring(nm, Np, Nc)
+    nx = 2 * nm
+    off = np.ones(nm - 1)
+    Fx = np.diag(off, 1) + np.diag(off, -1) - 2 * np.eye(nm)
+    A = np.block([[np.zeros((nm, nm)), np.eye(nm)], [Fx, np.zeros((nm, nm))]])
+    B = np.zeros((nx, 3))
+    for c, mass in enumerate((0, 2, 4)):
+        B[nm + mass, c] = 1.0
+    F, G = zoh(A, B, 0.5)
+    q = make_mpc(F, G, np.eye(nx), Np=Np, Nc=Nc, Q=100 * np.ones(nx), R=[1.0, 1.0, 1.0], Rr=np.zeros(3),
+                 umin=[-0.5] * 3, umax=[0.5] * 3, reference_tracking=False, Ts=0.5)
+    q.add_constraint(Ax=np.hstack([np.eye(nm), np.zeros((nm, nm))]), lb=-4 * np.ones(nm),
+                     ub=4 * np.ones(nm), ks=range(2, Nc + 1))
+    return q
+
+
 def preprocessing_kat() -> MPCProblem:
     """test/runtests.jl:1306-1318 (K4): two Au-only constraints fold into the simple bounds."""
     F, G = zoh(np.array([[0, 1.0], [10, 0]]), np.array([[0.0], [1.0]]), 0.1)

@@ -134,6 +134,22 @@ def main():
             assert not lp_feasible(q, theta[i]), i
     save("mass_spring", q, L, theta, X, ef, it, act)
 
+    # ---- BASELINE config 3 as worded (3 inputs): synthetic variant, n = 30 -> wavefront kernel
+    prob = omm.mass_spring_3in()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = np.vstack([rng.uniform(-4, 4, (192, 12)), rng.uniform(-2, 2, (192, 12)), rng.uniform(-1, 1, (128, 12))])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    nchk = 0
+    for i in range(theta.shape[0]):
+        if ef[i] == 1 and nchk < 120:
+            stat, pf, sg = kkt_residuals(q, theta[i], X[i], act[i])
+            assert stat < 1e-7 and pf < 2e-6 and sg > -1e-8, (i, stat, pf, sg)
+            nchk += 1
+        elif ef[i] == -1 and i % 8 == 0:
+            assert not lp_feasible(q, theta[i]), i
+    save("mass_spring_3in", q, L, theta, X, ef, it, act)
+
     # ---- K8: documentation example with SOFT output bounds (docs/src/manual/simple.md:60-107)
     prob = omm.doc_simple_soft()
     q = omm.mpc2mpqp(prob)

@@ -55,7 +55,7 @@ def test_K1_through_c_abi(lmpc):
     assert flag == 1 and abs(x[0] - 1.7612519326) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat"])
 def test_golden_vectors(lmpc, name):
     g = load_golden(name)
     qp = _qp_from_golden(lmpc, g)
@@ -472,3 +472,25 @@ def test_problem_without_parameters(lmpc):
     qp = lmpc.BatchedQP.from_mpqp(H, f, np.zeros((n, 0)), A, bu, bl, np.zeros((n + mg, 0)), sense)
     x, ef, it, act = _compare(qp, np.zeros((130, 0)))
     assert np.all(ef == ef[0]) and np.all(x == x[0])
+
+
+def test_broken_working_set_is_never_reported_optimal(lmpc):
+    # BASELINE config 3 as worded (3 inputs, n = 30, m = 84 -> wavefront kernel).  Some infeasible
+    # theta drive the dual iterates to ~1e15 through a nearly dependent working set; such a point
+    # must come back with a failure flag, not as "optimal" (every reported optimum satisfies all
+    # hard rows to primal_tol in the normalised constraint space)
+    g = load_golden("mass_spring_3in")
+    qp = _qp_from_golden(lmpc, g)
+    assert qp.kernel_name == "wave" and (qp.n, qp.m) == (30, 84)
+    rng = np.random.default_rng(1234)
+    theta = rng.uniform(-3, 3, (3000, 12))
+    x, ef, it, act = _compare(qp, theta)
+    assert (ef == 1).any() and (ef < 0).any()
+    pk = qp.ldp()
+    Afull = np.vstack([np.eye(30)[:30], g["A"]])
+    ok = np.flatnonzero(ef >= 1)
+    bu = g["bu"][None] + theta[ok] @ g["W"].T
+    bl = g["bl"][None] + theta[ok] @ g["W"].T
+    Ax = x[ok] @ Afull.T
+    scale = np.linalg.norm(Afull @ np.linalg.inv(np.linalg.cholesky(g["H"]).T), axis=1)
+    assert ((Ax - bu) / scale).max() < 1e-5 and ((bl - Ax) / scale).max() < 1e-5

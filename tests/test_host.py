@@ -37,7 +37,7 @@ def test_default_settings_match_reference_docs(lmpc):
         assert getattr(s, name) == getattr(so, name), name
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc"])
 def test_host_transform_matches_oracle_qp2ldp(lmpc, name):
     # library's C++ QP->LDP (lmpc_transform) vs the numpy restatement of codegen.jl:239-280
     g = load_golden(name)

@@ -94,7 +94,7 @@ def test_K8_doc_example_with_soft_output_bounds():
     assert ef[0] == 2
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc", "prestab"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc", "prestab"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -107,7 +107,7 @@ def test_oracle_reproduces_golden(name):
     assert np.abs(X[ok] - g["X"][ok]).max() <= 1e-12
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "preprocessing_kat", "soft_doc"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc"])
 def test_golden_pack_matches_restated_transform(name):
     g = load_golden(name)
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
