@@ -52,6 +52,7 @@ struct lmpc_handle {
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
     bool useWave = false, forceWave = false;
+    int waveLdsLimit = 0;       // tuning: KiB a wave-kernel workgroup may spend to keep M/Mt/G in LDS (0 = 80)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
@@ -314,7 +315,8 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     // shared data in LDS when it leaves room for at least two workgroups per CU
     const size_t perWave = sizeof(double) * (size_t)h->W.cap * h->W.ldc;
     const int nwv0 = perWave > 40 * 1024 ? 1 : 4;
-    const bool inLds = perWave * nwv0 + wave_const_bytes(h->P) <= kLdsMax / 2;
+    const size_t ldsLimit = h->waveLdsLimit > 0 ? (size_t)h->waveLdsLimit * 1024 : kLdsMax / 2;
+    const bool inLds = perWave * nwv0 + wave_const_bytes(h->P) <= ldsLimit;
 #define LMPC_WV(MRR) (inLds ? launch_wave_mr<MRR, true>(h, nprob, theta, x, flag, iters, active, warm, st) \
                             : launch_wave_mr<MRR, false>(h, nprob, theta, x, flag, iters, active, warm, st))
     if (mr <= 1) rc = LMPC_WV(1);
@@ -681,6 +683,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
+    if (std::strcmp(name, "wave_lds_kib") == 0) { h->waveLdsLimit = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");
