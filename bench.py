@@ -250,6 +250,27 @@ def main():
     elapsed = float(t.item())
 
     flags = fbuf[(args.steps - 1) % nbuf].cpu().numpy() if args.steps else np.zeros(0, np.int32)
+    # distribution of the work (untimed extra solve): throughput depends on how many iterations the
+    # batch needs, so the histograms travel with the number
+    it_d = torch.empty(n_local, dtype=torch.int32, device=dev)
+    ac_d = torch.zeros((n_local, qp.words), dtype=torch.int64, device=dev)
+    qp.solve_device(theta, x=xbuf[0], exitflag=fbuf[0], iters=it_d, active=ac_d)
+    torch.cuda.synchronize(dev)
+    it_hist = torch.bincount(it_d.clamp(max=31).to(torch.int64), minlength=2).cpu().tolist()
+    bits = ac_d.cpu().numpy().view(np.uint64)
+    nact = np.zeros(n_local, np.int64)
+    for w_ in range(bits.shape[1]):
+        v_ = bits[:, w_].copy()
+        while v_.any():
+            nact += (v_ & np.uint64(1)).astype(np.int64)
+            v_ >>= np.uint64(1)
+    act_hist = np.bincount(nact, minlength=1).tolist()
+    mean_it = float(it_d.to(torch.float64).mean().item())
+    # algorithmic FP64 work per solve: per iteration the scan 2mn, the primal
+    # step 2|W|n and the triangular solves 2|W|^2 (final |W| as a stand-in), plus the affine maps
+    flop_est = float(np.mean(it_d.cpu().numpy() * (2.0 * qp.m * qp.n) +
+                             it_d.cpu().numpy() * (2.0 * nact * qp.n + 2.0 * nact * nact))
+                     + 2.0 * qp.m * qp.nth + 2.0 * nout * qp.nth)
     if rank == 0:
         total = world * n_local * args.steps
         value = total / elapsed
@@ -285,13 +306,18 @@ def main():
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
                                   else "all_gather(x, exitflag) over RCCL once, after the last step" if final_gather
                                   else "none"),
-                       "solved_fraction": float((flags >= 1).mean()) if flags.size else None},
+                       "solved_fraction": float((flags >= 1).mean()) if flags.size else None,
+                       "iterations_hist": it_hist, "mean_iterations": mean_it,
+                       "active_set_size_hist": act_hist},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
                          "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
                          "duration_used_ms": dur_ms, "host_enqueue_ms_per_step": 1e3 * enqueue_s / max(args.steps, 1),
-                         "algorithmic_bytes_per_solve": bytes_per},
+                         "algorithmic_bytes_per_solve": bytes_per,
+                         "fp64_flop_per_solve_est": flop_est,
+                         "fp64_tflops_est": flop_est * value / 1e12,
+                         "solves_per_s_per_cu": value / world / 256.0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, theta_h, nout)
