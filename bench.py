@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
     ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
     ap.add_argument("--wave-lds-kib", type=int, default=0, help="wave kernel: LDS budget for shared data (tuning)")
+    ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
@@ -161,6 +162,9 @@ def main():
     if args.lane_per:
         for q_ in qps:
             q_.set_option("lane_per", args.lane_per)
+    if args.wave_cap:
+        for q_ in qps:
+            q_.set_option("wave_cap", args.wave_cap)
     if args.wave_lds_kib:
         for q_ in qps:
             q_.set_option("wave_lds_kib", args.wave_lds_kib)

@@ -27,7 +27,7 @@ constexpr size_t kLdsMax = 160 * 1024;
 constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 256;
 constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
-struct EventTriple { hipEvent_t a, mid, b; bool screened; };
+struct EventTriple { hipEvent_t a, mid, b; };
 
 }  // namespace
 
@@ -51,7 +51,8 @@ struct lmpc_handle {
     int countSet = 0;           // which of the two counter sets the next call uses
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
-    bool useWave = false, forceWave = false;
+    bool useWave = false;
+    int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
     int waveLdsLimit = 0;       // tuning: KiB a wave-kernel workgroup may spend to keep M/Mt/G in LDS (0 = 80)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
@@ -141,7 +142,7 @@ int finalize_handle(lmpc_handle *h) {
         return fail(h, LMPC_ERR_UNSUPPORTED,
                     "lmpc: problem outside what the kernels cover (lane: n<=12, m<=64, hard rows; "
                     "wave: n<=63, n+1+#soft<=64, m<=256)");
-    h->useWave = !laneOk || (h->forceWave && waveOk);
+    h->useWave = !laneOk;
     HIP_TRY(h, hipSetDevice(h->device));
     {
         hipDeviceProp_t prop;
@@ -288,7 +289,8 @@ int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocksPerCU = (int)(kLdsMax / (lds ? lds : 1));
-    if (blocksPerCU * nwv > 16) blocksPerCU = 16 / nwv;
+    const int waveCap = h->waveCap > 0 ? h->waveCap : 16;      // wavefronts per CU the persistent grid is sized for
+    if (blocksPerCU * nwv > waveCap) blocksPerCU = waveCap / nwv;
     if (blocksPerCU < 1) blocksPerCU = 1;
     long long grid = (long long)h->numCU * blocksPerCU;
     const long long need = (nprob + nwv - 1) / nwv;
@@ -302,7 +304,6 @@ int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x
 int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                 int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
-    ev.screened = false;
     if (h->prof) {
         HIP_TRY(h, pool_event(h, &ev.a));
         HIP_TRY(h, pool_event(h, &ev.mid));
@@ -363,7 +364,6 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         h->countSet = 0;
     }
     EventTriple ev{};
-    ev.screened = screened;
     if (h->prof) {
         HIP_TRY(h, pool_event(h, &ev.a));
         HIP_TRY(h, pool_event(h, &ev.mid));
@@ -684,6 +684,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "wave_lds_kib") == 0) { h->waveLdsLimit = value; return LMPC_OK; }
+    if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");

@@ -1,4 +1,4 @@
-// One-QP-per-lane dual active-set kernel for small condensed-MPC problems (n <= 12, m <= 64).
+// One-QP-per-lane dual active-set kernel for small condensed-MPC problems (n <= 12, m <= 64, hard rows).
 //
 // Mapping (gfx950): every lane of a 64-wide wavefront owns one parameter point theta and runs the
 // whole dual active-set iteration on it.  The LDL' factor, multipliers and working set of that
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     long long seg_cap, int nshards, long long nprob) {
     extern __shared__ __align__(16) double lds[];
 
-    const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
+    const int m = P.m, B = blockDim.x, tid = threadIdx.x;
     // `list` (from screen_kernel) holds the problems that need iterations, in `nshards` segments of
     // capacity seg_cap with one counter each; block b works on segment b % nshards.  Without a list
     // the kernel walks the whole batch.  Blocks stride over the work so a fixed grid covers any count.

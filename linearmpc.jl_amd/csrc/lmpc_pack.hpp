@@ -39,13 +39,4 @@ int qp_to_ldp(HostPack &P, int n, int m, int ms, int nth, int nout,
 // Fills P.G and P.nsoft from P.M / P.sense; validates shapes.
 int finish_pack(HostPack &P, std::string &err);
 
-// What the kernels receive by value.
-struct DevPack {
-    int n, m, ms, nth, nout, words;
-    const double *M, *G, *du0, *dl0, *Dth, *Rout, *x0, *Xth;
-    const int32_t *sense;
-    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
-    int cycle_tol, iter_limit;
-};
-
 }  // namespace lmpc
