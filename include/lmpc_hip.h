@@ -16,7 +16,10 @@
  *    utils.jl:46):  1 optimal, 2 soft-optimal, -1 infeasible, -2 cycle, -3 unbounded,
  *    -4 iteration limit, -5 non-convex, -6 over-determined initial working set.
  *  - sense bit flags are DAQP's (reference mpc2mpqp.jl:868-885): 1 ACTIVE, 2 LOWER,
- *    4 IMMUTABLE, 5 EQUALITY (=ACTIVE|IMMUTABLE), 8 SOFT, 16 BINARY.
+ *    4 IMMUTABLE, 5 EQUALITY (=ACTIVE|IMMUTABLE), 8 SOFT, 16 BINARY.  A problem with BINARY rows
+ *    (hybrid MPC, mpQP.has_binaries) is solved by branch and bound: every BINARY row ends up
+ *    active at one of its two bounds; the flag is 1 with the best assignment found, -1 if none is
+ *    feasible, -4 if the node limit (100000) was hit; `iters` is the sum over all nodes.
  *  - active-set masks: lmpc_active_words(h) 64-bit words per problem; bit j (0 <= j < m) set
  *    = constraint j active at its UPPER bound, bit m+j set = active at its LOWER bound.
  *  - a handle is bound to one GPU (the `device` given at setup); calls on one handle must not

@@ -52,6 +52,7 @@ struct lmpc_handle {
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
     // general path: one QP per wavefront
     bool useWave = false;
+    bool bnb = false;           // rows flagged BINARY: branch and bound in the wavefront kernel
     int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
     int waveLdsLimit = 0;       // tuning: KiB a wave-kernel workgroup may spend to keep M/Mt/G in LDS (0 = 80)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
@@ -135,7 +136,13 @@ int finalize_handle(lmpc_handle *h) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
     if (h->device < 0 || h->device >= ndev) return fail(h, LMPC_ERR_BADARG, "lmpc: bad device ordinal");
-    const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0;
+    int nBinary = 0;
+    for (int j = 0; j < P.m; j++) nBinary += (P.sense[j] & SENSE_BINARY) ? 1 : 0;
+    const bool anyBinary = nBinary > 0;
+    h->bnb = anyBinary;
+    if (nBinary > 64)    // the B&B stack of a problem lives on the 64 lanes of its wavefront
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: more than 64 binary rows");
+    const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0 && !anyBinary;
     const int cap = P.n + 1 + P.nsoft;
     const bool waveOk = P.n <= kWaveMaxN && cap <= kWaveMaxCap && P.m <= kWaveMaxM && P.m >= 1;
     if (!laneOk && !waveOk)
@@ -277,7 +284,7 @@ size_t wave_const_bytes(const HostPack &P) {
     return sizeof(double) * (2 * (size_t)P.m * P.n + (size_t)P.m * (P.m + 1) / 2);
 }
 
-template <int MR, bool LDSC>
+template <int MR, bool LDSC, bool BNB>
 int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                    int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;
@@ -285,7 +292,7 @@ int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x
     const int nwv = perWave > 40 * 1024 ? 1 : 4;        // wavefronts (problems in flight) per workgroup
     const size_t shared = LDSC ? wave_const_bytes(h->P) : 0;
     const size_t lds = perWave * nwv + shared;
-    auto kern = wave_kernel<MR, LDSC>;
+    auto kern = wave_kernel<MR, LDSC, BNB>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocksPerCU = (int)(kLdsMax / (lds ? lds : 1));
@@ -318,12 +325,14 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     const int nwv0 = perWave > 40 * 1024 ? 1 : 4;
     const size_t ldsLimit = h->waveLdsLimit > 0 ? (size_t)h->waveLdsLimit * 1024 : kLdsMax / 2;
     const bool inLds = perWave * nwv0 + wave_const_bytes(h->P) <= ldsLimit;
-#define LMPC_WV(MRR) (inLds ? launch_wave_mr<MRR, true>(h, nprob, theta, x, flag, iters, active, warm, st) \
-                            : launch_wave_mr<MRR, false>(h, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WV2(MRR, LD) (h->bnb ? launch_wave_mr<MRR, LD, true>(h, nprob, theta, x, flag, iters, active, nullptr, st) \
+                                  : launch_wave_mr<MRR, LD, false>(h, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WV(MRR) (inLds ? LMPC_WV2(MRR, true) : LMPC_WV2(MRR, false))
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
     else rc = LMPC_WV(4);
 #undef LMPC_WV
+#undef LMPC_WV2
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
@@ -693,7 +702,8 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     }
     if (std::strcmp(name, "wave") == 0) {
         if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
-        if (!value && h->laneN == 0) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
+        if (!value && (h->laneN == 0 || h->bnb))
+            return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
         h->useWave = value != 0;
         return LMPC_OK;
     }

@@ -65,7 +65,9 @@ __device__ __forceinline__ void wv_argmin(double &val, int &idx) {
 // (M, M transposed, packed Gram) are staged once per workgroup in LDS behind the per-wave factors
 // (when they fit) -- their reads sit on every iteration's critical path, and an LDS read returns in
 // ~1/8 of the time of an L2 hit.
-template <int MR, bool LDSC>
+// BNB: rows flagged BINARY must end up active at one of their bounds -- depth-first branch and
+// bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
+template <int MR, bool LDSC, bool BNB>
 __global__ __launch_bounds__(256) void wave_kernel(
     const WaveLayout P, const double *__restrict__ C, const int32_t *__restrict__ S,
     const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
@@ -85,12 +87,20 @@ __global__ __launch_bounds__(256) void wave_kernel(
         Mr = sc; Mt = sc + nM; G = sc + 2 * nM;
     }
 
-    int sense[MR];                                   // constraint slots of this lane
-#pragma unroll
+    int sense0[MR], sense[MR];                       // constraint slots of this lane: as given / of the
+#pragma unroll                                       // current solve (a B&B node adds its fixed binaries)
     for (int r = 0; r < MR; r++) {
         const int j = lane + 64 * r;
-        sense[r] = (j < m) ? S[j] : SENSE_IMMUTABLE;
+        sense0[r] = (j < m) ? S[j] : SENSE_IMMUTABLE;
+        sense[r] = sense0[r];
     }
+    // flags of row j (wave-uniform) from the slot that owns it
+    auto sense_of = [&](int j) -> int {
+        int v = 0;
+#pragma unroll
+        for (int r = 0; r < MR; r++) if (r == (j >> 6)) v = sense[r];
+        return __builtin_amdgcn_readlane(v, j & 63);
+    };
 
     for (long long pid = (long long)blockIdx.x * nwv + wv; pid < nprob; pid += (long long)gridDim.x * nwv) {
         const double *th = theta + pid * nth;
@@ -111,6 +121,7 @@ __global__ __launch_bounds__(256) void wave_kernel(
         int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT, nsoft_act = 0;
         double best = -1.0, fval = 0.0, soft_slack = 0.0;
         bool done = false;
+        double fbound = P.fval_bound;            // a B&B node stops as soon as it is dominated
 
         auto Gat = [&](int a, int c) -> double {
             return a >= c ? G[(size_t)a * (a + 1) / 2 + c] : G[(size_t)c * (c + 1) / 2 + a];
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(256) void wave_kernel(
 
         // ---- append constraint j (wave-uniform) to the working set
         auto ldl_add = [&](int j, bool lower) {
-            const int sj = S[j];
+            const int sj = sense_of(j);
             const bool is_soft = (sj & SENSE_SOFT) != 0;
             double q = (lane < na) ? Gat(WSi, j) : 0.0;
             q = sweep_fwd(q);
@@ -240,10 +251,17 @@ __global__ __launch_bounds__(256) void wave_kernel(
             rm = __builtin_amdgcn_readfirstlane(idx);
         };
 
-        // ---- initial working set: rows flagged ACTIVE (equalities), then the caller's warm-start mask
+        // ---- one LDP solve with the flags in sense[] (cold, or warm from the caller's mask)
+        auto solve_node = [&]() {
+        WSi = 0; possoft = 0; posimm = 0; poslow = 0;
+        lam = 0.0; ls = 0.0; rhs = 0.0; D = 0.0; Dinv = 0.0; u = 0.0;
+        actb = 0u; lowb = 0u;
+        na = 0; sing = -1; iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; nsoft_act = 0;
+        best = -1.0; fval = 0.0; soft_slack = 0.0; done = false;
+        // initial working set: rows flagged ACTIVE (equalities, fixed binaries), then the warm-start mask
         for (int j = 0; j < m && !done; j++) {
-            const int sj = S[j];
-            bool want = (sj & SENSE_ACTIVE) != 0, lower = false;
+            const int sj = sense_of(j);
+            bool want = (sj & SENSE_ACTIVE) != 0, lower = want && (sj & SENSE_LOWER) != 0;
             if (warm != nullptr && !(sj & SENSE_IMMUTABLE)) {
                 const uint64_t *wp = warm + pid * P.words;
                 if ((wp[j >> 6] >> (j & 63)) & 1ull) want = true;
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(256) void wave_kernel(
                             }
                     soft_slack = soft;
                     fval = fv + soft;
-                    if (fval > P.fval_bound) { flag = EXIT_INFEASIBLE; break; }
+                    if (fval > fbound) { flag = EXIT_INFEASIBLE; break; }
                     double Mu[MR];
 #pragma unroll
                     for (int r = 0; r < MR; r++) Mu[r] = 0.0;
@@ -354,6 +372,78 @@ __global__ __launch_bounds__(256) void wave_kernel(
                 ldl_remove(rm);
             }
             iter++;
+        }
+        };   // solve_node
+
+        if (!BNB) {
+            solve_node();
+        } else {
+            // depth-first branch and bound; stack entry d lives on lane d
+            int stk_j = 0, stk_side = 0, stk_tried = 0;
+            int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
+            double ubest = 0.0, bestval = P.fval_bound;
+            unsigned bestact = 0u, bestlow = 0u;
+            for (;;) {
+                if (nodes >= 100000) { bflag = EXIT_ITERLIMIT; break; }
+#pragma unroll
+                for (int r = 0; r < MR; r++) sense[r] = sense0[r];
+                for (int d = 0; d < depth; d++) {
+                    const int jf = __builtin_amdgcn_readlane(stk_j, d);
+                    const int sd = __builtin_amdgcn_readlane(stk_side, d);
+                    if (lane == (jf & 63)) {
+#pragma unroll
+                        for (int r = 0; r < MR; r++)
+                            if (r == (jf >> 6)) sense[r] |= SENSE_ACTIVE | SENSE_IMMUTABLE | (sd ? SENSE_LOWER : 0);
+                    }
+                }
+                fbound = bestval;
+                solve_node();
+                nodes++;
+                total_it += iter;
+                bool descend = false;
+                if (flag >= 1) {
+                    // lowest-index binary row that is not in the final working set
+                    int cand = 0x7fffffff;
+#pragma unroll
+                    for (int r = MR - 1; r >= 0; r--) {
+                        const int j = lane + 64 * r;
+                        if (j < m && (sense0[r] & SENSE_BINARY) && !((actb >> r) & 1u)) cand = j;
+                    }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const int o = __shfl_xor(cand, off);
+                        cand = o < cand ? o : cand;
+                    }
+                    const int jb = __builtin_amdgcn_readfirstlane(cand);
+                    if (jb == 0x7fffffff) {              // leaf: every binary sits on a bound
+                        if (!have || fval < bestval) {
+                            have = 1; bestval = fval; ubest = u; bestact = actb; bestlow = lowb;
+                        }
+                    } else {
+                        double Mu = 0.0;
+                        for (int k = 0; k < n; k++) Mu = __builtin_fma(Mr[(size_t)jb * n + k], wv_bcast(u, k), Mu);
+                        double bj = 0.0;
+#pragma unroll
+                        for (int r = 0; r < MR; r++) if (r == (jb >> 6)) bj = b[r];
+                        bj = wv_bcast(bj, jb & 63);
+                        const double dlo = C[P.odl + jb] + bj, dup = C[P.odu + jb] + bj;
+                        const int lower_first = (Mu - dlo) < (dup - Mu) ? 1 : 0;
+                        if (lane == depth) { stk_j = jb; stk_side = lower_first; stk_tried = 1; }
+                        depth++;
+                        descend = true;
+                    }
+                }
+                if (!descend) {                          // backtrack to the next untried side
+                    while (depth > 0 && __builtin_amdgcn_readlane(stk_tried, depth - 1) == 2) depth--;
+                    if (depth == 0) break;
+                    if (lane == depth - 1) { stk_side ^= 1; stk_tried = 2; }
+                }
+            }
+            u = have ? ubest : 0.0;
+            actb = have ? bestact : 0u;
+            lowb = have ? bestlow : 0u;
+            flag = have ? (bflag == EXIT_ITERLIMIT ? EXIT_ITERLIMIT : EXIT_OPTIMAL) : bflag;
+            iter = total_it;
         }
 
         // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k writes output k

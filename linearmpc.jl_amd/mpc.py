@@ -62,8 +62,6 @@ class MPC:
     # setup.jl:7-29
     def setup(self):
         q = self.mpQP
-        if q.has_binaries:
-            raise NotImplementedError("binary constraints (daqp_bnb) are outside the batched path")
         self.opt_model = BatchedQP.from_mpqp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses,
                                              nout=q.H.shape[0], settings=self.settings,
                                              device=self.device)

@@ -281,29 +281,35 @@ static void write_outputs(const work_t *w, const oracle_ldp *p, const double *th
     }
 }
 
-/* One cold- (warm == NULL) or warm-started solve.  Returns the DAQP-style exit flag. */
-static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
-                     const double *theta, const uint64_t *warm, double *xout,
-                     int32_t *iters, uint64_t *active, int nwords) {
-    const int n = p->n, m = p->m, nth = p->nth;
-    int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
-    double best_fval = -1.0;
-
-    /* mpc_update_qp.c:1-10 */
+/* dupper/dlower = du/dl + Dth*theta   (mpc_update_qp.c:1-10) */
+static void shift_bounds(work_t *w, const oracle_ldp *p, const double *theta) {
+    const int m = p->m, nth = p->nth;
     for (int j = 0; j < m; j++) {
         double sh = 0.0;
         for (int t = 0; t < nth; t++) sh = fma(p->Dth[(size_t)j * nth + t], theta[t], sh);
         w->dupper[j] = p->du0[j] + sh;
         w->dlower[j] = p->dl0[j] + sh;
-        w->sense[j] = p->sense[j] & ~SENSE_LOWER;
     }
+}
+
+/* One cold- (warm == NULL) or warm-started LDP solve on the bounds already in w.  sense0[m] are the
+ * constraint flags of THIS solve: rows flagged ACTIVE start in the working set (at their lower
+ * bound if also flagged LOWER) -- equalities, and the binaries a branch-and-bound node has fixed.
+ * Leaves the iterate in w (u, fval, working set) and returns the DAQP-style exit flag. */
+static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, const int32_t *sense0,
+                      const uint64_t *warm, int32_t *iters) {
+    const int n = p->n, m = p->m;
+    int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
+    double best_fval = -1.0;
+
+    for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
     w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
     for (int k = 0; k < n; k++) w->u[k] = 0.0;
 
-    /* initial working set: equality rows (ACTIVE|IMMUTABLE) and, if warm, the given mask */
+    /* initial working set: rows flagged ACTIVE and, if warm, the given mask */
     for (int j = 0; j < m; j++) {
-        int want = (p->sense[j] & SENSE_ACTIVE) != 0, lower = 0;
-        if (warm && !(p->sense[j] & SENSE_IMMUTABLE)) {
+        int want = (sense0[j] & SENSE_ACTIVE) != 0, lower = want && (sense0[j] & SENSE_LOWER);
+        if (warm && !(sense0[j] & SENSE_IMMUTABLE)) {
             if ((warm[j >> 6] >> (j & 63)) & 1) want = 1;
             else if ((warm[(m + j) >> 6] >> ((m + j) & 63)) & 1) { want = 1; lower = 1; }
         }
@@ -311,7 +317,7 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
         if (lower) w->sense[j] |= SENSE_LOWER;
         ldl_add(w, p, s, j);
         if (w->sing >= 0) {
-            if (p->sense[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
+            if (sense0[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
             /* dependent warm-start row: drop it again */
             w->na--; w->sing = -1;
             if (w->sense[j] & SENSE_SOFT) w->nsoft_act--;
@@ -392,9 +398,100 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
         }
     }
 done:
-    write_outputs(w, p, theta, xout, active, nwords);
     if (iters) *iters = iter;
     return exitflag;
+}
+
+static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
+                     const double *theta, const uint64_t *warm, double *xout,
+                     int32_t *iters, uint64_t *active, int nwords) {
+    shift_bounds(w, p, theta);
+    const int ef = solve_core(w, p, s, p->sense, warm, iters);
+    write_outputs(w, p, theta, xout, active, nwords);
+    return ef;
+}
+
+/* Depth-first branch and bound over the rows flagged BINARY (each must end up active at its upper
+ * or at its lower bound), what the reference gets from daqp_bnb ([EXT] libdaqp, called at
+ * /root/reference/codegen/mpc_update_qp.c:40-43 / utils.jl:277-282 when mpQP.has_binaries).
+ * libdaqp's source is not available, so the search order is this file's own (the optimum of a
+ * strictly convex MIQP does not depend on it):
+ *   - a node = a set of binaries fixed to a side; its relaxation is the LDP with those rows as
+ *     active immutable rows, solved from a cold start with fval_bound = incumbent value, so the
+ *     dual iterations stop as soon as the node is dominated;
+ *   - branch on the lowest-index binary row that is not in the relaxation's final working set,
+ *     first to the bound its row value M_j u is closer to, then to the other;
+ *   - a node whose binaries are all active is a leaf; it replaces the incumbent if strictly better.
+ * iters returns the iterations summed over all nodes; the flag is 1 if an incumbent exists,
+ * -1 if none, -4 if the node limit ran out first. */
+#define BNB_NODE_LIMIT 100000
+static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, const double *theta,
+                     double *xout, int32_t *iters, uint64_t *active, int nwords) {
+    const int n = p->n, m = p->m;
+    int32_t *sense = (int32_t *)malloc(sizeof(int32_t) * (m > 0 ? m : 1));
+    int *stk_j = (int *)malloc(sizeof(int) * (m + 1)), *stk_side = (int *)malloc(sizeof(int) * (m + 1)),
+        *stk_tried = (int *)malloc(sizeof(int) * (m + 1));
+    double *ubest = (double *)calloc(n, sizeof(double));
+    uint64_t *abest = (uint64_t *)calloc(nwords > 0 ? nwords : 1, sizeof(uint64_t));
+    oracle_settings sn = *s;
+    double best = s->fval_bound;
+    int have = 0, depth = 0, nodes = 0, total_it = 0, flag = EXIT_INFEASIBLE;
+    shift_bounds(w, p, theta);
+    for (;;) {
+        if (nodes >= BNB_NODE_LIMIT) { flag = EXIT_ITERLIMIT; break; }
+        for (int j = 0; j < m; j++) sense[j] = p->sense[j];
+        for (int d = 0; d < depth; d++)
+            sense[stk_j[d]] |= SENSE_ACTIVE | SENSE_IMMUTABLE | (stk_side[d] ? SENSE_LOWER : 0);
+        sn.fval_bound = best;
+        int32_t it = 0;
+        const int ef = solve_core(w, p, &sn, sense, NULL, &it);
+        nodes++;
+        total_it += it;
+        int descend = 0;
+        if (ef >= 1) {
+            int jb = -1;
+            for (int j = 0; j < m && jb < 0; j++)
+                if ((p->sense[j] & SENSE_BINARY) && !(w->sense[j] & SENSE_ACTIVE)) jb = j;
+            if (jb < 0) {                               /* leaf */
+                if (!have || w->fval < best) {
+                    have = 1; best = w->fval;
+                    for (int k = 0; k < n; k++) ubest[k] = w->u[k];
+                    for (int q = 0; q < nwords; q++) abest[q] = 0;
+                    for (int i = 0; i < w->na; i++) {
+                        const int j = w->WS[i];
+                        const int bit = (w->sense[j] & SENSE_LOWER) ? m + j : j;
+                        abest[bit >> 6] |= (uint64_t)1 << (bit & 63);
+                    }
+                }
+            } else {
+                const double *mj = &p->M[(size_t)jb * n];
+                double Mu = 0.0;
+                for (int k = 0; k < n; k++) Mu = fma(mj[k], w->u[k], Mu);
+                const int lower_first = (Mu - w->dlower[jb]) < (w->dupper[jb] - Mu);
+                stk_j[depth] = jb; stk_side[depth] = lower_first; stk_tried[depth] = 1;
+                depth++;
+                descend = 1;
+            }
+        }
+        if (!descend) {                                 /* backtrack to the next untried side */
+            while (depth > 0 && stk_tried[depth - 1] == 2) depth--;
+            if (depth == 0) break;
+            stk_side[depth - 1] ^= 1;
+            stk_tried[depth - 1] = 2;
+        }
+    }
+    if (have) {
+        if (flag != EXIT_ITERLIMIT) flag = EXIT_OPTIMAL;
+        for (int k = 0; k < n; k++) w->u[k] = ubest[k];
+    } else {
+        for (int k = 0; k < n; k++) w->u[k] = 0.0;
+    }
+    w->na = 0;                                          /* write_outputs: mask comes from abest */
+    write_outputs(w, p, theta, xout, NULL, 0);
+    if (active) for (int q = 0; q < nwords; q++) active[q] = have ? abest[q] : 0;
+    if (iters) *iters = total_it;
+    free(sense); free(stk_j); free(stk_side); free(stk_tried); free(ubest); free(abest);
+    return flag;
 }
 
 /* ---------------------------------------------------------------- exported entry points */
@@ -414,10 +511,14 @@ void oracle_solve_batch(const oracle_ldp *p, const oracle_settings *s, int64_t N
     int nsoft = 0;
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
+    int nbin = 0;
+    for (int j = 0; j < p->m; j++) nbin += (p->sense[j] & SENSE_BINARY) != 0;
     for (int64_t i = 0; i < N; i++) {
         int32_t it = 0;
-        int ef = solve_one(w, p, s, theta + i * p->nth, warm ? warm + i * nw : NULL,
-                           X + i * p->nout, &it, active ? active + i * nw : NULL, nw);
+        int ef = nbin ? solve_bnb(w, p, s, theta + i * p->nth, X + i * p->nout, &it,
+                                  active ? active + i * nw : NULL, nw)
+                      : solve_one(w, p, s, theta + i * p->nth, warm ? warm + i * nw : NULL,
+                                  X + i * p->nout, &it, active ? active + i * nw : NULL, nw);
         exitflag[i] = ef;
         if (iters) iters[i] = it;
     }
@@ -434,8 +535,9 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings *s, int64_t N, i
                      const double *r, double *uprev, double *U, double *X, int32_t *flag_min,
                      int32_t warm) {
     const int nw = oracle_active_words(p->m), nu = p->nout, nth = p->nth;
-    int nsoft = 0;
+    int nsoft = 0, nbin = 0;
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
+    for (int j = 0; j < p->m; j++) nbin += (p->sense[j] & SENSE_BINARY) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
     double *th = (double *)calloc(nth > 0 ? nth : 1, sizeof(double));
     double *u = (double *)calloc(nu, sizeof(double));
@@ -449,7 +551,8 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings *s, int64_t N, i
             for (int a = 0; a < nr; a++) th[nx + a] = r ? r[i * nr + a] : 0.0;
             for (int a = 0; a < nup; a++) th[nx + nr + a] = uprev ? uprev[i * nup + a] : 0.0;
             int32_t it = 0;
-            int ef = solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
+            int ef = nbin ? solve_bnb(w, p, s, th, u, &it, act, nw)      /* B&B nodes start cold */
+                          : solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
             for (int a = 0; a < nx; a++) {
                 double acc = 0.0;
                 for (int c = 0; c < nx; c++) acc = fma(F[a * nx + c], xi[c], acc);

@@ -98,6 +98,8 @@ class MPCProblem:
     K: Optional[np.ndarray] = None          # prestabilising feedback u = v - K x (setup.jl:186-199)
     Eu: Optional[np.ndarray] = None         # affine input cost (Eu p + eu)'u_k  (setup.jl:136-150)
     eu: Optional[np.ndarray] = None
+    binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
+    Nc_binary: int = -1                     # "binary control horizon" (-1 = whole control horizon)
 
     def np_base(self):
         """utils.jl:207-216 get_affine_parameter_base_dim (largest column count among Eu / Ap)."""
@@ -277,6 +279,15 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         f_theta = np.hstack([f_theta, Fp])
         nthc = H_theta.shape[0]
         H_theta = np.block([[H_theta, np.zeros((nthc, npb))], [np.zeros((npb, nthc)), np.zeros((npb, npb))]])
+    # regularisation of binary inputs (mpc2mpqp.jl:510-515): u^2 - (umin+umax) u is constant on
+    # {umin, umax}, so it does not move the optimum but keeps H positive definite when R = 0
+    if len(p.binary_controls):
+        fb = np.zeros(p.nu)
+        bc = list(p.binary_controls)
+        fb[bc] = (p.umax[bc] + p.umin[bc]) / 2
+        fbin = np.tile(fb, Nc)
+        f = f - fbin
+        H = H + np.diag((fbin != 0).astype(float))
     return (H + H.T) / 2, f, f_theta, H_theta
 
 
@@ -302,9 +313,16 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
         prio = np.zeros(n, int)
         if npb > 0:
             W = np.hstack([W, np.zeros((W.shape[0], npb))])
+        # binary controls (mpc2mpqp.jl:368-373): flag their bound rows over the binary horizon
+        single = np.zeros(nu, bool)
+        single[list(p.binary_controls)] = True
+        binary = np.tile(single, Nc)
+        if p.Nc_binary >= 0:
+            binary[p.Nc_binary * nu:] = False
     else:
         A, bu, bl = np.zeros((0, n)), np.zeros(0), np.zeros(0)
         W, soft, prio = np.zeros((0, nxe + npb)), np.zeros(0, bool), np.zeros(0, int)
+        binary = np.zeros(0, bool)
     if p.constraints:
         eyeX = np.eye(Np + 1)
         eyeU = np.vstack([np.eye(Nc), np.zeros((1 + Np - Nc, Nc))])
@@ -334,7 +352,9 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
         bl = np.concatenate([bl] + lbs)
         soft = np.concatenate([soft] + softs)
         prio = np.concatenate([prio] + prios)
-    return A, bu, bl, W, soft, prio
+        binary = np.concatenate([binary, np.zeros(sum(len(x) for x in softs), bool)])
+    p._binary_rows = binary                      # carried next to the constraint tuple (no row is dropped
+    return A, bu, bl, W, soft, prio              # or reordered among the simple bounds afterwards)
 
 
 def sort_by_priority(A, bu, bl, W, soft, prio):
@@ -453,6 +473,10 @@ def mpc2mpqp(p: MPCProblem) -> MPQP:
         elif abs(bu[i] - bl[i]) < 1e-12:
             senses[i] = EQUALITY
     senses[soft.astype(bool)] += SOFT
+    brow = getattr(p, "_binary_rows", np.zeros(0, bool))
+    if brow.any():                               # mpc2mpqp.jl:884 (binary rows are simple bounds here)
+        nsimple = bu.size - A.shape[0]
+        senses[:nsimple][brow[:nsimple]] += BINARY
     bu = np.clip(bu, -1e30, 1e30)
     bl = np.clip(bl, -1e30, 1e30)
     return MPQP(H, f, H_theta, f_theta, A, bu, bl, W, senses, prio.astype(np.int32), p.nu, p.nx)
@@ -523,6 +547,18 @@ def prestab_kat(prestabilize: bool) -> MPCProblem:
     p = make_mpc(F, G, np.eye(2), Np=30, umin=[-1.0], umax=[1.0], Ts=0.1)
     if prestabilize:
         p.set_prestabilizing_feedback()
+    return p
+
+
+def satellite(Np=20, Nc=None) -> MPCProblem:
+    """mpc_examples.jl:533-546 / example/hybrid.jl: attitude control with one continuous and two
+    on/off (binary) thrusters: u1 free, u2 in {0, 1}, u3 in {-1, 0}."""
+    A = np.array([[0.0, 1, 0], [0, 0, 0], [0, 0, 0]])
+    B = np.array([[0.0, 0, 0], [2.5, 1, 1], [-10, 0, 0]])
+    F, G = zoh(A, B, 0.1)
+    p = make_mpc(F, G, np.eye(3), Np=Np, Nc=Np if Nc is None else Nc, Q=[0.5e4, 1e-2, 1e-1],
+                 R=[10.0, 10.0, 10.0], Rr=np.zeros(3), umin=[-np.inf, 0.0, -1.0], umax=[np.inf, 1.0, 0.0], Ts=0.1)
+    p.binary_controls = (1, 2)
     return p
 
 

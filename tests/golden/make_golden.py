@@ -17,7 +17,13 @@ mask.  Before anything is written the answers are cross-checked by independent m
     (/root/reference/docs/src/manual/simple.md:98-107);
   * prestab: K2, nominal and LQR-prestabilised controllers give the same input
     (/root/reference/test/runtests.jl:119-136);
-  * preprocessing: the reference's K4 known answer (/root/reference/test/runtests.jl:1306-1318).
+  * preprocessing: the reference's K4 known answer (/root/reference/test/runtests.jl:1306-1318);
+  * satellite4 / satellite20: hybrid MPC with binary thrusters (/root/reference/src/mpc_examples.jl:533-546,
+    test/runtests.jl:820-834).  Np=4: every answer equals the best of the 2^8 binary assignments,
+    each solved as a plain linear system (no solver involved).  Np=20: the closed loop reaches the
+    reference and every binary input sits on a bound (the reference's own assertions).
+
+`python tests/golden/make_golden.py name ...` rewrites only the named fixtures.
 
 Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
 the oracle against regressions and carry the reference's known answers.
@@ -80,7 +86,12 @@ def lp_feasible(q, theta):
     return res.status == 0
 
 
+ONLY = set(sys.argv[1:])
+
+
 def save(name, q, L, theta, X, ef, it, act, extra=None):
+    if ONLY and name not in ONLY:
+        return
     d = dict(H=q.H, f=q.f, f_theta=q.f_theta, A=q.A, bu=q.bu, bl=q.bl, W=q.W, senses=q.senses,
              nu=q.nu, nx=q.nx, M=L.M, du=L.du0, dl=L.dl0, Dth=L.Dth, Rout=L.Rout, x0=L.x0, Xth=L.Xth,
              theta=theta, X=X, exitflag=ef, iters=it, active=act)
@@ -184,6 +195,64 @@ def main():
     theta = rng.uniform(-1, 1, (256, q.nth))
     X, ef, it, act = oldp.solve_batch(L, theta)
     save("preprocessing_kat", q, L, theta, X, ef, it, act)
+
+    # ---- hybrid MPC: satellite with two on/off thrusters (branch and bound over BINARY rows)
+    rng = np.random.default_rng(4321)
+    prob = omm.satellite(4)
+    q = omm.mpc2mpqp(prob)
+    assert np.sum((q.senses & 16) != 0) == 8 and q.A.shape[0] == 0
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    theta = np.hstack([rng.uniform(-0.4, 0.4, (256, 1)), rng.uniform(-1, 1, (256, 2)),
+                       rng.uniform(-0.5, 0.5, (256, 1)), np.zeros((256, 2))])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1)
+    bins = np.flatnonzero(q.senses & 16)
+    free = np.setdiff1d(np.arange(q.n), bins)
+    Hff, Hfb = q.H[np.ix_(free, free)], q.H[np.ix_(free, bins)]
+    for i in range(theta.shape[0]):
+        fth = q.f + q.f_theta @ theta[i]
+        bestv, bestx = np.inf, None
+        for combo in itertools.product((0, 1), repeat=len(bins)):
+            xb = np.where(combo, q.bu[bins], q.bl[bins]) + q.W[bins] @ theta[i]
+            xf = np.linalg.solve(Hff, -(fth[free] + Hfb @ xb))     # u1 is unbounded: plain stationarity
+            x = np.zeros(q.n)
+            x[bins], x[free] = xb, xf
+            v = 0.5 * x @ q.H @ x + fth @ x
+            if v < bestv:
+                bestv, bestx = v, x
+        vi = 0.5 * X[i] @ q.H @ X[i] + fth @ X[i]
+        assert vi <= bestv + 1e-7 * max(1.0, abs(bestv)), (i, vi, bestv)
+        assert np.all(np.minimum(np.abs(X[i, bins] - q.bu[bins]), np.abs(X[i, bins] - q.bl[bins])) < 1e-9)
+    save("satellite4", q, L, theta, X, ef, it, act)
+
+    prob = omm.satellite(20)
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    # closed loop of test/runtests.jl:820-834 with a constant reference 0.5 (no preview)
+    x = np.zeros(3)
+    r = np.array([0.5, 0.0, 0.0])
+    traj_theta, traj_u = [], []
+    for k in range(40):
+        th = omm.form_parameter(prob, x, r=r)
+        U, e, _, _ = oldp.solve_batch(L, th[None])
+        assert e[0] == 1
+        u = U[0, :3]
+        for b in prob.binary_controls:
+            assert min(abs(u[b] - prob.umin[b]), abs(u[b] - prob.umax[b])) < 1e-5, (k, u)
+        traj_theta.append(th)
+        traj_u.append(u)
+        x = prob.F @ x + prob.G @ u
+    assert abs(x[0] - 0.5) < 1e-3, x                                  # runtests.jl:829
+    theta = np.vstack([np.array(traj_theta),
+                       np.hstack([rng.uniform(-0.3, 0.3, (88, 1)), rng.uniform(-0.5, 0.5, (88, 2)),
+                                  rng.uniform(-0.5, 0.5, (88, 1)), np.zeros((88, 2))])])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    bins = np.flatnonzero(q.senses & 16)
+    ok = ef == 1
+    assert ok.sum() >= 100
+    assert np.all(np.minimum(np.abs(X[ok][:, bins] - q.bu[bins]), np.abs(X[ok][:, bins] - q.bl[bins])) < 1e-9)
+    save("satellite20", q, L, theta, X, ef, it, act,
+         dict(F=prob.F, G=prob.G, closed_loop_u=np.array(traj_u), closed_loop_xT=x))
 
 
 if __name__ == "__main__":

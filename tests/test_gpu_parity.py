@@ -494,3 +494,71 @@ def test_broken_working_set_is_never_reported_optimal(lmpc):
     Ax = x[ok] @ Afull.T
     scale = np.linalg.norm(Afull @ np.linalg.inv(np.linalg.cholesky(g["H"]).T), axis=1)
     assert ((Ax - bu) / scale).max() < 1e-5 and ((bl - Ax) / scale).max() < 1e-5
+
+
+# ------------------------------------------------------------------ hybrid MPC (binary rows, B&B)
+@pytest.mark.parametrize("name", ["satellite4", "satellite20"])
+def test_hybrid_branch_and_bound_matches_oracle(lmpc, name):
+    # /root/reference/test/runtests.jl:820-834; binaries of mpc_examples.jl:533-546
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    assert qp.kernel_name == "wave"
+    x, ef, it, act = _compare(qp, g["theta"])
+    assert np.all(ef == 1)
+    bins = np.flatnonzero(g["senses"] & 16)
+    assert np.all(np.minimum(np.abs(x[:, bins] - g["bu"][bins]), np.abs(x[:, bins] - g["bl"][bins])) < 1e-9)
+    # against the committed answers (numpy-transformed pack: rounding-level differences only)
+    assert np.array_equal(ef, g["exitflag"])
+    assert np.abs(x - g["X"]).max() <= 1e-8
+
+
+def test_hybrid_mpc_through_operator_interface(lmpc):
+    g = load_golden("satellite20")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                             has_binaries=True), nx=3, nu=3, nr=3)
+    x = np.zeros(3)
+    for k in range(40):
+        u = mpc.compute_control(x, r=[0.5, 0.0, 0.0])
+        assert np.abs(u - g["closed_loop_u"][k]).max() < 1e-8
+        x = g["F"] @ x + g["G"] @ u
+    assert abs(x[0] - 0.5) < 1e-3                                          # runtests.jl:829
+
+
+def test_hybrid_closed_loop_batch_simulation(lmpc):
+    from oracle import ldp as oldp
+    g = load_golden("satellite20")
+    qp = _qp_from_golden(lmpc, g, 3)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(12)
+    N, T = 24, 25
+    x0 = np.hstack([rng.uniform(-0.1, 0.1, (N, 1)), np.zeros((N, 2))]); x0[0] = 0.0
+    r = np.tile([0.5, 0.0, 0.0], (N, 1))
+    ref = oldp.simulate(L, x0, T, g["F"], g["G"], r=r, warm=False)
+    out = qp.simulate(x0, T, g["F"], g["G"], r=r, warm=False)
+    assert np.array_equal(out["flag_min"], ref["flag_min"]) and np.all(out["flag_min"] == 1)
+    assert np.abs(out["U"] - ref["U"]).max() <= TOL and np.abs(out["X"] - ref["X"]).max() <= TOL
+    for b in (1, 2):                                                       # runtests.jl:831-834
+        lo, hi = g["bl"][b], g["bu"][b]
+        assert np.all((np.abs(out["U"][:, :, b] - lo) < 1e-5) | (np.abs(out["U"][:, :, b] - hi) < 1e-5))
+
+
+def test_hybrid_random_problems_with_general_rows(lmpc):
+    # binaries next to general inequality rows and soft rows; infeasible assignments must prune
+    rng = np.random.default_rng(2024)
+    nsolved = 0
+    for trial in range(6):
+        n, mg, nth = 6, 5, 3
+        H, f, fth, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=(1 if trial % 2 else 0))
+        sense = sense.copy()
+        sense[:3] |= 16                                                    # first three bounds binary
+        qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense)
+        assert qp.kernel_name == "wave"
+        theta = rng.uniform(-1, 1, (200, nth))
+        x, ef, it, act = _compare(qp, theta)
+        ok = ef >= 1                                                       # trial 1 is infeasible throughout
+        nsolved += int(ok.sum())
+        xb = x[ok][:, :3]
+        lo = (bl[:3] + theta[ok] @ W[:3].T)
+        hi = (bu[:3] + theta[ok] @ W[:3].T)
+        assert np.all(np.minimum(np.abs(xb - lo), np.abs(xb - hi)) < 1e-8)
+    assert nsolved >= 800

@@ -94,7 +94,8 @@ def test_K8_doc_example_with_soft_output_bounds():
     assert ef[0] == 2
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc", "prestab"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc", "prestab",
+                                  "satellite4", "satellite20"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -107,7 +108,8 @@ def test_oracle_reproduces_golden(name):
     assert np.abs(X[ok] - g["X"][ok]).max() <= 1e-12
 
 
-@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc"])
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc",
+                                  "satellite4", "satellite20"])
 def test_golden_pack_matches_restated_transform(name):
     g = load_golden(name)
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
@@ -213,3 +215,61 @@ def test_K3_generalized_parameters_in_constraints():
     for par, expect in ((0.0, 1.0), (0.75, 0.25)):
         X, ef, _, _ = oldp.solve_batch(L, omm.form_parameter(prob, [0.0], r=[0.0], par=[par])[None])
         assert ef[0] == 1 and abs(X[0, 0] - expect) < 1e-6
+
+
+def _best_binary_assignment(g, theta):
+    """Hybrid problem with unbounded continuous inputs: best of all binary assignments, each a
+    plain linear solve (no QP solver involved)."""
+    import itertools
+    H, bu, bl, W, n = g["H"], g["bu"], g["bl"], g["W"], g["H"].shape[0]
+    bins = np.flatnonzero(g["senses"] & 16)
+    free = np.setdiff1d(np.arange(n), bins)
+    fth = g["f"] + g["f_theta"] @ theta
+    best = np.inf
+    for combo in itertools.product((0, 1), repeat=len(bins)):
+        xb = np.where(combo, bu[bins], bl[bins]) + W[bins] @ theta
+        xf = np.linalg.solve(H[np.ix_(free, free)], -(fth[free] + H[np.ix_(free, bins)] @ xb))
+        x = np.zeros(n)
+        x[bins], x[free] = xb, xf
+        best = min(best, 0.5 * x @ H @ x + fth @ x)
+    return best
+
+
+def test_hybrid_branch_and_bound_finds_best_binary_assignment():
+    # binaries of the satellite example (mpc_examples.jl:533-546), horizon 4: 2^8 assignments
+    g = load_golden("satellite4")
+    assert g["A"].shape[0] == 0 and np.sum((g["senses"] & 16) != 0) == 8
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    rng = np.random.default_rng(77)
+    theta = np.hstack([rng.uniform(-0.4, 0.4, (40, 1)), rng.uniform(-1, 1, (40, 2)),
+                       rng.uniform(-0.5, 0.5, (40, 1)), np.zeros((40, 2))])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1)
+    bins = np.flatnonzero(g["senses"] & 16)
+    for i in range(len(theta)):
+        fth = g["f"] + g["f_theta"] @ theta[i]
+        v = 0.5 * X[i] @ g["H"] @ X[i] + fth @ X[i]
+        best = _best_binary_assignment(g, theta[i])
+        assert v <= best + 1e-7 * max(1.0, abs(best))
+        assert np.all(np.minimum(np.abs(X[i, bins] - g["bu"][bins]), np.abs(X[i, bins] - g["bl"][bins])) < 1e-9)
+        # the mask names every binary row as active at one of its bounds
+        m = len(g["bu"])
+        for j in bins:
+            up = (int(act[i, j >> 6]) >> (j & 63)) & 1
+            lo = (int(act[i, (m + j) >> 6]) >> ((m + j) & 63)) & 1
+            assert up + lo == 1
+
+
+def test_hybrid_closed_loop_reaches_reference_with_binaries_on_bounds():
+    # test/runtests.jl:820-834 (constant reference instead of the preview the reference test uses)
+    prob = omm.satellite(20)
+    g = load_golden("satellite20")
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=3)
+    out = oldp.simulate(L, np.zeros((1, 3)), 40, prob.F, prob.G, r=np.array([[0.5, 0.0, 0.0]]))
+    assert out["flag_min"][0] == 1
+    assert abs(out["x"][0, 0] - 0.5) < 1e-3                               # runtests.jl:829
+    U = out["U"][:, 0, :]
+    for b in prob.binary_controls:                                        # runtests.jl:831-834
+        assert np.all((np.abs(U[:, b] - prob.umin[b]) < 1e-5) | (np.abs(U[:, b] - prob.umax[b]) < 1e-5))
+    assert np.abs(U - g["closed_loop_u"]).max() < 1e-9
