@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
     ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
-    ap.add_argument("--wave-lds-kib", type=int, default=0, help="wave kernel: LDS budget for shared data (tuning)")
+    ap.add_argument("--wave-level", type=int, default=-1, help="wave kernel: LDS staging level 0..3 (tuning)")
+    ap.add_argument("--wave-nwv", type=int, default=0, help="wave kernel: wavefronts per workgroup (tuning)")
     ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
@@ -165,9 +166,12 @@ def main():
     if args.wave_cap:
         for q_ in qps:
             q_.set_option("wave_cap", args.wave_cap)
-    if args.wave_lds_kib:
+    if args.wave_level >= 0:
         for q_ in qps:
-            q_.set_option("wave_lds_kib", args.wave_lds_kib)
+            q_.set_option("wave_level", args.wave_level)
+    if args.wave_nwv:
+        for q_ in qps:
+            q_.set_option("wave_nwv", args.wave_nwv)
     if args.lane_block:
         for q_ in qps:
             q_.set_option("lane_block", args.lane_block)

@@ -54,7 +54,10 @@ struct lmpc_handle {
     bool useWave = false;
     bool bnb = false;           // rows flagged BINARY: branch and bound in the wavefront kernel
     int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
-    int waveLdsLimit = 0;       // tuning: KiB a wave-kernel workgroup may spend to keep M/Mt/G in LDS (0 = 80)
+    bool waveQueue = true;      // tuning: dynamic problem queue of the wave kernel (0 = static split)
+    int32_t *dQueue = nullptr;
+    int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)
+    int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
@@ -280,36 +283,83 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     return LMPC_OK;
 }
 
-size_t wave_const_bytes(const HostPack &P) {
-    return sizeof(double) * (2 * (size_t)P.m * P.n + (size_t)P.m * (P.m + 1) / 2);
+// bytes of shared problem data a wave-kernel workgroup keeps in LDS at staging level `level`
+// (1: M transposed, 2: + M, 3: + packed Gram), rs = sizeof(real)
+size_t wave_shared_bytes(const HostPack &P, int level, size_t rs) {
+    const size_t nM = (size_t)P.m * P.n, nG = (size_t)P.m * (P.m + 1) / 2;
+    return rs * (level >= 3 ? 2 * nM + nG : (level == 2 ? 2 * nM : (level == 1 ? nM : 0)));
 }
 
-template <int MR, bool LDSC, bool BNB>
-int launch_wave_mr(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
-                   int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; };
+
+// Workgroup shape of the wave kernel: nwv wavefronts (= problems in flight) share one LDS copy of
+// the problem data.  Registers allow 4 wavefronts per SIMD (16 per CU; 12 for the 512-thread
+// instantiations); the per-wave factors and the shared copy compete for the 160 KiB of LDS.
+// Measured (tools/wave_sweep.sh): resident wavefronts matter more than the staging level (3-input
+// mass-spring: 16 waves with only M' staged 1.23e7/s, 8 waves with everything staged 0.85e7/s), and
+// at equal residency small workgroups win.  So: most wavefronts per CU first, then the highest
+// staging level that reaches it, then the smallest workgroup.
+WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     const WaveLayout &Wl = h->W;
-    const size_t perWave = sizeof(double) * (size_t)Wl.cap * Wl.ldc;
-    const int nwv = perWave > 40 * 1024 ? 1 : 4;        // wavefronts (problems in flight) per workgroup
-    const size_t shared = LDSC ? wave_const_bytes(h->P) : 0;
-    const size_t lds = perWave * nwv + shared;
-    auto kern = wave_kernel<MR, LDSC, BNB>;
-    if (lds > 48 * 1024)
-        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int blocksPerCU = (int)(kLdsMax / (lds ? lds : 1));
-    const int waveCap = h->waveCap > 0 ? h->waveCap : 16;      // wavefronts per CU the persistent grid is sized for
-    if (blocksPerCU * nwv > waveCap) blocksPerCU = waveCap / nwv;
-    if (blocksPerCU < 1) blocksPerCU = 1;
+    const size_t perWave = rs * (size_t)Wl.cap * Wl.ldc;
+    // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
+    // (more registers per lane, fewer resident wavefronts)
+    const bool big = (h->P.m > 128) || h->bnb;
+    const int maxNwv = big ? 8 : 16, maxWaves = big ? 12 : 16;
+    WaveConfig best{1, 0, 1, perWave};
+    int bestWaves = -1;
+    for (int level = 3; level >= 0; level--) {
+        if (h->waveLevel >= 0 && level != h->waveLevel) continue;
+        for (int nwv : {4, 8, 16, 2, 1}) {
+            if (nwv > maxNwv) continue;
+            if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
+            const size_t lds = perWave * nwv + wave_shared_bytes(h->P, level, rs);
+            if (lds > kLdsMax) continue;
+            int blocks = (int)(kLdsMax / lds);
+            if (blocks * nwv > maxWaves) blocks = maxWaves / nwv;
+            if (blocks < 1) continue;
+            const int waves = blocks * nwv;
+            if (waves > bestWaves) { bestWaves = waves; best = WaveConfig{nwv, level, blocks, lds}; }
+        }
+    }
+    return best;
+}
+
+template <typename R, int MR, int LDSC, bool BNB>
+int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
+                    int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const WaveLayout &Wl = h->W;
+    auto kern = wave_kernel<R, MR, LDSC, BNB>;
+    if (cfg.lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
+    int blocksPerCU = cfg.blocksPerCU;
+    if (h->waveCap > 0) {                              // tuning: wavefronts per CU of the persistent grid
+        blocksPerCU = h->waveCap / cfg.nwv;
+        if (blocksPerCU < 1) blocksPerCU = 1;
+    }
     long long grid = (long long)h->numCU * blocksPerCU;
-    const long long need = (nprob + nwv - 1) / nwv;
+    const long long need = (nprob + cfg.nwv - 1) / cfg.nwv;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * nwv), lds, st, Wl, h->dCw, h->dSw, theta, x, flag,
-                       iters, active, warm, (long long)nprob);
+    // more than two problems per resident wavefront: hand them out through the shared counter
+    int32_t *queue = nullptr;
+    int qchunk = 1;
+    if (nprob > 2 * grid * cfg.nwv && nprob < (int64_t)0x7fffffff && h->waveQueue) {
+        // ~16 tickets per resident wavefront over the whole batch, at most 64 problems per ticket
+        qchunk = (int)(nprob / (16 * grid * cfg.nwv));
+        qchunk = qchunk < 1 ? 1 : (qchunk > 64 ? 64 : qchunk);
+        if (!h->dQueue) HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
+        queue = h->dQueue;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
+                       iters, active, warm, queue, qchunk, (long long)nprob);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
 
-int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
-                int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+template <typename R>
+int launch_wave_t(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
+                  int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
     if (h->prof) {
         HIP_TRY(h, pool_event(h, &ev.a));
@@ -320,24 +370,25 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     }
     int rc;
     const int mr = (h->P.m + 63) / 64;
-    // shared data in LDS when it leaves room for at least two workgroups per CU
-    const size_t perWave = sizeof(double) * (size_t)h->W.cap * h->W.ldc;
-    const int nwv0 = perWave > 40 * 1024 ? 1 : 4;
-    const size_t ldsLimit = h->waveLdsLimit > 0 ? (size_t)h->waveLdsLimit * 1024 : kLdsMax / 2;
-    const bool inLds = perWave * nwv0 + wave_const_bytes(h->P) <= ldsLimit;
-#define LMPC_WV2(MRR, LD) (h->bnb ? launch_wave_mr<MRR, LD, true>(h, nprob, theta, x, flag, iters, active, nullptr, st) \
-                                  : launch_wave_mr<MRR, LD, false>(h, nprob, theta, x, flag, iters, active, warm, st))
-#define LMPC_WV(MRR) (inLds ? LMPC_WV2(MRR, true) : LMPC_WV2(MRR, false))
+    const WaveConfig cfg = wave_config(h, sizeof(R));
+#define LMPC_WV3(MRR, LV) (h->bnb ? launch_wave_cfg<R, MRR, LV, true>(h, cfg, dC, nprob, theta, x, flag, iters, active, nullptr, st) \
+                                  : launch_wave_cfg<R, MRR, LV, false>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WV(MRR) (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0))))
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
     else rc = LMPC_WV(4);
 #undef LMPC_WV
-#undef LMPC_WV2
+#undef LMPC_WV3
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     }
     return rc;
+}
+
+int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+                int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    return launch_wave_t<double>(h, h->dCw, nprob, theta, x, flag, iters, active, warm, st);
 }
 
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
@@ -692,7 +743,14 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
-    if (std::strcmp(name, "wave_lds_kib") == 0) { h->waveLdsLimit = value; return LMPC_OK; }
+    if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }
+    if (std::strcmp(name, "wave_nwv") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: wave_nwv must be 0, 1, 2, 4, 8 or 16");
+        h->waveNwv = value;
+        return LMPC_OK;
+    }
     if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
@@ -716,7 +774,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
-    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw);
+    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     delete h;
 }

@@ -1,24 +1,39 @@
 // One-QP-per-wavefront dual active-set kernel: the general path (n <= 63 variables, working sets
-// up to 64 rows, m <= 256 constraints, hard and SOFT rows).
+// up to 64 rows, m <= 256 constraints, hard and SOFT rows, BINARY rows by branch and bound),
+// in binary64 or binary32 (the reference's generated C has both: codegen.jl:19,31-37,82 `float_type`).
 //
 // Mapping (gfx950): a 64-lane wavefront owns one parameter point.  Working-set position i lives
-// on lane i (its multiplier, right-hand side, pivot, constraint id are that lane's registers),
-// variable k of the primal iterate u lives on lane k, constraint j on lane j % 64 (register slot
-// j / 64).  Only the LDL' factor sits in LDS, column-major with an odd leading dimension so that
-// both the column sweeps of the triangular solves and the row append are (near) conflict-free.
-// Triangular solves and the rank-one update are column sweeps: one v_readlane broadcast of the
-// finished entry, one fma on every lane behind it; arg-min searches are butterfly reductions over
-// (value, index) pairs.  All control flow is wave-uniform: no divergence inside a problem.
-// The shared problem data (M row-major for M_W rows, M transposed for the constraint scan, the
-// packed Gram matrix, Dth, bounds) are read from the one constant buffer through L1/L2.
+// on lane i (its multiplier, right-hand side, pivot, forward-solved right-hand side, constraint id
+// are that lane's registers), variable k of the primal iterate u lives on lane k, constraint j on
+// lane j % 64 (register slot j / 64).  Only the LDL' factor sits in LDS, column-major with an odd
+// leading dimension, so that a lane reads its ROW (forward sweep) at consecutive addresses across
+// lanes and its COLUMN (backward sweep) at an odd stride -- both conflict-free.
 //
-// Every fma chain runs in the same order as the CPU oracle's loops (per lane sequentially, or as
-// a wave-uniform serial chain where the oracle reduces over positions), so the results are
+// What the inner loops look like (and why):
+//  * every serial chain of the algorithm (triangular solves, the pivot recurrence, u'u, M u) is a
+//    chain of dependent fma's; everything that does NOT depend on the chain -- the L entries, the
+//    rows of M, the broadcast operands -- is fetched eight steps ahead into registers, so a step
+//    costs two v_readlane + one fma (+ the select that keeps finished lanes), not an LDS round trip;
+//  * lane masks of the sweeps ("rows behind column t") are scalar shifts handed to the VALU
+//    through inverse_ballot: no per-step vector compare;
+//  * the forward solve y = L^-1 rhs is kept per position and extended by ONE serial chain when a row
+//    is appended (it shares the loop with the new pivot's recurrence); only a removal re-runs the
+//    full sweep.  Per entry this is the same fma chain as the full sweep -> identical bits;
+//  * reductions: "is anything blocking / violated" is a ballot (the common answer is no); a minimum
+//    is four DPP butterflies inside the 16-lane rows plus three scalar-operand mins across rows;
+//    the winner is the lowest tied lane/index found with a second ballot;
+//  * all control flow is wave-uniform and the compiler is told so (readfirstlane on everything
+//    that steers a branch), so loop counters and branch conditions live in SGPRs.
+// The shared problem data (M row-major for M_W rows, M transposed for the constraint scan, the
+// packed Gram matrix) are staged in LDS per workgroup as far as they fit (LDSC level), the rest is
+// read from the one constant buffer through L1/L2.
+//
+// Every fma chain runs in the same order as the CPU oracle's loops, so the results are
 // bit-comparable with it, exactly as for the one-QP-per-lane kernel.
 //
 // Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp incl.
 // soft constraints ([EXT] libdaqp, called at mpc_update_qp.c:48 / utils.jl:282; rho_soft from
-// setup.jl:26) and mpc_get_solution (mpc_update_qp.c:14-22).
+// setup.jl:26), daqp_bnb (mpc_update_qp.c:40-43) and mpc_get_solution (mpc_update_qp.c:14-22).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,12 +51,18 @@ struct WaveLayout {
     int cycle_tol, iter_limit;
 };
 
+// ---- wave-level helpers, for double and float ---------------------------------------------------
 __device__ __forceinline__ double wv_bcast(double v, int src) {
     // `src` is wave-uniform: two v_readlane_b32
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float wv_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+__device__ __forceinline__ int wv_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 // value held identically by all lanes -> scalar registers (tells the compiler it is wave-uniform)
 __device__ __forceinline__ double wv_first(double v) {
@@ -49,50 +70,102 @@ __device__ __forceinline__ double wv_first(double v) {
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-
-// lexicographic (value, index) minimum over the wave; idx < 0 marks "no candidate"
-__device__ __forceinline__ void wv_argmin(double &val, int &idx) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(val, off);
-        const int oi = __shfl_xor(idx, off);
-        const bool take = (oi >= 0) && (idx < 0 || ov < val || (ov == val && oi < idx));
-        if (take) { val = ov; idx = oi; }
-    }
+__device__ __forceinline__ float wv_first(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// MR: register slots per lane for constraints (m <= 64*MR).  LDSC: the shared problem data
-// (M, M transposed, packed Gram) are staged once per workgroup in LDS behind the per-wave factors
-// (when they fit) -- their reads sit on every iteration's critical path, and an LDS read returns in
-// ~1/8 of the time of an L2 hit.
+// DPP lane permutations inside a row of 16 lanes (quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E,
+// row_half_mirror = 0x141, row_mirror = 0x140), wave_shl:1 = 0x130 (lane i reads lane i+1)
+template <int CTRL> __device__ __forceinline__ int wv_dpp(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ double wv_dpp(double v) {
+    return __hiloint2double(wv_dpp<CTRL>(__double2hiint(v)), wv_dpp<CTRL>(__double2loint(v)));
+}
+template <int CTRL> __device__ __forceinline__ float wv_dpp(float v) {
+    return __int_as_float(wv_dpp<CTRL>(__float_as_int(v)));
+}
+// lane i <- lane i+1 (lane 63 gets 0)
+template <typename V> __device__ __forceinline__ V wv_down1(V v) { return wv_dpp<0x130>(v); }
+
+__device__ __forceinline__ double wv_min2(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float wv_min2(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ int wv_min2(int a, int b) { return a < b ? a : b; }
+
+// minimum over the 64 lanes, returned wave-uniform
+template <typename V> __device__ __forceinline__ V wv_min(V v) {
+    v = wv_min2(v, wv_dpp<0xB1>(v));
+    v = wv_min2(v, wv_dpp<0x4E>(v));
+    v = wv_min2(v, wv_dpp<0x141>(v));
+    v = wv_min2(v, wv_dpp<0x140>(v));            // every lane of a row holds the row's minimum
+    const V a = wv_bcast(v, 0), b = wv_bcast(v, 16), c = wv_bcast(v, 32), d = wv_bcast(v, 48);
+    return wv_min2(wv_min2(a, b), wv_min2(c, d));
+}
+
+__device__ __forceinline__ double wv_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float wv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ bool wv_in(unsigned long long mask) {
+    // per-lane predicate from a scalar lane mask: no vector compare
+    return __builtin_amdgcn_inverse_ballot_w64(mask);
+}
+// lanes [0, k)
+__device__ __forceinline__ unsigned long long wv_below(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+
+template <typename R> struct wv_lim;
+template <> struct wv_lim<double> { static __device__ __forceinline__ double inf() { return __builtin_huge_val(); } };
+template <> struct wv_lim<float> { static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); } };
+
+// R: arithmetic type.  MR: register slots per lane for constraints (m <= 64*MR).  LDSC: how much of
+// the shared problem data is staged once per workgroup in LDS behind the per-wave factors:
+// 0 nothing, 1 M transposed (constraint scan), 2 + M (primal step), 3 + packed Gram (row append).
 // BNB: rows flagged BINARY must end up active at one of their bounds -- depth-first branch and
 // bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
-template <int MR, bool LDSC, bool BNB>
-__global__ __launch_bounds__(256) void wave_kernel(
-    const WaveLayout P, const double *__restrict__ C, const int32_t *__restrict__ S,
-    const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
+template <typename R, int MR, int LDSC, bool BNB>
+__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
+    const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
+    const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
-    long long nprob) {
-    extern __shared__ __align__(16) double lds[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    const int n = P.n, m = P.m, nth = P.nth, ldc = P.ldc;
-    double *L = lds + (size_t)wv * P.cap * ldc;      // L(i,t) = L[t*ldc + i], i > t
-    const double *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG;
-    if (LDSC) {
-        double *sc = lds + (size_t)nwv * P.cap * ldc;
+    int32_t *__restrict__ queue, int qchunk, long long nprob) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    R *lds = reinterpret_cast<R *>(lds_raw);
+    constexpr int CH = 8;                            // steps fetched ahead of a serial chain
+    const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
+    // wave-uniform by construction; telling the compiler keeps every loop counter of the solve in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = P.n, m = P.m, nth = P.nth, ldc = P.ldc, cap = P.cap;
+    R *L = lds + (size_t)wv * cap * ldc;             // L(i,t) = L[t*ldc + i], i > t
+    const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG;
+    if (LDSC > 0) {
+        R *sc = lds + (size_t)nwv * cap * ldc;
         const int nM = m * n, nG = m * (m + 1) / 2;
-        for (int i = threadIdx.x; i < nM; i += blockDim.x) { sc[i] = C[P.oM + i]; sc[nM + i] = C[P.oMt + i]; }
-        for (int i = threadIdx.x; i < nG; i += blockDim.x) sc[2 * nM + i] = C[P.oG + i];
+        for (int i = threadIdx.x; i < nM; i += blockDim.x) sc[i] = C[P.oMt + i];
+        Mt = sc;
+        if (LDSC > 1) {
+            for (int i = threadIdx.x; i < nM; i += blockDim.x) sc[nM + i] = C[P.oM + i];
+            Mr = sc + nM;
+        }
+        if (LDSC > 2) {
+            for (int i = threadIdx.x; i < nG; i += blockDim.x) sc[2 * nM + i] = C[P.oG + i];
+            G = sc + 2 * nM;
+        }
         __syncthreads();
-        Mr = sc; Mt = sc + nM; G = sc + 2 * nM;
     }
+    const R primal_tol = (R)P.primal_tol, dual_tol = (R)P.dual_tol, zero_tol = (R)P.zero_tol,
+            progress_tol = (R)P.progress_tol, rho_soft = (R)P.rho_soft;
+    const R kInf = wv_lim<R>::inf();
+    const int lrow = lane < cap ? lane : cap - 1;                // clamped row/column of L for prefetches
+    const int lrow1 = lane + 1 < cap ? lane + 1 : cap - 1;
+    const int lanen = lane < n ? lane : n - 1;
 
     int sense0[MR], sense[MR];                       // constraint slots of this lane: as given / of the
-#pragma unroll                                       // current solve (a B&B node adds its fixed binaries)
+    int jc[MR];                                      // current solve (a B&B node adds its fixed binaries)
+#pragma unroll
     for (int r = 0; r < MR; r++) {
         const int j = lane + 64 * r;
         sense0[r] = (j < m) ? S[j] : SENSE_IMMUTABLE;
         sense[r] = sense0[r];
+        jc[r] = j < m ? j : m - 1;
     }
     // flags of row j (wave-uniform) from the slot that owns it
     auto sense_of = [&](int j) -> int {
@@ -102,47 +175,89 @@ __global__ __launch_bounds__(256) void wave_kernel(
         return __builtin_amdgcn_readlane(v, j & 63);
     };
 
-    for (long long pid = (long long)blockIdx.x * nwv + wv; pid < nprob; pid += (long long)gridDim.x * nwv) {
-        const double *th = theta + pid * nth;
-        double b[MR];                            // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
+    // Every resident wavefront starts on its own chunk of qchunk consecutive problems; further chunks
+    // come from a shared counter (iteration counts vary by 10x inside a batch, a static split leaves
+    // a tail of idle SIMDs).  The ticket for the next chunk is drawn at the start of the current one so
+    // that its latency is hidden; the host sizes the chunk so that one counter word is never the
+    // bottleneck (it serves ~90 atomics per microsecond).
+    const long long gwaves = (long long)gridDim.x * nwv;
+    long long chunk = (long long)blockIdx.x * nwv + wv;
+    long long pid = chunk * qchunk;
+    int kin = 0, ticket = 0;
+    while (pid < nprob) {
+        if (queue != nullptr && kin == 0 && lane == 0) ticket = atomicAdd(queue, 1);
+        const R *th = theta + pid * nth;
+        R b[MR];                                 // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
         unsigned actb = 0u, lowb = 0u;           // bit r: slot r active / active at its lower bound
 #pragma unroll
-        for (int r = 0; r < MR; r++) {
-            const int j = lane + 64 * r;
-            double acc = 0.0;
-            if (j < m)
-                for (int t = 0; t < nth; t++) acc = __builtin_fma(C[P.oDth + j * nth + t], th[t], acc);
-            b[r] = acc;
+        for (int r = 0; r < MR; r++) b[r] = (R)0;
+        for (int t0 = 0; t0 < nth; t0 += CH) {
+            R tv[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) tv[q] = th[t0 + q < nth ? t0 + q : nth - 1];
+#pragma unroll
+            for (int r = 0; r < MR; r++) {
+                R dv[CH];
+                const R *dj = C + P.oDth + (size_t)jc[r] * nth;
+#pragma unroll
+                for (int q = 0; q < CH; q++) dv[q] = dj[t0 + q < nth ? t0 + q : nth - 1];
+#pragma unroll
+                for (int q = 0; q < CH; q++)
+                    if (t0 + q < nth) b[r] = wv_fma(dv[q], tv[q], b[r]);
+            }
         }
         // registers of working-set position `lane`
         int WSi = 0, possoft = 0, posimm = 0, poslow = 0;
-        double lam = 0.0, ls = 0.0, rhs = 0.0, D = 0.0, Dinv = 0.0;
-        double u = 0.0;                          // lane k < n holds u_k
+        R lam = (R)0, ls = (R)0, rhs = (R)0, D = (R)0, Dinv = (R)0, y = (R)0;
+        R u = (R)0;                              // lane k < n holds u_k
         int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT, nsoft_act = 0;
-        double best = -1.0, fval = 0.0, soft_slack = 0.0;
-        bool done = false;
-        double fbound = P.fval_bound;            // a B&B node stops as soon as it is dominated
+        R best = (R)-1, fval = (R)0, soft_slack = (R)0;
+        bool done = false, ydirty = false;
+        R fbound = (R)P.fval_bound;              // a B&B node stops as soon as it is dominated
 
-        auto Gat = [&](int a, int c) -> double {
+        auto Gat = [&](int a, int c) -> R {
             return a >= c ? G[(size_t)a * (a + 1) / 2 + c] : G[(size_t)c * (c + 1) / 2 + a];
         };
 
-        // Column sweeps: one v_readlane broadcast of the finished entry, one fma on every lane behind it.
-        // (A four-columns-per-trip variant with the LDS reads hoisted was measured: +3 % on working
-        // sets of ~10 rows, -15 % on small ones; not kept.)
-        // forward: v_i -= L(i,t) v_t for t = 0 .. na-2 in order (lane i holds v_i)
-        auto sweep_fwd = [&](double v) -> double {
-            for (int t = 0; t + 1 < na; t++) {
-                const double vt = wv_bcast(v, t);
-                if (lane > t && lane < na) v = __builtin_fma(-L[t * ldc + lane], vt, v);
+        // Column sweeps.  forward: v_i -= L(i,t) v_t for t = 0 .. na-2 in order (lane i holds v_i);
+        // lane i reads its row of L eight columns ahead of the chain.
+        auto sweep_fwd = [&](R v) -> R {
+            const unsigned long long rows = wv_below(na);
+            for (int t0 = 0; t0 + 1 < na; t0 += CH) {
+                R Lr[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int t = t0 + q < cap ? t0 + q : cap - 1;
+                    Lr[q] = L[t * ldc + lrow];
+                }
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int t = t0 + q;
+                    if (t + 1 < na) {
+                        const R vt = wv_bcast(v, t);
+                        if (wv_in(rows & (~1ull << t))) v = wv_fma(-Lr[q], vt, v);   // rows t < i < na
+                    }
+                }
             }
             return v;
         };
-        // backward: v_i -= L(t,i) v_t for t = top .. 1 in descending order
-        auto sweep_bwd = [&](double v, int top) -> double {
-            for (int t = top; t >= 1; t--) {
-                const double vt = wv_bcast(v, t);
-                if (lane < t) v = __builtin_fma(-L[lane * ldc + t], vt, v);
+        // backward: v_i -= L(t,i) v_t for t = top .. 1 in descending order; lane i reads its column
+        auto sweep_bwd = [&](R v, int top) -> R {
+            for (int t1 = top; t1 >= 1; t1 -= CH) {
+                R Lc[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int t = t1 - q > 0 ? t1 - q : 0;
+                    Lc[q] = L[lrow * ldc + t];
+                }
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int t = t1 - q;
+                    if (t >= 1) {
+                        const R vt = wv_bcast(v, t);
+                        if (wv_in(wv_below(t))) v = wv_fma(-Lc[q], vt, v);            // columns i < t
+                    }
+                }
             }
             return v;
         };
@@ -151,25 +266,41 @@ __global__ __launch_bounds__(256) void wave_kernel(
         auto ldl_add = [&](int j, bool lower) {
             const int sj = sense_of(j);
             const bool is_soft = (sj & SENSE_SOFT) != 0;
-            double q = (lane < na) ? Gat(WSi, j) : 0.0;
+            const int wsc = lane < na ? WSi : j;
+            R q = Gat(wsc, j);
+            const R gjj = wv_bcast(q, na < 64 ? na : 63);             // lanes >= na read G(j,j)
+            q = lane < na ? q : (R)0;
             q = sweep_fwd(q);
-            const double l = q * Dinv;               // lanes >= na: 0 * 0
-            double dnew = Gat(j, j);
-            if (is_soft) dnew += P.rho_soft;
-            for (int i = 0; i < na; i++) dnew = __builtin_fma(-wv_bcast(l, i), wv_bcast(q, i), dnew);
-            const bool singular = (dnew < P.zero_tol) || (!is_soft && (na - nsoft_act) >= n);
-            if (lane < na) L[lane * ldc + na] = l;   // new row: L(na, t) written by lane t
+            const R l = q * Dinv;                    // lanes >= na: 0 * 0
+            R dnew = na < 64 ? gjj : Gat(j, j);
+            if (is_soft) dnew += rho_soft;
             // bound of row j from the slot that owns it
-            double bj = 0.0;
+            R bj = (R)0;
 #pragma unroll
             for (int r = 0; r < MR; r++) if (r == (j >> 6)) bj = b[r];
             bj = wv_bcast(bj, j & 63);
-            const double rj = lower ? -(C[P.odl + j] + bj) : -(C[P.odu + j] + bj);
+            const R rj = lower ? -(C[P.odl + j] + bj) : -(C[P.odu + j] + bj);
+            // two serial chains over the old positions: the new pivot and the new entry of y = L^-1 rhs
+            R ynew = rj;
+            for (int i0 = 0; i0 < na; i0 += CH) {
+#pragma unroll
+                for (int qq = 0; qq < CH; qq++) {
+                    const int i = i0 + qq;
+                    if (i < na) {
+                        const R li = wv_bcast(l, i);
+                        dnew = wv_fma(-li, wv_bcast(q, i), dnew);
+                        ynew = wv_fma(-li, wv_bcast(y, i), ynew);
+                    }
+                }
+            }
+            dnew = wv_first(dnew);
+            const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft_act) >= n);
+            if (lane < na) L[lane * ldc + na] = l;   // new row: L(na, t) written by lane t
             if (lane == na) {
                 WSi = j; possoft = is_soft ? 1 : 0; posimm = (sj & SENSE_IMMUTABLE) ? 1 : 0; poslow = lower ? 1 : 0;
-                rhs = rj; lam = 0.0; ls = 0.0;
-                D = singular ? 0.0 : dnew;
-                Dinv = singular ? 0.0 : 1.0 / dnew;
+                rhs = rj; lam = (R)0; ls = (R)0; y = ynew;
+                D = singular ? (R)0 : dnew;
+                Dinv = singular ? (R)0 : (R)1 / dnew;
             }
             if (lane == (j & 63)) {
                 actb |= 1u << (j >> 6);
@@ -183,53 +314,77 @@ __global__ __launch_bounds__(256) void wave_kernel(
         // ---- drop working-set position r (wave-uniform): compact L, rank-one update of the tail
         auto ldl_remove = [&](int r) {
             const int nao = na;
-            double w = (lane > r && lane < nao) ? L[r * ldc + lane] : 0.0;   // old row index = lane
-            double alpha = wv_bcast(D, r);
+            R w = (lane > r && lane < nao) ? L[r * ldc + lane] : (R)0;   // old row index = lane
+            R alpha = wv_bcast(D, r);
             const int jrem = __builtin_amdgcn_readlane(WSi, r);
             const int softrem = __builtin_amdgcn_readlane(possoft, r);
-            // new L(i,c): old L(i+1,c) for c < r, old L(i+1,c+1) for c >= r   (i >= r)
-            for (int c = 0; c + 1 < nao - 1; c++) {
-                const int srcc = c < r ? c : c + 1;
-                const int lo = (c + 1 > r) ? c + 1 : r;
-                double v = 0.0;
-                const bool mine = lane >= lo && lane < nao - 1;
-                if (mine) v = L[srcc * ldc + lane + 1];
-                if (mine) L[c * ldc + lane] = v;
+            // new L(i,c): old L(i+1,c) for c < r, old L(i+1,c+1) for c >= r   (i >= r); eight
+            // columns are read before they are written (the reads of the next eight start behind them)
+            for (int c0 = 0; c0 + 1 < nao - 1; c0 += CH) {
+                R tmp[CH];
+#pragma unroll
+                for (int qq = 0; qq < CH; qq++) {
+                    int c = c0 + qq;
+                    c = c < cap - 2 ? c : (cap - 2 > 0 ? cap - 2 : 0);
+                    const int srcc = c < r ? c : c + 1;
+                    tmp[qq] = L[srcc * ldc + lrow1];
+                }
+#pragma unroll
+                for (int qq = 0; qq < CH; qq++) {
+                    const int c = c0 + qq;
+                    if (c + 1 < nao - 1) {
+                        const int lo = (c + 1 > r) ? c + 1 : r;
+                        if (wv_in(wv_below(nao - 1) & ~wv_below(lo))) L[c * ldc + lane] = tmp[qq];
+                    }
+                }
             }
             // shift the per-position registers down by one from position r on
             {
-                const int wn = __shfl_down(WSi, 1), sn = __shfl_down(possoft, 1), in = __shfl_down(posimm, 1),
-                          ln = __shfl_down(poslow, 1);
-                const double lamn = __shfl_down(lam, 1), rhsn = __shfl_down(rhs, 1), Dn = __shfl_down(D, 1),
-                             Din = __shfl_down(Dinv, 1), wnn = __shfl_down(w, 1);
+                const int wn = wv_down1(WSi), sn = wv_down1(possoft), in = wv_down1(posimm), ln = wv_down1(poslow);
+                const R lamn = wv_down1(lam), rhsn = wv_down1(rhs), Dn = wv_down1(D), Din = wv_down1(Dinv),
+                        wnn = wv_down1(w);
                 if (lane >= r && lane < nao - 1) {
                     WSi = wn; possoft = sn; posimm = in; poslow = ln; lam = lamn; rhs = rhsn; D = Dn; Dinv = Din;
                     w = wnn;
                 } else if (lane == nao - 1) {
-                    WSi = 0; possoft = 0; posimm = 0; poslow = 0; lam = 0.0; rhs = 0.0; D = 0.0; Dinv = 0.0; w = 0.0;
+                    WSi = 0; possoft = 0; posimm = 0; poslow = 0; lam = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; w = (R)0;
                 } else {
-                    w = 0.0;
+                    w = (R)0;
                 }
             }
             na = nao - 1;
             sing = -1;
-            for (int t = r; t < na; t++) {
-                const double pt = wv_bcast(w, t);
-                const double dold = wv_bcast(D, t);
-                const double dbar = __builtin_fma(alpha * pt, pt, dold);
-                if (dbar < P.zero_tol) {
-                    if (lane == t) { D = 0.0; Dinv = 0.0; }
-                    sing = t;
-                    break;
+            ydirty = true;
+            bool stop = false;
+            for (int t0 = r; t0 < na && !stop; t0 += CH) {
+                R lq[CH];
+#pragma unroll
+                for (int qq = 0; qq < CH; qq++) {
+                    const int t = t0 + qq < cap ? t0 + qq : cap - 1;
+                    lq[qq] = L[t * ldc + lrow];
                 }
-                const double rinv = 1.0 / dbar;
-                const double beta = (pt * alpha) * rinv;
-                alpha = (dold * alpha) * rinv;
-                if (lane == t) { D = dbar; Dinv = rinv; }
-                if (lane > t && lane < na) {
-                    const double lq = L[t * ldc + lane];
-                    w = __builtin_fma(-pt, lq, w);
-                    L[t * ldc + lane] = __builtin_fma(beta, w, lq);
+#pragma unroll
+                for (int qq = 0; qq < CH; qq++) {
+                    const int t = t0 + qq;
+                    if (t < na && !stop) {
+                        const R pt = wv_bcast(w, t);
+                        const R dold = wv_bcast(D, t);
+                        const R dbar = wv_fma(alpha * pt, pt, dold);
+                        if (dbar < zero_tol) {
+                            if (lane == t) { D = (R)0; Dinv = (R)0; }
+                            sing = t;
+                            stop = true;
+                        } else {
+                            const R rinv = (R)1 / dbar;
+                            const R beta = (pt * alpha) * rinv;
+                            alpha = (dold * alpha) * rinv;
+                            if (lane == t) { D = dbar; Dinv = rinv; }
+                            if (wv_in(wv_below(na) & (~1ull << t))) {
+                                w = wv_fma(-pt, lq[qq], w);
+                                L[t * ldc + lane] = wv_fma(beta, w, lq[qq]);
+                            }
+                        }
+                    }
                 }
             }
             if (lane == (jrem & 63)) {
@@ -240,25 +395,32 @@ __global__ __launch_bounds__(256) void wave_kernel(
         };
 
         // ---- blocking search over the working set: (alpha, rm) = first minimum of the ratios
-        auto blocking = [&](bool singular_dir, double &alpha, int &rm) {
-            const bool okd = poslow ? (ls < P.dual_tol) : (ls > -P.dual_tol);
+        auto blocking = [&](bool singular_dir, R &alpha, int &rm) {
+            const bool okd = poslow ? (ls < dual_tol) : (ls > -dual_tol);
             const bool blk = (lane < na) && !posimm && !okd;
-            double cand = 0.0;
+            const unsigned long long bm = __ballot(blk);
+            if (bm == 0ull) { rm = -1; alpha = (R)0; return; }
+            R cand = (R)0;
             if (blk) cand = singular_dir ? (-lam / ls) : (-lam / (ls - lam));
-            int idx = blk ? lane : -1;
-            wv_argmin(cand, idx);
-            alpha = wv_first(cand);
-            rm = __builtin_amdgcn_readfirstlane(idx);
+            const R g = wv_min(blk ? cand : kInf);
+            unsigned long long tie = __ballot(blk && cand == g);
+            if (tie == 0ull) tie = bm;
+            rm = (int)__builtin_ctzll(tie);
+            alpha = wv_bcast(cand, rm);
         };
 
         // ---- one LDP solve with the flags in sense[] (cold, or warm from the caller's mask)
         auto solve_node = [&]() {
         WSi = 0; possoft = 0; posimm = 0; poslow = 0;
-        lam = 0.0; ls = 0.0; rhs = 0.0; D = 0.0; Dinv = 0.0; u = 0.0;
+        lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; u = (R)0; y = (R)0;
         actb = 0u; lowb = 0u;
         na = 0; sing = -1; iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; nsoft_act = 0;
-        best = -1.0; fval = 0.0; soft_slack = 0.0; done = false;
+        best = (R)-1; fval = (R)0; soft_slack = (R)0; done = false; ydirty = false;
         // initial working set: rows flagged ACTIVE (equalities, fixed binaries), then the warm-start mask
+        unsigned long long want_any = 0ull;
+#pragma unroll
+        for (int r = 0; r < MR; r++) want_any |= __ballot((sense[r] & SENSE_ACTIVE) != 0 && lane + 64 * r < m);
+        if (want_any != 0ull || warm != nullptr) {
         for (int j = 0; j < m && !done; j++) {
             const int sj = sense_of(j);
             bool want = (sj & SENSE_ACTIVE) != 0, lower = want && (sj & SENSE_LOWER) != 0;
@@ -274,101 +436,132 @@ __global__ __launch_bounds__(256) void wave_kernel(
                 else {                              // dependent warm-start row: take it out again
                     na--;
                     sing = -1;
-                    if (lane == na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = 0.0; D = 0.0; Dinv = 0.0; }
+                    if (lane == na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0; }
                     if (sj & SENSE_SOFT) nsoft_act--;
                     if (lane == (j & 63)) { actb &= ~(1u << (j >> 6)); lowb &= ~(1u << (j >> 6)); }
                 }
             }
+        }
         }
 
         // ---- dual active-set iterations
         while (!done) {
             if (iter >= P.iter_limit) { flag = EXIT_ITERLIMIT; break; }
             int rm = -1;
-            double alpha = 0.0;
+            R alpha = (R)0;
             if (sing < 0) {
-                // constrained stationary point (L D L') lam* = rhs by two column sweeps
-                double x = (lane < na) ? rhs : 0.0;
-                x = sweep_fwd(x);
-                double acc = sweep_bwd(x * Dinv, na - 1);
-                ls = (lane < na) ? acc : 0.0;
+                // constrained stationary point (L D L') lam* = rhs: y = L^-1 rhs is kept up to date by
+                // ldl_add, only a removal re-runs the forward sweep; then one backward sweep
+                if (ydirty) {
+                    y = sweep_fwd((lane < na) ? rhs : (R)0);
+                    ydirty = false;
+                }
+                const R acc = sweep_bwd(y * Dinv, na - 1);
+                ls = (lane < na) ? acc : (R)0;
                 blocking(false, alpha, rm);
                 if (rm < 0) {
-                    // primal iterate u = -M_W' lam* (lane k owns u_k), objective, then the scan
-                    double uk = 0.0;
-                    for (int i = 0; i < na; i++) {
-                        const int w = __builtin_amdgcn_readlane(WSi, i);
-                        const double l = wv_bcast(ls, i);
-                        if (lane < n) uk = __builtin_fma(-Mr[(size_t)w * n + lane], l, uk);
+                    // primal iterate u = -M_W' lam* (lane k owns u_k): rows of M eight positions ahead
+                    R uk = (R)0;
+                    for (int i0 = 0; i0 < na; i0 += CH) {
+                        R mv[CH];
+#pragma unroll
+                        for (int q = 0; q < CH; q++) {
+                            const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
+                            mv[q] = Mr[(size_t)w * n + lanen];
+                        }
+#pragma unroll
+                        for (int q = 0; q < CH; q++)
+                            if (i0 + q < na) uk = wv_fma(-mv[q], wv_bcast(ls, i0 + q), uk);
                     }
-                    u = uk;
-                    double fv = 0.0, soft = 0.0;
-                    for (int k = 0; k < n; k++) { const double v = wv_bcast(u, k); fv = __builtin_fma(v, v, fv); }
+                    u = lane < n ? uk : (R)0;
+                    // objective u'u and the row values M u in one pass over the variables
+                    R fv = (R)0, soft = (R)0;
+                    R Mu[MR];
+#pragma unroll
+                    for (int r = 0; r < MR; r++) Mu[r] = (R)0;
+                    constexpr int CHM = MR == 1 ? 8 : (MR == 2 ? 4 : 2);   // same register budget for any MR
+                    for (int k0 = 0; k0 < n; k0 += CHM) {
+                        R mt[CHM][MR];
+#pragma unroll
+                        for (int q = 0; q < CHM; q++) {
+                            const int k = k0 + q < n ? k0 + q : n - 1;
+#pragma unroll
+                            for (int r = 0; r < MR; r++) mt[q][r] = Mt[(size_t)k * m + jc[r]];
+                        }
+#pragma unroll
+                        for (int q = 0; q < CHM; q++) {
+                            if (k0 + q < n) {
+                                const R v = wv_bcast(u, k0 + q);
+                                fv = wv_fma(v, v, fv);
+#pragma unroll
+                                for (int r = 0; r < MR; r++) Mu[r] = wv_fma(mt[q][r], v, Mu[r]);
+                            }
+                        }
+                    }
                     if (nsoft_act > 0)
                         for (int i = 0; i < na; i++)
                             if (__builtin_amdgcn_readlane(possoft, i)) {
-                                const double l = wv_bcast(ls, i);
-                                soft = __builtin_fma(l * l, P.rho_soft, soft);
+                                const R l = wv_bcast(ls, i);
+                                soft = wv_fma(l * l, rho_soft, soft);
                             }
-                    soft_slack = soft;
-                    fval = fv + soft;
+                    soft_slack = wv_first(soft);
+                    fval = wv_first(fv) + soft_slack;
                     if (fval > fbound) { flag = EXIT_INFEASIBLE; break; }
-                    double Mu[MR];
-#pragma unroll
-                    for (int r = 0; r < MR; r++) Mu[r] = 0.0;
-                    for (int k = 0; k < n; k++) {
-                        const double v = wv_bcast(u, k);
-#pragma unroll
-                        for (int r = 0; r < MR; r++) {
-                            const int j = lane + 64 * r;
-                            if (j < m) Mu[r] = __builtin_fma(Mt[(size_t)k * m + j], v, Mu[r]);
-                        }
-                    }
-                    double mval = -P.primal_tol;
+                    R mval = -primal_tol;
                     int midx = -1;
                     bool broken = false;
 #pragma unroll
                     for (int r = 0; r < MR; r++) {
                         const int j = lane + 64 * r;
                         if (j < m && !(sense[r] & SENSE_IMMUTABLE)) {
-                            const double vu = (C[P.odu + j] + b[r]) - Mu[r];
-                            const double vl = -((C[P.odl + j] + b[r]) - Mu[r]);
+                            const R vu = (C[P.odu + j] + b[r]) - Mu[r];
+                            const R vl = -((C[P.odl + j] + b[r]) - Mu[r]);
                             if (!((actb >> r) & 1u)) {
                                 if (vu < mval) { mval = vu; midx = 2 * j; }
                                 else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
-                            } else if (!(sense[r] & SENSE_SOFT) && (vu < -P.primal_tol || vl < -P.primal_tol)) {
+                            } else if (!(sense[r] & SENSE_SOFT) && (vu < -primal_tol || vl < -primal_tol)) {
                                 broken = true;  // the iterate violates a hard row of its own working set
                             }
                         }
                     }
-                    wv_argmin(mval, midx);
-                    midx = __builtin_amdgcn_readfirstlane(midx);
-                    if (midx < 0) {
+                    const unsigned long long viol = __ballot(midx >= 0);
+                    if (viol == 0ull) {
                         if (__ballot(broken) != 0ull) flag = EXIT_CYCLE;
-                        else flag = (soft_slack > P.primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
+                        else flag = (soft_slack > primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
                         break;
+                    }
+                    // most violated row: smallest value, ties to the lowest (row, side) index
+                    {
+                        const R g = wv_min(midx >= 0 ? mval : kInf);
+                        unsigned long long tie = __ballot(midx >= 0 && mval == g);
+                        if (tie == 0ull) tie = viol;
+                        if ((tie & (tie - 1ull)) == 0ull) {
+                            midx = __builtin_amdgcn_readlane(midx, (int)__builtin_ctzll(tie));
+                        } else {
+                            midx = wv_min(wv_in(tie) ? midx : 0x7fffffff);
+                        }
                     }
                     lam = ls;
                     ldl_add(midx >> 1, (midx & 1) != 0);
-                    if (fval - best < P.progress_tol) {
+                    if (fval - best < progress_tol) {
                         if (++cyc > P.cycle_tol) { flag = EXIT_CYCLE; break; }
                     } else { best = fval; cyc = 0; }
                 } else {
-                    lam = __builtin_fma(alpha, ls - lam, lam);
+                    lam = wv_fma(alpha, ls - lam, lam);
                     ldl_remove(rm);
                 }
             } else {
                 // singular working set: direction p with M_W' p = 0, p_sing = +-1
                 const int sg = sing;
-                double acc = (lane < sg) ? -L[lane * ldc + sg] : 0.0;
+                R acc = (lane < sg) ? -L[lane * ldc + sg] : (R)0;
                 acc = sweep_bwd(acc, sg - 1);
-                if (lane == sg) acc = 1.0;
-                if (lane > sg) acc = 0.0;
+                if (lane == sg) acc = (R)1;
+                if (lane > sg) acc = (R)0;
                 if (__builtin_amdgcn_readlane(poslow, sg)) acc = -acc;
                 ls = acc;
                 blocking(true, alpha, rm);
                 if (rm < 0) { flag = EXIT_INFEASIBLE; break; }
-                lam = __builtin_fma(alpha, ls, lam);
+                lam = wv_fma(alpha, ls, lam);
                 ldl_remove(rm);
             }
             iter++;
@@ -381,7 +574,7 @@ __global__ __launch_bounds__(256) void wave_kernel(
             // depth-first branch and bound; stack entry d lives on lane d
             int stk_j = 0, stk_side = 0, stk_tried = 0;
             int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
-            double ubest = 0.0, bestval = P.fval_bound;
+            R ubest = (R)0, bestval = (R)P.fval_bound;
             unsigned bestact = 0u, bestlow = 0u;
             for (;;) {
                 if (nodes >= 100000) { bflag = EXIT_ITERLIMIT; break; }
@@ -409,25 +602,20 @@ __global__ __launch_bounds__(256) void wave_kernel(
                         const int j = lane + 64 * r;
                         if (j < m && (sense0[r] & SENSE_BINARY) && !((actb >> r) & 1u)) cand = j;
                     }
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        const int o = __shfl_xor(cand, off);
-                        cand = o < cand ? o : cand;
-                    }
-                    const int jb = __builtin_amdgcn_readfirstlane(cand);
+                    const int jb = wv_min(cand);
                     if (jb == 0x7fffffff) {              // leaf: every binary sits on a bound
                         if (!have || fval < bestval) {
                             have = 1; bestval = fval; ubest = u; bestact = actb; bestlow = lowb;
                         }
                     } else {
-                        double Mu = 0.0;
-                        for (int k = 0; k < n; k++) Mu = __builtin_fma(Mr[(size_t)jb * n + k], wv_bcast(u, k), Mu);
-                        double bj = 0.0;
+                        R Mu = (R)0;
+                        for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], wv_bcast(u, k), Mu);
+                        R bj = (R)0;
 #pragma unroll
                         for (int r = 0; r < MR; r++) if (r == (jb >> 6)) bj = b[r];
                         bj = wv_bcast(bj, jb & 63);
-                        const double dlo = C[P.odl + jb] + bj, dup = C[P.odu + jb] + bj;
-                        const int lower_first = (Mu - dlo) < (dup - Mu) ? 1 : 0;
+                        const R dlo = C[P.odl + jb] + bj, dup = C[P.odu + jb] + bj;
+                        const int lower_first = (wv_first(Mu) - dlo) < (dup - wv_first(Mu)) ? 1 : 0;
                         if (lane == depth) { stk_j = jb; stk_side = lower_first; stk_tried = 1; }
                         depth++;
                         descend = true;
@@ -439,7 +627,7 @@ __global__ __launch_bounds__(256) void wave_kernel(
                     if (lane == depth - 1) { stk_side ^= 1; stk_tried = 2; }
                 }
             }
-            u = have ? ubest : 0.0;
+            u = have ? ubest : (R)0;
             actb = have ? bestact : 0u;
             lowb = have ? bestlow : 0u;
             flag = have ? (bflag == EXIT_ITERLIMIT ? EXIT_ITERLIMIT : EXIT_OPTIMAL) : bflag;
@@ -448,14 +636,19 @@ __global__ __launch_bounds__(256) void wave_kernel(
 
         // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k writes output k
         {
-            double xs = 0.0;
-            for (int c = 0; c < n; c++) {
-                const double v = wv_bcast(u, c);
-                if (lane < P.nout) xs = __builtin_fma(C[P.oRout + lane * n + c], v, xs);
+            R xs = (R)0;
+            const int lout = lane < P.nout ? lane : P.nout - 1;
+            for (int c0 = 0; c0 < n; c0 += CH) {
+                R rv[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) rv[q] = C[P.oRout + (size_t)lout * n + (c0 + q < n ? c0 + q : n - 1)];
+#pragma unroll
+                for (int q = 0; q < CH; q++)
+                    if (c0 + q < n) xs = wv_fma(rv[q], wv_bcast(u, c0 + q), xs);
             }
             if (lane < P.nout) {
-                double sh = C[P.ox0 + lane];
-                for (int t = 0; t < nth; t++) sh = __builtin_fma(C[P.oXth + lane * nth + t], th[t], sh);
+                R sh = C[P.ox0 + lane];
+                for (int t = 0; t < nth; t++) sh = wv_fma(C[P.oXth + lane * nth + t], th[t], sh);
                 X[pid * P.nout + lane] = xs + sh;
             }
         }
@@ -483,6 +676,13 @@ __global__ __launch_bounds__(256) void wave_kernel(
         if (lane == 0) {
             exitflag[pid] = flag;
             if (iters) iters[pid] = iter;
+        }
+        if (++kin < qchunk) {
+            pid++;
+        } else {
+            kin = 0;
+            chunk = queue != nullptr ? gwaves + (long long)__builtin_amdgcn_readfirstlane(ticket) : chunk + gwaves;
+            pid = chunk * qchunk;
         }
     }
 }

@@ -270,6 +270,26 @@ def test_wave_kernel_matches_oracle_and_lane_kernel(lmpc, name):
     _compare(qp, g["theta"][ok], warm=g["active"][ok])
 
 
+def test_wave_kernel_problem_queue(lmpc):
+    # large batch: the wavefront kernel hands problems out through its shared counter in chunks of
+    # several problems per ticket; results must not depend on who solved what (bit-identical to the
+    # static split, to the lane kernel, and -- on a sample -- to the oracle)
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g)
+    rng = np.random.default_rng(11)
+    N = 600_001
+    theta = np.hstack([rng.uniform(-20, 20, (N, 5)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    xl, efl, itl, actl = qp.solve(theta)
+    qp.set_option("wave", 1)
+    xq, efq, itq, actq = qp.solve(theta)
+    qp.set_option("wave_queue", 0)
+    xs, efs, its, acts = qp.solve(theta)
+    for a, b, c in ((xl, xq, xs), (efl, efq, efs), (itl, itq, its), (actl, actq, acts)):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    qp.set_option("wave_queue", 1)
+    _compare(qp, theta[-5000:])
+
+
 def test_K8_soft_constraints_through_c_abi(lmpc):
     # /root/reference/docs/src/manual/simple.md:98-107: u = -1 at x = [0.5, 1], r = [0, 0]
     g = load_golden("soft_doc")
