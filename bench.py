@@ -55,27 +55,37 @@ def make_theta(name, n, seed, hard=False):
         return np.ascontiguousarray(np.hstack([x, r, np.zeros((n, 1)), rng.uniform(-2, 2, (n, 1))]))
     if name in ("mass_spring", "mass_spring_3in"):
         return np.ascontiguousarray(rng.uniform(-4, 4, (n, 12)))
+    if name == "satellite20":   # hybrid MPC, theta = [x(3); r(3)] (reference mpc_examples.jl:533-546, runtests.jl:820-834)
+        return np.ascontiguousarray(np.hstack([rng.uniform(-0.3, 0.3, (n, 1)), rng.uniform(-0.5, 0.5, (n, 2)),
+                                               rng.uniform(-0.5, 0.5, (n, 1)), np.zeros((n, 2))]))
     if name == "soft_doc":      # docs example with soft output bounds (reference docs/src/manual/simple.md:60-83)
         return np.ascontiguousarray(np.hstack([rng.uniform(-1, 2, (n, 2)), rng.uniform(0, 1, (n, 2)),
                                                rng.uniform(-3, 3, (n, 1))]))
     raise ValueError(name)
 
 
-def algorithmic_bytes(nth, nout):
+def algorithmic_bytes(nth, nout, real_bytes=8):
     # read theta (8*nth) + write x (8*nout) + write exit flag (4); SURVEY.md section 8(d)
-    return 8 * nth + 8 * nout + 4
+    return real_bytes * nth + real_bytes * nout + 4
 
 
-def cpu_baseline(g, theta, nout, min_seconds=10.0):
-    """Single-thread CPU oracle (the restated DAQP algorithm) on the same batch; a reported
-    baseline, not the product path."""
+def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False):
+    """Single-thread CPU oracle (the restated DAQP algorithm) on a bounded sample of the same batch
+    (about 10-20 s of CPU work); a reported baseline, not the product path."""
     from oracle import ldp as oldp
+    dt_ = np.float32 if f32 else np.float64
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
-    oldp.solve_batch(L, theta[:1000])
+    probe = min(1000, theta.shape[0])
+    t0 = time.perf_counter()
+    oldp.solve_batch(L, theta[:probe], dtype=dt_)
+    per = (time.perf_counter() - t0) / probe
+    # sample: the leading rows of the batch, sized so that one pass takes ~2 s at most
+    ns = int(min(theta.shape[0], max(probe, 2.0 / max(per, 1e-9))))
+    sample = theta[:ns]
     t0 = time.perf_counter()
     passes = 0
     while True:
-        oldp.solve_batch(L, theta)
+        oldp.solve_batch(L, sample, dtype=dt_)
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= min_seconds or passes >= 200:
@@ -89,9 +99,9 @@ def cpu_baseline(g, theta, nout, min_seconds=10.0):
                     break
     except OSError:
         pass
-    return {"value": passes * theta.shape[0] / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} passes over the same {theta.shape[0]}-point batch, 1 thread of "
-                      f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c built -O2 -mfma"}
+    return {"value": passes * ns / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} passes over the first {ns} points of the same batch, 1 thread of "
+                      f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c ({'binary32' if f32 else 'binary64'} build) -O2 -mfma"}
 
 
 def main():
@@ -99,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc"])
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc", "hybrid"])
+    ap.add_argument("--f32", action="store_true",
+                    help="binary32 path (lmpc_solve_batch_f32_device; wavefront kernel; reference codegen float_type=float)")
     ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,13 +156,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    name = "pendulum" if args.workload.startswith("pendulum") else args.workload
+    name = "pendulum" if args.workload.startswith("pendulum") else ("satellite20" if args.workload == "hybrid" else args.workload)
     hard = args.workload == "pendulum_hard"
     g = make_problem(name)
     nout = int(g["nu"])
     nstreams = max(1, min(8, args.streams))
+    tdt = torch.float32 if args.f32 else torch.float64
     qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
-                                    g["senses"], nout=nout, device=local_rank) for _ in range(nstreams)]
+                                    g["senses"], nout=nout, device=local_rank,
+                                    settings=lmpc.default_settings_f32() if args.f32 else None) for _ in range(nstreams)]
     qp = qps[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     stream_handles = [s_.cuda_stream for s_ in streams]
@@ -180,19 +194,19 @@ def main():
             q_.set_option("ablate", args.ablate)
     n_local = args.batch
     theta_h = make_theta(name, n_local, 1234 + rank, hard)
-    theta = torch.from_numpy(theta_h).to(dev)
+    theta = torch.from_numpy(theta_h).to(dev).to(tdt)
 
     # double-buffered outputs so the gather of step k overlaps the solve of step k+1
     nbuf = max(2, nstreams)
-    xbuf = [torch.empty((n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    xbuf = [torch.empty((n_local, nout), dtype=tdt, device=dev) for _ in range(nbuf)]
     fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
     if final_gather:
-        xfin = torch.empty((world * n_local, nout), dtype=torch.float64, device=dev)
+        xfin = torch.empty((world * n_local, nout), dtype=tdt, device=dev)
         ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev)
     if do_gather:
-        xall = [torch.empty((world * n_local, nout), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        xall = [torch.empty((world * n_local, nout), dtype=tdt, device=dev) for _ in range(nbuf)]
         fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     pending = [None] * nbuf
 
@@ -282,7 +296,7 @@ def main():
     if rank == 0:
         total = world * n_local * args.steps
         value = total / elapsed
-        bytes_per = algorithmic_bytes(qp.nth, nout)
+        bytes_per = algorithmic_bytes(qp.nth, nout, 4 if args.f32 else 8)
         # One batch in flight: algorithmic bytes of a call / its device time (HIP events on the launch
         # stream).  Several batches in flight: their launches overlap on the chip, a single launch no
         # longer owns it, so the bytes one step moves are divided by the wall time one step takes
@@ -302,7 +316,7 @@ def main():
                       if args.workload == "pendulum" else f"condensed-MPC QP solves/sec ({args.workload})",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.f32 else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: "
                        + ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 "
@@ -310,7 +324,7 @@ def main():
                           if name == "pendulum" else ("mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), "
                                                       if name == "mass_spring" else f"{name} (n={qp.n}, m={qp.m}, nth={qp.nth}), "))
                        + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
-                       "batch_per_gpu": n_local, "kernel": qp.kernel_name, "batches_in_flight": nstreams,
+                       "batch_per_gpu": n_local, "kernel": "wave" if args.f32 else qp.kernel_name, "batches_in_flight": nstreams,
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
                                   else "all_gather(x, exitflag) over RCCL once, after the last step" if final_gather
                                   else "none"),
@@ -328,7 +342,7 @@ def main():
                          "solves_per_s_per_cu": value / world / 256.0},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, theta_h, nout)
+            out["cpu_baseline"] = cpu_baseline(g, theta_h, nout, f32=args.f32)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

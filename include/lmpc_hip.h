@@ -149,6 +149,26 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
                             int32_t *exitflag, int32_t *iters, uint64_t *active,
                             const uint64_t *warm, void *stream);
 
+/*
+ * The same hot path in binary32 -- the reference's single-precision build of this path
+ * (codegen.jl:19,31-37,82: float_type = "float" makes `c_float` a float and compiles DAQP with
+ * DAQP_SINGLE_PRECISION, so mpc_compute_control takes and returns floats).  theta and x are float
+ * records; the constant pack is the handle's binary64 pack rounded to binary32 on the first call;
+ * tolerances are the handle's settings rounded to binary32 -- give the handle settings that make
+ * sense at that precision (lmpc_default_settings_f32: primal 1e-4, dual 1e-6, zero 1e-6,
+ * progress 1e-4, rho_soft 1e-3; libdaqp's own single-precision defaults live in a header that is
+ * not part of the reference tree).  Runs on the wavefront kernel (any handle whose problem it covers:
+ * n <= 63, n + 1 + #soft <= 64, 1 <= m <= 256), including branch and bound over BINARY rows
+ * (BASELINE config 5); LMPC_ERR_UNSUPPORTED otherwise.
+ */
+void lmpc_default_settings_f32(lmpc_settings *s);
+int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x,
+                         int32_t *exitflag, int32_t *iters, uint64_t *active,
+                         const uint64_t *warm);
+int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, float *x,
+                                int32_t *exitflag, int32_t *iters, uint64_t *active,
+                                const uint64_t *warm, void *stream);
+
 /* N = 1 convenience with DAQP.solve's shape: returns the exit flag (or an LMPC_ERR_* <= -100),
  * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call. */
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);

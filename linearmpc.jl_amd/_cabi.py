@@ -20,7 +20,8 @@ ERR_NAMES = {-1: "INFEASIBLE", -5: "NONCONVEX", -6: "OVERDETERMINED", -100: "BAD
 SYMBOLS = (
     "lmpc_abi_version", "lmpc_default_settings", "lmpc_setup", "lmpc_setup_ldp", "lmpc_transform",
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
-    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one", "lmpc_simulate",
+    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one",
+    "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
     "lmpc_simulate_device", "lmpc_kernel_name",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
@@ -74,6 +75,12 @@ def lib():
     L.lmpc_solve_batch.restype = i32
     L.lmpc_solve_batch_device.argtypes = [vp, i64] + [vp] * 7
     L.lmpc_solve_batch_device.restype = i32
+    L.lmpc_default_settings_f32.argtypes = [ctypes.POINTER(Settings)]
+    L.lmpc_default_settings_f32.restype = None
+    L.lmpc_solve_batch_f32.argtypes = [vp, i64] + [vp] * 6
+    L.lmpc_solve_batch_f32.restype = i32
+    L.lmpc_solve_batch_f32_device.argtypes = [vp, i64] + [vp] * 7
+    L.lmpc_solve_batch_f32_device.restype = i32
     L.lmpc_solve_one.argtypes = [vp, vp, vp]
     L.lmpc_solve_one.restype = i32
     L.lmpc_simulate.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32]
@@ -99,6 +106,12 @@ def lib():
 def default_settings() -> Settings:
     s = Settings()
     lib().lmpc_default_settings(ctypes.byref(s))
+    return s
+
+
+def default_settings_f32() -> Settings:
+    s = Settings()
+    lib().lmpc_default_settings_f32(ctypes.byref(s))
     return s
 
 

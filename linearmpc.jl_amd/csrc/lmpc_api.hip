@@ -63,6 +63,7 @@ struct lmpc_handle {
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     WaveLayout W{};
     double *dCw = nullptr;
+    float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
     int32_t *dSw = nullptr;
     int numCU = 256;
     // closed-loop simulation scratch
@@ -391,6 +392,39 @@ int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
     return launch_wave_t<double>(h, h->dCw, nprob, theta, x, flag, iters, active, warm, st);
 }
 
+// binary32 constant pack of the wave kernel (same layout as the binary64 one): every array of the
+// f64 pack rounded to nearest, the Gram matrix re-accumulated IN binary32 from the rounded rows with
+// the same fma chain, so that a lookup stays bit-identical to recomputing the product in binary32.
+int ensure_f32(lmpc_handle *h) {
+    if (h->dCwf) return LMPC_OK;
+    if (!h->dCw)
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: the binary32 path runs on the wavefront kernel, which does not "
+                                             "cover this problem (n <= 63, n+1+#soft <= 64, 1 <= m <= 256)");
+    const HostPack &P = h->P;
+    const WaveLayout &Wl = h->W;
+    const size_t total = (size_t)Wl.oXth + (size_t)P.nout * P.nth;
+    std::vector<float> wb(total ? total : 1, 0.f);
+    std::vector<float> Mf((size_t)P.m * P.n);
+    for (size_t i = 0; i < Mf.size(); i++) Mf[i] = (float)P.M[i];
+    std::memcpy(&wb[Wl.oM], Mf.data(), sizeof(float) * Mf.size());
+    for (int j = 0; j < P.m; j++)
+        for (int k = 0; k < P.n; k++) wb[Wl.oMt + (size_t)k * P.m + j] = Mf[(size_t)j * P.n + k];
+    for (int a = 0; a < P.m; a++)
+        for (int b = 0; b <= a; b++) {
+            float acc = 0.f;
+            for (int k = 0; k < P.n; k++) acc = std::fmaf(Mf[(size_t)a * P.n + k], Mf[(size_t)b * P.n + k], acc);
+            wb[Wl.oG + (size_t)lmpc_tri(a) + b] = acc;
+        }
+    for (int j = 0; j < P.m; j++) { wb[Wl.odu + j] = (float)P.du0[j]; wb[Wl.odl + j] = (float)P.dl0[j]; }
+    for (size_t i = 0; i < P.Dth.size(); i++) wb[Wl.oDth + i] = (float)P.Dth[i];
+    for (size_t i = 0; i < P.Rout.size(); i++) wb[Wl.oRout + i] = (float)P.Rout[i];
+    for (size_t i = 0; i < P.x0.size(); i++) wb[Wl.ox0 + i] = (float)P.x0[i];
+    for (size_t i = 0; i < P.Xth.size(); i++) wb[Wl.oXth + i] = (float)P.Xth[i];
+    HIP_TRY(h, hipMalloc(&h->dCwf, sizeof(float) * wb.size()));
+    HIP_TRY(h, hipMemcpy(h->dCwf, wb.data(), sizeof(float) * wb.size(), hipMemcpyHostToDevice));
+    return LMPC_OK;
+}
+
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     if (h->useWave) return launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
@@ -490,6 +524,12 @@ void lmpc_default_settings(lmpc_settings *s) {
     if (!s) return;
     s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
     s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+}
+
+void lmpc_default_settings_f32(lmpc_settings *s) {
+    if (!s) return;
+    s->primal_tol = 1e-4; s->dual_tol = 1e-6; s->zero_tol = 1e-6; s->progress_tol = 1e-4;
+    s->fval_bound = 1e30; s->rho_soft = 1e-3; s->cycle_tol = 10; s->iter_limit = 10000;
 }
 
 int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
@@ -609,6 +649,49 @@ int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x, 
     rc = launch(h, N, h->sTheta, h->sX, h->sFlag, h->sIter, h->sAct, warm ? h->sWarm : nullptr, nullptr);
     if (rc != LMPC_OK) return rc;
     HIP_TRY(h, hipMemcpy(x, h->sX, sizeof(double) * (size_t)N * h->P.nout, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(exitflag, h->sFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(h, hipMemcpy(iters, h->sIter, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+    if (active) HIP_TRY(h, hipMemcpy(active, h->sAct, sizeof(uint64_t) * (size_t)N * w, hipMemcpyDeviceToHost));
+    return LMPC_OK;
+}
+
+int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
+                                int32_t *iters, uint64_t *active, const uint64_t *warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch_f32_device: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    if (N > (int64_t)0x7fffffff * 64) return fail(h, LMPC_ERR_BADARG, "lmpc: batch too large for one launch");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_f32(h);
+    if (rc != LMPC_OK) return rc;
+    return launch_wave_t<float>(h, h->dCwf, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
+}
+
+int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
+                         int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch_f32: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_f32(h);
+    if (rc == LMPC_OK) rc = ensure_staging(h, N, warm != nullptr);
+    if (rc != LMPC_OK) return rc;
+    const size_t w = (size_t)h->P.words();
+    float *dTh = reinterpret_cast<float *>(h->sTheta), *dX = reinterpret_cast<float *>(h->sX);   // f64-sized staging
+    if (h->P.nth > 0)
+        HIP_TRY(h, hipMemcpy(dTh, theta, sizeof(float) * (size_t)N * h->P.nth, hipMemcpyHostToDevice));
+    if (warm) HIP_TRY(h, hipMemcpy(h->sWarm, warm, sizeof(uint64_t) * (size_t)N * w, hipMemcpyHostToDevice));
+    rc = launch_wave_t<float>(h, h->dCwf, N, dTh, dX, h->sFlag, h->sIter, h->sAct, warm ? h->sWarm : nullptr, nullptr);
+    if (rc != LMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpy(x, dX, sizeof(float) * (size_t)N * h->P.nout, hipMemcpyDeviceToHost));
     HIP_TRY(h, hipMemcpy(exitflag, h->sFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
     if (iters) HIP_TRY(h, hipMemcpy(iters, h->sIter, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
     if (active) HIP_TRY(h, hipMemcpy(active, h->sAct, sizeof(uint64_t) * (size_t)N * w, hipMemcpyDeviceToHost));
@@ -774,7 +857,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
-    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dSw); hipFree(h->dQueue);
+    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     delete h;
 }

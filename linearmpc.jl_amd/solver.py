@@ -149,6 +149,25 @@ class BatchedQP:
                                      _ptr(w) if w is not None else None), self._h)
         return x, ef, it, act
 
+    def solve_f32(self, theta, warm=None, want_iters=True, want_active=True):
+        """Binary32 solve (`lmpc_solve_batch_f32`; reference codegen.jl:19 float_type="float"):
+        float32 host arrays in and out, wavefront kernel."""
+        theta = np.ascontiguousarray(np.asarray(theta, np.float32).reshape(-1, self.nth) if self.nth
+                                     else np.zeros((len(theta), 0), np.float32))
+        N = theta.shape[0]
+        x = np.empty((N, self.nout), np.float32)
+        ef = np.empty(N, np.int32)
+        it = np.empty(N, np.int32) if want_iters else None
+        act = np.zeros((N, self.words), np.uint64) if want_active else None
+        w = None
+        if warm is not None:
+            w = np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, self.words))
+        check(lib().lmpc_solve_batch_f32(self._h, N, _ptr(theta), _ptr(x), _ptr(ef),
+                                         _ptr(it) if it is not None else None,
+                                         _ptr(act) if act is not None else None,
+                                         _ptr(w) if w is not None else None), self._h)
+        return x, ef, it, act
+
     def solve_one(self, theta):
         """DAQP.solve shape for one theta: (x*, exitflag) (`lmpc_solve_one`)."""
         theta = _f64(np.asarray(theta, float).reshape(self.nth))
@@ -162,18 +181,21 @@ class BatchedQP:
         """Device-resident batch (`lmpc_solve_batch_device`): torch CUDA tensors in and out, the
         launch is enqueued on `stream` (default: torch's current stream) and NOT synchronised."""
         import torch
-        if not theta.is_cuda or theta.dtype != torch.float64 or not theta.is_contiguous():
-            raise ValueError("theta must be a contiguous float64 CUDA tensor of shape (N, nth)")
+        if not theta.is_cuda or theta.dtype not in (torch.float64, torch.float32) or not theta.is_contiguous():
+            raise ValueError("theta must be a contiguous float64 (or float32: binary32 path) CUDA tensor of shape (N, nth)")
         if theta.device.index != self.device:
             raise ValueError("theta lives on a different GPU than this handle")
         N = theta.shape[0]
         dev = theta.device
         if x is None:
-            x = torch.empty((N, self.nout), dtype=torch.float64, device=dev)
+            x = torch.empty((N, self.nout), dtype=theta.dtype, device=dev)
+        if x.dtype != theta.dtype:
+            raise ValueError("x and theta must have the same dtype")
         if exitflag is None:
             exitflag = torch.empty(N, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-        check(lib().lmpc_solve_batch_device(
+        fn = lib().lmpc_solve_batch_device if theta.dtype == torch.float64 else lib().lmpc_solve_batch_f32_device
+        check(fn(
             self._h, N, _vp(theta.data_ptr()), _vp(x.data_ptr()), _vp(exitflag.data_ptr()),
             _vp(iters.data_ptr()) if iters is not None else None,
             _vp(active.data_ptr()) if active is not None else None,

@@ -39,7 +39,7 @@
  * by any reference test ("parity vs DAQP internals: unpinned").
  *
  * Arithmetic contract (shared with the HIP kernels so that results are bit-comparable):
- * IEEE binary64, every multiply-add written as an explicit fma(), sums accumulated in
+ * IEEE binary64 (binary32 in the _f32 build), every multiply-add written as an explicit fma(), sums accumulated in
  * index order, correctly rounded division, pivots applied through their stored reciprocal
  * 1/D_i (one division per new pivot instead of one per use); build with -ffp-contract=off.
  */
@@ -47,6 +47,25 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* The file is type-generic: built as is it is the binary64 oracle; daqp_ldp_oracle_f32.c includes it
+ * with ORACLE_F32 defined, which gives the binary32 twin (every exported name gets the suffix _f32)
+ * that checks the kernels' single-precision path -- the reference's own single-precision build of
+ * this path is /root/reference/src/codegen.jl:19,31-37,82 (float_type = "float": c_float = float,
+ * DAQP_SINGLE_PRECISION). */
+#ifdef ORACLE_F32
+typedef float real;
+#define RFMA fmaf
+#define ORACLE_NAME(x) x##_f32
+#else
+typedef double real;
+#define RFMA fma
+#define ORACLE_NAME(x) x
+#endif
+#define oracle_active_words ORACLE_NAME(oracle_active_words)
+#define oracle_default_settings ORACLE_NAME(oracle_default_settings)
+#define oracle_solve_batch ORACLE_NAME(oracle_solve_batch)
+#define oracle_simulate ORACLE_NAME(oracle_simulate)
 
 #define SENSE_ACTIVE 1
 #define SENSE_LOWER 2
@@ -67,44 +86,59 @@
 
 typedef struct {
     int32_t n, m, ms, nth, nout;
-    const double *M;     /* m x n   row-major, rows normalised                 */
-    const double *du0;   /* m                                                   */
-    const double *dl0;   /* m                                                   */
-    const double *Dth;   /* m x nth row-major                                   */
-    const double *Rout;  /* nout x n row-major: first rows of R^-1              */
-    const double *x0;    /* nout                                                */
-    const double *Xth;   /* nout x nth row-major                                */
+    const real *M;     /* m x n   row-major, rows normalised                 */
+    const real *du0;   /* m                                                   */
+    const real *dl0;   /* m                                                   */
+    const real *Dth;   /* m x nth row-major                                   */
+    const real *Rout;  /* nout x n row-major: first rows of R^-1              */
+    const real *x0;    /* nout                                                */
+    const real *Xth;   /* nout x nth row-major                                */
     const int32_t *sense;/* m                                                   */
 } oracle_ldp;
 
+/* as handed over by the caller: always binary64 (same struct for both builds) */
 typedef struct {
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int32_t cycle_tol, iter_limit;
+} oracle_settings_abi;
+
+/* what the solver compares against: the caller's tolerances rounded to the working precision */
+typedef struct {
+    real primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
+    int32_t cycle_tol, iter_limit;
 } oracle_settings;
+
+static oracle_settings settings_from_abi(const oracle_settings_abi *a) {
+    oracle_settings s;
+    s.primal_tol = (real)a->primal_tol; s.dual_tol = (real)a->dual_tol; s.zero_tol = (real)a->zero_tol;
+    s.progress_tol = (real)a->progress_tol; s.fval_bound = (real)a->fval_bound; s.rho_soft = (real)a->rho_soft;
+    s.cycle_tol = a->cycle_tol; s.iter_limit = a->iter_limit;
+    return s;
+}
 
 typedef struct {
     int n, m, cap, na, sing, reuse, nsoft_act;
-    double *L, *D, *Dinv, *lam, *lam_star, *xl, *zl, *u, *dupper, *dlower, *w;
+    real *L, *D, *Dinv, *lam, *lam_star, *xl, *zl, *u, *dupper, *dlower, *w;
     int *WS;
     int32_t *sense;
-    double fval, soft_slack;
+    real fval, soft_slack;
 } work_t;
 
 static work_t *work_new(int n, int m, int nsoft) {
     work_t *w = (work_t *)calloc(1, sizeof(work_t));
     int cap = n + 1 + nsoft;                /* hard rows <= n (+1 singular), soft rows extra */
     w->n = n; w->m = m; w->cap = cap;
-    w->L = (double *)calloc((size_t)TRI(cap + 1), sizeof(double));
-    w->D = (double *)calloc(cap + 1, sizeof(double));
-    w->Dinv = (double *)calloc(cap + 1, sizeof(double));
-    w->lam = (double *)calloc(cap + 1, sizeof(double));
-    w->lam_star = (double *)calloc(cap + 1, sizeof(double));
-    w->xl = (double *)calloc(cap + 1, sizeof(double));
-    w->zl = (double *)calloc(cap + 1, sizeof(double));
-    w->w = (double *)calloc(cap + 1, sizeof(double));
-    w->u = (double *)calloc(n > 0 ? n : 1, sizeof(double));
-    w->dupper = (double *)calloc(m > 0 ? m : 1, sizeof(double));
-    w->dlower = (double *)calloc(m > 0 ? m : 1, sizeof(double));
+    w->L = (real *)calloc((size_t)TRI(cap + 1), sizeof(real));
+    w->D = (real *)calloc(cap + 1, sizeof(real));
+    w->Dinv = (real *)calloc(cap + 1, sizeof(real));
+    w->lam = (real *)calloc(cap + 1, sizeof(real));
+    w->lam_star = (real *)calloc(cap + 1, sizeof(real));
+    w->xl = (real *)calloc(cap + 1, sizeof(real));
+    w->zl = (real *)calloc(cap + 1, sizeof(real));
+    w->w = (real *)calloc(cap + 1, sizeof(real));
+    w->u = (real *)calloc(n > 0 ? n : 1, sizeof(real));
+    w->dupper = (real *)calloc(m > 0 ? m : 1, sizeof(real));
+    w->dlower = (real *)calloc(m > 0 ? m : 1, sizeof(real));
     w->WS = (int *)calloc(cap + 1, sizeof(int));
     w->sense = (int32_t *)calloc(m > 0 ? m : 1, sizeof(int32_t));
     return w;
@@ -119,30 +153,30 @@ static void work_free(work_t *w) {
 /* Append constraint j to the working set: new row of L, new pivot of D (paper sec. IV-A). */
 static void ldl_add(work_t *w, const oracle_ldp *p, const oracle_settings *s, int j) {
     const int n = w->n, na = w->na;
-    double *row = &w->L[TRI(na)];
-    const double *mj = &p->M[(size_t)j * n];
-    double dnew = 0.0;
+    real *row = &w->L[TRI(na)];
+    const real *mj = &p->M[(size_t)j * n];
+    real dnew = 0.0;
     for (int i = 0; i < na; i++) {
-        const double *mi = &p->M[(size_t)w->WS[i] * n];
-        double acc = 0.0;
-        for (int k = 0; k < n; k++) acc = fma(mi[k], mj[k], acc);
+        const real *mi = &p->M[(size_t)w->WS[i] * n];
+        real acc = 0.0;
+        for (int k = 0; k < n; k++) acc = RFMA(mi[k], mj[k], acc);
         row[i] = acc;
     }
-    for (int k = 0; k < n; k++) dnew = fma(mj[k], mj[k], dnew);
+    for (int k = 0; k < n; k++) dnew = RFMA(mj[k], mj[k], dnew);
     /* soft rows: slack measured in the normalised row's units, weight 1/rho_soft -- the
      * convention /root/reference/src/utils.jl:329-364 (make_singlesided) spells out */
     if (w->sense[j] & SENSE_SOFT) dnew += s->rho_soft;
     for (int i = 0; i < na; i++) {          /* q = L \ (M_W m_j) */
-        double acc = row[i];
-        const double *li = &w->L[TRI(i)];
-        for (int t = 0; t < i; t++) acc = fma(-li[t], row[t], acc);
+        real acc = row[i];
+        const real *li = &w->L[TRI(i)];
+        for (int t = 0; t < i; t++) acc = RFMA(-li[t], row[t], acc);
         row[i] = acc;
     }
     for (int i = 0; i < na; i++) {          /* l = D \ q ; d_new = m_j'm_j - sum l_i q_i */
-        double q = row[i];
-        double l = q * w->Dinv[i];
+        real q = row[i];
+        real l = q * w->Dinv[i];
         row[i] = l;
-        dnew = fma(-l, q, dnew);
+        dnew = RFMA(-l, q, dnew);
     }
     row[na] = 1.0;
     const int is_soft = (w->sense[j] & SENSE_SOFT) != 0;
@@ -167,12 +201,12 @@ static void ldl_add(work_t *w, const oracle_ldp *p, const oracle_settings *s, in
  * L~ D~ L~' = L D L' + D_r w w' to the trailing block (paper sec. IV-B). */
 static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
     const int na = w->na, nup = na - r - 1;
-    double *wv = w->w;
-    double alpha = w->D[r];
+    real *wv = w->w;
+    real alpha = w->D[r];
     for (int t = 0; t < nup; t++) wv[t] = w->L[TRI(r + 1 + t) + r];
     for (int i = r; i < na - 1; i++) {      /* new row i = old row i+1 without column r */
-        double *dst = &w->L[TRI(i)];
-        const double *src = &w->L[TRI(i + 1)];
+        real *dst = &w->L[TRI(i)];
+        const real *src = &w->L[TRI(i + 1)];
         for (int c = 0; c < r; c++) dst[c] = src[c];
         for (int c = r; c < i; c++) dst[c] = src[c + 1];
         dst[i] = 1.0;
@@ -180,9 +214,9 @@ static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
     w->sing = -1;
     for (int t = 0; t < nup; t++) {
         const int i = r + t;
-        const double pt = wv[t];
-        const double dold = w->D[i + 1];
-        const double dbar = fma(alpha * pt, pt, dold);
+        const real pt = wv[t];
+        const real dold = w->D[i + 1];
+        const real dbar = RFMA(alpha * pt, pt, dold);
         if (dbar < s->zero_tol) {
             /* only the last pivot can vanish in exact arithmetic; keep the tail shifted */
             w->D[i] = 0.0;
@@ -191,15 +225,15 @@ static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
             for (int q = i + 1; q < na - 1; q++) { w->D[q] = w->D[q + 1]; w->Dinv[q] = w->Dinv[q + 1]; }
             break;
         }
-        const double rinv = 1.0 / dbar;
-        const double beta = (pt * alpha) * rinv;
+        const real rinv = 1.0 / dbar;
+        const real beta = (pt * alpha) * rinv;
         alpha = (dold * alpha) * rinv;
         w->D[i] = dbar;
         w->Dinv[i] = rinv;
         for (int q = t + 1; q < nup; q++) {
-            double *lqi = &w->L[TRI(r + q) + i];
-            wv[q] = fma(-pt, *lqi, wv[q]);
-            *lqi = fma(beta, wv[q], *lqi);
+            real *lqi = &w->L[TRI(r + q) + i];
+            wv[q] = RFMA(-pt, *lqi, wv[q]);
+            *lqi = RFMA(beta, wv[q], *lqi);
         }
     }
     if (w->sense[w->WS[r]] & SENSE_SOFT) w->nsoft_act--;
@@ -217,15 +251,15 @@ static void compute_csp(work_t *w) {
     const int na = w->na;
     for (int i = w->reuse; i < na; i++) {
         const int j = w->WS[i];
-        double acc = (w->sense[j] & SENSE_LOWER) ? -w->dlower[j] : -w->dupper[j];
-        const double *li = &w->L[TRI(i)];
-        for (int t = 0; t < i; t++) acc = fma(-li[t], w->xl[t], acc);
+        real acc = (w->sense[j] & SENSE_LOWER) ? -w->dlower[j] : -w->dupper[j];
+        const real *li = &w->L[TRI(i)];
+        for (int t = 0; t < i; t++) acc = RFMA(-li[t], w->xl[t], acc);
         w->xl[i] = acc;
     }
     for (int i = w->reuse; i < na; i++) w->zl[i] = w->xl[i] * w->Dinv[i];
     for (int i = na - 1; i >= 0; i--) {
-        double acc = w->zl[i];
-        for (int t = na - 1; t > i; t--) acc = fma(-w->L[TRI(t) + i], w->lam_star[t], acc);
+        real acc = w->zl[i];
+        for (int t = na - 1; t > i; t--) acc = RFMA(-w->L[TRI(t) + i], w->lam_star[t], acc);
         w->lam_star[i] = acc;
     }
     w->reuse = na;
@@ -234,10 +268,10 @@ static void compute_csp(work_t *w) {
 /* Direction p with M_W' p = 0 and p_sing = +-1, stored in lam_star. */
 static void singular_direction(work_t *w) {
     const int sg = w->sing;
-    const double *ls = &w->L[TRI(sg)];
+    const real *ls = &w->L[TRI(sg)];
     for (int i = sg - 1; i >= 0; i--) {
-        double acc = -ls[i];
-        for (int t = sg - 1; t > i; t--) acc = fma(-w->L[TRI(t) + i], w->lam_star[t], acc);
+        real acc = -ls[i];
+        for (int t = sg - 1; t > i; t--) acc = RFMA(-w->L[TRI(t) + i], w->lam_star[t], acc);
         w->lam_star[i] = acc;
     }
     w->lam_star[sg] = 1.0;
@@ -247,28 +281,28 @@ static void singular_direction(work_t *w) {
 
 static void primal_and_fval(work_t *w, const oracle_ldp *p, const oracle_settings *s) {
     const int n = w->n;
-    double soft = 0.0;
+    real soft = 0.0;
     for (int k = 0; k < n; k++) w->u[k] = 0.0;
     for (int i = 0; i < w->na; i++) {
         const int j = w->WS[i];
-        const double *mi = &p->M[(size_t)j * n];
-        const double l = w->lam_star[i];
-        for (int k = 0; k < n; k++) w->u[k] = fma(-mi[k], l, w->u[k]);
-        if (w->sense[j] & SENSE_SOFT) soft = fma(l * l, s->rho_soft, soft);
+        const real *mi = &p->M[(size_t)j * n];
+        const real l = w->lam_star[i];
+        for (int k = 0; k < n; k++) w->u[k] = RFMA(-mi[k], l, w->u[k]);
+        if (w->sense[j] & SENSE_SOFT) soft = RFMA(l * l, s->rho_soft, soft);
     }
-    double fv = 0.0;
-    for (int k = 0; k < n; k++) fv = fma(w->u[k], w->u[k], fv);
+    real fv = 0.0;
+    for (int k = 0; k < n; k++) fv = RFMA(w->u[k], w->u[k], fv);
     w->soft_slack = soft;
     w->fval = fv + soft;
 }
 
-static void write_outputs(const work_t *w, const oracle_ldp *p, const double *theta,
-                          double *xout, uint64_t *active, int nwords) {
+static void write_outputs(const work_t *w, const oracle_ldp *p, const real *theta,
+                          real *xout, uint64_t *active, int nwords) {
     const int n = p->n, nth = p->nth;
     for (int k = 0; k < p->nout; k++) {
-        double xs = 0.0, sh = p->x0[k];
-        for (int c = 0; c < n; c++) xs = fma(p->Rout[(size_t)k * n + c], w->u[c], xs);
-        for (int t = 0; t < nth; t++) sh = fma(p->Xth[(size_t)k * nth + t], theta[t], sh);
+        real xs = 0.0, sh = p->x0[k];
+        for (int c = 0; c < n; c++) xs = RFMA(p->Rout[(size_t)k * n + c], w->u[c], xs);
+        for (int t = 0; t < nth; t++) sh = RFMA(p->Xth[(size_t)k * nth + t], theta[t], sh);
         xout[k] = xs + sh;
     }
     if (active) {
@@ -282,11 +316,11 @@ static void write_outputs(const work_t *w, const oracle_ldp *p, const double *th
 }
 
 /* dupper/dlower = du/dl + Dth*theta   (mpc_update_qp.c:1-10) */
-static void shift_bounds(work_t *w, const oracle_ldp *p, const double *theta) {
+static void shift_bounds(work_t *w, const oracle_ldp *p, const real *theta) {
     const int m = p->m, nth = p->nth;
     for (int j = 0; j < m; j++) {
-        double sh = 0.0;
-        for (int t = 0; t < nth; t++) sh = fma(p->Dth[(size_t)j * nth + t], theta[t], sh);
+        real sh = 0.0;
+        for (int t = 0; t < nth; t++) sh = RFMA(p->Dth[(size_t)j * nth + t], theta[t], sh);
         w->dupper[j] = p->du0[j] + sh;
         w->dlower[j] = p->dl0[j] + sh;
     }
@@ -300,7 +334,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                       const uint64_t *warm, int32_t *iters) {
     const int n = p->n, m = p->m;
     int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
-    double best_fval = -1.0;
+    real best_fval = -1.0;
 
     for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
     w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
@@ -329,13 +363,13 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
         if (w->sing < 0) {
             compute_csp(w);
             int nblock = 0, rm = -1;
-            double alpha = 0.0;
+            real alpha = 0.0;
             for (int i = 0; i < w->na; i++) {
                 const int j = w->WS[i];
                 if (w->sense[j] & SENSE_IMMUTABLE) continue;
                 if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
                 else if (w->lam_star[i] > -s->dual_tol) continue;
-                const double cand = -w->lam[i] / (w->lam_star[i] - w->lam[i]);
+                const real cand = -w->lam[i] / (w->lam_star[i] - w->lam[i]);
                 if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
                 nblock++;
             }
@@ -343,15 +377,15 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                 primal_and_fval(w, p, s);
                 if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
                 /* most violated constraint, primal_tol margin */
-                double min_val = -s->primal_tol;
+                real min_val = -s->primal_tol;
                 int add = -1, isupper = 0, broken = 0;
                 for (int j = 0; j < m; j++) {
                     if (w->sense[j] & SENSE_IMMUTABLE) continue;
-                    const double *mj = &p->M[(size_t)j * n];
-                    double Mu = 0.0;
-                    for (int k = 0; k < n; k++) Mu = fma(mj[k], w->u[k], Mu);
-                    const double vu = w->dupper[j] - Mu;
-                    const double vl = -(w->dlower[j] - Mu);
+                    const real *mj = &p->M[(size_t)j * n];
+                    real Mu = 0.0;
+                    for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
+                    const real vu = w->dupper[j] - Mu;
+                    const real vl = -(w->dlower[j] - Mu);
                     if (w->sense[j] & SENSE_ACTIVE) {
                         /* a hard row of the working set sits ON its bound in exact arithmetic; if the
                          * iterate violates it by more than primal_tol the factorisation has broken
@@ -376,24 +410,24 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                 } else { best_fval = w->fval; cycle = 0; }
             } else {
                 for (int i = 0; i < w->na; i++)
-                    w->lam[i] = fma(alpha, w->lam_star[i] - w->lam[i], w->lam[i]);
+                    w->lam[i] = RFMA(alpha, w->lam_star[i] - w->lam[i], w->lam[i]);
                 ldl_remove(w, s, rm);
             }
         } else {
             singular_direction(w);
             int nblock = 0, rm = -1;
-            double alpha = 0.0;
+            real alpha = 0.0;
             for (int i = 0; i < w->na; i++) {
                 const int j = w->WS[i];
                 if (w->sense[j] & SENSE_IMMUTABLE) continue;
                 if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
                 else if (w->lam_star[i] > -s->dual_tol) continue;
-                const double cand = -w->lam[i] / w->lam_star[i];
+                const real cand = -w->lam[i] / w->lam_star[i];
                 if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
                 nblock++;
             }
             if (nblock == 0) { exitflag = EXIT_INFEASIBLE; break; }
-            for (int i = 0; i < w->na; i++) w->lam[i] = fma(alpha, w->lam_star[i], w->lam[i]);
+            for (int i = 0; i < w->na; i++) w->lam[i] = RFMA(alpha, w->lam_star[i], w->lam[i]);
             ldl_remove(w, s, rm);
         }
     }
@@ -403,7 +437,7 @@ done:
 }
 
 static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
-                     const double *theta, const uint64_t *warm, double *xout,
+                     const real *theta, const uint64_t *warm, real *xout,
                      int32_t *iters, uint64_t *active, int nwords) {
     shift_bounds(w, p, theta);
     const int ef = solve_core(w, p, s, p->sense, warm, iters);
@@ -425,16 +459,16 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
  * iters returns the iterations summed over all nodes; the flag is 1 if an incumbent exists,
  * -1 if none, -4 if the node limit ran out first. */
 #define BNB_NODE_LIMIT 100000
-static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, const double *theta,
-                     double *xout, int32_t *iters, uint64_t *active, int nwords) {
+static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, const real *theta,
+                     real *xout, int32_t *iters, uint64_t *active, int nwords) {
     const int n = p->n, m = p->m;
     int32_t *sense = (int32_t *)malloc(sizeof(int32_t) * (m > 0 ? m : 1));
     int *stk_j = (int *)malloc(sizeof(int) * (m + 1)), *stk_side = (int *)malloc(sizeof(int) * (m + 1)),
         *stk_tried = (int *)malloc(sizeof(int) * (m + 1));
-    double *ubest = (double *)calloc(n, sizeof(double));
+    real *ubest = (real *)calloc(n, sizeof(real));
     uint64_t *abest = (uint64_t *)calloc(nwords > 0 ? nwords : 1, sizeof(uint64_t));
     oracle_settings sn = *s;
-    double best = s->fval_bound;
+    real best = s->fval_bound;
     int have = 0, depth = 0, nodes = 0, total_it = 0, flag = EXIT_INFEASIBLE;
     shift_bounds(w, p, theta);
     for (;;) {
@@ -464,9 +498,9 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
                     }
                 }
             } else {
-                const double *mj = &p->M[(size_t)jb * n];
-                double Mu = 0.0;
-                for (int k = 0; k < n; k++) Mu = fma(mj[k], w->u[k], Mu);
+                const real *mj = &p->M[(size_t)jb * n];
+                real Mu = 0.0;
+                for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
                 const int lower_first = (Mu - w->dlower[jb]) < (w->dupper[jb] - Mu);
                 stk_j[depth] = jb; stk_side[depth] = lower_first; stk_tried[depth] = 1;
                 depth++;
@@ -497,17 +531,23 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
 /* ---------------------------------------------------------------- exported entry points */
 int oracle_active_words(int m) { return (2 * m + 63) / 64; }
 
-void oracle_default_settings(oracle_settings *s) {
+void oracle_default_settings(oracle_settings_abi *s) {
+#ifdef ORACLE_F32
+    s->primal_tol = 1e-4; s->dual_tol = 1e-6; s->zero_tol = 1e-6; s->progress_tol = 1e-4;
+    s->fval_bound = 1e30; s->rho_soft = 1e-3; s->cycle_tol = 10; s->iter_limit = 10000;
+#else
     s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
     s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+#endif
 }
 
 /* theta: N rows of nth; X: N rows of nout; active: N rows of nwords (may be NULL);
  * warm: N rows of nwords initial working sets (may be NULL = cold start). */
-void oracle_solve_batch(const oracle_ldp *p, const oracle_settings *s, int64_t N,
-                        const double *theta, const uint64_t *warm, double *X,
+void oracle_solve_batch(const oracle_ldp *p, const oracle_settings_abi *sabi, int64_t N,
+                        const real *theta, const uint64_t *warm, real *X,
                         int32_t *exitflag, int32_t *iters, uint64_t *active) {
     const int nw = oracle_active_words(p->m);
+    const oracle_settings sr = settings_from_abi(sabi), *s = &sr;
     int nsoft = 0;
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
@@ -530,21 +570,22 @@ void oracle_solve_batch(const oracle_ldp *p, const oracle_settings *s, int64_t N
  * u = compute_control, x <- F x + G u (sums in index order, F then G), uprev <- u.
  * warm != 0 reuses the previous step's final working set (generated-C DAQP_WARMSTART,
  * /root/reference/codegen/mpc_update_qp.c:44-47); the first step is cold.  nout must equal nu. */
-void oracle_simulate(const oracle_ldp *p, const oracle_settings *s, int64_t N, int32_t T, int32_t nx,
-                     int32_t nr, int32_t nup, const double *F, const double *G, double *x,
-                     const double *r, double *uprev, double *U, double *X, int32_t *flag_min,
+void oracle_simulate(const oracle_ldp *p, const oracle_settings_abi *sabi, int64_t N, int32_t T, int32_t nx,
+                     int32_t nr, int32_t nup, const real *F, const real *G, real *x,
+                     const real *r, real *uprev, real *U, real *X, int32_t *flag_min,
                      int32_t warm) {
     const int nw = oracle_active_words(p->m), nu = p->nout, nth = p->nth;
+    const oracle_settings sr = settings_from_abi(sabi), *s = &sr;
     int nsoft = 0, nbin = 0;
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
     for (int j = 0; j < p->m; j++) nbin += (p->sense[j] & SENSE_BINARY) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
-    double *th = (double *)calloc(nth > 0 ? nth : 1, sizeof(double));
-    double *u = (double *)calloc(nu, sizeof(double));
-    double *xn = (double *)calloc(nx, sizeof(double));
+    real *th = (real *)calloc(nth > 0 ? nth : 1, sizeof(real));
+    real *u = (real *)calloc(nu, sizeof(real));
+    real *xn = (real *)calloc(nx, sizeof(real));
     uint64_t *act = (uint64_t *)calloc(nw, sizeof(uint64_t));
     for (int64_t i = 0; i < N; i++) {
-        double *xi = x + i * nx;
+        real *xi = x + i * nx;
         if (X) for (int a = 0; a < nx; a++) X[(size_t)i * nx + a] = xi[a];
         for (int k = 0; k < T; k++) {
             for (int a = 0; a < nx; a++) th[a] = xi[a];
@@ -554,9 +595,9 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings *s, int64_t N, i
             int ef = nbin ? solve_bnb(w, p, s, th, u, &it, act, nw)      /* B&B nodes start cold */
                           : solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
             for (int a = 0; a < nx; a++) {
-                double acc = 0.0;
-                for (int c = 0; c < nx; c++) acc = fma(F[a * nx + c], xi[c], acc);
-                for (int l = 0; l < nu; l++) acc = fma(G[a * nu + l], u[l], acc);
+                real acc = 0.0;
+                for (int c = 0; c < nx; c++) acc = RFMA(F[a * nx + c], xi[c], acc);
+                for (int l = 0; l < nu; l++) acc = RFMA(G[a * nu + l], u[l], acc);
                 xn[a] = acc;
             }
             for (int a = 0; a < nx; a++) {

@@ -114,7 +114,8 @@ _lib = None
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "daqp_ldp_oracle.c")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                              for f in ("daqp_ldp_oracle.c", "daqp_ldp_oracle_f32.c", "Makefile")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -126,6 +127,7 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_active_words.restype = ctypes.c_int
         _lib.oracle_solve_batch.restype = None
+        _lib.oracle_solve_batch_f32.restype = None
     return _lib
 
 
@@ -135,31 +137,42 @@ def default_settings() -> Settings:
     return s
 
 
+def default_settings_f32() -> Settings:
+    """Tolerances that make sense in binary32 (this build's choice; libdaqp's own single-precision
+    defaults live in a header outside the reference tree)."""
+    s = Settings()
+    lib().oracle_default_settings_f32(ctypes.byref(s))
+    return s
+
+
 def active_words(m):
     return (2 * m + 63) // 64
 
 
-def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None):
-    """Solve every row of theta (N x nth).  Returns X (N x nout), exitflag, iters, active."""
+def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None, dtype=np.float64):
+    """Solve every row of theta (N x nth).  Returns X (N x nout), exitflag, iters, active.
+
+    dtype=np.float32 runs the binary32 build of the oracle on the pack rounded to binary32 (what the
+    library's f32 path does with its binary64 pack)."""
     L = lib()
     ldp.contiguous()
-    theta = np.asarray(theta, np.float64)
+    f32 = np.dtype(dtype) == np.float32
+    theta = np.asarray(theta, dtype)
     theta = np.ascontiguousarray(theta.reshape(-1, ldp.nth) if ldp.nth else theta.reshape(len(theta), 0))
     N = theta.shape[0]
     nw = active_words(ldp.m)
-    X = np.empty((N, ldp.nout))
+    X = np.empty((N, ldp.nout), dtype)
     ef = np.empty(N, np.int32)
     it = np.empty(N, np.int32)
     act = np.zeros((N, nw), np.uint64)
-    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout,
-              *(a.ctypes.data for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0,
-                                        ldp.Xth, ldp.sense)))
-    s = settings if settings is not None else default_settings()
+    arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0, ldp.Xth)]
+    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout, *(a.ctypes.data for a in arrs), ldp.sense.ctypes.data)
+    s = settings if settings is not None else (default_settings_f32() if f32 else default_settings())
     wptr = None
     if warm is not None:
         warm = np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, nw))
         wptr = ctypes.c_void_p(warm.ctypes.data)
-    L.oracle_solve_batch(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N),
+    (L.oracle_solve_batch_f32 if f32 else L.oracle_solve_batch)(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N),
                          ctypes.c_void_p(theta.ctypes.data), wptr,
                          ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(ef.ctypes.data),
                          ctypes.c_void_p(it.ctypes.data), ctypes.c_void_p(act.ctypes.data))

@@ -582,3 +582,77 @@ def test_hybrid_random_problems_with_general_rows(lmpc):
         hi = (bu[:3] + theta[ok] @ W[:3].T)
         assert np.all(np.minimum(np.abs(xb - lo), np.abs(xb - hi)) < 1e-8)
     assert nsolved >= 800
+
+
+# ------------------------------------------------------------------ binary32 path (codegen float_type="float")
+def _copy_settings(lmpc, s):
+    from oracle import ldp as oldp
+    so = oldp.Settings()
+    for f, _ in so._fields_:
+        setattr(so, f, getattr(s, f))
+    return so
+
+
+@pytest.mark.parametrize("name,rho", [("pendulum", None), ("mass_spring", None), ("mass_spring_3in", None),
+                                      ("soft_doc", 1e-3), ("soft_doc", 1e-6), ("satellite4", None),
+                                      ("satellite20", None)])
+def test_f32_path_matches_f32_oracle(lmpc, name, rho):
+    # the reference's single-precision build of this path: codegen.jl:19,31-37,82 (c_float = float,
+    # DAQP_SINGLE_PRECISION).  Checker: the binary32 build of the oracle on the SAME pack rounded to
+    # binary32; bar: identical flags / iteration counts / active sets, |dx| <= 1e-6 (observed 0).
+    from oracle import ldp as oldp
+    g = load_golden(name)
+    s = lmpc.default_settings_f32()
+    if rho is not None:
+        s.rho_soft = rho
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                  settings=s)
+    theta = g["theta"].astype(np.float32)
+    x, ef, it, act = qp.solve_f32(theta)
+    assert x.dtype == np.float32
+    L = oracle_ldp_from(qp.ldp())
+    xo, efo, ito, acto = oldp.solve_batch(L, theta, _copy_settings(lmpc, s), dtype=np.float32)
+    assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto)
+    assert np.abs(x - xo).max() <= 1e-6
+    # against the binary64 answers of the fixture: same outcome on (nearly) every problem, x to
+    # single-precision accuracy where both solve
+    ok = (ef >= 1) & (g["exitflag"] >= 1)
+    assert ((ef >= 1) == (g["exitflag"] >= 1)).mean() > 0.9
+    tol = 5e-3 if name == "soft_doc" else 2e-3
+    assert np.abs(x[ok] - g["X"][ok]).max() <= tol * max(1.0, np.abs(g["X"][ok]).max())
+    if name.startswith("satellite"):                                  # runtests.jl:831-834 (f32: +-1e-5)
+        bins = np.flatnonzero(g["senses"] & 16)
+        assert np.all(np.minimum(np.abs(x[:, bins] - g["bu"][bins]), np.abs(x[:, bins] - g["bl"][bins])) < 1e-5)
+
+
+def test_f32_warm_start_and_device_path(lmpc):
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden("mass_spring_3in")
+    s = lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                  nout=3, settings=s)
+    theta = g["theta"].astype(np.float32)
+    x, ef, it, act = qp.solve_f32(theta)
+    ok = ef >= 1
+    L = oracle_ldp_from(qp.ldp())
+    xw, efw, itw, actw = qp.solve_f32(theta[ok], warm=act[ok])
+    xo, efo, ito, acto = oldp.solve_batch(L, theta[ok], _copy_settings(lmpc, s), warm=act[ok], dtype=np.float32)
+    assert np.array_equal(efw, efo) and np.array_equal(itw, ito) and np.array_equal(actw, acto)
+    assert np.abs(xw - xo).max() <= 1e-6
+    assert itw.mean() < it[ok].mean()
+    # device-resident float32 tensors through lmpc_solve_batch_f32_device
+    th_d = torch.from_numpy(theta).cuda()
+    x_d, ef_d = qp.solve_device(th_d)
+    torch.cuda.synchronize()
+    assert x_d.dtype == torch.float32
+    assert np.array_equal(x_d.cpu().numpy(), x) and np.array_equal(ef_d.cpu().numpy(), ef)
+
+
+def test_f32_refused_where_the_wave_kernel_does_not_reach(lmpc):
+    # m = 0: only the lane kernel covers it -> the binary32 entry point must fail loudly
+    H = np.eye(3)
+    qp = lmpc.BatchedQP.from_mpqp(H, np.zeros(3), np.ones((3, 2)), np.zeros((0, 3)), [], [], np.zeros((0, 2)))
+    with pytest.raises(lmpc.LmpcError) as e:
+        qp.solve_f32(np.zeros((4, 2), np.float32))
+    assert e.value.code == -103

@@ -273,3 +273,19 @@ def test_hybrid_closed_loop_reaches_reference_with_binaries_on_bounds():
     for b in prob.binary_controls:                                        # runtests.jl:831-834
         assert np.all((np.abs(U[:, b] - prob.umin[b]) < 1e-5) | (np.abs(U[:, b] - prob.umax[b]) < 1e-5))
     assert np.abs(U - g["closed_loop_u"]).max() < 1e-9
+
+
+def test_f32_oracle_tracks_the_f64_oracle():
+    # binary32 build of the same source (oracle/daqp_ldp_oracle_f32.c): same outcome as binary64 on
+    # well-conditioned problems, x to single-precision accuracy, identical active sets where both solve
+    for name, nout in (("pendulum", 1), ("satellite4", 12)):
+        g = load_golden(name)
+        L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+        th = g["theta"][:1500]
+        X, ef, it, act = oldp.solve_batch(L, th)
+        Xf, eff, itf, actf = oldp.solve_batch(L, th, dtype=np.float32)
+        assert Xf.dtype == np.float32
+        ok = (ef >= 1) & (eff >= 1)
+        assert ok.mean() > 0.98
+        assert np.abs(X[ok] - Xf[ok]).max() < 1e-3
+        assert (act[ok] == actf[ok]).all(axis=1).mean() > 0.99

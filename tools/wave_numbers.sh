@@ -7,3 +7,7 @@ run --workload mass_spring_3in --steps 5 --warmup 1 --batch 100000
 run --workload soft_doc --steps 10 --warmup 2 --batch 200000
 run --workload mass_spring --wave --steps 10 --warmup 2 --batch 200000
 run --workload pendulum_hard --wave --steps 10 --warmup 2
+run --workload mass_spring_3in --steps 5 --warmup 1 --batch 100000 --f32
+run --workload soft_doc --steps 10 --warmup 2 --batch 200000 --f32
+run --workload hybrid --steps 3 --warmup 1 --batch 20000
+run --workload hybrid --steps 3 --warmup 1 --batch 20000 --f32
