@@ -197,6 +197,42 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
                          const double *F, const double *G, double *x, const double *r, double *uprev,
                          double *U_traj, double *X_traj, int32_t *flag_min, int warm, void *stream);
 
+/*
+ * Batched form_parameter on the device, previews included: theta_i = [x_i; r; d; uprev_i; p]
+ * (reference explicit.jl:54-63) with r, d, p formatted as format_reference / format_disturbance /
+ * format_affine_parameters do (utils.jl:78-261) and, inside a closed loop, as Simulation's
+ * get_preview does (simulation.jl:100-103,128-134).
+ *
+ * A block is cut from a trajectory: `w` values per column, `T` columns stored column by column
+ * (a Julia w x T matrix) -- one matrix per scenario, `stride` doubles apart, or one shared by all
+ * scenarios (stride 0).  H == 0: the block is column k0 (a constant reference: T = 1, k0 = 0);
+ * H > 0 (preview over H steps, H = mpc.Np): columns k0 .. k0+H-1, flattened column by column.
+ * Columns past the end repeat the last one (how the reference pads a short trajectory); src == NULL
+ * gives zeros (the reference's `nothing` default); w == 0 leaves the block out.
+ * nx + width(r) + width(d) + nuprev + width(p) must equal the handle's nth.
+ */
+typedef struct lmpc_block {
+    const double *src;   /* DEVICE pointer or NULL                                  */
+    int64_t stride;      /* doubles between two scenarios' matrices, 0 = shared     */
+    int32_t w;           /* values per column (ny, nd or the base parameter count)  */
+    int32_t T;           /* columns available                                       */
+    int32_t k0;          /* first column taken                                      */
+    int32_t H;           /* 0 = one column, > 0 = preview over H columns            */
+} lmpc_block;
+int lmpc_form_parameter_device(lmpc_handle *h, int64_t N, double *theta, const double *x, int nx,
+                               const lmpc_block *r, const lmpc_block *d, const double *uprev,
+                               int nuprev, const lmpc_block *p, void *stream);
+
+/*
+ * Closed loop with a reference TRAJECTORY (reference simulation.jl:69-73,93-113: `rs` held at its
+ * last column, and with settings.reference_preview the controller sees columns k+1 .. k+Np at
+ * step k).  As lmpc_simulate_device, but the reference of step k (0-based) is cut from `r`:
+ * r->H == 0: column k; r->H > 0: columns k+1 .. k+H (r->k0 is ignored).  DEVICE pointers.
+ */
+int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmpc_block *r, int nuprev,
+                             const double *F, const double *G, double *x, double *uprev,
+                             double *U_traj, double *X_traj, int32_t *flag_min, int warm, void *stream);
+
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 

@@ -22,7 +22,7 @@ SYMBOLS = (
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
     "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one",
     "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
-    "lmpc_simulate_device", "lmpc_kernel_name",
+    "lmpc_simulate_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
@@ -39,6 +39,12 @@ class Settings(ctypes.Structure):
                 ("zero_tol", ctypes.c_double), ("progress_tol", ctypes.c_double),
                 ("fval_bound", ctypes.c_double), ("rho_soft", ctypes.c_double),
                 ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32)]
+
+
+class Block(ctypes.Structure):
+    """`lmpc_block`: one block of theta cut from a (w x T, column-major) trajectory on the device."""
+    _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("w", ctypes.c_int32),
+                ("T", ctypes.c_int32), ("k0", ctypes.c_int32), ("H", ctypes.c_int32)]
 
 
 _lib = None
@@ -87,6 +93,11 @@ def lib():
     L.lmpc_simulate.restype = i32
     L.lmpc_simulate_device.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32, vp]
     L.lmpc_simulate_device.restype = i32
+    bp = ctypes.POINTER(Block)
+    L.lmpc_form_parameter_device.argtypes = [vp, i64, vp, vp, i32, bp, bp, vp, i32, bp, vp]
+    L.lmpc_form_parameter_device.restype = i32
+    L.lmpc_simulate_ref_device.argtypes = [vp, i64, i32, i32, bp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.lmpc_simulate_ref_device.restype = i32
     L.lmpc_kernel_name.argtypes = [vp]
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]

@@ -747,6 +747,85 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     return LMPC_OK;
 }
 
+namespace {
+ThetaBlock to_block(const lmpc_block *b) {
+    ThetaBlock t{nullptr, 0, 0, 1, 0, 0};
+    if (b) { t.src = b->src; t.stride = b->stride; t.w = b->w; t.T = b->T > 0 ? b->T : 1; t.k0 = b->k0; t.H = b->H; }
+    return t;
+}
+}  // namespace
+
+int lmpc_form_parameter_device(lmpc_handle *h, int64_t N, double *theta, const double *x, int nx,
+                               const lmpc_block *r, const lmpc_block *d, const double *uprev, int nuprev,
+                               const lmpc_block *p, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    const ThetaBlock br = to_block(r), bd = to_block(d), bp = to_block(p);
+    if (N < 0 || nx < 0 || nuprev < 0 || br.w < 0 || bd.w < 0 || bp.w < 0 || br.H < 0 || bd.H < 0 || bp.H < 0 ||
+        (N > 0 && (!theta || (nx > 0 && !x))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_form_parameter_device: NULL array or negative size");
+    if (nx + br.width() + bd.width() + nuprev + bp.width() != h->P.nth)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_form_parameter_device: blocks do not add up to the handle's nth = " +
+                                            std::to_string(h->P.nth));
+    if (N == 0 || h->P.nth == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const long long total = (long long)N * h->P.nth;
+    hipLaunchKernelGGL(form_parameter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       theta, x, nx, br, bd, uprev, nuprev, bp, (long long)N);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmpc_block *r, int nuprev,
+                             const double *F, const double *G, double *x, double *uprev, double *U_traj,
+                             double *X_traj, int32_t *flag_min, int warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    const int nu = h->P.nout;
+    ThetaBlock br = to_block(r);
+    if (N < 0 || T < 0 || nx <= 0 || nx > 32 || nuprev < 0 || nuprev > nu || !F || !G || (N > 0 && !x) ||
+        (nuprev > 0 && N > 0 && !uprev) || br.w < 0 || br.H < 0 || nx + br.width() + nuprev != h->P.nth)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_simulate_ref_device: theta = [x; r-block; uprev] must match the handle "
+                                        "(nx + width(r) + nuprev == nth, nout == nu, nx <= 32)");
+    if (N == 0 || T == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w = (size_t)h->P.words();
+    if (N > h->simCap) {
+        hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+        h->simTheta = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
+        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
+        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
+        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
+        h->simCap = N;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
+    if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    const long long total = (long long)N * h->P.nth;
+    const ThetaBlock none{nullptr, 0, 0, 1, 0, 0};
+    for (int k = 0; k < T; k++) {
+        br.k0 = br.H > 0 ? k + 1 : k;                 // simulation.jl:101 get_preview(rs, k, Np) / rs[:,k]
+        hipLaunchKernelGGL(form_parameter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           h->simTheta, x, nx, br, none, uprev, nuprev, none, (long long)N);
+        const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
+        int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
+        if (rc != LMPC_OK) return rc;
+        hipLaunchKernelGGL(plant_kernel, dim3(grid), dim3(256), 0, st, x, uprev, h->simU, h->simFlag, h->simFG, nx,
+                           nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return LMPC_OK;
+}
+
 int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F, const double *G,
                   double *x, const double *r, double *uprev, double *U_traj, double *X_traj, int32_t *flag_min,
                   int warm) {

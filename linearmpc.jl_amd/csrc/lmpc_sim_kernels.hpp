@@ -21,6 +21,47 @@ __global__ __launch_bounds__(256) void form_theta_kernel(
     for (int k = 0; k < nup; k++) t[nx + nr + k] = uprev ? uprev[i * nup + k] : 0.0;
 }
 
+// One block of theta taken from a trajectory: `w` values per column, `T` columns stored column by
+// column (a Julia w x T matrix), one matrix per scenario (`stride` doubles apart) or one shared by
+// all (stride 0).  H == 0: the block is column k0; H > 0 (preview): columns k0 .. k0+H-1.  Columns
+// past the end repeat the last one (reference utils.jl:101-106 pads a short trajectory with its
+// last column, simulation.jl:128-134 get_preview clamps the same way); src == nullptr gives zeros
+// (utils.jl:80-82 `isnothing(r)`).
+struct ThetaBlock {
+    const double *src;
+    long long stride;
+    int w, T, k0, H;
+    __host__ __device__ int width() const { return w * (H > 0 ? H : 1); }
+};
+
+// theta_i = [x_i ; r-block ; d-block ; uprev_i ; p-block]   (reference explicit.jl:54-63 form_parameter
+// after format_reference / format_disturbance / format_affine_parameters, utils.jl:78-261);
+// one thread per entry of theta, consecutive threads write consecutive addresses.
+__global__ __launch_bounds__(256) void form_parameter_kernel(
+    double *__restrict__ theta, const double *__restrict__ x, int nx, ThetaBlock r, ThetaBlock d,
+    const double *__restrict__ uprev, int nup, ThetaBlock p, long long n) {
+    const int nr = r.width(), nd = d.width(), npp = p.width();
+    const int nth = nx + nr + nd + nup + npp;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * nth) return;
+    const long long i = idx / nth;
+    int e = (int)(idx - i * nth);
+    auto from_block = [&](const ThetaBlock &b, int q) -> double {
+        if (b.src == nullptr) return 0.0;
+        int col = b.k0 + q / b.w;
+        col = col < b.T ? col : b.T - 1;
+        col = col > 0 ? col : 0;
+        return b.src[i * b.stride + (long long)col * b.w + (q % b.w)];
+    };
+    double v;
+    if (e < nx) v = x[i * nx + e];
+    else if ((e -= nx) < nr) v = from_block(r, e);
+    else if ((e -= nr) < nd) v = from_block(d, e);
+    else if ((e -= nd) < nup) v = uprev ? uprev[i * nup + e] : 0.0;
+    else v = from_block(p, e - nup);
+    theta[idx] = v;
+}
+
 // x_i <- F x_i + G u_i (sums in index order, F then G), uprev_i <- u_i, bookkeeping of the run
 __global__ __launch_bounds__(256) void plant_kernel(
     double *__restrict__ x, double *__restrict__ uprev, const double *__restrict__ u,

@@ -7,6 +7,8 @@ and error behaviour, so that the parity tests read like test/runtests.jl:
     MPQP                         /root/reference/src/types.jl:75-98   (data contract)
     MPC.setup()                  /root/reference/src/setup.jl:7-29    (`setup!`)
     MPC.form_parameter           /root/reference/src/explicit.jl:54-63
+    MPC.format_reference / format_disturbance / format_affine_parameters
+                                 /root/reference/src/utils.jl:78-261  (preview tiling and padding)
     MPC.solve(theta)             /root/reference/src/utils.jl:268-283
     MPC.compute_control          /root/reference/src/utils.jl:43-51
     MPC.compute_control_trajectory  /root/reference/src/utils.jl:62-70
@@ -47,9 +49,18 @@ class MPC:
     """The fields of `mutable struct MPC` (types.jl:108-157) that the online path reads."""
 
     def __init__(self, mpqp: MPQP, nx, nu, nr=0, nd=0, nuprev=0, np_=0, K=None,
-                 soft_weight=1e6, device=0):
+                 soft_weight=1e6, device=0, Np=1, reference_preview=False, disturbance_preview=False,
+                 parameter_preview=False):
         self.mpQP = mpqp
         self.nx, self.nu, self.nr, self.nd, self.nuprev, self.np = nx, nu, nr, nd, nuprev, np_
+        # MPCSettings (types.jl:54-69): with a preview the block of theta holds Np columns
+        self.Np = int(Np)
+        self.reference_preview = bool(reference_preview)
+        self.disturbance_preview = bool(disturbance_preview)
+        self.parameter_preview = bool(parameter_preview)
+        self.ny = nr // self.Np if self.reference_preview else nr              # model.ny
+        self.nd_base = nd // self.Np if self.disturbance_preview else nd       # model.nd
+        self.np_base = np_ // self.Np if self.parameter_preview else np_       # utils.jl:204-217
         self.K = np.zeros((nu, nx)) if K is None else np.asarray(K, float).reshape(nu, nx)
         self.uprev = np.zeros(nu)
         self.settings = default_settings()
@@ -72,20 +83,91 @@ class MPC:
     def get_parameter_dims(self):
         return self.nx, self.nr, self.nd, self.nuprev, self.np
 
-    # explicit.jl:54-63 (constant reference / disturbance / parameter; previews are formatted on
-    # the LinearMPC.jl host before theta reaches this boundary)
+    @staticmethod
+    def _tile(a, w, Np, what, unit):
+        """The common body of utils.jl:84-111 / :149-170 / :240-258: a vector of the base width is
+        repeated over the horizon, a (w x T) trajectory is flattened column by column, cut at Np
+        columns or padded with its last column."""
+        a = np.asarray(a, float)
+        if a.ndim == 1:
+            if a.size != w:
+                raise ValueError(f"{what} vector length ({a.size}) must match number of {unit} ({w})")
+            return np.tile(a, Np)
+        if a.ndim != 2:
+            raise ValueError(f"{what} must be a vector or matrix")
+        if a.shape[0] != w:
+            raise ValueError(f"{what} matrix must have {w} rows (number of {unit})")
+        if a.shape[1] < Np:
+            a = np.hstack([a, np.tile(a[:, -1:], (1, Np - a.shape[1]))])
+        return a[:, :Np].T.reshape(-1)
+
+    @staticmethod
+    def _single(a, w, what, unit):
+        a = np.asarray(a, float)
+        if a.ndim == 1:
+            if a.size != w:
+                raise ValueError(f"{what} vector length ({a.size}) must match number of {unit} ({w})")
+            return a
+        if a.ndim == 2:                                   # first column in non-preview mode
+            if a.shape[0] != w:
+                raise ValueError(f"{what} matrix must have {w} rows (number of {unit})")
+            return a[:, 0].copy()
+        raise ValueError(f"{what} must be a vector or matrix")
+
+    # utils.jl:78-133 (reference_condensation / traj2setpoint stay on the LinearMPC.jl host)
+    def format_reference(self, r):
+        if self.nr == 0:                                  # reference_tracking off
+            return np.zeros(0)
+        if r is None:
+            r = np.zeros(self.ny)
+        if np.size(r) == 0:
+            return np.zeros(0)
+        if self.reference_preview:
+            return self._tile(r, self.ny, self.Np, "Reference", "outputs")
+        return self._single(r, self.ny, "Reference", "outputs")
+
+    # utils.jl:141-201
+    def format_disturbance(self, d):
+        if self.nd_base == 0:
+            return np.zeros(0)
+        if d is None:
+            d = np.zeros(self.nd_base)
+        if np.size(d) == 0:
+            return np.zeros(0)
+        if self.disturbance_preview:
+            return self._tile(d, self.nd_base, self.Np, "Disturbance", "disturbances")
+        return self._single(d, self.nd_base, "Disturbance", "disturbances")
+
+    # utils.jl:219-261
+    def format_affine_parameters(self, p):
+        if self.np == 0:
+            return np.zeros(0)
+        if p is None:
+            return np.zeros(self.np)
+        p = np.asarray(p, float)
+        if p.ndim == 1 and p.size == self.np_base:
+            return np.tile(p, self.Np) if self.parameter_preview else p.copy()
+        if p.ndim == 1 and p.size == self.np:
+            return p.copy()
+        if p.ndim == 2:
+            if p.shape[0] != self.np_base:
+                raise ValueError(f"Generalized parameter matrix must have {self.np_base} rows")
+            if not self.parameter_preview:
+                return p[:, 0].copy()
+            return self._tile(p, self.np_base, self.Np, "Generalized parameter", "parameters")
+        raise ValueError("Generalized parameters must be a vector or matrix")
+
+    # explicit.jl:54-63
     def form_parameter(self, x, r=None, d=None, uprev=None, p=None):
         x = np.asarray(x, float).reshape(-1)
         if x.size != self.nx:
             raise ValueError(f"State vector must have length {self.nx}")
-        r = np.zeros(self.nr) if r is None else np.asarray(r, float).reshape(-1)
-        if r.size != self.nr:
-            raise ValueError(f"Reference vector length ({r.size}) must match number of outputs ({self.nr})")
-        d = np.zeros(self.nd) if d is None else np.asarray(d, float).reshape(-1)
+        r = self.format_reference(r)
+        d = self.format_disturbance(d)
         if d.size != self.nd:
             raise ValueError(f"Disturbance vector must have length {self.nd}")
         up = self.uprev[:self.nuprev] if uprev is None else np.asarray(uprev, float).reshape(-1)[:self.nuprev]
-        p = np.zeros(self.np) if p is None else np.asarray(p, float).reshape(-1)
+        p = self.format_affine_parameters(p)
         if p.size != self.np:
             raise ValueError(f"Generalized parameters must have length {self.np}")
         return np.concatenate([x, r, d, up, p])

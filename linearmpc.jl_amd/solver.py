@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _cabi
-from ._cabi import LmpcError, Settings, check, lib
+from ._cabi import Block, LmpcError, Settings, check, lib
 
 _vp = ctypes.c_void_p
 
@@ -227,6 +227,74 @@ class BatchedQP:
                                   _ptr(up) if up is not None else None, _ptr(U), _ptr(X) if X is not None else None,
                                   _ptr(fm), int(bool(warm))), self._h)
         return dict(x=x, U=U, X=X, uprev=up, flag_min=fm)
+
+    # ------------------------------------------------------------------ theta on the device, previews
+    @staticmethod
+    def _block(t, H=0, k0=0):
+        """torch CUDA tensor (w,), (w, T) [shared] or (N, w, T) [per scenario] -> lmpc_block.
+        The C side wants each matrix column by column (Julia layout), i.e. the (T, w) transpose."""
+        import torch
+        if t is None:
+            return None, None
+        if t.dim() == 1:
+            t = t.reshape(-1, 1)
+        per = t.dim() == 3
+        keep = t.transpose(-1, -2).contiguous().to(torch.float64)          # (.., T, w): column after column
+        w, T = int(t.shape[-2]), int(t.shape[-1])
+        return Block(keep.data_ptr(), w * T if per else 0, w, T, int(k0), int(H)), keep
+
+    def form_parameter_device(self, x, r=None, d=None, uprev=None, p=None, r_preview=0, d_preview=0,
+                              p_preview=0, k0=0, theta=None, stream=None):
+        """Batched form_parameter (`lmpc_form_parameter_device`; reference explicit.jl:54-63 with
+        utils.jl:78-261 formatting).  x: (N, nx) CUDA tensor; r/d/p: (w,), (w, T) shared or (N, w, T);
+        *_preview = horizon Np (0 = constant block); k0 = first trajectory column taken."""
+        import torch
+        N, nx = x.shape
+        dev = x.device
+        br, kr = self._block(r, r_preview, k0)
+        bd, kd = self._block(d, d_preview, k0)
+        bp, kp = self._block(p, p_preview, k0)
+        nup = 0 if uprev is None else int(uprev.shape[1])
+        if theta is None:
+            theta = torch.empty((N, self.nth), dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        check(lib().lmpc_form_parameter_device(
+            self._h, N, _vp(theta.data_ptr()), _vp(x.data_ptr()), nx,
+            ctypes.byref(br) if br is not None else None, ctypes.byref(bd) if bd is not None else None,
+            _vp(uprev.data_ptr()) if uprev is not None else None, nup,
+            ctypes.byref(bp) if bp is not None else None, _vp(st)), self._h)
+        theta._lmpc_keep = (kr, kd, kp)          # the launch is asynchronous: keep the sources alive
+        return theta
+
+    def simulate_ref(self, x0, T, F, G, r, preview=0, uprev=None, warm=False):
+        """Closed loop with a reference trajectory (`lmpc_simulate_ref_device`; reference
+        simulation.jl:69-73,93-113).  r: (ny, Tr) shared or (N, ny, Tr); preview = Np for
+        settings.reference_preview, 0 otherwise.  Host arrays in and out."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        F = _f64(np.atleast_2d(F))
+        nx = F.shape[0]
+        nu = self.nout
+        G = _f64(np.asarray(G, float).reshape(nx, nu))
+        x = torch.from_numpy(_f64(np.array(np.asarray(x0, float).reshape(-1, nx), copy=True))).to(dev)
+        N = x.shape[0]
+        rt = torch.from_numpy(np.asarray(r, float)).to(dev)
+        br, keep = self._block(rt, preview, 0)
+        nup = self.nth - nx - br.w * (preview if preview > 0 else 1)
+        up = None
+        if nup:
+            up = torch.from_numpy(_f64(np.zeros((N, nup)) if uprev is None else np.asarray(uprev, float).reshape(N, nup))).to(dev)
+        U = torch.empty((T, N, nu), dtype=torch.float64, device=dev)
+        X = torch.empty((T + 1, N, nx), dtype=torch.float64, device=dev)
+        fm = torch.empty(N, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        check(lib().lmpc_simulate_ref_device(self._h, N, int(T), nx, ctypes.byref(br), nup, _ptr(F), _ptr(G),
+                                             _vp(x.data_ptr()), _vp(up.data_ptr()) if up is not None else None,
+                                             _vp(U.data_ptr()), _vp(X.data_ptr()), _vp(fm.data_ptr()),
+                                             int(bool(warm)), _vp(st)), self._h)
+        torch.cuda.synchronize(dev)
+        return dict(x=x.cpu().numpy(), U=U.cpu().numpy(), X=X.cpu().numpy(),
+                    uprev=None if up is None else up.cpu().numpy(), flag_min=fm.cpu().numpy())
 
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):

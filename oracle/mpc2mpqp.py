@@ -10,8 +10,8 @@ into the dense multi-parametric QP
 
 exactly the way the reference builds it on the Julia host, so that the fixtures
 fed to the HIP path are the matrices a LinearMPC.jl user would hand over.  Only
-the features the benchmark/known-answer problems exercise are restated (no
-preview modes, no move blocking, no binaries, no operating-point offsets).  Reference lines followed, all under
+the features the benchmark/known-answer problems exercise are restated (reference preview yes;
+no disturbance/parameter preview, no reference condensation, no move blocking, no operating-point offsets).  Reference lines followed, all under
 /root/reference/src/:
 
     zoh                     utils.jl:291-295
@@ -98,6 +98,7 @@ class MPCProblem:
     K: Optional[np.ndarray] = None          # prestabilising feedback u = v - K x (setup.jl:186-199)
     Eu: Optional[np.ndarray] = None         # affine input cost (Eu p + eu)'u_k  (setup.jl:136-150)
     eu: Optional[np.ndarray] = None
+    reference_preview: bool = False         # settings.reference_preview (types.jl:56,67): r is ny x Np in theta
     binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
     Nc_binary: int = -1                     # "binary control horizon" (-1 = whole control horizon)
 
@@ -137,6 +138,8 @@ class MPCProblem:
     # mpc2mpqp.jl:147-164
     def parameter_dims(self):
         nr = self.ny if self.reference_tracking else 0
+        if self.reference_preview and nr > 0:    # mpc2mpqp.jl:154-156: one reference per predicted step
+            nr = nr * self.Np
         nuprev = self.nu if np.any(self.Rr != 0) else 0
         return self.nx, nr, 0, nuprev, self.np_base()
 
@@ -205,8 +208,8 @@ def extended_system(p: MPCProblem):
     nu, ny = p.nu, p.ny
     K = p.gain()
     F, G, C = p.F - p.G @ K, p.G.copy(), p.C.copy()
-    if nr > 0:                                   # reference rides along as constant states
-        F = block_diag(F, np.eye(ny))
+    if nr > 0 and not p.reference_preview:       # reference rides along as constant states (:656-662;
+        F = block_diag(F, np.eye(ny))            # with preview it is no state, see ref_preview_cost)
         G = np.vstack([G, np.zeros((ny, nu))])
         C = np.hstack([C, -np.eye(ny)])
     if nuprev > 0:                               # previous input as a state, du as an output
@@ -229,7 +232,7 @@ def extended_cost(p: MPCProblem):
     Q, R, Rr = p.Q.copy(), p.R.copy(), p.Rr.copy()
     Qf = Q.copy()                                # Qf, Qfx unset => terminal weight = Q (:694)
     S = np.zeros((nx, nu))
-    if nr > 0:
+    if nr > 0 and not p.reference_preview:       # :701-703
         S = np.vstack([S, np.zeros((ny, nu))])
     if nuprev > 0:
         Q = block_diag(Q, Rr)
@@ -266,6 +269,23 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         GS = Gam.T @ Stot
         H = H + GS + GS.T
         f_theta = f_theta + Stot.T @ Phi
+    if p.reference_tracking and p.reference_preview:
+        # ref_preview_cost (mpc2mpqp.jl:535-577, no condensation): (C x_k - r_k)'Q(C x_k - r_k) with a
+        # reference per step; the cross term puts Fr = -Gam' kron(I, C'Q) (first block dropped: the
+        # reference at k = 0 meets no input) into f_theta right behind the state columns
+        ny, nxp = p.ny, p.nx
+        C_full, Q_full, Qf_full = C[:ny], Q[:ny, :ny], Qf[:ny, :ny]
+        CQ = np.kron(np.eye(N + 1), C_full.T @ Q_full)
+        CQ[-C_full.shape[1]:, -ny:] = C_full.T @ Qf_full
+        Fr = (-Gam.T @ CQ)[:, ny:]
+        Hr = np.kron(np.eye(N), Q_full)
+        Hr[-ny:, -ny:] = Qf_full
+        nrp = ny * N
+        f_theta = np.hstack([f_theta[:, :nxp], Fr, f_theta[:, nxp:]])
+        tail = H_theta.shape[0] - nxp
+        H_theta = np.block([[H_theta[:nxp, :nxp], np.zeros((nxp, nrp)), H_theta[:nxp, nxp:]],
+                            [np.zeros((nrp, nxp)), Hr, np.zeros((nrp, tail))],
+                            [H_theta[nxp:, :nxp], np.zeros((tail, nrp)), H_theta[nxp:, nxp:]]])
     f = np.zeros(H.shape[0])
     # generalised-parameter cost on the inputs (mpc2mpqp.jl:478-508): f += Umap' eu, f_theta gets
     # one column block Umap' (Eu stacked) for p (constant over the horizon, no preview)
@@ -295,8 +315,13 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
     """mpc2mpqp.jl:358-402 -> (A, bu, bl, W, issoft, prio); simple bounds first."""
     nx, nr, nd, nuprev, npb = p.parameter_dims()
     nu, Np, Nc = p.nu, p.Np, p.Nc
-    nxe = nx + nr + nd + nuprev
+    prev = p.reference_preview and nr > 0
+    nxe = nx + (0 if prev else nr) + nd + nuprev     # previewed references are no states (:210)
     n = Gam.shape[1]
+
+    def with_ref_block(Wm):                          # insert_preview_parameter_blocks (:70-92), Wr = 0
+        return np.hstack([Wm[:, :nx], np.zeros((Wm.shape[0], nr)), Wm[:, nx:]]) if prev else Wm
+
     if p.umax.size:
         # create_controlbounds (:206-245): with K = 0 simple bounds on U, otherwise general rows
         # (I - Kfull Gam) V <= b + Kfull Phi x0  for u_k = v_k - K x_k
@@ -309,6 +334,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
         else:
             A = np.zeros((0, n))
             W = np.zeros((Nc * nu, nxe))
+        W = with_ref_block(W)
         soft = np.zeros(n, bool)
         prio = np.zeros(n, int)
         if npb > 0:
@@ -321,7 +347,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             binary[p.Nc_binary * nu:] = False
     else:
         A, bu, bl = np.zeros((0, n)), np.zeros(0), np.zeros(0)
-        W, soft, prio = np.zeros((0, nxe + npb)), np.zeros(0, bool), np.zeros(0, int)
+        W, soft, prio = np.zeros((0, nxe + (nr if prev else 0) + npb)), np.zeros(0, bool), np.zeros(0, int)
         binary = np.zeros(0, bool)
     if p.constraints:
         eyeX = np.eye(Np + 1)
@@ -344,7 +370,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             prios.append(np.full(mi * len(ks), c.prio, int))
         Axt, Aut = np.vstack(Ax_rows), np.vstack(Au_rows)
         A = np.vstack([A, Axt @ Gam + Aut])
-        Wg = -Axt @ Phi
+        Wg = with_ref_block(-Axt @ Phi)
         if npb > 0:
             Wg = np.hstack([Wg, np.vstack(Wp_rows)])
         W = np.vstack([W, Wg])
@@ -584,10 +610,28 @@ def generalized_parameter_kat() -> MPCProblem:
     return p
 
 
+def format_reference_preview(r, ny, Np):
+    """utils.jl:84-111: a vector is repeated over the horizon; a trajectory (ny x T) is flattened
+    column by column, cut at Np columns or padded with its last column."""
+    r = np.asarray(r, float)
+    if r.ndim == 1:
+        if r.size != ny:
+            raise ValueError(f"Reference vector length ({r.size}) must match number of outputs ({ny})")
+        return np.tile(r, Np)
+    if r.shape[0] != ny:
+        raise ValueError(f"Reference matrix must have {ny} rows (number of outputs)")
+    if r.shape[1] >= Np:
+        return r[:, :Np].T.reshape(-1)
+    ext = np.hstack([r, np.tile(r[:, -1:], (1, Np - r.shape[1]))])
+    return ext.T.reshape(-1)
+
+
 def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):
     """explicit.jl:54-63: theta = [x; r; d; uprev; p] (d empty here; r, uprev, p default 0)."""
     nx, nr, _, nuprev, npb = p.parameter_dims()
     x = np.asarray(x, float).reshape(nx)
+    if p.reference_preview and r is not None and nr > 0:
+        r = format_reference_preview(np.asarray(r, float), p.ny, p.Np)
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
     pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]

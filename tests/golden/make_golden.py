@@ -254,6 +254,44 @@ def main():
     save("satellite20", q, L, theta, X, ef, it, act,
          dict(F=prob.F, G=prob.G, closed_loop_u=np.array(traj_u), closed_loop_xT=x))
 
+    # ---- the reference's hybrid test AS WORDED (test/runtests.jl:820-834): reference_preview = true,
+    # rs = [zeros(1,5) 0.5*ones(1,15); zeros(2,20)], 20 closed-loop steps from x0 = 0; at step k the
+    # controller sees rs[:, k+1 .. k+Np] held at the last column (simulation.jl:69-73,101,128-134)
+    prob = omm.satellite(20)
+    prob.reference_preview = True
+    q = omm.mpc2mpqp(prob)
+    assert (q.n, q.m, q.nth) == (60, 60, 3 + 3 * 20)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    Nsim = 20
+    rs = np.vstack([np.hstack([np.zeros((1, 5)), 0.5 * np.ones((1, Nsim - 5))]), np.zeros((2, Nsim))])
+    x = np.zeros(3)
+    ths, us, ys = [], [], []
+    for k in range(Nsim):
+        ys.append(x.copy())
+        prev = np.stack([rs[:, min(k + 1 + i, Nsim - 1)] for i in range(prob.Np)], 1)    # get_preview(rs, k+1, Np)
+        th = omm.form_parameter(prob, x, r=prev)
+        U, e, _, _ = oldp.solve_batch(L, th[None])
+        assert e[0] == 1
+        u = U[0, :3]
+        for b in prob.binary_controls:                                                   # runtests.jl:831-834
+            assert min(abs(u[b] - prob.umin[b]), abs(u[b] - prob.umax[b])) < 1e-5, (k, u)
+        ths.append(th)
+        us.append(u)
+        x = prob.F @ x + prob.G @ u
+    assert abs(ys[-1][0] - 0.5) < 1e-3, ys[-1]                                           # runtests.jl:829
+    rng2 = np.random.default_rng(99)
+    extra_th = []
+    for _ in range(44):                                  # more points: random states, random step references
+        xr = np.hstack([rng2.uniform(-0.2, 0.2), rng2.uniform(-0.3, 0.3, 2)])
+        step = rng2.integers(0, 20)
+        rr = np.zeros((3, 20))
+        rr[0, step:] = rng2.uniform(-0.4, 0.4)
+        extra_th.append(omm.form_parameter(prob, xr, r=rr))
+    theta = np.vstack([np.array(ths), np.array(extra_th)])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("satellite20_preview", q, L, theta, X, ef, it, act,
+         dict(F=prob.F, G=prob.G, rs=rs, closed_loop_u=np.array(us), closed_loop_y=np.array(ys)))
+
 
 if __name__ == "__main__":
     main()

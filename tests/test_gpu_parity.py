@@ -517,7 +517,7 @@ def test_broken_working_set_is_never_reported_optimal(lmpc):
 
 
 # ------------------------------------------------------------------ hybrid MPC (binary rows, B&B)
-@pytest.mark.parametrize("name", ["satellite4", "satellite20"])
+@pytest.mark.parametrize("name", ["satellite4", "satellite20", "satellite20_preview"])
 def test_hybrid_branch_and_bound_matches_oracle(lmpc, name):
     # /root/reference/test/runtests.jl:820-834; binaries of mpc_examples.jl:533-546
     g = load_golden(name)
@@ -656,3 +656,74 @@ def test_f32_refused_where_the_wave_kernel_does_not_reach(lmpc):
     with pytest.raises(lmpc.LmpcError) as e:
         qp.solve_f32(np.zeros((4, 2), np.float32))
     assert e.value.code == -103
+
+
+# ------------------------------------------------------------------ previews (utils.jl:78-261) on the device
+def test_form_parameter_device_matches_the_operator_interface(lmpc):
+    import torch
+    g = load_golden("satellite20_preview")
+    Np, ny = 20, 3
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                             has_binaries=True), nx=3, nu=3, nr=ny * Np, Np=Np, reference_preview=True)
+    mpc.setup()
+    qp = mpc.opt_model
+    rng = np.random.default_rng(5)
+    N = 37
+    X = rng.uniform(-1, 1, (N, 3))
+    xd = torch.from_numpy(X).cuda()
+    # (a) one short trajectory shared by all scenarios: padded with its last column (utils.jl:101-106)
+    r_short = rng.uniform(-1, 1, (ny, 7))
+    th = qp.form_parameter_device(xd, r=torch.from_numpy(r_short).cuda(), r_preview=Np)
+    torch.cuda.synchronize()
+    ref = np.stack([mpc.form_parameter(X[i], r=r_short) for i in range(N)])
+    assert np.array_equal(th.cpu().numpy(), ref)
+    # (b) a long trajectory per scenario, window starting at column k0 (simulation.jl:128-134)
+    r_long = rng.uniform(-1, 1, (N, ny, 31))
+    for k0 in (0, 5, 20, 30):
+        th = qp.form_parameter_device(xd, r=torch.from_numpy(r_long).cuda(), r_preview=Np, k0=k0)
+        torch.cuda.synchronize()
+        ref = np.stack([mpc.form_parameter(X[i], r=r_long[i][:, k0:]) for i in range(N)])
+        assert np.array_equal(th.cpu().numpy(), ref)
+    # (c) a constant reference vector is repeated over the horizon (utils.jl:88-94); None gives zeros
+    rv = rng.uniform(-1, 1, ny)
+    th = qp.form_parameter_device(xd, r=torch.from_numpy(np.tile(rv[:, None], (1, 1))).cuda(), r_preview=Np)
+    torch.cuda.synchronize()
+    assert np.array_equal(th.cpu().numpy(), np.stack([mpc.form_parameter(X[i], r=rv) for i in range(N)]))
+    # (d) non-preview handle: [x; r; uprev] with uprev per scenario
+    gp = load_golden("pendulum")
+    mp = lmpc.MPC(lmpc.MPQP(gp["H"], gp["f"], gp["f_theta"], gp["A"], gp["bu"], gp["bl"], gp["W"], gp["senses"]),
+                  nx=4, nu=1, nr=2, nuprev=1).setup()
+    X4 = rng.uniform(-1, 1, (N, 4)); up = rng.uniform(-1, 1, (N, 1)); r2 = rng.uniform(-1, 1, (N, 2, 1))
+    th = mp.opt_model.form_parameter_device(torch.from_numpy(X4).cuda(), r=torch.from_numpy(r2).cuda(),
+                                            uprev=torch.from_numpy(up).cuda())
+    torch.cuda.synchronize()
+    ref = np.stack([mp.form_parameter(X4[i], r=r2[i, :, 0], uprev=up[i]) for i in range(N)])
+    assert np.array_equal(th.cpu().numpy(), ref)
+    # blocks that do not add up to nth are refused
+    with pytest.raises(lmpc.LmpcError):
+        qp.form_parameter_device(xd, r=torch.from_numpy(r_short).cuda(), r_preview=Np - 1)
+
+
+def test_hybrid_closed_loop_with_reference_preview(lmpc):
+    # /root/reference/test/runtests.jl:820-834 as worded: reference_preview = true, a step in the
+    # reference trajectory, 20 closed-loop steps; y -> 0.5 +- 1e-3, binary inputs on a bound
+    g = load_golden("satellite20_preview")
+    qp = _qp_from_golden(lmpc, g, 3)
+    N = 6
+    x0 = np.zeros((N, 3)); x0[1:, 0] = np.linspace(-0.02, 0.02, N - 1)
+    out = qp.simulate_ref(x0, 20, g["F"], g["G"], g["rs"], preview=20)
+    assert np.all(out["flag_min"] == 1)
+    assert np.abs(out["U"][:, 0] - g["closed_loop_u"]).max() < 1e-8
+    assert np.abs(out["X"][:20, 0] - g["closed_loop_y"]).max() < 1e-8
+    assert abs(out["X"][19, 0, 0] - 0.5) < 1e-3                                       # runtests.jl:829
+    for b, (lo, hi) in ((1, (0.0, 1.0)), (2, (-1.0, 0.0))):                           # runtests.jl:831-834
+        ub = out["U"][:, :, b]
+        assert np.all((np.abs(ub - lo) < 1e-5) | (np.abs(ub - hi) < 1e-5))
+    # without preview the same entry point feeds column k of the trajectory: equals lmpc_simulate with
+    # a constant reference when the trajectory is constant
+    g0 = load_golden("satellite20")
+    q0 = _qp_from_golden(lmpc, g0, 3)
+    rc = np.tile(np.array([[0.5], [0.0], [0.0]]), (1, 4))
+    a = q0.simulate_ref(x0, 8, g0["F"], g0["G"], rc, preview=0)
+    b_ = q0.simulate(x0, 8, g0["F"], g0["G"], r=np.tile([0.5, 0.0, 0.0], (N, 1)), warm=False)
+    assert np.array_equal(a["U"], b_["U"]) and np.array_equal(a["X"], b_["X"])

@@ -143,3 +143,29 @@ def test_region_discovery_bookkeeping(lmpc):
         assert np.abs(Fz @ theta[i] + gz - X[i]).max() < 1e-8
     up, lo = lmpc.explicit.mask_to_sets(np.array([0b0000100010], np.uint64), 5)
     assert up == [1] and lo == [0]
+
+
+def test_preview_formatting_follows_the_reference():
+    # utils.jl:78-261: vector -> repeated over the horizon; trajectory -> flattened column by column,
+    # cut at Np or padded with its last column; wrong sizes raise with the reference's messages
+    import linearmpc_jl_amd as lmpc
+    q = lmpc.MPQP(np.eye(2), np.zeros(2), np.zeros((2, 11)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
+                  np.zeros((2, 11)), np.zeros(2, np.int32))
+    mpc = lmpc.MPC(q, nx=1, nu=1, nr=2 * 3, nd=1 * 3, np_=1, Np=3, reference_preview=True, disturbance_preview=True)
+    assert np.array_equal(mpc.format_reference([1.0, 2.0]), [1, 2, 1, 2, 1, 2])
+    assert np.array_equal(mpc.format_reference(np.array([[1.0, 3, 5, 7], [2, 4, 6, 8]])), [1, 2, 3, 4, 5, 6])
+    assert np.array_equal(mpc.format_reference(np.array([[1.0, 3], [2, 4]])), [1, 2, 3, 4, 3, 4])
+    assert np.array_equal(mpc.format_reference(None), np.zeros(6))
+    with pytest.raises(ValueError, match="must match number of outputs"):
+        mpc.format_reference([1.0, 2.0, 3.0])
+    with pytest.raises(ValueError, match="must have 2 rows"):
+        mpc.format_reference(np.zeros((3, 4)))
+    assert np.array_equal(mpc.format_disturbance([0.5]), [0.5, 0.5, 0.5])
+    assert np.array_equal(mpc.format_disturbance(np.array([[1.0, 2.0]])), [1, 2, 2])
+    assert np.array_equal(mpc.format_affine_parameters(np.array([[9.0, 8.0]])), [9.0])      # no parameter preview
+    th = mpc.form_parameter([7.0], r=[1.0, 2.0], d=[0.5], p=[4.0])
+    assert np.array_equal(th, [7, 1, 2, 1, 2, 1, 2, 0.5, 0.5, 0.5, 4])
+    plain = lmpc.MPC(q, nx=1, nu=1, nr=2, nd=0, nuprev=0, np_=0)
+    assert np.array_equal(plain.format_reference(np.array([[1.0, 3], [2, 4]])), [1, 2])    # first column
+    with pytest.raises(ValueError, match="must match number of outputs"):
+        plain.format_reference([1.0])

@@ -289,3 +289,31 @@ def test_f32_oracle_tracks_the_f64_oracle():
         assert ok.mean() > 0.98
         assert np.abs(X[ok] - Xf[ok]).max() < 1e-3
         assert (act[ok] == actf[ok]).all(axis=1).mean() > 0.99
+
+
+def test_reference_preview_condensing():
+    # mpc2mpqp.jl:535-577 ref_preview_cost: with a constant reference the preview problem has the same
+    # optimum as the plain one; theta grows from ny to ny*Np reference entries
+    for mk in (omm.pendulum, lambda: omm.satellite(6)):
+        p0, p1 = mk(), mk()
+        p1.reference_preview = True
+        q0, q1 = omm.mpc2mpqp(p0), omm.mpc2mpqp(p1)
+        assert q1.nth == q0.nth + p0.ny * (p0.Np - 1)
+        assert np.allclose(q0.H, q1.H) and np.array_equal(q0.bu, q1.bu)
+        L0 = oldp.qp2ldp(q0.H, q0.f, q0.f_theta, q0.A, q0.bu, q0.bl, q0.W, q0.senses, nout=q0.n)
+        L1 = oldp.qp2ldp(q1.H, q1.f, q1.f_theta, q1.A, q1.bu, q1.bl, q1.W, q1.senses, nout=q1.n)
+        rng = np.random.default_rng(3)
+        for _ in range(6):
+            x, r, up = rng.uniform(-.3, .3, p0.nx), rng.uniform(-.5, .5, p0.ny), rng.uniform(-1, 1, p0.nu)
+            X0, e0, _, _ = oldp.solve_batch(L0, omm.form_parameter(p0, x, r=r, uprev=up)[None])
+            X1, e1, _, _ = oldp.solve_batch(L1, omm.form_parameter(p1, x, r=r, uprev=up)[None])
+            assert e0[0] == e1[0] == 1 and np.abs(X0 - X1).max() < 1e-9
+
+
+def test_hybrid_preview_fixture_is_reproduced():
+    # the reference's hybrid test as worded (runtests.jl:820-834): fixture answers from the oracle
+    g = load_golden("satellite20_preview")
+    L = oracle_ldp_from({k: g[k] for k in ("M", "du", "dl", "Dth", "Rout", "x0", "Xth", "senses")} | {"ms": 60})
+    X, ef, it, act = oldp.solve_batch(L, g["theta"][:24])
+    assert np.array_equal(ef, g["exitflag"][:24]) and np.abs(X - g["X"][:24]).max() < 1e-9
+    assert abs(g["closed_loop_y"][-1, 0] - 0.5) < 1e-3
