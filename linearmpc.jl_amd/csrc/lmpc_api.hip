@@ -306,7 +306,7 @@ WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
     // (more registers per lane, fewer resident wavefronts)
     const bool big = (h->P.m > 128) || h->bnb;
-    const int maxNwv = big ? 8 : 16, maxWaves = big ? 12 : 16;
+    const int maxNwv = big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8), maxWaves = big ? 12 : (LMPC_WAVE_LB >= 1024 ? 16 : 12);
     WaveConfig best{1, 0, 1, perWave};
     int bestWaves = -1;
     for (int level = 3; level >= 0; level--) {

@@ -41,6 +41,10 @@
 
 #include "lmpc_pack.hpp"
 
+#ifndef LMPC_WAVE_LB
+#define LMPC_WAVE_LB 1024   // threads per workgroup the small instantiations are register-budgeted for
+#endif
+
 namespace lmpc {
 
 struct WaveLayout {
@@ -122,7 +126,7 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 // BNB: rows flagged BINARY must end up active at one of their bounds -- depth-first branch and
 // bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
 template <typename R, int MR, int LDSC, bool BNB>
-__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
+__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
@@ -409,39 +413,79 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
             alpha = wv_bcast(cand, rm);
         };
 
-        // ---- one LDP solve with the flags in sense[] (cold, or warm from the caller's mask)
-        auto solve_node = [&]() {
+        // ---- one LDP solve with the flags in sense[].
+        // forced < 0: fresh start; the initial working set is the rows flagged ACTIVE (equalities,
+        // fixed binaries) plus a warm-start mask -- the caller's (closed loop), or, for a B&B node
+        // reached by backtracking, its parent's final working set (pup/plo; flagged rows go in first
+        // so that a dependent warm row is dropped instead of making a fixed row look over-determined).
+        // forced >= 0: continue IN PLACE from the parent node's optimal working set and multipliers;
+        // row forced>>1 (side forced&1) has just been fixed and enters like a violated row would.
+        auto solve_node = [&](int forced, const unsigned long long (&pup)[MR], const unsigned long long (&plo)[MR],
+                              bool have_parent) {
+        iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; best = (R)-1; done = false;
+        if (!BNB || forced < 0) {
         WSi = 0; possoft = 0; posimm = 0; poslow = 0;
         lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; u = (R)0; y = (R)0;
         actb = 0u; lowb = 0u;
-        na = 0; sing = -1; iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; nsoft_act = 0;
-        best = (R)-1; fval = (R)0; soft_slack = (R)0; done = false; ydirty = false;
-        // initial working set: rows flagged ACTIVE (equalities, fixed binaries), then the warm-start mask
-        unsigned long long want_any = 0ull;
+        na = 0; sing = -1; nsoft_act = 0;
+        fval = (R)0; soft_slack = (R)0; ydirty = false;
+        for (int pass = 0; pass < (BNB ? 2 : 1) && !done; pass++) {
+            unsigned long long wm[MR], lm[MR];
 #pragma unroll
-        for (int r = 0; r < MR; r++) want_any |= __ballot((sense[r] & SENSE_ACTIVE) != 0 && lane + 64 * r < m);
-        if (want_any != 0ull || warm != nullptr) {
-        for (int j = 0; j < m && !done; j++) {
-            const int sj = sense_of(j);
-            bool want = (sj & SENSE_ACTIVE) != 0, lower = want && (sj & SENSE_LOWER) != 0;
-            if (warm != nullptr && !(sj & SENSE_IMMUTABLE)) {
-                const uint64_t *wp = warm + pid * P.words;
-                if ((wp[j >> 6] >> (j & 63)) & 1ull) want = true;
-                else if ((wp[(m + j) >> 6] >> ((m + j) & 63)) & 1ull) { want = true; lower = true; }
+            for (int r = 0; r < MR; r++) {
+                const int j = lane + 64 * r;
+                const int sj = sense[r];
+                const bool flagged = (j < m) && (sj & SENSE_ACTIVE) != 0;
+                bool want = flagged, lower = flagged && (sj & SENSE_LOWER) != 0;
+                if (BNB) {
+                    if (pass == 1) {
+                        want = false; lower = false;
+                        if (have_parent && j < m && !flagged && !(sj & SENSE_IMMUTABLE)) {
+                            if ((pup[r] >> lane) & 1ull) want = true;
+                            else if ((plo[r] >> lane) & 1ull) { want = true; lower = true; }
+                        }
+                    }
+                } else if (warm != nullptr && j < m && !(sj & SENSE_IMMUTABLE)) {
+                    const uint64_t *wp = warm + pid * P.words;
+                    if ((wp[j >> 6] >> (j & 63)) & 1ull) want = true;
+                    else if ((wp[(m + j) >> 6] >> ((m + j) & 63)) & 1ull) { want = true; lower = true; }
+                }
+                wm[r] = __ballot(want);
+                lm[r] = __ballot(lower);
             }
-            if (!want) continue;
-            ldl_add(j, lower);
-            if (sing >= 0) {
-                if (sj & SENSE_IMMUTABLE) { flag = EXIT_OVERDETERMINED; done = true; }
-                else {                              // dependent warm-start row: take it out again
-                    na--;
-                    sing = -1;
-                    if (lane == na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0; }
-                    if (sj & SENSE_SOFT) nsoft_act--;
-                    if (lane == (j & 63)) { actb &= ~(1u << (j >> 6)); lowb &= ~(1u << (j >> 6)); }
+#pragma unroll
+            for (int r = 0; r < MR; r++) {
+                unsigned long long todo = wm[r];
+                while (todo != 0ull && !done) {
+                    const int bit = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const int j = 64 * r + bit;
+                    const bool lower = (lm[r] >> bit) & 1ull;
+                    const int sj = sense_of(j);
+                    ldl_add(j, lower);
+                    if (sing >= 0) {
+                        if (sj & SENSE_IMMUTABLE) { flag = EXIT_OVERDETERMINED; done = true; }
+                        else {                              // dependent warm-start row: take it out again
+                            na--;
+                            sing = -1;
+                            if (lane == na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0; }
+                            if (sj & SENSE_SOFT) nsoft_act--;
+                            if (lane == (j & 63)) { actb &= ~(1u << (j >> 6)); lowb &= ~(1u << (j >> 6)); }
+                        }
+                    }
                 }
             }
         }
+        }
+
+        // ---- first step of a node that continues in place: the freshly fixed row joins the working set
+        if (BNB && forced >= 0 && iter < P.iter_limit) {
+            lam = ls;
+            ldl_add(forced >> 1, (forced & 1) != 0);
+            if (fval - best < progress_tol) {
+                if (++cyc > P.cycle_tol) { flag = EXIT_CYCLE; done = true; }
+            } else { best = fval; cyc = 0; }
+            iter++;
         }
 
         // ---- dual active-set iterations
@@ -450,6 +494,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
             int rm = -1;
             R alpha = (R)0;
             if (sing < 0) {
+                {
                 // constrained stationary point (L D L') lam* = rhs: y = L^-1 rhs is kept up to date by
                 // ldl_add, only a removal re-runs the forward sweep; then one backward sweep
                 if (ydirty) {
@@ -550,6 +595,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
                     lam = wv_fma(alpha, ls - lam, lam);
                     ldl_remove(rm);
                 }
+                }
             } else {
                 // singular working set: direction p with M_W' p = 0, p_sing = +-1
                 const int sg = sing;
@@ -568,12 +614,21 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
         }
         };   // solve_node
 
+        unsigned long long no_parent[MR];
+#pragma unroll
+        for (int r = 0; r < MR; r++) no_parent[r] = 0ull;
         if (!BNB) {
-            solve_node();
+            solve_node(-1, no_parent, no_parent, false);
         } else {
-            // depth-first branch and bound; stack entry d lives on lane d
+            // depth-first branch and bound; stack entry d lives on lane d: the row branched on, the
+            // side tried first, and the final working set of the node that branched (what its second
+            // child restarts from; the first child continues in place)
             int stk_j = 0, stk_side = 0, stk_tried = 0;
+            unsigned long long stk_up[MR], stk_lo[MR];
+#pragma unroll
+            for (int r = 0; r < MR; r++) { stk_up[r] = 0ull; stk_lo[r] = 0ull; }
             int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
+            bool inplace = false;
             R ubest = (R)0, bestval = (R)P.fval_bound;
             unsigned bestact = 0u, bestlow = 0u;
             for (;;) {
@@ -590,7 +645,21 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
                     }
                 }
                 fbound = bestval;
-                solve_node();
+                unsigned long long pup[MR], plo[MR];
+                const int dpar = depth > 0 ? depth - 1 : 0;
+#pragma unroll
+                for (int r = 0; r < MR; r++) {
+                    const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(stk_up[r] & 0xffffffffull), dpar);
+                    const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(stk_up[r] >> 32), dpar);
+                    const unsigned lo32b = (unsigned)__builtin_amdgcn_readlane((int)(stk_lo[r] & 0xffffffffull), dpar);
+                    const unsigned hi32b = (unsigned)__builtin_amdgcn_readlane((int)(stk_lo[r] >> 32), dpar);
+                    pup[r] = ((unsigned long long)hi32 << 32) | lo32;
+                    plo[r] = ((unsigned long long)hi32b << 32) | lo32b;
+                }
+                int forced = -1;
+                if (inplace)
+                    forced = 2 * __builtin_amdgcn_readlane(stk_j, dpar) + __builtin_amdgcn_readlane(stk_side, dpar);
+                solve_node(forced, pup, plo, depth > 0);
                 nodes++;
                 total_it += iter;
                 bool descend = false;
@@ -616,11 +685,23 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : 1024) void wave_kernel(
                         bj = wv_bcast(bj, jb & 63);
                         const R dlo = C[P.odl + jb] + bj, dup = C[P.odu + jb] + bj;
                         const int lower_first = (wv_first(Mu) - dlo) < (dup - wv_first(Mu)) ? 1 : 0;
-                        if (lane == depth) { stk_j = jb; stk_side = lower_first; stk_tried = 1; }
+                        unsigned long long nup[MR], nlo[MR];
+#pragma unroll
+                        for (int r = 0; r < MR; r++) {
+                            const bool a = (actb >> r) & 1u, lo = (lowb >> r) & 1u;
+                            nup[r] = __ballot(a && !lo);
+                            nlo[r] = __ballot(a && lo);
+                        }
+                        if (lane == depth) {
+                            stk_j = jb; stk_side = lower_first; stk_tried = 1;
+#pragma unroll
+                            for (int r = 0; r < MR; r++) { stk_up[r] = nup[r]; stk_lo[r] = nlo[r]; }
+                        }
                         depth++;
                         descend = true;
                     }
                 }
+                inplace = descend;
                 if (!descend) {                          // backtrack to the next untried side
                     while (depth > 0 && __builtin_amdgcn_readlane(stk_tried, depth - 1) == 2) depth--;
                     if (depth == 0) break;

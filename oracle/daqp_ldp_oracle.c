@@ -326,82 +326,107 @@ static void shift_bounds(work_t *w, const oracle_ldp *p, const real *theta) {
     }
 }
 
-/* One cold- (warm == NULL) or warm-started LDP solve on the bounds already in w.  sense0[m] are the
- * constraint flags of THIS solve: rows flagged ACTIVE start in the working set (at their lower
- * bound if also flagged LOWER) -- equalities, and the binaries a branch-and-bound node has fixed.
+/* One LDP solve on the bounds already in w.  sense0[m] are the constraint flags of THIS solve: rows
+ * flagged ACTIVE start in the working set (at their lower bound if also flagged LOWER) --
+ * equalities, and the binaries a branch-and-bound node has fixed.
+ *   forced < 0 : fresh start.  The initial working set is the rows flagged ACTIVE plus the rows of
+ *     `warm` (NULL = cold).  two_pass == 0: one pass in row order (the warm start of a closed loop,
+ *     /root/reference/codegen/mpc_update_qp.c:44-47).  two_pass != 0 (a B&B node restarted from its
+ *     parent's working set): the flagged rows first, the warm rows after them, so that a warm row
+ *     that turns out dependent is dropped instead of making a fixed row look over-determined.
+ *   forced >= 0: continue IN PLACE from the optimal working set left in w by the previous call (the
+ *     parent node): row forced>>1 has just been fixed (ACTIVE|IMMUTABLE, lower side if forced&1) and
+ *     enters the working set as the first step, exactly as a violated row would -- the dual iterate
+ *     of the parent stays feasible for the child, which is what makes a dual active-set method cheap
+ *     inside branch and bound (the reference gets this from daqp_bnb, [EXT]).
  * Leaves the iterate in w (u, fval, working set) and returns the DAQP-style exit flag. */
 static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, const int32_t *sense0,
-                      const uint64_t *warm, int32_t *iters) {
+                      const uint64_t *warm, int two_pass, int forced, int32_t *iters) {
     const int n = p->n, m = p->m;
     int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
     real best_fval = -1.0;
 
-    for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
-    w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
-    for (int k = 0; k < n; k++) w->u[k] = 0.0;
+    if (forced < 0) {
+        for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
+        w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
+        for (int k = 0; k < n; k++) w->u[k] = 0.0;
 
-    /* initial working set: rows flagged ACTIVE and, if warm, the given mask */
-    for (int j = 0; j < m; j++) {
-        int want = (sense0[j] & SENSE_ACTIVE) != 0, lower = want && (sense0[j] & SENSE_LOWER);
-        if (warm && !(sense0[j] & SENSE_IMMUTABLE)) {
-            if ((warm[j >> 6] >> (j & 63)) & 1) want = 1;
-            else if ((warm[(m + j) >> 6] >> ((m + j) & 63)) & 1) { want = 1; lower = 1; }
+        /* initial working set: rows flagged ACTIVE and, if warm, the given mask */
+        for (int pass = 0; pass < (two_pass ? 2 : 1); pass++) {
+            for (int j = 0; j < m; j++) {
+                int want = (sense0[j] & SENSE_ACTIVE) != 0, lower = want && (sense0[j] & SENSE_LOWER);
+                if (two_pass && pass == 1) { if (want) continue; }          /* flagged rows went in first */
+                if (warm && !(sense0[j] & SENSE_IMMUTABLE) && !(two_pass && pass == 0)) {
+                    if ((warm[j >> 6] >> (j & 63)) & 1) want = 1;
+                    else if ((warm[(m + j) >> 6] >> ((m + j) & 63)) & 1) { want = 1; lower = 1; }
+                }
+                if (!want) { w->sense[j] &= ~SENSE_ACTIVE; continue; }
+                if (lower) w->sense[j] |= SENSE_LOWER;
+                ldl_add(w, p, s, j);
+                if (w->sing >= 0) {
+                    if (sense0[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
+                    /* dependent warm-start row: drop it again */
+                    w->na--; w->sing = -1;
+                    if (w->sense[j] & SENSE_SOFT) w->nsoft_act--;
+                    w->sense[j] &= ~(SENSE_ACTIVE | SENSE_LOWER);
+                }
+            }
         }
-        if (!want) { w->sense[j] &= ~SENSE_ACTIVE; continue; }
-        if (lower) w->sense[j] |= SENSE_LOWER;
-        ldl_add(w, p, s, j);
-        if (w->sing >= 0) {
-            if (sense0[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
-            /* dependent warm-start row: drop it again */
-            w->na--; w->sing = -1;
-            if (w->sense[j] & SENSE_SOFT) w->nsoft_act--;
-            w->sense[j] &= ~(SENSE_ACTIVE | SENSE_LOWER);
-        }
+    } else {
+        const int jf = forced >> 1;
+        w->sense[jf] = (sense0[jf] & ~SENSE_LOWER) & ~SENSE_ACTIVE;             /* ldl_add sets ACTIVE */
     }
 
     for (; iter < s->iter_limit; iter++) {
         if (w->sing < 0) {
-            compute_csp(w);
-            int nblock = 0, rm = -1;
+            int nblock = 0, rm = -1, add = -1, isupper = 0;
             real alpha = 0.0;
-            for (int i = 0; i < w->na; i++) {
-                const int j = w->WS[i];
-                if (w->sense[j] & SENSE_IMMUTABLE) continue;
-                if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
-                else if (w->lam_star[i] > -s->dual_tol) continue;
-                const real cand = -w->lam[i] / (w->lam_star[i] - w->lam[i]);
-                if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
-                nblock++;
-            }
-            if (nblock == 0) {
-                primal_and_fval(w, p, s);
-                if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
-                /* most violated constraint, primal_tol margin */
-                real min_val = -s->primal_tol;
-                int add = -1, isupper = 0, broken = 0;
-                for (int j = 0; j < m; j++) {
+            if (forced >= 0) {
+                add = forced >> 1; isupper = !(forced & 1);
+                forced = -1;
+            } else {
+                compute_csp(w);
+                for (int i = 0; i < w->na; i++) {
+                    const int j = w->WS[i];
                     if (w->sense[j] & SENSE_IMMUTABLE) continue;
-                    const real *mj = &p->M[(size_t)j * n];
-                    real Mu = 0.0;
-                    for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
-                    const real vu = w->dupper[j] - Mu;
-                    const real vl = -(w->dlower[j] - Mu);
-                    if (w->sense[j] & SENSE_ACTIVE) {
-                        /* a hard row of the working set sits ON its bound in exact arithmetic; if the
-                         * iterate violates it by more than primal_tol the factorisation has broken
-                         * down (typically an infeasible problem with a nearly dependent working set,
-                         * multipliers ~1e15): never report that as optimal */
-                        if (!(w->sense[j] & SENSE_SOFT) && (vu < -s->primal_tol || vl < -s->primal_tol)) broken = 1;
-                        continue;
+                    if (w->sense[j] & SENSE_LOWER) { if (w->lam_star[i] < s->dual_tol) continue; }
+                    else if (w->lam_star[i] > -s->dual_tol) continue;
+                    const real cand = -w->lam[i] / (w->lam_star[i] - w->lam[i]);
+                    if (nblock == 0 || cand < alpha) { alpha = cand; rm = i; }
+                    nblock++;
+                }
+                if (nblock == 0) {
+                    primal_and_fval(w, p, s);
+                    if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
+                    /* most violated constraint, primal_tol margin */
+                    real min_val = -s->primal_tol;
+                    int broken = 0;
+                    for (int j = 0; j < m; j++) {
+                        if (w->sense[j] & SENSE_IMMUTABLE) continue;
+                        const real *mj = &p->M[(size_t)j * n];
+                        real Mu = 0.0;
+                        for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
+                        const real vu = w->dupper[j] - Mu;
+                        const real vl = -(w->dlower[j] - Mu);
+                        if (w->sense[j] & SENSE_ACTIVE) {
+                            /* a hard row of the working set sits ON its bound in exact arithmetic; if the
+                             * iterate violates it by more than primal_tol the factorisation has broken
+                             * down (typically an infeasible problem with a nearly dependent working set,
+                             * multipliers ~1e15): never report that as optimal */
+                            if (!(w->sense[j] & SENSE_SOFT) && (vu < -s->primal_tol || vl < -s->primal_tol)) broken = 1;
+                            continue;
+                        }
+                        if (vu < min_val) { add = j; isupper = 1; min_val = vu; }
+                        else if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
                     }
-                    if (vu < min_val) { add = j; isupper = 1; min_val = vu; }
-                    else if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
+                    if (add < 0) {
+                        if (broken) exitflag = EXIT_CYCLE;
+                        else exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
+                        break;
+                    }
                 }
-                if (add < 0) {
-                    if (broken) exitflag = EXIT_CYCLE;
-                    else exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
-                    break;
-                }
+            }
+            if (add >= 0) {
                 for (int i = 0; i < w->na; i++) w->lam[i] = w->lam_star[i];
                 if (!isupper) w->sense[add] |= SENSE_LOWER;
                 ldl_add(w, p, s, add);
@@ -440,7 +465,7 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
                      const real *theta, const uint64_t *warm, real *xout,
                      int32_t *iters, uint64_t *active, int nwords) {
     shift_bounds(w, p, theta);
-    const int ef = solve_core(w, p, s, p->sense, warm, iters);
+    const int ef = solve_core(w, p, s, p->sense, warm, 0, -1, iters);
     write_outputs(w, p, theta, xout, active, nwords);
     return ef;
 }
@@ -451,10 +476,14 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
  * libdaqp's source is not available, so the search order is this file's own (the optimum of a
  * strictly convex MIQP does not depend on it):
  *   - a node = a set of binaries fixed to a side; its relaxation is the LDP with those rows as
- *     active immutable rows, solved from a cold start with fval_bound = incumbent value, so the
- *     dual iterations stop as soon as the node is dominated;
+ *     active immutable rows, with fval_bound = incumbent value, so the dual iterations stop as soon
+ *     as the node is dominated;
  *   - branch on the lowest-index binary row that is not in the relaxation's final working set,
  *     first to the bound its row value M_j u is closer to, then to the other;
+ *   - the FIRST child continues in place from its parent's optimal working set and multipliers (the
+ *     newly fixed row enters like a violated row would: solve_core's `forced`); the SECOND child is
+ *     reached by backtracking, when that state is gone: it restarts from the parent's final working
+ *     set, kept on the stack as a mask (solve_core's two-pass warm start);
  *   - a node whose binaries are all active is a leaf; it replaces the incumbent if strictly better.
  * iters returns the iterations summed over all nodes; the flag is 1 if an incumbent exists,
  * -1 if none, -4 if the node limit ran out first. */
@@ -462,14 +491,16 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
 static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, const real *theta,
                      real *xout, int32_t *iters, uint64_t *active, int nwords) {
     const int n = p->n, m = p->m;
+    const int nw = nwords > 0 ? nwords : 1;
     int32_t *sense = (int32_t *)malloc(sizeof(int32_t) * (m > 0 ? m : 1));
     int *stk_j = (int *)malloc(sizeof(int) * (m + 1)), *stk_side = (int *)malloc(sizeof(int) * (m + 1)),
         *stk_tried = (int *)malloc(sizeof(int) * (m + 1));
+    uint64_t *stk_mask = (uint64_t *)calloc((size_t)nw * (m + 1), sizeof(uint64_t));
     real *ubest = (real *)calloc(n, sizeof(real));
-    uint64_t *abest = (uint64_t *)calloc(nwords > 0 ? nwords : 1, sizeof(uint64_t));
+    uint64_t *abest = (uint64_t *)calloc(nw, sizeof(uint64_t));
     oracle_settings sn = *s;
     real best = s->fval_bound;
-    int have = 0, depth = 0, nodes = 0, total_it = 0, flag = EXIT_INFEASIBLE;
+    int have = 0, depth = 0, nodes = 0, total_it = 0, flag = EXIT_INFEASIBLE, inplace = 0;
     shift_bounds(w, p, theta);
     for (;;) {
         if (nodes >= BNB_NODE_LIMIT) { flag = EXIT_ITERLIMIT; break; }
@@ -478,7 +509,9 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
             sense[stk_j[d]] |= SENSE_ACTIVE | SENSE_IMMUTABLE | (stk_side[d] ? SENSE_LOWER : 0);
         sn.fval_bound = best;
         int32_t it = 0;
-        const int ef = solve_core(w, p, &sn, sense, NULL, &it);
+        int ef;
+        if (inplace) ef = solve_core(w, p, &sn, sense, NULL, 0, 2 * stk_j[depth - 1] + stk_side[depth - 1], &it);
+        else ef = solve_core(w, p, &sn, sense, depth > 0 ? stk_mask + (size_t)(depth - 1) * nw : NULL, 1, -1, &it);
         nodes++;
         total_it += it;
         int descend = 0;
@@ -503,10 +536,18 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
                 for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
                 const int lower_first = (Mu - w->dlower[jb]) < (w->dupper[jb] - Mu);
                 stk_j[depth] = jb; stk_side[depth] = lower_first; stk_tried[depth] = 1;
+                uint64_t *mk = stk_mask + (size_t)depth * nw;       /* this node's final working set */
+                for (int q = 0; q < nw; q++) mk[q] = 0;
+                for (int i = 0; i < w->na; i++) {
+                    const int j = w->WS[i];
+                    const int bit = (w->sense[j] & SENSE_LOWER) ? m + j : j;
+                    mk[bit >> 6] |= (uint64_t)1 << (bit & 63);
+                }
                 depth++;
                 descend = 1;
             }
         }
+        inplace = descend;
         if (!descend) {                                 /* backtrack to the next untried side */
             while (depth > 0 && stk_tried[depth - 1] == 2) depth--;
             if (depth == 0) break;
@@ -524,7 +565,7 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
     write_outputs(w, p, theta, xout, NULL, 0);
     if (active) for (int q = 0; q < nwords; q++) active[q] = have ? abest[q] : 0;
     if (iters) *iters = total_it;
-    free(sense); free(stk_j); free(stk_side); free(stk_tried); free(ubest); free(abest);
+    free(sense); free(stk_j); free(stk_side); free(stk_tried); free(stk_mask); free(ubest); free(abest);
     return flag;
 }
 
