@@ -85,9 +85,12 @@ def test_gpu_vs_oracle_same_pack(lmpc, name, nout):
     _compare(qp, np.vstack([g["theta"], extra]))
 
 
-def test_ldp_setup_path_matches_mpqp_setup(lmpc):
-    # generated-C style setup (lmpc_setup_ldp) gives the same answers as the mpQP setup
-    g = load_golden("pendulum")
+@pytest.mark.parametrize("name", ["pendulum", "soft_doc", "prestab", "satellite20_preview"])
+def test_ldp_setup_path_matches_mpqp_setup(lmpc, name):
+    # generated-C style setup (lmpc_setup_ldp: the arrays LinearMPC.codegen writes, codegen.jl:183-189)
+    # gives the same answers as the mpQP setup -- the reference checks the same pair, Julia path vs
+    # generated C, on plain / preview / hybrid controllers (runtests.jl:78-81, :627-667, :836-858)
+    g = load_golden(name)
     qp1 = _qp_from_golden(lmpc, g)
     pk = qp1.ldp()
     qp2 = lmpc.BatchedQP.from_ldp(pk["M"], pk["du"], pk["dl"], pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"],
@@ -727,3 +730,33 @@ def test_hybrid_closed_loop_with_reference_preview(lmpc):
     a = q0.simulate_ref(x0, 8, g0["F"], g0["G"], rc, preview=0)
     b_ = q0.simulate(x0, 8, g0["F"], g0["G"], r=np.tile([0.5, 0.0, 0.0], (N, 1)), warm=False)
     assert np.array_equal(a["U"], b_["U"]) and np.array_equal(a["X"], b_["X"])
+
+
+def test_form_parameter_device_all_blocks(lmpc):
+    # theta = [x; r (preview); d (preview); uprev; p (constant)] -- every block of explicit.jl:54-63
+    import torch
+    rng = np.random.default_rng(8)
+    nx, ny, nd, nu, npar, Np = 2, 2, 1, 1, 2, 4
+    nth = nx + ny * Np + nd * Np + nu + npar
+    n = 3
+    H = np.eye(n)
+    q = lmpc.MPQP(H, np.zeros(n), rng.normal(size=(n, nth)), np.zeros((0, n)), np.ones(n), -np.ones(n),
+                  np.zeros((n, nth)), np.zeros(n, np.int32))
+    mpc = lmpc.MPC(q, nx=nx, nu=nu, nr=ny * Np, nd=nd * Np, nuprev=nu, np_=npar, Np=Np,
+                   reference_preview=True, disturbance_preview=True).setup()
+    N = 50
+    X = rng.normal(size=(N, nx)); R = rng.normal(size=(N, ny, 6)); D = rng.normal(size=(nd, 2))
+    U = rng.normal(size=(N, nu)); Pm = rng.normal(size=(N, npar, 1))
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for k0 in (0, 1, 4):
+        th = mpc.opt_model.form_parameter_device(cu(X), r=cu(R), d=cu(D), uprev=cu(U), p=cu(Pm),
+                                                 r_preview=Np, d_preview=Np, k0=k0)
+        torch.cuda.synchronize()
+        ref = np.stack([mpc.form_parameter(X[i], r=R[i][:, min(k0, 5):], d=D[:, min(k0, 1):], uprev=U[i],
+                                           p=Pm[i][:, 0]) for i in range(N)])
+        assert np.array_equal(th.cpu().numpy(), ref)
+    # and the formed batch solves like the host-formed one
+    x1, ef1, _, _ = mpc.opt_model.solve(th.cpu().numpy())
+    x2, ef2 = mpc.opt_model.solve_device(th)
+    torch.cuda.synchronize()
+    assert np.array_equal(x1, x2.cpu().numpy()) and np.array_equal(ef1, ef2.cpu().numpy())
