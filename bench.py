@@ -272,6 +272,20 @@ def main():
     elapsed = float(t.item())
 
     flags = fbuf[(args.steps - 1) % nbuf].cpu().numpy() if args.steps else np.zeros(0, np.int32)
+    # the same call with NOTHING else on the chip (outside the timed region): one launch after the
+    # other on one stream, HIP events on that stream -- the per-launch duration rocprofv3's kernel
+    # trace reports; with several batches in flight the launches above overlap and a single launch
+    # no longer owns the GPU
+    solo = None
+    if nstreams > 1 and rank == 0 and args.steps:
+        nsolo = int(min(200, max(20, args.steps)))
+        torch.cuda.synchronize(dev)
+        qp.profile(True)
+        for _ in range(nsolo):
+            qp.solve_device(theta, x=xbuf[0], exitflag=fbuf[0], stream=stream_handles[0])
+        torch.cuda.synchronize(dev)
+        solo = qp.profile_read()
+        qp.profile(False)
     # distribution of the work (untimed extra solve): throughput depends on how many iterations the
     # batch needs, so the histograms travel with the number
     it_d = torch.empty(n_local, dtype=torch.int32, device=dev)
@@ -341,6 +355,13 @@ def main():
                          "fp64_tflops_est": flop_est * value / 1e12,
                          "solves_per_s_per_cu": value / world / 256.0},
         }
+        if solo is not None and solo[0] > 0 and solo[1] > 0:
+            ach1 = (bytes_per * n_local) / (solo[1] * 1e-3) / 1e9
+            out["roofline"]["single_launch"] = {
+                "launches_timed": solo[0], "kernel_ms": solo[1], "screen_kernel_ms": solo[2],
+                "iterate_kernel_ms": solo[3], "achieved": ach1, "frac": ach1 / HBM_PEAK_GBS,
+                "note": "one call at a time on one stream (after the timed region): HIP-event duration of a "
+                        "single launch, the figure rocprofv3 --kernel-trace reports per kernel"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, theta_h, nout, f32=args.f32)
         print(json.dumps(out), flush=True)
