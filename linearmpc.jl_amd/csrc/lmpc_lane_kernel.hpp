@@ -318,11 +318,16 @@ __device__ __forceinline__ void lane_solve(
                 auto scan_row = [&](int j) {
                     if (!((P.imm_mask >> j) & 1ull)) {
                         double Mu = 0.0;
+                        // unrolled scan (MS > 0): rows and bounds as LDS broadcast reads (uniform address,
+                        // in-order return, +2.5 % on the headline batch over scalar loads, whose SGPR
+                        // operands cannot stay resident between iterations); run-time row count: scalar loads
+                        const double *mrow = MS > 0 ? sM + j * N : C + P.oM + j * N;
 #pragma unroll
-                        for (int k = 0; k < N; k++) Mu = __builtin_fma(C[P.oM + j * N + k], u[k], Mu);
+                        for (int k = 0; k < N; k++) Mu = __builtin_fma(mrow[k], u[k], Mu);
                         const double b = sB[j * B + tid];
-                        const double vu = (C[P.odu + j] + b) - Mu;
-                        const double vl = -((C[P.odl + j] + b) - Mu);
+                        const double duj = MS > 0 ? sdu[j] : C[P.odu + j], dlj = MS > 0 ? sdl[j] : C[P.odl + j];
+                        const double vu = (duj + b) - Mu;
+                        const double vl = -((dlj + b) - Mu);
                         if (!((act >> j) & 1ull)) {
                             if (vu < min_val) { add = j; addlow = false; min_val = vu; }
                             else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
