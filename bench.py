@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
                     help="N > 1: RCCL all-gather of x and exit flags once after the last step (default), "
                          "after every step (overlapped with the next solve), or never")
+    ap.add_argument("--no-single-launch", action="store_true",
+                    help="skip the one-call-at-a-time section after the timed region (profiling runs: keeps the "
+                         "kernel trace to the launches of the timed region)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
@@ -245,11 +248,22 @@ def main():
         step(k)
     drain()
     fence()
+    # Device time over the timed region: ONE pair of HIP events per launch stream brackets all of
+    # that stream's launches (events between every two kernels cost ~12 % throughput: each is an extra
+    # packet the queue has to retire in order).  Per-kernel durations come from the single-launch
+    # section below, which records events around every kernel.
+    per_call_events = os.environ.get("LMPC_BENCH_CALL_EVENTS") == "1"
     for q_ in qps:
-        q_.profile(True)
+        q_.profile(per_call_events)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     t0 = time.perf_counter()
+    for e_, s_ in zip(ev0, streams):
+        e_.record(s_)
     for k in range(args.steps):
         step(k)
+    for e_, s_ in zip(ev1, streams):
+        e_.record(s_)
     enqueue_s = time.perf_counter() - t0          # host time to issue all steps (diagnostic)
     drain()
     if final_gather and args.steps:
@@ -260,11 +274,13 @@ def main():
         dist.all_gather_into_tensor(ffin, fbuf[lastb])
     fence()
     elapsed = time.perf_counter() - t0
-    prof = [q_.profile_read() for q_ in qps]
+    prof = [q_.profile_read() for q_ in qps] if per_call_events else []
     for q_ in qps:
         q_.profile(False)
-    nlaunch = sum(p_[0] for p_ in prof)
-    kern_ms, screen_ms, iterate_ms = (sum(p_[0] * p_[i] for p_ in prof) / max(nlaunch, 1) for i in (1, 2, 3))
+    # average device time of one launch on its stream = event span of the stream / its launches
+    calls_on = [len(range(i_, args.steps, nstreams)) for i_ in range(nstreams)]
+    span_ms = [ev0[i_].elapsed_time(ev1[i_]) for i_ in range(nstreams)]
+    stream_call_ms = sum(span_ms) / max(sum(calls_on), 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -277,7 +293,7 @@ def main():
     # trace reports; with several batches in flight the launches above overlap and a single launch
     # no longer owns the GPU
     solo = None
-    if nstreams > 1 and rank == 0 and args.steps:
+    if rank == 0 and args.steps and not args.no_single_launch:
         nsolo = int(min(200, max(20, args.steps)))
         torch.cuda.synchronize(dev)
         qp.profile(True)
@@ -316,7 +332,9 @@ def main():
         # longer owns it, so the bytes one step moves are divided by the wall time one step takes
         # (about kernel_ms / batches_in_flight; kernel_ms stays in the record for the rocprof check).
         step_ms = 1e3 * elapsed / max(args.steps, 1)
-        dur_ms = kern_ms if nstreams == 1 else step_ms
+        kern_ms, screen_ms, iterate_ms = (solo[1], solo[2], solo[3]) if solo else (0.0, 0.0, 0.0)
+        nlaunch = args.steps
+        dur_ms = stream_call_ms if nstreams == 1 else step_ms
         achieved = (bytes_per * n_local) / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
@@ -347,6 +365,7 @@ def main():
                        "active_set_size_hist": act_hist},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "stream_call_ms": stream_call_ms,
                          "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
                          "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
                          "duration_used_ms": dur_ms, "host_enqueue_ms_per_step": 1e3 * enqueue_s / max(args.steps, 1),
