@@ -56,6 +56,7 @@ struct lmpc_handle {
     int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
     bool waveQueue = true;      // tuning: dynamic problem queue of the wave kernel (0 = static split)
     int32_t *dQueue = nullptr;
+    int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
     int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)
     int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
@@ -291,7 +292,7 @@ size_t wave_shared_bytes(const HostPack &P, int level, size_t rs) {
     return rs * (level >= 3 ? 2 * nM + nG : (level == 2 ? 2 * nM : (level == 1 ? nM : 0)));
 }
 
-struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; };
+struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; bool packed; };
 
 // Workgroup shape of the wave kernel: nwv wavefronts (= problems in flight) share one LDS copy of
 // the problem data.  Registers allow 4 wavefronts per SIMD (16 per CU; 12 for the 512-thread
@@ -300,17 +301,24 @@ struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; };
 // mass-spring: 16 waves with only M' staged 1.23e7/s, 8 waves with everything staged 0.85e7/s), and
 // at equal residency small workgroups win.  So: most wavefronts per CU first, then the highest
 // staging level that reaches it, then the smallest workgroup.
-WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
+WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) {
     const WaveLayout &Wl = h->W;
-    const size_t perWave = rs * (size_t)Wl.cap * Wl.ldc;
+    // per-wave factor L: square with an odd leading dimension, or packed strict lower triangle
+    const size_t perWave = rs * (packed ? ((size_t)Wl.cap * (Wl.cap - 1) / 2) : ((size_t)Wl.cap * Wl.ldc));
     // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
     // (more registers per lane, fewer resident wavefronts)
     const bool big = (h->P.m > 128) || h->bnb;
-    const int maxNwv = big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8), maxWaves = big ? 12 : (LMPC_WAVE_LB >= 1024 ? 16 : 12);
-    WaveConfig best{1, 0, 1, perWave};
+    // resident wavefronts per CU the instantiation's registers allow (see `make asm`): 16 for the plain
+    // ones and for binary32 B&B with m <= 64, 12 for binary64 B&B (m <= 128) and binary32 B&B (m <= 128),
+    // 8 beyond
+    const int maxNwv = big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8);
+    int maxWaves = LMPC_WAVE_LB >= 1024 ? 16 : 12;
+    if (h->P.m > 128) maxWaves = 8;
+    else if (h->bnb) maxWaves = (rs == 4 && h->P.m <= 64) ? 16 : 12;
+    WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
-    for (int level = 3; level >= 0; level--) {
-        if (h->waveLevel >= 0 && level != h->waveLevel) continue;
+    for (int level = packed ? 1 : 3; level >= 0; level--) {          // packed is instantiated for levels 0, 1
+        if (h->waveLevel >= 0 && level != (packed && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
         for (int nwv : {4, 8, 16, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
@@ -320,17 +328,25 @@ WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
             if (blocks * nwv > maxWaves) blocks = maxWaves / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
-            if (waves > bestWaves) { bestWaves = waves; best = WaveConfig{nwv, level, blocks, lds}; }
+            if (waves > bestWaves) { bestWaves = waves; best = WaveConfig{nwv, level, blocks, lds, packed}; }
         }
     }
     return best;
 }
 
-template <typename R, int MR, int LDSC, bool BNB>
+// square L unless the packed layout keeps at least a quarter more wavefronts resident
+WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
+    const WaveConfig sq = wave_config_for(h, rs, false), pk = wave_config_for(h, rs, true);
+    if (h->wavePacked == 0) return sq;
+    if (h->wavePacked == 1) return pk;
+    return 4 * pk.blocksPerCU * pk.nwv >= 5 * sq.blocksPerCU * sq.nwv ? pk : sq;
+}
+
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;
-    auto kern = wave_kernel<R, MR, LDSC, BNB>;
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
     int blocksPerCU = cfg.blocksPerCU;
@@ -372,14 +388,17 @@ int launch_wave_t(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R 
     int rc;
     const int mr = (h->P.m + 63) / 64;
     const WaveConfig cfg = wave_config(h, sizeof(R));
-#define LMPC_WV3(MRR, LV) (h->bnb ? launch_wave_cfg<R, MRR, LV, true>(h, cfg, dC, nprob, theta, x, flag, iters, active, nullptr, st) \
-                                  : launch_wave_cfg<R, MRR, LV, false>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
-#define LMPC_WV(MRR) (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0))))
+#define LMPC_WV4(MRR, LV, PK) (h->bnb ? launch_wave_cfg<R, MRR, LV, true, PK>(h, cfg, dC, nprob, theta, x, flag, iters, active, nullptr, st) \
+                                      : launch_wave_cfg<R, MRR, LV, false, PK>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
+#define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
+                                 : (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))))
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
     else rc = LMPC_WV(4);
 #undef LMPC_WV
 #undef LMPC_WV3
+#undef LMPC_WV4
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
@@ -905,6 +924,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
+    if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }
     if (std::strcmp(name, "wave_nwv") == 0) {

@@ -125,8 +125,10 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 // 0 nothing, 1 M transposed (constraint scan), 2 + M (primal step), 3 + packed Gram (row append).
 // BNB: rows flagged BINARY must end up active at one of their bounds -- depth-first branch and
 // bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
-template <typename R, int MR, int LDSC, bool BNB>
-__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_kernel(
+// PACKED: layout of the per-wave factor L, see below.
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
+__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB)
+__attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
@@ -137,11 +139,20 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
     const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
     // wave-uniform by construction; telling the compiler keeps every loop counter of the solve in SGPRs
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = P.n, m = P.m, nth = P.nth, ldc = P.ldc, cap = P.cap;
-    R *L = lds + (size_t)wv * cap * ldc;             // L(i,t) = L[t*ldc + i], i > t
+    const int n = P.n, m = P.m, nth = P.nth, cap = P.cap;
+    // L(i,t), i > t, lives at L[cbase(t) + i].  Square layout (cbase(t) = t*ldc, odd ldc): a forward
+    // sweep reads consecutive addresses across lanes, a backward sweep (lane i reads its own column)
+    // an odd stride -- both conflict-free.  PACKED layout (cbase(t) = t(2cap-1-t)/2 - t - 1: column
+    // after column of the strict lower triangle): half the LDS, which is what bounds the resident
+    // wavefronts once n reaches ~45 (hybrid MPC, n = 60: 5 -> 10 wavefronts per CU in binary64, +60 %);
+    // it costs ~6 % on small problems (index arithmetic, bank conflicts of the column reads), so the
+    // host picks it only where it buys residency.
+    const int lsize = PACKED ? cap * (cap - 1) / 2 : cap * P.ldc;
+    R *L = lds + (size_t)wv * lsize;
+    auto cbase = [&](int t) -> int { return PACKED ? t * (2 * cap - 1 - t) / 2 - t - 1 : t * P.ldc; };
     const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG;
     if (LDSC > 0) {
-        R *sc = lds + (size_t)nwv * cap * ldc;
+        R *sc = lds + (size_t)nwv * lsize;
         const int nM = m * n, nG = m * (m + 1) / 2;
         for (int i = threadIdx.x; i < nM; i += blockDim.x) sc[i] = C[P.oMt + i];
         Mt = sc;
@@ -160,6 +171,8 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
     const R kInf = wv_lim<R>::inf();
     const int lrow = lane < cap ? lane : cap - 1;                // clamped row/column of L for prefetches
     const int lrow1 = lane + 1 < cap ? lane + 1 : cap - 1;
+    const int lr1 = lrow > 0 ? lrow : 1;                         // row index that is valid in every column read
+    const int mycol = cbase(lrow);                               // this lane's own column: L(t, lane) = L[mycol + t]
     const int lanen = lane < n ? lane : n - 1;
 
     int sense0[MR], sense[MR];                       // constraint slots of this lane: as given / of the
@@ -232,7 +245,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
                     const int t = t0 + q < cap ? t0 + q : cap - 1;
-                    Lr[q] = L[t * ldc + lrow];
+                    Lr[q] = L[cbase(t) + lr1];
                 }
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
@@ -251,8 +264,8 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
                 R Lc[CH];
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
-                    const int t = t1 - q > 0 ? t1 - q : 0;
-                    Lc[q] = L[lrow * ldc + t];
+                    const int t = t1 - q > 1 ? t1 - q : 1;
+                    Lc[q] = L[mycol + t];
                 }
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
@@ -299,7 +312,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
             }
             dnew = wv_first(dnew);
             const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft_act) >= n);
-            if (lane < na) L[lane * ldc + na] = l;   // new row: L(na, t) written by lane t
+            if (lane < na) L[mycol + na] = l;        // new row: L(na, t) written by lane t
             if (lane == na) {
                 WSi = j; possoft = is_soft ? 1 : 0; posimm = (sj & SENSE_IMMUTABLE) ? 1 : 0; poslow = lower ? 1 : 0;
                 rhs = rj; lam = (R)0; ls = (R)0; y = ynew;
@@ -318,7 +331,8 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
         // ---- drop working-set position r (wave-uniform): compact L, rank-one update of the tail
         auto ldl_remove = [&](int r) {
             const int nao = na;
-            R w = (lane > r && lane < nao) ? L[r * ldc + lane] : (R)0;   // old row index = lane
+            R w = L[cbase(r) + lr1];                 // old row index = lane
+            w = (lane > r && lane < nao) ? w : (R)0;
             R alpha = wv_bcast(D, r);
             const int jrem = __builtin_amdgcn_readlane(WSi, r);
             const int softrem = __builtin_amdgcn_readlane(possoft, r);
@@ -331,14 +345,14 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
                     int c = c0 + qq;
                     c = c < cap - 2 ? c : (cap - 2 > 0 ? cap - 2 : 0);
                     const int srcc = c < r ? c : c + 1;
-                    tmp[qq] = L[srcc * ldc + lrow1];
+                    tmp[qq] = L[cbase(srcc) + lrow1];
                 }
 #pragma unroll
                 for (int qq = 0; qq < CH; qq++) {
                     const int c = c0 + qq;
                     if (c + 1 < nao - 1) {
                         const int lo = (c + 1 > r) ? c + 1 : r;
-                        if (wv_in(wv_below(nao - 1) & ~wv_below(lo))) L[c * ldc + lane] = tmp[qq];
+                        if (wv_in(wv_below(nao - 1) & ~wv_below(lo))) L[cbase(c) + lane] = tmp[qq];
                     }
                 }
             }
@@ -365,7 +379,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
 #pragma unroll
                 for (int qq = 0; qq < CH; qq++) {
                     const int t = t0 + qq < cap ? t0 + qq : cap - 1;
-                    lq[qq] = L[t * ldc + lrow];
+                    lq[qq] = L[cbase(t) + lr1];
                 }
 #pragma unroll
                 for (int qq = 0; qq < CH; qq++) {
@@ -385,7 +399,7 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
                             if (lane == t) { D = dbar; Dinv = rinv; }
                             if (wv_in(wv_below(na) & (~1ull << t))) {
                                 w = wv_fma(-pt, lq[qq], w);
-                                L[t * ldc + lane] = wv_fma(beta, w, lq[qq]);
+                                L[cbase(t) + lane] = wv_fma(beta, w, lq[qq]);
                             }
                         }
                     }
@@ -599,7 +613,8 @@ __global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB) void wave_ke
             } else {
                 // singular working set: direction p with M_W' p = 0, p_sing = +-1
                 const int sg = sing;
-                R acc = (lane < sg) ? -L[lane * ldc + sg] : (R)0;
+                R acc = L[mycol + (sg > 1 ? sg : 1)];
+                acc = (lane < sg) ? -acc : (R)0;
                 acc = sweep_bwd(acc, sg - 1);
                 if (lane == sg) acc = (R)1;
                 if (lane > sg) acc = (R)0;

@@ -293,6 +293,24 @@ def test_wave_kernel_problem_queue(lmpc):
     _compare(qp, theta[-5000:])
 
 
+@pytest.mark.parametrize("name", ["mass_spring_3in", "soft_doc", "satellite20"])
+def test_wave_kernel_layouts_and_staging_levels_agree(lmpc, name):
+    # the factor's LDS layout (square / packed) and the staging level of the shared data are launch
+    # choices: every combination must give the same bits
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    ref = qp.solve(g["theta"])
+    for packed in (0, 1):
+        for level in (0, 1, 3):
+            for nwv in (2, 8):
+                qp.set_option("wave_packed", packed)
+                qp.set_option("wave_level", level)
+                qp.set_option("wave_nwv", nwv)
+                out = qp.solve(g["theta"])
+                for a, b in zip(ref, out):
+                    assert np.array_equal(a, b), (packed, level, nwv)
+
+
 def test_K8_soft_constraints_through_c_abi(lmpc):
     # /root/reference/docs/src/manual/simple.md:98-107: u = -1 at x = [0.5, 1], r = [0, 0]
     g = load_golden("soft_doc")
