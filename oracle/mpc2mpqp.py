@@ -10,8 +10,9 @@ into the dense multi-parametric QP
 
 exactly the way the reference builds it on the Julia host, so that the fixtures
 fed to the HIP path are the matrices a LinearMPC.jl user would hand over.  Only
-the features the benchmark/known-answer problems exercise are restated (reference preview yes;
-no disturbance/parameter preview, no reference condensation, no move blocking, no operating-point offsets).  Reference lines followed, all under
+the features the benchmark/known-answer problems exercise are restated (reference preview, move
+blocking, constant offsets in dynamics and outputs yes; no disturbance/parameter preview, no
+reference condensation, no constraint tightening).  Reference lines followed, all under
 /root/reference/src/:
 
     zoh                     utils.jl:291-295
@@ -99,6 +100,10 @@ class MPCProblem:
     Eu: Optional[np.ndarray] = None         # affine input cost (Eu p + eu)'u_k  (setup.jl:136-150)
     eu: Optional[np.ndarray] = None
     reference_preview: bool = False         # settings.reference_preview (types.jl:56,67): r is ny x Np in theta
+    f_offset: Optional[np.ndarray] = None   # x+ = F x + G u + f_offset   (model.jl:20, setup.jl:516-531)
+    h_offset: Optional[np.ndarray] = None   # y  = C x + h_offset         (model.jl:30)
+    move_blocks: Optional[list] = None      # per input: block lengths (setup.jl:202-248)
+    x0_uncertainty: Optional[np.ndarray] = None   # mpc.dx0 (setup.jl:293-296): constraints tightened by |Ax| dx0
     binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
     Nc_binary: int = -1                     # "binary control horizon" (-1 = whole control horizon)
 
@@ -107,6 +112,40 @@ class MPCProblem:
         dims = [0 if self.Eu is None else np.atleast_2d(self.Eu).shape[1]]
         dims += [0 if c.Ap is None else np.atleast_2d(c.Ap).shape[1] for c in self.constraints]
         return max(dims)
+
+    def has_f_offset(self):
+        return self.f_offset is not None and np.any(np.asarray(self.f_offset) != 0)
+
+    def set_offset(self, xo=None, uo=None, fo=None, ho=None):
+        """setup.jl:516-531 set_offset!: f_offset = fo - F xo - G uo, h_offset = ho - C xo."""
+        xo = np.zeros(self.nx) if xo is None else np.asarray(xo, float)
+        uo = np.zeros(self.nu) if uo is None else np.asarray(uo, float)
+        fo = np.zeros(self.nx) if fo is None else np.asarray(fo, float)
+        ho = np.zeros(self.ny) if ho is None else np.asarray(ho, float)
+        self.f_offset = fo - self.F @ xo - self.G @ uo
+        self.h_offset = ho - self.C @ xo
+        self.uprev0 = uo.copy()                  # mpc.uprev .= uo
+        return self
+
+    def move_block(self, block):
+        """setup.jl:202-248 move_block!: the same block vector for every input; padded or clipped to Np;
+        Nc = (sum of all blocks but the last) + 1."""
+        block = [int(b) for b in block]
+        tot = sum(block)
+        if tot < self.Np:
+            block[-1] += self.Np - tot
+        elif tot > self.Np:
+            acc, i = 0, 0
+            while True:
+                acc += block[i]
+                if acc >= self.Np:
+                    break
+                i += 1
+            block = block[:i + 1]
+            block[-1] += self.Np - acc
+        self.move_blocks = [list(block) for _ in range(self.nu)]
+        self.Nc = max(sum(mb[:-1]) for mb in self.move_blocks) + 1
+        return self
 
     def gain(self):
         return np.zeros((self.nu, self.nx)) if self.K is None else np.asarray(self.K, float).reshape(self.nu, self.nx)
@@ -221,6 +260,11 @@ def extended_system(p: MPCProblem):
                        np.hstack([K, np.zeros((nu, nxe - nx)), np.eye(nu)])])
     if np.any(p.R != 0) and np.any(K != 0):      # u'Ru with u = v - Kx: K x becomes an output (:679-681)
         C = np.vstack([C, np.hstack([K, np.zeros((nu, C.shape[1] - nx))])])
+    if p.has_f_offset():                         # constant 1 as the last state (:683-688)
+        F = block_diag(F, np.eye(1))
+        F[:nx, -1] = np.asarray(p.f_offset, float)
+        G = np.vstack([G, np.zeros((1, nu))])
+        C = np.hstack([C, np.zeros((C.shape[0], 1))])
     return F, G, C
 
 
@@ -244,6 +288,8 @@ def extended_cost(p: MPCProblem):
         Q = block_diag(Q, p.R)
         Qf = block_diag(Qf, np.zeros((nu, nu)))
         S[:nx] -= K.T @ p.R
+    if p.has_f_offset():                         # :726-728
+        S = np.vstack([S, np.zeros((1, nu))])
     return Q, R, S, Qf
 
 
@@ -308,7 +354,44 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         fbin = np.tile(fb, Nc)
         f = f - fbin
         H = H + np.diag((fbin != 0).astype(float))
+    if p.has_f_offset():                         # collapse the constant state into f (:517-521)
+        assert npb == 0
+        f = f + f_theta[:, -1]
+        f_theta = f_theta[:, :-1]
+        H_theta = H_theta[:-1, :-1]
+    if p.reference_tracking and p.h_offset is not None and np.any(p.h_offset):   # r - h_offset (:523-530)
+        nrp = p.parameter_dims()[1]
+        ho = np.tile(p.h_offset, N) if p.reference_preview else np.asarray(p.h_offset, float)
+        f = f - f_theta[:, p.nx:p.nx + nrp] @ ho
     return (H + H.T) / 2, f, f_theta, H_theta
+
+
+def apply_move_block(p, H, f, f_theta, cons):
+    """mpc2mpqp.jl:830-857: U = T V with one column of T per block; bounds of dropped moves go."""
+    A, bu, bl, W, soft, prio = cons
+    nu, Nc = p.nu, p.Nc
+    nub = p.umax.size
+    nUold, nUnew = nu * Nc, sum(len(mb) for mb in p.move_blocks)
+    T = np.zeros((nUold, nUnew))
+    counter = list(range(nu))
+    keep, new_id = [], 0
+    for ps in range(max(len(mb) for mb in p.move_blocks)):
+        for iu, mb in enumerate(p.move_blocks):
+            if len(mb) <= ps:
+                continue
+            block = mb[ps] if len(mb) != ps + 1 else 1
+            T[counter[iu]:counter[iu] + nu * (block - 1) + 1:nu, new_id] = 1
+            if counter[iu] < nub * Nc:
+                keep.append(counter[iu])
+            counter[iu] += nu * block
+            new_id += 1
+    keep = keep + list(range(nub * Nc, bu.size))
+    K = p.gain()
+    Anew = (A[keep] @ T) if np.any(K != 0) else (A @ T)
+    binary = getattr(p, "_binary_rows", np.zeros(0, bool))
+    if binary.size:
+        p._binary_rows = binary[keep]
+    return T.T @ H @ T, T.T @ f, T.T @ f_theta, (Anew, bu[keep], bl[keep], W[keep], soft[keep], prio[keep])
 
 
 def dense_constraints(p: MPCProblem, Phi, Gam):
@@ -317,6 +400,8 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
     nu, Np, Nc = p.nu, p.Np, p.Nc
     prev = p.reference_preview and nr > 0
     nxe = nx + (0 if prev else nr) + nd + nuprev     # previewed references are no states (:210)
+    if p.has_f_offset():
+        nxe += 1                                     # constant offset in the dynamics (:212)
     n = Gam.shape[1]
 
     def with_ref_block(Wm):                          # insert_preview_parameter_blocks (:70-92), Wr = 0
@@ -361,8 +446,15 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             pad = np.zeros((mi, nxe - nx))
             Au_rows.append(np.kron(eyeU[sel], c.Au))
             Ax_rows.append(np.kron(eyeX[sel], np.hstack([c.Ax - c.Au @ p.gain(), pad])))
-            ubs.append(np.tile(c.ub, len(ks)))
-            lbs.append(np.tile(c.lb, len(ks)))
+            ubk, lbk = np.tile(c.ub, len(ks)), np.tile(c.lb, len(ks))
+            if p.x0_uncertainty is not None and np.any(p.x0_uncertainty):
+                # constraint_tightening (robust.jl:1-29) with wmin = wmax = 0: every row loses
+                # sum_j |Ax_ij dx0_j| on both sides, from k = 2 on (mpc2mpqp.jl:298-305)
+                acc = np.abs((c.Ax - c.Au @ p.gain()) * np.asarray(p.x0_uncertainty, float)[None, :]).sum(axis=1)
+                t = np.concatenate([acc if k >= 2 else np.zeros(mi) for k in ks])
+                ubk, lbk = ubk - t, lbk + t
+            ubs.append(ubk)
+            lbs.append(lbk)
             if npb > 0:                          # parameter_preview_direct (:125-143): W[:, p] = -Ap
                 Ap = np.zeros((mi, npb)) if c.Ap is None else c.Ap
                 Wp_rows.append(np.tile(-Ap, (len(ks), 1)))
@@ -380,7 +472,13 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
         prio = np.concatenate([prio] + prios)
         binary = np.concatenate([binary, np.zeros(sum(len(x) for x in softs), bool)])
     p._binary_rows = binary                      # carried next to the constraint tuple (no row is dropped
-    return A, bu, bl, W, soft, prio              # or reordered among the simple bounds afterwards)
+    if p.has_f_offset() and W.shape[0]:          # or reordered among the simple bounds afterwards)
+        col = nxe - 1 + (nr if prev else 0)      # collapse the constant state into the bounds (:393-398)
+        bu, bl = bu + W[:, col], bl + W[:, col]
+        W = np.delete(W, col, axis=1)
+    elif p.has_f_offset():
+        W = np.zeros((0, W.shape[1] - 1))
+    return A, bu, bl, W, soft, prio
 
 
 def sort_by_priority(A, bu, bl, W, soft, prio):
@@ -487,6 +585,8 @@ def mpc2mpqp(p: MPCProblem) -> MPQP:
     Q, R, S, Qf = extended_cost(p)
     H, f, f_theta, H_theta = dense_objective(p, F, Phi, Gam, C, Q, R, S, Qf)
     cons = dense_constraints(p, Phi, Gam)
+    if p.move_blocks:
+        H, f, f_theta, cons = apply_move_block(p, H, f, f_theta, cons)
     cons = sort_by_priority(*cons)
     if p.preprocess:
         cons = remove_redundant(*cons)
@@ -624,6 +724,30 @@ def format_reference_preview(r, ny, Np):
         return r[:, :Np].T.reshape(-1)
     ext = np.hstack([r, np.tile(r[:, -1:], (1, Np - r.shape[1]))])
     return ext.T.reshape(-1)
+
+
+def x0_uncertainty_kat() -> MPCProblem:
+    """test/runtests.jl:1067-1074 "x0 uncertainty": double integrator, |u| <= 0.2, soft output bounds
+    |y| <= 0.5 on k = 2..Np (set_bounds! ymin/ymax: soft, setup.jl:94), dx0 = 0.1: tracking r = 0.5
+    stops at the tightened bound, x1 -> 0.4."""
+    p = make_mpc([[1, 0.1], [0, 1]], [[0.005], [0.1]], [[1.0, 0.0]], Np=25, umin=[-0.2], umax=[0.2], Ts=0.1)
+    p.add_constraint(Ax=p.C, lb=[-0.5], ub=[0.5], ks=range(2, 26), soft=True)
+    p.x0_uncertainty = 0.1 * np.ones(2)
+    return p
+
+
+def offset_kat() -> MPCProblem:
+    """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
+    with r = 1.5 settles at u = 10.5, y = 1.5."""
+    p = make_mpc([[0.778800783]], [[1.0]], [[0.44239843385]], Np=10, Q=[1.0], R=[0.0], Rr=[0.1])
+    return p.set_offset(uo=[10.0], ho=[0.5])
+
+
+def moveblock_kat() -> MPCProblem:
+    """test/runtests.jl:1329-1335 "Unconstrained": move_block!([2,2,2,24]) on Np = 10 (clipped to
+    [2,2,2,4], Nc = 7, four moves), Q = 1, R = Rr = 0, no bounds; y reaches r = 5."""
+    p = make_mpc([[0.77880078307]], [[1.0]], [[2.211992169]], Np=10, Q=[1.0], R=[0.0], Rr=[0.0], Ts=100.0)
+    return p.move_block([2, 2, 2, 24])
 
 
 def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):

@@ -292,6 +292,64 @@ def main():
     save("satellite20_preview", q, L, theta, X, ef, it, act,
          dict(F=prob.F, G=prob.G, rs=rs, closed_loop_u=np.array(us), closed_loop_y=np.array(ys)))
 
+    # ---- K5: closed-loop end values the reference's tests assert
+    # (a) "x0 uncertainty" runtests.jl:1067-1074: x1 -> 0.4 (1e-6); soft output bounds, tightened
+    prob = omm.x0_uncertainty_kat()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    x, ths = np.zeros(2), []
+    for k in range(1000):                               # Simulation's default N
+        th = omm.form_parameter(prob, x, r=[0.5])
+        U, e, _, _ = oldp.solve_batch(L, th[None])
+        assert e[0] >= 1
+        ths.append(th)
+        x = prob.F @ x + prob.G @ U[0, :1]
+    assert abs(x[0] - 0.4) < 1e-6, x
+    rngk = np.random.default_rng(77)
+    theta = np.vstack([np.array(ths[:150]), np.array(ths[150::25]),
+                       np.hstack([rngk.uniform(-0.6, 0.6, (64, 1)), rngk.uniform(-0.5, 0.5, (64, 1)),
+                                  rngk.uniform(-0.6, 0.6, (64, 1))])])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("x0unc_kat", q, L, theta, X, ef, it, act, dict(F=prob.F, G=prob.G, x_end=x))
+
+    # (b) "Set offset" runtests.jl:1320-1327: us[end] = 10.5, ys[end] = 1.5
+    prob = omm.offset_kat()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    x, up, ths, us, ys = np.zeros(1), prob.uprev0.copy(), [], [], []
+    for k in range(50):
+        ys.append(prob.C @ x + prob.h_offset)
+        th = omm.form_parameter(prob, x, r=[1.5], uprev=up)
+        U, e, _, _ = oldp.solve_batch(L, th[None])
+        assert e[0] == 1
+        up = U[0, :1].copy()
+        ths.append(th)
+        us.append(up)
+        x = prob.F @ x + prob.G @ up + prob.f_offset
+    assert abs(us[-1][0] - 10.5) < 1e-7 and abs(ys[-1][0] - 1.5) < 1e-7, (us[-1], ys[-1])
+    theta = np.vstack([np.array(ths), np.hstack([rngk.uniform(-3, 3, (78, 1)), rngk.uniform(0, 3, (78, 1)),
+                                                 rngk.uniform(5, 15, (78, 1))])])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("offset_kat", q, L, theta, X, ef, it, act, dict(us=np.array(us), ys=np.array(ys)))
+
+    # (c) "Unconstrained" runtests.jl:1329-1335: move_block!([2,2,2,24]), ys[end] = 5.0
+    prob = omm.moveblock_kat()
+    q = omm.mpc2mpqp(prob)
+    assert (q.n, q.m, prob.Nc) == (4, 0, 7)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    x, ths, ys = np.zeros(1), [], []
+    for k in range(20):
+        ys.append(prob.C @ x)
+        th = omm.form_parameter(prob, x, r=[5.0])
+        U, e, _, _ = oldp.solve_batch(L, th[None])
+        assert e[0] == 1
+        ths.append(th)
+        x = prob.F @ x + prob.G @ U[0, :1]
+    assert abs(ys[-1][0] - 5.0) < 5e-8 * 5.0, ys[-1]                  # Julia's isapprox default
+    theta = np.vstack([np.array(ths), rngk.uniform(-5, 5, (108, 2))])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("moveblock_kat", q, L, theta, X, ef, it, act, dict(F=prob.F, G=prob.G, ys=np.array(ys)))
+
 
 if __name__ == "__main__":
     main()

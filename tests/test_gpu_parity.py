@@ -778,3 +778,35 @@ def test_form_parameter_device_all_blocks(lmpc):
     x2, ef2 = mpc.opt_model.solve_device(th)
     torch.cuda.synchronize()
     assert np.array_equal(x1, x2.cpu().numpy()) and np.array_equal(ef1, ef2.cpu().numpy())
+
+
+# ------------------------------------------------------------------ K5: closed-loop end values
+@pytest.mark.parametrize("name", ["x0unc_kat", "offset_kat", "moveblock_kat"])
+def test_K5_fixtures_through_c_abi(lmpc, name):
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    x, ef, it, act = _compare(qp, g["theta"])
+    assert np.array_equal(ef, g["exitflag"]) and np.array_equal(act, g["active"])
+    tol = 1e-4 if name == "x0unc_kat" else 1e-8      # soft rows: 1/rho amplifies pack rounding (see K8)
+    assert np.abs(x - g["X"]).max() <= tol
+
+
+def test_K5_closed_loops_on_the_gpu(lmpc):
+    # (a) runtests.jl:1067-1074: x1 -> 0.4 (soft, tightened output bound), many scenarios at once
+    g = load_golden("x0unc_kat")
+    qp = _qp_from_golden(lmpc, g, 1)
+    assert qp.kernel_name == "wave"
+    N = 16
+    out = qp.simulate(np.zeros((N, 2)), 400, g["F"], g["G"], r=np.full((N, 1), 0.5), warm=False, want_x=False)
+    assert np.all(out["flag_min"] >= 1) and np.abs(out["x"][:, 0] - 0.4).max() < 1e-6
+    # (c) runtests.jl:1329-1335: move-blocked, unconstrained (m = 0, lane kernel): y = C x -> 5.0
+    g = load_golden("moveblock_kat")
+    qp = _qp_from_golden(lmpc, g, 1)
+    out = qp.simulate(np.zeros((N, 1)), 20, g["F"], g["G"], r=np.full((N, 1), 5.0), warm=False)
+    y19 = 2.211992169 * out["X"][19, :, 0]
+    assert np.abs(y19 - 5.0).max() < 5e-8 * 5.0
+    # (b) runtests.jl:1320-1327: offsets live in f; the recorded closed loop, solved as one batch
+    g = load_golden("offset_kat")
+    qp = _qp_from_golden(lmpc, g, 1)
+    x, ef, _, _ = qp.solve(g["theta"][:50])
+    assert np.all(ef == 1) and np.abs(x[:, 0] - g["us"][:, 0]).max() < 1e-9 and abs(x[49, 0] - 10.5) < 1e-7

@@ -317,3 +317,51 @@ def test_hybrid_preview_fixture_is_reproduced():
     X, ef, it, act = oldp.solve_batch(L, g["theta"][:24])
     assert np.array_equal(ef, g["exitflag"][:24]) and np.abs(X - g["X"][:24]).max() < 1e-9
     assert abs(g["closed_loop_y"][-1, 0] - 0.5) < 1e-3
+
+
+def test_K5_closed_loop_end_values():
+    # end values the reference's closed-loop tests assert, through the restated
+    # condensing (offsets, move blocking, constraint tightening) and the oracle solver
+    # (a) runtests.jl:1067-1074 "x0 uncertainty": x1 -> 0.4 within 1e-6 (soft output bound 0.5 - |C| dx0)
+    p = omm.x0_uncertainty_kat()
+    q = omm.mpc2mpqp(p)
+    assert (q.n, q.m, q.nth) == (25, 49, 3) and int(((q.senses & 8) != 0).sum()) == 24
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    x = np.zeros(2)
+    for _ in range(400):
+        U, e, _, _ = oldp.solve_batch(L, omm.form_parameter(p, x, r=[0.5])[None])
+        assert e[0] >= 1
+        x = p.F @ x + p.G @ U[0]
+    assert abs(x[0] - 0.4) < 1e-6
+    # (b) runtests.jl:1320-1327 "Set offset": us[end] = 10.5, ys[end] = 1.5
+    p = omm.offset_kat()
+    q = omm.mpc2mpqp(p)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    x, up = np.zeros(1), p.uprev0.copy()
+    for _ in range(50):
+        y = p.C @ x + p.h_offset
+        U, e, _, _ = oldp.solve_batch(L, omm.form_parameter(p, x, r=[1.5], uprev=up)[None])
+        up = U[0].copy()
+        x = p.F @ x + p.G @ up + p.f_offset
+    assert abs(up[0] - 10.5) < 1e-7 and abs(y[0] - 1.5) < 1e-7
+    # (c) runtests.jl:1329-1335 "Unconstrained": move_block!([2,2,2,24]) -> four moves, ys[end] = 5.0
+    p = omm.moveblock_kat()
+    q = omm.mpc2mpqp(p)
+    assert p.move_blocks == [[2, 2, 2, 4]] and p.Nc == 7 and (q.n, q.m) == (4, 0)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    x = np.zeros(1)
+    for _ in range(20):
+        y = p.C @ x
+        U, e, _, _ = oldp.solve_batch(L, omm.form_parameter(p, x, r=[5.0])[None])
+        x = p.F @ x + p.G @ U[0]
+    assert abs(y[0] - 5.0) < 5e-8 * 5.0
+
+
+@pytest.mark.parametrize("name", ["x0unc_kat", "offset_kat", "moveblock_kat"])
+def test_K5_fixtures_are_reproduced(name):
+    g = load_golden(name)
+    L = oracle_ldp_from({k: g[k] for k in ("M", "du", "dl", "Dth", "Rout", "x0", "Xth", "senses")} |
+                        {"ms": int(g["bu"].size - g["A"].shape[0])})
+    X, ef, it, act = oldp.solve_batch(L, g["theta"])
+    assert np.array_equal(ef, g["exitflag"]) and np.array_equal(it, g["iters"]) and np.array_equal(act, g["active"])
+    assert np.abs(X - g["X"]).max() < 1e-9
