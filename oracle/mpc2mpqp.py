@@ -736,6 +736,16 @@ def x0_uncertainty_kat() -> MPCProblem:
     return p
 
 
+def preview_sim_kat(preview: bool) -> MPCProblem:
+    """test/runtests.jl:276-327 "Reference Preview Simulation": discrete double integrator, Np = 5,
+    Nc = 3, |u| <= 2, soft output bounds, Q = I, R = 0.1; a step in r1 at k = 10."""
+    p = make_mpc([[1, 1], [0, 1]], [[0], [1]], np.eye(2), Np=5, Nc=3, Q=[1.0, 1.0], R=[0.1],
+                 umin=[-2.0], umax=[2.0])
+    p.add_constraint(Ax=p.C, lb=[-1.0, -0.5], ub=[1.0, 0.5], ks=range(2, 6), soft=True)
+    p.reference_preview = preview
+    return p
+
+
 def offset_kat() -> MPCProblem:
     """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
     with r = 1.5 settles at u = 10.5, y = 1.5."""

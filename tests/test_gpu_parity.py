@@ -810,3 +810,27 @@ def test_K5_closed_loops_on_the_gpu(lmpc):
     qp = _qp_from_golden(lmpc, g, 1)
     x, ef, _, _ = qp.solve(g["theta"][:50])
     assert np.all(ef == 1) and np.abs(x[:, 0] - g["us"][:, 0]).max() < 1e-9 and abs(x[49, 0] - 10.5) < 1e-7
+
+
+def test_reference_preview_simulation_on_the_gpu(lmpc):
+    # /root/reference/test/runtests.jl:276-327 through lmpc_simulate_ref_device (preview window
+    # k+1 .. k+Np / column k), soft output bounds -> wavefront kernel; same four assertions, and the
+    # trajectories of the oracle's closed loop
+    from oracle import mpc2mpqp as omm
+    from test_oracle import _preview_sim
+    N = 20
+    outs = {}
+    for prev in (True, False):
+        p = omm.preview_sim_kat(prev)
+        q = omm.mpc2mpqp(p)
+        qp = lmpc.BatchedQP.from_mpqp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+        us_o, ys_o, rt = _preview_sim(prev, N)
+        out = qp.simulate_ref(np.tile([1.0, 0.0], (5, 1)), N, p.F, p.G, rt, preview=p.Np if prev else 0)
+        assert np.all(out["flag_min"] >= 1)
+        assert np.abs(out["U"][:, 0, 0] - us_o[0]).max() < 1e-6 and np.abs(out["X"][:N, 0].T - ys_o).max() < 1e-6
+        outs[prev] = (out["U"][:, 0].T, out["X"][:N, 0].T, rt)
+    (up, yp, rt), (un, yn, _) = outs[True], outs[False]
+    assert np.linalg.norm(up - un) > 1e-1
+    ep, en = yp - rt, yn - rt
+    assert np.linalg.norm(ep) / np.linalg.norm(en) < 0.9
+    assert np.linalg.norm(ep[:, -1]) < 1e-3 and np.linalg.norm(en[:, -1]) < 1e-3

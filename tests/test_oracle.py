@@ -365,3 +365,30 @@ def test_K5_fixtures_are_reproduced(name):
     X, ef, it, act = oldp.solve_batch(L, g["theta"])
     assert np.array_equal(ef, g["exitflag"]) and np.array_equal(it, g["iters"]) and np.array_equal(act, g["active"])
     assert np.abs(X - g["X"]).max() < 1e-9
+
+
+def _preview_sim(prev, N=20):
+    rt = np.zeros((2, N)); rt[0, 10:] = 1.0
+    p = omm.preview_sim_kat(prev)
+    q = omm.mpc2mpqp(p)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    x, us, ys = np.array([1.0, 0.0]), [], []
+    for k in range(N):
+        ys.append(p.C @ x)
+        r = np.stack([rt[:, min(k + 1 + i, N - 1)] for i in range(p.Np)], 1) if prev else rt[:, k]
+        U, e, _, _ = oldp.solve_batch(L, omm.form_parameter(p, x, r=r)[None])
+        assert e[0] >= 1
+        us.append(U[0])
+        x = p.F @ x + p.G @ U[0]
+    return np.array(us).T, np.array(ys).T, rt
+
+
+def test_reference_preview_simulation_assertions():
+    # /root/reference/test/runtests.jl:276-327: preview changes the inputs, lowers the tracking error
+    # (ratio < 0.9) and both loops meet the reference at the end (1e-3)
+    up, yp, rt = _preview_sim(True)
+    un, yn, _ = _preview_sim(False)
+    assert np.linalg.norm(up - un) > 1e-1
+    ep, en = yp - rt, yn - rt
+    assert np.linalg.norm(ep) / np.linalg.norm(en) < 0.9
+    assert np.linalg.norm(ep[:, -1]) < 1e-3 and np.linalg.norm(en[:, -1]) < 1e-3
