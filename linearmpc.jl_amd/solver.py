@@ -17,7 +17,9 @@ _vp = ctypes.c_void_p
 
 
 def _f64(a, order="C"):
-    return np.require(np.asarray(a, dtype=np.float64), requirements=["A", "O", order[0]])
+    # aligned + requested order; no OWNDATA requirement (it would copy every reshaped view, 56 MB per
+    # call for a 10^6-point theta)
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["A", order[0]])
 
 
 def _ptr(a):
@@ -136,10 +138,15 @@ class BatchedQP:
         """Host arrays in, host arrays out (`lmpc_solve_batch`)."""
         theta = _f64(np.asarray(theta, float).reshape(-1, self.nth) if self.nth else np.zeros((len(theta), 0)))
         N = theta.shape[0]
-        x = np.empty((N, self.nout))
-        ef = np.empty(N, np.int32)
-        it = np.empty(N, np.int32) if want_iters else None
+        # outputs are touched before the call: a device-to-host copy into pages the OS has not mapped
+        # yet runs at a fraction of the PCIe rate (measured: 22 ms instead of 1.3 ms for 10^6 problems)
+        x = np.zeros((N, self.nout))
+        ef = np.zeros(N, np.int32)
+        it = np.zeros(N, np.int32) if want_iters else None
         act = np.zeros((N, self.words), np.uint64) if want_active else None
+        for a_ in (x, ef, it, act):
+            if a_ is not None:
+                a_.fill(0)
         w = None
         if warm is not None:
             w = np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, self.words))
