@@ -273,14 +273,14 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
 
 template <int NTHMAX>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
-                  int32_t *iters, uint64_t *active, int32_t *count, hipStream_t st) {
+                  int32_t *iters, uint64_t *active, const uint64_t *warm, int32_t *count, hipStream_t st) {
     const int B = 256;
     const size_t lds = 0;
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
     hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
-                       iters, active, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
+                       iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -464,7 +464,9 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     }
     if (!bestB) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: constant pack does not fit in LDS");
     // Cold starts without initially-active rows go through the screening pass first.
-    const bool screened = h->screen && !warm && h->L.eq_mask == 0ull && h->S.iter_limit > 1 &&
+    // (warm starts too: the screening pass finishes the problems whose warm mask is empty and whose
+    // unconstrained optimum is feasible, everything else is queued with its mask)
+    const bool screened = h->screen && h->L.eq_mask == 0ull && h->S.iter_limit > 1 &&
                           h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
     if (screened && nprob > h->listCap) {
         hipFree(h->dList); hipFree(h->dCount);
@@ -490,9 +492,9 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
-        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
-        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
-        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, cnt_now, st);
+        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
+        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
+        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
     const int32_t *list = screened ? h->dList : nullptr;

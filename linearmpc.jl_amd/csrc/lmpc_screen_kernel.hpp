@@ -36,8 +36,8 @@ template <int NTHMAX>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-    uint64_t *__restrict__ active, int32_t *__restrict__ list, int32_t *__restrict__ count,
-    long long seg_cap, int nshards, long long nprob, int ablate) {
+    uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, int32_t *__restrict__ list,
+    int32_t *__restrict__ count, long long seg_cap, int nshards, long long nprob, int ablate) {
     const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
     const long long first = (long long)blockIdx.x * kScreenTPB * B + tid;
     const double ntol = -P.primal_tol;
@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 const double vl = -((bj[2 * q + 1] + b[q]) - 0.0);
                 if (!((imm >> q) & 1ull)) hard = hard || (vu < ntol) || (vl < ntol);
             }
+        }
+        // a warm start with an EMPTY initial working set is a cold start (the usual case once a
+        // closed loop has settled); any other mask goes to the iterating kernel, which starts from it
+        if (warm != nullptr && valid) {
+            unsigned long long wany = 0ull;
+            for (int w = 0; w < P.words; w++) wany |= warm[pid * P.words + w];
+            hard = hard || wany != 0ull;
         }
         hard = hard && valid;
 
