@@ -69,7 +69,7 @@ def algorithmic_bytes(nth, nout, real_bytes=8):
     return real_bytes * nth + real_bytes * nout + 4
 
 
-def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False):
+def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=5.0):
     """Single-thread CPU oracle (the restated DAQP algorithm) on a bounded sample of the same batch
     (about 10-20 s of CPU work); a reported baseline, not the product path."""
     from oracle import ldp as oldp
@@ -99,9 +99,33 @@ def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False):
                     break
     except OSError:
         pass
-    return {"value": passes * ns / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} passes over the first {ns} points of the same batch, 1 thread of "
-                      f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c ({'binary32' if f32 else 'binary64'} build) -O2 -mfma"}
+    out = {"value": passes * ns / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+           "sample": f"{passes} passes over the first {ns} points of the same batch, 1 thread of "
+                     f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c ({'binary32' if f32 else 'binary64'} build) -O2 -mfma"}
+    # the same oracle on all host cores this process may use: the sample cut
+    # into one contiguous slice per thread (the C call releases the GIL), ~5 s
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 64))
+    if ncores > 1 and all_cores_seconds > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        big = theta[:min(theta.shape[0], max(ns, 4096 * ncores))]
+        parts = [p_ for p_ in np.array_split(big, ncores) if len(p_)]
+        with ThreadPoolExecutor(len(parts)) as pool:
+            list(pool.map(lambda p_: oldp.solve_batch(L, p_[:256], dtype=dt_), parts))   # spin the threads up
+            t0 = time.perf_counter()
+            passes = 0
+            while True:
+                list(pool.map(lambda p_: oldp.solve_batch(L, p_, dtype=dt_), parts))
+                passes += 1
+                dta = time.perf_counter() - t0
+                if dta >= all_cores_seconds or passes >= 200:
+                    break
+        out["all_cores"] = {"value": passes * big.shape[0] / dta, "unit": "solves/s", "cores": len(parts),
+                            "sample": f"{passes} passes over the first {big.shape[0]} points, one contiguous slice per thread"}
+    return out
 
 
 def main():
@@ -247,6 +271,11 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
+    if final_gather:
+        # untimed: the first all-gather of this shape sets up RCCL's channels and buffers
+        torch.cuda.synchronize(dev)
+        dist.all_gather_into_tensor(xfin, xbuf[0])
+        dist.all_gather_into_tensor(ffin, fbuf[0])
     fence()
     # Device time over the timed region: ONE pair of HIP events per launch stream brackets all of
     # that stream's launches (events between every two kernels cost ~12 % throughput: each is an extra

@@ -14,7 +14,10 @@
  *    the Julia side == N records of nth doubles; x is nout x N == N records of nout doubles.
  *  - exit flags per problem use DAQP's sign convention (reference asserts exitflag >= 1,
  *    utils.jl:46):  1 optimal, 2 soft-optimal, -1 infeasible, -2 cycle, -3 unbounded,
- *    -4 iteration limit, -5 non-convex, -6 over-determined initial working set.
+ *    -4 iteration limit, -5 non-convex, -6 over-determined initial working set.  One flag is this
+ *    library's own: -7 = the working set would have outgrown the 64 rows the wavefront kernel
+ *    holds (only problems with n + 1 + #SOFT rows > 64 can get it; like every flag < 1 it fails
+ *    the reference's assertion).
  *  - sense bit flags are DAQP's (reference mpc2mpqp.jl:868-885): 1 ACTIVE, 2 LOWER,
  *    4 IMMUTABLE, 5 EQUALITY (=ACTIVE|IMMUTABLE), 8 SOFT, 16 BINARY.  A problem with BINARY rows
  *    (hybrid MPC, mpQP.has_binaries) is solved by branch and bound: every BINARY row ends up
@@ -158,7 +161,7 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
  * sense at that precision (lmpc_default_settings_f32: primal 1e-4, dual 1e-6, zero 1e-6,
  * progress 1e-4, rho_soft 1e-3; libdaqp's own single-precision defaults live in a header that is
  * not part of the reference tree).  Runs on the wavefront kernel (any handle whose problem it covers:
- * n <= 63, n + 1 + #soft <= 64, 1 <= m <= 256), including branch and bound over BINARY rows
+ * n <= 63, 1 <= m <= 1024), including branch and bound over BINARY rows
  * (BASELINE config 5); LMPC_ERR_UNSUPPORTED otherwise.
  */
 void lmpc_default_settings_f32(lmpc_settings *s);
@@ -232,6 +235,46 @@ int lmpc_form_parameter_device(lmpc_handle *h, int64_t N, double *theta, const d
 int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmpc_block *r, int nuprev,
                              const double *F, const double *G, double *x, double *uprev,
                              double *U_traj, double *X_traj, int32_t *flag_min, int warm, void *stream);
+
+/*
+ * The batched counterpart of the reference's GENERATED controller
+ *   int mpc_compute_control(c_float* control, c_float* state, c_float* reference,
+ *                           c_float* disturbance[, c_float* affine_parameter])
+ * (reference src/codegen.jl:1-17, codegen/mpc_update_qp.h:3-7, body codegen/mpc_update_qp.c:29-54):
+ * mpc_update_parameter (codegen/mpc_update_parameter.c:1-29) + mpc_update_qp + daqp_ldp/daqp_bnb +
+ * mpc_get_solution for N problems at once.  The handle must have been set up with nout = N_CONTROL.
+ *
+ * lmpc_set_parameter_layout gives the handle the constants the generated header defines
+ * (codegen.jl:154-165): N_STATE, N_REFERENCE, N_DISTURBANCE, N_CONTROL_PREV, N_AFFINE_PARAMETER --
+ * they must add up to nth -- and, for settings.reference_condensation (codegen.jl:191-195),
+ * N_PREVIEW_HORIZON with traj2setpoint[n_reference*n_preview_horizon*n_reference] exactly as the
+ * generator writes it (mpc.traj2setpoint[:], HOST array, copied).
+ *
+ *   control   N records of nout doubles: in = previous control (first n_control_prev entries are
+ *             read), out = u* -- the in/out convention of the generated function
+ *   state     N records of n_state            reference  N records of n_reference doubles, or of
+ *             n_reference*n_preview_horizon (an n_reference x n_preview_horizon trajectory, column by
+ *             column) when condensing; disturbance / affine_parameter: N records of their widths.
+ *             NULL for reference / disturbance / affine_parameter = zeros (runtests.jl:943 passes NULL
+ *             for absent blocks).
+ *   exitflag  N int32 (out) or NULL           warm != 0 = the DAQP_WARMSTART build
+ *             (mpc_update_qp.c:44-47): each problem starts from the working set its previous call
+ *             with the same N ended with; 0 = cold start every call.
+ * lmpc_compute_control: HOST pointers, synchronous.  lmpc_compute_control_device: DEVICE pointers,
+ * enqueued on `stream`, no synchronisation.
+ */
+typedef struct lmpc_param_layout {
+    int32_t n_state, n_reference, n_disturbance, n_control_prev, n_affine_parameter;
+    int32_t n_preview_horizon;       /* 0 unless settings.reference_condensation */
+    const double *traj2setpoint;     /* HOST, or NULL when n_preview_horizon == 0 */
+} lmpc_param_layout;
+int lmpc_set_parameter_layout(lmpc_handle *h, const lmpc_param_layout *layout);
+int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const double *state,
+                         const double *reference, const double *disturbance,
+                         const double *affine_parameter, int32_t *exitflag, int warm);
+int lmpc_compute_control_device(lmpc_handle *h, int64_t N, double *control, const double *state,
+                                const double *reference, const double *disturbance,
+                                const double *affine_parameter, int32_t *exitflag, int warm, void *stream);
 
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);

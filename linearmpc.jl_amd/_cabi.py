@@ -23,6 +23,7 @@ SYMBOLS = (
     "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one",
     "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
     "lmpc_simulate_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
+    "lmpc_set_parameter_layout", "lmpc_compute_control", "lmpc_compute_control_device",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
@@ -45,6 +46,14 @@ class Block(ctypes.Structure):
     """`lmpc_block`: one block of theta cut from a (w x T, column-major) trajectory on the device."""
     _fields_ = [("src", ctypes.c_void_p), ("stride", ctypes.c_int64), ("w", ctypes.c_int32),
                 ("T", ctypes.c_int32), ("k0", ctypes.c_int32), ("H", ctypes.c_int32)]
+
+
+class ParamLayout(ctypes.Structure):
+    """`lmpc_param_layout`: the N_STATE ... N_AFFINE_PARAMETER constants of the generated header
+    (reference codegen.jl:154-165) and, for reference condensation, N_PREVIEW_HORIZON + traj2setpoint."""
+    _fields_ = [("n_state", ctypes.c_int32), ("n_reference", ctypes.c_int32), ("n_disturbance", ctypes.c_int32),
+                ("n_control_prev", ctypes.c_int32), ("n_affine_parameter", ctypes.c_int32),
+                ("n_preview_horizon", ctypes.c_int32), ("traj2setpoint", ctypes.c_void_p)]
 
 
 _lib = None
@@ -98,6 +107,12 @@ def lib():
     L.lmpc_form_parameter_device.restype = i32
     L.lmpc_simulate_ref_device.argtypes = [vp, i64, i32, i32, bp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.lmpc_simulate_ref_device.restype = i32
+    L.lmpc_set_parameter_layout.argtypes = [vp, ctypes.POINTER(ParamLayout)]
+    L.lmpc_set_parameter_layout.restype = i32
+    L.lmpc_compute_control.argtypes = [vp, i64] + [vp] * 6 + [i32]
+    L.lmpc_compute_control.restype = i32
+    L.lmpc_compute_control_device.argtypes = [vp, i64] + [vp] * 6 + [i32, vp]
+    L.lmpc_compute_control_device.restype = i32
     L.lmpc_kernel_name.argtypes = [vp]
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]

@@ -3,6 +3,7 @@
 // with LMPC_ERR_NOGPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -24,7 +25,7 @@ constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
 constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
-constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 256;
+constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 1024;
 constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
 struct EventTriple { hipEvent_t a, mid, b; };
@@ -72,6 +73,12 @@ struct lmpc_handle {
     int32_t *simFlag = nullptr;
     uint64_t *simAct = nullptr;
     int64_t simCap = 0;
+    // generated-controller entry point (lmpc_compute_control*): layout of theta, scratch, warm-start state
+    int ccNx = -1, ccNr = 0, ccNd = 0, ccNup = 0, ccNp = 0, ccNph = 0;
+    double *ccT2S = nullptr, *ccTheta = nullptr;
+    uint64_t *ccAct = nullptr;
+    int32_t *ccFlag = nullptr;
+    int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
     // profiling
     bool prof = false;
     std::vector<EventTriple> events;
@@ -148,12 +155,14 @@ int finalize_handle(lmpc_handle *h) {
     if (nBinary > 64)    // the B&B stack of a problem lives on the 64 lanes of its wavefront
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: more than 64 binary rows");
     const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0 && !anyBinary;
-    const int cap = P.n + 1 + P.nsoft;
-    const bool waveOk = P.n <= kWaveMaxN && cap <= kWaveMaxCap && P.m <= kWaveMaxM && P.m >= 1;
+    // working-set capacity: n hard rows + 1 (the row that makes it singular) + the soft rows, but never
+    // more than the 64 lanes; a problem that wants more rows at once ends with exit flag -7
+    const int cap = std::min(P.n + 1 + P.nsoft, kWaveMaxCap);
+    const bool waveOk = P.n <= kWaveMaxN && P.m <= kWaveMaxM && P.m >= 1;
     if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,
                     "lmpc: problem outside what the kernels cover (lane: n<=12, m<=64, hard rows; "
-                    "wave: n<=63, n+1+#soft<=64, m<=256)");
+                    "wave: n<=63, 1<=m<=1024)");
     h->useWave = !laneOk;
     HIP_TRY(h, hipSetDevice(h->device));
     {
@@ -311,14 +320,16 @@ WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) {
     // resident wavefronts per CU the instantiation's registers allow (see `make asm`): 16 for the plain
     // ones and for binary32 B&B with m <= 64, 12 for binary64 B&B (m <= 128) and binary32 B&B (m <= 128),
     // 8 beyond
-    const int maxNwv = big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8);
+    const int maxNwv = h->P.m > 256 ? 4 : (big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8));
     int maxWaves = LMPC_WAVE_LB >= 1024 ? 16 : 12;
-    if (h->P.m > 128) maxWaves = 8;
+    if (h->P.m > 256) maxWaves = 4;
+    else if (h->P.m > 128) maxWaves = 8;
     else if (h->bnb) maxWaves = (rs == 4 && h->P.m <= 64) ? 16 : 12;
     WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
-    for (int level = packed ? 1 : 3; level >= 0; level--) {          // packed is instantiated for levels 0, 1
-        if (h->waveLevel >= 0 && level != (packed && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
+    // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
+    for (int level = (packed || h->P.m > 256) ? 1 : 3; level >= 0; level--) {
+        if (h->waveLevel >= 0 && level != ((packed || h->P.m > 256) && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
         for (int nwv : {4, 8, 16, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
@@ -393,9 +404,14 @@ int launch_wave_t(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R 
 #define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
 #define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
                                  : (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))))
+#define LMPC_WVB(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
+                                  : (cfg.level >= 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
-    else rc = LMPC_WV(4);
+    else if (mr <= 4) rc = LMPC_WV(4);
+    else if (mr <= 8) rc = LMPC_WVB(8);
+    else rc = LMPC_WVB(16);
+#undef LMPC_WVB
 #undef LMPC_WV
 #undef LMPC_WV3
 #undef LMPC_WV4
@@ -418,7 +434,7 @@ int ensure_f32(lmpc_handle *h) {
     if (h->dCwf) return LMPC_OK;
     if (!h->dCw)
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: the binary32 path runs on the wavefront kernel, which does not "
-                                             "cover this problem (n <= 63, n+1+#soft <= 64, 1 <= m <= 256)");
+                                             "cover this problem (n <= 63, 1 <= m <= 1024)");
     const HostPack &P = h->P;
     const WaveLayout &Wl = h->W;
     const size_t total = (size_t)Wl.oXth + (size_t)P.nout * P.nth;
@@ -847,6 +863,112 @@ int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmp
     return LMPC_OK;
 }
 
+int lmpc_set_parameter_layout(lmpc_handle *h, const lmpc_param_layout *l) {
+    if (!h || !l) return LMPC_ERR_BADARG;
+    if (l->n_state < 0 || l->n_reference < 0 || l->n_disturbance < 0 || l->n_control_prev < 0 ||
+        l->n_affine_parameter < 0 || l->n_preview_horizon < 0 || l->n_control_prev > h->P.nout ||
+        (l->n_preview_horizon > 0 && !l->traj2setpoint))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_set_parameter_layout: negative size, n_control_prev > nout, or "
+                                        "n_preview_horizon > 0 without traj2setpoint");
+    if (l->n_state + l->n_reference + l->n_disturbance + l->n_control_prev + l->n_affine_parameter != h->P.nth)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_set_parameter_layout: blocks do not add up to the handle's nth = " +
+                                            std::to_string(h->P.nth));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipFree(h->ccT2S);
+    h->ccT2S = nullptr;
+    if (l->n_preview_horizon > 0 && l->n_reference > 0) {
+        const size_t cnt = (size_t)l->n_reference * l->n_reference * l->n_preview_horizon;
+        HIP_TRY(h, hipMalloc(&h->ccT2S, sizeof(double) * cnt));
+        HIP_TRY(h, hipMemcpy(h->ccT2S, l->traj2setpoint, sizeof(double) * cnt, hipMemcpyHostToDevice));
+    }
+    h->ccNx = l->n_state; h->ccNr = l->n_reference; h->ccNd = l->n_disturbance; h->ccNup = l->n_control_prev;
+    h->ccNp = l->n_affine_parameter; h->ccNph = l->n_reference > 0 ? l->n_preview_horizon : 0;
+    h->ccWarmN = -1;
+    return LMPC_OK;
+}
+
+int lmpc_compute_control_device(lmpc_handle *h, int64_t N, double *control, const double *state,
+                                const double *reference, const double *disturbance,
+                                const double *affine_parameter, int32_t *exitflag, int warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (h->ccNx < 0) return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control: call lmpc_set_parameter_layout first");
+    if (N < 0 || (N > 0 && (!control || (h->ccNx > 0 && !state))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control: NULL control/state or negative N");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w = (size_t)h->P.words();
+    if (N > h->ccCap) {
+        hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag);
+        h->ccTheta = nullptr; h->ccAct = nullptr; h->ccFlag = nullptr; h->ccCap = 0; h->ccWarmN = -1;
+        HIP_TRY(h, hipMalloc(&h->ccTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
+        HIP_TRY(h, hipMalloc(&h->ccAct, sizeof(uint64_t) * (size_t)N * w));
+        HIP_TRY(h, hipMalloc(&h->ccFlag, sizeof(int32_t) * (size_t)N));
+        h->ccCap = N;
+    }
+    const long long total = (long long)N * h->P.nth;
+    if (total > 0) {
+        hipLaunchKernelGGL(update_parameter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           h->ccTheta, control, h->P.nout, state, h->ccNx, reference, h->ccNr, h->ccNph, h->ccT2S,
+                           disturbance, h->ccNd, h->ccNup, affine_parameter, h->ccNp, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    // DAQP_WARMSTART build (codegen/mpc_update_qp.c:44-47): the working sets the previous call ended
+    // with are the next call's starting point; otherwise every call starts cold
+    const bool use_warm = warm && h->ccWarmN == N && !h->bnb;
+    int rc = launch(h, N, h->ccTheta, control, exitflag ? exitflag : h->ccFlag, nullptr,
+                    (warm && !h->bnb) ? h->ccAct : nullptr, use_warm ? h->ccAct : nullptr, st);
+    if (rc != LMPC_OK) return rc;
+    h->ccWarmN = (warm && !h->bnb) ? N : -1;
+    return LMPC_OK;
+}
+
+int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const double *state,
+                         const double *reference, const double *disturbance, const double *affine_parameter,
+                         int32_t *exitflag, int warm) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (h->ccNx < 0) return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control: call lmpc_set_parameter_layout first");
+    if (N < 0 || (N > 0 && (!control || (h->ccNx > 0 && !state))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control: NULL control/state or negative N");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nu = h->P.nout;
+    const size_t wr = (size_t)h->ccNr * (h->ccNph > 0 ? h->ccNph : 1);
+    double *dc = nullptr, *ds = nullptr, *dr = nullptr, *dd = nullptr, *dp = nullptr;
+    int32_t *df = nullptr;
+    auto cleanup = [&]() { hipFree(dc); hipFree(ds); hipFree(dr); hipFree(dd); hipFree(dp); hipFree(df); };
+#define CC_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
+        return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    auto up = [&](double **dst, const double *src, size_t per) -> hipError_t {
+        if (!src || per == 0) return hipSuccess;
+        hipError_t e = hipMalloc(dst, sizeof(double) * (size_t)N * per);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, sizeof(double) * (size_t)N * per, hipMemcpyHostToDevice);
+    };
+    CC_TRY(up(&dc, control, (size_t)nu));
+    CC_TRY(up(&ds, state, (size_t)h->ccNx));
+    CC_TRY(up(&dr, reference, wr));
+    CC_TRY(up(&dd, disturbance, (size_t)h->ccNd));
+    CC_TRY(up(&dp, affine_parameter, (size_t)h->ccNp));
+    CC_TRY(hipMalloc(&df, sizeof(int32_t) * (size_t)N));
+    int rc = lmpc_compute_control_device(h, N, dc, ds, dr, dd, dp, df, warm, nullptr);
+    if (rc != LMPC_OK) { cleanup(); return rc; }
+    CC_TRY(hipMemcpy(control, dc, sizeof(double) * (size_t)N * nu, hipMemcpyDeviceToHost));
+    if (exitflag) CC_TRY(hipMemcpy(exitflag, df, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+#undef CC_TRY
+    cleanup();
+    return LMPC_OK;
+}
+
 int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F, const double *G,
                   double *x, const double *r, double *uprev, double *U_traj, double *X_traj, int32_t *flag_min,
                   int warm) {
@@ -960,6 +1082,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
+    hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag);
     delete h;
 }
 

@@ -62,6 +62,38 @@ __global__ __launch_bounds__(256) void form_parameter_kernel(
     theta[idx] = v;
 }
 
+// theta_i = [state_i ; reference_i ; disturbance_i ; control_i[0:nup] ; affine_parameter_i] from the
+// five arrays the reference's generated controller takes (codegen/mpc_update_parameter.c:1-29), one
+// record per problem in each array; a NULL array gives zeros.  nph > 0 (N_PREVIEW_HORIZON, i.e.
+// settings.reference_condensation): reference_i holds nr*nph values (an nr x nph trajectory, column
+// by column) and entry j of the block is sum_i reference_i[i] * t2s[i*nr + j], accumulated in index
+// order with separate multiply and add exactly as the C loop does (mpc_update_parameter.c:10-16).
+// One thread per entry of theta.
+__global__ __launch_bounds__(256) void update_parameter_kernel(
+    double *__restrict__ theta, const double *__restrict__ control, int ncontrol,
+    const double *__restrict__ state, int nx, const double *__restrict__ reference, int nr, int nph,
+    const double *__restrict__ t2s, const double *__restrict__ disturbance, int nd, int nup,
+    const double *__restrict__ parameter, int npar, long long n) {
+    const int nth = nx + nr + nd + nup + npar;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * nth) return;
+    const long long i = idx / nth;
+    int e = (int)(idx - i * nth);
+    double v = 0.0;
+    if (e < nx) v = state[i * nx + e];
+    else if ((e -= nx) < nr) {
+        if (reference == nullptr) v = 0.0;
+        else if (nph > 0) {
+            const double *ri = reference + i * (long long)nr * nph;
+            for (int q = 0; q < nr * nph; q++) v = __dadd_rn(v, __dmul_rn(ri[q], t2s[(long long)q * nr + e]));
+        } else v = reference[i * nr + e];
+    }
+    else if ((e -= nr) < nd) v = disturbance ? disturbance[i * nd + e] : 0.0;
+    else if ((e -= nd) < nup) v = control ? control[i * ncontrol + e] : 0.0;
+    else v = parameter ? parameter[i * npar + (e - nup)] : 0.0;
+    theta[idx] = v;
+}
+
 // x_i <- F x_i + G u_i (sums in index order, F then G), uprev_i <- u_i, bookkeeping of the run
 __global__ __launch_bounds__(256) void plant_kernel(
     double *__restrict__ x, double *__restrict__ uprev, const double *__restrict__ u,

@@ -1,5 +1,5 @@
 // One-QP-per-wavefront dual active-set kernel: the general path (n <= 63 variables, working sets
-// up to 64 rows, m <= 256 constraints, hard and SOFT rows, BINARY rows by branch and bound),
+// up to 64 rows, m <= 1024 constraints, hard and SOFT rows, BINARY rows by branch and bound),
 // in binary64 or binary32 (the reference's generated C has both: codegen.jl:19,31-37,82 `float_type`).
 //
 // Mapping (gfx950): a 64-lane wavefront owns one parameter point.  Working-set position i lives
@@ -127,7 +127,7 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 // bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
 // PACKED: layout of the per-wave factor L, see below.
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
-__global__ __launch_bounds__((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB)
+__global__ __launch_bounds__(MR >= 8 ? 256 : ((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
@@ -476,6 +476,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int j = 64 * r + bit;
                     const bool lower = (lm[r] >> bit) & 1ull;
                     const int sj = sense_of(j);
+                    if (na >= cap) { flag = EXIT_WSCAP; done = true; break; }
                     ldl_add(j, lower);
                     if (sing >= 0) {
                         if (sj & SENSE_IMMUTABLE) { flag = EXIT_OVERDETERMINED; done = true; }
@@ -493,7 +494,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         }
 
         // ---- first step of a node that continues in place: the freshly fixed row joins the working set
-        if (BNB && forced >= 0 && iter < P.iter_limit) {
+        if (BNB && forced >= 0 && iter < P.iter_limit && na >= cap) { flag = EXIT_WSCAP; done = true; }
+        if (BNB && forced >= 0 && iter < P.iter_limit && !done) {
             lam = ls;
             ldl_add(forced >> 1, (forced & 1) != 0);
             if (fval - best < progress_tol) {
@@ -600,6 +602,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                             midx = wv_min(wv_in(tie) ? midx : 0x7fffffff);
                         }
                     }
+                    // the working set lives on the 64 lanes: a problem whose working set would outgrow
+                    // them (n + 1 + #soft > 64 rows possible, more than 64 wanted at once) is given up
+                    if (na >= cap) { flag = EXIT_WSCAP; break; }
                     lam = ls;
                     ldl_add(midx >> 1, (midx & 1) != 0);
                     if (fval - best < progress_tol) {
@@ -677,6 +682,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 solve_node(forced, pup, plo, depth > 0);
                 nodes++;
                 total_it += iter;
+                if (flag == EXIT_WSCAP) { bflag = EXIT_WSCAP; have = 0; break; }
                 bool descend = false;
                 if (flag >= 1) {
                     // lowest-index binary row that is not in the final working set

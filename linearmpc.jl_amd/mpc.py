@@ -50,7 +50,7 @@ class MPC:
 
     def __init__(self, mpqp: MPQP, nx, nu, nr=0, nd=0, nuprev=0, np_=0, K=None,
                  soft_weight=1e6, device=0, Np=1, reference_preview=False, disturbance_preview=False,
-                 parameter_preview=False):
+                 parameter_preview=False, reference_condensation=False, traj2setpoint=None):
         self.mpQP = mpqp
         self.nx, self.nu, self.nr, self.nd, self.nuprev, self.np = nx, nu, nr, nd, nuprev, np_
         # MPCSettings (types.jl:54-69): with a preview the block of theta holds Np columns
@@ -58,7 +58,12 @@ class MPC:
         self.reference_preview = bool(reference_preview)
         self.disturbance_preview = bool(disturbance_preview)
         self.parameter_preview = bool(parameter_preview)
-        self.ny = nr // self.Np if self.reference_preview else nr              # model.ny
+        # settings.reference_condensation (types.jl:54,65): the Np-column reference trajectory is
+        # collapsed to ONE setpoint by mpc.traj2setpoint (ny x ny*Np, computed by the condensing step,
+        # mpc2mpqp.jl:550-566), so the block of theta is ny wide again
+        self.reference_condensation = bool(reference_condensation)
+        self.traj2setpoint = None if traj2setpoint is None else np.asarray(traj2setpoint, float)
+        self.ny = nr // self.Np if (self.reference_preview and not self.reference_condensation) else nr   # model.ny
         self.nd_base = nd // self.Np if self.disturbance_preview else nd       # model.nd
         self.np_base = np_ // self.Np if self.parameter_preview else np_       # utils.jl:204-217
         self.K = np.zeros((nu, nx)) if K is None else np.asarray(K, float).reshape(nu, nx)
@@ -114,7 +119,13 @@ class MPC:
             return a[:, 0].copy()
         raise ValueError(f"{what} must be a vector or matrix")
 
-    # utils.jl:78-133 (reference_condensation / traj2setpoint stay on the LinearMPC.jl host)
+    # utils.jl:136-146
+    def condense_reference(self, r):
+        if self.reference_condensation:
+            return self.traj2setpoint @ np.asarray(r, float).reshape(-1)
+        return r
+
+    # utils.jl:78-133
     def format_reference(self, r):
         if self.nr == 0:                                  # reference_tracking off
             return np.zeros(0)
@@ -123,7 +134,7 @@ class MPC:
         if np.size(r) == 0:
             return np.zeros(0)
         if self.reference_preview:
-            return self._tile(r, self.ny, self.Np, "Reference", "outputs")
+            return self.condense_reference(self._tile(r, self.ny, self.Np, "Reference", "outputs"))
         return self._single(r, self.ny, "Reference", "outputs")
 
     # utils.jl:141-201
@@ -242,3 +253,30 @@ class MPC:
         if check:
             assert np.all(ef >= 1), f"{int(np.sum(ef < 1))} problems did not solve (min flag {ef.min()})"
         return U, ef
+
+
+class GeneratedController:
+    """What `LinearMPC.codegen(mpc; warm_start)` produces, batched: the counterpart of the generated
+    `int mpc_compute_control(c_float* control, c_float* state, c_float* reference, c_float* disturbance
+    [, c_float* affine_parameter])` (reference src/codegen.jl:1-17,139-218, codegen/mpc_update_qp.c:29-54,
+    codegen/mpc_update_parameter.c) behind `lmpc_set_parameter_layout` + `lmpc_compute_control`.
+
+    The LDP arrays the generator writes (Dth, du, dl, Uth_offset incl. -K, u_offset: codegen.jl:140-141,
+    183-189) are what the handle's pack holds; N_STATE ... N_AFFINE_PARAMETER come from the MPC's
+    parameter dimensions, N_PREVIEW_HORIZON / traj2setpoint from settings.reference_condensation."""
+
+    def __init__(self, mpc: MPC, warm_start=False):
+        self.mpc = mpc
+        self.warm_start = bool(warm_start)
+        self.model = mpc.control_model()
+        cond = mpc.reference_preview and mpc.reference_condensation
+        self.model.set_parameter_layout(mpc.nx, mpc.nr, mpc.nd, mpc.nuprev, mpc.np,
+                                        preview_horizon=mpc.Np if cond else 0,
+                                        traj2setpoint=mpc.traj2setpoint if cond else None)
+
+    def mpc_compute_control(self, control, state, reference=None, disturbance=None, affine_parameter=None):
+        """control: (N, nu) float64, in = previous control, out = u* (in place); returns exit flags (N,).
+        reference: (N, nr) -- or (N, ny*Np), each an ny x Np trajectory column by column, when the
+        controller condenses references.  None stands for the C caller's NULL."""
+        return self.model.compute_control(control, state, reference, disturbance, affine_parameter,
+                                          warm=self.warm_start)

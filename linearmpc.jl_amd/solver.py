@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _cabi
-from ._cabi import Block, LmpcError, Settings, check, lib
+from ._cabi import Block, LmpcError, ParamLayout, Settings, check, lib
 
 _vp = ctypes.c_void_p
 
@@ -302,6 +302,59 @@ class BatchedQP:
         torch.cuda.synchronize(dev)
         return dict(x=x.cpu().numpy(), U=U.cpu().numpy(), X=X.cpu().numpy(),
                     uprev=None if up is None else up.cpu().numpy(), flag_min=fm.cpu().numpy())
+
+    # ------------------------------------------------------------------ generated-controller entry point
+    def set_parameter_layout(self, nx, nr=0, nd=0, nuprev=0, np_=0, preview_horizon=0, traj2setpoint=None):
+        """`lmpc_set_parameter_layout`: N_STATE, N_REFERENCE, N_DISTURBANCE, N_CONTROL_PREV,
+        N_AFFINE_PARAMETER of the generated header (reference codegen.jl:154-165); with reference
+        condensation N_PREVIEW_HORIZON and mpc.traj2setpoint (nr x nr*Np; passed as the generator
+        writes it, column by column)."""
+        t2s = None
+        if preview_horizon:
+            t2s = _f64(np.asarray(traj2setpoint, float).reshape(nr, nr * preview_horizon), "F")
+        lay = ParamLayout(int(nx), int(nr), int(nd), int(nuprev), int(np_), int(preview_horizon),
+                          t2s.ctypes.data if t2s is not None else None)
+        check(lib().lmpc_set_parameter_layout(self._h, ctypes.byref(lay)), self._h)
+        self._layout = (int(nx), int(nr), int(nd), int(nuprev), int(np_), int(preview_horizon))
+
+    def compute_control(self, control, state, reference=None, disturbance=None, affine_parameter=None, warm=False):
+        """`lmpc_compute_control`: the generated `mpc_compute_control(control, state, reference,
+        disturbance[, affine_parameter])` (reference codegen/mpc_update_qp.c:29-54) for N problems.
+        `control` (N x nu) is read (previous control) and overwritten (u*), as in the C function;
+        returns the exit flags."""
+        nx, nr, nd, nup, npp, nph = self._layout
+        if not (isinstance(control, np.ndarray) and control.dtype == np.float64 and control.flags.c_contiguous
+                and control.flags.writeable):
+            raise TypeError("control must be a writeable C-contiguous float64 array (it is updated in place)")
+        N = control.size // self.nout if self.nout else 0
+        control = control.reshape(N, self.nout)
+
+        def arr(a, w):
+            if a is None or w == 0:
+                return None
+            return _f64(np.asarray(a, float).reshape(N, w))
+
+        st, rf = arr(state, nx), arr(reference, nr * (nph if nph else 1))
+        ds, pr = arr(disturbance, nd), arr(affine_parameter, npp)
+        ef = np.empty(N, np.int32)
+        check(lib().lmpc_compute_control(self._h, N, _ptr(control), _ptr(st), _ptr(rf) if rf is not None else None,
+                                         _ptr(ds) if ds is not None else None, _ptr(pr) if pr is not None else None,
+                                         _ptr(ef), int(bool(warm))), self._h)
+        return ef
+
+    def compute_control_device(self, control, state, reference=None, disturbance=None, affine_parameter=None,
+                               exitflag=None, warm=False, stream=None):
+        """`lmpc_compute_control_device`: CUDA tensors in place, enqueued on the current (or given) stream."""
+        import torch
+        N = int(control.shape[0])
+        dev = control.device
+        if exitflag is None:
+            exitflag = torch.empty(N, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        p = lambda t: _vp(t.data_ptr()) if t is not None else None
+        check(lib().lmpc_compute_control_device(self._h, N, p(control), p(state), p(reference), p(disturbance),
+                                                p(affine_parameter), p(exitflag), int(bool(warm)), _vp(st)), self._h)
+        return exitflag
 
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):

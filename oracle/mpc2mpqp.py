@@ -100,6 +100,8 @@ class MPCProblem:
     Eu: Optional[np.ndarray] = None         # affine input cost (Eu p + eu)'u_k  (setup.jl:136-150)
     eu: Optional[np.ndarray] = None
     reference_preview: bool = False         # settings.reference_preview (types.jl:56,67): r is ny x Np in theta
+    reference_condensation: bool = False    # settings.reference_condensation (types.jl:54,65): the trajectory is
+    traj2setpoint: Optional[np.ndarray] = None   # collapsed to one setpoint by traj2setpoint (set by mpc2mpqp)
     f_offset: Optional[np.ndarray] = None   # x+ = F x + G u + f_offset   (model.jl:20, setup.jl:516-531)
     h_offset: Optional[np.ndarray] = None   # y  = C x + h_offset         (model.jl:30)
     move_blocks: Optional[list] = None      # per input: block lengths (setup.jl:202-248)
@@ -177,8 +179,8 @@ class MPCProblem:
     # mpc2mpqp.jl:147-164
     def parameter_dims(self):
         nr = self.ny if self.reference_tracking else 0
-        if self.reference_preview and nr > 0:    # mpc2mpqp.jl:154-156: one reference per predicted step
-            nr = nr * self.Np
+        if self.reference_preview and not self.reference_condensation and nr > 0:
+            nr = nr * self.Np                    # mpc2mpqp.jl:154-156: one reference per predicted step
         nuprev = self.nu if np.any(self.Rr != 0) else 0
         return self.nx, nr, 0, nuprev, self.np_base()
 
@@ -327,6 +329,18 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         Hr = np.kron(np.eye(N), Q_full)
         Hr[-ny:, -ny:] = Qf_full
         nrp = ny * N
+        if p.reference_condensation:
+            # mpc2mpqp.jl:550-569: the trajectory enters through ONE setpoint s = traj2setpoint r_traj,
+            # chosen so that W H^-1 Fr Is s is the least-squares match of W H^-1 Fr r_traj (W weights the
+            # first control move 1e6: its accuracy matters most); Is repeats the setpoint over the horizon
+            Is = np.tile(np.eye(ny), (N, 1))
+            Wc = np.eye(H.shape[0])
+            Wc[np.arange(p.nu), np.arange(p.nu)] = 1e6
+            WinvHFr = Wc @ np.linalg.solve(H, Fr)
+            p.traj2setpoint = np.linalg.lstsq(WinvHFr @ Is, WinvHFr, rcond=None)[0]
+            Fr = Fr @ Is
+            Hr = Is.T @ Hr @ Is
+            nrp = ny
         f_theta = np.hstack([f_theta[:, :nxp], Fr, f_theta[:, nxp:]])
         tail = H_theta.shape[0] - nxp
         H_theta = np.block([[H_theta[:nxp, :nxp], np.zeros((nxp, nrp)), H_theta[:nxp, nxp:]],
@@ -361,7 +375,8 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         H_theta = H_theta[:-1, :-1]
     if p.reference_tracking and p.h_offset is not None and np.any(p.h_offset):   # r - h_offset (:523-530)
         nrp = p.parameter_dims()[1]
-        ho = np.tile(p.h_offset, N) if p.reference_preview else np.asarray(p.h_offset, float)
+        ho = np.tile(p.h_offset, N) if (p.reference_preview and not p.reference_condensation) \
+            else np.asarray(p.h_offset, float)
         f = f - f_theta[:, p.nx:p.nx + nrp] @ ho
     return (H + H.T) / 2, f, f_theta, H_theta
 
@@ -746,6 +761,18 @@ def preview_sim_kat(preview: bool) -> MPCProblem:
     return p
 
 
+def refcond_kat() -> MPCProblem:
+    """test/runtests.jl:669-733 "Codegen Reference Preview - Condensed": double integrator, C = I,
+    Np = Nc = 5, |u| <= 2, Q = I, R = 0.1, reference_preview + reference_condensation; the test feeds
+    r_traj = [0 .5 1 1 1; 0 0 0 0 0] at x = 0 through Julia, generated C and explicit MPC and asserts
+    they agree to 1e-10, and that mpc_update_parameter gives theta = [x; traj2setpoint r_traj; u]."""
+    p = make_mpc([[1, 1], [0, 1]], [[0], [1]], np.eye(2), Np=5, Nc=5, Q=[1.0, 1.0], R=[0.1],
+                 umin=[-2.0], umax=[2.0])
+    p.reference_preview = True
+    p.reference_condensation = True
+    return p
+
+
 def offset_kat() -> MPCProblem:
     """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
     with r = 1.5 settles at u = 10.5, y = 1.5."""
@@ -766,6 +793,8 @@ def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):
     x = np.asarray(x, float).reshape(nx)
     if p.reference_preview and r is not None and nr > 0:
         r = format_reference_preview(np.asarray(r, float), p.ny, p.Np)
+        if p.reference_condensation:             # utils.jl:141-146 condense_reference
+            r = p.traj2setpoint @ r
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
     pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]

@@ -23,6 +23,10 @@ mask.  Before anything is written the answers are cross-checked by independent m
     each solved as a plain linear system (no solver involved).  Np=20: the closed loop reaches the
     reference and every binary input sits on a bound (the reference's own assertions).
 
+  * refcond_kat: reference condensation (/root/reference/test/runtests.jl:669-733): the condensed
+    controller's first move equals the uncondensed preview controller's on the test's trajectory, and
+    a constant trajectory condenses to itself.
+
 `python tests/golden/make_golden.py name ...` rewrites only the named fixtures.
 
 Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
@@ -349,6 +353,32 @@ def main():
     theta = np.vstack([np.array(ths), rngk.uniform(-5, 5, (108, 2))])
     X, ef, it, act = oldp.solve_batch(L, theta)
     save("moveblock_kat", q, L, theta, X, ef, it, act, dict(F=prob.F, G=prob.G, ys=np.array(ys)))
+
+    # ---- reference condensation (runtests.jl:669-733): the generated controller takes the ny x Np
+    # trajectory and collapses it with traj2setpoint (codegen/mpc_update_parameter.c:9-16)
+    prob = omm.refcond_kat()
+    q = omm.mpc2mpqp(prob)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    T2S = prob.traj2setpoint
+    rt = np.array([[0.0, 0.5, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0]])
+    th0 = omm.form_parameter(prob, [0.0, 0.0], r=rt)
+    # the uncondensed preview controller gives the same first move on the test's trajectory (the
+    # condensation weights the first move 1e6), and a constant trajectory condenses to itself
+    prob_full = omm.refcond_kat()
+    prob_full.reference_condensation = False
+    qf = omm.mpc2mpqp(prob_full)
+    Lf = oldp.qp2ldp(qf.H, qf.f, qf.f_theta, qf.A, qf.bu, qf.bl, qf.W, qf.senses, nout=qf.n)
+    u_c = oldp.solve_batch(L, th0[None])[0][0, 0]
+    u_f = oldp.solve_batch(Lf, omm.form_parameter(prob_full, [0.0, 0.0], r=rt)[None])[0][0, 0]
+    assert abs(u_c - u_f) < 1e-5, (u_c, u_f)
+    assert np.allclose(T2S @ np.tile([0.7, -0.2], 5), [0.7, -0.2], atol=1e-9)
+    rngc = np.random.default_rng(31)
+    states = np.vstack([np.zeros((1, 2)), rngc.uniform(-2, 2, (127, 2))])
+    trajs = np.vstack([rt.T.reshape(1, -1), np.cumsum(rngc.uniform(-0.5, 0.5, (127, 5, 2)), 1).reshape(127, -1)])
+    theta = np.array([omm.form_parameter(prob, states[i], r=trajs[i].reshape(5, 2).T) for i in range(128)])
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("refcond_kat", q, L, theta, X, ef, it, act,
+         dict(traj2setpoint=T2S, state=states, reference=trajs, u_full_preview=u_f))
 
 
 if __name__ == "__main__":

@@ -346,6 +346,55 @@ def test_wave_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
     _compare(qp, theta[:65], warm=act[:65])
 
 
+@pytest.mark.parametrize("n,mg,nth,nsoft,seed", [(8, 300, 3, 0, 11), (20, 480, 5, 60, 12), (40, 984, 4, 100, 13),
+                                                 (10, 500, 6, 200, 14)])
+def test_wave_kernel_many_rows(lmpc, n, mg, nth, nsoft, seed):
+    # 256 < m <= 1024: the 8- and 16-slot instantiations (long prediction horizons with output bounds);
+    # n + 1 + #soft may exceed the 64 lanes as long as the working sets themselves stay below
+    rng = np.random.default_rng(seed)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 2 * bu, 2 * bl, 0.3 * W, sense, nout=min(n, 4))
+    assert qp.kernel_name == "wave" and qp.m == n + mg
+    theta = rng.uniform(-2, 2, (300, nth))
+    x, ef, it, act = _compare(qp, theta)
+    assert (ef >= 1).mean() > 0.05 and (ef != -7).all()
+    ok = ef >= 1
+    _compare(qp, theta[ok][:65], warm=act[ok][:65])
+    if nsoft == 0:                                       # binary32 on the same instantiations
+        from oracle import ldp as oldp
+        s32 = lmpc.default_settings_f32()
+        qf = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 2 * bu, 2 * bl, 0.3 * W, sense, nout=min(n, 4), settings=s32)
+        th32 = theta.astype(np.float32)
+        xf, eff, itf, actf = qf.solve_f32(th32)
+        xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qf.ldp()), th32, _copy_settings(lmpc, s32), dtype=np.float32)
+        assert np.array_equal(eff, efo) and np.array_equal(itf, ito) and np.array_equal(actf, acto)
+        assert np.abs(xf - xo).max() <= 1e-6
+
+
+def test_working_set_capacity_flag(lmpc):
+    # soft rows never make a working set singular, so a problem with many of them can want more than
+    # 64 rows at once -- more than the wavefront has lanes.  Such a problem ends with exit flag -7
+    # (no DAQP flag; the reference asserts exitflag >= 1, utils.jl:46); every other problem of the
+    # batch is solved exactly as the oracle solves it.
+    from oracle import ldp as oldp
+    rng = np.random.default_rng(5)
+    n, mg, nth = 6, 150, 2
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=mg)
+    W[n:, 0] = np.abs(W[n:, 0]) + 0.5                    # theta_0 >> 0 pushes every soft row over its bound
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
+    theta = np.vstack([rng.uniform(-1, 1, (200, nth)),
+                       np.hstack([rng.uniform(30, 60, (56, 1)), rng.uniform(-1, 1, (56, 1))])])
+    x, ef, it, act = qp.solve(theta)
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta)
+    nact = np.array([sum(bin(int(w)).count("1") for w in row) for row in acto])
+    over = ef == -7
+    assert over.any() and (nact[over] >= 60).all()       # given up only where the working set is that large
+    assert (nact[~over] <= 64).all()
+    keep = ~over
+    assert np.array_equal(ef[keep], efo[keep]) and np.array_equal(it[keep], ito[keep])
+    assert np.array_equal(act[keep], acto[keep]) and np.abs(x[keep] - xo[keep]).max() <= TOL
+
+
 # ------------------------------------------------------------------ closed-loop batch simulation
 @pytest.mark.parametrize("warm", [False, True])
 def test_closed_loop_simulation_matches_oracle(lmpc, warm):
@@ -482,7 +531,7 @@ def test_unsupported_shapes_are_refused_loudly(lmpc):
     with pytest.raises(lmpc.LmpcError) as e:
         lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
     assert e.value.code == -103
-    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 8, 300, 3)       # m > 256
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 8, 1020, 3)      # m > 1024
     with pytest.raises(lmpc.LmpcError) as e:
         lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
     assert e.value.code == -103
@@ -492,7 +541,7 @@ def test_unsupported_shapes_are_refused_loudly(lmpc):
                                          (20, 236, "wave"), (2, 1, "lane")])
 def test_size_boundaries_between_kernels(lmpc, n, mg, kernel):
     # m = 64 is the last size the lane kernel's one-word masks cover, n = 12 its largest instantiation,
-    # m = 256 the wavefront kernel's limit
+    # m = 256 the last size of the 512-thread wavefront instantiations
     rng = np.random.default_rng(100 + n + mg)
     H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, 4)
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 3 * bu, 3 * bl, 0.2 * W, sense, nout=min(n, 3))
@@ -834,3 +883,74 @@ def test_reference_preview_simulation_on_the_gpu(lmpc):
     ep, en = yp - rt, yn - rt
     assert np.linalg.norm(ep) / np.linalg.norm(en) < 0.9
     assert np.linalg.norm(ep[:, -1]) < 1e-3 and np.linalg.norm(en[:, -1]) < 1e-3
+
+
+def test_generated_controller_entry_point(lmpc):
+    # lmpc_compute_control == the reference's generated mpc_compute_control(control, state, reference,
+    # disturbance) (codegen/mpc_update_qp.c:29-54, mpc_update_parameter.c) for N problems: control is
+    # in (previous control) / out (u*).  K1 the way the reference runs it on its generated C
+    # (runtests.jl:78-81), then a batch against solve(form_parameter(...)) -- same bits.
+    g = load_golden("pendulum")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                   nx=4, nu=1, nr=2, nuprev=1)
+    ctl = lmpc.GeneratedController(mpc)
+    u = np.zeros((1, 1))
+    ef = ctl.mpc_compute_control(u, np.array([[5.0, 5, 0, 0]]), np.zeros((1, 2)), None)
+    assert ef[0] == 1 and abs(u[0, 0] - 1.7612519326) < 1e-6
+    th = g["theta"][:3000]
+    control = np.ascontiguousarray(th[:, 6:7].copy())
+    ef = ctl.mpc_compute_control(control, th[:, :4], th[:, 4:6])
+    x, efs, _, _ = mpc.control_model().solve(th)
+    assert np.array_equal(ef, efs) and np.array_equal(control, x)
+    # NULL reference = zeros (the C caller's NULL for an absent block)
+    control = np.ascontiguousarray(th[:, 6:7].copy())
+    ctl.mpc_compute_control(control, th[:, :4], None)
+    th0 = th.copy()
+    th0[:, 4:6] = 0
+    assert np.array_equal(control, mpc.control_model().solve(th0)[0])
+    # DAQP_WARMSTART build: second call starts from the first call's working sets, same answers
+    warm = lmpc.GeneratedController(mpc, warm_start=True)
+    c1 = np.ascontiguousarray(th[:, 6:7].copy())
+    warm.mpc_compute_control(c1, th[:, :4], th[:, 4:6])
+    c2 = np.ascontiguousarray(th[:, 6:7].copy())
+    ef2 = warm.mpc_compute_control(c2, th[:, :4] + 1e-3, th[:, 4:6])
+    th2 = th.copy()
+    th2[:, :4] += 1e-3
+    xs, efs2, _, _ = mpc.control_model().solve(th2)
+    assert np.array_equal(ef2, efs2) and np.abs(c2 - xs).max() < 1e-9 and np.array_equal(c1, x)
+    # errors: layout that does not add up to nth, entry point before a layout was given
+    with pytest.raises(lmpc.LmpcError) as e:
+        mpc.control_model().set_parameter_layout(4, 2, 0, 0, 0)
+    assert e.value.code == -100
+    qp = _qp_from_golden(lmpc, g, 1)
+    with pytest.raises(lmpc.LmpcError):
+        qp._layout = (4, 2, 0, 1, 0, 0)
+        qp.compute_control(np.zeros((1, 1)), np.zeros((1, 4)))
+
+
+def test_generated_controller_reference_condensation(lmpc):
+    # /root/reference/test/runtests.jl:669-733: reference_preview + reference_condensation; the
+    # generated controller receives the ny x Np trajectory and collapses it with traj2setpoint
+    # (codegen/mpc_update_parameter.c:9-16).  Host and device entry points against the fixture.
+    import torch
+    g = load_golden("refcond_kat")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                   nx=2, nu=1, nr=2, Np=5, reference_preview=True, reference_condensation=True,
+                   traj2setpoint=g["traj2setpoint"])
+    # operator interface: compute_control(mpc, x; r = r_traj) condenses on the host (utils.jl:136-146)
+    rt = np.array([[0.0, 0.5, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0]])
+    assert np.abs(mpc.form_parameter([0.0, 0.0], r=rt) - g["theta"][0]).max() < 1e-12
+    u_julia = mpc.compute_control([0.0, 0.0], r=rt)
+    assert abs(u_julia[0] - g["X"][0, 0]) < 1e-9 and abs(u_julia[0] - float(g["u_full_preview"])) < 1e-5
+    ctl = lmpc.GeneratedController(mpc)
+    control = np.zeros((128, 1))
+    ef = ctl.mpc_compute_control(control, g["state"], g["reference"], None)
+    assert np.array_equal(ef, g["exitflag"])
+    assert np.abs(control[:, 0] - g["X"][:, 0]).max() < 1e-10
+    assert abs(control[0, 0] - u_julia[0]) < 1e-10                    # the reference's own assertion (:707)
+    dev = torch.device("cuda", 0)
+    cd = torch.zeros((128, 1), dtype=torch.float64, device=dev)
+    efd = ctl.model.compute_control_device(cd, torch.from_numpy(g["state"]).to(dev),
+                                           torch.from_numpy(np.ascontiguousarray(g["reference"])).to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(cd.cpu().numpy(), control) and np.array_equal(efd.cpu().numpy(), ef)

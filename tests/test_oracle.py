@@ -95,7 +95,7 @@ def test_K8_doc_example_with_soft_output_bounds():
 
 
 @pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc", "prestab",
-                                  "satellite4", "satellite20"])
+                                  "satellite4", "satellite20", "refcond_kat"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -109,7 +109,7 @@ def test_oracle_reproduces_golden(name):
 
 
 @pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc",
-                                  "satellite4", "satellite20"])
+                                  "satellite4", "satellite20", "refcond_kat"])
 def test_golden_pack_matches_restated_transform(name):
     g = load_golden(name)
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
@@ -392,3 +392,29 @@ def test_reference_preview_simulation_assertions():
     ep, en = yp - rt, yn - rt
     assert np.linalg.norm(ep) / np.linalg.norm(en) < 0.9
     assert np.linalg.norm(ep[:, -1]) < 1e-3 and np.linalg.norm(en[:, -1]) < 1e-3
+
+
+def test_reference_condensation_restated():
+    """/root/reference/test/runtests.jl:669-733 (reference_preview + reference_condensation) and
+    src/mpc2mpqp.jl:550-569: theta carries ONE setpoint = traj2setpoint * vec(r_traj); the test's own
+    check of mpc_update_parameter is theta == [x; condense_reference(r_traj); u]."""
+    from oracle import mpc2mpqp as omm
+    g = load_golden("refcond_kat")
+    p = omm.refcond_kat()
+    q = omm.mpc2mpqp(p)
+    assert q.nth == 4 and p.traj2setpoint.shape == (2, 10)          # x(2) + one setpoint(2), no u_prev (Rr = 0)
+    assert np.abs(p.traj2setpoint - g["traj2setpoint"]).max() < 1e-9
+    rt = np.array([[0.0, 0.5, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0]])
+    th = omm.form_parameter(p, [0.0, 0.0], r=rt)
+    assert np.abs(th - np.concatenate([[0, 0], p.traj2setpoint @ rt.T.reshape(-1)])).max() < 1e-12
+    assert np.abs(th - g["theta"][0]).max() < 1e-9
+    # a constant trajectory condenses to itself, and then the controller is the plain tracking one
+    assert np.abs(p.traj2setpoint @ np.tile([0.3, -0.1], 5) - [0.3, -0.1]).max() < 1e-9
+    p2 = omm.refcond_kat()
+    p2.reference_preview = p2.reference_condensation = False
+    q2 = omm.mpc2mpqp(p2)
+    assert np.abs(q.f_theta - q2.f_theta).max() < 1e-12 and np.abs(q.H - q2.H).max() == 0
+    # on the test's trajectory the first move equals the uncondensed preview controller's
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    u = oldp.solve_batch(L, th[None])[0][0, 0]
+    assert abs(u - float(g["u_full_preview"])) < 1e-5
