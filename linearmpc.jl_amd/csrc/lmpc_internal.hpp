@@ -1,0 +1,107 @@
+// Internals shared by the translation units of liblmpc_hip.so: the handle, error plumbing, the
+// wave kernel's launch interface.  The wavefront kernel's instantiations are compiled in their own
+// translation units (lmpc_wave_inst.hip, one per real type x branch-and-bound) so that the library
+// builds in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/lmpc_hip.h"
+#include "lmpc_pack.hpp"
+#include "lmpc_wave_layout.hpp"
+
+namespace lmpc {
+constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
+constexpr int kLaneMaxN = 12;
+constexpr int kLaneMaxM = 64;
+constexpr size_t kLdsMax = 160 * 1024;
+constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 1024;
+constexpr int kShards = 64;            // work-list segments (one atomic counter each)
+
+struct EventTriple { hipEvent_t a, mid, b; };
+}  // namespace lmpc
+
+struct lmpc_handle {
+    lmpc::HostPack P;
+    lmpc_settings S;
+    int device = 0;
+    int laneN = 0;              // lane-kernel instantiation (row stride of M/Rout on the device)
+    lmpc::PackLayout L{};
+    double *dC = nullptr;       // constant pack on the GPU
+    size_t nC = 0;
+    std::string err, kname;
+    // staging for the host-pointer entry point
+    double *sTheta = nullptr, *sX = nullptr;
+    int32_t *sFlag = nullptr, *sIter = nullptr;
+    uint64_t *sAct = nullptr, *sWarm = nullptr;
+    int64_t sCap = 0;
+    // work list of the problems the screening pass leaves for the iterating kernel
+    int32_t *dList = nullptr, *dCount = nullptr;
+    int64_t listCap = 0;        // batch size the list buffer was sized for
+    int countSet = 0;           // which of the two counter sets the next call uses
+    bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
+    // general path: one QP per wavefront
+    bool useWave = false;
+    bool bnb = false;           // rows flagged BINARY: branch and bound in the wavefront kernel
+    int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
+    bool waveQueue = true;      // tuning: dynamic problem queue of the wave kernel (0 = static split)
+    int32_t *dQueue = nullptr;
+    int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
+    int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)
+    int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)
+    int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
+    int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
+    int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
+    lmpc::WaveLayout W{};
+    double *dCw = nullptr;
+    float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
+    int32_t *dSw = nullptr;
+    int numCU = 256;
+    // closed-loop simulation scratch
+    double *simTheta = nullptr, *simU = nullptr, *simFG = nullptr;
+    int32_t *simFlag = nullptr;
+    uint64_t *simAct = nullptr;
+    int64_t simCap = 0;
+    // generated-controller entry point (lmpc_compute_control*): layout of theta, scratch, warm-start state
+    int ccNx = -1, ccNr = 0, ccNd = 0, ccNup = 0, ccNp = 0, ccNph = 0;
+    double *ccT2S = nullptr, *ccTheta = nullptr;
+    uint64_t *ccAct = nullptr;
+    int32_t *ccFlag = nullptr;
+    int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
+    // profiling
+    bool prof = false;
+    std::vector<lmpc::EventTriple> events;
+    std::vector<hipEvent_t> eventPool;   // recycled by lmpc_profile_read
+};
+
+namespace lmpc {
+
+hipError_t pool_event(lmpc_handle *h, hipEvent_t *e);
+int fail(lmpc_handle *h, int code, const std::string &msg);
+
+#define HIP_TRY(h, call)                                                                     \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return lmpc::fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
+// (R, BNB) in lmpc_wave_inst.hip)
+template <typename R, bool BNB>
+int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
+                     int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st);
+extern template int launch_wave_inst<double, false>(lmpc_handle *, const double *, int64_t, const double *, double *,
+                                                    int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+extern template int launch_wave_inst<double, true>(lmpc_handle *, const double *, int64_t, const double *, double *,
+                                                   int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+extern template int launch_wave_inst<float, false>(lmpc_handle *, const float *, int64_t, const float *, float *,
+                                                   int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+extern template int launch_wave_inst<float, true>(lmpc_handle *, const float *, int64_t, const float *, float *,
+                                                  int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+
+}  // namespace lmpc

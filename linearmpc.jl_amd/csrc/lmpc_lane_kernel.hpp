@@ -22,23 +22,13 @@
 #include <stdint.h>
 
 #include "lmpc_pack.hpp"
+#include "lmpc_wave_layout.hpp"
 
 #ifndef LMPC_LANE_WAVES
 #define LMPC_LANE_WAVES 3   // wavefronts per SIMD the small lane kernels are register-budgeted for
 #endif
 
 namespace lmpc {
-
-// Offsets (in doubles) of the constant arrays inside the single device buffer.
-struct PackLayout {
-    int n, m, ms, nth, nout, words;
-    int oM, oG, odu, odl, oDth, oRout, ox0, oXth;   // offsets into the double buffer
-    int oDthP, oBnd, oXthP, nthp;                   // screening copies: rows zero-padded to nthp columns,
-                                                    // bounds interleaved (du0_j, dl0_j)
-    unsigned long long imm_mask, eq_mask;           // m <= 64: IMMUTABLE rows / rows flagged ACTIVE
-    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
-    int cycle_tol, iter_limit;
-};
 
 // work-list counters sit one per 128-byte line
 constexpr int kCountStride = 32;

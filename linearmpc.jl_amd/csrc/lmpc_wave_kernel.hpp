@@ -40,20 +40,13 @@
 #include <stdint.h>
 
 #include "lmpc_pack.hpp"
+#include "lmpc_wave_layout.hpp"
 
 #ifndef LMPC_WAVE_LB
 #define LMPC_WAVE_LB 1024   // threads per workgroup the small instantiations are register-budgeted for
 #endif
 
 namespace lmpc {
-
-struct WaveLayout {
-    int n, m, ms, nth, nout, words;
-    int cap, ldc;                                   // working-set capacity, leading dim of L
-    int oM, oMt, oG, odu, odl, oDth, oRout, ox0, oXth;
-    double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
-    int cycle_tol, iter_limit;
-};
 
 // ---- wave-level helpers, for double and float ---------------------------------------------------
 __device__ __forceinline__ double wv_bcast(double v, int src) {

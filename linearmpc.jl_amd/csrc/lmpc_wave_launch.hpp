@@ -1,0 +1,137 @@
+// Launch configuration and dispatch of the wavefront kernel (included by lmpc_wave_inst.hip only).
+#pragma once
+
+#include "lmpc_internal.hpp"
+#include "lmpc_wave_kernel.hpp"
+
+namespace lmpc {
+
+// bytes of shared problem data a wave-kernel workgroup keeps in LDS at staging level `level`
+// (1: M transposed, 2: + M, 3: + packed Gram), rs = sizeof(real)
+inline size_t wave_shared_bytes(const HostPack &P, int level, size_t rs) {
+    const size_t nM = (size_t)P.m * P.n, nG = (size_t)P.m * (P.m + 1) / 2;
+    return rs * (level >= 3 ? 2 * nM + nG : (level == 2 ? 2 * nM : (level == 1 ? nM : 0)));
+}
+
+struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; bool packed; };
+
+// Workgroup shape of the wave kernel: nwv wavefronts (= problems in flight) share one LDS copy of
+// the problem data.  Registers allow 4 wavefronts per SIMD (16 per CU; 12 for the 512-thread
+// instantiations); the per-wave factors and the shared copy compete for the 160 KiB of LDS.
+// Measured (tools/wave_sweep.sh): resident wavefronts matter more than the staging level (3-input
+// mass-spring: 16 waves with only M' staged 1.23e7/s, 8 waves with everything staged 0.85e7/s), and
+// at equal residency small workgroups win.  So: most wavefronts per CU first, then the highest
+// staging level that reaches it, then the smallest workgroup.
+inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) {
+    const WaveLayout &Wl = h->W;
+    // per-wave factor L: square with an odd leading dimension, or packed strict lower triangle
+    const size_t perWave = rs * (packed ? ((size_t)Wl.cap * (Wl.cap - 1) / 2) : ((size_t)Wl.cap * Wl.ldc));
+    // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
+    // (more registers per lane, fewer resident wavefronts)
+    const bool big = (h->P.m > 128) || h->bnb;
+    // resident wavefronts per CU the instantiation's registers allow (see `make asm`): 16 for the plain
+    // ones and for binary32 B&B with m <= 64, 12 for binary64 B&B (m <= 128) and binary32 B&B (m <= 128),
+    // 8 beyond
+    const int maxNwv = h->P.m > 256 ? 4 : (big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8));
+    int maxWaves = LMPC_WAVE_LB >= 1024 ? 16 : 12;
+    if (h->P.m > 256) maxWaves = 4;
+    else if (h->P.m > 128) maxWaves = 8;
+    else if (h->bnb) maxWaves = (rs == 4 && h->P.m <= 64) ? 16 : 12;
+    WaveConfig best{1, 0, 1, perWave, packed};
+    int bestWaves = -1;
+    // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
+    for (int level = (packed || h->P.m > 256) ? 1 : 3; level >= 0; level--) {
+        if (h->waveLevel >= 0 && level != ((packed || h->P.m > 256) && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
+        for (int nwv : {4, 8, 16, 2, 1}) {
+            if (nwv > maxNwv) continue;
+            if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
+            const size_t lds = perWave * nwv + wave_shared_bytes(h->P, level, rs);
+            if (lds > kLdsMax) continue;
+            int blocks = (int)(kLdsMax / lds);
+            if (blocks * nwv > maxWaves) blocks = maxWaves / nwv;
+            if (blocks < 1) continue;
+            const int waves = blocks * nwv;
+            if (waves > bestWaves) { bestWaves = waves; best = WaveConfig{nwv, level, blocks, lds, packed}; }
+        }
+    }
+    return best;
+}
+
+// square L unless the packed layout keeps at least a quarter more wavefronts resident
+inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
+    const WaveConfig sq = wave_config_for(h, rs, false), pk = wave_config_for(h, rs, true);
+    if (h->wavePacked == 0) return sq;
+    if (h->wavePacked == 1) return pk;
+    return 4 * pk.blocksPerCU * pk.nwv >= 5 * sq.blocksPerCU * sq.nwv ? pk : sq;
+}
+
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
+int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
+                    int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const WaveLayout &Wl = h->W;
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED>;
+    if (cfg.lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
+    int blocksPerCU = cfg.blocksPerCU;
+    if (h->waveCap > 0) {                              // tuning: wavefronts per CU of the persistent grid
+        blocksPerCU = h->waveCap / cfg.nwv;
+        if (blocksPerCU < 1) blocksPerCU = 1;
+    }
+    long long grid = (long long)h->numCU * blocksPerCU;
+    const long long need = (nprob + cfg.nwv - 1) / cfg.nwv;
+    if (grid > need) grid = need;
+    // more than two problems per resident wavefront: hand them out through the shared counter
+    int32_t *queue = nullptr;
+    int qchunk = 1;
+    if (nprob > 2 * grid * cfg.nwv && nprob < (int64_t)0x7fffffff && h->waveQueue) {
+        // ~16 tickets per resident wavefront over the whole batch, at most 64 problems per ticket
+        qchunk = (int)(nprob / (16 * grid * cfg.nwv));
+        qchunk = qchunk < 1 ? 1 : (qchunk > 64 ? 64 : qchunk);
+        if (!h->dQueue) HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
+        queue = h->dQueue;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
+                       iters, active, warm, queue, qchunk, (long long)nprob);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+template <typename R, bool BNB>
+int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
+                     int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    EventTriple ev{};
+    if (h->prof) {
+        HIP_TRY(h, pool_event(h, &ev.a));
+        HIP_TRY(h, pool_event(h, &ev.mid));
+        HIP_TRY(h, pool_event(h, &ev.b));
+        HIP_TRY(h, hipEventRecord(ev.a, st));
+        HIP_TRY(h, hipEventRecord(ev.mid, st));
+    }
+    int rc;
+    const int mr = (h->P.m + 63) / 64;
+    const WaveConfig cfg = wave_config(h, sizeof(R));
+    if (BNB) warm = nullptr;                              // a B&B node takes its start from the search, not the caller
+#define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
+#define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
+#define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
+                                 : (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))))
+#define LMPC_WVB(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
+                                  : (cfg.level >= 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))
+    if (mr <= 1) rc = LMPC_WV(1);
+    else if (mr == 2) rc = LMPC_WV(2);
+    else if (mr <= 4) rc = LMPC_WV(4);
+    else if (mr <= 8) rc = LMPC_WVB(8);
+    else rc = LMPC_WVB(16);
+#undef LMPC_WVB
+#undef LMPC_WV
+#undef LMPC_WV3
+#undef LMPC_WV4
+    if (h->prof) {
+        if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    }
+    return rc;
+}
+
+}  // namespace lmpc

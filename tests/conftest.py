@@ -16,7 +16,7 @@ def pytest_configure(config):
     import subprocess
     lib = os.path.join(ROOT, "linearmpc.jl_amd", "lib", "liblmpc_hip.so")
     if not os.path.exists(lib):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "linearmpc.jl_amd", "csrc")], check=True)
+        subprocess.run(["make", "-j6", "-C", os.path.join(ROOT, "linearmpc.jl_amd", "csrc")], check=True)
     if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
