@@ -9,10 +9,11 @@ One "step" = one pass of the hot path (lmpc_solve_batch_device: constraint shift
 active-set solve, primal recovery) over one batch of 1e6 synthetic parameter points per GPU,
 already resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 1e6-point
 shard (weak scaling).  The solve needs no data-path collective: shards are independent and their
-results stay on the GPU that produced them; the one exchange step -- an RCCL all-gather of the
-solutions and exit flags over xGMI -- happens once, after the last step, inside the timed region
-(--gather step does it after every step, overlapped with the next solve; at 12 MB per rank and
-step that exchange is ~10x longer than the 30 us solve it follows, so it is not the default).  Consecutive steps are
+results stay on the GPU that produced them; the one exchange step -- an RCCL gather of the
+solutions and exit flags to rank 0 over xGMI (every rank sends on its own link) -- happens once,
+after the last step, inside the timed region (--gather step all-gathers after every step,
+overlapped with the next solve; at 12 MB per rank and step that exchange is ~10x longer than the
+30 us solve it follows, so it is not the default).  Consecutive steps are
 independent batches; by default three of them are kept in flight on three HIP streams (each with
 its own solver handle), which lets the streaming pass of one batch overlap the latency-bound
 iterating pass of another (--streams 1 serialises them).
@@ -140,14 +141,15 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
-                    help="N > 1: RCCL all-gather of x and exit flags once after the last step (default), "
-                         "after every step (overlapped with the next solve), or never")
+                    help="N > 1: RCCL gather of x and exit flags to rank 0 once after the last step (default), "
+                         "an all-gather after every step (overlapped with the next solve), or never")
     ap.add_argument("--no-single-launch", action="store_true",
                     help="skip the one-call-at-a-time section after the timed region (profiling runs: keeps the "
                          "kernel trace to the launches of the timed region)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
+    ap.add_argument("--lane-tier", type=int, default=-1, help="lane kernel: first-tier capacity on (1) / off (0) (tuning)")
     ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
     ap.add_argument("--wave-level", type=int, default=-1, help="wave kernel: LDS staging level 0..3 (tuning)")
     ap.add_argument("--wave-nwv", type=int, default=0, help="wave kernel: wavefronts per workgroup (tuning)")
@@ -216,6 +218,9 @@ def main():
     if args.lane_block:
         for q_ in qps:
             q_.set_option("lane_block", args.lane_block)
+    if args.lane_tier >= 0:
+        for q_ in qps:
+            q_.set_option("lane_tier", args.lane_tier)
     if args.ablate:
         for q_ in qps:
             q_.set_option("ablate", args.ablate)
@@ -230,8 +235,21 @@ def main():
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
     if final_gather:
-        xfin = torch.empty((world * n_local, nout), dtype=tdt, device=dev)
-        ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev)
+        # gather to rank 0: every rank sends its shard straight to the root over its own xGMI link
+        # (ncclSend/ncclRecv pairs), N-1 links in parallel -- a ring all-gather would move N-1 shards
+        # through every link and nobody but the root reads them
+        xfin = torch.empty((world * n_local, nout), dtype=tdt, device=dev) if rank == 0 else None
+        ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev) if rank == 0 else None
+
+    gather_impl = {"mode": "gather"}
+
+    def gather_to_root(xs, fs):
+        if gather_impl["mode"] == "gather":
+            dist.gather(xs, list(xfin.split(n_local)) if rank == 0 else None, dst=0)
+            dist.gather(fs, list(ffin.split(n_local)) if rank == 0 else None, dst=0)
+        else:                                    # fallback chosen during warm-up, see below
+            dist.all_gather_into_tensor(xfin, xs)
+            dist.all_gather_into_tensor(ffin, fs)
     if do_gather:
         xall = [torch.empty((world * n_local, nout), dtype=tdt, device=dev) for _ in range(nbuf)]
         fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
@@ -274,8 +292,18 @@ def main():
     if final_gather:
         # untimed: the first all-gather of this shape sets up RCCL's channels and buffers
         torch.cuda.synchronize(dev)
-        dist.all_gather_into_tensor(xfin, xbuf[0])
-        dist.all_gather_into_tensor(ffin, fbuf[0])
+        try:
+            gather_to_root(xbuf[0], fbuf[0])
+            torch.cuda.synchronize(dev)
+            ok = torch.ones(1, device=dev)
+        except RuntimeError:                     # a backend without gather: every rank takes all shards instead
+            ok = torch.zeros(1, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            gather_impl["mode"] = "all_gather"
+            xfin = torch.empty((world * n_local, nout), dtype=tdt, device=dev)
+            ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev)
+            gather_to_root(xbuf[0], fbuf[0])
     fence()
     # Device time over the timed region: ONE pair of HIP events per launch stream brackets all of
     # that stream's launches (events between every two kernels cost ~12 % throughput: each is an extra
@@ -299,8 +327,7 @@ def main():
         # the one exchange step of the sharded job: every rank receives all shards' solutions
         torch.cuda.synchronize(dev)
         lastb = (args.steps - 1) % nbuf
-        dist.all_gather_into_tensor(xfin, xbuf[lastb])
-        dist.all_gather_into_tensor(ffin, fbuf[lastb])
+        gather_to_root(xbuf[lastb], fbuf[lastb])
     fence()
     elapsed = time.perf_counter() - t0
     prof = [q_.profile_read() for q_ in qps] if per_call_events else []
@@ -387,7 +414,7 @@ def main():
                        + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
                        "batch_per_gpu": n_local, "kernel": "wave" if args.f32 else qp.kernel_name, "batches_in_flight": nstreams,
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
-                                  else "all_gather(x, exitflag) over RCCL once, after the last step" if final_gather
+                                  else (gather_impl["mode"] + "(x, exitflag) to rank 0 over RCCL once, after the last step") if final_gather
                                   else "none"),
                        "solved_fraction": float((flags >= 1).mean()) if flags.size else None,
                        "iterations_hist": it_hist, "mean_iterations": mean_it,

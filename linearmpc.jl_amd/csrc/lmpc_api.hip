@@ -205,7 +205,7 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
         grid = per * (unsigned)kShards;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag, iters, active,
-                       warm, list, count, count_next, segCap, kShards, (long long)nprob);
+                       warm, list, count, count_next, segCap, kShards, (long long)nprob, h->laneTier);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -867,6 +867,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         return LMPC_OK;
     }
     if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
+    if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");

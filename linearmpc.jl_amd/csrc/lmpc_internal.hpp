@@ -55,6 +55,7 @@ struct lmpc_handle {
     int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
+    int laneTier = 1;           // tuning: first-tier capacity in the boxed lane kernels (results identical either way)
     int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     lmpc::WaveLayout W{};
     double *dCw = nullptr;

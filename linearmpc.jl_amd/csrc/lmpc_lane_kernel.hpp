@@ -37,8 +37,50 @@ __host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
 // strict lower triangle, row i > col t
 __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
-// Whole dual active-set solve of problem `pid` on this lane (no barriers inside).
-// sM/sG/sdu/sdl: LDS copies of the constant pack; sB: this block's b[j][lane] columns.
+// Solver state of one lane for a working-set capacity of MA rows.
+template <int N, int MA> struct LaneState {
+    static constexpr int NSL = MA * (MA - 1) / 2;
+    double SL[NSL > 0 ? NSL : 1];
+    double D[MA], Dinv[MA], lam[MA], ls[MA], rhs[MA], u[N];
+    int WS[MA];
+    unsigned long long act, low;
+    int na, sing, iter, cyc, flag;
+    double best, fval;
+    bool done;
+
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < NSL; i++) SL[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MA; i++) { D[i] = 0.0; Dinv[i] = 0.0; lam[i] = 0.0; ls[i] = 0.0; rhs[i] = 0.0; WS[i] = 0; }
+#pragma unroll
+        for (int k = 0; k < N; k++) u[k] = 0.0;
+        act = 0ull; low = 0ull;
+        na = 0; sing = -1; iter = 1; cyc = 0; flag = EXIT_ITERLIMIT;
+        best = -1.0; fval = 0.0;
+        done = false;
+    }
+    // continue a solve that outgrew the capacity MB < MA: same values, the extra positions at exact zeros
+    template <int MB> __device__ __forceinline__ void extend_from(const LaneState<N, MB> &o) {
+        static_assert(MB <= MA, "capacity");
+        init();
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            D[i] = o.D[i]; Dinv[i] = o.Dinv[i]; lam[i] = o.lam[i]; ls[i] = o.ls[i]; rhs[i] = o.rhs[i]; WS[i] = o.WS[i];
+#pragma unroll
+            for (int t = 0; t < i; t++) SL[lmpc_sl(i, t)] = o.SL[lmpc_sl(i, t)];
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) u[k] = o.u[k];
+        act = o.act; low = o.low;
+        na = o.na; sing = o.sing; iter = o.iter; cyc = o.cyc; flag = o.flag;
+        best = o.best; fval = o.fval;
+        done = o.done;
+    }
+};
+
+// The dual active-set iterations of problem `pid` on this lane (no barriers inside), on the state `s`.
+// sM/sG/sdu/sdl: LDS copies of the constant pack; sB: this block's b[j][lane] columns (filled by the caller).
 // MS > 0: the number of constraints is the compile-time constant MS (the common box-constrained
 // MPC, m == n): the scans over rows are fully unrolled, so all their scalar loads are issued in one
 // batch instead of one round trip per row.  MS == 0: m is a run-time value.
@@ -46,63 +88,28 @@ __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2
 // singular working set).  A problem whose constraints are all simple bounds (ms == m == n) can
 // never hold more than n rows -- one per variable -- and those rows (rows of R^-1) are independent,
 // so MA = N is enough there: one position less in every unrolled loop and ~22 VGPRs less.
-template <int N, int MS, int MA>
-__device__ __forceinline__ void lane_solve(
+// TIER: MA is a FIRST-TIER capacity below the full one (cold starts only): every unrolled loop over
+// working-set positions is that much shorter; when the working set wants to outgrow it the function
+// returns true BEFORE touching the state, and the caller continues the same solve in place on a
+// full-capacity state (extend_from) -- the interrupted iteration is recomputed there from identical
+// values, so the result does not change by a bit.  Most problems of an MPC batch end with a handful
+// of active rows, far below n.
+template <int N, int MS, int MA, bool TIER>
+__device__ __forceinline__ bool lane_loop(
     const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
     const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
-    const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
-    int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm) {
-    static_assert(MA == N + 1 || MA == N, "capacity");
-    constexpr int NSL = MA * (MA - 1) / 2;
-    const int m = MS > 0 ? MS : P.m, nth = P.nth;
-    const bool one_out = P.nout == 1;
-    double sh0 = one_out ? C[P.ox0] : 0.0;      // x0 + Xth theta of the first output, built on the fly
-    const double *th = theta + pid * nth;
-
-    // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
-    // (loads issued back to back), the running sums live in this lane's LDS column; per row the
-    // products are still added in ascending t, as the oracle does
-    for (int t0 = 0; t0 < nth; t0 += 4) {
-        double tv[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) tv[q] = (t0 + q < nth) ? th[t0 + q] : 0.0;
-        auto brow = [&](int j) {
-            double acc = t0 ? sB[j * B + tid] : 0.0;
-            const double *dj = C + P.oDth + j * nth + t0;
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (t0 + q < nth) acc = __builtin_fma(dj[q], tv[q], acc);
-            sB[j * B + tid] = acc;
-        };
-        if constexpr (MS > 0) {
-#pragma unroll
-            for (int j = 0; j < MS; j++) brow(j);
-        } else {
-            for (int j = 0; j < m; j++) brow(j);
-        }
-        if (one_out) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (t0 + q < nth) sh0 = __builtin_fma(C[P.oXth + t0 + q], tv[q], sh0);
-        }
-    }
-    if (nth == 0)
-        for (int j = 0; j < m; j++) sB[j * B + tid] = 0.0;
-
-    double SL[NSL > 0 ? NSL : 1];
-    double D[MA], Dinv[MA], lam[MA], ls[MA], rhs[MA], u[N];
-    int WS[MA];
-#pragma unroll
-    for (int i = 0; i < NSL; i++) SL[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < MA; i++) { D[i] = 0.0; Dinv[i] = 0.0; lam[i] = 0.0; ls[i] = 0.0; rhs[i] = 0.0; WS[i] = 0; }
-#pragma unroll
-    for (int k = 0; k < N; k++) u[k] = 0.0;
-    unsigned long long act = 0ull, low = 0ull;
-    int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT;
-    double best = -1.0, fval = 0.0;
-    bool done = false;
-
+    const uint64_t *__restrict__ warm, LaneState<N, MA> &s) {
+    static_assert(TIER || MA == N + 1 || MA == N, "capacity");
+    const int m = MS > 0 ? MS : P.m;
+    constexpr int NSLA = (MA * (MA - 1) / 2 > 0) ? MA * (MA - 1) / 2 : 1;
+    double (&SL)[NSLA] = s.SL;
+    double (&D)[MA] = s.D, (&Dinv)[MA] = s.Dinv, (&lam)[MA] = s.lam, (&ls)[MA] = s.ls, (&rhs)[MA] = s.rhs;
+    double (&u)[N] = s.u;
+    int (&WS)[MA] = s.WS;
+    unsigned long long &act = s.act, &low = s.low;
+    int &na = s.na, &sing = s.sing, &iter = s.iter, &cyc = s.cyc, &flag = s.flag;
+    double &best = s.best, &fval = s.fval;
+    bool &done = s.done;
     // ---- append constraint j (at its lower bound if `lower`) to the working set
     auto ldl_add = [&](int j, bool lower) {
         double row[MA > 1 ? MA - 1 : 1];
@@ -212,7 +219,7 @@ __device__ __forceinline__ void lane_solve(
     };
 
     // ---- initial working set: equality rows, then the caller's warm-start mask
-    if (P.eq_mask != 0ull || warm != nullptr) {
+    if (!TIER && (P.eq_mask != 0ull || warm != nullptr)) {
         unsigned long long wup = 0ull, wlo = 0ull;
         if (warm != nullptr) {
             const uint64_t *wp = warm + pid * P.words;
@@ -333,7 +340,8 @@ __device__ __forceinline__ void lane_solve(
                     for (int j = 0; j < m; j++) scan_row(j);
                 }
                 if (add < 0) { flag = broken ? EXIT_CYCLE : EXIT_OPTIMAL; break; }
-                if (MA < N + 1 && na >= MA) { flag = EXIT_CYCLE; break; }   // cannot happen for pure bounds
+                if (TIER && na >= MA) return true;      // outgrown the first tier: nothing has been touched yet
+                if (!TIER && MA < N + 1 && na >= MA) { flag = EXIT_CYCLE; break; }   // cannot happen for pure bounds
 #pragma unroll
                 for (int i = 0; i < MA; i++) lam[i] = ls[i];
                 ldl_add(add, addlow);
@@ -396,6 +404,75 @@ __device__ __forceinline__ void lane_solve(
         iter++;
     }
 
+    return false;
+}
+
+// first-tier capacity of an instantiation (0 = none): the boxed variants from n = 4 on
+template <int N, int MS, int MA> struct lane_tier { static constexpr int value = (MS > 0 && N >= 4) ? 3 : 0; };
+
+// Whole solve of problem `pid` on this lane: b = Dth theta into LDS, the iterations, the outputs.
+template <int N, int MS, int MA>
+__device__ __forceinline__ void lane_solve(
+    const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
+    const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
+    const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
+    int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, const bool tier) {
+    static_assert(MA == N + 1 || MA == N, "capacity");
+    const int m = MS > 0 ? MS : P.m, nth = P.nth;
+    const bool one_out = P.nout == 1;
+    double sh0 = one_out ? C[P.ox0] : 0.0;      // x0 + Xth theta of the first output, built on the fly
+    const double *th = theta + pid * nth;
+
+    // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
+    // (loads issued back to back), the running sums live in this lane's LDS column; per row the
+    // products are still added in ascending t, as the oracle does
+    for (int t0 = 0; t0 < nth; t0 += 4) {
+        double tv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) tv[q] = (t0 + q < nth) ? th[t0 + q] : 0.0;
+        auto brow = [&](int j) {
+            double acc = t0 ? sB[j * B + tid] : 0.0;
+            const double *dj = C + P.oDth + j * nth + t0;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t0 + q < nth) acc = __builtin_fma(dj[q], tv[q], acc);
+            sB[j * B + tid] = acc;
+        };
+        if constexpr (MS > 0) {
+#pragma unroll
+            for (int j = 0; j < MS; j++) brow(j);
+        } else {
+            for (int j = 0; j < m; j++) brow(j);
+        }
+        if (one_out) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t0 + q < nth) sh0 = __builtin_fma(C[P.oXth + t0 + q], tv[q], sh0);
+        }
+    }
+    if (nth == 0)
+        for (int j = 0; j < m; j++) sB[j * B + tid] = 0.0;
+
+    LaneState<N, MA> s;
+    constexpr int MT = lane_tier<N, MS, MA>::value;
+    bool full = true;
+    if constexpr (MT > 0) {
+        if (tier && warm == nullptr && P.eq_mask == 0ull) {
+            LaneState<N, MT> s1;
+            s1.init();
+            full = lane_loop<N, MS, MT, true>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, nullptr, s1);
+            s.extend_from(s1);
+        } else {
+            s.init();
+        }
+    } else {
+        s.init();
+    }
+    if (full) lane_loop<N, MS, MA, false>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, warm, s);
+    double (&u)[N] = s.u;
+    const int flag = s.flag, iter = s.iter;
+    const unsigned long long act = s.act, low = s.low;
+
     // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22)
     if (one_out) {
         double xs = 0.0;
@@ -429,7 +506,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
-    long long seg_cap, int nshards, long long nprob) {
+    long long seg_cap, int nshards, long long nprob, int tier) {
     extern __shared__ __align__(16) double lds[];
 
     const int m = P.m, B = blockDim.x, tid = threadIdx.x;
@@ -459,7 +536,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const long long idx = base + tid;
     if (idx >= cnt) continue;
     const long long pid = list ? (long long)list[idx] : idx;
-    lane_solve<N, MS, MA>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm);
+    lane_solve<N, MS, MA>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
   }   // chunk loop
 }
 

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void screen_kernel(
         const double *src = theta + pid * nth;
         const bool ok = pid < nprob;
 #pragma unroll
-        for (int t = 0; t < NTHMAX; t++) dst[t] = (ok && t < nth) ? src[t] : 0.0;
+        for (int t = 0; t < NTHMAX; t++)
+            dst[t] = (ok && t < nth) ? ((ablate & 8) ? src[t] : __builtin_nontemporal_load(src + t)) : 0.0;
     };
     load_record(first, nx);
 
@@ -116,15 +117,22 @@ __global__ __launch_bounds__(256) void screen_kernel(
         }
         pmask = mask; pbase = basei; ppid = pid; phard = hard;
 
-        if (valid && !hard && !(ablate & 4)) {
+        // Outputs are written for EVERY valid problem, queued ones included (the iterating kernel runs
+        // behind this one on the same stream and overwrites theirs): the stores of a wavefront then
+        // cover whole lines instead of lines with holes; they bypass the caches (written once, read by
+        // nobody on this GPU soon)
+        const bool fill = (ablate & 16) ? (valid && !hard) : valid;
+        if (fill && !(ablate & 4)) {
             const double *xk = C + P.oXthP;
             for (int k = 0; k < P.nout; k++, xk += NTHMAX) {
                 double sh = C[P.ox0 + k];
 #pragma unroll
                 for (int t = 0; t < NTHMAX; t++) sh = __builtin_fma(xk[t], th[t], sh);
-                X[pid * P.nout + k] = 0.0 + sh;
+                if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
+                else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
             }
-            exitflag[pid] = EXIT_OPTIMAL;
+            if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
+            else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
             if (iters) iters[pid] = 1;
             if (active)
                 for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;

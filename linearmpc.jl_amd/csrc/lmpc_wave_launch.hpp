@@ -34,7 +34,7 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     // 8 beyond
     const int maxNwv = h->P.m > 256 ? 4 : (big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8));
     int maxWaves = LMPC_WAVE_LB >= 1024 ? 16 : 12;
-    if (h->P.m > 256) maxWaves = 4;
+    if (h->P.m > 256) maxWaves = (h->P.m <= 512 && !h->bnb) ? 8 : 4;   // 8 / 16 slots: 2 / 1 wavefronts per SIMD
     else if (h->P.m > 128) maxWaves = 8;
     else if (h->bnb) maxWaves = (rs == 4 && h->P.m <= 64) ? 16 : 12;
     WaveConfig best{1, 0, 1, perWave, packed};
