@@ -115,11 +115,9 @@ __device__ __forceinline__ bool lane_loop(
         double row[MA > 1 ? MA - 1 : 1];
 #pragma unroll
         for (int t = 0; t < MA - 1; t++) {
-            row[t] = 0.0;
-            if (t < na) {
-                const int a = WS[t];
-                row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
-            }
+            const int a = WS[t];                                 // 0 beyond |W|: a valid entry, dropped by the select
+            const double g = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
+            row[t] = (t < na) ? g : 0.0;
         }
         double dnew = sG[lmpc_tri(j) + j];
 #pragma unroll
@@ -296,14 +294,15 @@ __device__ __forceinline__ bool lane_loop(
                 // primal iterate u = -M_W' lam*, then the most violated inactive constraint
 #pragma unroll
                 for (int k = 0; k < N; k++) u[k] = 0.0;
+                // every position, no branch: beyond |W| the row index is 0 (a valid row) and the
+                // multiplier an exact zero, so the term adds nothing -- and the LDS reads of all
+                // positions are in flight together
 #pragma unroll
                 for (int i = 0; i < MA; i++) {
-                    if (i < na) {
-                        const double *mi = sM + WS[i] * N;
-                        const double l = ls[i];
+                    const double *mi = sM + WS[i] * N;
+                    const double l = (i < na) ? ls[i] : 0.0;
 #pragma unroll
-                        for (int k = 0; k < N; k++) u[k] = __builtin_fma(-mi[k], l, u[k]);
-                    }
+                    for (int k = 0; k < N; k++) u[k] = __builtin_fma(-mi[k], l, u[k]);
                 }
                 fval = 0.0;
 #pragma unroll
@@ -313,7 +312,8 @@ __device__ __forceinline__ bool lane_loop(
                 int add = -1;
                 bool addlow = false, broken = false;
                 auto scan_row = [&](int j) {
-                    if (!((P.imm_mask >> j) & 1ull)) {
+                    {
+                        const bool imm = (P.imm_mask >> j) & 1ull;     // an IMMUTABLE row is never a candidate
                         double Mu = 0.0;
                         // unrolled scan (MS > 0): rows and bounds as LDS broadcast reads (uniform address,
                         // in-order return, +2.5 % on the headline batch over scalar loads, whose SGPR
@@ -325,7 +325,8 @@ __device__ __forceinline__ bool lane_loop(
                         const double duj = MS > 0 ? sdu[j] : C[P.odu + j], dlj = MS > 0 ? sdl[j] : C[P.odl + j];
                         const double vu = (duj + b) - Mu;
                         const double vl = -((dlj + b) - Mu);
-                        if (!((act >> j) & 1ull)) {
+                        if (imm) {
+                        } else if (!((act >> j) & 1ull)) {
                             if (vu < min_val) { add = j; addlow = false; min_val = vu; }
                             else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
                         } else if (vu < -P.primal_tol || vl < -P.primal_tol) {
@@ -425,7 +426,37 @@ __device__ __forceinline__ void lane_solve(
 
     // b_j = Dth_j . theta   (mpc_update_qp.c:5-6): theta is pulled in four values at a time
     // (loads issued back to back), the running sums live in this lane's LDS column; per row the
-    // products are still added in ascending t, as the oracle does
+    // products are still added in ascending t, as the oracle does.
+    // nth <= 32: the rows come from the zero-padded copies the screening kernel uses (DthP, XthP: rows of
+    // nthp columns, a multiple of four) -- no guard on any term, so the scalar loads of a chunk are
+    // issued together instead of one exposed round trip per fma; theta's index is clamped into the
+    // record and meets a zero coefficient there (the padded terms add +0 exactly)
+    if (nth <= 32 && nth > 0) {
+        const int nthp = P.nthp;
+        for (int t0 = 0; t0 < nthp; t0 += 4) {
+            double tv[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) tv[q] = th[t0 + q < nth ? t0 + q : nth - 1];
+            auto brow = [&](int j) {
+                double acc = t0 ? sB[j * B + tid] : 0.0;
+                const double *dj = C + P.oDthP + j * nthp + t0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc = __builtin_fma(dj[q], tv[q], acc);
+                sB[j * B + tid] = acc;
+            };
+            if constexpr (MS > 0) {
+#pragma unroll
+                for (int j = 0; j < MS; j++) brow(j);
+            } else {
+                for (int j = 0; j < m; j++) brow(j);
+            }
+            if (one_out) {
+                const double *xk = C + P.oXthP + t0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) sh0 = __builtin_fma(xk[q], tv[q], sh0);
+            }
+        }
+    } else {
     for (int t0 = 0; t0 < nth; t0 += 4) {
         double tv[4];
 #pragma unroll
@@ -449,6 +480,7 @@ __device__ __forceinline__ void lane_solve(
             for (int q = 0; q < 4; q++)
                 if (t0 + q < nth) sh0 = __builtin_fma(C[P.oXth + t0 + q], tv[q], sh0);
         }
+    }
     }
     if (nth == 0)
         for (int j = 0; j < m; j++) sB[j * B + tid] = 0.0;
@@ -519,25 +551,34 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const int shard = list ? (int)(blockIdx.x % nshards) : 0;
     const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
     const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;
-    const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
-    if (first >= cnt) return;
+    // Everything the first problem needs that does not depend on anything else is requested in ONE
+    // round trip: the segment's count, this lane's first list entry (speculatively -- the segment is
+    // allocated up to seg_cap, an entry at or beyond the count is simply not used) and the constants
+    // for the LDS copy.  (Count -> constants -> list one after the other was three exposed trips.)
     if (list) list += (long long)shard * seg_cap;
+    int32_t pid0 = 0;
+    if (list) {
+        const long long i0 = first + tid;
+        pid0 = list[i0 < seg_cap ? i0 : seg_cap - 1];
+    }
+    const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
     double *sM = lds;                    // m x N   rows by per-lane constraint index
     double *sG = sM + m * N;             // packed lower triangle of M M'
     double *sdu = sG + lmpc_tri(m);      // du0
     double *sdl = sdu + m;               // dl0
     double *sB = sdl + m;                // b[j][lane]
-    for (int i = tid; i < m * N; i += B) sM[i] = C[P.oM + i];
-    for (int i = tid; i < lmpc_tri(m); i += B) sG[i] = C[P.oG + i];
-    for (int i = tid; i < m; i += B) { sdu[i] = C[P.odu + i]; sdl[i] = C[P.odl + i]; }
+    // M, G, du0, dl0 follow each other in the pack in the order of the LDS copy: one loop
+    const int nconst = m * N + lmpc_tri(m) + 2 * m;
+    for (int i = tid; i < nconst; i += B) lds[i] = C[P.oM + i];
+    if (first >= cnt) return;
     __syncthreads();
 
   for (long long base = first; base < cnt; base += stride) {
     const long long idx = base + tid;
     if (idx >= cnt) continue;
-    const long long pid = list ? (long long)list[idx] : idx;
+    const long long pid = list ? (base == first ? (long long)pid0 : (long long)list[idx]) : idx;
     lane_solve<N, MS, MA>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
-  }   // chunk loop
+}   // chunk loop
 }
 
 }  // namespace lmpc
