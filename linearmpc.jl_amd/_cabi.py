@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "liblmpc_hip.so")
+# LMPC_HIP_LIB: another build of the same library (A/B of compiler flags); default = the in-tree build
+LIB_PATH = os.environ.get("LMPC_HIP_LIB") or os.path.join(_PKG, "lib", "liblmpc_hip.so")
 
 LMPC_OK = 1
 ERR_NAMES = {-1: "INFEASIBLE", -5: "NONCONVEX", -6: "OVERDETERMINED", -100: "BADARG",

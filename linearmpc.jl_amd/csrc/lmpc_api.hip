@@ -577,17 +577,22 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
     const unsigned grid = (unsigned)((N + 255) / 256);
+    // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
+    // (the plant step writes x+ and u back into it), so a step is the solve plus one streaming kernel
+    hipLaunchKernelGGL(form_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
+                       nuprev, (long long)N);
     for (int k = 0; k < T; k++) {
-        hipLaunchKernelGGL(form_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
-                           nuprev, (long long)N);
         // warm start = previous step's final working set (reference codegen DAQP_WARMSTART,
         // codegen/mpc_update_qp.c:44-47); the first step is always cold
         const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
         int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
         if (rc != LMPC_OK) return rc;
-        hipLaunchKernelGGL(plant_kernel, dim3(grid), dim3(256), 0, st, x, uprev, h->simU, h->simFlag, h->simFG, nx,
-                           nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
-                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0, (long long)N);
+        const bool last = k == T - 1;
+        hipLaunchKernelGGL(plant_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, h->P.nth, nr, h->simU,
+                           h->simFlag, h->simFG, nx, nu, nuprev,
+                           X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0,
+                           last ? x : nullptr, (last && nuprev > 0) ? uprev : nullptr, (long long)N);
         HIP_TRY(h, hipGetLastError());
     }
     return LMPC_OK;

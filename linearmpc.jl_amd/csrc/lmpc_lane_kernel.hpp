@@ -115,9 +115,12 @@ __device__ __forceinline__ bool lane_loop(
         double row[MA > 1 ? MA - 1 : 1];
 #pragma unroll
         for (int t = 0; t < MA - 1; t++) {
-            const int a = WS[t];                                 // 0 beyond |W|: a valid entry, dropped by the select
-            const double g = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
-            row[t] = (t < na) ? g : 0.0;
+            row[t] = 0.0;
+            if (MA <= 6 || t < na) {                             // small capacities: every position, no branch
+                const int a = WS[t];                             // 0 beyond |W|: a valid entry, dropped by the select
+                const double g = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
+                row[t] = (t < na) ? g : 0.0;
+            }
         }
         double dnew = sG[lmpc_tri(j) + j];
 #pragma unroll
@@ -297,12 +300,15 @@ __device__ __forceinline__ bool lane_loop(
                 // every position, no branch: beyond |W| the row index is 0 (a valid row) and the
                 // multiplier an exact zero, so the term adds nothing -- and the LDS reads of all
                 // positions are in flight together
+                // (small capacities only: with many positions skipping the empty ones wins)
 #pragma unroll
                 for (int i = 0; i < MA; i++) {
-                    const double *mi = sM + WS[i] * N;
-                    const double l = (i < na) ? ls[i] : 0.0;
+                    if (MA <= 6 || i < na) {
+                        const double *mi = sM + WS[i] * N;
+                        const double l = (i < na) ? ls[i] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < N; k++) u[k] = __builtin_fma(-mi[k], l, u[k]);
+                        for (int k = 0; k < N; k++) u[k] = __builtin_fma(-mi[k], l, u[k]);
+                    }
                 }
                 fval = 0.0;
 #pragma unroll
@@ -312,8 +318,10 @@ __device__ __forceinline__ bool lane_loop(
                 int add = -1;
                 bool addlow = false, broken = false;
                 auto scan_row = [&](int j) {
-                    {
-                        const bool imm = (P.imm_mask >> j) & 1ull;     // an IMMUTABLE row is never a candidate
+                    // an IMMUTABLE row is never a candidate: unrolled scan -- folded into the selects, so the
+                    // rows' LDS reads stay in one block; run-time row loop -- a uniform branch around the row
+                    const bool imm = (P.imm_mask >> j) & 1ull;
+                    if ((MS > 0 && MA <= 6) || !imm) {
                         double Mu = 0.0;
                         // unrolled scan (MS > 0): rows and bounds as LDS broadcast reads (uniform address,
                         // in-order return, +2.5 % on the headline batch over scalar loads, whose SGPR
@@ -431,7 +439,7 @@ __device__ __forceinline__ void lane_solve(
     // nthp columns, a multiple of four) -- no guard on any term, so the scalar loads of a chunk are
     // issued together instead of one exposed round trip per fma; theta's index is clamped into the
     // record and meets a zero coefficient there (the padded terms add +0 exactly)
-    if (nth <= 32 && nth > 0) {
+    if (MA <= 6 && nth <= 32 && nth > 0) {     // (the register-bound large instantiations keep the guarded form)
         const int nthp = P.nthp;
         for (int t0 = 0; t0 < nthp; t0 += 4) {
             double tv[4];
@@ -551,32 +559,35 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const int shard = list ? (int)(blockIdx.x % nshards) : 0;
     const long long first = (list ? (long long)(blockIdx.x / nshards) : (long long)blockIdx.x) * B;
     const long long stride = (list ? (long long)(gridDim.x / nshards) : (long long)gridDim.x) * B;
-    // Everything the first problem needs that does not depend on anything else is requested in ONE
-    // round trip: the segment's count, this lane's first list entry (speculatively -- the segment is
-    // allocated up to seg_cap, an entry at or beyond the count is simply not used) and the constants
-    // for the LDS copy.  (Count -> constants -> list one after the other was three exposed trips.)
+    // Small instantiations: everything the first problem needs that does not depend on anything else
+    // is requested in ONE round trip -- the segment's count, this lane's first list entry
+    // (speculatively: the segment is allocated up to seg_cap, an entry at or beyond the count is simply
+    // not used) and the constants for the LDS copy (M, G, du0, dl0 follow each other in the pack in the
+    // order of the LDS copy: one loop).  The register-bound instantiations (one wavefront per SIMD)
+    // keep the plain order: one more live register costs them more than the two round trips.
+    constexpr bool kEarly = MA <= 6;
     if (list) list += (long long)shard * seg_cap;
     int32_t pid0 = 0;
-    if (list) {
+    if (kEarly && list) {
         const long long i0 = first + tid;
         pid0 = list[i0 < seg_cap ? i0 : seg_cap - 1];
     }
     const long long cnt = list ? (long long)count[shard * kCountStride] : nprob;
+    if (!kEarly && first >= cnt) return;
     double *sM = lds;                    // m x N   rows by per-lane constraint index
     double *sG = sM + m * N;             // packed lower triangle of M M'
     double *sdu = sG + lmpc_tri(m);      // du0
     double *sdl = sdu + m;               // dl0
     double *sB = sdl + m;                // b[j][lane]
-    // M, G, du0, dl0 follow each other in the pack in the order of the LDS copy: one loop
     const int nconst = m * N + lmpc_tri(m) + 2 * m;
     for (int i = tid; i < nconst; i += B) lds[i] = C[P.oM + i];
-    if (first >= cnt) return;
+    if (kEarly && first >= cnt) return;
     __syncthreads();
 
   for (long long base = first; base < cnt; base += stride) {
     const long long idx = base + tid;
     if (idx >= cnt) continue;
-    const long long pid = list ? (base == first ? (long long)pid0 : (long long)list[idx]) : idx;
+    const long long pid = list ? ((kEarly && base == first) ? (long long)pid0 : (long long)list[idx]) : idx;
     lane_solve<N, MS, MA>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
 }   // chunk loop
 }

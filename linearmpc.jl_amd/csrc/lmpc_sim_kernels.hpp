@@ -124,4 +124,46 @@ __global__ __launch_bounds__(256) void plant_kernel(
     }
 }
 
+// The same plant step with the scenario's state kept INSIDE its theta record (theta = [x; r; uprev]):
+// x <- F x + G u is written back into theta[0:nx], u into theta[nx+nr : nx+nr+nup], so the next
+// step's solve reads the record as it stands and no theta has to be formed again (the closed loop
+// with a constant reference then moves 2 x 8 nth + 8 nu bytes per scenario and step instead of
+// re-reading x and re-writing the whole record in a separate kernel).  Same sums in the same order
+// as plant_kernel.  x_out / uprev_out (last step): the caller's arrays.
+__global__ __launch_bounds__(256) void plant_theta_kernel(
+    double *__restrict__ theta, int nth, int nr, const double *__restrict__ u,
+    const int32_t *__restrict__ flag, const double *__restrict__ FG, int nx, int nu, int nup,
+    double *__restrict__ xtraj_next, double *__restrict__ utraj, int32_t *__restrict__ flag_min,
+    int first, double *__restrict__ x_out, double *__restrict__ uprev_out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *F = FG, *G = FG + nx * nx;
+    double *t = theta + i * nth;
+    double xo[32], xn[32];
+    for (int c = 0; c < nx; c++) xo[c] = t[c];
+    for (int a = 0; a < nx; a++) {
+        double acc = 0.0;
+        for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], xo[c], acc);
+        for (int l = 0; l < nu; l++) acc = __builtin_fma(G[a * nu + l], u[i * nu + l], acc);
+        xn[a] = acc;
+    }
+    for (int a = 0; a < nx; a++) {
+        t[a] = xn[a];
+        if (xtraj_next) xtraj_next[i * nx + a] = xn[a];
+        if (x_out) x_out[i * nx + a] = xn[a];
+    }
+    for (int l = 0; l < nu; l++) {
+        const double ul = u[i * nu + l];
+        if (l < nup) {
+            t[nx + nr + l] = ul;
+            if (uprev_out) uprev_out[i * nup + l] = ul;
+        }
+        if (utraj) utraj[i * nu + l] = ul;
+    }
+    if (flag_min) {
+        const int32_t f = flag[i];
+        flag_min[i] = first ? f : (f < flag_min[i] ? f : flag_min[i]);
+    }
+}
+
 }  // namespace lmpc
