@@ -276,6 +276,33 @@ int lmpc_compute_control_device(lmpc_handle *h, int64_t N, double *control, cons
                                 const double *reference, const double *disturbance,
                                 const double *affine_parameter, int32_t *exitflag, int warm, void *stream);
 
+/*
+ * The reference's GENERATED state observer for N scenarios at once: mpc_predict_state(state, control,
+ * disturbance) and mpc_correct_state(state, measurement, disturbance) (codegen/mpc_observer.c:1-28,
+ * mpc_observer.h; Julia: predict! / correct! of the KalmanFilter, src/observer.jl:104-123), the other
+ * two functions the generated controller exports next to mpc_compute_control.
+ *
+ * lmpc_set_observer takes the arrays exactly as the generator writes them (src/observer.jl:124-140):
+ *   plant_dynamics        MPC_PLANT_DYNAMICS       n_state rows [f_offset_i, F_i(n_state), G_i(n_control), Gd_i(n_disturbance)]
+ *   measurement_function  MPC_MEASUREMENT_FUNCTION n_measurement rows [h_offset_j, C_j(n_state), Dd_j(n_disturbance)]
+ *   k_transpose           K_TRANSPOSE_OBSERVER     n_measurement rows of n_state (the Kalman gain, transposed)
+ * (HOST arrays, copied).  state: N records of n_state, updated in place; control / measurement /
+ * disturbance: N records of their widths; disturbance may be NULL (zeros), as in the reference's calls
+ * (runtests.jl:942-946).  *_device variants take DEVICE pointers and a stream and do not synchronise.
+ */
+typedef struct lmpc_observer {
+    int32_t n_state, n_control, n_disturbance, n_measurement;
+    const double *plant_dynamics, *measurement_function, *k_transpose;
+} lmpc_observer;
+int lmpc_set_observer(lmpc_handle *h, const lmpc_observer *obs);
+int lmpc_predict_state(lmpc_handle *h, int64_t N, double *state, const double *control, const double *disturbance);
+int lmpc_correct_state(lmpc_handle *h, int64_t N, double *state, const double *measurement,
+                       const double *disturbance);
+int lmpc_predict_state_device(lmpc_handle *h, int64_t N, double *state, const double *control,
+                              const double *disturbance, void *stream);
+int lmpc_correct_state_device(lmpc_handle *h, int64_t N, double *state, const double *measurement,
+                              const double *disturbance, void *stream);
+
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 

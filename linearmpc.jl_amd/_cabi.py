@@ -25,6 +25,8 @@ SYMBOLS = (
     "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
     "lmpc_simulate_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
     "lmpc_set_parameter_layout", "lmpc_compute_control", "lmpc_compute_control_device",
+    "lmpc_set_observer", "lmpc_predict_state", "lmpc_correct_state", "lmpc_predict_state_device",
+    "lmpc_correct_state_device",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
@@ -55,6 +57,13 @@ class ParamLayout(ctypes.Structure):
     _fields_ = [("n_state", ctypes.c_int32), ("n_reference", ctypes.c_int32), ("n_disturbance", ctypes.c_int32),
                 ("n_control_prev", ctypes.c_int32), ("n_affine_parameter", ctypes.c_int32),
                 ("n_preview_horizon", ctypes.c_int32), ("traj2setpoint", ctypes.c_void_p)]
+
+
+class Observer(ctypes.Structure):
+    """`lmpc_observer`: the generated observer's arrays (reference src/observer.jl:124-141)."""
+    _fields_ = [("n_state", ctypes.c_int32), ("n_control", ctypes.c_int32), ("n_disturbance", ctypes.c_int32),
+                ("n_measurement", ctypes.c_int32), ("plant_dynamics", ctypes.c_void_p),
+                ("measurement_function", ctypes.c_void_p), ("k_transpose", ctypes.c_void_p)]
 
 
 _lib = None
@@ -114,6 +123,14 @@ def lib():
     L.lmpc_compute_control.restype = i32
     L.lmpc_compute_control_device.argtypes = [vp, i64] + [vp] * 6 + [i32, vp]
     L.lmpc_compute_control_device.restype = i32
+    L.lmpc_set_observer.argtypes = [vp, ctypes.POINTER(Observer)]
+    L.lmpc_set_observer.restype = i32
+    for fn in (L.lmpc_predict_state, L.lmpc_correct_state):
+        fn.argtypes = [vp, i64, vp, vp, vp]
+        fn.restype = i32
+    for fn in (L.lmpc_predict_state_device, L.lmpc_correct_state_device):
+        fn.argtypes = [vp, i64, vp, vp, vp, vp]
+        fn.restype = i32
     L.lmpc_kernel_name.argtypes = [vp]
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]

@@ -783,6 +783,102 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     return LMPC_OK;
 }
 
+int lmpc_set_observer(lmpc_handle *h, const lmpc_observer *o) {
+    if (!h || !o) return LMPC_ERR_BADARG;
+    if (o->n_state <= 0 || o->n_state > 32 || o->n_control < 0 || o->n_disturbance < 0 || o->n_measurement <= 0 ||
+        !o->plant_dynamics || !o->measurement_function || !o->k_transpose)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_set_observer: sizes (1 <= n_state <= 32, n_measurement >= 1) or NULL array");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nd_ = (size_t)o->n_state * (1 + o->n_state + o->n_control + o->n_disturbance);
+    const size_t nm_ = (size_t)o->n_measurement * (1 + o->n_state + o->n_disturbance);
+    const size_t nk_ = (size_t)o->n_measurement * o->n_state;
+    hipFree(h->obsC);
+    h->obsC = nullptr;
+    HIP_TRY(h, hipMalloc(&h->obsC, sizeof(double) * (nd_ + nm_ + nk_)));
+    HIP_TRY(h, hipMemcpy(h->obsC, o->plant_dynamics, sizeof(double) * nd_, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->obsC + nd_, o->measurement_function, sizeof(double) * nm_, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->obsC + nd_ + nm_, o->k_transpose, sizeof(double) * nk_, hipMemcpyHostToDevice));
+    h->obsNx = o->n_state; h->obsNu = o->n_control; h->obsNd = o->n_disturbance; h->obsNy = o->n_measurement;
+    return LMPC_OK;
+}
+
+int lmpc_predict_state_device(lmpc_handle *h, int64_t N, double *state, const double *control,
+                              const double *disturbance, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (!h->obsC) return fail(h, LMPC_ERR_BADARG, "lmpc_predict_state: call lmpc_set_observer first");
+    if (N < 0 || (N > 0 && (!state || (h->obsNu > 0 && !control))))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_predict_state: NULL state/control or negative N");
+    if (N == 0) return LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(predict_state_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       state, control, disturbance, h->obsC, h->obsNx, h->obsNu, h->obsNd, (long long)N);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+int lmpc_correct_state_device(lmpc_handle *h, int64_t N, double *state, const double *measurement,
+                              const double *disturbance, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (!h->obsC) return fail(h, LMPC_ERR_BADARG, "lmpc_correct_state: call lmpc_set_observer first");
+    if (N < 0 || (N > 0 && (!state || !measurement)))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_correct_state: NULL state/measurement or negative N");
+    if (N == 0) return LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nd_ = (size_t)h->obsNx * (1 + h->obsNx + h->obsNu + h->obsNd);
+    const size_t nm_ = (size_t)h->obsNy * (1 + h->obsNx + h->obsNd);
+    hipLaunchKernelGGL(correct_state_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       state, measurement, disturbance, h->obsC + nd_, h->obsC + nd_ + nm_, h->obsNx, h->obsNy,
+                       h->obsNd, (long long)N);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+namespace {
+// host-pointer wrapper shared by predict / correct: state in/out, one input array, optional disturbance
+int observer_host(lmpc_handle *h, int64_t N, double *state, const double *in, int win, const double *dist, bool predict) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (!h->obsC) return fail(h, LMPC_ERR_BADARG, "lmpc observer: call lmpc_set_observer first");
+    if (N < 0 || (N > 0 && (!state || (win > 0 && !in)))) return fail(h, LMPC_ERR_BADARG, "lmpc observer: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    double *ds = nullptr, *di = nullptr, *dd = nullptr;
+    auto cleanup = [&]() { hipFree(ds); hipFree(di); hipFree(dd); };
+#define OB_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
+        return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    const size_t nx = (size_t)h->obsNx, nd = (size_t)h->obsNd;
+    OB_TRY(hipMalloc(&ds, sizeof(double) * N * nx));
+    OB_TRY(hipMemcpy(ds, state, sizeof(double) * N * nx, hipMemcpyHostToDevice));
+    if (win > 0) {
+        OB_TRY(hipMalloc(&di, sizeof(double) * N * win));
+        OB_TRY(hipMemcpy(di, in, sizeof(double) * N * win, hipMemcpyHostToDevice));
+    }
+    if (dist && nd > 0) {
+        OB_TRY(hipMalloc(&dd, sizeof(double) * N * nd));
+        OB_TRY(hipMemcpy(dd, dist, sizeof(double) * N * nd, hipMemcpyHostToDevice));
+    }
+    int rc = predict ? lmpc_predict_state_device(h, N, ds, di, dd, nullptr) : lmpc_correct_state_device(h, N, ds, di, dd, nullptr);
+    if (rc != LMPC_OK) { cleanup(); return rc; }
+    OB_TRY(hipMemcpy(state, ds, sizeof(double) * N * nx, hipMemcpyDeviceToHost));
+#undef OB_TRY
+    cleanup();
+    return LMPC_OK;
+}
+}  // namespace
+
+int lmpc_predict_state(lmpc_handle *h, int64_t N, double *state, const double *control, const double *disturbance) {
+    return observer_host(h, N, state, control, h ? h->obsNu : 0, disturbance, true);
+}
+
+int lmpc_correct_state(lmpc_handle *h, int64_t N, double *state, const double *measurement, const double *disturbance) {
+    return observer_host(h, N, state, measurement, h ? h->obsNy : 0, disturbance, false);
+}
+
 int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F, const double *G,
                   double *x, const double *r, double *uprev, double *U_traj, double *X_traj, int32_t *flag_min,
                   int warm) {
@@ -897,7 +993,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
-    hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag);
+    hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     delete h;
 }
 

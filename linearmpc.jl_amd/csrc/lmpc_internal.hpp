@@ -72,6 +72,9 @@ struct lmpc_handle {
     double *ccT2S = nullptr, *ccTheta = nullptr;
     uint64_t *ccAct = nullptr;
     int32_t *ccFlag = nullptr;
+    // generated observer (lmpc_set_observer): [MPC_PLANT_DYNAMICS | MPC_MEASUREMENT_FUNCTION | K_TRANSPOSE_OBSERVER]
+    double *obsC = nullptr;
+    int obsNx = 0, obsNu = 0, obsNd = 0, obsNy = 0;
     int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
     // profiling
     bool prof = false;

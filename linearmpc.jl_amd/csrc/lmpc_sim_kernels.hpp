@@ -166,4 +166,45 @@ __global__ __launch_bounds__(256) void plant_theta_kernel(
     }
 }
 
+// The reference's generated state observer for N scenarios (codegen/mpc_observer.c:1-28; arrays as
+// src/observer.jl:136-138 writes them): `dyn` = MPC_PLANT_DYNAMICS, one row [f_offset_i, F_i, G_i, Gd_i]
+// per state; `meas` = MPC_MEASUREMENT_FUNCTION, one row [h_offset_j, C_j, Dd_j] per measurement;
+// `kt` = K_TRANSPOSE_OBSERVER (ny x nx).  Sums in the C code's order with separate multiply and add
+// (the reference compiles it with gcc -O3 -msse3: no fused multiply-add).  One thread per scenario.
+__global__ __launch_bounds__(256) void predict_state_kernel(
+    double *__restrict__ state, const double *__restrict__ control, const double *__restrict__ disturbance,
+    const double *__restrict__ dyn, int nx, int nu, int nd, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xo[32];
+    for (int c = 0; c < nx; c++) xo[c] = state[i * nx + c];
+    int disp = 0;
+    for (int a = 0; a < nx; a++) {
+        double acc = dyn[disp++];
+        for (int c = 0; c < nx; c++) acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], xo[c]));
+        for (int l = 0; l < nu; l++) acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], control[i * nu + l]));
+        for (int q = 0; q < nd; q++)
+            acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], disturbance ? disturbance[i * nd + q] : 0.0));
+        state[i * nx + a] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void correct_state_kernel(
+    double *__restrict__ state, const double *__restrict__ measurement, const double *__restrict__ disturbance,
+    const double *__restrict__ meas, const double *__restrict__ kt, int nx, int ny, int nd, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xo[32], xn[32];
+    for (int c = 0; c < nx; c++) { xo[c] = state[i * nx + c]; xn[c] = xo[c]; }
+    int dc = 0, dk = 0;
+    for (int j = 0; j < ny; j++) {
+        double inno = __dsub_rn(measurement[i * ny + j], meas[dc++]);
+        for (int c = 0; c < nx; c++) inno = __dsub_rn(inno, __dmul_rn(meas[dc++], xo[c]));
+        for (int q = 0; q < nd; q++)
+            inno = __dsub_rn(inno, __dmul_rn(meas[dc++], disturbance ? disturbance[i * nd + q] : 0.0));
+        for (int c = 0; c < nx; c++) xn[c] = __dadd_rn(xn[c], __dmul_rn(kt[dk++], inno));
+    }
+    for (int c = 0; c < nx; c++) state[i * nx + c] = xn[c];
+}
+
 }  // namespace lmpc

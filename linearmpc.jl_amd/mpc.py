@@ -274,6 +274,19 @@ class GeneratedController:
                                         preview_horizon=mpc.Np if cond else 0,
                                         traj2setpoint=mpc.traj2setpoint if cond else None)
 
+    def set_observer(self, plant_dynamics, measurement_function, k_transpose, nx, nu, nd, ny):
+        """The observer part of the generated code (`codegen(mpc.state_observer, ...)`, codegen.jl:209-212):
+        the three arrays as src/observer.jl:139-141 writes them."""
+        self.model.set_observer(plant_dynamics, measurement_function, k_transpose, nx, nu, nd, ny)
+
+    def mpc_predict_state(self, state, control, disturbance=None):
+        """generated `mpc_predict_state(state, control, disturbance)` for N scenarios, state in place."""
+        return self.model.predict_state(state, control, disturbance)
+
+    def mpc_correct_state(self, state, measurement, disturbance=None):
+        """generated `mpc_correct_state(state, measurement, disturbance)` for N scenarios, state in place."""
+        return self.model.correct_state(state, measurement, disturbance)
+
     def mpc_compute_control(self, control, state, reference=None, disturbance=None, affine_parameter=None):
         """control: (N, nu) float64, in = previous control, out = u* (in place); returns exit flags (N,).
         reference: (N, nr) -- or (N, ny*Np), each an ny x Np trajectory column by column, when the

@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 
 from . import _cabi
-from ._cabi import Block, LmpcError, ParamLayout, Settings, check, lib
+from ._cabi import Block, LmpcError, Observer, ParamLayout, Settings, check, lib
 
 _vp = ctypes.c_void_p
 
@@ -355,6 +355,50 @@ class BatchedQP:
         check(lib().lmpc_compute_control_device(self._h, N, p(control), p(state), p(reference), p(disturbance),
                                                 p(affine_parameter), p(exitflag), int(bool(warm)), _vp(st)), self._h)
         return exitflag
+
+    # ------------------------------------------------------------------ generated state observer
+    def set_observer(self, plant_dynamics, measurement_function, k_transpose, nx, nu, nd, ny):
+        """`lmpc_set_observer`: MPC_PLANT_DYNAMICS, MPC_MEASUREMENT_FUNCTION, K_TRANSPOSE_OBSERVER as the
+        reference's code generator writes them (src/observer.jl:124-141)."""
+        dyn = _f64(np.asarray(plant_dynamics, float).reshape(-1))
+        mea = _f64(np.asarray(measurement_function, float).reshape(-1))
+        kt = _f64(np.asarray(k_transpose, float).reshape(-1))
+        assert dyn.size == nx * (1 + nx + nu + nd) and mea.size == ny * (1 + nx + nd) and kt.size == ny * nx
+        o = Observer(int(nx), int(nu), int(nd), int(ny), dyn.ctypes.data, mea.ctypes.data, kt.ctypes.data)
+        check(lib().lmpc_set_observer(self._h, ctypes.byref(o)), self._h)
+        self._obs = (int(nx), int(nu), int(nd), int(ny))
+
+    def _observer_call(self, fn_host, fn_dev, state, other, w_other, disturbance, stream):
+        if getattr(self, "_obs", None) is None:           # the library says so (LMPC_ERR_BADARG)
+            check(fn_host(self._h, 1, None, None, None), self._h)
+        nx, nu, nd, ny = self._obs
+        if isinstance(state, np.ndarray):
+            if not (state.dtype == np.float64 and state.flags.c_contiguous and state.flags.writeable):
+                raise TypeError("state must be a writeable C-contiguous float64 array (it is updated in place)")
+            N = state.size // nx
+            w_other = self._obs[w_other]                  # index into (nx, nu, nd, ny): control or measurement width
+            oth = _f64(np.asarray(other, float).reshape(N, w_other)) if w_other else None
+            dd = _f64(np.asarray(disturbance, float).reshape(N, nd)) if (disturbance is not None and nd) else None
+            check(fn_host(self._h, N, _ptr(state), _ptr(oth) if oth is not None else None,
+                          _ptr(dd) if dd is not None else None), self._h)
+            return state
+        import torch
+        N = int(state.shape[0])
+        st = torch.cuda.current_stream(state.device).cuda_stream if stream is None else stream
+        p = lambda t: _vp(t.data_ptr()) if t is not None else None
+        check(fn_dev(self._h, N, p(state), p(other), p(disturbance), _vp(st)), self._h)
+        return state
+
+    def predict_state(self, state, control, disturbance=None, stream=None):
+        """`lmpc_predict_state[_device]` = generated mpc_predict_state for N scenarios; `state` (N x nx,
+        numpy or CUDA tensor) is updated in place."""
+        return self._observer_call(lib().lmpc_predict_state, lib().lmpc_predict_state_device, state, control,
+                                   1, disturbance, stream)
+
+    def correct_state(self, state, measurement, disturbance=None, stream=None):
+        """`lmpc_correct_state[_device]` = generated mpc_correct_state for N scenarios, in place."""
+        return self._observer_call(lib().lmpc_correct_state, lib().lmpc_correct_state_device, state, measurement,
+                                   3, disturbance, stream)
 
     # ------------------------------------------------------------------ profiling
     def profile(self, enable=True):

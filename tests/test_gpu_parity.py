@@ -954,3 +954,121 @@ def test_generated_controller_reference_condensation(lmpc):
                                            torch.from_numpy(np.ascontiguousarray(g["reference"])).to(dev))
     torch.cuda.synchronize()
     assert np.array_equal(cd.cpu().numpy(), control) and np.array_equal(efd.cpu().numpy(), ef)
+
+
+def test_handles_are_independent_across_threads(lmpc):
+    # include/lmpc_hip.h: calls on ONE handle must not overlap, DIFFERENT handles are independent (the
+    # reference's DAQP workspace is one-per-MPC and not thread-safe either, types.jl:93-97,141): four
+    # host threads, each with its own handle (two different problems), hammer the host-pointer entry
+    # point at the same time; every answer must equal the single-threaded one
+    import threading
+    gp, gm = load_golden("pendulum"), load_golden("mass_spring")
+    jobs = [(gp, gp["theta"][:4000]), (gm, gm["theta"][:600]), (gp, gp["theta"][4000:8000]), (gm, gm["theta"][300:900])]
+    ref = []
+    for g, th in jobs:
+        ref.append(_qp_from_golden(lmpc, g, 1).solve(th))
+    out = [None] * len(jobs)
+    errs = []
+
+    def work(i):
+        try:
+            g, th = jobs[i]
+            qp = _qp_from_golden(lmpc, g, 1)
+            for _ in range(8):
+                out[i] = qp.solve(th)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for (x, ef, it, act), (xr, efr, itr, actr) in zip(out, ref):
+        assert np.array_equal(x, xr) and np.array_equal(ef, efr) and np.array_equal(it, itr) and np.array_equal(act, actr)
+
+
+def test_generated_observer_entry_points(lmpc):
+    # lmpc_predict_state / lmpc_correct_state == the generated mpc_predict_state / mpc_correct_state
+    # (codegen/mpc_observer.c) for N scenarios; the reference checks them against predict!/correct! to
+    # 1e-9 (runtests.jl:936-947, with a disturbance :977-987); here also against the C loops restated
+    # term by term (same order, no fused multiply-add: identical bits expected, 1e-12 asserted)
+    import torch
+    from oracle import observer as oobs
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    kd = oobs.kalman_filter([[1, 1], [0, 1.0]], [[0], [1.0]], [[1.0, 0], [0, 1.0]], Gd=[[0.5], [1.0]],
+                            Dd=[[0.1], [0.0]], f_offset=[0.1, -0.2], h_offset=[0.3, 0.0], Q=[1.0, 1], R=[1e-2, 1.0])
+    nx, nu, nd, ny = kd.dims
+    dyn, meas, kt = kd.codegen_arrays()
+    qp.set_observer(dyn, meas, kt, nx, nu, nd, ny)
+    rng = np.random.default_rng(8)
+    N = 1000
+    x0, u, y, d = rng.standard_normal((N, nx)), rng.standard_normal((N, nu)), rng.standard_normal((N, ny)), rng.standard_normal((N, nd))
+    xp = x0.copy()
+    qp.predict_state(xp, u, d)
+    ref = np.array([oobs.c_predict(dyn, x0[i], u[i], d[i], nx, nu, nd) for i in range(N)])
+    assert np.abs(xp - ref).max() <= 1e-12
+    assert np.abs(xp - np.array([kd.predict(x0[i], u[i], d[i]) for i in range(N)])).max() < 1e-9
+    xc = xp.copy()
+    qp.correct_state(xc, y, d)
+    ref = np.array([oobs.c_correct(meas, kt, xp[i], y[i], d[i], nx, ny, nd) for i in range(N)])
+    assert np.abs(xc - ref).max() <= 1e-12
+    assert np.abs(xc - np.array([kd.correct(xp[i], y[i], d[i]) for i in range(N)])).max() < 1e-9
+    # NULL disturbance = zeros (runtests.jl:942-946 passes C_NULL), device tensors in place
+    xd = torch.from_numpy(x0).cuda()
+    qp.predict_state(xd, torch.from_numpy(u).cuda(), None)
+    torch.cuda.synchronize()
+    ref0 = np.array([oobs.c_predict(dyn, x0[i], u[i], np.zeros(nd), nx, nu, nd) for i in range(N)])
+    assert np.abs(xd.cpu().numpy() - ref0).max() <= 1e-12
+    with pytest.raises(lmpc.LmpcError):
+        _qp_from_golden(lmpc, g, 1).predict_state(x0.copy(), u)        # no observer set
+
+
+def test_observer_closed_loop_as_in_the_reference(lmpc):
+    # /root/reference/test/runtests.jl:894-921 "Observer": invpend with Np = 100, move_block!([1,1,5,10,10]),
+    # Kalman filter Q = 1e2*[1e-3,1,1e-3,1], R = [1,0.1]; 2000 closed-loop steps with measurement and
+    # process noise: correct! -> compute_control(x_hat; r) -> predict! -> plant; x1 must settle within 1.0
+    # of the reference 10.  Here for 64 noise realisations at once, every step through the generated
+    # controller's three entry points on the device.
+    import torch
+    from oracle import mpc2mpqp as omm
+    from oracle import observer as oobs
+    p = omm.pendulum(Np=100, Nc=100).move_block([1, 1, 5, 10, 10])
+    q = omm.mpc2mpqp(p)
+    assert (q.n, q.nth) == (5, 7)
+    mpc = lmpc.MPC(lmpc.MPQP(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses), nx=4, nu=1, nr=2, nuprev=1)
+    ctl = lmpc.GeneratedController(mpc)
+    kf = oobs.kalman_filter(p.F, p.G, p.C, Q=1e2 * np.array([1e-3, 1, 1e-3, 1]), R=[1, 0.1])
+    ctl.set_observer(*kf.codegen_arrays(), 4, 1, 0, 2)
+    dev = torch.device("cuda", 0)
+    S, T = 64, 2000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    F = torch.from_numpy(p.F).to(dev)
+    G = torch.from_numpy(p.G).to(dev)
+    C = torch.from_numpy(p.C).to(dev)
+    Wn = torch.tensor([[0, 0], [0.05, 0], [0, 0], [0, 0.005]], dtype=torch.float64, device=dev)
+    vn = torch.tensor([0.05, 0.005], dtype=torch.float64, device=dev)
+    x = torch.zeros((S, 4), dtype=torch.float64, device=dev)
+    xhat = torch.zeros((S, 4), dtype=torch.float64, device=dev)
+    u = torch.zeros((S, 1), dtype=torch.float64, device=dev)
+    r0 = torch.zeros((S, 2), dtype=torch.float64, device=dev)
+    r1 = torch.tensor([10.0, 0.0], dtype=torch.float64, device=dev).repeat(S, 1)
+    flags = torch.empty(S, dtype=torch.int32, device=dev)
+    worst = torch.ones(S, dtype=torch.int32, device=dev)
+    x1_tail = []
+    for k in range(T):
+        y = x @ C.T + vn * torch.randn((S, 2), dtype=torch.float64, device=dev, generator=gen)
+        ctl.model.correct_state(xhat, y.contiguous())
+        ctl.model.compute_control_device(u, xhat, r0 if k < 20 else r1, exitflag=flags)
+        worst = torch.minimum(worst, flags)
+        ctl.model.predict_state(xhat, u)
+        x = x @ F.T + u @ G.T + torch.randn((S, 2), dtype=torch.float64, device=dev, generator=gen) @ Wn.T
+        if k >= T - 51:
+            x1_tail.append(x[:, 0].clone())
+    torch.cuda.synchronize()
+    assert int(worst.min().item()) >= 1
+    tail = torch.stack(x1_tail).cpu().numpy()
+    assert np.all(np.abs(tail - 10.0) < 1.0), np.abs(tail - 10.0).max()

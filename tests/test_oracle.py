@@ -418,3 +418,32 @@ def test_reference_condensation_restated():
     L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
     u = oldp.solve_batch(L, th[None])[0][0, 0]
     assert abs(u - float(g["u_full_preview"])) < 1e-5
+
+
+def test_observer_restated():
+    """/root/reference/src/observer.jl:53-72,104-123 and codegen/mpc_observer.c: the Kalman gain solves the
+    filter Riccati equation, predict!/correct! equal the generated C loops on the generated arrays
+    (the reference's own check, runtests.jl:936-947, to 1e-9)."""
+    from oracle import observer as oobs
+    from oracle import mpc2mpqp as omm
+    p = omm.pendulum(Np=100, Nc=100)
+    kf = oobs.kalman_filter(p.F, p.G, p.C, Q=1e2 * np.array([1e-3, 1, 1e-3, 1]), R=[1, 0.1])
+    nx, nu, nd, ny = kf.dims
+    assert (nx, nu, nd, ny) == (4, 1, 0, 2)
+    # K = P C'(C P C' + R)^-1 with P the stabilising solution: F (I - K C) is a stable matrix
+    assert np.abs(np.linalg.eigvals(kf.F @ (np.eye(nx) - kf.K @ kf.C))).max() < 1.0
+    dyn, meas, kt = kf.codegen_arrays()
+    assert dyn.size == nx * (1 + nx + nu + nd) and meas.size == ny * (1 + nx + nd) and kt.size == ny * nx
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        x, u, y = rng.standard_normal(nx), rng.standard_normal(nu), rng.standard_normal(ny)
+        x1 = kf.predict(x, u)
+        assert np.linalg.norm(oobs.c_predict(dyn, x, u, None, nx, nu, nd) - x1) < 1e-9
+        assert np.linalg.norm(oobs.c_correct(meas, kt, x1, y, None, nx, ny, nd) - kf.correct(x1, y)) < 1e-9
+    # with a measured disturbance (runtests.jl:951-987 "Observer + disturbance")
+    kd = oobs.kalman_filter([[1, 1], [0, 1.0]], [[0], [1.0]], [[1.0, 0]], Gd=[[0.5], [1.0]], Dd=[[0.1]],
+                            f_offset=[0.1, -0.2], h_offset=[0.3], Q=[1.0, 1], R=[1e-2])
+    dyn, meas, kt = kd.codegen_arrays()
+    x, u, y, d = rng.standard_normal(2), rng.standard_normal(1), rng.standard_normal(1), rng.standard_normal(1)
+    assert np.linalg.norm(oobs.c_predict(dyn, x, u, d, 2, 1, 1) - kd.predict(x, u, d)) < 1e-9
+    assert np.linalg.norm(oobs.c_correct(meas, kt, x, y, d, 2, 1, 1) - kd.correct(x, y, d)) < 1e-9
