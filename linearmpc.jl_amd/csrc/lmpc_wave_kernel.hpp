@@ -108,6 +108,8 @@ __device__ __forceinline__ bool wv_in(unsigned long long mask) {
 }
 // lanes [0, k)
 __device__ __forceinline__ unsigned long long wv_below(int k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }
+// the same for 0 <= k <= 63 (a working-set position): one s_bfm_b64 instead of shift, not and a guarded select
+__device__ __forceinline__ unsigned long long wv_below63(int k) { return (1ull << (k & 63)) - 1ull; }
 
 template <typename R> struct wv_lim;
 template <> struct wv_lim<double> { static __device__ __forceinline__ double inf() { return __builtin_huge_val(); } };
@@ -265,7 +267,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int t = t1 - q;
                     if (t >= 1) {
                         const R vt = wv_bcast(v, t);
-                        if (wv_in(wv_below(t))) v = wv_fma(-Lc[q], vt, v);            // columns i < t
+                        if (wv_in(wv_below63(t))) v = wv_fma(-Lc[q], vt, v);          // columns i < t  (1 <= t <= 63)
                     }
                 }
             }
@@ -345,7 +347,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int c = c0 + qq;
                     if (c + 1 < nao - 1) {
                         const int lo = (c + 1 > r) ? c + 1 : r;
-                        if (wv_in(wv_below(nao - 1) & ~wv_below(lo))) L[cbase(c) + lane] = tmp[qq];
+                        if (wv_in(wv_below63(nao - 1) & ~wv_below63(lo))) L[cbase(c) + lane] = tmp[qq];   // lo <= nao - 1 <= 63
                     }
                 }
             }
