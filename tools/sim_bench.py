@@ -15,6 +15,9 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warm", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--groups", type=int, default=1,
+                help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
+                     "(scenarios are independent: the groups' kernels overlap on the chip)")
 a = ap.parse_args()
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", "pendulum.npz")))
 sys.path.insert(0, ROOT)
@@ -41,3 +44,35 @@ for rep in range(a.reps):
     t2 = time.perf_counter()
     print(f"N={N} T={T} warm={a.warm}: {N*T/(t2-t0):.3e} scenario-steps/s, {1e6*(t2-t0)/T:.1f} us/step "
           f"(host enqueue {1e6*(t1-t0)/T:.1f} us/step), min flag {int(fm.min())}")
+
+
+if a.groups > 1:
+    import threading
+    Gn = a.groups
+    qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+           for _ in range(Gn)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(Gn)]
+    bounds = np.linspace(0, N, Gn + 1).astype(int)
+    for rep in range(a.reps):
+        xs = [x0[bounds[i]:bounds[i + 1]].clone() for i in range(Gn)]
+        rs = [r[bounds[i]:bounds[i + 1]].contiguous() for i in range(Gn)]
+        ups = [torch.zeros((bounds[i + 1] - bounds[i], 1), dtype=torch.float64, device=dev) for i in range(Gn)]
+        fms = [torch.empty(bounds[i + 1] - bounds[i], dtype=torch.int32, device=dev) for i in range(Gn)]
+        torch.cuda.synchronize()
+
+        def run(i):
+            n_i = int(bounds[i + 1] - bounds[i])
+            check(lib().lmpc_simulate_device(qps[i]._h, n_i, T, 4, 2, 1, vp(F.ctypes.data), vp(G.ctypes.data),
+                                             vp(xs[i].data_ptr()), vp(rs[i].data_ptr()), vp(ups[i].data_ptr()), None, None,
+                                             vp(fms[i].data_ptr()), a.warm, vp(streams[i].cuda_stream)), qps[i]._h)
+
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(Gn)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"N={N} T={T} warm={a.warm} groups={Gn}: {N*T/(t2-t0):.3e} scenario-steps/s, {1e6*(t2-t0)/T:.1f} us/step, "
+              f"min flag {min(int(f_.min()) for f_ in fms)}")
