@@ -180,11 +180,11 @@ long long lane_seg_cap(long long nprob) {
     return (nblocks + kShards - 1) / kShards * kScreenTPB * 256;
 }
 
-template <int N, int MS, int MA>
+template <int N, int MS, int MA, bool SIM>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
                 const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
-    auto kern = lane_kernel<N, MS, MA>;
+    auto kern = lane_kernel<N, MS, MA, SIM>;
     const long long segCap = lane_seg_cap(nprob);
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -210,7 +210,7 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
     return LMPC_OK;
 }
 
-template <int NTHMAX>
+template <int NTHMAX, bool SIM>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, int32_t *count, hipStream_t st) {
     const int B = 256;
@@ -218,7 +218,7 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
-    hipLaunchKernelGGL(screen_kernel<NTHMAX>, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
+    hipLaunchKernelGGL((screen_kernel<NTHMAX, SIM>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
                        iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
@@ -311,15 +311,19 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         HIP_TRY(h, hipEventRecord(ev.a, st));
     }
     int rc = LMPC_OK;
+    const bool sim = h->L.sim.FG != nullptr;      // closed-loop instantiations (SimFuse), lmpc_simulate* only
     // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
     int32_t *cnt_now = nullptr, *cnt_next = nullptr;
     if (screened) {
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
-        if (h->P.nth <= 8) rc = launch_screen<8>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
-        else if (h->P.nth <= 16) rc = launch_screen<16>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
-        else rc = launch_screen<32>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st);
+#define LMPC_SCR(NT) (sim ? launch_screen<NT, true>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                          : launch_screen<NT, false>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+        if (h->P.nth <= 8) rc = LMPC_SCR(8);
+        else if (h->P.nth <= 16) rc = LMPC_SCR(16);
+        else rc = LMPC_SCR(32);
+#undef LMPC_SCR
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
     const int32_t *list = screened ? h->dList : nullptr;
@@ -328,10 +332,12 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     // instantiation with the row scans unrolled and the working-set capacity cut to N
     const bool boxed = h->P.m == h->laneN && h->P.n == h->laneN && h->P.ms == h->P.m;
     if (rc == LMPC_OK) switch (h->laneN) {
-#define LMPC_CASE(NN) case NN: rc = boxed ? launch_lane<NN, NN, NN>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
-                                          : launch_lane<NN, 0, NN + 1>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st); break;
+#define LMPC_LN(NN, MSS, MAA) (sim ? launch_lane<NN, MSS, MAA, true>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
+                                   : launch_lane<NN, MSS, MAA, false>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st))
+#define LMPC_CASE(NN) case NN: rc = boxed ? LMPC_LN(NN, NN, NN) : LMPC_LN(NN, 0, NN + 1); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE
+#undef LMPC_LN
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
     }
     if (h->prof) {
@@ -564,8 +570,8 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     hipStream_t st = (hipStream_t)stream;
     const size_t w = (size_t)h->P.words();
     if (N > h->simCap) {
-        hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-        h->simTheta = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
         HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
         HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
         HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
@@ -578,9 +584,30 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
     const unsigned grid = (unsigned)((N + 255) / 256);
     // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
-    // (the plant step writes x+ and u back into it), so a step is the solve plus one streaming kernel
     hipLaunchKernelGGL(form_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
                        nuprev, (long long)N);
+    // Lane / screening kernels: the kernel that finishes a problem also advances its scenario and
+    // writes the next step's record into the other theta buffer (SimFuse) -- a closed-loop step is
+    // the solve's two launches and nothing else
+    if (!h->useWave && h->simFused && nu <= kMaxSimU) {
+        if (!h->simTheta2) HIP_TRY(h, hipMalloc(&h->simTheta2, sizeof(double) * (size_t)h->simCap * h->P.nth));
+        double *cur = h->simTheta, *nxt = h->simTheta2;
+        int rc = LMPC_OK;
+        for (int k = 0; k < T && rc == LMPC_OK; k++) {
+            h->L.sim = SimFuse{h->simFG, nxt, flag_min, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                               nx, nu, nr, nuprev, k == 0 ? 1 : 0};
+            const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
+            rc = launch(h, N, cur, U_traj ? U_traj + (size_t)k * N * nu : h->simU, h->simFlag, nullptr,
+                        warm ? h->simAct : nullptr, wm, st);
+            std::swap(cur, nxt);
+        }
+        h->L.sim = SimFuse{};
+        if (rc != LMPC_OK) return rc;
+        hipLaunchKernelGGL(unpack_theta_kernel, dim3(grid), dim3(256), 0, st, cur, x, nuprev > 0 ? uprev : nullptr, nx,
+                           nr, nuprev, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+        return LMPC_OK;
+    }
     for (int k = 0; k < T; k++) {
         // warm start = previous step's final working set (reference codegen DAQP_WARMSTART,
         // codegen/mpc_update_qp.c:44-47); the first step is always cold
@@ -647,8 +674,8 @@ int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmp
     hipStream_t st = (hipStream_t)stream;
     const size_t w = (size_t)h->P.words();
     if (N > h->simCap) {
-        hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-        h->simTheta = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
         HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
         HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
         HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
@@ -969,6 +996,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     }
     if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");
@@ -992,7 +1020,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->simTheta); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
+    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     delete h;
 }

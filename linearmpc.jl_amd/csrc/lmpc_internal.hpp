@@ -63,7 +63,8 @@ struct lmpc_handle {
     int32_t *dSw = nullptr;
     int numCU = 256;
     // closed-loop simulation scratch
-    double *simTheta = nullptr, *simU = nullptr, *simFG = nullptr;
+    double *simTheta = nullptr, *simTheta2 = nullptr, *simU = nullptr, *simFG = nullptr;
+    int simFused = 1;           // tuning: plant step inside the lane / screening kernels (lmpc_set_option "sim_fused")
     int32_t *simFlag = nullptr;
     uint64_t *simAct = nullptr;
     int64_t simCap = 0;

@@ -37,6 +37,32 @@ __host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
 // strict lower triangle, row i > col t
 __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
+// Closed-loop tail of a finished problem (SimFuse): x+ = F x + G u with the sums in plant_kernel's /
+// the oracle's order (F's terms, then G's), the next record [x+; r; u[0:nup]], bookkeeping of the run.
+// th: this problem's current record; u: its nu outputs.  kMaxSimU bounds the outputs kept in registers.
+constexpr int kMaxSimU = 4;
+__device__ __forceinline__ void sim_advance(const SimFuse &S, const double *__restrict__ th, const double *u,
+                                            const long long pid, const int flag) {
+    const int nx = S.nx, nu = S.nu, nr = S.nr, nup = S.nup;
+    const int nth = nx + nr + nup;
+    const double *F = S.FG, *G = S.FG + nx * nx;
+    double *to = S.theta_out + pid * nth;
+    for (int a = 0; a < nx; a++) {
+        double acc = 0.0;
+        for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], th[c], acc);
+#pragma unroll
+        for (int l = 0; l < kMaxSimU; l++)
+            if (l < nu) acc = __builtin_fma(G[a * nu + l], u[l], acc);
+        to[a] = acc;
+        if (S.xtraj) S.xtraj[pid * nx + a] = acc;
+    }
+    for (int k = 0; k < nr; k++) to[nx + k] = th[nx + k];
+#pragma unroll
+    for (int l = 0; l < kMaxSimU; l++)
+        if (l < nup) to[nx + nr + l] = u[l];
+    if (S.flag_min) S.flag_min[pid] = S.first ? flag : (flag < S.flag_min[pid] ? flag : S.flag_min[pid]);
+}
+
 // Solver state of one lane for a working-set capacity of MA rows.
 template <int N, int MA> struct LaneState {
     static constexpr int NSL = MA * (MA - 1) / 2;
@@ -420,7 +446,7 @@ __device__ __forceinline__ bool lane_loop(
 template <int N, int MS, int MA> struct lane_tier { static constexpr int value = (MS > 0 && N >= 4) ? 3 : 0; };
 
 // Whole solve of problem `pid` on this lane: b = Dth theta into LDS, the iterations, the outputs.
-template <int N, int MS, int MA>
+template <int N, int MS, int MA, bool SIM>
 __device__ __forceinline__ void lane_solve(
     const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
     const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
@@ -514,20 +540,28 @@ __device__ __forceinline__ void lane_solve(
     const unsigned long long act = s.act, low = s.low;
 
     // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22)
+    double uo[kMaxSimU];
+#pragma unroll
+    for (int l = 0; l < kMaxSimU; l++) uo[l] = 0.0;
     if (one_out) {
         double xs = 0.0;
 #pragma unroll
         for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + c], u[c], xs);
-        X[pid] = xs + sh0;
+        uo[0] = xs + sh0;
+        X[pid] = uo[0];
     } else {
         for (int k = 0; k < P.nout; k++) {
             double xs = 0.0, sh = C[P.ox0 + k];
 #pragma unroll
             for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
             for (int t = 0; t < nth; t++) sh = __builtin_fma(C[P.oXth + k * nth + t], th[t], sh);
-            X[pid * P.nout + k] = xs + sh;
+            const double xo = xs + sh;
+#pragma unroll
+            for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = xo;
+            X[pid * P.nout + k] = xo;
         }
     }
+    if constexpr (SIM) sim_advance(P.sim, th, uo, pid, flag);
     exitflag[pid] = flag;
     if (iters) iters[pid] = iter;
     if (active) {
@@ -540,7 +574,7 @@ __device__ __forceinline__ void lane_solve(
     }
 }
 
-template <int N, int MS, int MA>
+template <int N, int MS, int MA, bool SIM>
 __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -588,7 +622,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const long long idx = base + tid;
     if (idx >= cnt) continue;
     const long long pid = list ? ((kEarly && base == first) ? (long long)pid0 : (long long)list[idx]) : idx;
-    lane_solve<N, MS, MA>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
+    lane_solve<N, MS, MA, SIM>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
 }   // chunk loop
 }
 

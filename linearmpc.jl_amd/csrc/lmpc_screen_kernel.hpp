@@ -32,7 +32,7 @@ namespace lmpc {
 #endif
 constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 
-template <int NTHMAX>
+template <int NTHMAX, bool SIM>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -124,12 +124,44 @@ __global__ __launch_bounds__(256) void screen_kernel(
         const bool fill = (ablate & 16) ? (valid && !hard) : valid;
         if (fill && !(ablate & 4)) {
             const double *xk = C + P.oXthP;
+            double uo[kMaxSimU];
+#pragma unroll
+            for (int l = 0; l < kMaxSimU; l++) uo[l] = 0.0;
             for (int k = 0; k < P.nout; k++, xk += NTHMAX) {
                 double sh = C[P.ox0 + k];
 #pragma unroll
                 for (int t = 0; t < NTHMAX; t++) sh = __builtin_fma(xk[t], th[t], sh);
+#pragma unroll
+                for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
                 if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
                 else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
+            }
+            // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
+            if (SIM && !hard) {
+                // (the record sits in registers here: every index into it is a compile-time constant)
+                const SimFuse &S = P.sim;
+                const int nx = S.nx, nu = S.nu, nr = S.nr, nup = S.nup;
+                const double *F = S.FG, *G = S.FG + nx * nx;
+                double *to = S.theta_out + pid * nth;
+                for (int a = 0; a < nx; a++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NTHMAX; c++)
+                        if (c < nx) acc = __builtin_fma(F[a * nx + c], th[c], acc);
+#pragma unroll
+                    for (int l = 0; l < kMaxSimU; l++)
+                        if (l < nu) acc = __builtin_fma(G[a * nu + l], uo[l], acc);
+                    to[a] = acc;
+                    if (S.xtraj) S.xtraj[pid * nx + a] = acc;
+                }
+#pragma unroll
+                for (int t = 0; t < NTHMAX; t++)
+                    if (t >= nx && t < nx + nr) to[t] = th[t];
+#pragma unroll
+                for (int l = 0; l < kMaxSimU; l++)
+                    if (l < nup) to[nx + nr + l] = uo[l];
+                if (S.flag_min) S.flag_min[pid] = S.first ? (int)EXIT_OPTIMAL
+                                                           : (EXIT_OPTIMAL < S.flag_min[pid] ? (int)EXIT_OPTIMAL : S.flag_min[pid]);
             }
             if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
             else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);

@@ -207,4 +207,15 @@ __global__ __launch_bounds__(256) void correct_state_kernel(
     for (int c = 0; c < nx; c++) state[i * nx + c] = xn[c];
 }
 
+// theta = [x; r; uprev] records -> the caller's x and uprev arrays (end of a fused closed loop)
+__global__ __launch_bounds__(256) void unpack_theta_kernel(
+    const double *__restrict__ theta, double *__restrict__ x, double *__restrict__ uprev, int nx, int nr, int nup,
+    long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *t = theta + i * (nx + nr + nup);
+    for (int a = 0; a < nx; a++) x[i * nx + a] = t[a];
+    if (uprev) for (int l = 0; l < nup; l++) uprev[i * nup + l] = t[nx + nr + l];
+}
+
 }  // namespace lmpc

@@ -4,6 +4,17 @@
 
 namespace lmpc {
 
+// Closed-loop mode of the lane / screening kernels (lmpc_simulate*): the kernel that finishes a
+// problem also advances its scenario -- x+ = F x + G u -- and writes the NEXT step's record
+// [x+; r; u] to theta_out, so a closed-loop step is the solve and nothing else.  FG == nullptr: off.
+struct SimFuse {
+    const double *FG;            // F (nx*nx) then G (nx*nu), row-major, device
+    double *theta_out;           // next step's records (a different buffer than the one being read)
+    int *flag_min;               // smallest exit flag over the steps so far, or nullptr
+    double *xtraj;               // this step's slot of the state trajectory, or nullptr
+    int nx, nu, nr, nup, first;
+};
+
 // Offsets (in doubles) of the constant arrays inside the single device buffer.
 struct PackLayout {
     int n, m, ms, nth, nout, words;
@@ -13,6 +24,7 @@ struct PackLayout {
     unsigned long long imm_mask, eq_mask;           // m <= 64: IMMUTABLE rows / rows flagged ACTIVE
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int cycle_tol, iter_limit;
+    SimFuse sim;
 };
 
 struct WaveLayout {

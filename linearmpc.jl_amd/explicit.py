@@ -100,3 +100,51 @@ def discover_regions(solve_fn, theta, group=None):
         masks, counts, first = um[order], uc[order], None
         solved = sum(g[2] for g in gathered)
     return {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved}
+
+
+def certify_sampled(solve_fn, theta, group=None):
+    """Empirical iteration-complexity certificate over a parameter sample.
+
+    The reference's `certify` (/root/reference/src/certify.jl:18-30) hands the mpQP to ASCertain, which
+    partitions the parameter range into regions of equal solver behaviour and returns the exact worst-case
+    iteration count (`max_iterations`, `partition`).  The batched backend's share of that job is the
+    data-parallel one: solve the sample, report the largest iteration count that occurred (a LOWER bound
+    of the certified maximum -- points the sample misses are not covered), where it occurred, the
+    iteration histogram, and the distinct (final active set, iteration count) pairs that were seen
+    (each is a union of ASCertain's partition cells, which are finer -- equal working-set SEQUENCE;
+    the reference's test finds more than 100 of them for the pendulum, runtests.jl:199-204, where the
+    sample sees about 50 pairs).
+
+    solve_fn / group as in `discover_regions`: with a torch.distributed group every rank passes its
+    shard of the sample and all ranks return the merged result."""
+    theta = np.asarray(theta, float)
+    x, ef, it, act = solve_fn(theta)
+    ef = np.asarray(ef)
+    it = np.asarray(it).astype(np.int64)
+    act = np.ascontiguousarray(np.asarray(act, np.uint64).reshape(len(ef), -1))
+    ok = ef >= 1
+    hist = np.bincount(it[ok], minlength=1)
+    if ok.any():
+        worst = int(np.flatnonzero(ok)[np.argmax(it[ok])])
+        max_it, arg = int(it[worst]), theta[worst].copy()
+    else:
+        max_it, arg = 0, None
+    cells = np.unique(np.hstack([act[ok], it[ok, None].astype(np.uint64)]), axis=0) if ok.any() \
+        else np.zeros((0, act.shape[1] + 1), np.uint64)
+    flags = {int(k): int(v) for k, v in zip(*np.unique(ef, return_counts=True))}
+    if group is not None:
+        import torch.distributed as dist
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, (max_it, arg, hist, cells, flags), group=group)
+        best = max(range(len(gathered)), key=lambda r_: (gathered[r_][0], -r_))
+        max_it, arg = gathered[best][0], gathered[best][1]
+        L = max(len(g_[2]) for g_ in gathered)
+        hist = sum(np.pad(g_[2], (0, L - len(g_[2]))) for g_ in gathered)
+        nonempty = [g_[3] for g_ in gathered if len(g_[3])]
+        cells = np.unique(np.concatenate(nonempty, 0), axis=0) if nonempty else cells
+        flags = {}
+        for g_ in gathered:
+            for k, v in g_[4].items():
+                flags[k] = flags.get(k, 0) + v
+    return {"max_iterations": max_it, "argmax_theta": arg, "iterations_hist": np.asarray(hist),
+            "cells": cells, "n_cells": int(len(cells)), "exitflags": flags}

@@ -95,3 +95,52 @@ def test_sharded_region_discovery_equals_single_process(tmp_path):
     for r in range(world):
         assert key(np.load(tmp_path / f"masks{r}.npy"), np.load(tmp_path / f"counts{r}.npy")) == \
             key(ref["masks"], ref["counts"])
+
+
+
+def _certify_worker(rank, world, port, out_dir):
+    import pickle
+    import sys
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import linearmpc_jl_amd as lmpc
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
+    theta = lmpc.explicit.sample_range(lb, ub, 20001, seed=5)
+    lo, hi = lmpc.shard_bounds(len(theta), world, rank)
+    out = lmpc.explicit.certify_sampled(lambda th: oldp.solve_batch(L, th), theta[lo:hi], group=dist.group.WORLD)
+    with open(os.path.join(out_dir, f"cert{rank}.pkl"), "wb") as fh:
+        pickle.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_sampled_certificate_equals_single_process(tmp_path):
+    # the caller side of /root/reference/src/certify.jl on the batched path, sharded like any batch
+    import pickle
+    import linearmpc_jl_amd as lmpc
+    from oracle import ldp as oldp
+    world = 2
+    mp.spawn(_certify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g = load_golden("pendulum")
+    pk = dict(g); pk["sense"] = g["senses"]
+    L = oracle_ldp_from(pk)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
+    theta = lmpc.explicit.sample_range(lb, ub, 20001, seed=5)
+    ref = lmpc.explicit.certify_sampled(lambda th: oldp.solve_batch(L, th), theta)
+    # (the reference's exact partition, by working-set SEQUENCE, has > 100 regions: runtests.jl:199-204; the
+    # sample's cells -- final active set x iteration count -- are unions of those: ~40-50 on this range)
+    assert ref["max_iterations"] >= 6 and ref["n_cells"] >= 30
+    x, ef, it, _ = oldp.solve_batch(L, ref["argmax_theta"][None])
+    assert it[0] == ref["max_iterations"]
+    for r in range(world):
+        out = pickle.load(open(tmp_path / f"cert{r}.pkl", "rb"))
+        assert out["max_iterations"] == ref["max_iterations"] and out["n_cells"] == ref["n_cells"]
+        assert np.array_equal(out["cells"], ref["cells"]) and np.array_equal(out["iterations_hist"], ref["iterations_hist"])
+        assert out["exitflags"] == ref["exitflags"]
+        x, ef, it, _ = oldp.solve_batch(L, out["argmax_theta"][None])
+        assert it[0] == ref["max_iterations"]

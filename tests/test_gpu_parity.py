@@ -454,6 +454,22 @@ def test_region_discovery_on_gpu(lmpc):
     assert np.array_equal(act[0], out["masks"][3]) and np.abs(Fz @ theta[i] + gz - x[0]).max() < 1e-8
 
 
+def test_sampled_complexity_certificate_on_gpu(lmpc):
+    # the caller side of /root/reference/src/certify.jl: the reference certifies invpend over its
+    # ParameterRange and gets a partition of more than 100 regions of equal working-set SEQUENCE
+    # (runtests.jl:199-204); the sample's distinct (final active set, iteration count) pairs are unions of
+    # such regions (about 50 on this range), its largest iteration count a lower bound of the certified one
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0])
+    ub = np.array([20.0] * 4 + [20.0, 0.0] + [2.0])
+    theta = lmpc.explicit.sample_range(lb, ub, 300000, seed=2)
+    out = lmpc.explicit.certify_sampled(qp.solve, theta)
+    assert 40 <= out["n_cells"] <= 243 * 8 and out["exitflags"] == {1: 300000} and out["max_iterations"] >= 7
+    x, ef, it, act = qp.solve(out["argmax_theta"][None])
+    assert it[0] == out["max_iterations"] == len(out["iterations_hist"]) - 1
+
+
 def test_K2_prestabilising_feedback_through_c_abi(lmpc):
     # /root/reference/test/runtests.jl:119-136; u = U*[1:nu] - K x (reference src/utils.jl:48-49)
     from oracle import mpc2mpqp as omm
