@@ -83,15 +83,30 @@ __global__ __launch_bounds__(256) void screen_kernel(
             double b[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) b[q] = 0.0;
+            if (j + 4 <= m || (ablate & 32)) {
 #pragma unroll
-            for (int t = 0; t < NTHMAX; t++)
+                for (int t = 0; t < NTHMAX; t++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
+                    for (int q = 0; q < 4; q++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double vu = (bj[2 * q] + b[q]) - 0.0;
-                const double vl = -((bj[2 * q + 1] + b[q]) - 0.0);
-                if (!((imm >> q) & 1ull)) hard = hard || (vu < ntol) || (vl < ntol);
+                for (int q = 0; q < 4; q++) {
+                    const double vu = (bj[2 * q] + b[q]) - 0.0;
+                    const double vl = -((bj[2 * q + 1] + b[q]) - 0.0);
+                    if (!((imm >> q) & 1ull)) hard = hard || (vu < ntol) || (vl < ntol);
+                }
+            } else {
+                // last, partial group of rows: only the real ones (the padded rows can never be violated,
+                // skipping them changes nothing but the instruction count)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    if (j + q < m) {
+#pragma unroll
+                        for (int t = 0; t < NTHMAX; t++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
+                        const double vu = (bj[2 * q] + b[q]) - 0.0;
+                        const double vl = -((bj[2 * q + 1] + b[q]) - 0.0);
+                        if (!((imm >> q) & 1ull)) hard = hard || (vu < ntol) || (vl < ntol);
+                    }
+                }
             }
         }
         // a warm start with an EMPTY initial working set is a cold start (the usual case once a
