@@ -292,7 +292,8 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     // (warm starts too: the screening pass finishes the problems whose warm mask is empty and whose
     // unconstrained optimum is feasible, everything else is queued with its mask)
     const bool screened = h->screen && h->L.eq_mask == 0ull && h->S.iter_limit > 1 &&
-                          h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
+                          h->P.nth >= 1 && h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
+    static_assert((kShards & (kShards - 1)) == 0, "the screening kernel masks the shard index");
     if (screened && nprob > h->listCap) {
         hipFree(h->dList); hipFree(h->dCount);
         h->dList = h->dCount = nullptr; h->listCap = 0;

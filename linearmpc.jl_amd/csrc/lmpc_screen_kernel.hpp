@@ -42,15 +42,20 @@ __global__ __launch_bounds__(256) void screen_kernel(
     const long long first = (long long)blockIdx.x * kScreenTPB * B + tid;
     const double ntol = -P.primal_tol;
     const int lane = tid & 63;
-    const int shard = blockIdx.x % nshards;
+    const int shard = blockIdx.x & (nshards - 1);      // nshards is a power of two (checked by the host)
 
     double nx[NTHMAX];                                 // record of the problem after the current one
+    // No guard on any load: a problem index past the end is clamped to the last problem (its results are
+    // dropped by `valid`), a parameter index past the record to the record's last entry -- it meets a zero
+    // coefficient in the padded rows, so the term adds +0 exactly.  (Guarded, every one of the loads sat
+    // in its own exec-masked block: six scalar instructions and a branch per parameter.)
     auto load_record = [&](long long pid, double *dst) {
-        const double *src = theta + pid * nth;
-        const bool ok = pid < nprob;
+        const double *src = theta + (pid < nprob ? pid : nprob - 1) * nth;
 #pragma unroll
-        for (int t = 0; t < NTHMAX; t++)
-            dst[t] = (ok && t < nth) ? ((ablate & 8) ? src[t] : __builtin_nontemporal_load(src + t)) : 0.0;
+        for (int t = 0; t < NTHMAX; t++) {
+            const int tc = t < nth ? t : nth - 1;
+            dst[t] = (ablate & 8) ? src[tc] : __builtin_nontemporal_load(src + tc);
+        }
     };
     load_record(first, nx);
 
