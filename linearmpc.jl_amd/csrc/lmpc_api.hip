@@ -210,7 +210,7 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
     return LMPC_OK;
 }
 
-template <int NTHMAX, bool SIM>
+template <int NTHMAX, int NT, bool SIM>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, int32_t *count, hipStream_t st) {
     const int B = 256;
@@ -218,7 +218,7 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
-    hipLaunchKernelGGL((screen_kernel<NTHMAX, SIM>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
+    hipLaunchKernelGGL((screen_kernel<NTHMAX, NT, SIM>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
                        iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
@@ -319,11 +319,19 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
-#define LMPC_SCR(NT) (sim ? launch_screen<NT, true>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
-                          : launch_screen<NT, false>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
-        if (h->P.nth <= 8) rc = LMPC_SCR(8);
-        else if (h->P.nth <= 16) rc = LMPC_SCR(16);
-        else rc = LMPC_SCR(32);
+#define LMPC_SCR(NM, NT) (sim ? launch_screen<NM, NT, true>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                              : launch_screen<NM, NT, false>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+        switch (h->P.nth <= 16 ? h->P.nth : 32) {       // exact column count up to 16, padded beyond
+            case 1: rc = LMPC_SCR(8, 1); break;    case 2: rc = LMPC_SCR(8, 2); break;
+            case 3: rc = LMPC_SCR(8, 3); break;    case 4: rc = LMPC_SCR(8, 4); break;
+            case 5: rc = LMPC_SCR(8, 5); break;    case 6: rc = LMPC_SCR(8, 6); break;
+            case 7: rc = LMPC_SCR(8, 7); break;    case 8: rc = LMPC_SCR(8, 8); break;
+            case 9: rc = LMPC_SCR(16, 9); break;   case 10: rc = LMPC_SCR(16, 10); break;
+            case 11: rc = LMPC_SCR(16, 11); break; case 12: rc = LMPC_SCR(16, 12); break;
+            case 13: rc = LMPC_SCR(16, 13); break; case 14: rc = LMPC_SCR(16, 14); break;
+            case 15: rc = LMPC_SCR(16, 15); break; case 16: rc = LMPC_SCR(16, 16); break;
+            default: rc = LMPC_SCR(32, 32); break;
+        }
 #undef LMPC_SCR
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));

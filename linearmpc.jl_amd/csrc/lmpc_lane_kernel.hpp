@@ -443,7 +443,10 @@ __device__ __forceinline__ bool lane_loop(
 }
 
 // first-tier capacity of an instantiation (0 = none): the boxed variants from n = 4 on
-template <int N, int MS, int MA> struct lane_tier { static constexpr int value = (MS > 0 && N >= 4) ? 3 : 0; };
+#ifndef LMPC_LANE_TIER_CAP
+#define LMPC_LANE_TIER_CAP 3
+#endif
+template <int N, int MS, int MA> struct lane_tier { static constexpr int value = (MS > 0 && N >= 4) ? LMPC_LANE_TIER_CAP : 0; };
 
 // Whole solve of problem `pid` on this lane: b = Dth theta into LDS, the iterations, the outputs.
 template <int N, int MS, int MA, bool SIM>

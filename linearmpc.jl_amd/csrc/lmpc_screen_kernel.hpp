@@ -32,7 +32,10 @@ namespace lmpc {
 #endif
 constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 
-template <int NTHMAX, bool SIM>
+// NTHMAX: column stride of the padded rows (8, 16 or 32).  NT: columns the unrolled chains run over --
+// the exact nth for nth <= 16 (one instantiation per value: with three batches in flight the pass is
+// bound by vector issue, and the padded column of the 7-parameter pendulum cost 6 %), else NTHMAX.
+template <int NTHMAX, int NT, bool SIM>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -44,16 +47,17 @@ __global__ __launch_bounds__(256) void screen_kernel(
     const int lane = tid & 63;
     const int shard = blockIdx.x & (nshards - 1);      // nshards is a power of two (checked by the host)
 
-    double nx[NTHMAX];                                 // record of the problem after the current one
+    double nx[NT];                                     // record of the problem after the current one
     // No guard on any load: a problem index past the end is clamped to the last problem (its results are
-    // dropped by `valid`), a parameter index past the record to the record's last entry -- it meets a zero
-    // coefficient in the padded rows, so the term adds +0 exactly.  (Guarded, every one of the loads sat
-    // in its own exec-masked block: six scalar instructions and a branch per parameter.)
+    // dropped by `valid`), a parameter index past the record (NT > nth, padded instantiations only) to the
+    // record's last entry -- it meets a zero coefficient in the padded rows, so the term adds +0 exactly.
+    // (Guarded, every one of the loads sat in its own exec-masked block: six scalar instructions and a
+    // branch per parameter.)
     auto load_record = [&](long long pid, double *dst) {
         const double *src = theta + (pid < nprob ? pid : nprob - 1) * nth;
 #pragma unroll
-        for (int t = 0; t < NTHMAX; t++) {
-            const int tc = t < nth ? t : nth - 1;
+        for (int t = 0; t < NT; t++) {
+            const int tc = (NT <= 16 || t < nth) ? t : nth - 1;      // NT <= 16: NT == nth exactly
             dst[t] = (ablate & 8) ? src[tc] : __builtin_nontemporal_load(src + tc);
         }
     };
@@ -70,9 +74,9 @@ __global__ __launch_bounds__(256) void screen_kernel(
         const long long pid = first + (long long)it * B;
         if (pid - tid >= nprob) break;                 // uniform over the workgroup
         const bool valid = pid < nprob;
-        double th[NTHMAX];
+        double th[NT];
 #pragma unroll
-        for (int t = 0; t < NTHMAX; t++) th[t] = nx[t];
+        for (int t = 0; t < NT; t++) th[t] = nx[t];
         if (it + 1 < kScreenTPB) load_record(pid + B, nx);
 
         bool hard = false;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
             for (int q = 0; q < 4; q++) b[q] = 0.0;
             if (j + 4 <= m || (ablate & 32)) {
 #pragma unroll
-                for (int t = 0; t < NTHMAX; t++)
+                for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
 #pragma unroll
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 for (int q = 0; q < 3; q++) {
                     if (j + q < m) {
 #pragma unroll
-                        for (int t = 0; t < NTHMAX; t++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
+                        for (int t = 0; t < NT; t++) b[q] = __builtin_fma(dj[q * NTHMAX + t], th[t], b[q]);
                         const double vu = (bj[2 * q] + b[q]) - 0.0;
                         const double vl = -((bj[2 * q + 1] + b[q]) - 0.0);
                         if (!((imm >> q) & 1ull)) hard = hard || (vu < ntol) || (vl < ntol);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
             for (int k = 0; k < P.nout; k++, xk += NTHMAX) {
                 double sh = C[P.ox0 + k];
 #pragma unroll
-                for (int t = 0; t < NTHMAX; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
 #pragma unroll
                 for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
                 if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 for (int a = 0; a < nx; a++) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int c = 0; c < NTHMAX; c++)
+                    for (int c = 0; c < NT; c++)
                         if (c < nx) acc = __builtin_fma(F[a * nx + c], th[c], acc);
 #pragma unroll
                     for (int l = 0; l < kMaxSimU; l++)
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                     if (S.xtraj) S.xtraj[pid * nx + a] = acc;
                 }
 #pragma unroll
-                for (int t = 0; t < NTHMAX; t++)
+                for (int t = 0; t < NT; t++)
                     if (t >= nx && t < nx + nr) to[t] = th[t];
 #pragma unroll
                 for (int l = 0; l < kMaxSimU; l++)
