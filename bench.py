@@ -215,6 +215,11 @@ def main():
     if args.wave_nwv:
         for q_ in qps:
             q_.set_option("wave_nwv", args.wave_nwv)
+    # several batches in flight: 64-lane workgroups for the iterating kernel (its wavefronts then spread
+    # over the CUs independently of each other; +3 % over the library's stand-alone choice of 256,
+    # which is the better one with a single batch in flight: tools/block_sweep.sh)
+    if not args.lane_block and nstreams > 1 and not args.f32 and not args.wave and args.workload.startswith("pendulum"):
+        args.lane_block = 64
     if args.lane_block:
         for q_ in qps:
             q_.set_option("lane_block", args.lane_block)
