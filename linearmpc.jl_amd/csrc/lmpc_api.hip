@@ -93,7 +93,14 @@ int finalize_handle(lmpc_handle *h) {
         return fail(h, LMPC_ERR_UNSUPPORTED,
                     "lmpc: problem outside what the kernels cover (lane: n<=12, m<=64, hard rows; "
                     "wave: n<=63, 1<=m<=1024)");
-    h->useWave = !laneOk;
+    // Which kernel by default when both cover the problem: the lane kernels (one QP per lane, screening
+    // pass in front) are 5-10x faster on box-constrained problems of every size they are built for, but a
+    // lane scans all m rows of general constraints by itself every iteration -- from about m*n = 600 on
+    // the wavefront kernel, which spreads the rows over its lanes, is ahead (tools/lane_vs_wave.py:
+    // mass-spring n=10: m=46 lane 1.40e8 vs 1.26e8, m=63 lane 1.06e8 vs wave 1.45e8; n=8, m=49 lane
+    // 1.69e8 vs 1.60e8).  lmpc_set_option("wave", 0 | 1) overrides.
+    const bool manyGeneralRows = P.ms < P.m && (long long)P.m * P.n >= 600;
+    h->useWave = !laneOk || (waveOk && manyGeneralRows);
     HIP_TRY(h, hipSetDevice(h->device));
     {
         hipDeviceProp_t prop;
@@ -135,7 +142,7 @@ int finalize_handle(lmpc_handle *h) {
     if (!laneOk) { h->kname = "wave"; return LMPC_OK; }
     h->laneN = 0;
     for (int s : kLaneSizes) if (s >= P.n) { h->laneN = s; break; }
-    h->kname = h->useWave ? "wave" : "screen+lane<" + std::to_string(h->laneN) + ">";
+    h->kname = "screen+lane<" + std::to_string(h->laneN) + ">";       // lmpc_kernel_name says "wave" while useWave is set
     fill_layout(h);
     const int N = h->laneN;
     std::vector<double> buf(h->nC, 0.0);
