@@ -1090,3 +1090,55 @@ def test_observer_closed_loop_as_in_the_reference(lmpc):
     assert int(worst.min().item()) >= 1
     tail = torch.stack(x1_tail).cpu().numpy()
     assert np.all(np.abs(tail - 10.0) < 1.0), np.abs(tail - 10.0).max()
+
+
+def test_randomized_differential_against_the_oracle(lmpc):
+    # Sixty random problem shapes across every kernel family and row kind: n 1..14, 0..45 general rows,
+    # 0..12 parameters, simple bounds present or not, SOFT / EQUALITY / IMMUTABLE / one-sided rows mixed in,
+    # loose and tight bounds (feasible and infeasible batches), cold and warm starts -- each batch must
+    # agree with the oracle in exit flags, iteration counts, active sets (bit for bit) and x (1e-10).
+    from oracle import ldp as oldp
+    rng = np.random.default_rng(20261003)
+    kinds = {"lane": 0, "wave": 0}
+    seen_flags = set()
+    for trial in range(60):
+        n = int(rng.integers(1, 15))
+        mg = int(rng.integers(0, 46))
+        ms = n if rng.random() < 0.7 else 0
+        nth = int(rng.integers(0, 13))
+        if ms + mg == 0:
+            mg = 1
+        nsoft = int(rng.integers(0, mg + 1)) if (mg and rng.random() < 0.4) else 0
+        H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, max(nth, 1), nsoft, ms=ms)
+        if nth == 0:
+            f_theta, W = f_theta[:, :0], W[:, :0]
+        scale = rng.choice([0.3, 1.0, 3.0])
+        bu, bl = scale * bu, scale * bl
+        m = ms + mg
+        for j in range(m):                                   # sprinkle the other row kinds
+            r = rng.random()
+            if sense[j] == 0 and r < 0.08:
+                bu[j], sense[j] = 1e30, 0                    # one-sided (lower bound only)
+            elif sense[j] == 0 and r < 0.16:
+                bl[j] = -1e30                                # one-sided (upper bound only)
+            elif sense[j] == 0 and r < 0.20:
+                bu[j], bl[j], sense[j] = 1e30, -1e30, 4      # IMMUTABLE: both bounds infinite
+            elif sense[j] == 0 and j >= ms and r < 0.24 and n >= 3:
+                v = rng.uniform(-0.2, 0.2)
+                bu[j], bl[j], sense[j] = v, v, 5             # EQUALITY general row
+        if (sense == 5).sum() > max(n - 1, 0):
+            sense[sense == 5] = 0
+        try:
+            qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=min(n, 3))
+        except lmpc.LmpcError as e:
+            assert e.code in (-1, -6), e                     # setup flags of DAQP (infeasible bounds / dependent equalities)
+            continue
+        kinds["wave" if qp.kernel_name == "wave" else "lane"] += 1
+        theta = rng.uniform(-2, 2, (257, max(nth, 0))) if nth else np.zeros((257, 0))
+        x, ef, it, act = _compare(qp, theta)
+        seen_flags |= set(np.unique(ef).tolist())
+        ok = ef >= 1
+        if ok.sum() >= 8:
+            _compare(qp, theta[ok][:64], warm=act[ok][:64])
+    assert kinds["lane"] >= 10 and kinds["wave"] >= 10, kinds
+    assert {1, -1} <= seen_flags and (2 in seen_flags), seen_flags
