@@ -800,29 +800,34 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     HIP_TRY(h, hipSetDevice(h->device));
     const int nu = h->P.nout;
     const size_t wr = (size_t)h->ccNr * (h->ccNph > 0 ? h->ccNph : 1);
-    double *dc = nullptr, *ds = nullptr, *dr = nullptr, *dd = nullptr, *dp = nullptr;
-    int32_t *df = nullptr;
-    auto cleanup = [&]() { hipFree(dc); hipFree(ds); hipFree(dr); hipFree(dd); hipFree(dp); hipFree(df); };
-#define CC_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
-        return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
-    auto up = [&](double **dst, const double *src, size_t per) -> hipError_t {
-        if (!src || per == 0) return hipSuccess;
-        hipError_t e = hipMalloc(dst, sizeof(double) * (size_t)N * per);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, sizeof(double) * (size_t)N * per, hipMemcpyHostToDevice);
+    // one staging block per handle, kept between calls (a closed loop calls this once per time step):
+    // [control | state | reference | disturbance | parameter] doubles, then the flags
+    const size_t per = (size_t)nu + h->ccNx + wr + h->ccNd + h->ccNp;
+    if (N > h->ccStageCap || per > h->ccStagePer) {
+        hipFree(h->ccStage); hipFree(h->ccStageFlag);
+        h->ccStage = nullptr; h->ccStageFlag = nullptr; h->ccStageCap = 0; h->ccStagePer = 0;
+        HIP_TRY(h, hipMalloc(&h->ccStage, sizeof(double) * (size_t)N * per));
+        HIP_TRY(h, hipMalloc(&h->ccStageFlag, sizeof(int32_t) * (size_t)N));
+        h->ccStageCap = N; h->ccStagePer = per;
+    }
+    double *cur = h->ccStage;
+    auto up = [&](const double *src, size_t w, double **dst) -> hipError_t {
+        *dst = nullptr;
+        if (!src || w == 0) return hipSuccess;
+        *dst = cur;
+        cur += (size_t)N * w;
+        return hipMemcpy(*dst, src, sizeof(double) * (size_t)N * w, hipMemcpyHostToDevice);
     };
-    CC_TRY(up(&dc, control, (size_t)nu));
-    CC_TRY(up(&ds, state, (size_t)h->ccNx));
-    CC_TRY(up(&dr, reference, wr));
-    CC_TRY(up(&dd, disturbance, (size_t)h->ccNd));
-    CC_TRY(up(&dp, affine_parameter, (size_t)h->ccNp));
-    CC_TRY(hipMalloc(&df, sizeof(int32_t) * (size_t)N));
-    int rc = lmpc_compute_control_device(h, N, dc, ds, dr, dd, dp, df, warm, nullptr);
-    if (rc != LMPC_OK) { cleanup(); return rc; }
-    CC_TRY(hipMemcpy(control, dc, sizeof(double) * (size_t)N * nu, hipMemcpyDeviceToHost));
-    if (exitflag) CC_TRY(hipMemcpy(exitflag, df, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-#undef CC_TRY
-    cleanup();
+    double *dc, *ds, *dr, *dd, *dp;
+    HIP_TRY(h, up(control, (size_t)nu, &dc));
+    HIP_TRY(h, up(state, (size_t)h->ccNx, &ds));
+    HIP_TRY(h, up(reference, wr, &dr));
+    HIP_TRY(h, up(disturbance, (size_t)h->ccNd, &dd));
+    HIP_TRY(h, up(affine_parameter, (size_t)h->ccNp, &dp));
+    int rc = lmpc_compute_control_device(h, N, dc, ds, dr, dd, dp, h->ccStageFlag, warm, nullptr);
+    if (rc != LMPC_OK) return rc;
+    HIP_TRY(h, hipMemcpy(control, dc, sizeof(double) * (size_t)N * nu, hipMemcpyDeviceToHost));
+    if (exitflag) HIP_TRY(h, hipMemcpy(exitflag, h->ccStageFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
     return LMPC_OK;
 }
 
@@ -1038,6 +1043,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
+    hipFree(h->ccStage); hipFree(h->ccStageFlag);
     delete h;
 }
 

@@ -76,6 +76,10 @@ struct lmpc_handle {
     // generated observer (lmpc_set_observer): [MPC_PLANT_DYNAMICS | MPC_MEASUREMENT_FUNCTION | K_TRANSPOSE_OBSERVER]
     double *obsC = nullptr;
     int obsNx = 0, obsNu = 0, obsNd = 0, obsNy = 0;
+    double *ccStage = nullptr;          // host-pointer entry point: device copies of the five argument arrays
+    int32_t *ccStageFlag = nullptr;
+    int64_t ccStageCap = 0;
+    size_t ccStagePer = 0;
     int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
     // profiling
     bool prof = false;
