@@ -55,6 +55,8 @@ void fill_layout(lmpc_handle *h) {
     L.oBnd = o; o += 2 * mp;
     o = (o + 7) & ~7;
     L.oXthP = o; o += P.nout * L.nthp;
+    o = (o + 7) & ~7;
+    L.oFG = o; o += 32 * 32 + 32 * kMaxSimU;           // closed loop: F (nx <= 32) and G (nu <= kMaxSimU)
     h->nC = (size_t)o;
     L.imm_mask = 0; L.eq_mask = 0;
     for (int j = 0; j < P.m && j < 64; j++) {
@@ -606,6 +608,8 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // writes the next step's record into the other theta buffer (SimFuse) -- a closed-loop step is
     // the solve's two launches and nothing else
     if (!h->useWave && h->simFused && nu <= kMaxSimU) {
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
         if (!h->simTheta2) HIP_TRY(h, hipMalloc(&h->simTheta2, sizeof(double) * (size_t)h->simCap * h->P.nth));
         double *cur = h->simTheta, *nxt = h->simTheta2;
         int rc = LMPC_OK;

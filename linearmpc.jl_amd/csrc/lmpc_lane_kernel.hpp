@@ -41,11 +41,12 @@ __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2
 // the oracle's order (F's terms, then G's), the next record [x+; r; u[0:nup]], bookkeeping of the run.
 // th: this problem's current record; u: its nu outputs.  kMaxSimU bounds the outputs kept in registers.
 constexpr int kMaxSimU = 4;
-__device__ __forceinline__ void sim_advance(const SimFuse &S, const double *__restrict__ th, const double *u,
+__device__ __forceinline__ void sim_advance(const SimFuse &S, const double *__restrict__ FGc,
+                                            const double *__restrict__ th, const double *u,
                                             const long long pid, const int flag) {
     const int nx = S.nx, nu = S.nu, nr = S.nr, nup = S.nup;
     const int nth = nx + nr + nup;
-    const double *F = S.FG, *G = S.FG + nx * nx;
+    const double *F = FGc, *G = FGc + nx * nx;            // inside the constant pack: scalar loads
     double *to = S.theta_out + pid * nth;
     for (int a = 0; a < nx; a++) {
         double acc = 0.0;
@@ -564,7 +565,7 @@ __device__ __forceinline__ void lane_solve(
             X[pid * P.nout + k] = xo;
         }
     }
-    if constexpr (SIM) sim_advance(P.sim, th, uo, pid, flag);
+    if constexpr (SIM) sim_advance(P.sim, C + P.oFG, th, uo, pid, flag);
     exitflag[pid] = flag;
     if (iters) iters[pid] = iter;
     if (active) {

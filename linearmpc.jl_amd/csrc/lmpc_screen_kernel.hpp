@@ -162,28 +162,40 @@ __global__ __launch_bounds__(256) void screen_kernel(
             }
             // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
             if (SIM && !hard) {
-                // (the record sits in registers here: every index into it is a compile-time constant)
+                // The record sits in registers here, and the next one is assembled in registers too --
+                // every index a compile-time constant -- and stored in one run of wide stores (element by
+                // element from a run-time loop the 8-byte stores at a 56-byte stride made this pass 3.6x
+                // slower than the plain one).
                 const SimFuse &S = P.sim;
                 const int nx = S.nx, nu = S.nu, nr = S.nr, nup = S.nup;
-                const double *F = S.FG, *G = S.FG + nx * nx;
-                double *to = S.theta_out + pid * nth;
-                for (int a = 0; a < nx; a++) {
-                    double acc = 0.0;
+                const double *F = C + P.oFG, *G = F + nx * nx;         // in the constant pack: scalar loads
+                double rec[NT];
 #pragma unroll
-                    for (int c = 0; c < NT; c++)
-                        if (c < nx) acc = __builtin_fma(F[a * nx + c], th[c], acc);
+                for (int a = 0; a < NT; a++) {
+                    rec[a] = th[a];                                    // the reference block is carried over
+                    if (a < nx) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < NT; c++)
+                            if (c < nx) acc = __builtin_fma(F[a * nx + c], th[c], acc);
+#pragma unroll
+                        for (int l = 0; l < kMaxSimU; l++)
+                            if (l < nu) acc = __builtin_fma(G[a * nu + l], uo[l], acc);
+                        rec[a] = acc;
+                    }
 #pragma unroll
                     for (int l = 0; l < kMaxSimU; l++)
-                        if (l < nu) acc = __builtin_fma(G[a * nu + l], uo[l], acc);
-                    to[a] = acc;
-                    if (S.xtraj) S.xtraj[pid * nx + a] = acc;
+                        if (l < nup && a == nx + nr + l) rec[a] = uo[l];
                 }
+                double *to = S.theta_out + pid * nth;
 #pragma unroll
                 for (int t = 0; t < NT; t++)
-                    if (t >= nx && t < nx + nr) to[t] = th[t];
+                    if (NT <= 16 || t < nth) to[t] = rec[t];
+                if (S.xtraj) {
 #pragma unroll
-                for (int l = 0; l < kMaxSimU; l++)
-                    if (l < nup) to[nx + nr + l] = uo[l];
+                    for (int t = 0; t < NT; t++)
+                        if (t < nx) S.xtraj[pid * nx + t] = rec[t];
+                }
                 if (S.flag_min) S.flag_min[pid] = S.first ? (int)EXIT_OPTIMAL
                                                            : (EXIT_OPTIMAL < S.flag_min[pid] ? (int)EXIT_OPTIMAL : S.flag_min[pid]);
             }

@@ -8,7 +8,9 @@ namespace lmpc {
 // problem also advances its scenario -- x+ = F x + G u -- and writes the NEXT step's record
 // [x+; r; u] to theta_out, so a closed-loop step is the solve and nothing else.  FG == nullptr: off.
 struct SimFuse {
-    const double *FG;            // F (nx*nx) then G (nx*nu), row-major, device
+    const double *FG;            // non-null = closed-loop mode on; F (nx*nx) then G (nx*nu), row-major, are
+                                 // read from the constant pack at PackLayout::oFG (scalar loads: the pack is
+                                 // const __restrict__, a pointer inside this struct is not)
     double *theta_out;           // next step's records (a different buffer than the one being read)
     int *flag_min;               // smallest exit flag over the steps so far, or nullptr
     double *xtraj;               // this step's slot of the state trajectory, or nullptr
@@ -19,6 +21,7 @@ struct SimFuse {
 struct PackLayout {
     int n, m, ms, nth, nout, words;
     int oM, oG, odu, odl, oDth, oRout, ox0, oXth;   // offsets into the double buffer
+    int oFG;                                        // closed loop: room for F and G behind the pack (SimFuse)
     int oDthP, oBnd, oXthP, nthp;                   // screening copies: rows zero-padded to nthp columns,
                                                     // bounds interleaved (du0_j, dl0_j)
     unsigned long long imm_mask, eq_mask;           // m <= 64: IMMUTABLE rows / rows flagged ACTIVE
