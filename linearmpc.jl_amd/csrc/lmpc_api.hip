@@ -716,9 +716,17 @@ int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmp
         const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
         int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
         if (rc != LMPC_OK) return rc;
-        hipLaunchKernelGGL(plant_kernel, dim3(grid), dim3(256), 0, st, x, uprev, h->simU, h->simFlag, h->simFG, nx,
-                           nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
-                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0, (long long)N);
+        {
+#define LMPC_PK(NX) hipLaunchKernelGGL(plant_kernel<NX>, dim3(grid), dim3(256), 0, st, x, uprev, h->simU, h->simFlag, h->simFG, nx, \
+                           nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr, \
+                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0, (long long)N)
+            switch (nx) {
+                case 1: LMPC_PK(1); break; case 2: LMPC_PK(2); break; case 3: LMPC_PK(3); break; case 4: LMPC_PK(4); break;
+                case 5: LMPC_PK(5); break; case 6: LMPC_PK(6); break; case 7: LMPC_PK(7); break; case 8: LMPC_PK(8); break;
+                default: LMPC_PK(0); break;
+            }
+#undef LMPC_PK
+        }
         HIP_TRY(h, hipGetLastError());
     }
     return LMPC_OK;
@@ -865,8 +873,14 @@ int lmpc_predict_state_device(lmpc_handle *h, int64_t N, double *state, const do
         return fail(h, LMPC_ERR_BADARG, "lmpc_predict_state: NULL state/control or negative N");
     if (N == 0) return LMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(predict_state_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       state, control, disturbance, h->obsC, h->obsNx, h->obsNu, h->obsNd, (long long)N);
+#define LMPC_PS(NX) hipLaunchKernelGGL(predict_state_kernel<NX>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, \
+        (hipStream_t)stream, state, control, disturbance, h->obsC, h->obsNx, h->obsNu, h->obsNd, (long long)N)
+    switch (h->obsNx) {
+        case 1: LMPC_PS(1); break; case 2: LMPC_PS(2); break; case 3: LMPC_PS(3); break; case 4: LMPC_PS(4); break;
+        case 5: LMPC_PS(5); break; case 6: LMPC_PS(6); break; case 7: LMPC_PS(7); break; case 8: LMPC_PS(8); break;
+        default: LMPC_PS(0); break;
+    }
+#undef LMPC_PS
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -881,9 +895,15 @@ int lmpc_correct_state_device(lmpc_handle *h, int64_t N, double *state, const do
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t nd_ = (size_t)h->obsNx * (1 + h->obsNx + h->obsNu + h->obsNd);
     const size_t nm_ = (size_t)h->obsNy * (1 + h->obsNx + h->obsNd);
-    hipLaunchKernelGGL(correct_state_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       state, measurement, disturbance, h->obsC + nd_, h->obsC + nd_ + nm_, h->obsNx, h->obsNy,
-                       h->obsNd, (long long)N);
+#define LMPC_CS(NX) hipLaunchKernelGGL(correct_state_kernel<NX>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, \
+        (hipStream_t)stream, state, measurement, disturbance, h->obsC + nd_, h->obsC + nd_ + nm_, h->obsNx, \
+        h->obsNy, h->obsNd, (long long)N)
+    switch (h->obsNx) {
+        case 1: LMPC_CS(1); break; case 2: LMPC_CS(2); break; case 3: LMPC_CS(3); break; case 4: LMPC_CS(4); break;
+        case 5: LMPC_CS(5); break; case 6: LMPC_CS(6); break; case 7: LMPC_CS(7); break; case 8: LMPC_CS(8); break;
+        default: LMPC_CS(0); break;
+    }
+#undef LMPC_CS
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }

@@ -94,25 +94,50 @@ __global__ __launch_bounds__(256) void update_parameter_kernel(
     theta[idx] = v;
 }
 
-// x_i <- F x_i + G u_i (sums in index order, F then G), uprev_i <- u_i, bookkeeping of the run
+// x_i <- F x_i + G u_i (sums in index order, F then G), uprev_i <- u_i, bookkeeping of the run.
+// NXT > 0: compile-time state count (<= 8), the state record read and written with wide accesses
+// (element by element from run-time loops a 32-byte record moved at a quarter of the rate); 0: run-time nx.
+template <int NXT>
 __global__ __launch_bounds__(256) void plant_kernel(
     double *__restrict__ x, double *__restrict__ uprev, const double *__restrict__ u,
-    const int32_t *__restrict__ flag, const double *__restrict__ FG, int nx, int nu, int nup,
+    const int32_t *__restrict__ flag, const double *__restrict__ FG, int nx_rt, int nu, int nup,
     double *__restrict__ xtraj_next, double *__restrict__ utraj, int32_t *__restrict__ flag_min,
     int first, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    constexpr int NXA = NXT > 0 ? NXT : 32;
+    const int nx = NXT > 0 ? NXT : nx_rt;
     const double *F = FG, *G = FG + nx * nx;
-    double xn[32];
-    for (int a = 0; a < nx; a++) {
-        double acc = 0.0;
-        for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], x[i * nx + c], acc);
-        for (int l = 0; l < nu; l++) acc = __builtin_fma(G[a * nu + l], u[i * nu + l], acc);
-        xn[a] = acc;
-    }
-    for (int a = 0; a < nx; a++) {
-        x[i * nx + a] = xn[a];
-        if (xtraj_next) xtraj_next[i * nx + a] = xn[a];
+    double xo[NXA], xn[NXA];
+    if constexpr (NXT > 0) {
+#pragma unroll
+        for (int c = 0; c < NXT; c++) xo[c] = x[i * NXT + c];
+#pragma unroll
+        for (int a = 0; a < NXT; a++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NXT; c++) acc = __builtin_fma(F[a * NXT + c], xo[c], acc);
+            for (int l = 0; l < nu; l++) acc = __builtin_fma(G[a * nu + l], u[i * nu + l], acc);
+            xn[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < NXT; a++) x[i * NXT + a] = xn[a];
+        if (xtraj_next) {
+#pragma unroll
+            for (int a = 0; a < NXT; a++) xtraj_next[i * NXT + a] = xn[a];
+        }
+    } else {
+        for (int c = 0; c < nx; c++) xo[c] = x[i * nx + c];
+        for (int a = 0; a < nx; a++) {
+            double acc = 0.0;
+            for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], xo[c], acc);
+            for (int l = 0; l < nu; l++) acc = __builtin_fma(G[a * nu + l], u[i * nu + l], acc);
+            xn[a] = acc;
+        }
+        for (int a = 0; a < nx; a++) {
+            x[i * nx + a] = xn[a];
+            if (xtraj_next) xtraj_next[i * nx + a] = xn[a];
+        }
     }
     for (int l = 0; l < nu; l++) {
         if (l < nup) uprev[i * nup + l] = u[i * nu + l];
@@ -171,40 +196,89 @@ __global__ __launch_bounds__(256) void plant_theta_kernel(
 // per state; `meas` = MPC_MEASUREMENT_FUNCTION, one row [h_offset_j, C_j, Dd_j] per measurement;
 // `kt` = K_TRANSPOSE_OBSERVER (ny x nx).  Sums in the C code's order with separate multiply and add
 // (the reference compiles it with gcc -O3 -msse3: no fused multiply-add).  One thread per scenario.
+// NXT > 0: the state count is the compile-time constant NXT (<= 8): the record is read and written with
+// wide accesses (every index static); NXT == 0: run-time nx (<= 32).
+template <int NXT>
 __global__ __launch_bounds__(256) void predict_state_kernel(
     double *__restrict__ state, const double *__restrict__ control, const double *__restrict__ disturbance,
-    const double *__restrict__ dyn, int nx, int nu, int nd, long long n) {
+    const double *__restrict__ dyn, int nx_rt, int nu, int nd, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double xo[32];
-    for (int c = 0; c < nx; c++) xo[c] = state[i * nx + c];
-    int disp = 0;
-    for (int a = 0; a < nx; a++) {
-        double acc = dyn[disp++];
-        for (int c = 0; c < nx; c++) acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], xo[c]));
-        for (int l = 0; l < nu; l++) acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], control[i * nu + l]));
+    constexpr int NXA = NXT > 0 ? NXT : 32;
+    const int nx = NXT > 0 ? NXT : nx_rt;
+    double xo[NXA], xn[NXA];
+    if constexpr (NXT > 0) {
+#pragma unroll
+        for (int c = 0; c < NXT; c++) xo[c] = state[i * NXT + c];
+    } else {
+        for (int c = 0; c < nx; c++) xo[c] = state[i * nx + c];
+    }
+    const int stride = 1 + nx + nu + nd;
+    auto row = [&](int a) -> double {
+        const double *d = dyn + a * stride;
+        double acc = d[0];
+        if constexpr (NXT > 0) {
+#pragma unroll
+            for (int c = 0; c < NXT; c++) acc = __dadd_rn(acc, __dmul_rn(d[1 + c], xo[c]));
+        } else {
+            for (int c = 0; c < nx; c++) acc = __dadd_rn(acc, __dmul_rn(d[1 + c], xo[c]));
+        }
+        for (int l = 0; l < nu; l++) acc = __dadd_rn(acc, __dmul_rn(d[1 + nx + l], control[i * nu + l]));
         for (int q = 0; q < nd; q++)
-            acc = __dadd_rn(acc, __dmul_rn(dyn[disp++], disturbance ? disturbance[i * nd + q] : 0.0));
-        state[i * nx + a] = acc;
+            acc = __dadd_rn(acc, __dmul_rn(d[1 + nx + nu + q], disturbance ? disturbance[i * nd + q] : 0.0));
+        return acc;
+    };
+    if constexpr (NXT > 0) {
+#pragma unroll
+        for (int a = 0; a < NXT; a++) xn[a] = row(a);
+#pragma unroll
+        for (int a = 0; a < NXT; a++) state[i * NXT + a] = xn[a];
+    } else {
+        for (int a = 0; a < nx; a++) xn[a] = row(a);
+        for (int a = 0; a < nx; a++) state[i * nx + a] = xn[a];
     }
 }
 
+template <int NXT>
 __global__ __launch_bounds__(256) void correct_state_kernel(
     double *__restrict__ state, const double *__restrict__ measurement, const double *__restrict__ disturbance,
-    const double *__restrict__ meas, const double *__restrict__ kt, int nx, int ny, int nd, long long n) {
+    const double *__restrict__ meas, const double *__restrict__ kt, int nx_rt, int ny, int nd, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    double xo[32], xn[32];
-    for (int c = 0; c < nx; c++) { xo[c] = state[i * nx + c]; xn[c] = xo[c]; }
-    int dc = 0, dk = 0;
-    for (int j = 0; j < ny; j++) {
-        double inno = __dsub_rn(measurement[i * ny + j], meas[dc++]);
-        for (int c = 0; c < nx; c++) inno = __dsub_rn(inno, __dmul_rn(meas[dc++], xo[c]));
-        for (int q = 0; q < nd; q++)
-            inno = __dsub_rn(inno, __dmul_rn(meas[dc++], disturbance ? disturbance[i * nd + q] : 0.0));
-        for (int c = 0; c < nx; c++) xn[c] = __dadd_rn(xn[c], __dmul_rn(kt[dk++], inno));
+    constexpr int NXA = NXT > 0 ? NXT : 32;
+    const int nx = NXT > 0 ? NXT : nx_rt;
+    double xo[NXA], xn[NXA];
+    if constexpr (NXT > 0) {
+#pragma unroll
+        for (int c = 0; c < NXT; c++) { xo[c] = state[i * NXT + c]; xn[c] = xo[c]; }
+    } else {
+        for (int c = 0; c < nx; c++) { xo[c] = state[i * nx + c]; xn[c] = xo[c]; }
     }
-    for (int c = 0; c < nx; c++) state[i * nx + c] = xn[c];
+    const int stride = 1 + nx + nd;
+    for (int j = 0; j < ny; j++) {
+        const double *mr = meas + j * stride;
+        double inno = __dsub_rn(measurement[i * ny + j], mr[0]);
+        if constexpr (NXT > 0) {
+#pragma unroll
+            for (int c = 0; c < NXT; c++) inno = __dsub_rn(inno, __dmul_rn(mr[1 + c], xo[c]));
+        } else {
+            for (int c = 0; c < nx; c++) inno = __dsub_rn(inno, __dmul_rn(mr[1 + c], xo[c]));
+        }
+        for (int q = 0; q < nd; q++)
+            inno = __dsub_rn(inno, __dmul_rn(mr[1 + nx + q], disturbance ? disturbance[i * nd + q] : 0.0));
+        if constexpr (NXT > 0) {
+#pragma unroll
+            for (int c = 0; c < NXT; c++) xn[c] = __dadd_rn(xn[c], __dmul_rn(kt[j * NXT + c], inno));
+        } else {
+            for (int c = 0; c < nx; c++) xn[c] = __dadd_rn(xn[c], __dmul_rn(kt[j * nx + c], inno));
+        }
+    }
+    if constexpr (NXT > 0) {
+#pragma unroll
+        for (int c = 0; c < NXT; c++) state[i * NXT + c] = xn[c];
+    } else {
+        for (int c = 0; c < nx; c++) state[i * nx + c] = xn[c];
+    }
 }
 
 // theta = [x; r; uprev] records -> the caller's x and uprev arrays (end of a fused closed loop)
