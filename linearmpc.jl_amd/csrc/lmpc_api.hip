@@ -219,7 +219,7 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
     return LMPC_OK;
 }
 
-template <int NTHMAX, int NT, bool SIM>
+template <int NTHMAX, int NT, int MODE>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, int32_t *count, hipStream_t st) {
     const int B = 256;
@@ -227,7 +227,7 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
-    hipLaunchKernelGGL((screen_kernel<NTHMAX, NT, SIM>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
+    hipLaunchKernelGGL((screen_kernel<NTHMAX, NT, MODE>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
                        iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
@@ -278,6 +278,12 @@ int ensure_f32(lmpc_handle *h) {
     return LMPC_OK;
 }
 
+// does a batch of this handle go through the screening pass first?
+bool will_screen(const lmpc_handle *h, int64_t nprob) {
+    return !h->useWave && h->screen && h->L.eq_mask == 0ull && h->S.iter_limit > 1 && h->P.nth >= 1 &&
+           h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
+}
+
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     if (h->useWave) return launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
@@ -300,8 +306,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     // Cold starts without initially-active rows go through the screening pass first.
     // (warm starts too: the screening pass finishes the problems whose warm mask is empty and whose
     // unconstrained optimum is feasible, everything else is queued with its mask)
-    const bool screened = h->screen && h->L.eq_mask == 0ull && h->S.iter_limit > 1 &&
-                          h->P.nth >= 1 && h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
+    const bool screened = will_screen(h, nprob);
     static_assert((kShards & (kShards - 1)) == 0, "the screening kernel masks the shard index");
     if (screened && nprob > h->listCap) {
         hipFree(h->dList); hipFree(h->dCount);
@@ -322,14 +327,17 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     }
     int rc = LMPC_OK;
     const bool sim = h->L.sim.FG != nullptr;      // closed-loop instantiations (SimFuse), lmpc_simulate* only
+    const bool gather = !sim && h->L.gat.state != nullptr;   // generated-controller screening (GatherArgs)
+    if (gather && !screened) return fail(h, LMPC_ERR_BADARG, "lmpc: gather mode needs the screening pass");
     // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
     int32_t *cnt_now = nullptr, *cnt_next = nullptr;
     if (screened) {
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
-#define LMPC_SCR(NM, NT) (sim ? launch_screen<NM, NT, true>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
-                              : launch_screen<NM, NT, false>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+#define LMPC_SCR(NM, NT) (sim ? launch_screen<NM, NT, 1>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                         : gather ? launch_screen<NM, NT, 2>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                                  : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
         switch (h->P.nth <= 16 ? h->P.nth : 32) {       // exact column count up to 16, padded beyond
             case 1: rc = LMPC_SCR(8, 1); break;    case 2: rc = LMPC_SCR(8, 2); break;
             case 3: rc = LMPC_SCR(8, 3); break;    case 4: rc = LMPC_SCR(8, 4); break;
@@ -781,6 +789,20 @@ int lmpc_compute_control_device(lmpc_handle *h, int64_t N, double *control, cons
         HIP_TRY(h, hipMalloc(&h->ccFlag, sizeof(int32_t) * (size_t)N));
         h->ccCap = N;
     }
+    // lane / screening path without reference condensation: the screening kernel assembles theta from the
+    // five arrays itself (GatherArgs) and hands the records of the problems that need iterations to the
+    // iterating kernel through ccTheta -- no theta buffer is written or read for the others
+    if (will_screen(h, N) && h->ccNph == 0 && h->ccFused) {
+        h->L.gat = GatherArgs{state, reference, disturbance, control, affine_parameter, h->ccTheta,
+                              h->ccNx, h->ccNr, h->ccNd, h->ccNup, h->ccNp, h->P.nout};
+        const bool use_warm_g = warm && h->ccWarmN == N;
+        int rcg = launch(h, N, h->ccTheta, control, exitflag ? exitflag : h->ccFlag, nullptr, warm ? h->ccAct : nullptr,
+                         use_warm_g ? h->ccAct : nullptr, st);
+        h->L.gat = GatherArgs{};
+        if (rcg != LMPC_OK) return rcg;
+        h->ccWarmN = warm ? N : -1;
+        return LMPC_OK;
+    }
     const long long total = (long long)N * h->P.nth;
     if (total > 0) {
         hipLaunchKernelGGL(update_parameter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -1042,6 +1064,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");

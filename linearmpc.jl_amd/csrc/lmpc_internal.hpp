@@ -64,6 +64,7 @@ struct lmpc_handle {
     int numCU = 256;
     // closed-loop simulation scratch
     double *simTheta = nullptr, *simTheta2 = nullptr, *simU = nullptr, *simFG = nullptr;
+    int ccFused = 1;            // tuning: lmpc_compute_control assembles theta inside the screening kernel ("cc_fused")
     int simFused = 1;           // tuning: plant step inside the lane / screening kernels (lmpc_set_option "sim_fused")
     int32_t *simFlag = nullptr;
     uint64_t *simAct = nullptr;

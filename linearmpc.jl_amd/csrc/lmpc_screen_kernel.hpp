@@ -35,7 +35,8 @@ constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 // NTHMAX: column stride of the padded rows (8, 16 or 32).  NT: columns the unrolled chains run over --
 // the exact nth for nth <= 16 (one instantiation per value: with three batches in flight the pass is
 // bound by vector issue, and the padded column of the 7-parameter pendulum cost 6 %), else NTHMAX.
-template <int NTHMAX, int NT, bool SIM>
+// MODE: 0 the plain solve, 1 closed loop (SimFuse), 2 generated controller (GatherArgs).
+template <int NTHMAX, int NT, int MODE>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
     const double ntol = -P.primal_tol;
     const int lane = tid & 63;
     const int shard = blockIdx.x & (nshards - 1);      // nshards is a power of two (checked by the host)
+    constexpr bool SIM = MODE == 1, GATHER = MODE == 2;
 
     double nx[NT];                                     // record of the problem after the current one
     // No guard on any load: a problem index past the end is clamped to the last problem (its results are
@@ -54,11 +56,30 @@ __global__ __launch_bounds__(256) void screen_kernel(
     // (Guarded, every one of the loads sat in its own exec-masked block: six scalar instructions and a
     // branch per parameter.)
     auto load_record = [&](long long pid, double *dst) {
-        const double *src = theta + (pid < nprob ? pid : nprob - 1) * nth;
+        const long long pc = pid < nprob ? pid : nprob - 1;
+        if constexpr (GATHER) {
+            // theta = [state; reference; disturbance; control[0:nup]; parameter] straight from the caller's
+            // arrays (codegen/mpc_update_parameter.c without the detour through a theta buffer); a NULL
+            // array stands for zeros
+            const GatherArgs &Ga = P.gat;
+            const int o1 = Ga.nx, o2 = o1 + Ga.nr, o3 = o2 + Ga.nd, o4 = o3 + Ga.nup;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                double v = 0.0;
+                if (t < o1) v = Ga.state[pc * Ga.nx + t];
+                else if (t < o2) { if (Ga.reference) v = Ga.reference[pc * Ga.nr + (t - o1)]; }
+                else if (t < o3) { if (Ga.disturbance) v = Ga.disturbance[pc * Ga.nd + (t - o2)]; }
+                else if (t < o4) { if (Ga.control) v = Ga.control[pc * Ga.ncontrol + (t - o3)]; }
+                else if (t < nth) { if (Ga.parameter) v = Ga.parameter[pc * Ga.np + (t - o4)]; }
+                dst[t] = v;
+            }
+        } else {
+        const double *src = theta + pc * nth;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int tc = (NT <= 16 || t < nth) ? t : nth - 1;      // NT <= 16: NT == nth exactly
             dst[t] = (ablate & 8) ? src[tc] : __builtin_nontemporal_load(src + tc);
+        }
         }
     };
     load_record(first, nx);
@@ -145,7 +166,18 @@ __global__ __launch_bounds__(256) void screen_kernel(
         // behind this one on the same stream and overwrites theirs): the stores of a wavefront then
         // cover whole lines instead of lines with holes; they bypass the caches (written once, read by
         // nobody on this GPU soon)
-        const bool fill = (ablate & 16) ? (valid && !hard) : valid;
+        // (generated-controller mode: X is the caller's control array, whose previous-control entries the
+        // iterating kernel's problems have not consumed yet -- there only finished problems are written, and
+        // the queued ones get their assembled record handed over instead)
+        const bool fill = ((ablate & 16) || GATHER) ? (valid && !hard) : valid;
+        if constexpr (GATHER) {
+            if (hard) {
+                double *to = P.gat.theta_out + pid * nth;
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+                    if (NT <= 16 || t < nth) to[t] = th[t];
+            }
+        }
         if (fill && !(ablate & 4)) {
             const double *xk = C + P.oXthP;
             double uo[kMaxSimU];

@@ -17,6 +17,15 @@ struct SimFuse {
     int nx, nu, nr, nup, first;
 };
 
+// Generated-controller mode of the screening kernel (lmpc_compute_control*): theta is not read from a
+// buffer but assembled from the five argument arrays of mpc_compute_control (state == nullptr: off);
+// problems that need iterations get their record written to theta_out for the iterating kernel.
+struct GatherArgs {
+    const double *state, *reference, *disturbance, *control, *parameter;
+    double *theta_out;
+    int nx, nr, nd, nup, np, ncontrol;
+};
+
 // Offsets (in doubles) of the constant arrays inside the single device buffer.
 struct PackLayout {
     int n, m, ms, nth, nout, words;
@@ -28,6 +37,7 @@ struct PackLayout {
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int cycle_tol, iter_limit;
     SimFuse sim;
+    GatherArgs gat;
 };
 
 struct WaveLayout {
