@@ -233,8 +233,10 @@ __global__ __launch_bounds__(256) void screen_kernel(
             }
             if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
             else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
-            if (iters) iters[pid] = 1;
-            if (active)
+            // (iteration count and active set only for the problems finished here: `active` may be the
+            // very buffer the iterating kernel still has to read its warm-start masks from)
+            if (iters && !hard) iters[pid] = 1;
+            if (active && !hard)
                 for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;
         }
     }

@@ -1142,3 +1142,48 @@ def test_randomized_differential_against_the_oracle(lmpc):
             _compare(qp, theta[ok][:64], warm=act[ok][:64])
     assert kinds["lane"] >= 10 and kinds["wave"] >= 10, kinds
     assert {1, -1} <= seen_flags and (2 in seen_flags), seen_flags
+
+
+@pytest.mark.parametrize("layout", [(2, 1, 2, 1, 2), (3, 0, 0, 2, 0), (1, 2, 0, 0, 3), (4, 2, 1, 1, 1)])
+def test_generated_controller_all_blocks_fused_and_unfused(lmpc, layout):
+    # theta = [state; reference; disturbance; control[0:nup]; affine_parameter] assembled inside the
+    # screening kernel (default on the lane path) or by update_parameter_kernel ("cc_fused" 0): both must
+    # equal solve(theta) bit for bit, with NULL blocks standing for zeros and with the DAQP_WARMSTART mode
+    nx, nr, nd, nup, npar = layout
+    nth = nx + nr + nd + nup + npar
+    nu = max(nup, 1) + 1
+    rng = np.random.default_rng(sum(layout))
+    n, mg = 2 * nu, 6
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth)
+    N = 3000
+    blocks = [rng.uniform(-1.5, 1.5, (N, w)) for w in (nx, nr, nd, nu, npar)]
+    theta = np.ascontiguousarray(np.hstack([blocks[0], blocks[1], blocks[2], blocks[3][:, :nup], blocks[4]]))
+    ref_qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+    xr, efr, _, actr = ref_qp.solve(theta)
+    assert "lane" in ref_qp.kernel_name and (efr >= 1).mean() > 0.3
+    for fused in (1, 0):
+        qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+        qp.set_option("cc_fused", fused)
+        qp.set_parameter_layout(nx, nr, nd, nup, npar)
+        control = np.ascontiguousarray(blocks[3].copy())
+        ef = qp.compute_control(control, blocks[0], blocks[1] if nr else None, blocks[2] if nd else None,
+                                blocks[4] if npar else None)
+        assert np.array_equal(ef, efr) and np.array_equal(control, xr)
+        # warm: the second call starts from the first call's working sets
+        control = np.ascontiguousarray(blocks[3].copy())
+        qp.compute_control(control, blocks[0], blocks[1] if nr else None, blocks[2] if nd else None,
+                           blocks[4] if npar else None, warm=True)
+        c2 = np.ascontiguousarray(blocks[3].copy())
+        ef2 = qp.compute_control(c2, blocks[0], blocks[1] if nr else None, blocks[2] if nd else None,
+                                 blocks[4] if npar else None, warm=True)
+        xw, efw, _, _ = ref_qp.solve(theta, warm=actr)
+        assert np.array_equal(ef2, efw) and np.array_equal(c2, xw)
+    # NULL blocks = zeros
+    if nr or nd or npar:
+        th0 = theta.copy()
+        th0[:, nx:nx + nr + nd] = 0
+        th0[:, nx + nr + nd + nup:] = 0
+        control = np.ascontiguousarray(blocks[3].copy())
+        qp.set_option("cc_fused", 1)
+        qp.compute_control(control, blocks[0], None, None, None)
+        assert np.array_equal(control, ref_qp.solve(th0)[0])
