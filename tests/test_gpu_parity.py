@@ -1187,3 +1187,24 @@ def test_generated_controller_all_blocks_fused_and_unfused(lmpc, layout):
         qp.set_option("cc_fused", 1)
         qp.compute_control(control, blocks[0], None, None, None)
         assert np.array_equal(control, ref_qp.solve(th0)[0])
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "soft_doc"])
+def test_warm_masks_in_place(lmpc, name):
+    # the closed loop and the generated controller keep ONE mask buffer per handle: the previous call's
+    # final working sets are read (warm) and this call's are written (active) in the same place -- lane /
+    # screening path and wavefront path alike; results must equal the two-buffer call
+    import torch
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g, 1)
+    theta = g["theta"]
+    x0, ef0, it0, act0 = qp.solve(theta)
+    xw, efw, itw, actw = qp.solve(theta, warm=act0)
+    dev = torch.device("cuda", 0)
+    th = torch.from_numpy(theta).to(dev)
+    buf = torch.from_numpy(act0.view(np.int64).copy()).to(dev)
+    it = torch.empty(len(theta), dtype=torch.int32, device=dev)
+    x, ef = qp.solve_device(th, iters=it, active=buf, warm=buf)
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy(), xw) and np.array_equal(ef.cpu().numpy(), efw)
+    assert np.array_equal(it.cpu().numpy(), itw) and np.array_equal(buf.cpu().numpy().view(np.uint64), actw)
