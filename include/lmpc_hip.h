@@ -201,6 +201,19 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
                          double *U_traj, double *X_traj, int32_t *flag_min, int warm, void *stream);
 
 /*
+ * The closed loop in binary32 -- the reference's generated controller built with float_type = "float"
+ * (codegen.jl:19,31-37) inside a simulation: x, r, uprev and the trajectories are float records, the
+ * plant (F, G: HOST binary64 arrays as everywhere) is rounded to binary32 like the constant pack, the
+ * plant step is an fmaf chain in the same order.  Wavefront kernel (see lmpc_solve_batch_f32).
+ */
+int lmpc_simulate_f32(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev,
+                      const double *F, const double *G, float *x, const float *r, float *uprev,
+                      float *U_traj, float *X_traj, int32_t *flag_min, int warm);
+int lmpc_simulate_f32_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev,
+                             const double *F, const double *G, float *x, const float *r, float *uprev,
+                             float *U_traj, float *X_traj, int32_t *flag_min, int warm, void *stream);
+
+/*
  * Batched form_parameter on the device, previews included: theta_i = [x_i; r; d; uprev_i; p]
  * (reference explicit.jl:54-63) with r, d, p formatted as format_reference / format_disturbance /
  * format_affine_parameters do (utils.jl:78-261) and, inside a closed loop, as Simulation's

@@ -23,7 +23,7 @@ SYMBOLS = (
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
     "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one",
     "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
-    "lmpc_simulate_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
+    "lmpc_simulate_device", "lmpc_simulate_f32", "lmpc_simulate_f32_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
     "lmpc_set_parameter_layout", "lmpc_compute_control", "lmpc_compute_control_device",
     "lmpc_set_observer", "lmpc_predict_state", "lmpc_correct_state", "lmpc_predict_state_device",
     "lmpc_correct_state_device",
@@ -112,6 +112,10 @@ def lib():
     L.lmpc_simulate.restype = i32
     L.lmpc_simulate_device.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32, vp]
     L.lmpc_simulate_device.restype = i32
+    L.lmpc_simulate_f32.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32]
+    L.lmpc_simulate_f32.restype = i32
+    L.lmpc_simulate_f32_device.argtypes = [vp, i64] + [i32] * 4 + [vp] * 8 + [i32, vp]
+    L.lmpc_simulate_f32_device.restype = i32
     bp = ctypes.POINTER(Block)
     L.lmpc_form_parameter_device.argtypes = [vp, i64, vp, vp, i32, bp, bp, vp, i32, bp, vp]
     L.lmpc_form_parameter_device.restype = i32

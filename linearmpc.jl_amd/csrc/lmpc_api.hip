@@ -610,7 +610,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
     const unsigned grid = (unsigned)((N + 255) / 256);
     // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
-    hipLaunchKernelGGL(form_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
+    hipLaunchKernelGGL(form_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
                        nuprev, (long long)N);
     // Lane / screening kernels: the kernel that finishes a problem also advances its scenario and
     // writes the next step's record into the other theta buffer (SimFuse) -- a closed-loop step is
@@ -643,13 +643,103 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
         if (rc != LMPC_OK) return rc;
         const bool last = k == T - 1;
-        hipLaunchKernelGGL(plant_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, h->P.nth, nr, h->simU,
+        hipLaunchKernelGGL(plant_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, h->P.nth, nr, h->simU,
                            h->simFlag, h->simFG, nx, nu, nuprev,
                            X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
                            U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0,
                            last ? x : nullptr, (last && nuprev > 0) ? uprev : nullptr, (long long)N);
         HIP_TRY(h, hipGetLastError());
     }
+    return LMPC_OK;
+}
+
+int lmpc_simulate_f32_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F,
+                             const double *G, float *x, const float *r, float *uprev, float *U_traj,
+                             float *X_traj, int32_t *flag_min, int warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    const int nu = h->P.nout;
+    if (N < 0 || T < 0 || nx <= 0 || nx > 32 || nr < 0 || nuprev < 0 || nuprev > nu || nu > 64 || !F || !G ||
+        (N > 0 && !x) || (nuprev > 0 && N > 0 && !uprev) || nx + nr + nuprev != h->P.nth)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_simulate_f32_device: theta = [x; r; uprev] must match the handle "
+                                        "(nx + nr + nuprev == nth, nout == nu, nx <= 32)");
+    if (N == 0 || T == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_f32(h);
+    if (rc != LMPC_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w = (size_t)h->P.words();
+    if (N > h->simCap) {      // the binary64-sized scratch of the closed loop serves both precisions
+        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
+        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
+        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
+        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
+        h->simCap = N;
+    }
+    float *dTh = reinterpret_cast<float *>(h->simTheta), *dU = reinterpret_cast<float *>(h->simU),
+          *dFG = reinterpret_cast<float *>(h->simFG);
+    std::vector<float> fg((size_t)nx * nx + (size_t)nx * nu);       // the plant rounded to binary32, like the pack
+    for (int i = 0; i < nx * nx; i++) fg[i] = (float)F[i];
+    for (int i = 0; i < nx * nu; i++) fg[(size_t)nx * nx + i] = (float)G[i];
+    HIP_TRY(h, hipMemcpy(dFG, fg.data(), sizeof(float) * fg.size(), hipMemcpyHostToDevice));
+    if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(float) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(form_theta_kernel<float>, dim3(grid), dim3(256), 0, st, dTh, x, r, uprev, nx, nr, nuprev,
+                       (long long)N);
+    for (int k = 0; k < T; k++) {
+        const uint64_t *wm = (warm && k > 0 && !h->bnb) ? h->simAct : nullptr;
+        rc = launch_wave_t<float>(h, h->dCwf, N, dTh, dU, h->simFlag, nullptr, (warm && !h->bnb) ? h->simAct : nullptr,
+                                  wm, st);
+        if (rc != LMPC_OK) return rc;
+        const bool last = k == T - 1;
+        hipLaunchKernelGGL(plant_theta_kernel<float>, dim3(grid), dim3(256), 0, st, dTh, h->P.nth, nr, dU, h->simFlag,
+                           dFG, nx, nu, nuprev, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                           U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0,
+                           last ? x : nullptr, (last && nuprev > 0) ? uprev : nullptr, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return LMPC_OK;
+}
+
+int lmpc_simulate_f32(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F, const double *G,
+                      float *x, const float *r, float *uprev, float *U_traj, float *X_traj, int32_t *flag_min,
+                      int warm) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N <= 0 || T <= 0) return N < 0 || T < 0 ? LMPC_ERR_BADARG : LMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int nu = h->P.nout;
+    float *dx = nullptr, *dr = nullptr, *du = nullptr, *dU = nullptr, *dX = nullptr;
+    int32_t *df = nullptr;
+    auto cleanup = [&]() { hipFree(dx); hipFree(dr); hipFree(du); hipFree(dU); hipFree(dX); hipFree(df); };
+#define SIMF_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
+        return fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+    SIMF_TRY(hipMalloc(&dx, sizeof(float) * (size_t)N * nx));
+    SIMF_TRY(hipMemcpy(dx, x, sizeof(float) * (size_t)N * nx, hipMemcpyHostToDevice));
+    if (r && nr > 0) {
+        SIMF_TRY(hipMalloc(&dr, sizeof(float) * (size_t)N * nr));
+        SIMF_TRY(hipMemcpy(dr, r, sizeof(float) * (size_t)N * nr, hipMemcpyHostToDevice));
+    }
+    if (uprev && nuprev > 0) {
+        SIMF_TRY(hipMalloc(&du, sizeof(float) * (size_t)N * nuprev));
+        SIMF_TRY(hipMemcpy(du, uprev, sizeof(float) * (size_t)N * nuprev, hipMemcpyHostToDevice));
+    }
+    if (U_traj) SIMF_TRY(hipMalloc(&dU, sizeof(float) * (size_t)T * N * nu));
+    if (X_traj) SIMF_TRY(hipMalloc(&dX, sizeof(float) * (size_t)(T + 1) * N * nx));
+    if (flag_min) SIMF_TRY(hipMalloc(&df, sizeof(int32_t) * (size_t)N));
+    int rc = lmpc_simulate_f32_device(h, N, T, nx, nr, nuprev, F, G, dx, dr, du, dU, dX, df, warm, nullptr);
+    if (rc != LMPC_OK) { cleanup(); return rc; }
+    SIMF_TRY(hipMemcpy(x, dx, sizeof(float) * (size_t)N * nx, hipMemcpyDeviceToHost));
+    if (du) SIMF_TRY(hipMemcpy(uprev, du, sizeof(float) * (size_t)N * nuprev, hipMemcpyDeviceToHost));
+    if (dU) SIMF_TRY(hipMemcpy(U_traj, dU, sizeof(float) * (size_t)T * N * nu, hipMemcpyDeviceToHost));
+    if (dX) SIMF_TRY(hipMemcpy(X_traj, dX, sizeof(float) * (size_t)(T + 1) * N * nx, hipMemcpyDeviceToHost));
+    if (df) SIMF_TRY(hipMemcpy(flag_min, df, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+#undef SIMF_TRY
+    cleanup();
     return LMPC_OK;
 }
 

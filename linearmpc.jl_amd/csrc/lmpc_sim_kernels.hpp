@@ -8,17 +8,21 @@
 
 namespace lmpc {
 
+__device__ __forceinline__ double sim_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float sim_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // theta_i = [x_i ; r_i ; uprev_i]   (reference src/explicit.jl:54-63 with nd = np = 0)
+template <typename R>
 __global__ __launch_bounds__(256) void form_theta_kernel(
-    double *__restrict__ theta, const double *__restrict__ x, const double *__restrict__ r,
-    const double *__restrict__ uprev, int nx, int nr, int nup, long long n) {
+    R *__restrict__ theta, const R *__restrict__ x, const R *__restrict__ r,
+    const R *__restrict__ uprev, int nx, int nr, int nup, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int nth = nx + nr + nup;
-    double *t = theta + i * nth;
+    R *t = theta + i * nth;
     for (int k = 0; k < nx; k++) t[k] = x[i * nx + k];
-    for (int k = 0; k < nr; k++) t[nx + k] = r ? r[i * nr + k] : 0.0;
-    for (int k = 0; k < nup; k++) t[nx + nr + k] = uprev ? uprev[i * nup + k] : 0.0;
+    for (int k = 0; k < nr; k++) t[nx + k] = r ? r[i * nr + k] : (R)0;
+    for (int k = 0; k < nup; k++) t[nx + nr + k] = uprev ? uprev[i * nup + k] : (R)0;
 }
 
 // One block of theta taken from a trajectory: `w` values per column, `T` columns stored column by
@@ -155,21 +159,22 @@ __global__ __launch_bounds__(256) void plant_kernel(
 // with a constant reference then moves 2 x 8 nth + 8 nu bytes per scenario and step instead of
 // re-reading x and re-writing the whole record in a separate kernel).  Same sums in the same order
 // as plant_kernel.  x_out / uprev_out (last step): the caller's arrays.
+template <typename R>
 __global__ __launch_bounds__(256) void plant_theta_kernel(
-    double *__restrict__ theta, int nth, int nr, const double *__restrict__ u,
-    const int32_t *__restrict__ flag, const double *__restrict__ FG, int nx, int nu, int nup,
-    double *__restrict__ xtraj_next, double *__restrict__ utraj, int32_t *__restrict__ flag_min,
-    int first, double *__restrict__ x_out, double *__restrict__ uprev_out, long long n) {
+    R *__restrict__ theta, int nth, int nr, const R *__restrict__ u,
+    const int32_t *__restrict__ flag, const R *__restrict__ FG, int nx, int nu, int nup,
+    R *__restrict__ xtraj_next, R *__restrict__ utraj, int32_t *__restrict__ flag_min,
+    int first, R *__restrict__ x_out, R *__restrict__ uprev_out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double *F = FG, *G = FG + nx * nx;
-    double *t = theta + i * nth;
-    double xo[32], xn[32];
+    const R *F = FG, *G = FG + nx * nx;
+    R *t = theta + i * nth;
+    R xo[32], xn[32];
     for (int c = 0; c < nx; c++) xo[c] = t[c];
     for (int a = 0; a < nx; a++) {
-        double acc = 0.0;
-        for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], xo[c], acc);
-        for (int l = 0; l < nu; l++) acc = __builtin_fma(G[a * nu + l], u[i * nu + l], acc);
+        R acc = (R)0;
+        for (int c = 0; c < nx; c++) acc = sim_fma(F[a * nx + c], xo[c], acc);
+        for (int l = 0; l < nu; l++) acc = sim_fma(G[a * nu + l], u[i * nu + l], acc);
         xn[a] = acc;
     }
     for (int a = 0; a < nx; a++) {
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void plant_theta_kernel(
         if (x_out) x_out[i * nx + a] = xn[a];
     }
     for (int l = 0; l < nu; l++) {
-        const double ul = u[i * nu + l];
+        const R ul = u[i * nu + l];
         if (l < nup) {
             t[nx + nr + l] = ul;
             if (uprev_out) uprev_out[i * nup + l] = ul;

@@ -235,6 +235,31 @@ class BatchedQP:
                                   _ptr(fm), int(bool(warm))), self._h)
         return dict(x=x, U=U, X=X, uprev=up, flag_min=fm)
 
+    def simulate_f32(self, x0, T, F, G, r=None, uprev=None, warm=True, want_x=True):
+        """Binary32 closed loop (`lmpc_simulate_f32`): float32 arrays in and out, wavefront kernel."""
+        F = _f64(np.atleast_2d(F))
+        nx = F.shape[0]
+        nu = self.nout
+        G = _f64(np.asarray(G, float).reshape(nx, nu))
+        x = np.ascontiguousarray(np.array(np.asarray(x0, np.float32).reshape(-1, nx), copy=True))
+        N = x.shape[0]
+        nr = 0 if r is None else np.asarray(r).reshape(N, -1).shape[1]
+        nup = self.nth - nx - nr
+        if nup < 0 or nup > nu:
+            raise ValueError("theta = [x; r; uprev] does not match this handle")
+        rr = None if nr == 0 else np.ascontiguousarray(np.asarray(r, np.float32).reshape(N, nr))
+        up = None
+        if nup:
+            up = np.ascontiguousarray(np.zeros((N, nup), np.float32) if uprev is None
+                                      else np.array(np.asarray(uprev, np.float32).reshape(N, nup), copy=True))
+        U = np.empty((T, N, nu), np.float32)
+        X = np.empty((T + 1, N, nx), np.float32) if want_x else None
+        fm = np.empty(N, np.int32)
+        check(lib().lmpc_simulate_f32(self._h, N, int(T), nx, nr, nup, _ptr(F), _ptr(G), _ptr(x),
+                                      _ptr(rr) if rr is not None else None, _ptr(up) if up is not None else None,
+                                      _ptr(U), _ptr(X) if X is not None else None, _ptr(fm), int(bool(warm))), self._h)
+        return dict(x=x, U=U, X=X, uprev=up, flag_min=fm)
+
     # ------------------------------------------------------------------ theta on the device, previews
     @staticmethod
     def _block(t, H=0, k0=0):

@@ -179,31 +179,35 @@ def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None, dt
     return X, ef, it, act
 
 
-def simulate(ldp: LDP, x0, T, F, G, r=None, uprev=None, settings: Settings | None = None, warm=True):
-    """Closed loop on the CPU oracle (oracle_simulate): returns dict(x, U (T,N,nu), X (T+1,N,nx), uprev, flag_min)."""
+def simulate(ldp: LDP, x0, T, F, G, r=None, uprev=None, settings: Settings | None = None, warm=True,
+             dtype=np.float64):
+    """Closed loop on the CPU oracle (oracle_simulate): returns dict(x, U (T,N,nu), X (T+1,N,nx), uprev, flag_min).
+    dtype=np.float32: the binary32 build of the oracle on the pack and the plant rounded to binary32."""
     Lb = lib()
     ldp.contiguous()
-    F = np.ascontiguousarray(np.atleast_2d(np.asarray(F, np.float64)))
+    f32 = np.dtype(dtype) == np.float32
+    F = np.ascontiguousarray(np.atleast_2d(np.asarray(F, np.float64)).astype(dtype))
     nx = F.shape[0]
     nu = ldp.nout
-    G = np.ascontiguousarray(np.asarray(G, np.float64).reshape(nx, nu))
-    x = np.ascontiguousarray(np.array(np.asarray(x0, np.float64).reshape(-1, nx), copy=True))
+    G = np.ascontiguousarray(np.asarray(G, np.float64).reshape(nx, nu).astype(dtype))
+    x = np.ascontiguousarray(np.array(np.asarray(x0, dtype).reshape(-1, nx), copy=True))
     N = x.shape[0]
     nr = 0 if r is None else np.asarray(r).reshape(N, -1).shape[1]
     nup = ldp.nth - nx - nr
-    rr = None if nr == 0 else np.ascontiguousarray(np.asarray(r, np.float64).reshape(N, nr))
-    up = np.ascontiguousarray(np.zeros((N, max(nup, 1))) if uprev is None else
-                              np.array(np.asarray(uprev, np.float64).reshape(N, nup), copy=True))
-    U = np.empty((T, N, nu))
-    X = np.empty((T + 1, N, nx))
+    rr = None if nr == 0 else np.ascontiguousarray(np.asarray(r, dtype).reshape(N, nr))
+    up = np.ascontiguousarray(np.zeros((N, max(nup, 1)), dtype) if uprev is None else
+                              np.array(np.asarray(uprev, dtype).reshape(N, nup), copy=True))
+    U = np.empty((T, N, nu), dtype)
+    X = np.empty((T + 1, N, nx), dtype)
     fm = np.empty(N, np.int32)
-    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout,
-              *(a.ctypes.data for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0, ldp.Xth, ldp.sense)))
-    s = settings if settings is not None else default_settings()
-    Lb.oracle_simulate.restype = None
+    arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0, ldp.Xth)]
+    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout, *(a.ctypes.data for a in arrs), ldp.sense.ctypes.data)
+    s = settings if settings is not None else (default_settings_f32() if f32 else default_settings())
+    fn = Lb.oracle_simulate_f32 if f32 else Lb.oracle_simulate
+    fn.restype = None
     vp = ctypes.c_void_p
-    Lb.oracle_simulate(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_int32(T), ctypes.c_int32(nx),
-                       ctypes.c_int32(nr), ctypes.c_int32(nup), vp(F.ctypes.data), vp(G.ctypes.data), vp(x.ctypes.data),
-                       vp(rr.ctypes.data) if rr is not None else None, vp(up.ctypes.data), vp(U.ctypes.data),
-                       vp(X.ctypes.data), vp(fm.ctypes.data), ctypes.c_int32(int(bool(warm))))
+    fn(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_int32(T), ctypes.c_int32(nx),
+       ctypes.c_int32(nr), ctypes.c_int32(nup), vp(F.ctypes.data), vp(G.ctypes.data), vp(x.ctypes.data),
+       vp(rr.ctypes.data) if rr is not None else None, vp(up.ctypes.data), vp(U.ctypes.data),
+       vp(X.ctypes.data), vp(fm.ctypes.data), ctypes.c_int32(int(bool(warm))))
     return dict(x=x, U=U, X=X, uprev=up[:, :nup], flag_min=fm)

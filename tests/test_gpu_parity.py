@@ -1208,3 +1208,29 @@ def test_warm_masks_in_place(lmpc, name):
     torch.cuda.synchronize()
     assert np.array_equal(x.cpu().numpy(), xw) and np.array_equal(ef.cpu().numpy(), efw)
     assert np.array_equal(it.cpu().numpy(), itw) and np.array_equal(buf.cpu().numpy().view(np.uint64), actw)
+
+
+@pytest.mark.parametrize("name,warm", [("pendulum", False), ("pendulum", True), ("soft_doc", True)])
+def test_f32_closed_loop_matches_the_f32_oracle(lmpc, name, warm):
+    # lmpc_simulate_f32: the reference's float_type="float" controller (codegen.jl:19,31-37) in a closed
+    # loop; checker: the binary32 build of the oracle's closed loop on the same rounded pack and plant
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    g = load_golden(name)
+    prob = omm.pendulum() if name == "pendulum" else omm.doc_simple_soft()
+    s32 = lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                  nout=int(g["nu"]), settings=s32)
+    nx = prob.F.shape[0]
+    rng = np.random.default_rng(12)
+    N, T = 96, 25
+    th = g["theta"][:N]
+    x0 = th[:, :nx].astype(np.float32)
+    nr = qp.nth - nx - int(g["nu"])
+    r = th[:, nx:nx + nr].astype(np.float32)
+    out = qp.simulate_f32(x0, T, prob.F, prob.G, r=r, warm=warm)
+    ref = oldp.simulate(oracle_ldp_from(qp.ldp()), x0, T, prob.F, prob.G, r=r, settings=_copy_settings(lmpc, s32),
+                        warm=warm, dtype=np.float32)
+    assert np.array_equal(out["flag_min"], ref["flag_min"])
+    assert np.abs(out["U"] - ref["U"]).max() <= 1e-6 and np.abs(out["X"] - ref["X"]).max() <= 1e-5
+    assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])      # observed: identical bits
