@@ -316,6 +316,19 @@ int lmpc_predict_state_device(lmpc_handle *h, int64_t N, double *state, const do
 int lmpc_correct_state_device(lmpc_handle *h, int64_t N, double *state, const double *measurement,
                               const double *disturbance, void *stream);
 
+/*
+ * The generated offset-free observer's controller call for N scenarios (reference src/observer.jl:156-196):
+ *   int mpc_compute_control_observer(control, observer_state, reference, measured_disturbance[, affine_parameter])
+ * = mpc_get_estimated_state (state = observer_state[0:n_state]) + mpc_get_estimated_disturbance (disturbance =
+ * [measured_disturbance or zeros; observer_state[n_state : n_state + n_offset_free]]) + mpc_compute_control.
+ * n_offset_free = the layout's n_disturbance - n_measured_disturbance; observer_state: N records of
+ * n_state + n_offset_free doubles.  DEVICE pointers, enqueued on `stream`.
+ */
+int lmpc_compute_control_observer_device(lmpc_handle *h, int64_t N, double *control, const double *observer_state,
+                                         int n_measured_disturbance, const double *reference,
+                                         const double *measured_disturbance, const double *affine_parameter,
+                                         int32_t *exitflag, int warm, void *stream);
+
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 

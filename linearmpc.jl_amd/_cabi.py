@@ -26,7 +26,7 @@ SYMBOLS = (
     "lmpc_simulate_device", "lmpc_simulate_f32", "lmpc_simulate_f32_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
     "lmpc_set_parameter_layout", "lmpc_compute_control", "lmpc_compute_control_device",
     "lmpc_set_observer", "lmpc_predict_state", "lmpc_correct_state", "lmpc_predict_state_device",
-    "lmpc_correct_state_device",
+    "lmpc_correct_state_device", "lmpc_compute_control_observer_device",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
 )
 
@@ -135,6 +135,8 @@ def lib():
     for fn in (L.lmpc_predict_state_device, L.lmpc_correct_state_device):
         fn.argtypes = [vp, i64, vp, vp, vp, vp]
         fn.restype = i32
+    L.lmpc_compute_control_observer_device.argtypes = [vp, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp]
+    L.lmpc_compute_control_observer_device.restype = i32
     L.lmpc_kernel_name.argtypes = [vp]
     L.lmpc_kernel_name.restype = ctypes.c_char_p
     L.lmpc_profile.argtypes = [vp, i32]

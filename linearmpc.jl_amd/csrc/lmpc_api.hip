@@ -928,7 +928,7 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     // [control | state | reference | disturbance | parameter] doubles, then the flags
     const size_t per = (size_t)nu + h->ccNx + wr + h->ccNd + h->ccNp;
     if (N > h->ccStageCap || per > h->ccStagePer) {
-        hipFree(h->ccStage); hipFree(h->ccStageFlag);
+        hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
         h->ccStage = nullptr; h->ccStageFlag = nullptr; h->ccStageCap = 0; h->ccStagePer = 0;
         HIP_TRY(h, hipMalloc(&h->ccStage, sizeof(double) * (size_t)N * per));
         HIP_TRY(h, hipMalloc(&h->ccStageFlag, sizeof(int32_t) * (size_t)N));
@@ -953,6 +953,40 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     HIP_TRY(h, hipMemcpy(control, dc, sizeof(double) * (size_t)N * nu, hipMemcpyDeviceToHost));
     if (exitflag) HIP_TRY(h, hipMemcpy(exitflag, h->ccStageFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
     return LMPC_OK;
+}
+
+int lmpc_compute_control_observer_device(lmpc_handle *h, int64_t N, double *control, const double *observer_state,
+                                         int n_measured_disturbance, const double *reference,
+                                         const double *measured_disturbance, const double *affine_parameter,
+                                         int32_t *exitflag, int warm, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (h->ccNx < 0) return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control_observer: call lmpc_set_parameter_layout first");
+    const int ndm = n_measured_disturbance, ndo = h->ccNd - ndm;
+    if (N < 0 || ndm < 0 || ndo < 0 || (N > 0 && (!control || !observer_state)))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_compute_control_observer: NULL array, negative N, or more measured "
+                                        "disturbances than the layout's n_disturbance");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t per = (size_t)h->ccNx + h->ccNd;
+    if (N > h->ccObsCap) {
+        hipFree(h->ccObsScratch);
+        h->ccObsScratch = nullptr; h->ccObsCap = 0;
+        HIP_TRY(h, hipMalloc(&h->ccObsScratch, sizeof(double) * (size_t)N * (per ? per : 1)));
+        h->ccObsCap = N;
+    }
+    double *st_ = h->ccObsScratch, *di_ = h->ccObsScratch + (size_t)N * h->ccNx;
+    const long long total = (long long)N * (long long)per;
+    if (total > 0) {
+        hipLaunchKernelGGL(split_observer_state_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, st_, di_, observer_state, measured_disturbance, h->ccNx, ndm, ndo,
+                           (long long)N);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return lmpc_compute_control_device(h, N, control, st_, reference, h->ccNd > 0 ? di_ : nullptr, affine_parameter,
+                                       exitflag, warm, stream);
 }
 
 int lmpc_set_observer(lmpc_handle *h, const lmpc_observer *o) {
@@ -1180,7 +1214,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
-    hipFree(h->ccStage); hipFree(h->ccStageFlag);
+    hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
     delete h;
 }
 

@@ -77,6 +77,8 @@ struct lmpc_handle {
     // generated observer (lmpc_set_observer): [MPC_PLANT_DYNAMICS | MPC_MEASUREMENT_FUNCTION | K_TRANSPOSE_OBSERVER]
     double *obsC = nullptr;
     int obsNx = 0, obsNu = 0, obsNd = 0, obsNy = 0;
+    double *ccObsScratch = nullptr;     // lmpc_compute_control_observer: state and disturbance split from the observer state
+    int64_t ccObsCap = 0;
     double *ccStage = nullptr;          // host-pointer entry point: device copies of the five argument arrays
     int32_t *ccStageFlag = nullptr;
     int64_t ccStageCap = 0;

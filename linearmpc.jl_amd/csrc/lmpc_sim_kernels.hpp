@@ -297,4 +297,20 @@ __global__ __launch_bounds__(256) void unpack_theta_kernel(
     if (uprev) for (int l = 0; l < nup; l++) uprev[i * nup + l] = t[nx + nr + l];
 }
 
+// mpc_get_estimated_state + mpc_get_estimated_disturbance of the generated offset-free observer code
+// (reference src/observer.jl:163-175) for N scenarios: state = observer_state[0:nx], disturbance =
+// [measured_disturbance (or zeros); observer_state[nx : nx+ndo]].  One thread per output entry.
+__global__ __launch_bounds__(256) void split_observer_state_kernel(
+    double *__restrict__ state, double *__restrict__ disturbance, const double *__restrict__ observer_state,
+    const double *__restrict__ measured, int nx, int ndm, int ndo, long long n) {
+    const int w = nx + ndm + ndo, nobs = nx + ndo;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * w) return;
+    const long long i = idx / w;
+    const int e = (int)(idx - i * w);
+    if (e < nx) state[i * nx + e] = observer_state[i * nobs + e];
+    else if (e < nx + ndm) disturbance[i * (ndm + ndo) + (e - nx)] = measured ? measured[i * ndm + (e - nx)] : 0.0;
+    else disturbance[i * (ndm + ndo) + (e - nx)] = observer_state[i * nobs + nx + (e - nx - ndm)];
+}
+
 }  // namespace lmpc

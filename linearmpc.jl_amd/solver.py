@@ -381,6 +381,23 @@ class BatchedQP:
                                                 p(affine_parameter), p(exitflag), int(bool(warm)), _vp(st)), self._h)
         return exitflag
 
+    def compute_control_observer_device(self, control, observer_state, n_measured=0, reference=None,
+                                        measured_disturbance=None, affine_parameter=None, exitflag=None,
+                                        warm=False, stream=None):
+        """`lmpc_compute_control_observer_device`: generated `mpc_compute_control_observer` of an offset-free
+        observer for N scenarios (CUDA tensors; control in place)."""
+        import torch
+        N = int(control.shape[0])
+        dev = control.device
+        if exitflag is None:
+            exitflag = torch.empty(N, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        p = lambda t: _vp(t.data_ptr()) if t is not None else None
+        check(lib().lmpc_compute_control_observer_device(self._h, N, p(control), p(observer_state), int(n_measured),
+                                                         p(reference), p(measured_disturbance), p(affine_parameter),
+                                                         p(exitflag), int(bool(warm)), _vp(st)), self._h)
+        return exitflag
+
     # ------------------------------------------------------------------ generated state observer
     def set_observer(self, plant_dynamics, measurement_function, k_transpose, nx, nu, nd, ny):
         """`lmpc_set_observer`: MPC_PLANT_DYNAMICS, MPC_MEASUREMENT_FUNCTION, K_TRANSPOSE_OBSERVER as the

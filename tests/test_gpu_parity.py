@@ -1234,3 +1234,37 @@ def test_f32_closed_loop_matches_the_f32_oracle(lmpc, name, warm):
     assert np.array_equal(out["flag_min"], ref["flag_min"])
     assert np.abs(out["U"] - ref["U"]).max() <= 1e-6 and np.abs(out["X"] - ref["X"]).max() <= 1e-5
     assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])      # observed: identical bits
+
+
+def test_offset_free_observer_controller_call(lmpc):
+    # generated mpc_compute_control_observer (reference src/observer.jl:156-196): the controller reads the
+    # state and the estimated disturbance out of the augmented observer state.  Layout here: nx = 2, one
+    # measured + one estimated disturbance (nd = 2), nr = 1, nuprev = 1.
+    import torch
+    nx, nr, ndm, ndo, nup = 2, 1, 1, 1, 1
+    nth = nx + nr + ndm + ndo + nup
+    rng = np.random.default_rng(77)
+    n, mg, nu = 4, 5, 2
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+    qp.set_parameter_layout(nx, nr, ndm + ndo, nup, 0)
+    N = 2000
+    xaug = rng.uniform(-1, 1, (N, nx + ndo))
+    ref = rng.uniform(-1, 1, (N, nr))
+    dm = rng.uniform(-1, 1, (N, ndm))
+    u0 = rng.uniform(-1, 1, (N, nu))
+    theta = np.ascontiguousarray(np.hstack([xaug[:, :nx], ref, dm, xaug[:, nx:], u0[:, :nup]]))
+    xr, efr, _, _ = qp.solve(theta)
+    dev = torch.device("cuda", 0)
+    c = torch.from_numpy(u0.copy()).to(dev)
+    ef = qp.compute_control_observer_device(c, torch.from_numpy(xaug).to(dev), ndm, torch.from_numpy(ref).to(dev),
+                                            torch.from_numpy(dm).to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(ef.cpu().numpy(), efr) and np.array_equal(c.cpu().numpy(), xr)
+    # measured disturbance NULL = zeros (the generated code's `measured_disturbance ? ... : 0`)
+    th0 = theta.copy()
+    th0[:, nx + nr:nx + nr + ndm] = 0
+    c = torch.from_numpy(u0.copy()).to(dev)
+    qp.compute_control_observer_device(c, torch.from_numpy(xaug).to(dev), ndm, torch.from_numpy(ref).to(dev), None)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), qp.solve(th0)[0])
