@@ -1,0 +1,79 @@
+# Julia glue for liblmpc_hip.so -- the file INTEGRATION.md walks through.  Written against include/lmpc_hip.h;
+# Julia is not installed in the build image, so it has not been executed there (examples/abi_check.c is the
+# C client that is built and run by the test-suite).
+module LmpcHipExt
+using LinearMPC, LinearAlgebra
+const liblmpc = get(ENV, "LMPC_HIP_LIB", "liblmpc_hip.so")
+
+struct LmpcSettings            # == lmpc_settings (include/lmpc_hip.h)
+    primal_tol::Cdouble; dual_tol::Cdouble; zero_tol::Cdouble; progress_tol::Cdouble
+    fval_bound::Cdouble; rho_soft::Cdouble; cycle_tol::Cint; iter_limit::Cint
+end
+LmpcSettings(mpc) = LmpcSettings(1e-6, 1e-12, 1e-11, 1e-6, 1e30, 1/mpc.settings.soft_weight, 10, 10000)
+
+mutable struct BatchedModel    # stands next to mpc.opt_model
+    h::Ptr{Cvoid}; n::Int; nout::Int; nth::Int; words::Int
+end
+
+"setup!(mpc) for the batched backend: same inputs DAQP.setup gets (setup.jl:11-13)"
+function setup_batched(mpc::LinearMPC.MPC; nout=mpc.model.nu, device=0)
+    mpc.mpqp_issetup || LinearMPC.setup!(mpc)
+    q = mpc.mpQP; n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
+    h = Ref{Ptr{Cvoid}}(C_NULL); s = Ref(LmpcSettings(mpc))
+    K = iszero(mpc.K) ? C_NULL : Matrix{Float64}(mpc.K[1:nout, :])
+    flag = ccall((:lmpc_setup, liblmpc), Cint,
+        (Ref{Ptr{Cvoid}}, Cint,Cint,Cint,Cint,Cint, Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},
+         Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cint},Ptr{Cdouble},Cint,Ref{LmpcSettings},Cint),
+        h, n,m,ms,nth,nout, q.H,q.f,q.f_theta,q.A,q.bu,q.bl,q.W,q.senses, K, mpc.model.nx, s, device)
+    flag == 1 || error("lmpc_setup failed ($flag): ", unsafe_string(ccall((:lmpc_last_error, liblmpc), Cstring, (Ptr{Cvoid},), C_NULL)))
+    words = ccall((:lmpc_active_words, liblmpc), Cint, (Ptr{Cvoid},), h[])
+    bm = BatchedModel(h[], n, nout, nth, words)
+    finalizer(b -> ccall((:lmpc_free, liblmpc), Cvoid, (Ptr{Cvoid},), b.h), bm)
+    return bm
+end
+
+"solve(mpc, Θ) for a matrix of parameters (nth × N): the batched twin of utils.jl:268-283"
+function LinearMPC.solve(bm::BatchedModel, Θ::Matrix{Float64})
+    @assert size(Θ,1) == bm.nth
+    N = size(Θ,2); X = Matrix{Float64}(undef, bm.nout, N); flags = Vector{Cint}(undef, N)
+    rc = ccall((:lmpc_solve_batch, liblmpc), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}, Ptr{UInt64}, Ptr{UInt64}),
+        bm.h, N, Θ, X, flags, C_NULL, C_NULL, C_NULL)
+    rc == 1 || error("lmpc_solve_batch failed ($rc)")
+    return X, flags
+end
+
+"single-precision twin (the reference's codegen float_type=\"float\" build of the same path)"
+function solve_f32(bm::BatchedModel, Θ::Matrix{Float32})
+    N = size(Θ,2); X = Matrix{Float32}(undef, bm.nout, N); flags = Vector{Cint}(undef, N)
+    rc = ccall((:lmpc_solve_batch_f32, liblmpc), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cint}, Ptr{Cint}, Ptr{UInt64}, Ptr{UInt64}),
+        bm.h, N, Θ, X, flags, C_NULL, C_NULL, C_NULL)
+    rc == 1 || error("lmpc_solve_batch_f32 failed ($rc)")
+    return X, flags
+end
+
+"the generated controller's signature, batched: control (nu × N) in = previous control, out = u*"
+function mpc_compute_control!(bm::BatchedModel, control::Matrix{Float64}, state::Matrix{Float64},
+                              reference=C_NULL, disturbance=C_NULL, parameter=C_NULL; warm=false)
+    N = size(control,2); flags = Vector{Cint}(undef, N)
+    rc = ccall((:lmpc_compute_control, liblmpc), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Cint),
+        bm.h, N, control, state, reference, disturbance, parameter, flags, warm)
+    rc == 1 || error("lmpc_compute_control failed ($rc)")
+    return flags
+end
+# once per handle, from the MPC's parameter dimensions (get_parameter_dims, mpc2mpqp.jl:147-164):
+#   lay = LmpcParamLayout(nx, nr, nd, nuprev, np, cond ? mpc.Np : 0, cond ? pointer(mpc.traj2setpoint) : C_NULL)
+#   ccall((:lmpc_set_parameter_layout, liblmpc), Cint, (Ptr{Cvoid}, Ref{LmpcParamLayout}), bm.h, lay)
+
+"compute_control for N scenarios at once (utils.jl:43-51 without the mutable mpc.uprev)"
+function compute_control_batch(mpc, bm::BatchedModel, X0::Matrix; R=nothing, Uprev=nothing, check=true)
+    N = size(X0,2)
+    Θ = reduce(hcat, [LinearMPC.form_parameter(mpc, X0[:,i], isnothing(R) ? nothing : R[:,i], nothing,
+                                              isnothing(Uprev) ? zeros(mpc.model.nu) : Uprev[:,i]) for i in 1:N])
+    U, flags = LinearMPC.solve(bm, Θ)          # K·x already subtracted inside the library
+    check && @assert all(flags .>= 1)
+    return U, flags
+end
+end

@@ -1268,3 +1268,20 @@ def test_offset_free_observer_controller_call(lmpc):
     qp.compute_control_observer_device(c, torch.from_numpy(xaug).to(dev), ndm, torch.from_numpy(ref).to(dev), None)
     torch.cuda.synchronize()
     assert np.array_equal(c.cpu().numpy(), qp.solve(th0)[0])
+
+
+def test_c_client_solves_on_the_gpu(lmpc, tmp_path):
+    # examples/abi_check.c, the plain-C99 client of the shared library, on a box with a GPU: setup, a batch
+    # through lmpc_solve_batch and through the generated controller's lmpc_compute_control, closed-form check
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    libdir = os.path.dirname(lmpc.LIB_PATH)
+    exe = tmp_path / "abi_check"
+    subprocess.run([shutil.which("gcc"), "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "abi_check.c"), "-o", str(exe), "-L", libdir, "-llmpc_hip",
+                    f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "solved through the C ABI on a HIP device" in out.stdout

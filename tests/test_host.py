@@ -169,3 +169,22 @@ def test_preview_formatting_follows_the_reference():
     assert np.array_equal(plain.format_reference(np.array([[1.0, 3], [2, 4]])), [1, 2])    # first column
     with pytest.raises(ValueError, match="must match number of outputs"):
         plain.format_reference([1.0])
+
+
+def test_c_client_links_and_runs(tmp_path):
+    """A plain C99 program (examples/abi_check.c) compiled with gcc against include/lmpc_hip.h and linked to
+    the shared library: the header is valid C (not only C++), every symbol it uses links with C linkage, the
+    host-only transform runs, and without a GPU setup refuses loudly (with one it solves and checks)."""
+    import shutil
+    import subprocess
+    import linearmpc_jl_amd as lmpc
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = tmp_path / "abi_check"
+    libdir = os.path.dirname(lmpc.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "abi_check.c"), "-o", str(exe), "-L", libdir, "-llmpc_hip",
+                    f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "ok" in out.stdout
