@@ -106,6 +106,8 @@ class MPCProblem:
     h_offset: Optional[np.ndarray] = None   # y  = C x + h_offset         (model.jl:30)
     move_blocks: Optional[list] = None      # per input: block lengths (setup.jl:202-248)
     x0_uncertainty: Optional[np.ndarray] = None   # mpc.dx0 (setup.jl:293-296): constraints tightened by |Ax| dx0
+    Gd: Optional[np.ndarray] = None         # measured disturbance: x+ = F x + G u + Gd d (model.jl:17,70)
+    Dd: Optional[np.ndarray] = None         #                       y  = C x + Dd d       (model.jl:28)
     binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
     Nc_binary: int = -1                     # "binary control horizon" (-1 = whole control horizon)
 
@@ -114,6 +116,10 @@ class MPCProblem:
         dims = [0 if self.Eu is None else np.atleast_2d(self.Eu).shape[1]]
         dims += [0 if c.Ap is None else np.atleast_2d(c.Ap).shape[1] for c in self.constraints]
         return max(dims)
+
+    @property
+    def nd(self):
+        return 0 if self.Gd is None else np.atleast_2d(self.Gd).shape[1]
 
     def has_f_offset(self):
         return self.f_offset is not None and np.any(np.asarray(self.f_offset) != 0)
@@ -182,7 +188,7 @@ class MPCProblem:
         if self.reference_preview and not self.reference_condensation and nr > 0:
             nr = nr * self.Np                    # mpc2mpqp.jl:154-156: one reference per predicted step
         nuprev = self.nu if np.any(self.Rr != 0) else 0
-        return self.nx, nr, 0, nuprev, self.np_base()
+        return self.nx, nr, self.nd, nuprev, self.np_base()     # (no disturbance preview: nd = model.nd)
 
     def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0, Ap=None):
         """setup.jl:57-79 add_constraint! (default ks = 2:Np, missing side = +-1e30)."""
@@ -201,7 +207,7 @@ class MPCProblem:
 
 
 def make_mpc(F, G, C=None, Np=10, Nc=None, Q=None, R=None, Rr=None, umin=(), umax=(),
-             reference_tracking=True, Ts=-1.0):
+             reference_tracking=True, Ts=-1.0, Gd=None, Dd=None):
     """MPC(F,G;...) + set_objective! + set_bounds! (types.jl:159-172, setup.jl:36-46,:136-150).
 
     Default weights follow MPCWeights(nu,nx,nr) (types.jl:34-37): Q=I_ny, R=I_nu, Rr=0.
@@ -215,9 +221,13 @@ def make_mpc(F, G, C=None, Np=10, Nc=None, Q=None, R=None, Rr=None, umin=(), uma
     Q = np.eye(ny) if Q is None else _as_weight(Q, ny)
     R = np.eye(nu) if R is None else _as_weight(R, nu)
     Rr = np.zeros((nu, nu)) if Rr is None else _as_weight(Rr, nu)
-    return MPCProblem(F, G, C, Np, Nc, Q, R, Rr,
-                      np.atleast_1d(np.asarray(umin, float)), np.atleast_1d(np.asarray(umax, float)),
-                      [], reference_tracking, True, Ts)
+    p = MPCProblem(F, G, C, Np, Nc, Q, R, Rr,
+                   np.atleast_1d(np.asarray(umin, float)), np.atleast_1d(np.asarray(umax, float)),
+                   [], reference_tracking, True, Ts)
+    if Gd is not None:
+        p.Gd = np.asarray(Gd, float).reshape(nx, -1)
+        p.Dd = np.zeros((ny, p.Gd.shape[1])) if Dd is None else np.asarray(Dd, float).reshape(ny, -1)
+    return p
 
 
 # --------------------------------------------------------------------------- prediction
@@ -244,8 +254,8 @@ def state_predictor(F, G, Np, Nc):
 
 
 def extended_system(p: MPCProblem):
-    """mpc2mpqp.jl:649-690, no disturbance, no offsets."""
-    nx, nr, _, nuprev, _ = p.parameter_dims()
+    """mpc2mpqp.jl:649-690 (no disturbance preview)."""
+    nx, nr, nd, nuprev, _ = p.parameter_dims()
     nu, ny = p.nu, p.ny
     K = p.gain()
     F, G, C = p.F - p.G @ K, p.G.copy(), p.C.copy()
@@ -253,6 +263,12 @@ def extended_system(p: MPCProblem):
         F = block_diag(F, np.eye(ny))            # with preview it is no state, see ref_preview_cost)
         G = np.vstack([G, np.zeros((ny, nu))])
         C = np.hstack([C, -np.eye(ny)])
+    if nd > 0:                                   # measured disturbance as constant states (:664-669)
+        F = block_diag(F, np.eye(nd))
+        F[:nx, -nd:] = np.asarray(p.Gd, float).reshape(nx, nd)
+        G = np.vstack([G, np.zeros((nd, nu))])
+        Dd = np.zeros((ny, nd)) if p.Dd is None else np.asarray(p.Dd, float).reshape(ny, nd)
+        C = np.hstack([C, Dd])
     if nuprev > 0:                               # previous input as a state, du as an output
         F = block_diag(F, np.zeros((nu, nu)))
         F[-nu:, :nx] = -K
@@ -272,7 +288,7 @@ def extended_system(p: MPCProblem):
 
 def extended_cost(p: MPCProblem):
     """mpc2mpqp.jl:692-731.  Returns Q, R, S, Qf of the extended system."""
-    nx, nr, _, nuprev, _ = p.parameter_dims()
+    nx, nr, nd, nuprev, _ = p.parameter_dims()
     nu, ny = p.nu, p.ny
     K = p.gain()
     Q, R, Rr = p.Q.copy(), p.R.copy(), p.Rr.copy()
@@ -280,6 +296,8 @@ def extended_cost(p: MPCProblem):
     S = np.zeros((nx, nu))
     if nr > 0 and not p.reference_preview:       # :701-703
         S = np.vstack([S, np.zeros((ny, nu))])
+    if nd > 0:                                   # :705-707
+        S = np.vstack([S, np.zeros((nd, nu))])
     if nuprev > 0:
         Q = block_diag(Q, Rr)
         Qf = block_diag(Qf, np.zeros((nu, nu)))
@@ -773,6 +791,13 @@ def refcond_kat() -> MPCProblem:
     return p
 
 
+def observer_disturbance_kat() -> MPCProblem:
+    """test/runtests.jl:951-961 "Observer + disturbance": double integrator, Gd = [1 0; 0 0], Dd = [0 1],
+    C = [1 0], every default (Np = Nc = 10, Q = I, R = I, no bounds): theta = [x(2); r(1); d(2)].  With the
+    Kalman filter (Q = [1,1], R = 1e-2) and d = [1,1] the measured output settles at 0 (|mean| < 1e-2)."""
+    return make_mpc([[1, 1], [0, 1]], [[0], [1]], [[1.0, 0.0]], Np=10, Gd=[[1, 0], [0, 0]], Dd=[[0, 1]])
+
+
 def offset_kat() -> MPCProblem:
     """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
     with r = 1.5 settles at u = 10.5, y = 1.5."""
@@ -787,9 +812,9 @@ def moveblock_kat() -> MPCProblem:
     return p.move_block([2, 2, 2, 24])
 
 
-def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):
-    """explicit.jl:54-63: theta = [x; r; d; uprev; p] (d empty here; r, uprev, p default 0)."""
-    nx, nr, _, nuprev, npb = p.parameter_dims()
+def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None, d=None):
+    """explicit.jl:54-63: theta = [x; r; d; uprev; p] (r, d, uprev, p default 0)."""
+    nx, nr, nd, nuprev, npb = p.parameter_dims()
     x = np.asarray(x, float).reshape(nx)
     if p.reference_preview and r is not None and nr > 0:
         r = format_reference_preview(np.asarray(r, float), p.ny, p.Np)
@@ -798,4 +823,5 @@ def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None):
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
     pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]
-    return np.concatenate([x, r, u, pp])
+    dd = np.zeros(nd) if d is None else np.asarray(d, float).reshape(-1)[:nd]
+    return np.concatenate([x, r, dd, u, pp])

@@ -1285,3 +1285,42 @@ def test_c_client_solves_on_the_gpu(lmpc, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "solved through the C ABI on a HIP device" in out.stdout
+
+
+def test_measured_disturbance_closed_loop_with_observer_on_the_gpu(lmpc):
+    # /root/reference/test/runtests.jl:951-961 "Observer + disturbance" for 128 noise realisations at once,
+    # every step through lmpc_correct_state_device(y, d) -> lmpc_compute_control_device(xhat, r, d) ->
+    # lmpc_predict_state_device(u, d); the reference's assertion |mean(ys[end-20:end])| < 1e-2 per realisation
+    import torch
+    from oracle import mpc2mpqp as omm
+    from oracle import observer as oobs
+    p = omm.observer_disturbance_kat()
+    q = omm.mpc2mpqp(p)
+    mpc = lmpc.MPC(lmpc.MPQP(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses), nx=2, nu=1, nr=1, nd=2)
+    ctl = lmpc.GeneratedController(mpc)
+    kf = oobs.kalman_filter(p.F, p.G, p.C, Gd=p.Gd, Dd=p.Dd, Q=[1.0, 1], R=[1e-2])
+    ctl.set_observer(*kf.codegen_arrays(), 2, 1, 2, 1)
+    dev = torch.device("cuda", 0)
+    S, T = 128, 100
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    t64 = dict(dtype=torch.float64, device=dev)
+    F, G, Gd = (torch.from_numpy(np.asarray(a, float)).to(dev) for a in (p.F, p.G, p.Gd))
+    x = torch.tensor([1.0, 0.0], **t64).repeat(S, 1)
+    xhat = x.clone()
+    d = torch.ones((S, 2), **t64)
+    r = torch.zeros((S, 1), **t64)
+    u = torch.zeros((S, 1), **t64)
+    flags = torch.empty(S, dtype=torch.int32, device=dev)
+    ys = []
+    for k in range(T):
+        ys.append((x[:, 0] + d[:, 1]).clone())                               # y = C x + Dd d
+        ym = (x[:, :1] + d[:, 1:2] + 0.01 * torch.randn((S, 1), generator=gen, **t64)).contiguous()
+        ctl.model.correct_state(xhat, ym, d)
+        ctl.model.compute_control_device(u, xhat, r, d, exitflag=flags)
+        assert int(flags.min().item()) >= 1
+        ctl.model.predict_state(xhat, u, d)
+        x = x @ F.T + u @ G.T + d @ Gd.T
+    torch.cuda.synchronize()
+    tail = torch.stack(ys[-21:]).mean(0).cpu().numpy()
+    assert np.abs(tail).max() < 1e-2

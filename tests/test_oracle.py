@@ -447,3 +447,45 @@ def test_observer_restated():
     x, u, y, d = rng.standard_normal(2), rng.standard_normal(1), rng.standard_normal(1), rng.standard_normal(1)
     assert np.linalg.norm(oobs.c_predict(dyn, x, u, d, 2, 1, 1) - kd.predict(x, u, d)) < 1e-9
     assert np.linalg.norm(oobs.c_correct(meas, kt, x, y, d, 2, 1, 1) - kd.correct(x, y, d)) < 1e-9
+
+
+def _observer_disturbance_loop(seed, solve):
+    """Simulation of /root/reference/test/runtests.jl:951-961 (src/simulation.jl:93-113 with an observer and a
+    constant measured disturbance): y_meas = x1 + d2 + noise -> correct!(y, d) -> compute_control(xhat; r = 0, d)
+    -> predict!(u, d) -> x+ = F x + G u + Gd d.  Returns the outputs y = C x + Dd d."""
+    from oracle import observer as oobs
+    p = omm.observer_disturbance_kat()
+    kf = oobs.kalman_filter(p.F, p.G, p.C, Gd=p.Gd, Dd=p.Dd, Q=[1.0, 1], R=[1e-2])
+    rng = np.random.default_rng(seed)
+    x, xh, d, ys = np.array([1.0, 0.0]), np.array([1.0, 0.0]), np.array([1.0, 1.0]), []
+    for _ in range(100):
+        ym = np.array([x[0] + d[1] + 0.01 * rng.standard_normal()])
+        ys.append((p.C @ x + p.Dd @ d)[0])
+        xh = kf.correct(xh, ym, d)
+        u = solve(omm.form_parameter(p, xh, r=[0.0], d=d))
+        xh = kf.predict(xh, u, d)
+        x = p.F @ x + p.G @ u + p.Gd @ d
+    return np.array(ys)
+
+
+def test_measured_disturbance_with_observer_reference_assertion():
+    # "Observer + disturbance": the controller knows d through theta = [x; r; d] (extended system,
+    # mpc2mpqp.jl:664-669), the Kalman filter through Gd / Dd; the reference asserts |mean(ys[end-20:end])| < 1e-2
+    p = omm.observer_disturbance_kat()
+    q = omm.mpc2mpqp(p)
+    assert (q.n, q.m, q.nth) == (10, 0, 5)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+
+    def solve(th):
+        U, ef, _, _ = oldp.solve_batch(L, th[None])
+        assert ef[0] >= 1
+        return U[0, :1]
+
+    for seed in range(5):
+        ys = _observer_disturbance_loop(seed, solve)
+        assert abs(np.mean(ys[-21:])) < 1e-2
+    # without the disturbance in theta the offset stays: the same loop with d hidden from the controller
+    def solve_blind(th):
+        th = th.copy(); th[3:5] = 0.0
+        return solve(th)
+    assert abs(np.mean(_observer_disturbance_loop(0, solve_blind)[-21:])) > 0.1
