@@ -625,7 +625,8 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
             h->L.sim = SimFuse{h->simFG, nxt, flag_min, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
                                nx, nu, nr, nuprev, k == 0 ? 1 : 0};
             const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
-            rc = launch(h, N, cur, U_traj ? U_traj + (size_t)k * N * nu : h->simU, h->simFlag, nullptr,
+            // no input trajectory asked for: the kernels write neither u nor the per-step flags
+            rc = launch(h, N, cur, U_traj ? U_traj + (size_t)k * N * nu : nullptr, nullptr, nullptr,
                         warm ? h->simAct : nullptr, wm, st);
             std::swap(cur, nxt);
         }

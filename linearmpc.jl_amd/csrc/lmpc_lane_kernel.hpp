@@ -552,7 +552,7 @@ __device__ __forceinline__ void lane_solve(
 #pragma unroll
         for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + c], u[c], xs);
         uo[0] = xs + sh0;
-        X[pid] = uo[0];
+        if (!SIM || X != nullptr) X[pid] = uo[0];
     } else {
         for (int k = 0; k < P.nout; k++) {
             double xs = 0.0, sh = C[P.ox0 + k];
@@ -562,11 +562,11 @@ __device__ __forceinline__ void lane_solve(
             const double xo = xs + sh;
 #pragma unroll
             for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = xo;
-            X[pid * P.nout + k] = xo;
+            if (!SIM || X != nullptr) X[pid * P.nout + k] = xo;
         }
     }
     if constexpr (SIM) sim_advance(P.sim, C + P.oFG, th, uo, pid, flag);
-    exitflag[pid] = flag;
+    if (!SIM || exitflag != nullptr) exitflag[pid] = flag;
     if (iters) iters[pid] = iter;
     if (active) {
         const unsigned long long up = act & ~low, lo = act & low;

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
 #pragma unroll
                 for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
-                if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
+                if (SIM && X == nullptr) {                          // closed loop without an input trajectory
+                } else if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
                 else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
             }
             // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 if (S.flag_min) S.flag_min[pid] = S.first ? (int)EXIT_OPTIMAL
                                                            : (EXIT_OPTIMAL < S.flag_min[pid] ? (int)EXIT_OPTIMAL : S.flag_min[pid]);
             }
-            if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
+            if (SIM && exitflag == nullptr) {                       // closed loop: flag_min carries the flags
+            } else if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
             else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
             // (iteration count and active set only for the problems finished here: `active` may be the
             // very buffer the iterating kernel still has to read its warm-start masks from)
