@@ -169,6 +169,8 @@ __global__ __launch_bounds__(256) void screen_kernel(
         // (generated-controller mode: X is the caller's control array, whose previous-control entries the
         // iterating kernel's problems have not consumed yet -- there only finished problems are written, and
         // the queued ones get their assembled record handed over instead)
+        double rec[NT];                                // closed loop: the next record of a finished problem
+        bool recok = false;
         const bool fill = ((ablate & 16) || GATHER) ? (valid && !hard) : valid;
         if constexpr (GATHER) {
             if (hard) {
@@ -202,7 +204,6 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 const SimFuse &S = P.sim;
                 const int nx = S.nx, nu = S.nu, nr = S.nr, nup = S.nup;
                 const double *F = C + P.oFG, *G = F + nx * nx;         // in the constant pack: scalar loads
-                double rec[NT];
 #pragma unroll
                 for (int a = 0; a < NT; a++) {
                     rec[a] = th[a];                                    // the reference block is carried over
@@ -220,10 +221,13 @@ __global__ __launch_bounds__(256) void screen_kernel(
                     for (int l = 0; l < kMaxSimU; l++)
                         if (l < nup && a == nx + nr + l) rec[a] = uo[l];
                 }
-                double *to = S.theta_out + pid * nth;
+                recok = true;
+                if constexpr (NT > 16) {                               // padded instantiation: record stride nth != NT
+                    double *to = S.theta_out + pid * nth;
 #pragma unroll
-                for (int t = 0; t < NT; t++)
-                    if (NT <= 16 || t < nth) to[t] = rec[t];
+                    for (int t = 0; t < NT; t++)
+                        if (t < nth) to[t] = rec[t];
+                }
                 if (S.xtraj) {
 #pragma unroll
                     for (int t = 0; t < NT; t++)
@@ -240,6 +244,25 @@ __global__ __launch_bounds__(256) void screen_kernel(
             if (iters && !hard) iters[pid] = 1;
             if (active && !hard)
                 for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;
+        }
+        if constexpr (SIM && NT <= 16) {
+            // The wavefront's 64 records are one contiguous run of 64*NT doubles in theta_out: they go through
+            // a wave-private LDS transpose and leave as NT fully coalesced stores (lane l writes doubles
+            // j*64 + l), each double under the "finished here" bit of the record it belongs to.  (Record by
+            // record every store instruction touched 64 different 56-byte records.)
+            __shared__ double srec[256 * NT];
+            double *sw = srec + (tid & ~63) * NT;
+            const unsigned long long okmask = __ballot(recok);
+#pragma unroll
+            for (int t = 0; t < NT; t++) sw[lane * NT + t] = rec[t];
+            __builtin_amdgcn_wave_barrier();
+            double *tob = P.sim.theta_out + (pid - lane) * NT;      // NT == nth for these instantiations
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int idx = j * 64 + lane;
+                if ((okmask >> (idx / NT)) & 1ull) tob[idx] = sw[idx];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (pmask != 0ull) {
