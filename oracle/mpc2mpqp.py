@@ -106,6 +106,7 @@ class MPCProblem:
     h_offset: Optional[np.ndarray] = None   # y  = C x + h_offset         (model.jl:30)
     move_blocks: Optional[list] = None      # per input: block lengths (setup.jl:202-248)
     x0_uncertainty: Optional[np.ndarray] = None   # mpc.dx0 (setup.jl:293-296): constraints tightened by |Ax| dx0
+    disturbance_preview: bool = False       # settings.disturbance_preview (types.jl:57,68): d is nd x Np in theta
     Gd: Optional[np.ndarray] = None         # measured disturbance: x+ = F x + G u + Gd d (model.jl:17,70)
     Dd: Optional[np.ndarray] = None         #                       y  = C x + Dd d       (model.jl:28)
     binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
@@ -188,7 +189,8 @@ class MPCProblem:
         if self.reference_preview and not self.reference_condensation and nr > 0:
             nr = nr * self.Np                    # mpc2mpqp.jl:154-156: one reference per predicted step
         nuprev = self.nu if np.any(self.Rr != 0) else 0
-        return self.nx, nr, self.nd, nuprev, self.np_base()     # (no disturbance preview: nd = model.nd)
+        nd = self.nd * self.Np if (self.disturbance_preview and self.nd > 0) else self.nd     # :157-160
+        return self.nx, nr, nd, nuprev, self.np_base()
 
     def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0, Ap=None):
         """setup.jl:57-79 add_constraint! (default ks = 2:Np, missing side = +-1e30)."""
@@ -263,7 +265,7 @@ def extended_system(p: MPCProblem):
         F = block_diag(F, np.eye(ny))            # with preview it is no state, see ref_preview_cost)
         G = np.vstack([G, np.zeros((ny, nu))])
         C = np.hstack([C, -np.eye(ny)])
-    if nd > 0:                                   # measured disturbance as constant states (:664-669)
+    if nd > 0 and not p.disturbance_preview:     # measured disturbance as constant states (:664-669)
         F = block_diag(F, np.eye(nd))
         F[:nx, -nd:] = np.asarray(p.Gd, float).reshape(nx, nd)
         G = np.vstack([G, np.zeros((nd, nu))])
@@ -296,7 +298,7 @@ def extended_cost(p: MPCProblem):
     S = np.zeros((nx, nu))
     if nr > 0 and not p.reference_preview:       # :701-703
         S = np.vstack([S, np.zeros((ny, nu))])
-    if nd > 0:                                   # :705-707
+    if nd > 0 and not p.disturbance_preview:     # :705-707
         S = np.vstack([S, np.zeros((nd, nu))])
     if nuprev > 0:
         Q = block_diag(Q, Rr)
@@ -364,6 +366,33 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         H_theta = np.block([[H_theta[:nxp, :nxp], np.zeros((nxp, nrp)), H_theta[:nxp, nxp:]],
                             [np.zeros((nrp, nxp)), Hr, np.zeros((nrp, tail))],
                             [H_theta[nxp:, :nxp], np.zeros((tail, nrp)), H_theta[nxp:, nxp:]]])
+    if p.disturbance_preview and p.nd > 0:
+        # disturbance_preview_cost (mpc2mpqp.jl:579-604): d_k enters the predicted states through
+        # Psi (disturbance_predictor, :48-58: x_k collects Gd d_0 .. Gd d_{k-1}) and the outputs through Dd;
+        # the cross term with U puts Fd = (C Gam)' Qy Yd into f_theta behind the state and reference columns
+        ny, nxp = p.ny, p.nx
+        nd0 = p.nd
+        nrp = p.parameter_dims()[1]
+        C_full, Q_full, Qf_full = C[:ny], Q[:ny, :ny], Qf[:ny, :ny]
+        E = np.vstack([np.asarray(p.Gd, float).reshape(nxp, nd0), np.zeros((nxe - nxp, nd0))])
+        Psi = np.zeros(((N + 1) * nxe, N * nd0))
+        for k in range(1, N + 1):
+            Psi[k * nxe:(k + 1) * nxe] = F @ Psi[(k - 1) * nxe:k * nxe]
+            Psi[k * nxe:(k + 1) * nxe, (k - 1) * nd0:k * nd0] += E
+        CY = np.kron(np.eye(N), C_full)
+        Dd = np.zeros((ny, nd0)) if p.Dd is None else np.asarray(p.Dd, float).reshape(ny, nd0)
+        Gy = CY @ Gam[nxe:]
+        Yd = CY @ Psi[nxe:] + np.kron(np.eye(N), Dd)
+        Qy = np.kron(np.eye(N), Q_full)
+        Qy[-ny:, -ny:] = Qf_full
+        Fd, Hd = Gy.T @ Qy @ Yd, Yd.T @ Qy @ Yd
+        split = nxp + nrp
+        tail = H_theta.shape[0] - split
+        ndp = N * nd0
+        f_theta = np.hstack([f_theta[:, :split], Fd, f_theta[:, split:]])
+        H_theta = np.block([[H_theta[:split, :split], np.zeros((split, ndp)), H_theta[:split, split:]],
+                            [np.zeros((ndp, split)), Hd, np.zeros((ndp, tail))],
+                            [H_theta[split:, :split], np.zeros((tail, ndp)), H_theta[split:, split:]]])
     f = np.zeros(H.shape[0])
     # generalised-parameter cost on the inputs (mpc2mpqp.jl:478-508): f += Umap' eu, f_theta gets
     # one column block Umap' (Eu stacked) for p (constant over the horizon, no preview)
@@ -432,13 +461,20 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
     nx, nr, nd, nuprev, npb = p.parameter_dims()
     nu, Np, Nc = p.nu, p.Np, p.Nc
     prev = p.reference_preview and nr > 0
-    nxe = nx + (0 if prev else nr) + nd + nuprev     # previewed references are no states (:210)
+    dprev = p.disturbance_preview and nd > 0
+    nxe = nx + (0 if prev else nr) + (0 if dprev else nd) + nuprev   # previewed blocks are no states (:210-211)
     if p.has_f_offset():
         nxe += 1                                     # constant offset in the dynamics (:212)
     n = Gam.shape[1]
 
-    def with_ref_block(Wm):                          # insert_preview_parameter_blocks (:70-92), Wr = 0
-        return np.hstack([Wm[:, :nx], np.zeros((Wm.shape[0], nr)), Wm[:, nx:]]) if prev else Wm
+    def with_ref_block(Wm, Wd=None):                 # insert_preview_parameter_blocks (:70-92), Wr = 0
+        if prev:
+            Wm = np.hstack([Wm[:, :nx], np.zeros((Wm.shape[0], nr)), Wm[:, nx:]])
+        if dprev:                                    # the disturbance block sits behind state and reference
+            at = nx + nr
+            Wdd = np.zeros((Wm.shape[0], nd)) if Wd is None else Wd
+            Wm = np.hstack([Wm[:, :at], Wdd, Wm[:, at:]])
+        return Wm
 
     if p.umax.size:
         # create_controlbounds (:206-245): with K = 0 simple bounds on U, otherwise general rows
@@ -465,7 +501,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             binary[p.Nc_binary * nu:] = False
     else:
         A, bu, bl = np.zeros((0, n)), np.zeros(0), np.zeros(0)
-        W, soft, prio = np.zeros((0, nxe + (nr if prev else 0) + npb)), np.zeros(0, bool), np.zeros(0, int)
+        W, soft, prio = np.zeros((0, nxe + (nr if prev else 0) + (nd if dprev else 0) + npb)), np.zeros(0, bool), np.zeros(0, int)
         binary = np.zeros(0, bool)
     if p.constraints:
         eyeX = np.eye(Np + 1)
@@ -495,7 +531,17 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             prios.append(np.full(mi * len(ks), c.prio, int))
         Axt, Aut = np.vstack(Ax_rows), np.vstack(Au_rows)
         A = np.vstack([A, Axt @ Gam + Aut])
-        Wg = with_ref_block(-Axt @ Phi)
+        Wd = None
+        if dprev:                                # :348: Wd = -Axtot Psi (no direct Ad terms here)
+            nd0 = p.nd
+            Fx = extended_system(p)[0]
+            E = np.vstack([np.asarray(p.Gd, float).reshape(nx, nd0), np.zeros((nxe - nx, nd0))])
+            Psi = np.zeros(((Np + 1) * nxe, Np * nd0))
+            for k in range(1, Np + 1):
+                Psi[k * nxe:(k + 1) * nxe] = Fx @ Psi[(k - 1) * nxe:k * nxe]
+                Psi[k * nxe:(k + 1) * nxe, (k - 1) * nd0:k * nd0] += E
+            Wd = -Axt @ Psi
+        Wg = with_ref_block(-Axt @ Phi, Wd)
         if npb > 0:
             Wg = np.hstack([Wg, np.vstack(Wp_rows)])
         W = np.vstack([W, Wg])
@@ -506,7 +552,7 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
         binary = np.concatenate([binary, np.zeros(sum(len(x) for x in softs), bool)])
     p._binary_rows = binary                      # carried next to the constraint tuple (no row is dropped
     if p.has_f_offset() and W.shape[0]:          # or reordered among the simple bounds afterwards)
-        col = nxe - 1 + (nr if prev else 0)      # collapse the constant state into the bounds (:393-398)
+        col = nxe - 1 + (nr if prev else 0) + (nd if dprev else 0)   # collapse the constant state into the bounds (:393-398)
         bu, bl = bu + W[:, col], bl + W[:, col]
         W = np.delete(W, col, axis=1)
     elif p.has_f_offset():
@@ -798,6 +844,15 @@ def observer_disturbance_kat() -> MPCProblem:
     return make_mpc([[1, 1], [0, 1]], [[0], [1]], [[1.0, 0.0]], Np=10, Gd=[[1, 0], [0, 0]], Dd=[[0, 1]])
 
 
+def disturbance_preview_kat(preview=True) -> MPCProblem:
+    """test/runtests.jl:735-774 "Codegen Disturbance Preview": double integrator, Gd = [0; 1], C = [1 0],
+    Np = Nc = 4, |u| <= 0.5, Q = 10, R = 0.1, disturbance_preview: theta = [x(2); r(1); vec(d_traj)(4)]."""
+    p = make_mpc([[1, 1], [0, 1]], [[0], [1]], [[1.0, 0.0]], Np=4, Nc=4, Q=[10.0], R=[0.1],
+                 umin=[-0.5], umax=[0.5], Gd=[[0], [1]])
+    p.disturbance_preview = preview
+    return p
+
+
 def offset_kat() -> MPCProblem:
     """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
     with r = 1.5 settles at u = 10.5, y = 1.5."""
@@ -823,5 +878,7 @@ def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None, d=None):
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
     pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]
+    if p.disturbance_preview and d is not None and nd > 0:
+        d = format_reference_preview(np.asarray(d, float), p.nd, p.Np)     # utils.jl:149-170: same tiling / padding
     dd = np.zeros(nd) if d is None else np.asarray(d, float).reshape(-1)[:nd]
     return np.concatenate([x, r, dd, u, pp])

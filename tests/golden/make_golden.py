@@ -27,6 +27,9 @@ mask.  Before anything is written the answers are cross-checked by independent m
     controller's first move equals the uncondensed preview controller's on the test's trajectory, and
     a constant trajectory condenses to itself.
 
+  * dist_preview_kat: disturbance preview (/root/reference/test/runtests.jl:735-774): theta = [x; r; vec(d_traj)];
+    a constant trajectory reproduces the non-preview controller's answers to 1e-12.
+
 `python tests/golden/make_golden.py name ...` rewrites only the named fixtures.
 
 Julia/DAQP cannot run in this image, so no fixture is an output of the reference itself; they pin
@@ -379,6 +382,30 @@ def main():
     X, ef, it, act = oldp.solve_batch(L, theta)
     save("refcond_kat", q, L, theta, X, ef, it, act,
          dict(traj2setpoint=T2S, state=states, reference=trajs, u_full_preview=u_f))
+
+    # ---- disturbance preview (runtests.jl:735-774): theta = [x; r; vec(d_traj)], the generated controller
+    # takes the nd x Np trajectory as its `disturbance` argument
+    prob = omm.disturbance_preview_kat(True)
+    q = omm.mpc2mpqp(prob)
+    assert q.nth == 7
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    # a constant trajectory is the non-preview controller's constant disturbance (same H, same optimum)
+    prob0 = omm.disturbance_preview_kat(False)
+    q0 = omm.mpc2mpqp(prob0)
+    L0 = oldp.qp2ldp(q0.H, q0.f, q0.f_theta, q0.A, q0.bu, q0.bl, q0.W, q0.senses, nout=q0.n)
+    rngd = np.random.default_rng(41)
+    for _ in range(50):
+        xx, rr, dd = rngd.uniform(-1, 1, 2), rngd.uniform(-1, 1, 1), rngd.uniform(-0.3, 0.3, 1)
+        ua = oldp.solve_batch(L, omm.form_parameter(prob, xx, r=rr, d=np.tile(dd[:, None], (1, 4)))[None])[0]
+        ub = oldp.solve_batch(L0, omm.form_parameter(prob0, xx, r=rr, d=dd)[None])[0]
+        assert np.abs(ua - ub).max() < 1e-12
+    states = np.vstack([np.zeros((1, 2)), rngd.uniform(-1, 1, (127, 2))])
+    refs = np.vstack([np.zeros((1, 1)), rngd.uniform(-1, 1, (127, 1))])
+    dtraj = np.vstack([np.array([[0.0, 1.0, 1.0, 1.0]]), rngd.uniform(-0.4, 0.4, (127, 4))])
+    theta = np.hstack([states, refs, dtraj])
+    assert np.array_equal(theta[0], omm.form_parameter(prob, [0, 0], r=[0.0], d=np.array([[0.0, 1, 1, 1]])))
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    save("dist_preview_kat", q, L, theta, X, ef, it, act, dict(state=states, reference=refs, disturbance=dtraj))
 
 
 if __name__ == "__main__":

@@ -1324,3 +1324,21 @@ def test_measured_disturbance_closed_loop_with_observer_on_the_gpu(lmpc):
     torch.cuda.synchronize()
     tail = torch.stack(ys[-21:]).mean(0).cpu().numpy()
     assert np.abs(tail).max() < 1e-2
+
+
+def test_generated_controller_disturbance_preview(lmpc):
+    # /root/reference/test/runtests.jl:735-774: the generated controller takes the nd x Np disturbance
+    # trajectory as its `disturbance` argument (N_DISTURBANCE = nd*Np, mpc_update_parameter.c:19-21)
+    g = load_golden("dist_preview_kat")
+    mpc = lmpc.MPC(lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"]),
+                   nx=2, nu=1, nr=1, nd=4, Np=4, disturbance_preview=True)
+    # operator interface: compute_control(mpc, x; r, d = d_traj)
+    d_traj = np.array([[0.0, 1.0, 1.0, 1.0]])
+    assert np.array_equal(mpc.form_parameter([0.0, 0.0], r=[0.0], d=d_traj), g["theta"][0])
+    u_julia = mpc.compute_control([0.0, 0.0], r=[0.0], d=d_traj)
+    assert abs(u_julia[0] - g["X"][0, 0]) < 1e-10
+    ctl = lmpc.GeneratedController(mpc)
+    control = np.zeros((128, 1))
+    ef = ctl.mpc_compute_control(control, g["state"], g["reference"], g["disturbance"])
+    assert np.array_equal(ef, g["exitflag"]) and np.abs(control[:, 0] - g["X"][:, 0]).max() < 1e-10
+    assert abs(control[0, 0] - u_julia[0]) < 1e-10                    # the reference's own assertion (:772)

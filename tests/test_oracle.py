@@ -95,7 +95,7 @@ def test_K8_doc_example_with_soft_output_bounds():
 
 
 @pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc", "prestab",
-                                  "satellite4", "satellite20", "refcond_kat"])
+                                  "satellite4", "satellite20", "refcond_kat", "dist_preview_kat"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     pk = dict(g); pk["sense"] = g["senses"]
@@ -109,7 +109,7 @@ def test_oracle_reproduces_golden(name):
 
 
 @pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "soft_doc",
-                                  "satellite4", "satellite20", "refcond_kat"])
+                                  "satellite4", "satellite20", "refcond_kat", "dist_preview_kat"])
 def test_golden_pack_matches_restated_transform(name):
     g = load_golden(name)
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=g["H"].shape[0])
@@ -489,3 +489,25 @@ def test_measured_disturbance_with_observer_reference_assertion():
         th = th.copy(); th[3:5] = 0.0
         return solve(th)
     assert abs(np.mean(_observer_disturbance_loop(0, solve_blind)[-21:])) > 0.1
+
+
+def test_disturbance_preview_restated():
+    """/root/reference/test/runtests.jl:735-774 and src/mpc2mpqp.jl:48-66,579-604: theta = [x; r; vec(d_traj)]
+    (the test's own check of mpc_update_parameter), and a constant trajectory is the non-preview controller."""
+    g = load_golden("dist_preview_kat")
+    p = omm.disturbance_preview_kat(True)
+    q = omm.mpc2mpqp(p)
+    assert q.nth == 7 and np.abs(q.f_theta - g["f_theta"]).max() < 1e-12
+    th = omm.form_parameter(p, [0.0, 0.0], r=[0.0], d=np.array([[0.0, 1.0, 1.0, 1.0]]))
+    assert np.array_equal(th, np.array([0, 0, 0, 0, 1.0, 1, 1]))
+    p0 = omm.disturbance_preview_kat(False)
+    q0 = omm.mpc2mpqp(p0)
+    assert q0.nth == 4 and np.abs(q.H - q0.H).max() == 0
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+    L0 = oldp.qp2ldp(q0.H, q0.f, q0.f_theta, q0.A, q0.bu, q0.bl, q0.W, q0.senses, nout=1)
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        x, r, d = rng.uniform(-1, 1, 2), rng.uniform(-1, 1, 1), rng.uniform(-0.3, 0.3, 1)
+        a = oldp.solve_batch(L, omm.form_parameter(p, x, r=r, d=np.tile(d[:, None], (1, 4)))[None])[0]
+        b = oldp.solve_batch(L0, omm.form_parameter(p0, x, r=r, d=d)[None])[0]
+        assert np.abs(a - b).max() < 1e-12
