@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Long randomized differential run: random problem shapes / row kinds / bounds, HIP path vs CPU oracle on the
+same pack -- exit flags, iteration counts, active sets bit for bit, x to 1e-10; cold and warm; f64 and (every
+fourth trial, wavefront-kernel shapes) f32.  usage: tools/fuzz_parity.py [trials] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import linearmpc_jl_amd as lmpc
+from conftest import oracle_ldp_from
+from oracle import ldp as oldp
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+bad = 0
+stats = {"lane": 0, "wave": 0, "refused": 0, "f32": 0}
+flags_seen = {}
+t0 = time.time()
+
+
+def copy_settings(s):
+    so = oldp.Settings()
+    for f, _ in so._fields_:
+        setattr(so, f, getattr(s, f))
+    return so
+
+
+for trial in range(trials):
+    n = int(rng.integers(1, 40)) if rng.random() < 0.3 else int(rng.integers(1, 15))
+    mg = int(rng.integers(0, 120)) if rng.random() < 0.3 else int(rng.integers(0, 46))
+    ms = n if rng.random() < 0.7 else 0
+    nth = int(rng.integers(0, 20))
+    if ms + mg == 0:
+        mg = 1
+    nsoft = int(rng.integers(0, mg + 1)) if (mg and rng.random() < 0.4) else 0
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + n * np.eye(n)
+    A = rng.standard_normal((mg, n))
+    m = ms + mg
+    scale = rng.choice([0.3, 1.0, 3.0])
+    bu = scale * rng.uniform(0.5, 2.0, m); bl = -scale * rng.uniform(0.5, 2.0, m)
+    W = 0.3 * rng.standard_normal((m, nth)); W[:ms] = 0.0
+    f_theta = rng.standard_normal((n, nth))
+    sense = np.zeros(m, np.int32)
+    if nsoft:
+        sense[ms + rng.choice(mg, nsoft, replace=False)] = 8
+    for j in range(m):
+        r = rng.random()
+        if sense[j] == 0 and r < 0.08: bu[j] = 1e30
+        elif sense[j] == 0 and r < 0.16: bl[j] = -1e30
+        elif sense[j] == 0 and r < 0.20: bu[j], bl[j], sense[j] = 1e30, -1e30, 4
+        elif sense[j] == 0 and j >= ms and r < 0.24 and n >= 3:
+            v = rng.uniform(-0.2, 0.2); bu[j], bl[j], sense[j] = v, v, 5
+    if (sense == 5).sum() > max(n - 1, 0):
+        sense[sense == 5] = 0
+    f32 = trial % 4 == 3
+    st = lmpc.default_settings_f32() if f32 else None
+    try:
+        qp = lmpc.BatchedQP.from_mpqp(H, np.zeros(n), f_theta, A, bu, bl, W, sense, nout=min(n, 3), settings=st)
+    except lmpc.LmpcError as e:
+        stats["refused"] += 1
+        assert e.code in (-1, -6, -103), e
+        continue
+    theta = rng.uniform(-2, 2, (193, nth))
+    L = oracle_ldp_from(qp.ldp())
+    try:
+        if f32:
+            x, ef, it, act = qp.solve_f32(theta.astype(np.float32))
+            xo, efo, ito, acto = oldp.solve_batch(L, theta.astype(np.float32), copy_settings(st), dtype=np.float32)
+            tol = 1e-5
+            stats["f32"] += 1
+        else:
+            x, ef, it, act = qp.solve(theta)
+            xo, efo, ito, acto = oldp.solve_batch(L, theta)
+            tol = 1e-10
+            stats["wave" if qp.kernel_name == "wave" else "lane"] += 1
+    except lmpc.LmpcError as e:
+        assert e.code == -103 and f32, e          # binary32 needs the wavefront kernel
+        continue
+    keep = ef != -7                                # working-set capacity: the oracle has no such limit
+    ok = np.array_equal(ef[keep], efo[keep]) and np.array_equal(it[keep], ito[keep]) and np.array_equal(act[keep], acto[keep])
+    ok = ok and (np.abs(x[keep] - xo[keep]).max() <= tol if keep.any() else True)
+    if ok and not f32 and (ef >= 1).sum() >= 8:
+        sel = ef >= 1
+        xw, efw, itw, actw = qp.solve(theta[sel][:64], warm=act[sel][:64])
+        xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], warm=act[sel][:64])
+        ok = np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= tol
+    for k, c in zip(*np.unique(ef, return_counts=True)):
+        flags_seen[int(k)] = flags_seen.get(int(k), 0) + int(c)
+    if not ok:
+        bad += 1
+        print(f"MISMATCH trial {trial}: n={n} ms={ms} mg={mg} nth={nth} nsoft={nsoft} f32={f32} kernel={qp.kernel_name}", flush=True)
+    if trial % 100 == 99:
+        print(f"trial {trial + 1}: {bad} mismatches, {stats}, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {trials} trials, {bad} mismatches, {stats}, exit flags {flags_seen}")
+sys.exit(1 if bad else 0)
