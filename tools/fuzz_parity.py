@@ -53,6 +53,13 @@ for trial in range(trials):
             v = rng.uniform(-0.2, 0.2); bu[j], bl[j], sense[j] = v, v, 5
     if (sense == 5).sum() > max(n - 1, 0):
         sense[sense == 5] = 0
+    bnb = trial % 5 == 4 and ms == n and n <= 10
+    if bnb:                                        # hybrid: some simple bounds become BINARY rows
+        sense[:ms][sense[:ms] != 0] = 0
+        bu[:ms] = np.where(bu[:ms] > 1e20, 1.0, bu[:ms]); bl[:ms] = np.where(bl[:ms] < -1e20, -1.0, bl[:ms])
+        nb = int(rng.integers(1, min(n, 6) + 1))
+        sense[rng.choice(ms, nb, replace=False)] = 16
+        stats["bnb"] = stats.get("bnb", 0) + 1
     f32 = trial % 4 == 3
     st = lmpc.default_settings_f32() if f32 else None
     try:
@@ -80,7 +87,7 @@ for trial in range(trials):
     keep = ef != -7                                # working-set capacity: the oracle has no such limit
     ok = np.array_equal(ef[keep], efo[keep]) and np.array_equal(it[keep], ito[keep]) and np.array_equal(act[keep], acto[keep])
     ok = ok and (np.abs(x[keep] - xo[keep]).max() <= tol if keep.any() else True)
-    if ok and not f32 and (ef >= 1).sum() >= 8:
+    if ok and not f32 and not bnb and (ef >= 1).sum() >= 8:
         sel = ef >= 1
         xw, efw, itw, actw = qp.solve(theta[sel][:64], warm=act[sel][:64])
         xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], warm=act[sel][:64])
