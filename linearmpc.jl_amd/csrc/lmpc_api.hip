@@ -373,6 +373,22 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     return rc;
 }
 
+// scratch of the closed-loop entry points (binary64-sized; the binary32 loop uses the same buffers)
+int ensure_sim(lmpc_handle *h, int64_t N) {
+    if (N <= h->simCap) return LMPC_OK;
+    const int nu = h->P.nout;
+    const size_t w = (size_t)h->P.words();
+    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
+    h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+    HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
+    HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * (nu ? nu : 1)));
+    HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
+    HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
+    HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
+    h->simCap = N;
+    return LMPC_OK;
+}
+
 int ensure_staging(lmpc_handle *h, int64_t N, bool warm) {
     if (N <= h->sCap && (!warm || h->sWarm)) return LMPC_OK;
     if (N > h->sCap) {
@@ -594,17 +610,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     if (N == 0 || T == 0) return LMPC_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const size_t w = (size_t)h->P.words();
-    if (N > h->simCap) {
-        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
-        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
-        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
-        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
-        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
-        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
-        h->simCap = N;
-    }
+    { const int rce = ensure_sim(h, N); if (rce != LMPC_OK) return rce; }
     HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
@@ -671,17 +677,7 @@ int lmpc_simulate_f32_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, i
     int rc = ensure_f32(h);
     if (rc != LMPC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t w = (size_t)h->P.words();
-    if (N > h->simCap) {      // the binary64-sized scratch of the closed loop serves both precisions
-        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
-        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
-        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
-        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
-        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
-        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
-        h->simCap = N;
-    }
+    { const int rce = ensure_sim(h, N); if (rce != LMPC_OK) return rce; }
     float *dTh = reinterpret_cast<float *>(h->simTheta), *dU = reinterpret_cast<float *>(h->simU),
           *dFG = reinterpret_cast<float *>(h->simFG);
     std::vector<float> fg((size_t)nx * nx + (size_t)nx * nu);       // the plant rounded to binary32, like the pack
@@ -791,17 +787,7 @@ int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmp
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const size_t w = (size_t)h->P.words();
-    if (N > h->simCap) {
-        hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-        h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
-        HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * h->P.nth));
-        HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * nu));
-        HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
-        HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
-        HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
-        h->simCap = N;
-    }
+    { const int rce = ensure_sim(h, N); if (rce != LMPC_OK) return rce; }
     HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
