@@ -106,6 +106,7 @@ class MPCProblem:
     h_offset: Optional[np.ndarray] = None   # y  = C x + h_offset         (model.jl:30)
     move_blocks: Optional[list] = None      # per input: block lengths (setup.jl:202-248)
     x0_uncertainty: Optional[np.ndarray] = None   # mpc.dx0 (setup.jl:293-296): constraints tightened by |Ax| dx0
+    parameter_preview: bool = False         # settings.parameter_preview (types.jl:58,69): p is np_base x Np in theta
     disturbance_preview: bool = False       # settings.disturbance_preview (types.jl:57,68): d is nd x Np in theta
     Gd: Optional[np.ndarray] = None         # measured disturbance: x+ = F x + G u + Gd d (model.jl:17,70)
     Dd: Optional[np.ndarray] = None         #                       y  = C x + Dd d       (model.jl:28)
@@ -190,7 +191,8 @@ class MPCProblem:
             nr = nr * self.Np                    # mpc2mpqp.jl:154-156: one reference per predicted step
         nuprev = self.nu if np.any(self.Rr != 0) else 0
         nd = self.nd * self.Np if (self.disturbance_preview and self.nd > 0) else self.nd     # :157-160
-        return self.nx, nr, nd, nuprev, self.np_base()
+        npp = self.np_base() * (self.Np if self.parameter_preview else 1)                     # :162
+        return self.nx, nr, nd, nuprev, npp
 
     def add_constraint(self, Ax=None, Au=None, lb=(), ub=(), ks=None, soft=False, prio=0, Ap=None):
         """setup.jl:57-79 add_constraint! (default ks = 2:Np, missing side = +-1e30)."""
@@ -402,10 +404,13 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
         f = f + Umap.T @ np.tile(np.asarray(p.eu, float).reshape(p.nu), N)
     if npb > 0:
         Eu = np.zeros((p.nu, npb)) if p.Eu is None else np.atleast_2d(np.asarray(p.Eu, float))
-        Fp = Umap.T @ np.tile(Eu, (N, 1))
+        # stage_parameter_matrix (:145): one parameter for the whole horizon, or one per predicted step
+        stage = np.kron(np.eye(N), Eu) if p.parameter_preview else np.tile(Eu, (N, 1))
+        Fp = Umap.T @ stage
+        npp = stage.shape[1]
         f_theta = np.hstack([f_theta, Fp])
         nthc = H_theta.shape[0]
-        H_theta = np.block([[H_theta, np.zeros((nthc, npb))], [np.zeros((npb, nthc)), np.zeros((npb, npb))]])
+        H_theta = np.block([[H_theta, np.zeros((nthc, npp))], [np.zeros((npp, nthc)), np.zeros((npp, npp))]])
     # regularisation of binary inputs (mpc2mpqp.jl:510-515): u^2 - (umin+umax) u is constant on
     # {umin, umax}, so it does not move the optimum but keeps H positive definite when R = 0
     if len(p.binary_controls):
@@ -525,8 +530,16 @@ def dense_constraints(p: MPCProblem, Phi, Gam):
             ubs.append(ubk)
             lbs.append(lbk)
             if npb > 0:                          # parameter_preview_direct (:125-143): W[:, p] = -Ap
-                Ap = np.zeros((mi, npb)) if c.Ap is None else c.Ap
-                Wp_rows.append(np.tile(-Ap, (len(ks), 1)))
+                nb0 = p.np_base()
+                Ap = np.zeros((mi, nb0)) if c.Ap is None else c.Ap
+                if p.parameter_preview:          # stage k reads the parameter of its own step (held at Np)
+                    Wp = np.zeros((mi * len(ks), nb0 * Np))
+                    for i_, k_ in enumerate(ks):
+                        col = min(k_, Np) - 1
+                        Wp[i_ * mi:(i_ + 1) * mi, col * nb0:(col + 1) * nb0] = -Ap
+                    Wp_rows.append(Wp)
+                else:
+                    Wp_rows.append(np.tile(-Ap, (len(ks), 1)))
             softs.append(np.full(mi * len(ks), c.soft))
             prios.append(np.full(mi * len(ks), c.prio, int))
         Axt, Aut = np.vstack(Ax_rows), np.vstack(Au_rows)
@@ -853,6 +866,16 @@ def disturbance_preview_kat(preview=True) -> MPCProblem:
     return p
 
 
+def parameter_preview_kat() -> MPCProblem:
+    """test/runtests.jl:1270-1304 "Generalized Parameter Codegen for Explicit Preview": scalar integrator,
+    Np = Nc = 3, 0 <= u <= 2, Q = 0, R = 1, Eu = -2, parameter_preview: theta = [x; r; p_0 p_1 p_2].  With
+    Q = 0 the moves decouple: u_k = argmin 1/2 u^2 - 2 p_k u = 2 p_k clipped to [0, 2]."""
+    p = make_mpc([[1.0]], [[1.0]], [[1.0]], Np=3, Nc=3, Q=[0.0], R=[1.0], umin=[0.0], umax=[2.0])
+    p.Eu = np.array([[-2.0]])
+    p.parameter_preview = True
+    return p
+
+
 def offset_kat() -> MPCProblem:
     """test/runtests.jl:1320-1327 "Set offset": first-order plant, uo = 10, ho = 0.5; the closed loop
     with r = 1.5 settles at u = 10.5, y = 1.5."""
@@ -877,6 +900,13 @@ def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None, d=None):
             r = p.traj2setpoint @ r
     r = np.zeros(nr) if r is None else np.asarray(r, float).reshape(-1)[:nr]
     u = np.zeros(nuprev) if uprev is None else np.asarray(uprev, float).reshape(-1)[:nuprev]
+    if p.parameter_preview and par is not None and npb > 0:
+        par = np.asarray(par, float)
+        nb0 = p.np_base()
+        if par.ndim == 1 and par.size == nb0:                                   # utils.jl:219-261
+            par = np.tile(par, p.Np)
+        elif par.ndim == 2:
+            par = format_reference_preview(par, nb0, p.Np)
     pp = np.zeros(npb) if par is None else np.asarray(par, float).reshape(-1)[:npb]
     if p.disturbance_preview and d is not None and nd > 0:
         d = format_reference_preview(np.asarray(d, float), p.nd, p.Np)     # utils.jl:149-170: same tiling / padding

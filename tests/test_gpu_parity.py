@@ -1342,3 +1342,25 @@ def test_generated_controller_disturbance_preview(lmpc):
     ef = ctl.mpc_compute_control(control, g["state"], g["reference"], g["disturbance"])
     assert np.array_equal(ef, g["exitflag"]) and np.abs(control[:, 0] - g["X"][:, 0]).max() < 1e-10
     assert abs(control[0, 0] - u_julia[0]) < 1e-10                    # the reference's own assertion (:772)
+
+
+def test_generated_controller_parameter_preview(lmpc):
+    # /root/reference/test/runtests.jl:1270-1304 "Generalized Parameter Codegen for Explicit Preview": the
+    # generated controller's affine_parameter argument carries one parameter per predicted step; closed form
+    # u_0 = clip(2 p_0, 0, 2) (x = 0, r = 0, p = [0.5, 0, 0] -> u = 1)
+    from oracle import mpc2mpqp as omm
+    p = omm.parameter_preview_kat()
+    q = omm.mpc2mpqp(p)
+    mpc = lmpc.MPC(lmpc.MPQP(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses), nx=1, nu=1, nr=1, np_=3, Np=3,
+                   parameter_preview=True)
+    u_julia = mpc.compute_control([0.0], r=[0.0], p=[0.5, 0.0, 0.0])
+    assert abs(u_julia[0] - 1.0) < 1e-12
+    ctl = lmpc.GeneratedController(mpc)
+    rng = np.random.default_rng(9)
+    N = 500
+    P = rng.uniform(-0.5, 1.5, (N, 3))
+    P[0] = [0.5, 0.0, 0.0]
+    control = np.zeros((N, 1))
+    ef = ctl.mpc_compute_control(control, np.zeros((N, 1)), np.zeros((N, 1)), None, P)
+    assert np.all(ef == 1) and np.abs(control[:, 0] - np.clip(2 * P[:, 0], 0, 2)).max() < 1e-12
+    assert abs(control[0, 0] - u_julia[0]) < 1e-12

@@ -511,3 +511,30 @@ def test_disturbance_preview_restated():
         a = oldp.solve_batch(L, omm.form_parameter(p, x, r=r, d=np.tile(d[:, None], (1, 4)))[None])[0]
         b = oldp.solve_batch(L0, omm.form_parameter(p0, x, r=r, d=d)[None])[0]
         assert np.abs(a - b).max() < 1e-12
+
+
+def test_parameter_preview_restated():
+    """/root/reference/test/runtests.jl:1136-1155 and :1270-1304 (src/mpc2mpqp.jl:125-145,162,478-508): with
+    parameter_preview theta carries one generalised parameter per predicted step."""
+    p2 = omm.make_mpc([[1, 1], [0, 1]], [[0], [1]], np.eye(2), Np=5, Nc=3, Q=[1.0, 1.0], R=[0.1], umin=[-2.0], umax=[2.0])
+    p2.Eu = np.array([[1.0]])
+    p2.parameter_preview = True
+    assert p2.parameter_dims() == (2, 2, 0, 0, 5)                                    # :1147
+    q2 = omm.mpc2mpqp(p2)
+    L2 = oldp.qp2ldp(q2.H, q2.f, q2.f_theta, q2.A, q2.bu, q2.bl, q2.W, q2.senses, nout=1)
+    th_c = omm.form_parameter(p2, [-1.0, 0.0], r=[0.0, 0.0], par=np.array([1.0]))
+    th_p = omm.form_parameter(p2, [-1.0, 0.0], r=[0.0, 0.0], par=np.array([[1.0, 0.0, 0.0, 0.0, 0.0]]))
+    assert np.array_equal(th_c[4:], np.ones(5)) and np.array_equal(th_p[4:], [1.0, 0, 0, 0, 0])   # :1148-1149
+    uc = oldp.solve_batch(L2, th_c[None])[0][0]
+    up = oldp.solve_batch(L2, th_p[None])[0][0]
+    assert np.linalg.norm(uc - up) > 1e-3                                           # :1153
+    # the explicit-preview codegen problem has a closed form: Q = 0 decouples the moves, u_k = clip(2 p_k, 0, 2)
+    p = omm.parameter_preview_kat()
+    q = omm.mpc2mpqp(p)
+    assert q.nth == 5
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=3)
+    rng = np.random.default_rng(4)
+    P = rng.uniform(-0.5, 1.5, (200, 3))
+    theta = np.hstack([np.zeros((200, 2)), P])
+    X, ef, _, _ = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1) and np.abs(X - np.clip(2 * P, 0, 2)).max() < 1e-12
