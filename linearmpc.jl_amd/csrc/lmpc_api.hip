@@ -223,7 +223,8 @@ template <int NTHMAX, int NT, int MODE>
 int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, int32_t *count, hipStream_t st) {
     const int B = 256;
-    const size_t lds = 0;
+    // several outputs per problem: room for the wave-private transpose of the outputs (plain mode)
+    const size_t lds = MODE == 3 ? sizeof(double) * B * (size_t)h->P.nout : 0;
     const long long ntiles = (nprob + B - 1) / B;
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
@@ -328,6 +329,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     int rc = LMPC_OK;
     const bool sim = h->L.sim.FG != nullptr;      // closed-loop instantiations (SimFuse), lmpc_simulate* only
     const bool gather = !sim && h->L.gat.state != nullptr;   // generated-controller screening (GatherArgs)
+    const bool wide = !sim && !gather && h->P.nout > 1 && h->P.nout <= 16;   // several outputs: transposed stores
     if (gather && !screened) return fail(h, LMPC_ERR_BADARG, "lmpc: gather mode needs the screening pass");
     // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
     int32_t *cnt_now = nullptr, *cnt_next = nullptr;
@@ -337,7 +339,8 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         h->countSet ^= 1;
 #define LMPC_SCR(NM, NT) (sim ? launch_screen<NM, NT, 1>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
                          : gather ? launch_screen<NM, NT, 2>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
-                                  : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+                         : wide ? launch_screen<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                                : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
         switch (h->P.nth <= 16 ? h->P.nth : 32) {       // exact column count up to 16, padded beyond
             case 1: rc = LMPC_SCR(8, 1); break;    case 2: rc = LMPC_SCR(8, 2); break;
             case 3: rc = LMPC_SCR(8, 3); break;    case 4: rc = LMPC_SCR(8, 4); break;

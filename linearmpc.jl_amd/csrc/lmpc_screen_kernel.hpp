@@ -35,7 +35,8 @@ constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 // NTHMAX: column stride of the padded rows (8, 16 or 32).  NT: columns the unrolled chains run over --
 // the exact nth for nth <= 16 (one instantiation per value: with three batches in flight the pass is
 // bound by vector issue, and the padded column of the 7-parameter pendulum cost 6 %), else NTHMAX.
-// MODE: 0 the plain solve, 1 closed loop (SimFuse), 2 generated controller (GatherArgs).
+// MODE: 0 the plain solve, 1 closed loop (SimFuse), 2 generated controller (GatherArgs), 3 the plain solve
+// with several outputs per problem (their stores go through a wave-private LDS transpose).
 template <int NTHMAX, int NT, int MODE>
 __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
     const double ntol = -P.primal_tol;
     const int lane = tid & 63;
     const int shard = blockIdx.x & (nshards - 1);      // nshards is a power of two (checked by the host)
-    constexpr bool SIM = MODE == 1, GATHER = MODE == 2;
+    constexpr bool SIM = MODE == 1, GATHER = MODE == 2, WIDE = MODE == 3;
 
     double nx[NT];                                     // record of the problem after the current one
     // No guard on any load: a problem index past the end is clamped to the last problem (its results are
@@ -169,6 +170,12 @@ __global__ __launch_bounds__(256) void screen_kernel(
         // (generated-controller mode: X is the caller's control array, whose previous-control entries the
         // iterating kernel's problems have not consumed yet -- there only finished problems are written, and
         // the queued ones get their assembled record handed over instead)
+        // several outputs per problem (compute_control_trajectory): the wavefront's 64 * nout outputs are one
+        // contiguous run of X -- they go through a wave-private LDS transpose and leave as nout coalesced
+        // stores (8-byte stores at a stride of 8 * nout bytes cost this pass 12 us at nout = 5).  Plain mode
+        // only: there every valid problem of the wavefront writes its outputs.
+        extern __shared__ double sxo[];                // 256 * nout doubles, given by the launch (MODE 3)
+        const bool wide_out = WIDE && !(ablate & (4 | 16));
         double rec[NT];                                // closed loop: the next record of a finished problem
         bool recok = false;
         const bool fill = ((ablate & 16) || GATHER) ? (valid && !hard) : valid;
@@ -192,7 +199,8 @@ __global__ __launch_bounds__(256) void screen_kernel(
 #pragma unroll
                 for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
                 if (SIM && X == nullptr) {                          // closed loop without an input trajectory
-                } else if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
+                } else if (wide_out) sxo[(tid & ~63) * P.nout + lane * P.nout + k] = 0.0 + sh;   // see below
+                else if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
                 else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
             }
             // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
@@ -244,6 +252,17 @@ __global__ __launch_bounds__(256) void screen_kernel(
             if (iters && !hard) iters[pid] = 1;
             if (active && !hard)
                 for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;
+        }
+        if (WIDE && wide_out) {
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long vmask = __ballot(valid);
+            const double *sw = sxo + (tid & ~63) * P.nout;
+            double *xb = X + (pid - lane) * P.nout;
+            for (int j = 0; j < P.nout; j++) {
+                const int idx = j * 64 + lane;
+                if ((vmask >> (idx / P.nout)) & 1ull) xb[idx] = sw[idx];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         if constexpr (SIM && NT <= 16) {
             // The wavefront's 64 records are one contiguous run of 64*NT doubles in theta_out: they go through
