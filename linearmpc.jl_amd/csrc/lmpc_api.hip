@@ -189,11 +189,11 @@ long long lane_seg_cap(long long nprob) {
     return (nblocks + kShards - 1) / kShards * kScreenTPB * 256;
 }
 
-template <int N, int MS, int MA, bool SIM>
+template <int N, int MS, int MA, bool SIM, bool MULTI>
 int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *theta, double *x,
                 int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm,
                 const int32_t *list, const int32_t *count, int32_t *count_next, hipStream_t st) {
-    auto kern = lane_kernel<N, MS, MA, SIM>;
+    auto kern = lane_kernel<N, MS, MA, SIM, MULTI>;
     const long long segCap = lane_seg_cap(nprob);
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -330,6 +330,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     const bool sim = h->L.sim.FG != nullptr;      // closed-loop instantiations (SimFuse), lmpc_simulate* only
     const bool gather = !sim && h->L.gat.state != nullptr;   // generated-controller screening (GatherArgs)
     const bool wide = !sim && !gather && h->P.nout > 1 && h->P.nout <= 16;   // several outputs: transposed stores
+    const bool multi = !sim && h->P.nout > 1;                                  // ... and the iterating kernel's epilogue
     if (gather && !screened) return fail(h, LMPC_ERR_BADARG, "lmpc: gather mode needs the screening pass");
     // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
     int32_t *cnt_now = nullptr, *cnt_next = nullptr;
@@ -361,8 +362,9 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     // instantiation with the row scans unrolled and the working-set capacity cut to N
     const bool boxed = h->P.m == h->laneN && h->P.n == h->laneN && h->P.ms == h->P.m;
     if (rc == LMPC_OK) switch (h->laneN) {
-#define LMPC_LN(NN, MSS, MAA) (sim ? launch_lane<NN, MSS, MAA, true>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
-                                   : launch_lane<NN, MSS, MAA, false>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st))
+#define LMPC_LN(NN, MSS, MAA) (sim ? launch_lane<NN, MSS, MAA, true, false>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
+                               : (multi && NN <= 6) ? launch_lane<NN, MSS, MAA, false, (NN <= 6)>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st) \
+                                   : launch_lane<NN, MSS, MAA, false, false>(h, bestB, bestLds, nprob, theta, x, flag, iters, active, warm, list, count, cnt_next, st))
 #define LMPC_CASE(NN) case NN: rc = boxed ? LMPC_LN(NN, NN, NN) : LMPC_LN(NN, 0, NN + 1); break;
         LMPC_CASE(2) LMPC_CASE(3) LMPC_CASE(4) LMPC_CASE(5) LMPC_CASE(6) LMPC_CASE(8) LMPC_CASE(10) LMPC_CASE(12)
 #undef LMPC_CASE

@@ -450,7 +450,10 @@ __device__ __forceinline__ bool lane_loop(
 template <int N, int MS, int MA> struct lane_tier { static constexpr int value = (MS > 0 && N >= 4) ? LMPC_LANE_TIER_CAP : 0; };
 
 // Whole solve of problem `pid` on this lane: b = Dth theta into LDS, the iterations, the outputs.
-template <int N, int MS, int MA, bool SIM>
+// MULTI: instantiation for several outputs per problem (compute_control_trajectory): the epilogue reads the
+// record back ONCE into registers and runs one chain per output (small instantiations, plain solve only; in
+// the shared kernel the same code cost the single-output path 7 %).
+template <int N, int MS, int MA, bool SIM, bool MULTI>
 __device__ __forceinline__ void lane_solve(
     const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
     const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
@@ -553,6 +556,19 @@ __device__ __forceinline__ void lane_solve(
         for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + c], u[c], xs);
         uo[0] = xs + sh0;
         if (!SIM || X != nullptr) X[pid] = uo[0];
+    } else if (MULTI && nth <= 16 && nth > 0) {
+        double tv[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) tv[t] = th[t < nth ? t : nth - 1];     // clamped entries meet no coefficient
+        for (int k = 0; k < P.nout; k++) {
+            double xs = 0.0, sh = C[P.ox0 + k];
+#pragma unroll
+            for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
+#pragma unroll
+            for (int t = 0; t < 16; t++)
+                if (t < nth) sh = __builtin_fma(C[P.oXth + k * nth + t], tv[t], sh);
+            X[pid * P.nout + k] = xs + sh;
+        }
     } else {
         for (int k = 0; k < P.nout; k++) {
             double xs = 0.0, sh = C[P.ox0 + k];
@@ -578,7 +594,7 @@ __device__ __forceinline__ void lane_solve(
     }
 }
 
-template <int N, int MS, int MA, bool SIM>
+template <int N, int MS, int MA, bool SIM, bool MULTI>
 __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -626,7 +642,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const long long idx = base + tid;
     if (idx >= cnt) continue;
     const long long pid = list ? ((kEarly && base == first) ? (long long)pid0 : (long long)list[idx]) : idx;
-    lane_solve<N, MS, MA, SIM>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
+    lane_solve<N, MS, MA, SIM, MULTI>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
 }   // chunk loop
 }
 
