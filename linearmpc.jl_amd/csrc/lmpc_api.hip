@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,7 @@
 #include "lmpc_internal.hpp"
 #include "lmpc_lane_kernel.hpp"
 #include "lmpc_screen_kernel.hpp"
+#include "lmpc_simrun_kernel.hpp"
 #include "lmpc_sim_kernels.hpp"
 
 using namespace lmpc;
@@ -310,12 +312,12 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     const bool screened = will_screen(h, nprob);
     static_assert((kShards & (kShards - 1)) == 0, "the screening kernel masks the shard index");
     if (screened && nprob > h->listCap) {
-        hipFree(h->dList); hipFree(h->dCount);
-        h->dList = h->dCount = nullptr; h->listCap = 0;
+        hipFree(h->dList); hipFree(h->dCount); hipFree(h->dList2); hipFree(h->dList3);
+        h->dList = h->dCount = h->dList2 = h->dList3 = nullptr; h->listCap = 0;
         const size_t segCap = (size_t)lane_seg_cap(nprob);
         HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
-        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 2 * kShards * kCountStride));
-        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 2 * kShards * kCountStride, st));
+        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 3 * kShards * kCountStride));   // two alternating sets + the parked list's
+        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st));
         h->listCap = nprob;
         h->countSet = 0;
     }
@@ -334,7 +336,44 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     if (gather && !screened) return fail(h, LMPC_ERR_BADARG, "lmpc: gather mode needs the screening pass");
     // two counter sets used alternately: the iterating kernel of call k clears the set of call k+1
     int32_t *cnt_now = nullptr, *cnt_next = nullptr;
-    if (screened) {
+    if (screened && h->asyncPhase == 2) {          // scenario-asynchronous closed loop, iterating half: the work
+        cnt_now = h->asyncCntNow;                  // list and its counters come from the sim_run pass before
+        cnt_next = h->asyncCntNext;
+    } else if (screened && h->asyncPhase == 1) {   // ... streaming half: sim_run_kernel instead of the screening pass
+        cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+        cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+        h->countSet ^= 1;
+        h->asyncCntNow = cnt_now; h->asyncCntNext = cnt_next;
+        const long long segCap = lane_seg_cap(nprob);
+        if (!h->dList2) HIP_TRY(h, hipMalloc(&h->dList2, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
+        if (!h->dList3) HIP_TRY(h, hipMalloc(&h->dList3, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
+        int32_t *parkCnt = h->dCount + 2 * (size_t)kShards * kCountStride;
+        // first round: every scenario; later rounds: the scenarios of the round before's list, compacted
+        const int32_t *lin = h->asyncListIn, *cin = h->asyncCntIn;
+        int32_t *lout = (lin == h->dList) ? h->dList2 : h->dList;   // (the parked list as input: the work list is empty)
+        h->asyncListOut = lout;
+        const unsigned grid = lin ? (unsigned)(((h->asyncMaxIn + 255) / 256) * kShards) : (unsigned)((nprob + 255) / 256);
+        const SimFuse &Sf = h->L.sim;
+        const int nthp_ = h->L.nthp;
+        const size_t mp_ = ((size_t)h->P.m + 7) & ~(size_t)7;
+        const size_t ldsr = sizeof(double) * (mp_ * nthp_ + 2 * mp_ + (size_t)kMaxSimU * nthp_ + kMaxSimU + 64 + 8 * kMaxSimU);
+#define LMPC_SRUN(NM, NT) hipLaunchKernelGGL((sim_run_kernel<NM, NT>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
+            const_cast<double *>(theta), Sf.kstep, h->asyncT, active, warm != nullptr ? 1 : 0, Sf.utraj, Sf.xtraj_base, \
+            Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt)
+        switch (h->P.nth) {
+            case 1: LMPC_SRUN(8, 1); break;    case 2: LMPC_SRUN(8, 2); break;    case 3: LMPC_SRUN(8, 3); break;
+            case 4: LMPC_SRUN(8, 4); break;    case 5: LMPC_SRUN(8, 5); break;    case 6: LMPC_SRUN(8, 6); break;
+            case 7: LMPC_SRUN(8, 7); break;    case 8: LMPC_SRUN(8, 8); break;    case 9: LMPC_SRUN(16, 9); break;
+            case 10: LMPC_SRUN(16, 10); break; case 11: LMPC_SRUN(16, 11); break; case 12: LMPC_SRUN(16, 12); break;
+            case 13: LMPC_SRUN(16, 13); break; case 14: LMPC_SRUN(16, 14); break; case 15: LMPC_SRUN(16, 15); break;
+            case 16: LMPC_SRUN(16, 16); break;
+            default: return fail(h, LMPC_ERR_BADARG, "lmpc: sim_run needs nth <= 16");
+        }
+#undef LMPC_SRUN
+        HIP_TRY(h, hipGetLastError());
+        if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
+        return LMPC_OK;
+    } else if (screened) {
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
@@ -356,7 +395,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
 #undef LMPC_SCR
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
-    const int32_t *list = screened ? h->dList : nullptr;
+    const int32_t *list = screened ? (h->asyncPhase == 2 ? h->asyncListOut : h->dList) : nullptr;
     const int32_t *count = cnt_now;
     // problems whose constraints are exactly the n simple bounds (ms == m == n == N) get the
     // instantiation with the row scans unrolled and the working-set capacity cut to N
@@ -383,8 +422,8 @@ int ensure_sim(lmpc_handle *h, int64_t N) {
     if (N <= h->simCap) return LMPC_OK;
     const int nu = h->P.nout;
     const size_t w = (size_t)h->P.words();
-    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG);
-    h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simCap = 0;
+    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simFG); hipFree(h->simK);
+    h->simTheta = h->simTheta2 = h->simU = h->simFG = nullptr; h->simFlag = nullptr; h->simAct = nullptr; h->simK = nullptr; h->simCap = 0;
     HIP_TRY(h, hipMalloc(&h->simTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
     HIP_TRY(h, hipMalloc(&h->simU, sizeof(double) * (size_t)N * (nu ? nu : 1)));
     HIP_TRY(h, hipMalloc(&h->simFlag, sizeof(int32_t) * (size_t)N));
@@ -626,6 +665,76 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // Lane / screening kernels: the kernel that finishes a problem also advances its scenario and
     // writes the next step's record into the other theta buffer (SimFuse) -- a closed-loop step is
     // the solve's two launches and nothing else
+    // Scenario-asynchronous loop (lmpc_simrun_kernel.hpp): scenarios are independent, so each one runs ahead
+    // in registers through its unconstrained steps and only the steps that need iterations go through the
+    // iterating kernel, one round per such step.  The host reads the work-list counters after every
+    // streaming pass (one stream synchronisation per round) and stops when nothing is queued any more.
+    if (!h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N)) {
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
+        if (!h->simK) HIP_TRY(h, hipMalloc(&h->simK, sizeof(int32_t) * (size_t)h->simCap));
+        HIP_TRY(h, hipMemsetAsync(h->simK, 0, sizeof(int32_t) * (size_t)N, st));
+        if (warm) HIP_TRY(h, hipMemsetAsync(h->simAct, 0, sizeof(uint64_t) * (size_t)N * (size_t)h->P.words(), st));   // first step is cold
+        const bool prof = h->prof;
+        h->prof = false;
+        h->asyncT = T;
+        h->L.sim = SimFuse{h->simFG, h->simTheta, flag_min, nullptr, nx, nu, nr, nuprev, 0, h->simK, U_traj, X_traj,
+                           (long long)N};
+        constexpr int kBurst = 2;   // steps a scenario of a (short) work list may run ahead before it is parked
+        const size_t setLen = (size_t)kShards * kCountStride;
+        std::vector<int32_t> hc(3 * setLen);
+        uint64_t *masks = warm ? h->simAct : nullptr;
+        int rc = LMPC_OK;
+        h->asyncListIn = h->asyncCntIn = nullptr;
+        h->asyncCap = T + 1;
+        h->asyncResetPark = false;
+        const bool dbg = std::getenv("LMPC_DEBUG_SIM") != nullptr;
+        // pass 0 runs every scenario up to its first step that needs iterations; then: solve that step for the
+        // listed scenarios, let them run ahead a little (most meet the next such step at once: the transient),
+        // park the ones that broke free; when the list has drained, run the parked ones on, compacted.
+        for (int pass = 0; pass <= 2 * T + 4 && rc == LMPC_OK; pass++) {
+            h->asyncPhase = 1;
+            rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
+            if (rc != LMPC_OK) break;
+            if (hipMemcpyAsync(hc.data(), h->dCount, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { rc = fail(h, LMPC_ERR_HIP, "lmpc_simulate: reading the work-list counters"); break; }
+            const size_t off = (size_t)(h->asyncCntNow - h->dCount);
+            long long queued = 0, longest = 0, parked = 0, plongest = 0;
+            for (int sh = 0; sh < kShards; sh++) {
+                const long long q = hc[off + (size_t)sh * kCountStride], pk = h->asyncResetPark ? 0 : hc[2 * setLen + (size_t)sh * kCountStride];
+                queued += q; parked += pk;
+                longest = q > longest ? q : longest;
+                plongest = pk > plongest ? pk : plongest;
+            }
+            if (dbg) std::fprintf(stderr, "lmpc sim pass %d: %lld scenarios queued, %lld parked\n", pass, queued, parked);
+            h->asyncResetPark = false;
+            if (queued > 0) {
+                h->asyncPhase = 2;
+                rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
+                h->asyncListIn = h->asyncListOut; h->asyncCntIn = h->asyncCntNow; h->asyncMaxIn = longest;
+                h->asyncCap = kBurst;
+            } else if (parked > 0) {
+                // no iterating kernel ran, so nobody cleared the counter set the next pass writes
+                if (hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 2 * setLen, st) != hipSuccess) { rc = fail(h, LMPC_ERR_HIP, "lmpc_simulate: clearing the work-list counters"); break; }
+                h->asyncListIn = h->dList3; h->asyncCntIn = h->dCount + 2 * setLen; h->asyncMaxIn = plongest;
+                h->asyncCap = T + 1;
+                h->asyncResetPark = true;
+            } else {
+                break;
+            }
+        }
+        h->asyncPhase = 0;
+        h->asyncListIn = h->asyncCntIn = nullptr;
+        // the last streaming pass queued nothing, so no iterating kernel cleared the other counter set
+        if (h->dCount) { hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st); h->countSet = 0; }
+        h->L.sim = SimFuse{};
+        h->prof = prof;
+        if (rc != LMPC_OK) return rc;
+        hipLaunchKernelGGL(unpack_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, nuprev > 0 ? uprev : nullptr,
+                           nx, nr, nuprev, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+        return LMPC_OK;
+    }
     if (!h->useWave && h->simFused && nu <= kMaxSimU) {
         HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
         HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
@@ -1181,6 +1290,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");
@@ -1203,8 +1313,8 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
-    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct);
+    hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
+    hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
     delete h;

@@ -41,6 +41,7 @@ struct lmpc_handle {
     int64_t sCap = 0;
     // work list of the problems the screening pass leaves for the iterating kernel
     int32_t *dList = nullptr, *dCount = nullptr;
+    int32_t *dList2 = nullptr, *dList3 = nullptr;          // second work list of the scenario-asynchronous closed loop (lists alternate per round)
     int64_t listCap = 0;        // batch size the list buffer was sized for
     int countSet = 0;           // which of the two counter sets the next call uses
     bool screen = true;         // two-pass (screen + iterate) for cold starts; lmpc_set_option
@@ -64,6 +65,15 @@ struct lmpc_handle {
     int numCU = 256;
     // closed-loop simulation scratch
     double *simTheta = nullptr, *simTheta2 = nullptr, *simU = nullptr, *simFG = nullptr;
+    int asyncPhase = 0, asyncT = 0;     // scenario-asynchronous closed loop: which half `launch` runs (0 = off)
+    int32_t *asyncCntNow = nullptr, *asyncCntNext = nullptr;
+    int32_t *asyncListOut = nullptr;    // ... the list the last streaming pass wrote (the iterating half reads it)
+    const int32_t *asyncListIn = nullptr, *asyncCntIn = nullptr;   // ... the round before's list: the scenarios to continue
+    int asyncCap = 0;                   // ... steps a scenario may run ahead in this streaming pass
+    bool asyncResetPark = false;        // ... this pass consumes the parked list: clear its counters afterwards
+    long long asyncMaxIn = 0;           // ... its longest shard segment (sizes the grid)
+    int32_t *simK = nullptr;            // per-scenario step counters
+    int simAsync = 1;           // tuning: scenario-asynchronous closed loop ("sim_async")
     int ccFused = 1;            // tuning: lmpc_compute_control assembles theta inside the screening kernel ("cc_fused")
     int simFused = 1;           // tuning: plant step inside the lane / screening kernels (lmpc_set_option "sim_fused")
     int32_t *simFlag = nullptr;

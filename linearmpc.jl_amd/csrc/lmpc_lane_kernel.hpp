@@ -48,6 +48,42 @@ __device__ __forceinline__ void sim_advance(const SimFuse &S, const double *__re
     const int nth = nx + nr + nup;
     const double *F = FGc, *G = FGc + nx * nx;            // inside the constant pack: scalar loads
     double *to = S.theta_out + pid * nth;
+    if (S.kstep != nullptr) {
+        // scenario-asynchronous mode: in place (to == th), so the old state is taken into registers first
+        // (nx <= 8, checked by the host); trajectories at this scenario's own step
+        const int k = S.kstep[pid];
+        double xo[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) xo[c] = c < nx ? th[c] : 0.0;
+        double xn[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            double acc = 0.0;
+            if (a < nx) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+                    if (c < nx) acc = __builtin_fma(F[a * nx + c], xo[c], acc);
+#pragma unroll
+                for (int l = 0; l < kMaxSimU; l++)
+                    if (l < nu) acc = __builtin_fma(G[a * nu + l], u[l], acc);
+            }
+            xn[a] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+            if (a < nx) {
+                to[a] = xn[a];
+                if (S.xtraj_base) S.xtraj_base[((long long)(k + 1) * S.nscen + pid) * nx + a] = xn[a];
+            }
+#pragma unroll
+        for (int l = 0; l < kMaxSimU; l++) {
+            if (l < nup) to[nx + nr + l] = u[l];
+            if (l < nu && S.utraj) S.utraj[((long long)k * S.nscen + pid) * nu + l] = u[l];
+        }
+        if (S.flag_min) S.flag_min[pid] = k == 0 ? flag : (flag < S.flag_min[pid] ? flag : S.flag_min[pid]);
+        S.kstep[pid] = k + 1;
+        return;
+    }
     for (int a = 0; a < nx; a++) {
         double acc = 0.0;
         for (int c = 0; c < nx; c++) acc = __builtin_fma(F[a * nx + c], th[c], acc);

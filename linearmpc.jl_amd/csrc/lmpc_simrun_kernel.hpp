@@ -1,0 +1,183 @@
+// Scenario-asynchronous closed loop, streaming half: every lane owns one scenario and advances it, IN
+// REGISTERS, through as many time steps as its problem stays "finished by screening" (no violated row at
+// u = 0, empty warm mask) -- u = x0 + Xth theta, x+ = F x + G u, theta <- [x+; r; u] -- and stops at the first
+// step that needs iterations (or at T).  It writes the record and the scenario's step counter back once and
+// queues the scenario for the iterating kernel, which solves that one step, advances the scenario
+// (sim_advance, in place) and hands it back for the next round.
+//
+// Scenarios are independent of each other, so the lock-step of the reference's Simulation loop
+// (src/simulation.jl:93-113) is not needed for the result: per scenario and step the arithmetic is the one
+// of screen_kernel / lane_solve / plant_kernel, hence the trajectories equal the lock-step ones bit for
+// bit.  What changes is the traffic: a settled loop costs no memory round trip per step at all.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "lmpc_lane_kernel.hpp"
+
+namespace lmpc {
+
+template <int NTHMAX, int NT>
+__global__ __launch_bounds__(256) void sim_run_kernel(
+    const PackLayout P, const double *__restrict__ C, double *theta, int32_t *kstep, const int T,
+    uint64_t *active, const int use_warm, double *U_traj, double *X_traj, int32_t *flag_min,
+    int32_t *__restrict__ list, int32_t *__restrict__ count, const long long seg_cap, const int nshards,
+    const long long nprob, const int32_t *__restrict__ list_in, const int32_t *count_in,
+    const int step_cap, int32_t *__restrict__ park_list, int32_t *park_count) {
+    static_assert(NT <= 16, "exact parameter count");
+    const int m = P.m, tid = threadIdx.x, lane = tid & 63;
+    const int shard = blockIdx.x & (nshards - 1);
+    // round 0 walks all scenarios; later rounds only those the iterating kernel just advanced -- the list of
+    // the round before, shard by shard, so that wavefronts stay full however few scenarios are still running
+    long long pid = (long long)blockIdx.x * blockDim.x + tid;
+    bool valid = pid < nprob;
+    if (list_in != nullptr) {
+        const long long idx = (long long)(blockIdx.x / nshards) * blockDim.x + tid;
+        valid = idx < (long long)count_in[shard * kCountStride];
+        pid = valid ? (long long)list_in[(long long)shard * seg_cap + idx] : 0;
+    }
+    const long long pc = valid ? pid : nprob - 1;
+    const double ntol = -P.primal_tol;
+    const int nx = P.sim.nx, nu = P.sim.nu, nr = P.sim.nr, nup = P.sim.nup;
+    // The constants of a step are used again at every one of up to T steps: they are staged in LDS once per
+    // workgroup and read from there by uniform (broadcast) addresses.  They are staged PADDED, so that the
+    // step below is branch-free and its chains are independent (a wavefront that runs alone through ~100
+    // steps is bound by the latency of one step, not by its instruction count):
+    //   rows of Dth to a multiple of 8; padding rows and rows that are ignored at start (imm_mask) get the
+    //     bounds (+1e300, -1e300), which no finite b violates -- only the truth value `hard` leaves the test;
+    //   Xth / x0 to kMaxSimU rows of zeros (u_l = 0 + 0 = +0 for l >= nu, used nowhere);
+    //   F to NXP x NXP, G to NXP x kMaxSimU with zeros: fma(0, finite, acc) == acc bit for bit (acc starts
+    //     at +0 and a sum of finite terms is never -0), so the padded chains equal plant_kernel's.
+    extern __shared__ double sc[];
+    const int mp = (m + 7) & ~7, nxp = nx <= 4 ? 4 : 8;
+    double *sD = sc, *sBnd = sD + mp * NTHMAX, *sXth = sBnd + 2 * mp, *sx0 = sXth + kMaxSimU * NTHMAX,
+           *sF = sx0 + kMaxSimU, *sG = sF + 64;
+    for (int i = tid; i < mp * NTHMAX; i += blockDim.x) sD[i] = i < m * NTHMAX ? C[P.oDthP + i] : 0.0;
+    for (int i = tid; i < 2 * mp; i += blockDim.x) {
+        const int j = i >> 1;
+        const bool live = j < m && !((P.imm_mask >> j) & 1ull);
+        sBnd[i] = live ? C[P.oBnd + i] : ((i & 1) ? -1e300 : 1e300);
+    }
+    for (int i = tid; i < kMaxSimU * NTHMAX; i += blockDim.x) sXth[i] = i < nu * NTHMAX ? C[P.oXthP + i] : 0.0;
+    for (int i = tid; i < kMaxSimU; i += blockDim.x) sx0[i] = i < nu ? C[P.ox0 + i] : 0.0;
+    for (int i = tid; i < 64; i += blockDim.x) {
+        const int a_ = i / nxp, c_ = i % nxp;
+        sF[i] = (a_ < nx && c_ < nx) ? C[P.oFG + a_ * nx + c_] : 0.0;
+    }
+    for (int i = tid; i < 8 * kMaxSimU; i += blockDim.x) {
+        const int a_ = i / kMaxSimU, l_ = i % kMaxSimU;
+        sG[i] = (a_ < nx && l_ < nu) ? C[P.oFG + nx * nx + a_ * nu + l_] : 0.0;
+    }
+    __syncthreads();
+
+    int k = valid ? kstep[pc] : T;
+    const int k0 = k;
+    double th[NT];
+    {
+        const double *src = theta + pc * NT;
+#pragma unroll
+        for (int t = 0; t < NT; t++) th[t] = src[t];
+    }
+    bool wany = false;
+    if (use_warm && active != nullptr && k < T)
+        for (int w = 0; w < P.words; w++) wany = wany || active[pc * P.words + w] != 0ull;
+
+    bool hard = false;
+    auto run = [&](auto nxp_c) {
+        constexpr int NXP = decltype(nxp_c)::value;
+        constexpr int NXS = NXP < NT ? NXP : NT;          // state rows that exist in the record
+        while (k < T && k - k0 < step_cap) {
+            // the screening test of this step: rows of  dl + b <= 0 <= du + b,  b = Dth theta  (screen_kernel's chains)
+            bool h_ = (k == k0) && wany;
+            for (int j0 = 0; j0 < mp; j0 += 8) {
+                double b[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const double *dj = sD + (j0 + jj) * NTHMAX;
+                    b[jj] = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) b[jj] = __builtin_fma(dj[t], th[t], b[jj]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const double vu = (sBnd[2 * (j0 + jj)] + b[jj]) - 0.0;
+                    const double vl = -((sBnd[2 * (j0 + jj) + 1] + b[jj]) - 0.0);
+                    h_ = h_ | (vu < ntol) | (vl < ntol);
+                }
+            }
+            hard = h_;
+            if (hard) break;
+            // finished by screening: u = x0 + Xth theta, then the plant step, all in registers
+            double uo[kMaxSimU];
+#pragma unroll
+            for (int l = 0; l < kMaxSimU; l++) {
+                double sh = sx0[l];
+                const double *xk = sXth + l * NTHMAX;
+#pragma unroll
+                for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                uo[l] = 0.0 + sh;
+            }
+            double rec[NT];
+#pragma unroll
+            for (int a = 0; a < NT; a++) {
+                rec[a] = th[a];
+                if (a < NXS) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NXS; c++) acc = __builtin_fma(sF[a * NXP + c], th[c], acc);
+#pragma unroll
+                    for (int l = 0; l < kMaxSimU; l++) acc = __builtin_fma(sG[a * kMaxSimU + l], uo[l], acc);
+                    rec[a] = a < nx ? acc : th[a];
+                }
+#pragma unroll
+                for (int l = 0; l < kMaxSimU; l++) rec[a] = (l < nup && a == nx + nr + l) ? uo[l] : rec[a];
+            }
+            if (U_traj) {
+#pragma unroll
+                for (int l = 0; l < kMaxSimU; l++)
+                    if (l < nu) U_traj[((long long)k * nprob + pid) * nu + l] = uo[l];
+            }
+            if (X_traj) {
+#pragma unroll
+                for (int a = 0; a < NXS; a++)
+                    if (a < nx) X_traj[((long long)(k + 1) * nprob + pid) * nx + a] = rec[a];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) th[t] = rec[t];
+            k++;
+        }
+    };
+    if (nxp == 4) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, 8>{});
+    if (valid && k > k0) {
+        double *dst = theta + pid * NT;
+#pragma unroll
+        for (int t = 0; t < NT; t++) dst[t] = th[t];
+        kstep[pid] = k;
+        if (active)
+            for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;   // the last step left no active row
+        if (flag_min) flag_min[pid] = (k0 == 0) ? (int)EXIT_OPTIMAL
+                                                : (EXIT_OPTIMAL < flag_min[pid] ? (int)EXIT_OPTIMAL : flag_min[pid]);
+    }
+    // scenarios that stopped at a step which needs iterations go on the work list (one atomic per wavefront);
+    // scenarios that used up their step allowance without meeting such a step are parked: a wavefront of a
+    // short list would otherwise spend ~2 us per step on a handful of lanes.  The host runs the parked
+    // scenarios on, compacted, once the work list has drained.
+    const bool queue = valid && k < T && hard;
+    const unsigned long long mask = __ballot(queue);
+    int basei = 0;
+    if (mask != 0ull && lane == 0) basei = atomicAdd(&count[shard * kCountStride], __popcll(mask));
+    basei = __shfl(basei, 0);
+    if (queue) list[(long long)shard * seg_cap + basei + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)pid;
+    const bool park = valid && k < T && !hard;
+    const unsigned long long pmask = __ballot(park);
+    int pbase = 0;
+    if (pmask != 0ull && lane == 0) pbase = atomicAdd(&park_count[shard * kCountStride], __popcll(pmask));
+    pbase = __shfl(pbase, 0);
+    if (park) park_list[(long long)shard * seg_cap + pbase + __popcll(pmask & ((1ull << lane) - 1ull))] = (int32_t)pid;
+}
+
+}  // namespace lmpc

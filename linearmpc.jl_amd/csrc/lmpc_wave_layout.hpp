@@ -15,6 +15,12 @@ struct SimFuse {
     int *flag_min;               // smallest exit flag over the steps so far, or nullptr
     double *xtraj;               // this step's slot of the state trajectory, or nullptr
     int nx, nu, nr, nup, first;
+    // scenario-asynchronous closed loop (kstep != nullptr): every scenario carries its own step counter, the
+    // records are updated IN PLACE (theta_out is the buffer being read), trajectories are addressed by the
+    // scenario's own step
+    int *kstep;
+    double *utraj, *xtraj_base;
+    long long nscen;
 };
 
 // Generated-controller mode of the screening kernel (lmpc_compute_control*): theta is not read from a

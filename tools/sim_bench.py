@@ -15,6 +15,7 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warm", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1) or lock-step (0)")
 ap.add_argument("--fused", type=int, default=1, help="plant step inside the solve kernels (1) or as its own kernel (0)")
 ap.add_argument("--groups", type=int, default=1,
                 help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
@@ -26,6 +27,7 @@ from oracle import mpc2mpqp as omm
 prob = omm.pendulum()
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
 qp.set_option("sim_fused", a.fused)
+qp.set_option("sim_async", a.asyn)
 rng = np.random.default_rng(0)
 N, T = a.n, a.steps
 dev = torch.device("cuda", 0)
