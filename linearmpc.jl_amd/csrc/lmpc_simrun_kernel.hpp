@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
         for (int w = 0; w < P.words; w++) wany = wany || active[pc * P.words + w] != 0ull;
 
     bool hard = false;
-    auto run = [&](auto nxp_c) {
+    auto run = [&](auto nxp_c, auto nu_c) {
         constexpr int NXP = decltype(nxp_c)::value;
+        constexpr int NUP = decltype(nu_c)::value;        // controls computed: 1 (a single input) or all kMaxSimU
         constexpr int NXS = NXP < NT ? NXP : NT;          // state rows that exist in the record
         while (k < T && k - k0 < step_cap) {
             // the screening test of this step: rows of  dl + b <= 0 <= du + b,  b = Dth theta  (screen_kernel's chains)
@@ -114,11 +115,14 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
             double uo[kMaxSimU];
 #pragma unroll
             for (int l = 0; l < kMaxSimU; l++) {
-                double sh = sx0[l];
-                const double *xk = sXth + l * NTHMAX;
+                uo[l] = 0.0;
+                if (l < NUP) {
+                    double sh = sx0[l];
+                    const double *xk = sXth + l * NTHMAX;
 #pragma unroll
-                for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
-                uo[l] = 0.0 + sh;
+                    for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                    uo[l] = 0.0 + sh;
+                }
             }
             double rec[NT];
 #pragma unroll
@@ -129,12 +133,17 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
 #pragma unroll
                     for (int c = 0; c < NXS; c++) acc = __builtin_fma(sF[a * NXP + c], th[c], acc);
 #pragma unroll
-                    for (int l = 0; l < kMaxSimU; l++) acc = __builtin_fma(sG[a * kMaxSimU + l], uo[l], acc);
+                    for (int l = 0; l < NUP; l++) acc = __builtin_fma(sG[a * kMaxSimU + l], uo[l], acc);
                     rec[a] = a < nx ? acc : th[a];
                 }
-#pragma unroll
-                for (int l = 0; l < kMaxSimU; l++) rec[a] = (l < nup && a == nx + nr + l) ? uo[l] : rec[a];
             }
+            // the previous-control block of the record (uniform branches: nup is 0 or 1 for most controllers)
+#pragma unroll
+            for (int l = 0; l < NUP; l++)
+                if (l < nup) {
+#pragma unroll
+                    for (int a = 1; a < NT; a++) rec[a] = (a == nx + nr + l) ? uo[l] : rec[a];
+                }
             if (U_traj) {
 #pragma unroll
                 for (int l = 0; l < kMaxSimU; l++)
@@ -150,8 +159,10 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
             k++;
         }
     };
-    if (nxp == 4) run(std::integral_constant<int, 4>{});
-    else run(std::integral_constant<int, 8>{});
+    if (nxp == 4 && nu == 1) run(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+    else if (nxp == 4) run(std::integral_constant<int, 4>{}, std::integral_constant<int, kMaxSimU>{});
+    else if (nu == 1) run(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 8>{}, std::integral_constant<int, kMaxSimU>{});
     if (valid && k > k0) {
         double *dst = theta + pid * NT;
 #pragma unroll
