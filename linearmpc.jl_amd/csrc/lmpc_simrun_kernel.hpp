@@ -93,22 +93,28 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
         while (k < T && k - k0 < step_cap) {
             // the screening test of this step: rows of  dl + b <= 0 <= du + b,  b = Dth theta  (screen_kernel's chains)
             bool h_ = (k == k0) && wany;
-            for (int j0 = 0; j0 < mp; j0 += 8) {
-                double b[8];
+            auto rows = [&](auto ch_c, const int j0) {
+                constexpr int CH = decltype(ch_c)::value;
+                double b[CH];
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
+                for (int jj = 0; jj < CH; jj++) {
                     const double *dj = sD + (j0 + jj) * NTHMAX;
                     b[jj] = 0.0;
 #pragma unroll
                     for (int t = 0; t < NT; t++) b[jj] = __builtin_fma(dj[t], th[t], b[jj]);
                 }
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
+                for (int jj = 0; jj < CH; jj++) {
                     const double vu = (sBnd[2 * (j0 + jj)] + b[jj]) - 0.0;
                     const double vl = -((sBnd[2 * (j0 + jj) + 1] + b[jj]) - 0.0);
                     h_ = h_ | (vu < ntol) | (vl < ntol);
                 }
-            }
+            };
+            // rows in groups of 8 independent chains, then 4, then one at a time (m = 5: 4 + 1, nothing padded)
+            int j0 = 0;
+            for (; j0 + 8 <= m; j0 += 8) rows(std::integral_constant<int, 8>{}, j0);
+            if (j0 + 4 <= m) { rows(std::integral_constant<int, 4>{}, j0); j0 += 4; }
+            for (; j0 < m; j0++) rows(std::integral_constant<int, 1>{}, j0);
             hard = h_;
             if (hard) break;
             // finished by screening: u = x0 + Xth theta, then the plant step, all in registers
