@@ -713,6 +713,16 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
                 rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
                 h->asyncListIn = h->asyncListOut; h->asyncCntIn = h->asyncCntNow; h->asyncMaxIn = longest;
                 h->asyncCap = kBurst;
+                // a few more rounds without asking: a list never grows from one round to the next, so the grid of
+                // `longest` covers them, and a round on an empty list costs less than the host round trip it saves
+                for (int e = 0; e < h->simBlind && rc == LMPC_OK; e++) {
+                    h->asyncPhase = 1;
+                    rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
+                    if (rc != LMPC_OK) break;
+                    h->asyncPhase = 2;
+                    rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
+                    h->asyncListIn = h->asyncListOut; h->asyncCntIn = h->asyncCntNow;
+                }
             } else if (parked > 0) {
                 // no iterating kernel ran, so nobody cleared the counter set the next pass writes
                 if (hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 2 * setLen, st) != hipSuccess) { rc = fail(h, LMPC_ERR_HIP, "lmpc_simulate: clearing the work-list counters"); break; }
@@ -1290,6 +1300,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "sim_blind") == 0) { h->simBlind = value < 0 ? 0 : value; return LMPC_OK; }
     if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)

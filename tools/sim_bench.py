@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warm", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1) or lock-step (0)")
+ap.add_argument("--blind", type=int, default=-1, help="rounds enqueued between two counter reads (library default if < 0)")
 ap.add_argument("--fused", type=int, default=1, help="plant step inside the solve kernels (1) or as its own kernel (0)")
 ap.add_argument("--groups", type=int, default=1,
                 help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
@@ -28,6 +29,8 @@ prob = omm.pendulum()
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
+if a.blind >= 0:
+    qp.set_option("sim_blind", a.blind)
 rng = np.random.default_rng(0)
 N, T = a.n, a.steps
 dev = torch.device("cuda", 0)
