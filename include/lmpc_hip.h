@@ -342,7 +342,11 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
 
 /* Tuning switches: "screen" (default 1) = run cold-start batches through the streaming
  * screening pass before the iterating kernel; 0 = iterating kernel only.  Results are
- * bit-identical either way. */
+ * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
+ * advance independently of each other (rounds of a streaming kernel and the iterating kernel),
+ * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two
+ * reads of the work-list counters; "sim_fused" (default 1) = plant step inside the solve's
+ * kernels.  All of them change the execution order only, never a result. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
 void lmpc_free(lmpc_handle *h);

@@ -421,6 +421,34 @@ def test_closed_loop_simulation_matches_oracle(lmpc, warm):
     assert abs(out["U"][0, 0, 0] - 1.7612519326) < 1e-6
 
 
+@pytest.mark.parametrize("warm", [False, True])
+def test_closed_loop_execution_modes_agree_bit_for_bit(lmpc, warm):
+    # scenario-asynchronous rounds (default), with and without un-asked rounds, the lock-step fused loop and
+    # the unfused one run the same arithmetic per scenario and step: identical arrays, not merely close ones.
+    # Sizes that are no multiple of a wavefront, a one-step loop, and a scenario that needs iterations at
+    # every step of the transient (x0 far out) are in the set.
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    prob = omm.pendulum()
+    g = load_golden("pendulum")
+    rng = np.random.default_rng(21)
+    for N, T in ((1, 1), (37, 3), (700, 60)):
+        x0 = rng.uniform([-8, -5, -.3, -2], [8, 5, .3, 2], (N, 4))
+        r = np.stack([rng.uniform(-4, 4, N), np.zeros(N)], 1)
+        outs = []
+        for opts in ({}, {"sim_blind": 0}, {"sim_blind": 5}, {"sim_async": 0}, {"sim_async": 0, "sim_fused": 0}):
+            qp = _qp_from_golden(lmpc, g, 1)
+            for k, v in opts.items():
+                qp.set_option(k, v)
+            outs.append(qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm))
+        ref = oldp.simulate(oracle_ldp_from(qp.ldp()), x0, T, prob.F, prob.G, r=r, warm=warm)
+        assert np.array_equal(outs[0]["flag_min"], ref["flag_min"])
+        assert np.abs(outs[0]["U"] - ref["U"]).max() <= TOL and np.abs(outs[0]["X"] - ref["X"]).max() <= TOL
+        for o in outs[1:]:
+            for key in ("U", "X", "x", "uprev", "flag_min"):
+                assert np.array_equal(o[key], outs[0][key]), (N, T, key)
+
+
 def test_closed_loop_simulation_soft_problem_wave_kernel(lmpc):
     from oracle import ldp as oldp
     from oracle import mpc2mpqp as omm

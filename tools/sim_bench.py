@@ -17,6 +17,7 @@ ap.add_argument("--warm", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1) or lock-step (0)")
 ap.add_argument("--blind", type=int, default=-1, help="rounds enqueued between two counter reads (library default if < 0)")
+ap.add_argument("--traj", type=int, default=0, help="also record the U (T x N x nu) and X ((T+1) x N x nx) trajectories")
 ap.add_argument("--fused", type=int, default=1, help="plant step inside the solve kernels (1) or as its own kernel (0)")
 ap.add_argument("--groups", type=int, default=1,
                 help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
@@ -39,12 +40,15 @@ r = torch.from_numpy(np.hstack([rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1))])).
 F = np.ascontiguousarray(prob.F); G = np.ascontiguousarray(prob.G)
 vp = ctypes.c_void_p
 fm = torch.empty(N, dtype=torch.int32, device=dev)
+Ut = torch.empty((T, N, 1), dtype=torch.float64, device=dev) if a.traj else None
+Xt = torch.empty((T + 1, N, 4), dtype=torch.float64, device=dev) if a.traj else None
 for rep in range(a.reps):
     x = x0.clone(); up = torch.zeros((N, 1), dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     check(lib().lmpc_simulate_device(qp._h, N, T, 4, 2, 1, vp(F.ctypes.data), vp(G.ctypes.data), vp(x.data_ptr()),
-                                     vp(r.data_ptr()), vp(up.data_ptr()), None, None, vp(fm.data_ptr()), a.warm,
+                                     vp(r.data_ptr()), vp(up.data_ptr()), vp(Ut.data_ptr()) if a.traj else None,
+                                     vp(Xt.data_ptr()) if a.traj else None, vp(fm.data_ptr()), a.warm,
                                      vp(torch.cuda.current_stream(dev).cuda_stream)), qp._h)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
