@@ -90,6 +90,28 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
         constexpr int NXP = decltype(nxp_c)::value;
         constexpr int NUP = decltype(nu_c)::value;        // controls computed: 1 (a single input) or all kMaxSimU
         constexpr int NXS = NXP < NT ? NXP : NT;          // state rows that exist in the record
+        // single input, nx <= 4: the plant and the output map (28 values at NT = 7) are kept as wave-uniform
+        // values -- scalar registers, a free operand of the fma -- instead of being read from LDS every step
+        constexpr bool UNI = (NXP == 4 && NUP == 1);
+        constexpr int NUF = UNI ? NXS * NXS : 1, NUG = UNI ? NXS : 1, NUX = UNI ? NT : 1;
+        double cF[NUF], cG[NUG], cX[NUX], cx0 = 0.0;
+        if constexpr (UNI) {
+            auto uni = [](double v) {
+                const long long b = __builtin_bit_cast(long long, v);
+                const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+                return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+            };
+#pragma unroll
+            for (int a = 0; a < NXS; a++) {
+#pragma unroll
+                for (int c = 0; c < NXS; c++) cF[a * NXS + c] = uni(sF[a * NXP + c]);
+                cG[a] = uni(sG[a * kMaxSimU]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) cX[t] = uni(sXth[t]);
+            cx0 = uni(sx0[0]);
+        }
         while (k < T && k - k0 < step_cap) {
             // the screening test of this step: rows of  dl + b <= 0 <= du + b,  b = Dth theta  (screen_kernel's chains)
             bool h_ = (k == k0) && wany;
@@ -123,10 +145,10 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
             for (int l = 0; l < kMaxSimU; l++) {
                 uo[l] = 0.0;
                 if (l < NUP) {
-                    double sh = sx0[l];
+                    double sh = UNI ? cx0 : sx0[l];
                     const double *xk = sXth + l * NTHMAX;
 #pragma unroll
-                    for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                    for (int t = 0; t < NT; t++) sh = __builtin_fma(UNI ? cX[UNI ? t : 0] : xk[t], th[t], sh);
                     uo[l] = 0.0 + sh;
                 }
             }
@@ -137,9 +159,9 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
                 if (a < NXS) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int c = 0; c < NXS; c++) acc = __builtin_fma(sF[a * NXP + c], th[c], acc);
+                    for (int c = 0; c < NXS; c++) acc = __builtin_fma(UNI ? cF[UNI ? a * NXS + c : 0] : sF[a * NXP + c], th[c], acc);
 #pragma unroll
-                    for (int l = 0; l < NUP; l++) acc = __builtin_fma(sG[a * kMaxSimU + l], uo[l], acc);
+                    for (int l = 0; l < NUP; l++) acc = __builtin_fma(UNI ? cG[UNI ? a : 0] : sG[a * kMaxSimU + l], uo[l], acc);
                     rec[a] = a < nx ? acc : th[a];
                 }
             }
