@@ -345,7 +345,8 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
  * advance independently of each other (rounds of a streaming kernel and the iterating kernel),
  * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two
- * reads of the work-list counters; "sim_fused" (default 1) = plant step inside the solve's
+ * reads of the work-list counters; "sim_small" (default 1) = the all-in-registers instantiation
+ * of the streaming kernel for single-input problems with nx <= 4, m <= 8; "sim_fused" (default 1) = plant step inside the solve's
  * kernels.  All of them change the execution order only, never a result. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 

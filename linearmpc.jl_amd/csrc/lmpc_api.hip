@@ -357,9 +357,12 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         const int nthp_ = h->L.nthp;
         const size_t mp_ = ((size_t)h->P.m + 7) & ~(size_t)7;
         const size_t ldsr = sizeof(double) * (mp_ * nthp_ + 2 * mp_ + (size_t)kMaxSimU * nthp_ + kMaxSimU + 64 + 8 * kMaxSimU);
-#define LMPC_SRUN(NM, NT) hipLaunchKernelGGL((sim_run_kernel<NM, NT>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
+        const bool small_ = h->simSmall && Sf.nx <= 4 && Sf.nu == 1 && h->P.m >= 1 && h->P.m <= 8 && h->P.nth <= 8;
+#define LMPC_SRUN_(NM, NT, SM) hipLaunchKernelGGL((sim_run_kernel<NM, NT, SM>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
             const_cast<double *>(theta), Sf.kstep, h->asyncT, active, warm != nullptr ? 1 : 0, Sf.utraj, Sf.xtraj_base, \
             Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt)
+#define LMPC_SRUN(NM, NT) do { if constexpr (NT <= 8) { if (small_) LMPC_SRUN_(NM, NT, true); else LMPC_SRUN_(NM, NT, false); } \
+                                else LMPC_SRUN_(NM, NT, false); } while (0)
         switch (h->P.nth) {
             case 1: LMPC_SRUN(8, 1); break;    case 2: LMPC_SRUN(8, 2); break;    case 3: LMPC_SRUN(8, 3); break;
             case 4: LMPC_SRUN(8, 4); break;    case 5: LMPC_SRUN(8, 5); break;    case 6: LMPC_SRUN(8, 6); break;
@@ -370,6 +373,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             default: return fail(h, LMPC_ERR_BADARG, "lmpc: sim_run needs nth <= 16");
         }
 #undef LMPC_SRUN
+#undef LMPC_SRUN_
         HIP_TRY(h, hipGetLastError());
         if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
         return LMPC_OK;
@@ -1300,6 +1304,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_blind") == 0) { h->simBlind = value < 0 ? 0 : value; return LMPC_OK; }
     if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {

@@ -20,7 +20,9 @@
 
 namespace lmpc {
 
-template <int NTHMAX, int NT>
+// SMALL: the instantiation for single-input problems with nx <= 4 and m <= 8 rows, all constants in registers
+// (244 VGPRs, two wavefronts per SIMD, no LDS read in the step); the general one keeps 4 wavefronts per SIMD.
+template <int NTHMAX, int NT, bool SMALL>
 __global__ __launch_bounds__(256) void sim_run_kernel(
     const PackLayout P, const double *__restrict__ C, double *theta, int32_t *kstep, const int T,
     uint64_t *active, const int use_warm, double *U_traj, double *X_traj, int32_t *flag_min,
@@ -86,9 +88,10 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
         for (int w = 0; w < P.words; w++) wany = wany || active[pc * P.words + w] != 0ull;
 
     bool hard = false;
-    auto run = [&](auto nxp_c, auto nu_c) {
+    auto run = [&](auto nxp_c, auto nu_c, auto m_c) {
         constexpr int NXP = decltype(nxp_c)::value;
-        constexpr int NUP = decltype(nu_c)::value;        // controls computed: 1 (a single input) or all kMaxSimU
+        constexpr int NUP = decltype(nu_c)::value;
+        constexpr int MC = decltype(m_c)::value;          // > 0: exactly MC rows, held in registers (small problems)        // controls computed: 1 (a single input) or all kMaxSimU
         constexpr int NXS = NXP < NT ? NXP : NT;          // state rows that exist in the record
         // single input, nx <= 4: the plant and the output map (28 values at NT = 7) are kept as wave-uniform
         // values -- scalar registers, a free operand of the fma -- instead of being read from LDS every step
@@ -112,6 +115,20 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
             for (int t = 0; t < NT; t++) cX[t] = uni(sXth[t]);
             cx0 = uni(sx0[0]);
         }
+        // small problems (m <= 8, single input, nx <= 4): the rows of Dth and the bounds live in vector registers
+        // for the whole run -- the step then has no LDS read left, which is what bounded it (64 lanes x 16 B
+        // per broadcast read, one LDS pipe for four SIMDs)
+        constexpr int NCD = MC > 0 ? MC * NT : 1, NCB = MC > 0 ? MC : 1;
+        double cD[NCD], cBu[NCB], cBl[NCB];
+        if constexpr (MC > 0) {
+#pragma unroll
+            for (int j = 0; j < MC; j++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) cD[j * NT + t] = sD[j * NTHMAX + t];
+                cBu[j] = sBnd[2 * j];
+                cBl[j] = sBnd[2 * j + 1];
+            }
+        }
         while (k < T && k - k0 < step_cap) {
             // the screening test of this step: rows of  dl + b <= 0 <= du + b,  b = Dth theta  (screen_kernel's chains)
             bool h_ = (k == k0) && wany;
@@ -132,11 +149,27 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
                     h_ = h_ | (vu < ntol) | (vl < ntol);
                 }
             };
-            // rows in groups of 8 independent chains, then 4, then one at a time (m = 5: 4 + 1, nothing padded)
-            int j0 = 0;
-            for (; j0 + 8 <= m; j0 += 8) rows(std::integral_constant<int, 8>{}, j0);
-            if (j0 + 4 <= m) { rows(std::integral_constant<int, 4>{}, j0); j0 += 4; }
-            for (; j0 < m; j0++) rows(std::integral_constant<int, 1>{}, j0);
+            if constexpr (MC > 0) {
+                double b[NCB];
+#pragma unroll
+                for (int j = 0; j < MC; j++) {
+                    b[j] = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) b[j] = __builtin_fma(cD[j * NT + t], th[t], b[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < MC; j++) {
+                    const double vu = (cBu[j] + b[j]) - 0.0;
+                    const double vl = -((cBl[j] + b[j]) - 0.0);
+                    h_ = h_ | (vu < ntol) | (vl < ntol);
+                }
+            } else {
+                // rows in groups of 8 independent chains, then 4, then one at a time (m = 5: 4 + 1, nothing padded)
+                int j0 = 0;
+                for (; j0 + 8 <= m; j0 += 8) rows(std::integral_constant<int, 8>{}, j0);
+                if (j0 + 4 <= m) { rows(std::integral_constant<int, 4>{}, j0); j0 += 4; }
+                for (; j0 < m; j0++) rows(std::integral_constant<int, 1>{}, j0);
+            }
             hard = h_;
             if (hard) break;
             // finished by screening: u = x0 + Xth theta, then the plant step, all in registers
@@ -187,10 +220,26 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
             k++;
         }
     };
-    if (nxp == 4 && nu == 1) run(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-    else if (nxp == 4) run(std::integral_constant<int, 4>{}, std::integral_constant<int, kMaxSimU>{});
-    else if (nu == 1) run(std::integral_constant<int, 8>{}, std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 8>{}, std::integral_constant<int, kMaxSimU>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    using IU = std::integral_constant<int, kMaxSimU>;
+    if constexpr (SMALL) {       // host guarantees nxp == 4, nu == 1, 1 <= m <= 8
+        switch (m) {
+            case 1: run(I4{}, I1{}, std::integral_constant<int, 1>{}); break;
+            case 2: run(I4{}, I1{}, std::integral_constant<int, 2>{}); break;
+            case 3: run(I4{}, I1{}, std::integral_constant<int, 3>{}); break;
+            case 4: run(I4{}, I1{}, std::integral_constant<int, 4>{}); break;
+            case 5: run(I4{}, I1{}, std::integral_constant<int, 5>{}); break;
+            case 6: run(I4{}, I1{}, std::integral_constant<int, 6>{}); break;
+            case 7: run(I4{}, I1{}, std::integral_constant<int, 7>{}); break;
+            default: run(I4{}, I1{}, std::integral_constant<int, 8>{}); break;
+        }
+    } else if (nxp == 4 && nu == 1) run(I4{}, I1{}, I0{});
+    else if (nxp == 4) run(I4{}, IU{}, I0{});
+    else if (nu == 1) run(I8{}, I1{}, I0{});
+    else run(I8{}, IU{}, I0{});
     if (valid && k > k0) {
         double *dst = theta + pid * NT;
 #pragma unroll

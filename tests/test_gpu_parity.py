@@ -436,7 +436,8 @@ def test_closed_loop_execution_modes_agree_bit_for_bit(lmpc, warm):
         x0 = rng.uniform([-8, -5, -.3, -2], [8, 5, .3, 2], (N, 4))
         r = np.stack([rng.uniform(-4, 4, N), np.zeros(N)], 1)
         outs = []
-        for opts in ({}, {"sim_blind": 0}, {"sim_blind": 5}, {"sim_async": 0}, {"sim_async": 0, "sim_fused": 0}):
+        for opts in ({}, {"sim_small": 0}, {"sim_blind": 0}, {"sim_blind": 5}, {"sim_async": 0},
+                     {"sim_async": 0, "sim_fused": 0}):
             qp = _qp_from_golden(lmpc, g, 1)
             for k, v in opts.items():
                 qp.set_option(k, v)

@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1) or lock-step (0)")
 ap.add_argument("--blind", type=int, default=-1, help="rounds enqueued between two counter reads (library default if < 0)")
 ap.add_argument("--traj", type=int, default=0, help="also record the U (T x N x nu) and X ((T+1) x N x nx) trajectories")
+ap.add_argument("--small", type=int, default=1, help="all-in-registers streaming kernel (1) or the general one (0)")
 ap.add_argument("--fused", type=int, default=1, help="plant step inside the solve kernels (1) or as its own kernel (0)")
 ap.add_argument("--groups", type=int, default=1,
                 help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
@@ -30,6 +31,7 @@ prob = omm.pendulum()
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
+qp.set_option("sim_small", a.small)
 if a.blind >= 0:
     qp.set_option("sim_blind", a.blind)
 rng = np.random.default_rng(0)
