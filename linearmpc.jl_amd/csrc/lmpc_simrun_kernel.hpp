@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
     if (use_warm && active != nullptr && k < T)
         for (int w = 0; w < P.words; w++) wany = wany || active[pc * P.words + w] != 0ull;
 
+    const bool xvec = (nx & 1) == 0 && (reinterpret_cast<uintptr_t>(X_traj) & 15) == 0;
     bool hard = false;
     auto run = [&](auto nxp_c, auto nu_c, auto m_c) {
         constexpr int NXP = decltype(nxp_c)::value;
@@ -211,9 +212,16 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
                     if (l < nu) U_traj[((long long)k * nprob + pid) * nu + l] = uo[l];
             }
             if (X_traj) {
+                double *xd = X_traj + ((long long)(k + 1) * nprob + pid) * nx;
+                if (xvec) {          // even nx, 16-byte aligned rows: half as many store instructions
 #pragma unroll
-                for (int a = 0; a < NXS; a++)
-                    if (a < nx) X_traj[((long long)(k + 1) * nprob + pid) * nx + a] = rec[a];
+                    for (int a = 0; a + 1 < NXS; a += 2)
+                        if (a < nx) *reinterpret_cast<double2 *>(xd + a) = make_double2(rec[a], rec[a + 1]);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < NXS; a++)
+                        if (a < nx) xd[a] = rec[a];
+                }
             }
 #pragma unroll
             for (int t = 0; t < NT; t++) th[t] = rec[t];
