@@ -177,7 +177,12 @@ int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, f
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
 
 /*
- * Batched closed-loop simulation: N independent scenarios advanced T steps in lock-step on the GPU.
+ * Batched closed-loop simulation: N independent scenarios advanced T steps on the GPU (by default each
+ * scenario at its own pace -- the scenarios do not interact, so the arrays returned are those of the
+ * step-by-step loop bit for bit; lmpc_set_option "sim_async").  That execution order reads a few
+ * counters back between rounds: lmpc_simulate_device waits on `stream` a few times before it returns
+ * (its outputs are still only complete once `stream` is), so it cannot be captured into a hipGraph;
+ * with "sim_async" 0 it only enqueues.
  * Per step and scenario it does what one pass of the reference's Simulation loop does
  * (src/simulation.jl:93-113 without observer): theta = [x; r; uprev] (src/explicit.jl:54-63),
  * u = compute_control (the batched solve of this handle, which must have been set up with

@@ -450,6 +450,45 @@ def test_closed_loop_execution_modes_agree_bit_for_bit(lmpc, warm):
                 assert np.array_equal(o[key], outs[0][key]), (N, T, key)
 
 
+def test_closed_loop_random_shapes_all_execution_modes(lmpc):
+    # Random controllers on the lane-kernel path across the instantiations of the streaming kernel: one to four
+    # inputs, nx below and above 4, nth below and above 8, with and without reference / previous-control blocks,
+    # simple bounds only or general rows too.  Every execution order must reproduce the oracle's closed loop.
+    from oracle import ldp as oldp
+    rng = np.random.default_rng(77)
+    shapes = [(2, 1, 0, 1, 3, 0), (4, 1, 2, 1, 4, 3), (3, 2, 1, 2, 4, 2), (6, 2, 1, 2, 5, 0), (5, 3, 0, 3, 6, 4),
+              (8, 4, 2, 4, 6, 2), (4, 1, 0, 0, 2, 9), (7, 1, 3, 1, 3, 1)]
+    for nx, nu, nr, nup, n, mg in shapes:
+        nth = nx + nr + nup
+        H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth)
+        f_theta *= 0.6
+        qp0 = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+        assert "lane" in qp0.kernel_name
+        Fm = rng.standard_normal((nx, nx))
+        Fm *= 0.9 / np.abs(np.linalg.eigvals(Fm)).max()
+        Gm = 0.5 * rng.standard_normal((nx, nu))
+        N, T = 333, 25
+        x0 = rng.uniform(-2, 2, (N, nx))
+        r = rng.uniform(-1, 1, (N, nr)) if nr else None
+        L = oracle_ldp_from(qp0.ldp())
+        for warm in (False, True):
+            ref = oldp.simulate(L, x0, T, Fm, Gm, r=r, warm=warm)
+            first = None
+            for opts in ({}, {"sim_small": 0}, {"sim_async": 0}):
+                qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+                for k, v in opts.items():
+                    qp.set_option(k, v)
+                out = qp.simulate(x0, T, Fm, Gm, r=r, warm=warm)
+                assert np.array_equal(out["flag_min"], ref["flag_min"]), (nx, nu, nr, nup, opts)
+                assert np.abs(out["U"] - ref["U"]).max() <= TOL and np.abs(out["X"] - ref["X"]).max() <= TOL
+                if first is None:
+                    first = out
+                    assert (out["U"] != 0).any()
+                else:
+                    for key in ("U", "X", "x", "flag_min"):
+                        assert np.array_equal(out[key], first[key]), (nx, nu, nr, nup, opts, key)
+
+
 def test_closed_loop_simulation_soft_problem_wave_kernel(lmpc):
     from oracle import ldp as oldp
     from oracle import mpc2mpqp as omm
