@@ -360,7 +360,8 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         const bool small_ = h->simSmall && Sf.nx <= 4 && Sf.nu == 1 && h->P.m >= 1 && h->P.m <= 8 && h->P.nth <= 8;
 #define LMPC_SRUN_(NM, NT, SM) hipLaunchKernelGGL((sim_run_kernel<NM, NT, SM>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
             const_cast<double *>(theta), Sf.kstep, h->asyncT, active, warm != nullptr ? 1 : 0, Sf.utraj, Sf.xtraj_base, \
-            Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt)
+            Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt, \
+            h->asyncX, h->asyncR, h->asyncUp)
 #define LMPC_SRUN(NM, NT) do { if constexpr (NT <= 8) { if (small_) LMPC_SRUN_(NM, NT, true); else LMPC_SRUN_(NM, NT, false); } \
                                 else LMPC_SRUN_(NM, NT, false); } while (0)
         switch (h->P.nth) {
@@ -375,6 +376,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
 #undef LMPC_SRUN
 #undef LMPC_SRUN_
         HIP_TRY(h, hipGetLastError());
+        h->asyncX = h->asyncR = h->asyncUp = nullptr;       // only the first pass forms theta
         if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
         return LMPC_OK;
     } else if (screened) {
@@ -664,8 +666,11 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
     const unsigned grid = (unsigned)((N + 255) / 256);
     // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
-    hipLaunchKernelGGL(form_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
-                       nuprev, (long long)N);
+    // (the scenario-asynchronous loop forms it in its first streaming pass)
+    const bool asyncLoop = !h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N);
+    if (!asyncLoop)
+        hipLaunchKernelGGL(form_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
+                           nuprev, (long long)N);
     // Lane / screening kernels: the kernel that finishes a problem also advances its scenario and
     // writes the next step's record into the other theta buffer (SimFuse) -- a closed-loop step is
     // the solve's two launches and nothing else
@@ -673,7 +678,8 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // in registers through its unconstrained steps and only the steps that need iterations go through the
     // iterating kernel, one round per such step.  The host reads the work-list counters after every
     // streaming pass (one stream synchronisation per round) and stops when nothing is queued any more.
-    if (!h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N)) {
+    if (asyncLoop) {
+        h->asyncX = x; h->asyncR = r; h->asyncUp = nuprev > 0 ? uprev : nullptr;
         HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
         HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
         if (!h->simK) HIP_TRY(h, hipMalloc(&h->simK, sizeof(int32_t) * (size_t)h->simCap));

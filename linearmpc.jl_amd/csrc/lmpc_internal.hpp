@@ -69,6 +69,7 @@ struct lmpc_handle {
     int32_t *asyncCntNow = nullptr, *asyncCntNext = nullptr;
     int32_t *asyncListOut = nullptr;    // ... the list the last streaming pass wrote (the iterating half reads it)
     const int32_t *asyncListIn = nullptr, *asyncCntIn = nullptr;   // ... the round before's list: the scenarios to continue
+    const double *asyncX = nullptr, *asyncR = nullptr, *asyncUp = nullptr;   // ... first pass: form theta from these
     int simSmall = 1;                   // ... the all-in-registers instantiation of sim_run_kernel where it applies
     int simBlind = 2;                   // ... rounds enqueued between two reads of the work-list counters
     int asyncCap = 0;                   // ... steps a scenario may run ahead in this streaming pass

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
     uint64_t *active, const int use_warm, double *U_traj, double *X_traj, int32_t *flag_min,
     int32_t *__restrict__ list, int32_t *__restrict__ count, const long long seg_cap, const int nshards,
     const long long nprob, const int32_t *__restrict__ list_in, const int32_t *count_in,
-    const int step_cap, int32_t *__restrict__ park_list, int32_t *park_count) {
+    const int step_cap, int32_t *__restrict__ park_list, int32_t *park_count, const double *__restrict__ x_in,
+    const double *__restrict__ r_in, const double *__restrict__ up_in) {
     static_assert(NT <= 16, "exact parameter count");
     const int m = P.m, tid = threadIdx.x, lane = tid & 63;
     const int shard = blockIdx.x & (nshards - 1);
@@ -78,7 +79,17 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
     int k = valid ? kstep[pc] : T;
     const int k0 = k;
     double th[NT];
-    {
+    const bool formed = x_in != nullptr;     // first pass: theta = [x; r; uprev] is formed here (form_theta_kernel's rule)
+    if (formed) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            double v = 0.0;
+            if (t < nx) v = x_in[pc * nx + t];
+            else if (t < nx + nr) v = r_in ? r_in[pc * nr + (t - nx)] : 0.0;
+            else v = up_in ? up_in[pc * nup + (t - nx - nr)] : 0.0;
+            th[t] = v;
+        }
+    } else {
         const double *src = theta + pc * NT;
 #pragma unroll
         for (int t = 0; t < NT; t++) th[t] = src[t];
@@ -248,10 +259,12 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
     else if (nxp == 4) run(I4{}, IU{}, I0{});
     else if (nu == 1) run(I8{}, I1{}, I0{});
     else run(I8{}, IU{}, I0{});
-    if (valid && k > k0) {
+    if (valid && (k > k0 || formed)) {       // (a record formed here is stored even if its first step needs iterations)
         double *dst = theta + pid * NT;
 #pragma unroll
         for (int t = 0; t < NT; t++) dst[t] = th[t];
+    }
+    if (valid && k > k0) {
         kstep[pid] = k;
         if (active)
             for (int w = 0; w < P.words; w++) active[pid * P.words + w] = 0ull;   // the last step left no active row
