@@ -7,21 +7,34 @@
 
 One "step" = one pass of the hot path (lmpc_solve_batch_device: constraint shift, dual
 active-set solve, primal recovery) over one batch of 1e6 synthetic parameter points per GPU,
-already resident in HBM.  With N > 1 every rank (one process per GPU) owns its own 1e6-point
-shard (weak scaling).  The solve needs no data-path collective: shards are independent and their
-results stay on the GPU that produced them; the one exchange step -- an RCCL gather of the
-solutions and exit flags to rank 0 over xGMI (every rank sends on its own link) -- happens once,
-after the last step, inside the timed region (--gather step all-gathers after every step,
-overlapped with the next solve; at 12 MB per rank and step that exchange is ~10x longer than the
-30 us solve it follows, so it is not the default).  Consecutive steps are
-independent batches; by default three of them are kept in flight on three HIP streams (each with
-its own solver handle), which lets the streaming pass of one batch overlap the latency-bound
-iterating pass of another (--streams 1 serialises them).
+already resident in HBM.  Consecutive steps are DIFFERENT batches: the bench rotates through
+enough distinct theta / output buffers that more than 256 MiB passes between two uses of a line,
+so no step is served from the 256 MiB Infinity Cache ("cold HBM"; the cache-resident figures --
+one theta buffer reused every step -- are reported next to it, under roofline.cache_resident).
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).
+With N > 1 every rank (one process per GPU) owns its own 1e6-point shard (weak scaling).  The
+solve needs no data-path collective: shards are independent and their results stay on the GPU
+that produced them; the one exchange step -- an RCCL gather of the solutions and exit flags to
+rank 0 over xGMI (every rank sends on its own link) -- happens once, after the last step, inside
+the timed region (--gather step all-gathers after every step, overlapped with the next solve).
+By default three batches are kept in flight on three HIP streams (each with its own solver
+handle): the streaming pass of one batch overlaps the latency-bound iterating pass of another.
+
+Rank 0 prints ONE JSON line:
+  value / ms_per_step   whole-job throughput of the timed region (cold HBM, batches in flight)
+  roofline              ONE call at a time on one stream, cold HBM: algorithmic bytes of a call /
+                        the HIP-event duration of that call (screening kernel + iterating kernel);
+                        .pipelined = the same bytes / ms_per_step of the timed region;
+                        .cache_resident = both figures with one theta buffer reused
+  cpu_baseline          the C oracle on the host cores (kind "port": libdaqp is not available)
+  configs               the other single-GPU BASELINE.json configurations, measured in the same
+                        process: mass_spring_3in@1e6 (f64), hybrid (f32), pendulum_hard@1e6 --
+                        each with its own roofline (VALU flop based for the wavefront kernel)
+                        and cpu_baseline sample.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -34,6 +47,8 @@ if ROOT not in sys.path:
 
 BATCH = 1_000_000
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # dense vector peaks (MI355X_MICROARCH.md)
+L3_BYTES = 256 * 1024 * 1024     # Infinity Cache
 
 
 def make_problem(name):
@@ -70,62 +85,244 @@ def algorithmic_bytes(nth, nout, real_bytes=8):
     return real_bytes * nth + real_bytes * nout + 4
 
 
-def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=5.0):
-    """Single-thread CPU oracle (the restated DAQP algorithm) on a bounded sample of the same batch
-    (about 10-20 s of CPU work); a reported baseline, not the product path."""
-    from oracle import ldp as oldp
-    dt_ = np.float32 if f32 else np.float64
-    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
-    probe = min(1000, theta.shape[0])
-    t0 = time.perf_counter()
-    oldp.solve_batch(L, theta[:probe], dtype=dt_)
-    per = (time.perf_counter() - t0) / probe
-    # sample: the leading rows of the batch, sized so that one pass takes ~2 s at most
-    ns = int(min(theta.shape[0], max(probe, 2.0 / max(per, 1e-9))))
-    sample = theta[:ns]
-    t0 = time.perf_counter()
-    passes = 0
-    while True:
-        oldp.solve_batch(L, sample, dtype=dt_)
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt >= min_seconds or passes >= 200:
-            break
-    model = ""
+def rotation_depth(n_local, bytes_per):
+    """Distinct batches to rotate through so that > 1.25 x 256 MiB passes between two uses of a line."""
+    per_batch = max(1, n_local * bytes_per)
+    return int(min(64, max(2, math.ceil(1.25 * L3_BYTES / per_batch) + 1)))
+
+
+def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
             for line in fh:
                 if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
+                    return line.split(":", 1)[1].strip()
     except OSError:
         pass
+    return ""
+
+
+def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=5.0, marginal=False):
+    """The CPU oracle (the restated DAQP algorithm; `kind: port` -- libdaqp itself is not available
+    here or on the GPU box) on a bounded sample of the same batch: one thread, then every core this
+    process may use.  Built with -O3 -march=native on the machine that runs it.  A reported baseline,
+    not the product path."""
+    from oracle import ldp as oldp
+    flags = oldp.use_native()
+    dt_ = np.float32 if f32 else np.float64
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+    probe = min(256, theta.shape[0])
+    t0 = time.perf_counter()
+    oldp.solve_batch(L, theta[:probe], dtype=dt_)
+    per = (time.perf_counter() - t0) / probe
+    # sample: the leading rows of the batch, sized so that one pass takes ~1 s at most
+    ns = int(min(theta.shape[0], max(probe, 1.0 / max(per, 1e-9))))
+    run1 = oldp.runner(L, theta[:ns], dtype=dt_)
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        run1()
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or passes >= 100000:
+            break
+    mrep = oldp.marginal_report(L, theta[:min(theta.shape[0], 1000000)]) if (marginal and not f32) else None
     out = {"value": passes * ns / dt, "unit": "solves/s", "cores": 1, "kind": "port",
            "sample": f"{passes} passes over the first {ns} points of the same batch, 1 thread of "
-                     f"{os.cpu_count()} ({model}), oracle/daqp_ldp_oracle.c ({'binary32' if f32 else 'binary64'} build) -O2 -mfma"}
+                     f"{os.cpu_count()} ({_cpu_model()}), oracle/daqp_ldp_oracle.c "
+                     f"({'binary32' if f32 else 'binary64'} build) {flags}"}
     # the same oracle on all host cores this process may use (SURVEY.md section 8d-ii): the sample cut
-    # into one contiguous slice per thread (the C call releases the GIL), ~5 s
+    # into one contiguous slice per thread; every thread makes `reps` bare C calls over its slice (the C
+    # call releases the GIL), all threads start together and the slowest one ends the measurement
     try:
         ncores = len(os.sched_getaffinity(0))
     except AttributeError:
         ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 64))
     if ncores > 1 and all_cores_seconds > 0:
         from concurrent.futures import ThreadPoolExecutor
-        big = theta[:min(theta.shape[0], max(ns, 4096 * ncores))]
-        parts = [p_ for p_ in np.array_split(big, ncores) if len(p_)]
+        rate1 = out["value"]
+        # bounded: at most the points all cores get through in about all_cores_seconds
+        nall = int(min(theta.shape[0], max(ncores * 32, rate1 * 0.6 * ncores * all_cores_seconds)))
+        theta = theta[:nall]
+        parts = [p_ for p_ in np.array_split(theta, ncores) if len(p_)]
+        runs = [oldp.runner(L, p_, dtype=dt_) for p_ in parts]
+        reps = int(max(1, all_cores_seconds * rate1 * 0.6 / max(len(parts[0]), 1)))   # (all cores busy: lower clocks)
         with ThreadPoolExecutor(len(parts)) as pool:
-            list(pool.map(lambda p_: oldp.solve_batch(L, p_[:256], dtype=dt_), parts))   # spin the threads up
+            list(pool.map(lambda r_: r_(1), runs))              # spin the threads up, touch the outputs
             t0 = time.perf_counter()
-            passes = 0
-            while True:
-                list(pool.map(lambda p_: oldp.solve_batch(L, p_, dtype=dt_), parts))
-                passes += 1
-                dta = time.perf_counter() - t0
-                if dta >= all_cores_seconds or passes >= 200:
-                    break
-        out["all_cores"] = {"value": passes * big.shape[0] / dta, "unit": "solves/s", "cores": len(parts),
-                            "sample": f"{passes} passes over the first {big.shape[0]} points, one contiguous slice per thread"}
+            list(pool.map(lambda r_: r_(reps), runs))
+            dta = time.perf_counter() - t0
+        out["all_cores"] = {"value": reps * theta.shape[0] / dta, "unit": "solves/s", "cores": len(parts),
+                            "sample": f"{reps} passes over the first {theta.shape[0]} points, one contiguous slice "
+                                      f"per thread, {len(parts)} threads"}
+    if mrep is not None:
+        out["marginal_cases"] = mrep
+    return out
+
+
+class Workload:
+    """One benchmark configuration resident on one GPU: solver handles (one per stream), a rotation of
+    distinct theta batches and output buffers."""
+
+    def __init__(self, torch, lmpc, workload, n_local, dev, local_rank, rank, nstreams, f32=False, rotate=True,
+                 options=None):
+        self.torch = torch
+        self.workload = workload
+        self.name = ("pendulum" if workload.startswith("pendulum") else
+                     ("satellite20" if workload == "hybrid" else workload))
+        self.hard = workload == "pendulum_hard"
+        self.f32 = f32
+        self.g = make_problem(self.name)
+        self.nout = int(self.g["nu"])
+        self.n_local = n_local
+        self.dev = dev
+        self.tdt = torch.float32 if f32 else torch.float64
+        self.nstreams = nstreams
+        g = self.g
+        self.qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
+                                             g["senses"], nout=self.nout, device=local_rank,
+                                             settings=lmpc.default_settings_f32() if f32 else None)
+                    for _ in range(nstreams)]
+        for q_ in self.qps:
+            for k_, v_ in (options or {}).items():
+                q_.set_option(k_, v_)
+        self.qp = self.qps[0]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        self.stream_handles = [s_.cuda_stream for s_ in self.streams]
+        self.bytes_per = algorithmic_bytes(self.qp.nth, self.nout, 4 if f32 else 8)
+        self.nrot = rotation_depth(n_local, self.bytes_per) if rotate else 1
+        self.theta_h = make_theta(self.name, n_local, 1234 + rank, self.hard)
+        self.thetas = [torch.from_numpy(self.theta_h).to(dev).to(self.tdt)]
+        for r_ in range(1, self.nrot):
+            self.thetas.append(torch.from_numpy(make_theta(self.name, n_local, 7919 * r_ + 1234 + rank, self.hard))
+                               .to(dev).to(self.tdt))
+        self.nbuf = max(2, nstreams, self.nrot)
+        self.xbuf = [torch.empty((n_local, self.nout), dtype=self.tdt, device=dev) for _ in range(self.nbuf)]
+        self.fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(self.nbuf)]
+
+    @property
+    def kernel(self):
+        return "wave" if self.f32 else self.qp.kernel_name
+
+    def launch(self, k, sidx=None, resident=False):
+        """Enqueue step k on its stream (raw stream handle: no torch context switch)."""
+        sidx = k % self.nstreams if sidx is None else sidx
+        th = self.thetas[0] if resident else self.thetas[k % self.nrot]
+        b = (k % max(2, self.nstreams)) if resident else (k % self.nbuf)
+        self.qps[sidx].solve_device(th, x=self.xbuf[b], exitflag=self.fbuf[b], stream=self.stream_handles[sidx])
+        return b
+
+    def timed(self, steps, warmup, resident=False, nstreams=None):
+        """`steps` launches over the first `nstreams` streams, bracketed by device synchronisation; returns
+        wall seconds.  (The headline's own timed region lives in main(): it adds the barrier and the gather.)"""
+        torch = self.torch
+        ns = self.nstreams if nstreams is None else nstreams
+        for k in range(warmup):
+            self.launch(k, k % ns, resident)
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.launch(k, k % ns, resident)
+        torch.cuda.synchronize(self.dev)
+        return time.perf_counter() - t0
+
+    def single_launch(self, ncalls, resident=False):
+        """One call at a time on ONE stream with HIP events around the call and between its two kernels
+        (recorded by the library on the launch stream): the per-launch durations rocprofv3's kernel trace
+        reports.  Returns (calls, call ms, screening-kernel ms, iterating-kernel ms)."""
+        torch = self.torch
+        for k in range(4):
+            self.launch(k, 0, resident)
+        torch.cuda.synchronize(self.dev)
+        self.qp.profile(True)
+        for k in range(ncalls):
+            self.launch(k, 0, resident)
+        torch.cuda.synchronize(self.dev)
+        solo = self.qp.profile_read()
+        self.qp.profile(False)
+        return solo
+
+    def work_distribution(self):
+        """Iteration and active-set-size histograms of batch 0 (untimed extra solve) and the algorithmic
+        flop estimate of SURVEY.md section 8d: per iteration the scan 2mn, the primal step 2|W|n and the
+        triangular solves 2|W|^2 (final |W| as a stand-in), plus the two affine maps."""
+        torch = self.torch
+        qp = self.qp
+        it_d = torch.empty(self.n_local, dtype=torch.int32, device=self.dev)
+        ac_d = torch.zeros((self.n_local, qp.words), dtype=torch.int64, device=self.dev)
+        qp.solve_device(self.thetas[0], x=self.xbuf[0], exitflag=self.fbuf[0], iters=it_d, active=ac_d)
+        torch.cuda.synchronize(self.dev)
+        flags = self.fbuf[0].cpu().numpy()
+        it = it_d.cpu().numpy().astype(np.int64)
+        bits = ac_d.cpu().numpy().view(np.uint64)
+        nact = np.zeros(self.n_local, np.int64)
+        for w_ in range(bits.shape[1]):
+            v_ = bits[:, w_].copy()
+            while v_.any():
+                nact += (v_ & np.uint64(1)).astype(np.int64)
+                v_ >>= np.uint64(1)
+        flop = float(np.mean(it * (2.0 * qp.m * qp.n) + it * (2.0 * nact * qp.n + 2.0 * nact * nact))
+                     + 2.0 * qp.m * qp.nth + 2.0 * self.nout * qp.nth)
+        return {"solved_fraction": float((flags >= 1).mean()),
+                "iterations_hist": np.bincount(np.minimum(it, 31), minlength=2).tolist() if it.max() < 4000 else None,
+                "mean_iterations": float(it.mean()), "max_iterations": int(it.max()),
+                "active_set_size_hist": np.bincount(nact, minlength=1).tolist()}, flop
+
+    def close(self):
+        for q_ in self.qps:
+            q_.close()
+        self.thetas = self.xbuf = self.fbuf = None
+
+
+def describe(w):
+    qp = w.qp
+    if w.name == "pendulum":
+        body = ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 (n=5 vars, 5 two-sided input bounds, "
+                "theta=[x;r;u_prev] nth=7)" + (", parameters from the example's +-20 range" if w.hard else ""))
+    elif w.name == "mass_spring":
+        body = "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12)"
+    elif w.name == "mass_spring_3in":
+        body = f"oscillating masses, 12 states / 3 inputs (synthetic B), Nc=10 (n={qp.n}, m={qp.m}, nth={qp.nth})"
+    elif w.name == "satellite20":
+        body = f"hybrid MPC, satellite Np=Nc=20, 40 binary rows, branch and bound (n={qp.n}, m={qp.m}, nth={qp.nth})"
+    else:
+        body = f"{w.name} (n={qp.n}, m={qp.m}, nth={qp.nth})"
+    return f"{w.workload}: {body}, {w.n_local} parameter points per GPU, cold start, first move u0 returned"
+
+
+def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f32, want_cpu, cpu_seconds=4.0):
+    """One of the other single-GPU BASELINE configurations, measured in the same process: one batch in
+    flight on one stream (these kernels fill the chip by themselves), rotation past the Infinity Cache,
+    roofline from the live HIP-event duration of a call."""
+    w = Workload(torch, lmpc, workload, batch, dev, local_rank, 0, 1, f32=f32)
+    dist_info, flop = w.work_distribution()
+    el = w.timed(steps, warmup)
+    solo = w.single_launch(max(3, min(steps, 20)))
+    value = batch * steps / el
+    wave = w.kernel == "wave"
+    dtype = "f32" if f32 else "f64"
+    call_ms = solo[1]
+    if wave:     # VALU-bound kernel: flop roofline against the dense vector peak
+        ach = flop * batch / (call_ms * 1e-3) / 1e12 if call_ms > 0 else 0.0
+        roof = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                "frac": ach / VALU_PEAK_TFLOPS[dtype], "traffic": None,
+                "flop_per_solve_est": flop, "duration_used_ms": call_ms,
+                "duration": "HIP-event duration of one lmpc_solve_batch_device call, one at a time on one stream",
+                "hbm_algorithmic_GBs": w.bytes_per * batch / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0}
+    else:
+        ach = w.bytes_per * batch / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "duration_used_ms": call_ms, "screen_kernel_ms": solo[2], "iterate_kernel_ms": solo[3],
+                "duration": "HIP-event duration of one lmpc_solve_batch_device call (screening + iterating kernel), "
+                            "one at a time on one stream, cold HBM (rotating batches)",
+                "fp64_flop_per_solve_est": flop}
+    out = {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+           "dtype": dtype, "batch": batch, "kernel": w.kernel, "rotating_batches": w.nrot,
+           "workload": describe(w), **dist_info, "roofline": roof}
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(w.g, w.theta_h, w.nout, min_seconds=cpu_seconds, f32=f32,
+                                           all_cores_seconds=cpu_seconds / 2)
+    w.close()
     return out
 
 
@@ -140,14 +337,16 @@ def main():
     ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the other BASELINE configurations (profiling runs: keeps the kernel trace to one workload)")
     ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
                     help="N > 1: RCCL gather of x and exit flags to rank 0 once after the last step (default), "
                          "an all-gather after every step (overlapped with the next solve), or never")
     ap.add_argument("--no-single-launch", action="store_true",
-                    help="skip the one-call-at-a-time section after the timed region (profiling runs: keeps the "
+                    help="skip the one-call-at-a-time sections after the timed region (profiling runs: keeps the "
                          "kernel trace to the launches of the timed region)")
+    ap.add_argument("--no-rotate", action="store_true", help="reuse ONE theta buffer every step (cache-resident; diagnostic)")
     ap.add_argument("--no-screen", action="store_true", help="iterating kernel only (diagnostic)")
-    ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation bits for the screening kernel")
     ap.add_argument("--lane-per", type=int, default=0, help="work-list workgroups per shard (tuning)")
     ap.add_argument("--lane-tier", type=int, default=-1, help="lane kernel: first-tier capacity on (1) / off (0) (tuning)")
     ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
@@ -185,58 +384,35 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    name = "pendulum" if args.workload.startswith("pendulum") else ("satellite20" if args.workload == "hybrid" else args.workload)
-    hard = args.workload == "pendulum_hard"
-    g = make_problem(name)
-    nout = int(g["nu"])
     nstreams = max(1, min(8, args.streams))
-    tdt = torch.float32 if args.f32 else torch.float64
-    qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
-                                    g["senses"], nout=nout, device=local_rank,
-                                    settings=lmpc.default_settings_f32() if args.f32 else None) for _ in range(nstreams)]
-    qp = qps[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-    stream_handles = [s_.cuda_stream for s_ in streams]
+    opts = {}
     if args.no_screen:
-        for q_ in qps:
-            q_.set_option("screen", 0)
+        opts["screen"] = 0
     if args.wave:
-        for q_ in qps:
-            q_.set_option("wave", 1)
+        opts["wave"] = 1
     if args.lane_per:
-        for q_ in qps:
-            q_.set_option("lane_per", args.lane_per)
+        opts["lane_per"] = args.lane_per
     if args.wave_cap:
-        for q_ in qps:
-            q_.set_option("wave_cap", args.wave_cap)
+        opts["wave_cap"] = args.wave_cap
     if args.wave_level >= 0:
-        for q_ in qps:
-            q_.set_option("wave_level", args.wave_level)
+        opts["wave_level"] = args.wave_level
     if args.wave_nwv:
-        for q_ in qps:
-            q_.set_option("wave_nwv", args.wave_nwv)
+        opts["wave_nwv"] = args.wave_nwv
     # several batches in flight: 64-lane workgroups for the iterating kernel (its wavefronts then spread
     # over the CUs independently of each other; +3 % over the library's stand-alone choice of 256,
     # which is the better one with a single batch in flight: tools/block_sweep.sh)
     if not args.lane_block and nstreams > 1 and not args.f32 and not args.wave and args.workload.startswith("pendulum"):
         args.lane_block = 64
     if args.lane_block:
-        for q_ in qps:
-            q_.set_option("lane_block", args.lane_block)
+        opts["lane_block"] = args.lane_block
     if args.lane_tier >= 0:
-        for q_ in qps:
-            q_.set_option("lane_tier", args.lane_tier)
-    if args.ablate:
-        for q_ in qps:
-            q_.set_option("ablate", args.ablate)
+        opts["lane_tier"] = args.lane_tier
     n_local = args.batch
-    theta_h = make_theta(name, n_local, 1234 + rank, hard)
-    theta = torch.from_numpy(theta_h).to(dev).to(tdt)
+    W = Workload(torch, lmpc, args.workload, n_local, dev, local_rank, rank, nstreams, f32=args.f32,
+                 rotate=not args.no_rotate, options=opts)
+    qp, qps, streams, nout, tdt = W.qp, W.qps, W.streams, W.nout, W.tdt
+    xbuf, fbuf, nbuf = W.xbuf, W.fbuf, W.nbuf
 
-    # double-buffered outputs so the gather of step k overlaps the solve of step k+1
-    nbuf = max(2, nstreams)
-    xbuf = [torch.empty((n_local, nout), dtype=tdt, device=dev) for _ in range(nbuf)]
-    fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
     if final_gather:
@@ -249,6 +425,7 @@ def main():
     gather_impl = {"mode": "gather"}
 
     def gather_to_root(xs, fs):
+        nonlocal xfin, ffin
         if gather_impl["mode"] == "gather":
             dist.gather(xs, list(xfin.split(n_local)) if rank == 0 else None, dst=0)
             dist.gather(fs, list(ffin.split(n_local)) if rank == 0 else None, dst=0)
@@ -259,25 +436,26 @@ def main():
         xall = [torch.empty((world * n_local, nout), dtype=tdt, device=dev) for _ in range(nbuf)]
         fall = [torch.empty(world * n_local, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     pending = [None] * nbuf
+    last_b = [0]
 
     def step(k):
-        b = k % nbuf
-        # step k runs on stream k % nstreams with that stream's own handle (work list, counters):
-        # consecutive steps are independent batches, so the streaming pass of one overlaps the
+        # step k runs on stream k % nstreams with that stream's own handle (work list, counters) on batch
+        # k % nrot: consecutive steps are independent batches, so the streaming pass of one overlaps the
         # latency-bound iterating pass of the other
-        sidx = k % nstreams
-        if not do_gather:                        # single GPU: raw stream handle, no context switch
-            qps[sidx].solve_device(theta, x=xbuf[b], exitflag=fbuf[b], stream=stream_handles[sidx])
+        if not do_gather:                        # raw stream handle, no context switch
+            last_b[0] = W.launch(k)
             return
+        b = k % nbuf
+        sidx = k % nstreams
         with torch.cuda.stream(streams[sidx]):
             if pending[b] is not None:           # buffer b is free once its gather has finished
                 for w in pending[b]:
                     w.wait()
                 pending[b] = None
-            qps[sidx].solve_device(theta, x=xbuf[b], exitflag=fbuf[b])
-            if do_gather:
-                pending[b] = (dist.all_gather_into_tensor(xall[b], xbuf[b], async_op=True),
-                              dist.all_gather_into_tensor(fall[b], fbuf[b], async_op=True))
+            qps[sidx].solve_device(W.thetas[k % W.nrot], x=xbuf[b], exitflag=fbuf[b])
+            pending[b] = (dist.all_gather_into_tensor(xall[b], xbuf[b], async_op=True),
+                          dist.all_gather_into_tensor(fall[b], fbuf[b], async_op=True))
+        last_b[0] = b
 
     def drain():
         for b in range(nbuf):
@@ -295,7 +473,7 @@ def main():
         step(k)
     drain()
     if final_gather:
-        # untimed: the first all-gather of this shape sets up RCCL's channels and buffers
+        # untimed: the first collective of this shape sets up RCCL's channels and buffers
         torch.cuda.synchronize(dev)
         try:
             gather_to_root(xbuf[0], fbuf[0])
@@ -310,13 +488,7 @@ def main():
             ffin = torch.empty(world * n_local, dtype=torch.int32, device=dev)
             gather_to_root(xbuf[0], fbuf[0])
     fence()
-    # Device time over the timed region: ONE pair of HIP events per launch stream brackets all of
-    # that stream's launches (events between every two kernels cost ~12 % throughput: each is an extra
-    # packet the queue has to retire in order).  Per-kernel durations come from the single-launch
-    # section below, which records events around every kernel.
-    per_call_events = os.environ.get("LMPC_BENCH_CALL_EVENTS") == "1"
-    for q_ in qps:
-        q_.profile(per_call_events)
+    # ---- the timed region: EXACTLY args.steps steps between two barrier + synchronize fences
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
     t0 = time.perf_counter()
@@ -329,15 +501,11 @@ def main():
     enqueue_s = time.perf_counter() - t0          # host time to issue all steps (diagnostic)
     drain()
     if final_gather and args.steps:
-        # the one exchange step of the sharded job: every rank receives all shards' solutions
+        # the one exchange step of the sharded job: rank 0 receives every shard's solutions
         torch.cuda.synchronize(dev)
-        lastb = (args.steps - 1) % nbuf
-        gather_to_root(xbuf[lastb], fbuf[lastb])
+        gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
     fence()
     elapsed = time.perf_counter() - t0
-    prof = [q_.profile_read() for q_ in qps] if per_call_events else []
-    for q_ in qps:
-        q_.profile(False)
     # average device time of one launch on its stream = event span of the stream / its launches
     calls_on = [len(range(i_, args.steps, nstreams)) for i_ in range(nstreams)]
     span_ms = [ev0[i_].elapsed_time(ev1[i_]) for i_ in range(nstreams)]
@@ -348,102 +516,94 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    flags = fbuf[(args.steps - 1) % nbuf].cpu().numpy() if args.steps else np.zeros(0, np.int32)
-    # the same call with NOTHING else on the chip (outside the timed region): one launch after the
-    # other on one stream, HIP events on that stream -- the per-launch duration rocprofv3's kernel
-    # trace reports; with several batches in flight the launches above overlap and a single launch
-    # no longer owns the GPU
-    solo = None
-    if rank == 0 and args.steps and not args.no_single_launch:
-        nsolo = int(min(200, max(20, args.steps)))
-        torch.cuda.synchronize(dev)
-        qp.profile(True)
-        for _ in range(nsolo):
-            qp.solve_device(theta, x=xbuf[0], exitflag=fbuf[0], stream=stream_handles[0])
-        torch.cuda.synchronize(dev)
-        solo = qp.profile_read()
-        qp.profile(False)
-    # distribution of the work (untimed extra solve): throughput depends on how many iterations the
-    # batch needs, so the histograms travel with the number
-    it_d = torch.empty(n_local, dtype=torch.int32, device=dev)
-    ac_d = torch.zeros((n_local, qp.words), dtype=torch.int64, device=dev)
-    qp.solve_device(theta, x=xbuf[0], exitflag=fbuf[0], iters=it_d, active=ac_d)
-    torch.cuda.synchronize(dev)
-    it_hist = torch.bincount(it_d.clamp(max=31).to(torch.int64), minlength=2).cpu().tolist()
-    bits = ac_d.cpu().numpy().view(np.uint64)
-    nact = np.zeros(n_local, np.int64)
-    for w_ in range(bits.shape[1]):
-        v_ = bits[:, w_].copy()
-        while v_.any():
-            nact += (v_ & np.uint64(1)).astype(np.int64)
-            v_ >>= np.uint64(1)
-    act_hist = np.bincount(nact, minlength=1).tolist()
-    mean_it = float(it_d.to(torch.float64).mean().item())
-    # algorithmic FP64 work per solve: per iteration the scan 2mn, the primal
-    # step 2|W|n and the triangular solves 2|W|^2 (final |W| as a stand-in), plus the affine maps
-    flop_est = float(np.mean(it_d.cpu().numpy() * (2.0 * qp.m * qp.n) +
-                             it_d.cpu().numpy() * (2.0 * nact * qp.n + 2.0 * nact * nact))
-                     + 2.0 * qp.m * qp.nth + 2.0 * nout * qp.nth)
     if rank == 0:
         total = world * n_local * args.steps
-        value = total / elapsed
-        bytes_per = algorithmic_bytes(qp.nth, nout, 4 if args.f32 else 8)
-        # One batch in flight: algorithmic bytes of a call / its device time (HIP events on the launch
-        # stream).  Several batches in flight: their launches overlap on the chip, a single launch no
-        # longer owns it, so the bytes one step moves are divided by the wall time one step takes
-        # (about kernel_ms / batches_in_flight; kernel_ms stays in the record for the rocprof check).
+        value = total / elapsed if elapsed > 0 else 0.0
         step_ms = 1e3 * elapsed / max(args.steps, 1)
-        kern_ms, screen_ms, iterate_ms = (solo[1], solo[2], solo[3]) if solo else (0.0, 0.0, 0.0)
-        nlaunch = args.steps
-        dur_ms = stream_call_ms if nstreams == 1 else step_ms
-        achieved = (bytes_per * n_local) / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        traffic = None
+        bytes_call = W.bytes_per * n_local
+        gbs = lambda ms: bytes_call / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        dist_info, flop_est = W.work_distribution()
+        wave = W.kernel == "wave"
+        dtype = "f32" if args.f32 else "f64"
+        roof = {"bound": "hbm", "achieved": gbs(step_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs(step_ms) / HBM_PEAK_GBS, "traffic": None,
+                "duration_used_ms": step_ms,
+                "duration": "no single-launch section was run: wall time per step of the timed region "
+                            f"({nstreams} batches in flight)"}
+        # ---- one call at a time, cold HBM: THE roofline figure
+        if args.steps and not args.no_single_launch:
+            nsolo = int(min(120, max(24, args.steps)))
+            cold = W.single_launch(nsolo, resident=False)
+            if cold[0] > 0 and cold[1] > 0:
+                roof.update({"achieved": gbs(cold[1]), "frac": gbs(cold[1]) / HBM_PEAK_GBS, "duration_used_ms": cold[1],
+                             "duration": "HIP-event duration of ONE lmpc_solve_batch_device call (screening kernel + "
+                                         "iterating kernel, events recorded by the library on the launch stream), calls "
+                                         f"issued one at a time on one stream over {W.nrot} rotating batches (cold HBM: "
+                                         f"{W.nrot * bytes_call / 2**20:.0f} MiB pass between two uses of a line)",
+                             "launches_timed": cold[0], "kernel_ms": cold[1],
+                             "screen_kernel_ms": cold[2], "iterate_kernel_ms": cold[3],
+                             "screen_kernel_frac": gbs(cold[2]) / HBM_PEAK_GBS if cold[2] > 0 else None})
+            if not args.no_rotate:
+                # cache-resident counterparts (ONE theta buffer reused): what round 1 reported
+                res = W.single_launch(nsolo, resident=True)
+                el_res = W.timed(max(args.steps, 60), 6, resident=True)
+                res_step_ms = 1e3 * el_res / max(args.steps, 60)
+                roof["cache_resident"] = {
+                    "note": "one 56 MB theta buffer reused every step: inputs served from the 256 MiB Infinity Cache",
+                    "single_launch": {"kernel_ms": res[1], "screen_kernel_ms": res[2], "iterate_kernel_ms": res[3],
+                                      "achieved": gbs(res[1]), "frac": gbs(res[1]) / HBM_PEAK_GBS},
+                    "pipelined": {"ms_per_step": res_step_ms, "value": n_local / (res_step_ms * 1e-3),
+                                  "achieved": gbs(res_step_ms), "frac": gbs(res_step_ms) / HBM_PEAK_GBS,
+                                  "batches_in_flight": nstreams}}
+        roof["pipelined"] = {"ms_per_step": step_ms, "achieved": gbs(step_ms), "frac": gbs(step_ms) / HBM_PEAK_GBS,
+                             "batches_in_flight": nstreams, "stream_call_ms": stream_call_ms,
+                             "note": "algorithmic bytes of a step / wall time per step of the timed region: a pipeline "
+                                     "throughput figure (launches of several batches overlap), not a kernel duration"}
+        roof.update({"host_enqueue_ms_per_step": 1e3 * enqueue_s / max(args.steps, 1),
+                     "algorithmic_bytes_per_solve": W.bytes_per,
+                     "fp64_flop_per_solve_est": flop_est, "fp64_tflops_est": flop_est * value / 1e12,
+                     "solves_per_s_per_cu": value / world / 256.0})
+        if wave:       # diagnostics on the wavefront kernel: VALU bound, not HBM
+            ms_ = roof["duration_used_ms"]
+            ach = flop_est * n_local / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            roof.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": ach / VALU_PEAK_TFLOPS[dtype]})
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
-                traffic = None
+                pass
         out = {
             "metric": "condensed-MPC QP solves/sec (batch 1e6 params), pendulum Nc=5"
                       if args.workload == "pendulum" else f"condensed-MPC QP solves/sec ({args.workload})",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.f32 else "f64",
+            "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: "
-                       + ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 "
-                          "(n=5 vars, 5 two-sided input bounds, theta=[x;r;u_prev] nth=7), "
-                          if name == "pendulum" else ("mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12), "
-                                                      if name == "mass_spring" else f"{name} (n={qp.n}, m={qp.m}, nth={qp.nth}), "))
-                       + f"{n_local} parameter points per GPU, cold start, first move u0 returned",
-                       "batch_per_gpu": n_local, "kernel": "wave" if args.f32 else qp.kernel_name, "batches_in_flight": nstreams,
+            "config": {"workload": describe(W), "batch_per_gpu": n_local, "kernel": W.kernel,
+                       "batches_in_flight": nstreams, "rotating_batches": W.nrot,
+                       "inputs": ("cold HBM: every step reads a batch that has been evicted from the Infinity Cache"
+                                  if W.nrot > 1 else "cache-resident: one theta buffer reused"),
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
                                   else (gather_impl["mode"] + "(x, exitflag) to rank 0 over RCCL once, after the last step") if final_gather
                                   else "none"),
-                       "solved_fraction": float((flags >= 1).mean()) if flags.size else None,
-                       "iterations_hist": it_hist, "mean_iterations": mean_it,
-                       "active_set_size_hist": act_hist},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "stream_call_ms": stream_call_ms,
-                         "kernel_ms": kern_ms, "screen_kernel_ms": screen_ms,
-                         "iterate_kernel_ms": iterate_ms, "launches_timed": nlaunch,
-                         "duration_used_ms": dur_ms, "host_enqueue_ms_per_step": 1e3 * enqueue_s / max(args.steps, 1),
-                         "algorithmic_bytes_per_solve": bytes_per,
-                         "fp64_flop_per_solve_est": flop_est,
-                         "fp64_tflops_est": flop_est * value / 1e12,
-                         "solves_per_s_per_cu": value / world / 256.0},
+                       **dist_info},
+            "roofline": roof,
         }
-        if solo is not None and solo[0] > 0 and solo[1] > 0:
-            ach1 = (bytes_per * n_local) / (solo[1] * 1e-3) / 1e9
-            out["roofline"]["single_launch"] = {
-                "launches_timed": solo[0], "kernel_ms": solo[1], "screen_kernel_ms": solo[2],
-                "iterate_kernel_ms": solo[3], "achieved": ach1, "frac": ach1 / HBM_PEAK_GBS,
-                "note": "one call at a time on one stream (after the timed region): HIP-event duration of a "
-                        "single launch, the figure rocprofv3 --kernel-trace reports per kernel"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, theta_h, nout, f32=args.f32)
+            out["cpu_baseline"] = cpu_baseline(W.g, W.theta_h, nout, f32=args.f32, marginal=True)
+            if "marginal_cases" in out["cpu_baseline"]:
+                out["config"]["marginal_cases"] = out["cpu_baseline"].pop("marginal_cases")
+        # ---- the other single-GPU BASELINE configurations, same process (driver-timed as part of this run)
+        if world == 1 and args.workload == "pendulum" and not args.no_configs and not args.f32 and not args.wave:
+            W.close()
+            want_cpu = not args.no_cpu_baseline
+            cfgs = {}
+            cfgs["pendulum_hard"] = side_config(torch, lmpc, "pendulum_hard", BATCH, dev, local_rank, 40, 5, False, want_cpu, 3.0)
+            cfgs["mass_spring_3in"] = side_config(torch, lmpc, "mass_spring_3in", BATCH, dev, local_rank, 4, 1, False, want_cpu, 4.0)
+            cfgs["hybrid_f32"] = side_config(torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
+            out["configs"] = cfgs
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

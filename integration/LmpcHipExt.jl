@@ -18,7 +18,11 @@ end
 "setup!(mpc) for the batched backend: same inputs DAQP.setup gets (setup.jl:11-13)"
 function setup_batched(mpc::LinearMPC.MPC; nout=mpc.model.nu, device=0)
     mpc.mpqp_issetup || LinearMPC.setup!(mpc)
-    q = mpc.mpQP; n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
+    q = mpc.mpQP
+    # setup.jl:11-13 hands break_points / is_avi to DAQP.setup; the batched backend implements neither mode
+    isempty(q.break_points) || error("lmpc: prioritised constraints (mpQP.break_points) are not supported")
+    q.is_symmetric || error("lmpc: variational objective (is_avi) is not supported")
+    n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
     h = Ref{Ptr{Cvoid}}(C_NULL); s = Ref(LmpcSettings(mpc))
     K = iszero(mpc.K) ? C_NULL : Matrix{Float64}(mpc.K[1:nout, :])
     flag = ccall((:lmpc_setup, liblmpc), Cint,

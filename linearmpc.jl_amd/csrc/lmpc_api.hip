@@ -105,7 +105,7 @@ int finalize_handle(lmpc_handle *h) {
     // 1.69e8 vs 1.60e8).  lmpc_set_option("wave", 0 | 1) overrides.
     const bool manyGeneralRows = P.ms < P.m && (long long)P.m * P.n >= 600;
     h->useWave = !laneOk || (waveOk && manyGeneralRows);
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);                              // the caller's current device comes back when setup returns
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -173,7 +173,6 @@ int finalize_handle(lmpc_handle *h) {
         for (int k = 0; k < P.nout; k++)
             for (int t = 0; t < P.nth; t++) buf[L.oXthP + k * L.nthp + t] = P.Xth[(size_t)k * P.nth + t];
     }
-    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMalloc(&h->dC, sizeof(double) * (h->nC ? h->nC : 1)));
     HIP_TRY(h, hipMemcpy(h->dC, buf.data(), sizeof(double) * h->nC, hipMemcpyHostToDevice));
     return LMPC_OK;
@@ -231,7 +230,7 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
     const unsigned grid = (unsigned)((ntiles + kScreenTPB - 1) / kScreenTPB);
     const long long segCap = lane_seg_cap(nprob);
     hipLaunchKernelGGL((screen_kernel<NTHMAX, NT, MODE>), dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag,
-                       iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob, h->ablate);
+                       iters, active, warm, h->dList, count, segCap, kShards, (long long)nprob);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -573,7 +572,7 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
         return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch_device: NULL array or negative N");
     if (N == 0) return LMPC_OK;
     if (N > (int64_t)0x7fffffff * 64) return fail(h, LMPC_ERR_BADARG, "lmpc: batch too large for one launch");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     return launch(h, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
 }
 
@@ -583,7 +582,7 @@ int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x, 
     if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
         return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch: NULL array or negative N");
     if (N == 0) return LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     int rc = ensure_staging(h, N, warm != nullptr);
     if (rc != LMPC_OK) return rc;
     const size_t w = (size_t)h->P.words();
@@ -609,7 +608,7 @@ int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, f
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     int rc = ensure_f32(h);
     if (rc != LMPC_OK) return rc;
     return launch_wave_t<float>(h, h->dCwf, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
@@ -624,7 +623,7 @@ int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     int rc = ensure_f32(h);
     if (rc == LMPC_OK) rc = ensure_staging(h, N, warm != nullptr);
     if (rc != LMPC_OK) return rc;
@@ -658,7 +657,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         return fail(h, LMPC_ERR_BADARG, "lmpc_simulate_device: theta = [x; r; uprev] must match the handle "
                                         "(nx + nr + nuprev == nth, nout == nu, nx <= 32)");
     if (N == 0 || T == 0) return LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     { const int rce = ensure_sim(h, N); if (rce != LMPC_OK) return rce; }
     HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
@@ -702,6 +701,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         // pass 0 runs every scenario up to its first step that needs iterations; then: solve that step for the
         // listed scenarios, let them run ahead a little (most meet the next such step at once: the transient),
         // park the ones that broke free; when the list has drained, run the parked ones on, compacted.
+        bool drained = false;
         for (int pass = 0; pass <= 2 * T + 4 && rc == LMPC_OK; pass++) {
             h->asyncPhase = 1;
             rc = launch(h, N, h->simTheta, nullptr, nullptr, nullptr, masks, masks, st);
@@ -740,9 +740,15 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
                 h->asyncCap = T + 1;
                 h->asyncResetPark = true;
             } else {
+                drained = true;
                 break;
             }
         }
+        // the pass cap is generous (every scenario needs at most T rounds), but running into it with scenarios
+        // still queued or parked must not look like success: their states and trajectory slots are unfinished
+        if (rc == LMPC_OK && !drained)
+            rc = fail(h, LMPC_ERR_HIP, "lmpc_simulate: the scenario-asynchronous loop hit its pass limit with scenarios "
+                                       "still queued (lmpc_set_option(\"sim_async\", 0) runs the step-synchronous loop)");
         h->asyncPhase = 0;
         h->asyncListIn = h->asyncCntIn = nullptr;
         // the last streaming pass queued nothing, so no iterating kernel cleared the other counter set
@@ -807,7 +813,7 @@ int lmpc_simulate_f32_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, i
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     int rc = ensure_f32(h);
     if (rc != LMPC_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -842,7 +848,7 @@ int lmpc_simulate_f32(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nupr
                       int warm) {
     if (!h) return LMPC_ERR_BADARG;
     if (N <= 0 || T <= 0) return N < 0 || T < 0 ? LMPC_ERR_BADARG : LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const int nu = h->P.nout;
     float *dx = nullptr, *dr = nullptr, *du = nullptr, *dU = nullptr, *dX = nullptr;
     int32_t *df = nullptr;
@@ -855,9 +861,10 @@ int lmpc_simulate_f32(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nupr
         SIMF_TRY(hipMalloc(&dr, sizeof(float) * (size_t)N * nr));
         SIMF_TRY(hipMemcpy(dr, r, sizeof(float) * (size_t)N * nr, hipMemcpyHostToDevice));
     }
-    if (uprev && nuprev > 0) {
+    if (nuprev > 0) {                                    // NULL = zeros, as in lmpc_simulate
         SIMF_TRY(hipMalloc(&du, sizeof(float) * (size_t)N * nuprev));
-        SIMF_TRY(hipMemcpy(du, uprev, sizeof(float) * (size_t)N * nuprev, hipMemcpyHostToDevice));
+        if (uprev) SIMF_TRY(hipMemcpy(du, uprev, sizeof(float) * (size_t)N * nuprev, hipMemcpyHostToDevice));
+        else SIMF_TRY(hipMemset(du, 0, sizeof(float) * (size_t)N * nuprev));
     }
     if (U_traj) SIMF_TRY(hipMalloc(&dU, sizeof(float) * (size_t)T * N * nu));
     if (X_traj) SIMF_TRY(hipMalloc(&dX, sizeof(float) * (size_t)(T + 1) * N * nx));
@@ -865,7 +872,7 @@ int lmpc_simulate_f32(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nupr
     int rc = lmpc_simulate_f32_device(h, N, T, nx, nr, nuprev, F, G, dx, dr, du, dU, dX, df, warm, nullptr);
     if (rc != LMPC_OK) { cleanup(); return rc; }
     SIMF_TRY(hipMemcpy(x, dx, sizeof(float) * (size_t)N * nx, hipMemcpyDeviceToHost));
-    if (du) SIMF_TRY(hipMemcpy(uprev, du, sizeof(float) * (size_t)N * nuprev, hipMemcpyDeviceToHost));
+    if (du && uprev) SIMF_TRY(hipMemcpy(uprev, du, sizeof(float) * (size_t)N * nuprev, hipMemcpyDeviceToHost));
     if (dU) SIMF_TRY(hipMemcpy(U_traj, dU, sizeof(float) * (size_t)T * N * nu, hipMemcpyDeviceToHost));
     if (dX) SIMF_TRY(hipMemcpy(X_traj, dX, sizeof(float) * (size_t)(T + 1) * N * nx, hipMemcpyDeviceToHost));
     if (df) SIMF_TRY(hipMemcpy(flag_min, df, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
@@ -897,7 +904,7 @@ int lmpc_form_parameter_device(lmpc_handle *h, int64_t N, double *theta, const d
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const long long total = (long long)N * h->P.nth;
     hipLaunchKernelGGL(form_parameter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        theta, x, nx, br, bd, uprev, nuprev, bp, (long long)N);
@@ -919,7 +926,7 @@ int lmpc_simulate_ref_device(lmpc_handle *h, int64_t N, int T, int nx, const lmp
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     { const int rce = ensure_sim(h, N); if (rce != LMPC_OK) return rce; }
     HIP_TRY(h, hipMemcpyAsync(h->simFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
@@ -964,7 +971,7 @@ int lmpc_set_parameter_layout(lmpc_handle *h, const lmpc_param_layout *l) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     hipFree(h->ccT2S);
     h->ccT2S = nullptr;
     if (l->n_preview_horizon > 0 && l->n_reference > 0) {
@@ -989,7 +996,7 @@ int lmpc_compute_control_device(lmpc_handle *h, int64_t N, double *control, cons
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     const size_t w = (size_t)h->P.words();
     if (N > h->ccCap) {
@@ -1042,14 +1049,14 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const int nu = h->P.nout;
     const size_t wr = (size_t)h->ccNr * (h->ccNph > 0 ? h->ccNph : 1);
     // one staging block per handle, kept between calls (a closed loop calls this once per time step):
     // [control | state | reference | disturbance | parameter] doubles, then the flags
     const size_t per = (size_t)nu + h->ccNx + wr + h->ccNd + h->ccNp;
     if (N > h->ccStageCap || per > h->ccStagePer) {
-        hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
+        hipFree(h->ccStage); hipFree(h->ccStageFlag);       // (ccObsScratch is another entry point's buffer)
         h->ccStage = nullptr; h->ccStageFlag = nullptr; h->ccStageCap = 0; h->ccStagePer = 0;
         HIP_TRY(h, hipMalloc(&h->ccStage, sizeof(double) * (size_t)N * per));
         HIP_TRY(h, hipMalloc(&h->ccStageFlag, sizeof(int32_t) * (size_t)N));
@@ -1090,7 +1097,7 @@ int lmpc_compute_control_observer_device(lmpc_handle *h, int64_t N, double *cont
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const size_t per = (size_t)h->ccNx + h->ccNd;
     if (N > h->ccObsCap) {
         hipFree(h->ccObsScratch);
@@ -1118,7 +1125,7 @@ int lmpc_set_observer(lmpc_handle *h, const lmpc_observer *o) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const size_t nd_ = (size_t)o->n_state * (1 + o->n_state + o->n_control + o->n_disturbance);
     const size_t nm_ = (size_t)o->n_measurement * (1 + o->n_state + o->n_disturbance);
     const size_t nk_ = (size_t)o->n_measurement * o->n_state;
@@ -1139,7 +1146,7 @@ int lmpc_predict_state_device(lmpc_handle *h, int64_t N, double *state, const do
     if (N < 0 || (N > 0 && (!state || (h->obsNu > 0 && !control))))
         return fail(h, LMPC_ERR_BADARG, "lmpc_predict_state: NULL state/control or negative N");
     if (N == 0) return LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
 #define LMPC_PS(NX) hipLaunchKernelGGL(predict_state_kernel<NX>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, \
         (hipStream_t)stream, state, control, disturbance, h->obsC, h->obsNx, h->obsNu, h->obsNd, (long long)N)
     switch (h->obsNx) {
@@ -1159,7 +1166,7 @@ int lmpc_correct_state_device(lmpc_handle *h, int64_t N, double *state, const do
     if (N < 0 || (N > 0 && (!state || !measurement)))
         return fail(h, LMPC_ERR_BADARG, "lmpc_correct_state: NULL state/measurement or negative N");
     if (N == 0) return LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const size_t nd_ = (size_t)h->obsNx * (1 + h->obsNx + h->obsNu + h->obsNd);
     const size_t nm_ = (size_t)h->obsNy * (1 + h->obsNx + h->obsNd);
 #define LMPC_CS(NX) hipLaunchKernelGGL(correct_state_kernel<NX>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, \
@@ -1185,7 +1192,7 @@ int observer_host(lmpc_handle *h, int64_t N, double *state, const double *in, in
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     double *ds = nullptr, *di = nullptr, *dd = nullptr;
     auto cleanup = [&]() { hipFree(ds); hipFree(di); hipFree(dd); };
 #define OB_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); \
@@ -1223,7 +1230,7 @@ int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, 
                   int warm) {
     if (!h) return LMPC_ERR_BADARG;
     if (N <= 0 || T <= 0) return N < 0 || T < 0 ? LMPC_ERR_BADARG : LMPC_OK;
-    HIP_TRY(h, hipSetDevice(h->device));
+    LMPC_ENTER_DEVICE(h);
     const int nu = h->P.nout;
     double *dx = nullptr, *dr = nullptr, *du = nullptr, *dU = nullptr, *dX = nullptr;
     int32_t *df = nullptr;
@@ -1295,7 +1302,6 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
 int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
-    if (std::strcmp(name, "ablate") == 0) { h->ablate = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
@@ -1331,7 +1337,8 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
 
 void lmpc_free(lmpc_handle *h) {
     if (!h) return;
-    if (h->dC || h->sTheta) hipSetDevice(h->device);
+    lmpc::DeviceScope scope;
+    if (h->dC || h->dCw || h->sTheta) scope.enter(h->device);
     for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);

@@ -57,7 +57,6 @@ struct lmpc_handle {
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int laneTier = 1;           // tuning: first-tier capacity in the boxed lane kernels (results identical either way)
-    int ablate = 0;             // diagnostic: switches parts of the screening kernel off (timing only)
     lmpc::WaveLayout W{};
     double *dCw = nullptr;
     float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
@@ -114,6 +113,22 @@ int fail(lmpc_handle *h, int code, const std::string &msg);
         if (e__ != hipSuccess)                                                               \
             return lmpc::fail(h, LMPC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// Every entry point works on the handle's GPU and hands the caller's current device back when it returns
+// (a host application with several GPUs keeps its own notion of "current device").
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) return hipSuccess;
+        const hipError_t e = hipSetDevice(dev);
+        switched = (e == hipSuccess) && prev >= 0;
+        return e;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+#define LMPC_ENTER_DEVICE(h) lmpc::DeviceScope lmpc_dev_scope__; HIP_TRY(h, lmpc_dev_scope__.enter((h)->device))
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

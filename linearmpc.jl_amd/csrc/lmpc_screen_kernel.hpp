@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, int32_t *__restrict__ list,
-    int32_t *__restrict__ count, long long seg_cap, int nshards, long long nprob, int ablate) {
+    int32_t *__restrict__ count, long long seg_cap, int nshards, long long nprob) {
     const int m = P.m, nth = P.nth, B = blockDim.x, tid = threadIdx.x;
     const long long first = (long long)blockIdx.x * kScreenTPB * B + tid;
     const double ntol = -P.primal_tol;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int tc = (NT <= 16 || t < nth) ? t : nth - 1;      // NT <= 16: NT == nth exactly
-            dst[t] = (ablate & 8) ? src[tc] : __builtin_nontemporal_load(src + tc);
+            dst[t] = __builtin_nontemporal_load(src + tc);
         }
         }
     };
@@ -109,12 +109,12 @@ __global__ __launch_bounds__(256) void screen_kernel(
         const double *dj = C + P.oDthP;
         const double *bj = C + P.oBnd;
         unsigned long long imm = P.imm_mask;
-        const int mp = (ablate & 2) ? 0 : ((m + 3) & ~3);
+        const int mp = (m + 3) & ~3;
         for (int j = 0; j < mp; j += 4, dj += 4 * NTHMAX, bj += 8, imm >>= 4) {
             double b[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) b[q] = 0.0;
-            if (j + 4 <= m || (ablate & 32)) {
+            if (j + 4 <= m) {
 #pragma unroll
                 for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(256) void screen_kernel(
         // near 90 atomics/us, which 15k wavefronts would turn into the bottleneck of the whole pass.
         const unsigned long long mask = __ballot(hard);
         int basei = 0;
-        if (mask != 0ull && lane == 0 && !(ablate & 1)) basei = atomicAdd(&count[shard * kCountStride], __popcll(mask));
+        if (mask != 0ull && lane == 0) basei = atomicAdd(&count[shard * kCountStride], __popcll(mask));
         if (pmask != 0ull) {
             const int pb = __shfl(pbase, 0);
-            if (phard && !(ablate & 1))
+            if (phard)
                 list[(long long)shard * seg_cap + pb + __popcll(pmask & ((1ull << lane) - 1ull))] = (int32_t)ppid;
         }
         pmask = mask; pbase = basei; ppid = pid; phard = hard;
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(256) void screen_kernel(
         // stores (8-byte stores at a stride of 8 * nout bytes cost this pass 12 us at nout = 5).  Plain mode
         // only: there every valid problem of the wavefront writes its outputs.
         extern __shared__ double sxo[];                // 256 * nout doubles, given by the launch (MODE 3)
-        const bool wide_out = WIDE && !(ablate & (4 | 16));
+        constexpr bool wide_out = WIDE;
         double rec[NT];                                // closed loop: the next record of a finished problem
         bool recok = false;
-        const bool fill = ((ablate & 16) || GATHER) ? (valid && !hard) : valid;
+        const bool fill = GATHER ? (valid && !hard) : valid;
         if constexpr (GATHER) {
             if (hard) {
                 double *to = P.gat.theta_out + pid * nth;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                     if (NT <= 16 || t < nth) to[t] = th[t];
             }
         }
-        if (fill && !(ablate & 4)) {
+        if (fill) {
             const double *xk = C + P.oXthP;
             double uo[kMaxSimU];
 #pragma unroll
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
                 if (SIM && X == nullptr) {                          // closed loop without an input trajectory
                 } else if (wide_out) sxo[(tid & ~63) * P.nout + lane * P.nout + k] = 0.0 + sh;   // see below
-                else if (ablate & 8) X[pid * P.nout + k] = 0.0 + sh;
                 else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
             }
             // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
@@ -245,8 +244,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                                                            : (EXIT_OPTIMAL < S.flag_min[pid] ? (int)EXIT_OPTIMAL : S.flag_min[pid]);
             }
             if (SIM && exitflag == nullptr) {                       // closed loop: flag_min carries the flags
-            } else if (ablate & 8) exitflag[pid] = EXIT_OPTIMAL;
-            else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
+            } else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
             // (iteration count and active set only for the problems finished here: `active` may be the
             // very buffer the iterating kernel still has to read its warm-start masks from)
             if (iters && !hard) iters[pid] = 1;
@@ -286,7 +284,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
     }
     if (pmask != 0ull) {
         const int pb = __shfl(pbase, 0);
-        if (phard && !(ablate & 1))
+        if (phard)
             list[(long long)shard * seg_cap + pb + __popcll(pmask & ((1ull << lane) - 1ull))] = (int32_t)ppid;
     }
 }

@@ -48,6 +48,23 @@ int qp_to_ldp(HostPack &P, int n, int m, int ms, int nth, int nout,
     const int mg = m - ms;
     P.n = n; P.m = m; P.ms = ms; P.nth = nth; P.nout = nout;
 
+    // A variational objective (reference mpc2mpqp.jl:900-950, several players) gives a NON-symmetric H, which
+    // the reference hands to DAQP as an affine variational inequality (setup.jl:13 is_avi = !is_symmetric,
+    // mpc2mpqp.jl:897 isapprox(H, H', rtol = 1e-9)).  That mode is not built here: refuse instead of silently
+    // solving the symmetrised problem.
+    {
+        double dif = 0.0, nrm = 0.0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) {
+                const double a = H[i + (size_t)n * j], b = H[j + (size_t)n * i];
+                dif += (a - b) * (a - b);
+                nrm += a * a;
+            }
+        if (!(std::sqrt(dif) <= 1e-9 * std::sqrt(nrm))) {
+            err = "lmpc_setup: H is not symmetric (variational objective, DAQP's is_avi mode): not supported";
+            return LMPC_ERR_UNSUPPORTED;
+        }
+    }
     // upper Cholesky factor of the symmetrised Hessian, H = R'R (codegen.jl:242)
     std::vector<double> R((size_t)n * n, 0.0);
     auto Hs = [&](int i, int j) { return 0.5 * (H[i + (size_t)n * j] + H[j + (size_t)n * i]); };

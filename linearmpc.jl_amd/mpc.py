@@ -78,6 +78,15 @@ class MPC:
     # setup.jl:7-29
     def setup(self):
         q = self.mpQP
+        # setup.jl:11-13 passes break_points (constraint priority levels: hierarchical soft constraints) and
+        # is_avi = !is_symmetric (variational objective) to DAQP.setup.  Neither mode is built in the HIP
+        # backend: refuse loudly rather than return the answer of a different problem.
+        if np.size(q.break_points) > 0:
+            raise NotImplementedError("mpQP.break_points is non-empty (prioritised constraints): the batched "
+                                      "backend does not implement DAQP's hierarchical mode")
+        if not q.is_symmetric:
+            raise NotImplementedError("mpQP.is_symmetric is false (variational objective): the batched backend "
+                                      "does not implement DAQP's is_avi mode")
         self.opt_model = BatchedQP.from_mpqp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses,
                                              nout=q.H.shape[0], settings=self.settings,
                                              device=self.device)

@@ -55,6 +55,30 @@ def transform(H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0)
     return out
 
 
+def _dev_arg(t, name, dtype, numel, device, optional=True):
+    """Validate a CUDA tensor handed to a *_device entry point as a raw pointer: the kernels write
+    through it with a fixed element size and a dense layout, so a wrong dtype, a strided view or a
+    tensor on another GPU would silently corrupt memory.  Returns the pointer (or None)."""
+    if t is None:
+        if optional:
+            return None
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda or t.device.index != device:
+        raise ValueError(f"{name} must be a CUDA tensor on cuda:{device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if t.numel() != numel:
+        raise ValueError(f"{name} must hold {numel} elements, got {t.numel()}")
+    return _vp(t.data_ptr())
+
+
+def _mask_dtypes():
+    import torch
+    return (torch.int64, torch.uint64) if hasattr(torch, "uint64") else (torch.int64,)
+
+
 class BatchedQP:
     """One condensed-MPC QP structure resident on one GPU, solved for batches of theta."""
 
@@ -200,13 +224,23 @@ class BatchedQP:
             raise ValueError("x and theta must have the same dtype")
         if exitflag is None:
             exitflag = torch.empty(N, dtype=torch.int32, device=dev)
+        if theta.dim() != 2 or theta.shape[1] != self.nth:
+            raise ValueError(f"theta must have shape (N, {self.nth})")
+        # `stream` is a raw hipStream_t: tensors this call allocated live on torch's current stream, so the
+        # caller who passes a foreign stream must keep x / exitflag alive until that stream has finished
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
         fn = lib().lmpc_solve_batch_device if theta.dtype == torch.float64 else lib().lmpc_solve_batch_f32_device
+
+        def mask(t, name):
+            if t is not None and t.dtype not in _mask_dtypes():
+                raise ValueError(f"{name} must be a 64-bit integer tensor")
+            return _dev_arg(t, name, t.dtype if t is not None else None, N * self.words, self.device)
+
         check(fn(
-            self._h, N, _vp(theta.data_ptr()), _vp(x.data_ptr()), _vp(exitflag.data_ptr()),
-            _vp(iters.data_ptr()) if iters is not None else None,
-            _vp(active.data_ptr()) if active is not None else None,
-            _vp(warm.data_ptr()) if warm is not None else None, _vp(st)), self._h)
+            self._h, N, _vp(theta.data_ptr()), _dev_arg(x, "x", theta.dtype, N * self.nout, self.device, False),
+            _dev_arg(exitflag, "exitflag", torch.int32, N, self.device, False),
+            _dev_arg(iters, "iters", torch.int32, N, self.device), mask(active, "active"), mask(warm, "warm"),
+            _vp(st)), self._h)
         return x, exitflag
 
     def simulate(self, x0, T, F, G, r=None, uprev=None, warm=True, want_x=True):
@@ -371,14 +405,20 @@ class BatchedQP:
                                exitflag=None, warm=False, stream=None):
         """`lmpc_compute_control_device`: CUDA tensors in place, enqueued on the current (or given) stream."""
         import torch
+        nx, nr, nd, nup, npp, nph = self._layout
         N = int(control.shape[0])
         dev = control.device
         if exitflag is None:
             exitflag = torch.empty(N, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-        p = lambda t: _vp(t.data_ptr()) if t is not None else None
-        check(lib().lmpc_compute_control_device(self._h, N, p(control), p(state), p(reference), p(disturbance),
-                                                p(affine_parameter), p(exitflag), int(bool(warm)), _vp(st)), self._h)
+        f64, d = torch.float64, self.device
+        check(lib().lmpc_compute_control_device(
+            self._h, N, _dev_arg(control, "control", f64, N * self.nout, d, False),
+            _dev_arg(state, "state", f64, N * nx, d, nx == 0),
+            _dev_arg(reference, "reference", f64, N * nr * (nph if nph else 1), d),
+            _dev_arg(disturbance, "disturbance", f64, N * nd, d),
+            _dev_arg(affine_parameter, "affine_parameter", f64, N * npp, d),
+            _dev_arg(exitflag, "exitflag", torch.int32, N, d, False), int(bool(warm)), _vp(st)), self._h)
         return exitflag
 
     def compute_control_observer_device(self, control, observer_state, n_measured=0, reference=None,
@@ -387,15 +427,21 @@ class BatchedQP:
         """`lmpc_compute_control_observer_device`: generated `mpc_compute_control_observer` of an offset-free
         observer for N scenarios (CUDA tensors; control in place)."""
         import torch
+        nx, nr, nd, nup, npp, nph = self._layout
         N = int(control.shape[0])
         dev = control.device
         if exitflag is None:
             exitflag = torch.empty(N, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
-        p = lambda t: _vp(t.data_ptr()) if t is not None else None
-        check(lib().lmpc_compute_control_observer_device(self._h, N, p(control), p(observer_state), int(n_measured),
-                                                         p(reference), p(measured_disturbance), p(affine_parameter),
-                                                         p(exitflag), int(bool(warm)), _vp(st)), self._h)
+        f64, d = torch.float64, self.device
+        nm = int(n_measured)
+        check(lib().lmpc_compute_control_observer_device(
+            self._h, N, _dev_arg(control, "control", f64, N * self.nout, d, False),
+            _dev_arg(observer_state, "observer_state", f64, N * (nx + nd - nm), d, False), nm,
+            _dev_arg(reference, "reference", f64, N * nr * (nph if nph else 1), d),
+            _dev_arg(measured_disturbance, "measured_disturbance", f64, N * nm, d),
+            _dev_arg(affine_parameter, "affine_parameter", f64, N * npp, d),
+            _dev_arg(exitflag, "exitflag", torch.int32, N, d, False), int(bool(warm)), _vp(st)), self._h)
         return exitflag
 
     # ------------------------------------------------------------------ generated state observer

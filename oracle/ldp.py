@@ -120,10 +120,28 @@ def build(force=False):
     return _LIB_PATH
 
 
+def use_native():
+    """Switch to a -O3 -march=native build of the same sources, compiled on THIS machine (the CPU baseline
+    leg of bench.py: SURVEY.md section 8d asks for the host's own instruction set).  Same arithmetic
+    contract, so results do not change.  Returns the flags description; falls back to the portable
+    build if the compiler is missing."""
+    global _lib, _LIB_PATH
+    native = os.path.join(_HERE, "_build", "liboracle_native.so")
+    try:
+        subprocess.run(["make", "-C", _HERE, "-s", "native"], check=True, capture_output=True)
+    except (OSError, subprocess.CalledProcessError):
+        return "-O3 -march=x86-64-v3"
+    _LIB_PATH = native
+    _lib = None
+    lib()
+    return "-O3 -march=native"
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not _LIB_PATH.endswith("_native.so"):
+            build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_active_words.restype = ctypes.c_int
         _lib.oracle_solve_batch.restype = None
@@ -179,6 +197,35 @@ def solve_batch(ldp: LDP, theta, settings: Settings | None = None, warm=None, dt
     return X, ef, it, act
 
 
+def runner(ldp: LDP, theta, settings: Settings | None = None, dtype=np.float64):
+    """Timing front end (bench.py's cpu_baseline leg): all arguments marshalled ONCE, returns
+    run(reps) that makes `reps` bare C calls over the same batch -- a few microseconds of Python per
+    call instead of solve_batch's array set-up, which matters when a thread's slice is small."""
+    L = lib()
+    ldp.contiguous()
+    f32 = np.dtype(dtype) == np.float32
+    theta = np.ascontiguousarray(np.asarray(theta, dtype).reshape(-1, ldp.nth))
+    N = theta.shape[0]
+    nw = active_words(ldp.m)
+    X = np.empty((N, ldp.nout), dtype)
+    ef = np.empty(N, np.int32)
+    it = np.empty(N, np.int32)
+    arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0, ldp.Xth)]
+    c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout, *(a.ctypes.data for a in arrs), ldp.sense.ctypes.data)
+    s = settings if settings is not None else (default_settings_f32() if f32 else default_settings())
+    fn = L.oracle_solve_batch_f32 if f32 else L.oracle_solve_batch
+    args = (ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_void_p(theta.ctypes.data), None,
+            ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(ef.ctypes.data), ctypes.c_void_p(it.ctypes.data), None)
+    keep = (theta, X, ef, it, arrs, c, s)
+
+    def run(reps=1):
+        for _ in range(reps):
+            fn(*args)
+        return keep[1]
+    run.N = N
+    return run
+
+
 def simulate(ldp: LDP, x0, T, F, G, r=None, uprev=None, settings: Settings | None = None, warm=True,
              dtype=np.float64):
     """Closed loop on the CPU oracle (oracle_simulate): returns dict(x, U (T,N,nu), X (T+1,N,nx), uprev, flag_min).
@@ -211,3 +258,69 @@ def simulate(ldp: LDP, x0, T, F, G, r=None, uprev=None, settings: Settings | Non
        vp(rr.ctypes.data) if rr is not None else None, vp(up.ctypes.data), vp(U.ctypes.data),
        vp(X.ctypes.data), vp(fm.ctypes.data), ctypes.c_int32(int(bool(warm))))
     return dict(x=x, U=U, X=X, uprev=up[:, :nup], flag_min=fm)
+
+
+def marginal_report(ldp: LDP, theta, settings: Settings | None = None, dual_band=1e-9, max_list=20):
+    """Classify the MARGINAL parameter points of a sample ("hard parts"): points
+    where a terminal decision of the dual active-set method sits inside its tolerance band, so that
+    another correct implementation (libdaqp itself) may legitimately stop on a different active set and
+    differ from this oracle by up to O(primal_tol):
+
+      primal-marginal  an INACTIVE row's slack at the terminal iterate is below primal_tol (the row is
+                       within the band in which "violated" and "satisfied" are the same answer);
+      dual-marginal    an ACTIVE row's multiplier is within `dual_band` of zero (the row could as
+                       well have been left out).
+
+    Slacks and multipliers are recomputed here from the final active set by a dense KKT solve in
+    numpy (independent of the solver's recursions).  Returns counts and the first `max_list` indices."""
+    s = settings if settings is not None else default_settings()
+    theta = np.ascontiguousarray(np.asarray(theta, float).reshape(-1, ldp.nth))
+    X, ef, it, act = solve_batch(ldp, theta, s)
+    m, n = ldp.m, ldp.n
+    B = theta @ ldp.Dth.T                                  # shifts b_j per problem
+    up_bits = np.zeros((len(theta), m), bool)
+    lo_bits = np.zeros((len(theta), m), bool)
+    for j in range(m):
+        up_bits[:, j] = (act[:, j >> 6] >> np.uint64(j & 63)) & np.uint64(1)
+        jj = m + j
+        lo_bits[:, j] = (act[:, jj >> 6] >> np.uint64(jj & 63)) & np.uint64(1)
+    imm = (ldp.sense & 4) != 0
+    soft = (ldp.sense & 8) != 0
+    ok = ef >= 1
+    primal_list, dual_list = [], []
+    n_primal = n_dual = 0
+    keys = np.ascontiguousarray(act).view([("", act.dtype)] * act.shape[1]).reshape(-1)
+    for key in np.unique(keys[ok]):
+        idx = np.nonzero(ok & (keys == key))[0]
+        i0 = idx[0]
+        rows = np.nonzero(up_bits[i0] | lo_bits[i0])[0]
+        lower = lo_bits[i0][rows]
+        u = np.zeros((len(idx), n))
+        if len(rows):
+            Mw = ldp.M[rows]
+            d = np.where(lower, ldp.dl0[rows] + B[np.ix_(idx, rows)], ldp.du0[rows] + B[np.ix_(idx, rows)])
+            K = Mw @ Mw.T + np.diag(np.where(soft[rows], s.rho_soft, 0.0))
+            lam = -np.linalg.solve(K, d.T).T               # u = -M_W' lam
+            u = -lam @ Mw
+            free = ~imm[rows]
+            dm = (np.abs(lam[:, free]) < dual_band).any(axis=1) if free.any() else np.zeros(len(idx), bool)
+            n_dual += int(dm.sum())
+            for i in idx[dm][:max(0, max_list - len(dual_list))]:
+                dual_list.append(int(i))
+        inact = np.ones(m, bool)
+        inact[rows] = False
+        inact &= ~imm
+        if inact.any():
+            Mu = u @ ldp.M[inact].T
+            su = (ldp.du0[inact] + B[np.ix_(idx, np.nonzero(inact)[0])]) - Mu
+            sl = Mu - (ldp.dl0[inact] + B[np.ix_(idx, np.nonzero(inact)[0])])
+            pm = (np.minimum(su, sl) < s.primal_tol).any(axis=1)
+            n_primal += int(pm.sum())
+            for i in idx[pm][:max(0, max_list - len(primal_list))]:
+                primal_list.append(int(i))
+    return {"sample": int(len(theta)), "solved": int(ok.sum()),
+            "primal_marginal": n_primal, "dual_marginal": n_dual,
+            "primal_tol": float(s.primal_tol), "dual_band": float(dual_band),
+            "primal_marginal_first": sorted(primal_list), "dual_marginal_first": sorted(dual_list),
+            "note": "points where libdaqp may legitimately end on a different active set (difference in u* up to "
+                    "O(primal_tol)); everywhere else a strictly convex QP has one optimum and one active set"}
