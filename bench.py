@@ -405,6 +405,8 @@ def main():
         args.lane_block = 64
     if args.lane_block:
         opts["lane_block"] = args.lane_block
+    if nstreams > 1 and args.workload == "pendulum" and not args.f32 and not args.wave:
+        opts["fast_nstr"] = 4        # one-launch kernel: all four wavefronts of a workgroup stream (+5 % with 3 in flight)
     if args.lane_tier >= 0:
         opts["lane_tier"] = args.lane_tier
     n_local = args.batch

@@ -140,7 +140,10 @@ int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
  *   active    N records of lmpc_active_words words (out) or NULL
  *   warm      N records of the same layout: initial working sets (in) or NULL = cold
  *
- * lmpc_solve_batch: HOST pointers; copies in, launches, copies out, synchronises.
+ * lmpc_solve_batch: HOST pointers; synchronous.  The batch moves through a three-stage pipeline in chunks
+ * (each half of what is left, the last one "host_chunk" problems, default 32768): H2D copy of chunk k+1,
+ * kernels of chunk k, D2H copy of chunk k-1 on three streams, the caller's arrays pinned in place for the duration of the call
+ * (hipHostRegister; "host_register" 0 switches that off), so PCIe runs in both directions at once.
  * lmpc_solve_batch_device: DEVICE pointers on the handle's GPU; enqueues the kernels on
  * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns without
  * synchronising -- this is what bench.py times with inputs resident in HBM.
@@ -171,6 +174,47 @@ int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x
 int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, float *x,
                                 int32_t *exitflag, int32_t *iters, uint64_t *active,
                                 const uint64_t *warm, void *stream);
+
+/* A caller that reuses its Theta / X / exitflag arrays from call to call (a Monte-Carlo loop, a closed
+ * loop over many scenarios) can pin them ONCE: lmpc_solve_batch* then finds them pinned and skips its own
+ * per-call hipHostRegister / hipHostUnregister (~0.1 ms per 10^6 pendulum problems).  Unpin before the
+ * memory is freed. */
+int lmpc_pin_host(void *p, size_t bytes);
+int lmpc_unpin_host(void *p);
+
+/*
+ * Several GPUs behind ONE call -- the shape the reference's caller has (one process, one Theta:
+ * /root/reference/src/utils.jl:268-283 `solve`; SURVEY.md section 8(b) `n_devices`, section 8(e)).
+ *
+ * lmpc_setup_multi: lmpc_setup on every listed device (devices == NULL or n_devices <= 0: all visible
+ * devices, 0 .. count-1); the constant pack is replicated, each device gets its own handle.
+ * lmpc_solve_batch_multi: HOST pointers as lmpc_solve_batch.  The batch is cut into contiguous shards
+ * (lmpc_multi_partition: N/n_devices each, the remainder on the leading devices); every device moves its
+ * shard through the same chunked H2D / kernels / D2H pipeline lmpc_solve_batch uses, all driven from the
+ * calling thread, results written straight into the caller's x / exitflag / iters / active.
+ * lmpc_solve_batch_multi_device: shards already RESIDENT on their GPUs (theta[d], x[d], exitflag[d] are
+ * DEVICE pointers on device d, N_dev[d] problems).  Every device solves its shard on its own stream; if
+ * x_root / exitflag_root (DEVICE pointers on the FIRST device, sum(N_dev) records) are given, the
+ * per-shard solutions are gathered there over xGMI with RCCL (ncclCommInitAll in this process,
+ * ncclSend / ncclRecv pairs: every device sends on its own link).  Returns after all devices finished.
+ * The problems are independent: no collective runs inside the solve.
+ */
+typedef struct lmpc_multi lmpc_multi;
+int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout,
+                     const double *H, const double *f, const double *f_theta,
+                     const double *A, const double *bu, const double *bl, const double *W,
+                     const int32_t *sense, const double *Kfb, int nx,
+                     const lmpc_settings *s, const int *devices, int n_devices);
+int lmpc_multi_devices(const lmpc_multi *hm);
+lmpc_handle *lmpc_multi_handle(lmpc_multi *hm, int i);      /* device i's handle (options, inspection) */
+void lmpc_multi_partition(int64_t N, int n_devices, int64_t *offsets /* n_devices + 1 */);
+int lmpc_solve_batch_multi(lmpc_multi *hm, int64_t N, const double *theta, double *x,
+                           int32_t *exitflag, int32_t *iters, uint64_t *active, const uint64_t *warm);
+int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const double *const *theta,
+                                  double *const *x, int32_t *const *exitflag,
+                                  double *x_root, int32_t *exitflag_root);
+const char *lmpc_multi_last_error(const lmpc_multi *hm);
+void lmpc_free_multi(lmpc_multi *hm);
 
 /* N = 1 convenience with DAQP.solve's shape: returns the exit flag (or an LMPC_ERR_* <= -100),
  * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call. */
@@ -345,7 +389,11 @@ const char *lmpc_kernel_name(const lmpc_handle *h);
 int lmpc_profile(lmpc_handle *h, int enable);
 int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
 
-/* Tuning switches: "screen" (default 1) = run cold-start batches through the streaming
+/* Tuning switches (none of them changes a result): "fast" (default 1) = small box-constrained problems
+ * (m == ms == n <= 5, up to 16 parameters -- 8 for n = 5 --, cold start) are solved by ONE kernel that streams the batch and
+ * runs the iterations underneath (0 = the two-kernel form below); "fast_nstr" 1..4 = streaming wavefronts per
+ * workgroup of that kernel (default 3; 4 suits several batches in flight); "lane_straight" (default 1) =
+ * straight-line first tier in the boxed iterating kernels.  "screen" (default 1) = run cold-start batches through the streaming
  * screening pass before the iterating kernel; 0 = iterating kernel only.  Results are
  * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
  * advance independently of each other (rounds of a streaming kernel and the iterating kernel),

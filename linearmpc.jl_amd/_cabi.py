@@ -28,6 +28,9 @@ SYMBOLS = (
     "lmpc_set_observer", "lmpc_predict_state", "lmpc_correct_state", "lmpc_predict_state_device",
     "lmpc_correct_state_device", "lmpc_compute_control_observer_device",
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
+    "lmpc_setup_multi", "lmpc_multi_devices", "lmpc_multi_handle", "lmpc_multi_partition",
+    "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
+    "lmpc_pin_host", "lmpc_unpin_host",
 )
 
 
@@ -147,6 +150,26 @@ def lib():
     L.lmpc_set_option.restype = i32
     L.lmpc_free.argtypes = [vp]
     L.lmpc_free.restype = None
+    L.lmpc_setup_multi.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32, vp, vp, i32]
+    L.lmpc_setup_multi.restype = i32
+    L.lmpc_multi_devices.argtypes = [vp]
+    L.lmpc_multi_devices.restype = i32
+    L.lmpc_multi_handle.argtypes = [vp, i32]
+    L.lmpc_multi_handle.restype = vp
+    L.lmpc_multi_partition.argtypes = [i64, i32, ctypes.POINTER(i64)]
+    L.lmpc_multi_partition.restype = None
+    L.lmpc_solve_batch_multi.argtypes = [vp, i64] + [vp] * 6
+    L.lmpc_solve_batch_multi.restype = i32
+    L.lmpc_solve_batch_multi_device.argtypes = [vp] + [vp] * 6
+    L.lmpc_solve_batch_multi_device.restype = i32
+    L.lmpc_multi_last_error.argtypes = [vp]
+    L.lmpc_multi_last_error.restype = ctypes.c_char_p
+    L.lmpc_free_multi.argtypes = [vp]
+    L.lmpc_free_multi.restype = None
+    L.lmpc_pin_host.argtypes = [vp, ctypes.c_size_t]
+    L.lmpc_pin_host.restype = i32
+    L.lmpc_unpin_host.argtypes = [vp]
+    L.lmpc_unpin_host.restype = i32
     L.lmpc_last_error.argtypes = [vp]
     L.lmpc_last_error.restype = ctypes.c_char_p
     _lib = L

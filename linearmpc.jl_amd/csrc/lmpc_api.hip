@@ -18,7 +18,7 @@
 
 using namespace lmpc;
 
-thread_local std::string g_setup_err;
+thread_local std::string g_setup_err;      // text of a failed setup call (no handle to carry it)
 
 namespace lmpc {
 
@@ -185,9 +185,9 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
 // capacity of one work-list segment: the problems of all screening workgroups with the same
 // (blockIdx % kShards), each covering kScreenTPB tiles of 256
 long long lane_seg_cap(long long nprob) {
-    const long long ntiles = (nprob + 255) / 256;
-    const long long nblocks = (ntiles + kScreenTPB - 1) / kScreenTPB;
-    return (nblocks + kShards - 1) / kShards * kScreenTPB * 256;
+    // screening kernel: workgroup b (256 problems) -> shard b % kShards; fast kernel: wavefront g (64 T problems,
+    // T <= 32) -> shard g % kShards.  One bound for both: an even share plus one unit of either kind, rounded up.
+    return (((nprob + kShards - 1) / kShards + 64 * 32 + 256) + 255) & ~255ll;
 }
 
 template <int N, int MS, int MA, bool SIM, bool MULTI>
@@ -214,8 +214,14 @@ int launch_lane(lmpc_handle *h, int B, size_t lds, int64_t nprob, const double *
         if (per < 1u) per = 1u;
         grid = per * (unsigned)kShards;
     }
+    // first tier of the boxed instantiations: 0 none, 1 the generic loop at capacity 3, 2 the straight-line tiers
+    // of lmpc_tiers.hpp (their preconditions on the row flags and the settings checked here)
+    int tierArg = h->laneTier;
+    if (tierArg && h->laneStraight && h->L.imm_mask == 0ull && h->L.eq_mask == 0ull &&
+        h->S.iter_limit > LMPC_FAST_KMAX + 1 && h->S.cycle_tol >= LMPC_FAST_KMAX + 1)
+        tierArg = 2;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(B), lds, st, h->L, h->dC, theta, x, flag, iters, active,
-                       warm, list, count, count_next, segCap, kShards, (long long)nprob, h->laneTier);
+                       warm, list, count, count_next, segCap, kShards, (long long)nprob, tierArg);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -378,6 +384,21 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         h->asyncX = h->asyncR = h->asyncUp = nullptr;       // only the first pass forms theta
         if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
         return LMPC_OK;
+    } else if (screened && !sim && !gather && warm == nullptr && fast_covers(h)) {
+        // small boxed problems, cold plain solve: ONE kernel streams the batch and solves what needs iterations
+        // (lmpc_fast_kernel.hpp); no work list, no second launch
+        rc = launch_fast(h, nprob, theta, x, flag, iters, active, st);
+        if (h->prof) {       // one kernel: no event between "the two kernels" (each record is a packet the queue retires)
+            h->eventPool.push_back(ev.mid); ev.mid = nullptr;
+            if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+            else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+        }
+        if (rc == LMPC_OK && std::getenv("LMPC_DEBUG_FAST") != nullptr) {          // diagnostic: the kernel's error flag
+            int32_t e = 0;
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&e, h->dFastErr, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess)
+                std::fprintf(stderr, "lmpc fast kernel: error flag %d\n", e);
+        }
+        return rc;
     } else if (screened) {
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
@@ -435,25 +456,6 @@ int ensure_sim(lmpc_handle *h, int64_t N) {
     HIP_TRY(h, hipMalloc(&h->simAct, sizeof(uint64_t) * (size_t)N * w));
     HIP_TRY(h, hipMalloc(&h->simFG, sizeof(double) * (32 * 32 + 32 * 64)));
     h->simCap = N;
-    return LMPC_OK;
-}
-
-int ensure_staging(lmpc_handle *h, int64_t N, bool warm) {
-    if (N <= h->sCap && (!warm || h->sWarm)) return LMPC_OK;
-    if (N > h->sCap) {
-        hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter); hipFree(h->sAct); hipFree(h->sWarm);
-        h->sTheta = h->sX = nullptr; h->sFlag = h->sIter = nullptr; h->sAct = h->sWarm = nullptr;
-        h->sCap = 0;
-        const size_t w = (size_t)h->P.words();
-        HIP_TRY(h, hipMalloc(&h->sTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
-        HIP_TRY(h, hipMalloc(&h->sX, sizeof(double) * (size_t)N * h->P.nout));
-        HIP_TRY(h, hipMalloc(&h->sFlag, sizeof(int32_t) * (size_t)N));
-        HIP_TRY(h, hipMalloc(&h->sIter, sizeof(int32_t) * (size_t)N));
-        HIP_TRY(h, hipMalloc(&h->sAct, sizeof(uint64_t) * (size_t)N * w));
-        h->sCap = N;
-    }
-    if (warm && !h->sWarm)
-        HIP_TRY(h, hipMalloc(&h->sWarm, sizeof(uint64_t) * (size_t)h->sCap * h->P.words()));
     return LMPC_OK;
 }
 
@@ -576,28 +578,6 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
     return launch(h, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
 }
 
-int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x, int32_t *exitflag,
-                     int32_t *iters, uint64_t *active, const uint64_t *warm) {
-    if (!h) return LMPC_ERR_BADARG;
-    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
-        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch: NULL array or negative N");
-    if (N == 0) return LMPC_OK;
-    LMPC_ENTER_DEVICE(h);
-    int rc = ensure_staging(h, N, warm != nullptr);
-    if (rc != LMPC_OK) return rc;
-    const size_t w = (size_t)h->P.words();
-    if (h->P.nth > 0)
-        HIP_TRY(h, hipMemcpy(h->sTheta, theta, sizeof(double) * (size_t)N * h->P.nth, hipMemcpyHostToDevice));
-    if (warm) HIP_TRY(h, hipMemcpy(h->sWarm, warm, sizeof(uint64_t) * (size_t)N * w, hipMemcpyHostToDevice));
-    rc = launch(h, N, h->sTheta, h->sX, h->sFlag, h->sIter, h->sAct, warm ? h->sWarm : nullptr, nullptr);
-    if (rc != LMPC_OK) return rc;
-    HIP_TRY(h, hipMemcpy(x, h->sX, sizeof(double) * (size_t)N * h->P.nout, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(exitflag, h->sFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-    if (iters) HIP_TRY(h, hipMemcpy(iters, h->sIter, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-    if (active) HIP_TRY(h, hipMemcpy(active, h->sAct, sizeof(uint64_t) * (size_t)N * w, hipMemcpyDeviceToHost));
-    return LMPC_OK;
-}
-
 int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
                                 int32_t *iters, uint64_t *active, const uint64_t *warm, void *stream) {
     if (!h) return LMPC_ERR_BADARG;
@@ -612,33 +592,6 @@ int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, f
     int rc = ensure_f32(h);
     if (rc != LMPC_OK) return rc;
     return launch_wave_t<float>(h, h->dCwf, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
-}
-
-int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
-                         int32_t *iters, uint64_t *active, const uint64_t *warm) {
-    if (!h) return LMPC_ERR_BADARG;
-    if (N < 0 || (N > 0 && (!x || !exitflag || (h->P.nth > 0 && !theta))))
-        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batch_f32: NULL array or negative N");
-    if (N == 0) return LMPC_OK;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
-    LMPC_ENTER_DEVICE(h);
-    int rc = ensure_f32(h);
-    if (rc == LMPC_OK) rc = ensure_staging(h, N, warm != nullptr);
-    if (rc != LMPC_OK) return rc;
-    const size_t w = (size_t)h->P.words();
-    float *dTh = reinterpret_cast<float *>(h->sTheta), *dX = reinterpret_cast<float *>(h->sX);   // f64-sized staging
-    if (h->P.nth > 0)
-        HIP_TRY(h, hipMemcpy(dTh, theta, sizeof(float) * (size_t)N * h->P.nth, hipMemcpyHostToDevice));
-    if (warm) HIP_TRY(h, hipMemcpy(h->sWarm, warm, sizeof(uint64_t) * (size_t)N * w, hipMemcpyHostToDevice));
-    rc = launch_wave_t<float>(h, h->dCwf, N, dTh, dX, h->sFlag, h->sIter, h->sAct, warm ? h->sWarm : nullptr, nullptr);
-    if (rc != LMPC_OK) return rc;
-    HIP_TRY(h, hipMemcpy(x, dX, sizeof(float) * (size_t)N * h->P.nout, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(exitflag, h->sFlag, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-    if (iters) HIP_TRY(h, hipMemcpy(iters, h->sIter, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-    if (active) HIP_TRY(h, hipMemcpy(active, h->sAct, sizeof(uint64_t) * (size_t)N * w, hipMemcpyDeviceToHost));
-    return LMPC_OK;
 }
 
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
@@ -1283,13 +1236,14 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
     for (auto &ev : h->events) {
         float ms = 0.f, ms1 = 0.f, ms2 = 0.f;
         if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess &&
-            hipEventElapsedTime(&ms1, ev.a, ev.mid) == hipSuccess &&
-            hipEventElapsedTime(&ms2, ev.mid, ev.b) == hipSuccess) {
+            (ev.mid == nullptr || (hipEventElapsedTime(&ms1, ev.a, ev.mid) == hipSuccess &&
+                                   hipEventElapsedTime(&ms2, ev.mid, ev.b) == hipSuccess))) {
+            if (ev.mid == nullptr) ms1 = ms;             // single-kernel call (lmpc_fast_kernel.hpp)
             tot += ms; scr += ms1; itr += ms2;
             cnt++;
         }
         h->eventPool.push_back(ev.a);
-        h->eventPool.push_back(ev.mid);
+        if (ev.mid) h->eventPool.push_back(ev.mid);
         h->eventPool.push_back(ev.b);
     }
     h->events.clear();
@@ -1303,6 +1257,8 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
+    if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
+    if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }
@@ -1314,6 +1270,10 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     }
     if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "fast") == 0) { h->fastPath = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "lane_straight") == 0) { h->laneStraight = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "fast_tiles") == 0) { h->fastTiles = value < 0 ? 0 : (value > 256 ? 256 : value); return LMPC_OK; }
+    if (std::strcmp(name, "fast_nstr") == 0) { h->fastNstr = value; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
@@ -1339,13 +1299,17 @@ void lmpc_free(lmpc_handle *h) {
     if (!h) return;
     lmpc::DeviceScope scope;
     if (h->dC || h->dCw || h->sTheta) scope.enter(h->device);
-    for (auto &ev : h->events) { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    for (auto &ev : h->events) { hipEventDestroy(ev.a); if (ev.mid) hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
-    hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
+    hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch); hipFree(h->dFastErr);
+    for (auto &e : h->pipeEv) hipEventDestroy(e);
+    if (h->sUp) hipStreamDestroy(h->sUp);
+    if (h->sRun) hipStreamDestroy(h->sRun);
+    if (h->sDown) hipStreamDestroy(h->sDown);
     delete h;
 }
 

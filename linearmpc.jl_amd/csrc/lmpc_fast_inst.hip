@@ -1,0 +1,94 @@
+// Instantiations and launch of the one-launch solver for small box-constrained problems
+// (lmpc_fast_kernel.hpp).  Its own translation unit: the kernel set builds next to the others.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "lmpc_internal.hpp"
+#include "lmpc_fast_kernel.hpp"
+
+namespace lmpc {
+
+// Which handles take the fast kernel for a cold, plain (no closed loop, no generated-controller gather) batch:
+// the lane path's boxed problems up to n = 5 with up to 16 parameters and no IMMUTABLE / ACTIVE-flagged rows,
+// and settings under which the tiers cannot meet a guard of the generic loop (iteration limit, cycle counter).
+bool fast_covers(const lmpc_handle *h) {
+    const HostPack &P = h->P;
+    constexpr int kmax = LMPC_FAST_KMAX;
+    // (n = 6, and n = 5 with more than 8 parameters, would spill at three wavefronts per SIMD: they keep the
+    // two-kernel form)
+    return h->fastPath && !h->useWave && h->laneN >= 2 && h->laneN <= 5 && P.n == h->laneN && P.m == P.n && P.ms == P.m &&
+           P.nth >= 1 && P.nth <= (h->laneN == 5 ? 8 : 16) && h->L.eq_mask == 0ull && h->L.imm_mask == 0ull && P.nsoft == 0 && !h->bnb &&
+           h->S.iter_limit > kmax + 1 && h->S.cycle_tol >= kmax + 1;
+}
+
+template <int NTHMAX, int NT, int N>
+static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+                         uint64_t *active, hipStream_t st) {
+    // R tiles of 64 problems per workgroup: enough that a workgroup's queue fills a 64-problem claim several
+    // times over, few enough that the grid is a couple of workgroups per CU (one resident round)
+    const int nstr = h->fastNstr >= 1 && h->fastNstr <= 4 ? h->fastNstr : 3;
+    const long long ntiles = (nprob + 63) / 64;
+    // ONE resident round with the same number of workgroups on every CU (LMPC_FAST_WAVES per CU: four
+    // wavefronts each): with 652 workgroups on 768 slots the CUs that got three were still streaming 5 us
+    // after those that got two had finished (tools/fast_trace.py)
+    long long slots = (long long)h->numCU * LMPC_FAST_WAVES;
+    int R = (int)((ntiles + slots - 1) / slots);
+    if (R < 8) R = 8;
+    if (h->fastTiles > 0) R = h->fastTiles;
+    if (R > ntiles) R = (int)(ntiles > 0 ? ntiles : 1);
+    const unsigned grid = (unsigned)((ntiles + R - 1) / R);
+    const size_t lds = fast_lds_bytes(N, R);
+    if (!h->dFastErr) {
+#ifdef LMPC_FAST_TRACE
+        const size_t eb = 64 + sizeof(long long) * 8 * 4 * 65536;
+#else
+        const size_t eb = sizeof(int32_t);
+#endif
+        HIP_TRY(h, hipMalloc(&h->dFastErr, eb));
+        HIP_TRY(h, hipMemsetAsync(h->dFastErr, 0, eb, st));
+    }
+    hipLaunchKernelGGL((fast_kernel<NTHMAX, NT, N>), dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
+                       active, (long long)nprob, R, nstr, h->dFastErr);
+    HIP_TRY(h, hipGetLastError());
+#ifdef LMPC_FAST_TRACE
+    if (const char *f = std::getenv("LMPC_FAST_TRACE_FILE")) {
+        std::vector<long long> tr((size_t)grid * 4 * 8);
+        if (hipStreamSynchronize(st) == hipSuccess &&
+            hipMemcpy(tr.data(), reinterpret_cast<char *>(h->dFastErr) + 64, sizeof(long long) * tr.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *fp = std::fopen(f, "wb")) { std::fwrite(tr.data(), sizeof(long long), tr.size(), fp); std::fclose(fp); }
+        }
+    }
+#endif
+    return LMPC_OK;
+}
+
+int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+                uint64_t *active, hipStream_t st) {
+#define LMPC_FN(NM, NT)                                                                                               \
+    switch (h->laneN) {                                                                                               \
+        case 2: return launch_fast_t<NM, NT, 2>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 3: return launch_fast_t<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 4: return launch_fast_t<NM, NT, 4>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 5: if constexpr (NT <= 8) return launch_fast_t<NM, NT, 5>(h, nprob, theta, x, flag, iters, active, st); break; \
+        default: break;                                                                                               \
+    }                                                                                                                 \
+    break;
+    switch (h->P.nth) {
+#ifdef LMPC_FAST_ONLY_PENDULUM
+        case 7: if (h->laneN == 5) return launch_fast_t<8, 7, 5>(h, nprob, theta, x, flag, iters, active, st); break;
+#else
+        case 1: LMPC_FN(8, 1)   case 2: LMPC_FN(8, 2)   case 3: LMPC_FN(8, 3)   case 4: LMPC_FN(8, 4)
+        case 5: LMPC_FN(8, 5)   case 6: LMPC_FN(8, 6)   case 7: LMPC_FN(8, 7)   case 8: LMPC_FN(8, 8)
+        case 9: LMPC_FN(16, 9)  case 10: LMPC_FN(16, 10) case 11: LMPC_FN(16, 11) case 12: LMPC_FN(16, 12)
+        case 13: LMPC_FN(16, 13) case 14: LMPC_FN(16, 14) case 15: LMPC_FN(16, 15) case 16: LMPC_FN(16, 16)
+#endif
+        default: break;
+    }
+#undef LMPC_FN
+    return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no fast-kernel instantiation");
+}
+
+}  // namespace lmpc

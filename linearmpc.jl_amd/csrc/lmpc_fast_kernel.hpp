@@ -1,0 +1,263 @@
+// ONE launch for small box-constrained problems (m == ms == n <= 6, cold start): streaming pass and the
+// iterations of the problems that need them in the same kernel, overlapped in time.
+//
+// Why: in the two-launch form (screen_kernel, then lane_kernel on the work list) the second kernel is a latency
+// chain -- launch, count -> list -> record loads, then ~1500 dependent instructions per wavefront -- of 16 us
+// behind 16 us of streaming, although its work is a tenth of the first kernel's.  Here the same work runs
+// UNDER the stream:
+//
+//   * a workgroup of four wavefronts covers R consecutive tiles of 64 problems.  The first `nstr` wavefronts
+//     stream them (the record of a wavefront's next tile is in flight while the current one is screened exactly
+//     as screen_kernel does it), finish the problems whose unconstrained optimum is feasible and push the
+//     indices of the others into the workgroup's queue in LDS (reserve with one LDS atomic per tile, write);
+//   * the remaining wavefronts -- and every streaming wavefront once its tiles are done -- claim 64 queued
+//     problems at a time (compare-and-swap on the read index) and solve them one per lane: the straight-line
+//     tiers of lmpc_tiers.hpp first, the generic loop of lane_kernel (lane_loop, same LDS layout) for the lanes
+//     the tiers do not finish, so the kernel is complete by itself and no second launch follows.
+//
+// Synchronisation is workgroup-local and one-directional: producers never wait (the queue holds every problem
+// of the workgroup), consumers wait only for producers -- for the queue to fill up to a claim, and for a
+// reserved slot to be written (slots start at -1; a producer writes its slots right after reserving them).
+// Every wait is bounded by a spin limit that raises an error flag instead of hanging.
+//
+// Results are those of the two-launch form bit for bit: the screening test, the tiers and lane_loop are the
+// same code or the same fma chains.
+//
+// Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp ([EXT] libdaqp,
+// called at mpc_update_qp.c:48 / utils.jl:282) and mpc_get_solution (mpc_update_qp.c:14-22).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lmpc_lane_kernel.hpp"
+#include "lmpc_tiers.hpp"
+
+namespace lmpc {
+
+#ifndef LMPC_FAST_WAVES
+#define LMPC_FAST_WAVES 3      // wavefronts per SIMD the kernel is register-budgeted for (lane_loop sets the need)
+#endif
+constexpr int kFastSpinLimit = 1 << 22;
+
+__device__ __forceinline__ int lds_load(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// bytes of dynamic LDS a workgroup of fast_kernel<.., N> needs for R tiles
+__host__ __device__ constexpr size_t fast_lds_bytes(int N, int R) {
+    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64) + sizeof(int32_t) * ((size_t)R * 64 + 4);
+}
+
+template <int NTHMAX, int NT, int N>
+__global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
+    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
+    double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
+    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag) {
+    constexpr int KMAX = LMPC_FAST_KMAX < N ? LMPC_FAST_KMAX : N;
+    constexpr int nconst = N * N + N * (N + 1) / 2 + 2 * N;
+    extern __shared__ __align__(16) double lds[];
+    double *sconst = lds;                                      // M, G, du0, dl0 (as in the pack, as lane_kernel keeps them)
+    double *sBall = sconst + ((nconst + 1) & ~1);              // b[j][lane] of the four wavefronts (generic loop)
+    int32_t *ring = reinterpret_cast<int32_t *>(sBall + 4 * N * 64);
+    int *ctrl = reinterpret_cast<int *>(ring + R * 64);        // [0] write index, [1] read index, [2] producers done
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nth = P.nth;
+    for (int i = tid; i < nconst; i += 256) sconst[i] = C[P.oM + i];
+    for (int i = tid; i < R * 64; i += 256) ring[i] = -1;
+    if (tid < 4) ctrl[tid] = 0;
+    __syncthreads();
+    const double *sM = sconst, *sG = sM + N * N, *sdu = sG + N * (N + 1) / 2, *sdl = sdu + N;
+    double *sB = sBall + wv * N * 64;
+    const double ntol = -P.primal_tol;
+    const long long ntiles = (nprob + 63) / 64;
+#ifdef LMPC_FAST_TRACE      // diagnostic build: 100 MHz timestamps per wavefront into errflag[16 + 8 * wave ..]
+    long long *trc = reinterpret_cast<long long *>(errflag + 16) + ((long long)blockIdx.x * 4 + wv) * 8;
+    int npass = 0;
+#define LMPC_TRC(i) do { if (lane == 0) trc[i] = (long long)wall_clock64(); } while (0)
+#else
+#define LMPC_TRC(i) do { } while (0)
+#endif
+    LMPC_TRC(0);
+    const long long t0 = (long long)blockIdx.x * R;
+    const long long t1 = t0 + R < ntiles ? t0 + R : ntiles;
+
+    auto load_record = [&](long long pid, double *dst) {
+        const long long pc = pid < nprob ? pid : nprob - 1;
+        const double *src = theta + pc * nth;
+#pragma unroll
+        for (int t = 0; t < NT; t++) dst[t] = src[t];          // NT == nth (nth <= 16)
+    };
+    auto write_x = [&](long long pid, const double (&th)[NT], const double (&u)[N], bool with_u) {
+        const double *xk = C + P.oXthP;
+        for (int k = 0; k < P.nout; k++, xk += NTHMAX) {
+            double sh = C[P.ox0 + k];
+#pragma unroll
+            for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+            double xs = 0.0;
+            if (with_u) {
+#pragma unroll
+                for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + k * N + c], u[c], xs);
+            }
+            X[pid * P.nout + k] = xs + sh;
+        }
+    };
+
+    // ------------------------------------------------------------------ producer: stream this wavefront's tiles
+    if (wv < nstr) {
+        // the record of this wavefront's next tile is in flight while the current one is screened (a second
+        // tile in flight changed nothing: the stream runs at the HBM rate, 14 us for the 68 MB of the headline
+        // batch with nine streaming wavefronts per CU; tools/fast_trace.py)
+        double nx[NT];
+        long long tile = t0 + wv;
+        if (tile < t1) load_record(tile * 64 + lane, nx);
+        for (; tile < t1; tile += nstr) {
+            const long long pid = tile * 64 + lane;
+            const bool valid = pid < nprob;
+            double th[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) th[t] = nx[t];
+            if (tile + nstr < t1) load_record(pid + (long long)nstr * 64, nx);
+            // screening test of screen_kernel: any row of dl + b <= 0 <= du + b violated by more than primal_tol?
+            bool hard = false;
+            const double *dj = C + P.oDthP;
+            const double *bj = C + P.oBnd;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th[t], acc);
+                const double vu = (bj[2 * j] + acc) - 0.0;
+                const double vl = -((bj[2 * j + 1] + acc) - 0.0);
+                hard = hard || (vu < ntol) || (vl < ntol);
+            }
+            hard = hard && valid;
+            const unsigned long long mask = __ballot(hard);
+            if (mask != 0ull) {
+                int base = 0;
+                if (lane == 0) base = __hip_atomic_fetch_add(&ctrl[0], __popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = __shfl(base, 0);
+                if (hard) __hip_atomic_store(&ring[base + __popcll(mask & ((1ull << lane) - 1ull))], (int32_t)(pid - t0 * 64),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (valid && !hard) {
+                double u0[N];
+#pragma unroll
+                for (int c = 0; c < N; c++) u0[c] = 0.0;
+                write_x(pid, th, u0, false);                   // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
+                exitflag[pid] = EXIT_OPTIMAL;
+                if (iters) iters[pid] = 1;
+                if (active) active[pid * P.words] = 0ull;
+            }
+        }
+        // all of this wavefront's reservations are in the LDS queue ahead of this add (LDS keeps a wave's order)
+        if (lane == 0) __hip_atomic_fetch_add(&ctrl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        LMPC_TRC(1);
+    }
+
+    // ------------------------------------------------------------------ consumer: claim and solve queued problems
+    int spins = 0;
+    for (;;) {
+        int start = 0, n = 0;
+        if (lane == 0) {
+            for (;;) {
+                // read BEFORE the write index (acquire keeps the order): d == nstr => the write index is final
+                const int d = __hip_atomic_load(&ctrl[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int w = lds_load(&ctrl[0]);
+                int r = lds_load(&ctrl[1]);
+                const int avail = w - r;
+                if (avail >= 64 || (d >= nstr && avail > 0)) {
+                    const int take = avail < 64 ? avail : 64;
+                    if (__hip_atomic_compare_exchange_strong(&ctrl[1], &r, r + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) { start = r; n = take; break; }
+                } else if (d >= nstr) {
+                    n = -1;                                    // nothing left and nothing to come
+                    break;
+                } else {
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (++spins > kFastSpinLimit) { n = -2; break; }
+            }
+        }
+        start = __builtin_amdgcn_readfirstlane(start);
+        n = __builtin_amdgcn_readfirstlane(n);
+        if (n == -2 && lane == 0 && errflag) *errflag = 1;
+        if (n < 0) break;
+#ifdef LMPC_FAST_TRACE
+        if (npass < 3) LMPC_TRC(2 + npass);
+        npass++;
+#endif
+        const bool mine = lane < n;
+        int rel = -1;
+        if (mine) {
+            int sp = 0;
+            while ((rel = __hip_atomic_load(&ring[start + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) {
+                if (++sp > kFastSpinLimit) break;              // (a reserved slot is written at once: never in practice)
+            }
+        }
+        if (__any(mine && rel < 0)) { if (lane == 0 && errflag) *errflag = 2; break; }
+        const long long pid = mine ? t0 * 64 + rel : t0 * 64;
+        double b[N], u[N];
+        double sh0 = C[P.ox0];                                 // x0 + Xth theta of the first output (kept: 2 registers)
+        {
+            double th0[NT];
+            load_record(pid, th0);
+            const double *dj = C + P.oDthP;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th0[t], acc);
+                b[j] = acc;
+            }
+            const double *xk = C + P.oXthP;
+#pragma unroll
+            for (int t = 0; t < NT; t++) sh0 = __builtin_fma(xk[t], th0[t], sh0);
+        }
+        int iter = 1, nact = 0, wrow[KMAX], flag = EXIT_ITERLIMIT;
+        bool wlow[KMAX];
+        unsigned long long act = 0ull, low = 0ull;
+        const int res = fast_tiers<N, KMAX>(P, sM, sG, sdu, sdl, mine, b, u, iter, wrow, wlow, nact);
+        bool solved = res == EXIT_OPTIMAL;
+        if (solved) {
+            flag = EXIT_OPTIMAL;
+#pragma unroll
+            for (int i = 0; i < KMAX; i++)
+                if (i < nact) { act |= 1ull << wrow[i]; if (wlow[i]) low |= 1ull << wrow[i]; }
+        }
+        if (mine && !solved) {
+            // the generic loop of lane_kernel on the lanes the tiers did not finish (from scratch)
+#pragma unroll
+            for (int j = 0; j < N; j++) sB[j * 64 + lane] = b[j];
+            LaneState<N, N> s;
+            s.init();
+            lane_loop<N, N, N, false>(P, C, sM, sG, sdu, sdl, sB, 64, lane, pid, nullptr, s);
+#pragma unroll
+            for (int c = 0; c < N; c++) u[c] = s.u[c];
+            flag = s.flag; iter = s.iter; act = s.act; low = s.low;
+        }
+        if (mine) {
+            if (P.nout == 1) {
+                double xs = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; c++) xs = __builtin_fma(C[P.oRout + c], u[c], xs);
+                X[pid] = xs + sh0;
+            } else {
+                double th[NT];                                 // several outputs: the record is read again (an L2 hit)
+                load_record(pid, th);
+                write_x(pid, th, u, true);
+            }
+            exitflag[pid] = flag;
+            if (iters) iters[pid] = iter;
+            if (active) active[pid * P.words] = (act & ~low) | ((act & low) << N);     // m == N <= 6: one word
+        }
+    }
+    LMPC_TRC(6);
+#ifdef LMPC_FAST_TRACE
+    if (lane == 0) trc[7] = npass;
+#endif
+#undef LMPC_TRC
+}
+
+}  // namespace lmpc

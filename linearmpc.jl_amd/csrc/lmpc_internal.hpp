@@ -39,6 +39,11 @@ struct lmpc_handle {
     int32_t *sFlag = nullptr, *sIter = nullptr;
     uint64_t *sAct = nullptr, *sWarm = nullptr;
     int64_t sCap = 0;
+    // ... and its three-stage pipeline: H2D copies, kernels, D2H copies on their own streams (lmpc_multi.hip)
+    hipStream_t sUp = nullptr, sRun = nullptr, sDown = nullptr;
+    std::vector<hipEvent_t> pipeEv;
+    int hostChunk = 32768;      // tuning: smallest (= last) chunk of the pipeline's schedule ("host_chunk")
+    int hostRegister = 1;       // tuning: pin the caller's arrays in place for the call ("host_register")
     // work list of the problems the screening pass leaves for the iterating kernel
     int32_t *dList = nullptr, *dCount = nullptr;
     int32_t *dList2 = nullptr, *dList3 = nullptr;          // second work list of the scenario-asynchronous closed loop (lists alternate per round)
@@ -57,6 +62,11 @@ struct lmpc_handle {
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
     int laneTier = 1;           // tuning: first-tier capacity in the boxed lane kernels (results identical either way)
+    int laneStraight = 1;       // tuning: straight-line first tier in the boxed lane kernels ("lane_straight", lmpc_tiers.hpp)
+    int fastPath = 1;           // tuning: one-launch kernel for small boxed problems ("fast", lmpc_fast_kernel.hpp)
+    int fastTiles = 0;          // tuning: tiles of 64 problems per workgroup of that kernel (0 = 24)
+    int fastNstr = 0;           // tuning: streaming wavefronts per workgroup of that kernel, 1..4 (0 = 3)
+    int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected)
     lmpc::WaveLayout W{};
     double *dCw = nullptr;
     float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
@@ -102,6 +112,8 @@ struct lmpc_handle {
     std::vector<hipEvent_t> eventPool;   // recycled by lmpc_profile_read
 };
 
+extern thread_local std::string g_setup_err;
+
 namespace lmpc {
 
 hipError_t pool_event(lmpc_handle *h, hipEvent_t *e);
@@ -129,6 +141,11 @@ struct DeviceScope {
     ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 #define LMPC_ENTER_DEVICE(h) lmpc::DeviceScope lmpc_dev_scope__; HIP_TRY(h, lmpc_dev_scope__.enter((h)->device))
+
+// one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
+bool fast_covers(const lmpc_handle *h);
+int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+                uint64_t *active, hipStream_t st);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

@@ -23,6 +23,7 @@
 
 #include "lmpc_pack.hpp"
 #include "lmpc_wave_layout.hpp"
+#include "lmpc_tiers.hpp"
 
 #ifndef LMPC_LANE_WAVES
 #define LMPC_LANE_WAVES 3   // wavefronts per SIMD the small lane kernels are register-budgeted for
@@ -33,9 +34,6 @@ namespace lmpc {
 // work-list counters sit one per 128-byte line
 constexpr int kCountStride = 32;
 
-__host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
-// strict lower triangle, row i > col t
-__host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
 // Closed-loop tail of a finished problem (SimFuse): x+ = F x + G u with the sums in plant_kernel's /
 // the oracle's order (F's terms, then G's), the next record [x+; r; u[0:nup]], bookkeeping of the run.
@@ -494,7 +492,7 @@ __device__ __forceinline__ void lane_solve(
     const PackLayout &P, const double *__restrict__ C, const double *sM, const double *sG,
     const double *sdu, const double *sdl, double *sB, const int B, const int tid, const long long pid,
     const double *__restrict__ theta, double *__restrict__ X, int32_t *__restrict__ exitflag,
-    int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, const bool tier) {
+    int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm, const int tier) {
     static_assert(MA == N + 1 || MA == N, "capacity");
     const int m = MS > 0 ? MS : P.m, nth = P.nth;
     const bool one_out = P.nout == 1;
@@ -562,25 +560,51 @@ __device__ __forceinline__ void lane_solve(
     if (nth == 0)
         for (int j = 0; j < m; j++) sB[j * B + tid] = 0.0;
 
-    LaneState<N, MA> s;
-    constexpr int MT = lane_tier<N, MS, MA>::value;
-    bool full = true;
-    if constexpr (MT > 0) {
-        if (tier && warm == nullptr && P.eq_mask == 0ull) {
-            LaneState<N, MT> s1;
-            s1.init();
-            full = lane_loop<N, MS, MT, true>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, nullptr, s1);
-            s.extend_from(s1);
+    double u[N];
+    int flag = EXIT_ITERLIMIT, iter = 1;
+    unsigned long long act = 0ull, low = 0ull;
+    bool solved = false;
+    // Small boxed problems, cold start (tier == 2: the host has checked the settings and the row flags):
+    // the straight-line tiers of lmpc_tiers.hpp first.  They finish all but a handful of an MPC batch's
+    // problems; only a wavefront that holds one of the others runs the generic loop below (on those lanes).
+    if constexpr (MS > 0 && MS == N && N <= 6) {
+        if (tier >= 2 && warm == nullptr) {
+            constexpr int KMAX = LMPC_FAST_KMAX < N ? LMPC_FAST_KMAX : N;
+            double bb[N];
+#pragma unroll
+            for (int j = 0; j < N; j++) bb[j] = sB[j * B + tid];
+            int wrow[KMAX], nact = 0, it1 = 1;
+            bool wlow[KMAX];
+            const int res = fast_tiers<N, KMAX>(P, sM, sG, sdu, sdl, true, bb, u, it1, wrow, wlow, nact);
+            if (res == EXIT_OPTIMAL) {
+                solved = true; flag = EXIT_OPTIMAL; iter = it1;
+#pragma unroll
+                for (int i = 0; i < KMAX; i++)
+                    if (i < nact) { act |= 1ull << wrow[i]; if (wlow[i]) low |= 1ull << wrow[i]; }
+            }
+        }
+    }
+    if (!solved) {
+        LaneState<N, MA> s;
+        constexpr int MT = lane_tier<N, MS, MA>::value;
+        bool full = true;
+        if constexpr (MT > 0) {
+            if (tier && warm == nullptr && P.eq_mask == 0ull) {
+                LaneState<N, MT> s1;
+                s1.init();
+                full = lane_loop<N, MS, MT, true>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, nullptr, s1);
+                s.extend_from(s1);
+            } else {
+                s.init();
+            }
         } else {
             s.init();
         }
-    } else {
-        s.init();
+        if (full) lane_loop<N, MS, MA, false>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, warm, s);
+#pragma unroll
+        for (int c = 0; c < N; c++) u[c] = s.u[c];
+        flag = s.flag; iter = s.iter; act = s.act; low = s.low;
     }
-    if (full) lane_loop<N, MS, MA, false>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, warm, s);
-    double (&u)[N] = s.u;
-    const int flag = s.flag, iter = s.iter;
-    const unsigned long long act = s.act, low = s.low;
 
     // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22)
     double uo[kMaxSimU];
@@ -678,7 +702,7 @@ __global__ __launch_bounds__(256, (N <= 5 ? LMPC_LANE_WAVES : 1)) void lane_kern
     const long long idx = base + tid;
     if (idx >= cnt) continue;
     const long long pid = list ? ((kEarly && base == first) ? (long long)pid0 : (long long)list[idx]) : idx;
-    lane_solve<N, MS, MA, SIM, MULTI>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier != 0);
+    lane_solve<N, MS, MA, SIM, MULTI>(P, C, sM, sG, sdu, sdl, sB, B, tid, pid, theta, X, exitflag, iters, active, warm, tier);
 }   // chunk loop
 }
 

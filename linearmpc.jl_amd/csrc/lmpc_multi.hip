@@ -1,0 +1,448 @@
+// Host-pointer entry points and the multi-device layer of liblmpc_hip.so.
+//
+//  * lmpc_solve_batch / lmpc_solve_batch_f32 (what a LinearMPC.jl caller with Theta in host memory
+//    uses; reference src/utils.jl:268-283 `solve`, one caller, one Theta): the batch is cut into chunks
+//    that move through a three-stage pipeline -- H2D copy of chunk k+1, kernels of chunk k, D2H copy of
+//    chunk k-1 -- on three HIP streams per device, the caller's arrays pinned in place for the duration
+//    of the call (hipHostRegister) so that every copy is asynchronous and PCIe runs in both directions
+//    at once.
+//  * lmpc_setup_multi / lmpc_solve_batch_multi: ONE process, one handle per GPU, the batch split into
+//    contiguous shards (independent problems, constant pack replicated), every device running the same
+//    pipeline on its shard, results written straight into the caller's arrays.
+//  * lmpc_solve_batch_multi_device: shards already resident on their GPUs; per-shard solutions are
+//    gathered to device 0 over xGMI with RCCL (ncclCommInitAll, ncclSend / ncclRecv pairs: every rank
+//    sends on its own link).  RCCL is loaded on first use (dlopen), the library has no link-time
+//    dependency on it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lmpc_internal.hpp"
+
+using namespace lmpc;
+
+namespace {
+
+// ---------------------------------------------------------------- pinned view of the caller's arrays
+// hipHostRegister pins the pages in place (what the runtime does internally for a large pageable copy,
+// but then the copy call blocks); registered, hipMemcpyAsync returns at once and the stages overlap.
+struct PinScope {
+    std::vector<void *> pinned;
+    void pin(const void *p, size_t bytes) {
+        if (!p || bytes == 0) return;
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess)
+            pinned.push_back(const_cast<void *>(p));
+        else
+            (void)hipGetLastError();      // already registered by the caller, or not pinnable: copies still work
+    }
+    ~PinScope() { for (void *p : pinned) (void)hipHostUnregister(p); }
+};
+
+int ensure_staging(lmpc_handle *h, int64_t N, bool warm) {
+    if (N <= h->sCap && (!warm || h->sWarm)) return LMPC_OK;
+    if (N > h->sCap) {
+        hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter); hipFree(h->sAct); hipFree(h->sWarm);
+        h->sTheta = h->sX = nullptr; h->sFlag = h->sIter = nullptr; h->sAct = h->sWarm = nullptr;
+        h->sCap = 0;
+        const size_t w = (size_t)h->P.words();
+        HIP_TRY(h, hipMalloc(&h->sTheta, sizeof(double) * (size_t)N * (h->P.nth ? h->P.nth : 1)));
+        HIP_TRY(h, hipMalloc(&h->sX, sizeof(double) * (size_t)N * h->P.nout));
+        HIP_TRY(h, hipMalloc(&h->sFlag, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->sIter, sizeof(int32_t) * (size_t)N));
+        HIP_TRY(h, hipMalloc(&h->sAct, sizeof(uint64_t) * (size_t)N * w));
+        h->sCap = N;
+    }
+    if (warm && !h->sWarm)
+        HIP_TRY(h, hipMalloc(&h->sWarm, sizeof(uint64_t) * (size_t)h->sCap * h->P.words()));
+    return LMPC_OK;
+}
+
+int ensure_pipe(lmpc_handle *h, size_t nev) {
+    if (!h->sUp) HIP_TRY(h, hipStreamCreateWithFlags(&h->sUp, hipStreamNonBlocking));
+    if (!h->sRun) HIP_TRY(h, hipStreamCreateWithFlags(&h->sRun, hipStreamNonBlocking));
+    if (!h->sDown) HIP_TRY(h, hipStreamCreateWithFlags(&h->sDown, hipStreamNonBlocking));
+    while (h->pipeEv.size() < nev) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->pipeEv.push_back(e);
+    }
+    return LMPC_OK;
+}
+
+// one device's share of a host-pointer call (rs = bytes per real: 8 binary64, 4 binary32)
+struct HostJob {
+    lmpc_handle *h;
+    int64_t N;
+    const char *theta;
+    char *x;
+    int32_t *flag, *iters;
+    uint64_t *active;
+    const uint64_t *warm;
+};
+
+int launch_chunk(lmpc_handle *h, size_t rs, int64_t n, int64_t off, bool warm) {
+    const size_t nth = (size_t)h->P.nth, nout = (size_t)h->P.nout, w = (size_t)h->P.words();
+    char *dTh = reinterpret_cast<char *>(h->sTheta), *dX = reinterpret_cast<char *>(h->sX);
+    if (rs == 8)
+        return lmpc_solve_batch_device(h, n, reinterpret_cast<const double *>(dTh + rs * off * nth),
+                                       reinterpret_cast<double *>(dX + rs * off * nout), h->sFlag + off, h->sIter + off,
+                                       h->sAct + off * w, warm ? h->sWarm + off * w : nullptr, h->sRun);
+    return lmpc_solve_batch_f32_device(h, n, reinterpret_cast<const float *>(dTh + rs * off * nth),
+                                       reinterpret_cast<float *>(dX + rs * off * nout), h->sFlag + off, h->sIter + off,
+                                       h->sAct + off * w, warm ? h->sWarm + off * w : nullptr, h->sRun);
+}
+
+// Chunk schedule of one shard: every chunk half of what is left, down to `smallest` problems.  The H2D
+// copies are the longest stage (56 B in against 12 B out per pendulum problem), so what the pipeline adds to
+// the plain copy time is its tail -- kernels and D2H copy of the LAST chunk -- and the per-chunk enqueue cost
+// (~40 us of host time: equal chunks of 65536 made the HOST the bottleneck, 1.45 ms per 10^6 against 1.18 ms
+// with 262144): few, large chunks first, a small one last.
+std::vector<int64_t> chunk_offsets(int64_t N, int64_t smallest) {
+    std::vector<int64_t> off{0};
+    int64_t left = N;
+    while (left > 0) {
+        int64_t c = left / 2;
+        if (c < smallest) c = std::min(left, smallest);
+        if (left - c < smallest / 2) c = left;           // no crumbs
+        off.push_back(off.back() + c);
+        left -= c;
+    }
+    return off;
+}
+
+// All jobs advance chunk by chunk from ONE host thread: after pinning every call below only enqueues.
+int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh) {
+    int64_t maxN = 0;
+    for (auto &j : jobs) maxN = std::max(maxN, j.N);
+    if (maxN == 0) return LMPC_OK;
+    lmpc_handle *h0 = jobs[0].h;
+    const int64_t smallest = std::max<int64_t>(1024, h0->hostChunk);
+    std::vector<std::vector<int64_t>> sched;
+    int64_t nchunks = 0;
+    for (auto &j : jobs) {
+        sched.push_back(chunk_offsets(j.N, smallest));
+        nchunks = std::max<int64_t>(nchunks, (int64_t)sched.back().size() - 1);
+    }
+    for (auto &j : jobs) {
+        if (j.N == 0) continue;
+        DeviceScope sc;
+        HIP_TRY(j.h, sc.enter(j.h->device));
+        int rc = ensure_staging(j.h, j.N, j.warm != nullptr);
+        if (rc == LMPC_OK) rc = ensure_pipe(j.h, (size_t)(2 * nchunks));
+        if (rc != LMPC_OK) { if (errh != j.h) errh->err = j.h->err; return rc; }
+    }
+    int rc = LMPC_OK;
+    for (int64_t c = 0; c < nchunks && rc == LMPC_OK; c++) {
+        for (size_t ji = 0; ji < jobs.size(); ji++) {
+            HostJob &j = jobs[ji];
+            if (c + 1 >= (int64_t)sched[ji].size()) continue;
+            lmpc_handle *h = j.h;
+            const int64_t off = sched[ji][c], n = sched[ji][c + 1] - off;
+            const size_t nth = (size_t)h->P.nth, nout = (size_t)h->P.nout, w = (size_t)h->P.words();
+            DeviceScope sc;
+            HIP_TRY(h, sc.enter(h->device));
+            hipEvent_t evUp = h->pipeEv[2 * c], evRun = h->pipeEv[2 * c + 1];
+            if (nth > 0)
+                HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char *>(h->sTheta) + rs * off * nth, j.theta + rs * off * nth,
+                                          rs * n * nth, hipMemcpyHostToDevice, h->sUp));
+            if (j.warm)
+                HIP_TRY(h, hipMemcpyAsync(h->sWarm + off * w, j.warm + off * w, sizeof(uint64_t) * n * w,
+                                          hipMemcpyHostToDevice, h->sUp));
+            HIP_TRY(h, hipEventRecord(evUp, h->sUp));
+            HIP_TRY(h, hipStreamWaitEvent(h->sRun, evUp, 0));
+            rc = launch_chunk(h, rs, n, off, j.warm != nullptr);
+            if (rc != LMPC_OK) { if (errh != h) errh->err = h->err; break; }
+            HIP_TRY(h, hipEventRecord(evRun, h->sRun));
+            HIP_TRY(h, hipStreamWaitEvent(h->sDown, evRun, 0));
+            HIP_TRY(h, hipMemcpyAsync(j.x + rs * off * nout, reinterpret_cast<char *>(h->sX) + rs * off * nout,
+                                      rs * n * nout, hipMemcpyDeviceToHost, h->sDown));
+            HIP_TRY(h, hipMemcpyAsync(j.flag + off, h->sFlag + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
+            if (j.iters)
+                HIP_TRY(h, hipMemcpyAsync(j.iters + off, h->sIter + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
+            if (j.active)
+                HIP_TRY(h, hipMemcpyAsync(j.active + off * w, h->sAct + off * w, sizeof(uint64_t) * n * w,
+                                          hipMemcpyDeviceToHost, h->sDown));
+        }
+    }
+    // drain every device's pipeline, also after an error (nothing may still write into the caller's arrays)
+    for (auto &j : jobs) {
+        if (j.N == 0) continue;
+        DeviceScope sc;
+        if (sc.enter(j.h->device) != hipSuccess) continue;
+        hipError_t e1 = hipStreamSynchronize(j.h->sUp), e2 = hipStreamSynchronize(j.h->sRun),
+                   e3 = hipStreamSynchronize(j.h->sDown);
+        if (rc == LMPC_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess))
+            rc = fail(errh, LMPC_ERR_HIP, std::string("lmpc: host pipeline: ") +
+                                              hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+    }
+    return rc;
+}
+
+void pin_call(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag,
+              int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    if (!h->hostRegister) return;
+    const size_t w = (size_t)h->P.words();
+    pin.pin(theta, rs * (size_t)N * h->P.nth);
+    pin.pin(x, rs * (size_t)N * h->P.nout);
+    pin.pin(flag, sizeof(int32_t) * (size_t)N);
+    pin.pin(iters, sizeof(int32_t) * (size_t)N);
+    pin.pin(active, sizeof(uint64_t) * (size_t)N * w);
+    pin.pin(warm, sizeof(uint64_t) * (size_t)N * w);
+}
+
+int solve_host(lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag, int32_t *iters,
+               uint64_t *active, const uint64_t *warm, const char *who) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (N < 0 || (N > 0 && (!x || !flag || (h->P.nth > 0 && !theta))))
+        return fail(h, LMPC_ERR_BADARG, std::string(who) + ": NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    LMPC_ENTER_DEVICE(h);
+    PinScope pin;
+    // small calls (a closed loop's single solve): pinning and three streams would cost more than they hide
+    if ((size_t)N * (rs * (h->P.nth + h->P.nout) + 4) >= ((size_t)1 << 20))
+        pin_call(pin, h, rs, N, theta, x, flag, iters, active, warm);
+    std::vector<HostJob> jobs{HostJob{h, N, static_cast<const char *>(theta), static_cast<char *>(x), flag, iters, active, warm}};
+    return run_host_jobs(jobs, rs, h);
+}
+
+// ---------------------------------------------------------------- RCCL, loaded on first use
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        const char *env = std::getenv("LMPC_RCCL_LIB");
+        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            lib = dlopen(n, RTLD_LAZY | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("lmpc: cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : ""); return false; }
+#define LMPC_SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) { err = "lmpc: RCCL lacks " name; return false; }
+        LMPC_SYM(CommInitAll, "ncclCommInitAll") LMPC_SYM(CommDestroy, "ncclCommDestroy")
+        LMPC_SYM(GroupStart, "ncclGroupStart") LMPC_SYM(GroupEnd, "ncclGroupEnd") LMPC_SYM(Send, "ncclSend")
+        LMPC_SYM(Recv, "ncclRecv") LMPC_SYM(GetErrorString, "ncclGetErrorString")
+#undef LMPC_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+
+}  // namespace
+
+struct lmpc_multi {
+    std::vector<lmpc_handle *> h;      // one per device, same problem
+    std::vector<int> dev;
+    std::vector<hipStream_t> stream;   // device-resident path: one stream per device
+    std::vector<ncclComm_t> comm;      // created on the first gather
+    std::string err;
+};
+
+namespace {
+int mfail(lmpc_multi *hm, int code, const std::string &msg) {
+    if (hm) hm->err = msg; else g_setup_err = msg;
+    return code;
+}
+}  // namespace
+
+extern "C" {
+
+int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x, int32_t *exitflag,
+                     int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    return solve_host(h, sizeof(double), N, theta, x, exitflag, iters, active, warm, "lmpc_solve_batch");
+}
+
+int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
+                         int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    return solve_host(h, sizeof(float), N, theta, x, exitflag, iters, active, warm, "lmpc_solve_batch_f32");
+}
+
+int lmpc_pin_host(void *p, size_t bytes) {
+    if (!p || bytes == 0) return LMPC_ERR_BADARG;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e == hipSuccess) return LMPC_OK;
+    (void)hipGetLastError();
+    return mfail(nullptr, e == hipErrorNoDevice ? LMPC_ERR_NOGPU : LMPC_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+}
+
+int lmpc_unpin_host(void *p) {
+    if (!p) return LMPC_ERR_BADARG;
+    const hipError_t e = hipHostUnregister(p);
+    if (e == hipSuccess) return LMPC_OK;
+    (void)hipGetLastError();
+    return mfail(nullptr, LMPC_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+}
+
+void lmpc_multi_partition(int64_t N, int n_devices, int64_t *offsets) {
+    // contiguous shards, the remainder spread over the leading devices: offsets[d] .. offsets[d+1]
+    if (!offsets || n_devices <= 0) return;
+    const int64_t base = N > 0 ? N / n_devices : 0, rem = N > 0 ? N % n_devices : 0;
+    offsets[0] = 0;
+    for (int d = 0; d < n_devices; d++) offsets[d + 1] = offsets[d] + base + (d < rem ? 1 : 0);
+}
+
+int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout, const double *H, const double *f,
+                     const double *f_theta, const double *A, const double *bu, const double *bl, const double *W,
+                     const int32_t *sense, const double *Kfb, int nx, const lmpc_settings *s, const int *devices,
+                     int n_devices) {
+    if (!out) return mfail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_multi: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return mfail(nullptr, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    if (n_devices <= 0) { n_devices = ndev; devices = nullptr; }      // all visible devices
+    lmpc_multi *hm = new lmpc_multi();
+    for (int d = 0; d < n_devices; d++) {
+        const int dev = devices ? devices[d] : d;
+        if (dev < 0 || dev >= ndev || std::find(hm->dev.begin(), hm->dev.end(), dev) != hm->dev.end()) {
+            lmpc_free_multi(hm);
+            return mfail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_multi: bad or repeated device ordinal");
+        }
+        lmpc_handle *h = nullptr;
+        const int rc = lmpc_setup(&h, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, s, dev);
+        if (rc != LMPC_OK) { lmpc_free_multi(hm); return rc; }       // (the text is lmpc_last_error(NULL))
+        hm->h.push_back(h);
+        hm->dev.push_back(dev);
+    }
+    *out = hm;
+    return LMPC_OK;
+}
+
+int lmpc_multi_devices(const lmpc_multi *hm) { return hm ? (int)hm->h.size() : LMPC_ERR_BADARG; }
+
+lmpc_handle *lmpc_multi_handle(lmpc_multi *hm, int i) {
+    return (hm && i >= 0 && i < (int)hm->h.size()) ? hm->h[i] : nullptr;
+}
+
+const char *lmpc_multi_last_error(const lmpc_multi *hm) { return hm ? hm->err.c_str() : g_setup_err.c_str(); }
+
+int lmpc_solve_batch_multi(lmpc_multi *hm, int64_t N, const double *theta, double *x, int32_t *exitflag,
+                           int32_t *iters, uint64_t *active, const uint64_t *warm) {
+    if (!hm || hm->h.empty()) return LMPC_ERR_BADARG;
+    lmpc_handle *h0 = hm->h[0];
+    if (N < 0 || (N > 0 && (!x || !exitflag || (h0->P.nth > 0 && !theta))))
+        return mfail(hm, LMPC_ERR_BADARG, "lmpc_solve_batch_multi: NULL array or negative N");
+    if (N == 0) return LMPC_OK;
+    const int nd = (int)hm->h.size();
+    const size_t nth = (size_t)h0->P.nth, nout = (size_t)h0->P.nout, w = (size_t)h0->P.words();
+    std::vector<int64_t> off((size_t)nd + 1);
+    lmpc_multi_partition(N, nd, off.data());
+    PinScope pin;
+    pin_call(pin, h0, sizeof(double), N, theta, x, exitflag, iters, active, warm);
+    std::vector<HostJob> jobs;
+    for (int d = 0; d < nd; d++) {
+        const int64_t o = off[d];
+        jobs.push_back(HostJob{hm->h[d], off[d + 1] - o, reinterpret_cast<const char *>(theta + o * nth),
+                               reinterpret_cast<char *>(x + o * nout), exitflag + o, iters ? iters + o : nullptr,
+                               active ? active + o * w : nullptr, warm ? warm + o * w : nullptr});
+    }
+    const int rc = run_host_jobs(jobs, sizeof(double), h0);
+    if (rc != LMPC_OK) hm->err = h0->err;
+    return rc;
+}
+
+int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const double *const *theta,
+                                  double *const *x, int32_t *const *exitflag, double *x_root,
+                                  int32_t *exitflag_root) {
+    if (!hm || hm->h.empty() || !N_dev || !theta || !x || !exitflag) return LMPC_ERR_BADARG;
+    const int nd = (int)hm->h.size();
+    const size_t nout = (size_t)hm->h[0]->P.nout;
+    if (hm->stream.empty()) {
+        hm->stream.assign((size_t)nd, nullptr);
+        for (int d = 0; d < nd; d++) {
+            DeviceScope sc;
+            if (sc.enter(hm->dev[d]) != hipSuccess || hipStreamCreateWithFlags(&hm->stream[d], hipStreamNonBlocking) != hipSuccess)
+                return mfail(hm, LMPC_ERR_HIP, "lmpc_solve_batch_multi_device: cannot create the device streams");
+        }
+    }
+    const bool gather = x_root != nullptr || exitflag_root != nullptr;
+    if (gather && nd > 1 && hm->comm.empty()) {
+        if (!g_rccl.load(hm->err)) return LMPC_ERR_UNSUPPORTED;
+        hm->comm.assign((size_t)nd, nullptr);
+        const ncclResult_t r = g_rccl.CommInitAll(hm->comm.data(), nd, hm->dev.data());
+        if (r != ncclSuccess) {
+            hm->comm.clear();
+            return mfail(hm, LMPC_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    // every device solves its own shard on its own stream (no data-path collective inside the solve)
+    for (int d = 0; d < nd; d++) {
+        if (N_dev[d] < 0) return mfail(hm, LMPC_ERR_BADARG, "lmpc_solve_batch_multi_device: negative shard size");
+        if (N_dev[d] == 0) continue;
+        const int rc = lmpc_solve_batch_device(hm->h[d], N_dev[d], theta[d], x[d], exitflag[d], nullptr, nullptr,
+                                               nullptr, hm->stream[d]);
+        if (rc != LMPC_OK) { hm->err = hm->h[d]->err; return rc; }
+    }
+    int rc = LMPC_OK;
+    if (gather) {
+        // the one exchange step of the sharded job: per-shard solutions to device 0.  Shard 0 is a local
+        // copy; every other device sends its shard on its own xGMI link (ncclSend / ncclRecv pairs inside
+        // one group), device 0 receives them behind its own solve.
+        std::vector<int64_t> off((size_t)nd + 1, 0);
+        for (int d = 0; d < nd; d++) off[d + 1] = off[d] + N_dev[d];
+        {
+            DeviceScope sc;
+            if (sc.enter(hm->dev[0]) != hipSuccess) return mfail(hm, LMPC_ERR_HIP, "lmpc: hipSetDevice");
+            if (x_root && N_dev[0] > 0 && x_root != x[0] &&
+                hipMemcpyAsync(x_root, x[0], sizeof(double) * N_dev[0] * nout, hipMemcpyDeviceToDevice, hm->stream[0]) != hipSuccess)
+                rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: local copy of shard 0");
+            if (exitflag_root && N_dev[0] > 0 && exitflag_root != exitflag[0] &&
+                hipMemcpyAsync(exitflag_root, exitflag[0], sizeof(int32_t) * N_dev[0], hipMemcpyDeviceToDevice, hm->stream[0]) != hipSuccess)
+                rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: local copy of shard 0");
+        }
+        if (rc == LMPC_OK && nd > 1) {
+            ncclResult_t r = g_rccl.GroupStart();
+            for (int d = 1; d < nd && r == ncclSuccess; d++) {
+                if (N_dev[d] == 0) continue;
+                if (x_root) {
+                    r = g_rccl.Send(x[d], (size_t)N_dev[d] * nout, ncclFloat64, 0, hm->comm[d], hm->stream[d]);
+                    if (r == ncclSuccess)
+                        r = g_rccl.Recv(x_root + off[d] * nout, (size_t)N_dev[d] * nout, ncclFloat64, d, hm->comm[0], hm->stream[0]);
+                }
+                if (exitflag_root && r == ncclSuccess) {
+                    r = g_rccl.Send(exitflag[d], (size_t)N_dev[d], ncclInt32, 0, hm->comm[d], hm->stream[d]);
+                    if (r == ncclSuccess)
+                        r = g_rccl.Recv(exitflag_root + off[d], (size_t)N_dev[d], ncclInt32, d, hm->comm[0], hm->stream[0]);
+                }
+            }
+            const ncclResult_t re = g_rccl.GroupEnd();
+            if (r == ncclSuccess) r = re;
+            if (r != ncclSuccess) rc = mfail(hm, LMPC_ERR_HIP, std::string("RCCL gather: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    for (int d = 0; d < nd; d++) {
+        DeviceScope sc;
+        if (sc.enter(hm->dev[d]) != hipSuccess) continue;
+        const hipError_t e = hipStreamSynchronize(hm->stream[d]);
+        if (e != hipSuccess && rc == LMPC_OK) rc = mfail(hm, LMPC_ERR_HIP, std::string("lmpc: device stream: ") + hipGetErrorString(e));
+    }
+    return rc;
+}
+
+void lmpc_free_multi(lmpc_multi *hm) {
+    if (!hm) return;
+    for (ncclComm_t c : hm->comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+    for (size_t d = 0; d < hm->stream.size(); d++) {
+        DeviceScope sc;
+        if (hm->stream[d] && sc.enter(hm->dev[d]) == hipSuccess) hipStreamDestroy(hm->stream[d]);
+    }
+    for (lmpc_handle *h : hm->h) lmpc_free(h);
+    delete hm;
+}
+
+}  // extern "C"

@@ -32,6 +32,32 @@ namespace lmpc {
 #endif
 constexpr int kScreenTPB = LMPC_SCREEN_TPB;
 
+// Cache policy of the streaming accesses, decided by same-box A/B (tools/hot_ab.py) on 10^6 pendulum points:
+// record LOADS plain -- nontemporal loads cost the pass 6 us of 16 (22.3 vs 16.4 us; round 1 believed it had
+// measured them "neutral": its run-time switch between the two forms had been folded into a plain load);
+// output STORES plain as well (nontemporal stores: same pass time, but the iterating kernel behind it, which
+// overwrites the queued problems' outputs, ran 0.3-0.7 us longer on lines that had been pushed out).
+#ifndef LMPC_SCREEN_NT_LOAD
+#define LMPC_SCREEN_NT_LOAD 0
+#endif
+#ifndef LMPC_SCREEN_NT_STORE
+#define LMPC_SCREEN_NT_STORE 0
+#endif
+template <typename T> __device__ __forceinline__ T screen_ld(const T *p) {
+#if LMPC_SCREEN_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T> __device__ __forceinline__ void screen_st(T v, T *p) {
+#if LMPC_SCREEN_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // NTHMAX: column stride of the padded rows (8, 16 or 32).  NT: columns the unrolled chains run over --
 // the exact nth for nth <= 16 (one instantiation per value: with three batches in flight the pass is
 // bound by vector issue, and the padded column of the 7-parameter pendulum cost 6 %), else NTHMAX.
@@ -79,7 +105,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int tc = (NT <= 16 || t < nth) ? t : nth - 1;      // NT <= 16: NT == nth exactly
-            dst[t] = __builtin_nontemporal_load(src + tc);
+            dst[t] = screen_ld(src + tc);
         }
         }
     };
@@ -200,7 +226,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                 for (int l = 0; l < kMaxSimU; l++) if (SIM && l == k) uo[l] = 0.0 + sh;
                 if (SIM && X == nullptr) {                          // closed loop without an input trajectory
                 } else if (wide_out) sxo[(tid & ~63) * P.nout + lane * P.nout + k] = 0.0 + sh;   // see below
-                else __builtin_nontemporal_store(0.0 + sh, X + pid * P.nout + k);
+                else screen_st(0.0 + sh, X + pid * P.nout + k);
             }
             // closed loop: a problem finished here also advances its scenario (queued ones: lane kernel)
             if (SIM && !hard) {
@@ -244,7 +270,7 @@ __global__ __launch_bounds__(256) void screen_kernel(
                                                            : (EXIT_OPTIMAL < S.flag_min[pid] ? (int)EXIT_OPTIMAL : S.flag_min[pid]);
             }
             if (SIM && exitflag == nullptr) {                       // closed loop: flag_min carries the flags
-            } else __builtin_nontemporal_store((int32_t)EXIT_OPTIMAL, exitflag + pid);
+            } else screen_st((int32_t)EXIT_OPTIMAL, exitflag + pid);
             // (iteration count and active set only for the problems finished here: `active` may be the
             // very buffer the iterating kernel still has to read its warm-start masks from)
             if (iters && !hard) iters[pid] = 1;

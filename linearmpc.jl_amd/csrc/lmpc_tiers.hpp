@@ -1,0 +1,181 @@
+// Straight-line dual active-set iterations for the first rows of a small box-constrained problem's working set
+// (shared by lane_kernel's first tier and fast_kernel).
+//
+// 99.9999 % of the problems of an MPC batch that need iterations at all follow the same short path: rows are
+// appended one after the other (no removal, no singular pivot) and the solve ends with a handful of active rows.
+// On that path every working-set position is a compile-time constant, so it is written as straight-line code:
+//
+//   tier k (k + 1 rows in the working set, k = 0 .. KMAX-1):  append the most violated row (new L row, pivot),
+//   constrained stationary point on the factor, dual feasibility test, u = -M_W' lam*, the scan of all rows.
+//
+// Each chain is the fma chain of lane_loop / the CPU oracle in the same order (positions beyond |W| hold exact
+// zeros there and drop out of every chain), so a problem finished here has the bits the generic loop would give
+// it -- at about a third of its instructions (no register arrays with data-dependent positions emulated by
+// selects).  Anything else -- a blocking multiplier (removal), a singular pivot, a row violated inside its own
+// working set, a working set that wants more than KMAX rows, an objective above fval_bound -- is NOT finished
+// here: the caller runs the generic loop on it from scratch.  The caller guarantees: m == n == N rows (simple
+// bounds), no IMMUTABLE / ACTIVE-flagged rows, cold start, iter_limit > KMAX + 1, cycle_tol >= KMAX + 1 (then
+// none of the generic loop's guards can fire inside these iterations).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lmpc_pack.hpp"
+#include "lmpc_wave_layout.hpp"
+
+// rows the tiers go up to (capped at n).  5: on the headline batch (n = 5) a problem that wants a fourth or
+// fifth row is rare (1.2 % / 1e-6), but ONE of them in the generic loop is a 18 us latency chain at the end of
+// a 25 us kernel; with all five tiers only removals and singular pivots leave the straight-line path.
+#ifndef LMPC_FAST_KMAX
+#define LMPC_FAST_KMAX 5
+#endif
+
+namespace lmpc {
+
+__host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
+// strict lower triangle, row i > col t
+__host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
+
+// straight-line tiers on one problem per lane (`mine`: this lane holds a problem).  Returns EXIT_OPTIMAL or
+// 0 = not finished here (the generic kernel takes it).  On success u, iter and the working set (wrow / wlow,
+// nact rows) are set.
+template <int N, int KMAX>
+__device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM, const double *sG, const double *sdu,
+                                          const double *sdl, const bool mine, const double (&b)[N], double (&u)[N],
+                                          int &iter, int (&wrow)[KMAX], bool (&wlow)[KMAX], int &nact) {
+    const double ptol = P.primal_tol;
+    // ---- iteration 1 (empty working set, u = 0): the most violated row, as lane_loop's scan finds it
+    double min_val = -ptol;
+    int add = -1;
+    bool addlow = false;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const double vu = (sdu[j] + b[j]) - 0.0;
+        const double vl = -((sdl[j] + b[j]) - 0.0);
+        if (vu < min_val) { add = j; addlow = false; min_val = vu; }
+        else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+    }
+    double SL[KMAX * (KMAX - 1) / 2 > 0 ? KMAX * (KMAX - 1) / 2 : 1], D[KMAX], Dinv[KMAX], rhs[KMAX], ls[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; i++) { D[i] = 0.0; Dinv[i] = 0.0; rhs[i] = 0.0; ls[i] = 0.0; wrow[i] = 0; wlow[i] = false; }
+    double fval = 0.0;
+    int result = 0;
+    bool running = mine && add >= 0;       // (a queued problem always has a violated row)
+    if (add < 0) add = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+        // ---- append row `add` at position k (lane_loop's ldl_add with na = k)
+        if (running) {
+            const int j = add;
+            double row[KMAX > 1 ? KMAX - 1 : 1];
+#pragma unroll
+            for (int t = 0; t < k; t++) {
+                const int a = wrow[t];
+                row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
+            }
+            double dnew = sG[lmpc_tri(j) + j];
+#pragma unroll
+            for (int i = 1; i < k; i++) {
+                double acc = row[i];
+#pragma unroll
+                for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], row[t], acc);
+                row[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) {
+                const double q = row[i];
+                const double l = q * Dinv[i];
+                row[i] = l;
+                dnew = __builtin_fma(-l, q, dnew);
+            }
+            if (dnew < P.zero_tol) running = false;            // singular working set: generic kernel
+            double bj = 0.0;
+#pragma unroll
+            for (int q = 0; q < N; q++) bj = (q == j) ? b[q] : bj;
+            wrow[k] = j; wlow[k] = addlow;
+            rhs[k] = addlow ? -(sdl[j] + bj) : -(sdu[j] + bj);
+            D[k] = dnew; Dinv[k] = 1.0 / dnew;
+#pragma unroll
+            for (int t = 0; t < k; t++) SL[lmpc_sl(k, t)] = row[t];
+        }
+        if (!__any(running)) break;
+        // ---- iteration k + 2 on the working set of k + 1 rows
+        // (the rows of M and the bounds are re-read from LDS in every tier: hoisted out of the tile loop they
+        // would sit in ~70 registers for the whole kernel; the empty asm hides that the addresses repeat)
+        int ofs = 0;
+        asm volatile("" : "+s"(ofs));
+        const double *sMk = sM + ofs, *sduk = sdu + ofs, *sdlk = sdl + ofs;
+        const int na = k + 1;
+        double xl[KMAX];
+#pragma unroll
+        for (int i = 0; i < na; i++) {
+            double acc = rhs[i];
+#pragma unroll
+            for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], xl[t], acc);
+            xl[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < na; i++) xl[i] = xl[i] * Dinv[i];
+#pragma unroll
+        for (int i = na - 1; i >= 0; i--) {
+            double acc = xl[i];
+#pragma unroll
+            for (int t = na - 1; t > i; t--) acc = __builtin_fma(-SL[lmpc_sl(t, i)], ls[t], acc);
+            ls[i] = acc;
+        }
+        bool blocked = false;
+#pragma unroll
+        for (int i = 0; i < na; i++) {
+            const bool ok = wlow[i] ? (ls[i] < P.dual_tol) : (ls[i] > -P.dual_tol);
+            blocked = blocked || !ok;
+        }
+        if (blocked) running = false;                          // a removal: generic kernel
+        // primal iterate and objective (uu: lanes that finished in an earlier tier keep their u)
+        double uu[N];
+#pragma unroll
+        for (int c = 0; c < N; c++) uu[c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < na; i++) {
+            const double *mi = sMk + wrow[i] * N;
+#pragma unroll
+            for (int c = 0; c < N; c++) uu[c] = __builtin_fma(-mi[c], ls[i], uu[c]);
+        }
+        fval = 0.0;
+#pragma unroll
+        for (int c = 0; c < N; c++) fval = __builtin_fma(uu[c], uu[c], fval);
+        if (fval > P.fval_bound) running = false;              // EXIT_INFEASIBLE: generic kernel reports it
+        unsigned actmask = 0u;
+#pragma unroll
+        for (int i = 0; i < na; i++) actmask |= 1u << wrow[i];
+        min_val = -ptol;
+        add = -1;
+        addlow = false;
+        bool broken = false;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double Mu = 0.0;
+            const double *mrow = sMk + j * N;
+#pragma unroll
+            for (int c = 0; c < N; c++) Mu = __builtin_fma(mrow[c], uu[c], Mu);
+            const double vu = (sduk[j] + b[j]) - Mu;
+            const double vl = -((sdlk[j] + b[j]) - Mu);
+            if (!((actmask >> j) & 1u)) {
+                if (vu < min_val) { add = j; addlow = false; min_val = vu; }
+                else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+            } else if (vu < -ptol || vl < -ptol) {
+                broken = true;
+            }
+        }
+        if (broken) running = false;                           // EXIT_CYCLE: generic kernel reports it
+        if (running && add < 0) {
+            result = EXIT_OPTIMAL; iter = k + 2; nact = na; running = false;
+#pragma unroll
+            for (int c = 0; c < N; c++) u[c] = uu[c];
+        }
+        if (k + 1 == KMAX) running = false;                    // wants a further row: generic kernel
+    }
+    return result;
+}
+
+}  // namespace lmpc

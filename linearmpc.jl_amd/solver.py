@@ -512,3 +512,106 @@ class BatchedQP:
             self.close()
         except Exception:
             pass
+
+
+class MultiQP:
+    """One condensed-MPC QP structure replicated on several GPUs of this process (`lmpc_multi`,
+    include/lmpc_hip.h): one call solves a batch across all of them -- the shape of the reference's
+    caller, one process with one Theta (/root/reference/src/utils.jl:268-283)."""
+
+    def __init__(self, handle):
+        self._hm = handle
+        self.ndev = int(lib().lmpc_multi_devices(self._hm))
+        self.parts = [BatchedQP(lib().lmpc_multi_handle(self._hm, i), None) for i in range(self.ndev)]
+        for q in self.parts:
+            q.close = lambda: None                      # the multi handle owns them
+        q0 = self.parts[0]
+        self.n, self.m, self.ms, self.nth, self.nout, self.words = q0.n, q0.m, q0.ms, q0.nth, q0.nout, q0.words
+
+    @classmethod
+    def from_mpqp(cls, H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0,
+                  settings: Settings | None = None, devices=None):
+        """`lmpc_setup_multi`; devices = None: every visible GPU."""
+        H = _f64(H, "F")
+        n = H.shape[0]
+        f_theta = _f64(np.asarray(f_theta, float).reshape(n, -1), "F")
+        nth = f_theta.shape[1]
+        bu = _f64(np.asarray(bu, float).reshape(-1))
+        bl = _f64(np.asarray(bl, float).reshape(-1))
+        m = bu.size
+        A = _f64(np.asarray(A, float).reshape(-1, n), "F")
+        ms = m - A.shape[0]
+        W = _f64(np.asarray(W, float).reshape(m, nth), "F")
+        f = _f64(np.zeros(n) if f is None else np.asarray(f, float).reshape(n))
+        nout = n if nout is None else int(nout)
+        sense = np.ascontiguousarray(np.zeros(m, np.int32) if senses is None else senses, dtype=np.int32)
+        Kf = None if K is None else _f64(np.asarray(K, float).reshape(nout, -1), "F")
+        devs = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        h = _vp()
+        rc = lib().lmpc_setup_multi(ctypes.byref(h), n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta),
+                                    _ptr(A), _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense),
+                                    _ptr(Kf) if Kf is not None else None, int(nx if K is not None else 0),
+                                    ctypes.cast(ctypes.pointer(settings), _vp) if settings is not None else None,
+                                    _ptr(devs) if devs is not None else None, 0 if devs is None else int(devs.size))
+        check(rc)
+        return cls(h)
+
+    def _check(self, rc):
+        if rc != _cabi.LMPC_OK:
+            raise LmpcError(rc, (lib().lmpc_multi_last_error(self._hm) or b"").decode())
+
+    @staticmethod
+    def partition(N, ndev):
+        """`lmpc_multi_partition`: shard d = [off[d], off[d+1])."""
+        off = (ctypes.c_int64 * (ndev + 1))()
+        lib().lmpc_multi_partition(int(N), int(ndev), off)
+        return [int(v) for v in off]
+
+    def solve(self, theta, warm=None, want_iters=True, want_active=True):
+        """`lmpc_solve_batch_multi`: host arrays in and out, the batch split over the GPUs."""
+        theta = _f64(np.asarray(theta, float).reshape(-1, self.nth) if self.nth else np.zeros((len(theta), 0)))
+        N = theta.shape[0]
+        x = np.zeros((N, self.nout))
+        ef = np.zeros(N, np.int32)
+        it = np.zeros(N, np.int32) if want_iters else None
+        act = np.zeros((N, self.words), np.uint64) if want_active else None
+        w = None if warm is None else np.ascontiguousarray(np.asarray(warm, np.uint64).reshape(N, self.words))
+        self._check(lib().lmpc_solve_batch_multi(self._hm, N, _ptr(theta), _ptr(x), _ptr(ef),
+                                                 _ptr(it) if it is not None else None,
+                                                 _ptr(act) if act is not None else None,
+                                                 _ptr(w) if w is not None else None))
+        return x, ef, it, act
+
+    def solve_device(self, thetas, gather=True):
+        """`lmpc_solve_batch_multi_device`: thetas[d] = (N_d, nth) float64 CUDA tensor on device d.
+        Returns (x shards, exit-flag shards, x gathered on the first device or None, flags gathered or None)."""
+        import torch
+        assert len(thetas) == self.ndev
+        xs = [torch.empty((t.shape[0], self.nout), dtype=torch.float64, device=t.device) for t in thetas]
+        fs = [torch.empty(t.shape[0], dtype=torch.int32, device=t.device) for t in thetas]
+        for t in thetas:
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == self.nth):
+                raise ValueError("every shard must be a contiguous float64 CUDA tensor of shape (N_d, nth)")
+            torch.cuda.synchronize(t.device)            # the library launches on its own streams
+        ntot = sum(int(t.shape[0]) for t in thetas)
+        xr = torch.empty((ntot, self.nout), dtype=torch.float64, device=thetas[0].device) if gather else None
+        fr = torch.empty(ntot, dtype=torch.int32, device=thetas[0].device) if gather else None
+        arr = lambda ts: (ctypes.c_void_p * self.ndev)(*[t.data_ptr() for t in ts])
+        nd = (ctypes.c_int64 * self.ndev)(*[int(t.shape[0]) for t in thetas])
+        self._check(lib().lmpc_solve_batch_multi_device(
+            self._hm, ctypes.cast(nd, _vp), ctypes.cast(arr(thetas), _vp), ctypes.cast(arr(xs), _vp),
+            ctypes.cast(arr(fs), _vp), _vp(xr.data_ptr()) if gather else None, _vp(fr.data_ptr()) if gather else None))
+        return xs, fs, xr, fr
+
+    def close(self):
+        if self._hm:
+            for q in self.parts:
+                q._h = None
+            lib().lmpc_free_multi(self._hm)
+            self._hm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

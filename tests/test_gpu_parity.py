@@ -1432,3 +1432,151 @@ def test_generated_controller_parameter_preview(lmpc):
     ef = ctl.mpc_compute_control(control, np.zeros((N, 1)), np.zeros((N, 1)), None, P)
     assert np.all(ef == 1) and np.abs(control[:, 0] - np.clip(2 * P[:, 0], 0, 2)).max() < 1e-12
     assert abs(control[0, 0] - u_julia[0]) < 1e-12
+
+
+# ------------------------------------------------------------------ host pipeline, several GPUs behind one call
+@pytest.mark.parametrize("chunk", [1024, 4096, 131072])
+def test_host_pipeline_chunks_do_not_change_results(lmpc, chunk):
+    # lmpc_solve_batch moves the batch through H2D / kernels / D2H in chunks; any chunk size, ragged last
+    # chunk included, gives the bits of the device-resident call on the whole batch
+    import torch
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    rng = np.random.default_rng(11)
+    N = 3 * 4096 + 77
+    theta = np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    qp.set_option("host_chunk", chunk)
+    x, ef, it, act = qp.solve(theta)
+    th_d = torch.from_numpy(theta).cuda()
+    it_d = torch.empty(N, dtype=torch.int32, device="cuda")
+    ac_d = torch.zeros((N, qp.words), dtype=torch.int64, device="cuda")
+    x_d, ef_d = qp.solve_device(th_d, iters=it_d, active=ac_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(x, x_d.cpu().numpy()) and np.array_equal(ef, ef_d.cpu().numpy())
+    assert np.array_equal(it, it_d.cpu().numpy()) and np.array_equal(act, ac_d.cpu().numpy().view(np.uint64))
+    # unpinned copies (host_register 0) and a warm start through the pipeline
+    qp.set_option("host_register", 0)
+    x2, ef2, it2, act2 = qp.solve(theta, warm=act)
+    assert np.array_equal(ef2, ef) and np.abs(x2 - x).max() <= TOL and np.array_equal(act2, act)
+    _compare(qp, theta[:2000], warm=act[:2000])
+
+
+def test_multi_device_entry_points(lmpc):
+    # lmpc_setup_multi / lmpc_solve_batch_multi / lmpc_solve_batch_multi_device with however many GPUs this
+    # box shows (one is fine): the sharded call returns the bits of the single-device call
+    import torch
+    g = load_golden("pendulum")
+    nd = torch.cuda.device_count()
+    mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+    assert mq.ndev == nd and mq.nth == 7
+    qp = _qp_from_golden(lmpc, g, 1)
+    rng = np.random.default_rng(12)
+    N = 200_003
+    theta = np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    x1, ef1, it1, act1 = qp.solve(theta)
+    for q_ in mq.parts:
+        q_.set_option("host_chunk", 30000)
+    x, ef, it, act = mq.solve(theta)
+    assert np.array_equal(x, x1) and np.array_equal(ef, ef1) and np.array_equal(it, it1) and np.array_equal(act, act1)
+    # device-resident shards + gather to the first device
+    off = lmpc.MultiQP.partition(N, nd)
+    shards = [torch.from_numpy(theta[off[d]:off[d + 1]]).to(f"cuda:{d}") for d in range(nd)]
+    xs, fs, xr, fr = mq.solve_device(shards, gather=True)
+    assert np.array_equal(xr.cpu().numpy(), x1) and np.array_equal(fr.cpu().numpy(), ef1)
+    for d in range(nd):
+        assert np.array_equal(xs[d].cpu().numpy(), x1[off[d]:off[d + 1]])
+    # the caller's current device is left alone by every entry point
+    assert torch.cuda.current_device() == 0
+    mq.close()
+
+
+def test_mixed_controller_entry_points_on_one_handle(lmpc):
+    # compute_control_observer_device, then the host compute_control (regrows its staging
+    # block), then the observer call again -- the observer scratch must survive
+    import torch
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_parameter_layout(4, 2, 0, 1, 0)
+    rng = np.random.default_rng(13)
+    N = 3000
+    state = rng.uniform(-3, 3, (N, 4)); ref = rng.uniform(-2, 2, (N, 2)); ctrl0 = rng.uniform(-1, 1, (N, 1))
+
+    def observer_call():
+        c = torch.from_numpy(ctrl0.copy()).cuda()
+        ef = qp.compute_control_observer_device(c, torch.from_numpy(state).cuda(), 0, reference=torch.from_numpy(ref).cuda())
+        torch.cuda.synchronize()
+        return c.cpu().numpy(), ef.cpu().numpy()
+
+    c1, e1 = observer_call()
+    big = 3 * N                                              # larger batch: the host staging block regrows
+    ch = np.tile(ctrl0, (3, 1)).copy()
+    efh = qp.compute_control(ch, np.tile(state, (3, 1)), np.tile(ref, (3, 1)))
+    c2, e2 = observer_call()
+    assert np.array_equal(c1, c2) and np.array_equal(e1, e2)
+    assert np.array_equal(ch[:N], c1) and np.array_equal(efh[:N], e1) and big == len(ch)
+
+
+# ------------------------------------------------------------------ one-launch kernel (lmpc_fast_kernel.hpp)
+def _boxed_problem(rng, n, nth, spread):
+    """Random strictly convex QP with the n simple bounds as its only constraints (the input-bounded MPC shape)."""
+    Rm = rng.normal(size=(n, n))
+    H = Rm @ Rm.T + n * np.eye(n) * rng.uniform(0.05, 1.0)
+    f_theta = rng.normal(size=(n, nth)) * spread
+    f = rng.normal(size=n) * 0.3
+    bu = rng.uniform(0.2, 1.5, n)
+    bl = -rng.uniform(0.2, 1.5, n)
+    W = rng.normal(size=(n, nth)) * 0.2 * (rng.uniform() < 0.5)
+    return H, f, f_theta, bu, bl, W
+
+
+@pytest.mark.parametrize("n,nth", [(2, 1), (3, 5), (4, 16), (5, 7), (5, 8), (4, 9), (5, 3)])
+def test_one_launch_kernel_matches_two_kernel_form_and_oracle(lmpc, n, nth):
+    # small boxed problems, cold start: ONE kernel (streaming pass + straight-line tiers + generic loop for the
+    # rest) against the two-kernel form ("fast" 0) and against the oracle, with parameter spreads from "hardly
+    # ever iterates" to "every problem iterates, rows are removed again"; ragged batch sizes around the tile
+    # and workgroup sizes; one and n outputs
+    import torch
+    rng = np.random.default_rng(100 * n + nth)
+    for spread, nout in ((0.3, 1), (1.5, n), (6.0, 1)):
+        H, f, f_theta, bu, bl, W = _boxed_problem(rng, n, nth, spread)
+        qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, np.zeros((0, n)), bu, bl, W, nout=nout)
+        assert qp.kernel_name.startswith("screen+lane")
+        for N in (1, 63, 64, 65, 1500, 30011):
+            theta = rng.normal(size=(N, nth))
+            x, ef, it, act = _compare(qp, theta)                     # (fast path on by default) vs the oracle
+            qp.set_option("fast", 0)
+            x0, ef0, it0, act0 = qp.solve(theta)
+            qp.set_option("fast", 1)
+            assert np.array_equal(x, x0) and np.array_equal(ef, ef0) and np.array_equal(it, it0) and np.array_equal(act, act0)
+        for nstr in (1, 2, 4):                                        # any split of streaming / solving wavefronts
+            qp.set_option("fast_nstr", nstr)
+            qp.set_option("fast_tiles", 8 if nstr == 2 else 0)
+            x1, ef1, it1, act1 = qp.solve(theta)
+            assert np.array_equal(x1, x) and np.array_equal(ef1, ef) and np.array_equal(it1, it) and np.array_equal(act1, act)
+        # device-resident call without the optional outputs
+        th_d = torch.from_numpy(theta).cuda()
+        xd, efd = qp.solve_device(th_d)
+        torch.cuda.synchronize()
+        assert np.array_equal(xd.cpu().numpy(), x) and np.array_equal(efd.cpu().numpy(), ef)
+        if spread == 6.0:
+            assert it.max() >= 3 and (it >= 2).mean() > 0.5, "the hard spread should make most problems iterate"
+
+
+def test_one_launch_kernel_respects_the_solver_guards(lmpc):
+    # an iteration limit or cycle tolerance that could fire inside the straight-line tiers switches them off
+    # (host-side check): flags and iteration counts stay those of the oracle
+    g = load_golden("pendulum")
+    rng = np.random.default_rng(21)
+    N = 5000
+    theta = np.hstack([rng.uniform(-20, 20, (N, 4)), rng.uniform(-20, 20, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    from oracle import ldp as oldp
+    for lim, cyc in ((3, 10), (5, 10), (10000, 2)):
+        s = lmpc.default_settings()
+        s.iter_limit, s.cycle_tol = lim, cyc
+        so = oldp.default_settings()
+        so.iter_limit, so.cycle_tol = lim, cyc
+        qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                      nout=1, settings=s)
+        x, ef, it, act = _compare(qp, theta, settings=so)
+        if lim == 3:
+            assert (ef == -4).any()

@@ -188,3 +188,39 @@ def test_c_client_links_and_runs(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "ok" in out.stdout
+
+
+def test_multi_device_partition(lmpc):
+    # lmpc_multi_partition: contiguous shards, remainder on the leading devices
+    for N, nd in [(10, 1), (10, 3), (1_000_003, 8), (5, 8), (0, 4)]:
+        off = lmpc.MultiQP.partition(N, nd)
+        assert off[0] == 0 and off[-1] == N and len(off) == nd + 1
+        sizes = np.diff(off)
+        assert sizes.min() >= 0 and sizes.max() - sizes.min() <= 1
+        assert np.all(np.diff(sizes) <= 0)          # the larger shards come first
+    assert lmpc.MultiQP.partition(10, 3) == list(np.cumsum([0] + lmpc.shard_counts(10, 3)))
+
+
+def test_multi_setup_refused_without_gpu(lmpc, has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.MultiQP.from_mpqp(np.eye(2), np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
+                               np.zeros((2, 1)))
+    assert e.value.code == -101
+
+
+def test_nonsymmetric_hessian_and_priorities_are_refused(lmpc):
+    # setup.jl:11-13: is_avi = !is_symmetric and break_points go to DAQP.setup; neither mode is built here
+    H = np.array([[2.0, 0.5], [0.0, 2.0]])
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.transform(H, np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2), np.zeros((2, 1)))
+    assert e.value.code == -103
+    q = lmpc.MPQP(np.eye(2), np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
+                  np.zeros((2, 1)), np.zeros(2, np.int32), break_points=np.array([1, 2], np.int32))
+    with pytest.raises(NotImplementedError, match="break_points"):
+        lmpc.MPC(q, nx=1, nu=1).setup()
+    q2 = lmpc.MPQP(H, np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
+                   np.zeros((2, 1)), np.zeros(2, np.int32), is_symmetric=False)
+    with pytest.raises(NotImplementedError, match="is_symmetric"):
+        lmpc.MPC(q2, nx=1, nu=1).setup()
