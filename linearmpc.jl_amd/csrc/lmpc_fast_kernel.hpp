@@ -104,13 +104,17 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         }
     };
 
+    // Roles rotate with the workgroup index: a workgroup's wavefronts sit on the four SIMDs of its CU in order,
+    // and with a fixed role all dedicated solving wavefronts of a CU -- the VALU-heavy ones -- would share ONE
+    // SIMD while the other three only stream.
+    const int role = (wv + (int)(blockIdx.x & 3)) & 3;
     // ------------------------------------------------------------------ producer: stream this wavefront's tiles
-    if (wv < nstr) {
+    if (role < nstr) {
         // the record of this wavefront's next tile is in flight while the current one is screened (a second
         // tile in flight changed nothing: the stream runs at the HBM rate, 14 us for the 68 MB of the headline
         // batch with nine streaming wavefronts per CU; tools/fast_trace.py)
         double nx[NT];
-        long long tile = t0 + wv;
+        long long tile = t0 + role;
         if (tile < t1) load_record(tile * 64 + lane, nx);
         for (; tile < t1; tile += nstr) {
             const long long pid = tile * 64 + lane;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         if (n == -2 && lane == 0 && errflag) *errflag = 1;
         if (n < 0) break;
 #ifdef LMPC_FAST_TRACE
-        if (npass < 3) LMPC_TRC(2 + npass);
+        if (npass < 2) LMPC_TRC(2 + npass);
         npass++;
 #endif
         const bool mine = lane < n;
@@ -215,11 +219,17 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
 #pragma unroll
             for (int t = 0; t < NT; t++) sh0 = __builtin_fma(xk[t], th0[t], sh0);
         }
+#ifdef LMPC_FAST_TRACE
+        if (npass == 1) { if (lane == 0) trc[4] = (long long)(b[0] != 12345.678 ? wall_clock64() : 0); }
+#endif
         int iter = 1, nact = 0, wrow[KMAX], flag = EXIT_ITERLIMIT;
         bool wlow[KMAX];
         unsigned long long act = 0ull, low = 0ull;
         const int res = fast_tiers<N, KMAX>(P, sM, sG, sdu, sdl, mine, b, u, iter, wrow, wlow, nact);
         bool solved = res == EXIT_OPTIMAL;
+#ifdef LMPC_FAST_TRACE
+        if (npass == 1) { if (lane == 0) trc[5] = (long long)(res != 77 ? wall_clock64() : 0); }
+#endif
         if (solved) {
             flag = EXIT_OPTIMAL;
 #pragma unroll

@@ -38,13 +38,18 @@ __host__ __device__ constexpr int lmpc_tri(int i) { return i * (i + 1) / 2; }
 __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2 + t; }
 
 // straight-line tiers on one problem per lane (`mine`: this lane holds a problem).  Returns EXIT_OPTIMAL or
-// 0 = not finished here (the generic kernel takes it).  On success u, iter and the working set (wrow / wlow,
+// 0 = not finished here (the generic loop takes it).  On success u, iter and the working set (wrow / wlow,
 // nact rows) are set.
+// Written WITHOUT per-lane branches: every lane computes every tier (until no lane of the wavefront is running
+// any more -- a uniform branch), a lane that has finished or dropped out computes values nobody reads, and
+// results are committed by selects.  (With `if (running) { ... }` blocks the compiler built nested exec-mask
+// regions: 150 branches, saved masks spilling out of the scalar registers through v_writelane / v_readlane,
+// 1000 moves -- a tier pass of 1500 instructions took 5 us on its own.)
 template <int N, int KMAX>
 __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM, const double *sG, const double *sdu,
                                           const double *sdl, const bool mine, const double (&b)[N], double (&u)[N],
                                           int &iter, int (&wrow)[KMAX], bool (&wlow)[KMAX], int &nact) {
-    const double ptol = P.primal_tol;
+    const double ptol = P.primal_tol, dtol = P.dual_tol, ztol = P.zero_tol, fbound = P.fval_bound;
     // ---- iteration 1 (empty working set, u = 0): the most violated row, as lane_loop's scan finds it
     double min_val = -ptol;
     int add = -1;
@@ -53,55 +58,57 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
     for (int j = 0; j < N; j++) {
         const double vu = (sdu[j] + b[j]) - 0.0;
         const double vl = -((sdl[j] + b[j]) - 0.0);
-        if (vu < min_val) { add = j; addlow = false; min_val = vu; }
-        else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
+        const bool tu = vu < min_val;
+        const bool tl = !tu && (vl < min_val);
+        add = (tu || tl) ? j : add;
+        addlow = tu ? false : (tl ? true : addlow);
+        min_val = tu ? vu : (tl ? vl : min_val);
     }
     double SL[KMAX * (KMAX - 1) / 2 > 0 ? KMAX * (KMAX - 1) / 2 : 1], D[KMAX], Dinv[KMAX], rhs[KMAX], ls[KMAX];
 #pragma unroll
     for (int i = 0; i < KMAX; i++) { D[i] = 0.0; Dinv[i] = 0.0; rhs[i] = 0.0; ls[i] = 0.0; wrow[i] = 0; wlow[i] = false; }
-    double fval = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; c++) u[c] = 0.0;
     int result = 0;
     bool running = mine && add >= 0;       // (a queued problem always has a violated row)
-    if (add < 0) add = 0;
+    iter = 1; nact = 0;
 #pragma unroll
     for (int k = 0; k < KMAX; k++) {
         // ---- append row `add` at position k (lane_loop's ldl_add with na = k)
-        if (running) {
-            const int j = add;
-            double row[KMAX > 1 ? KMAX - 1 : 1];
+        const int j = add < 0 ? 0 : add;
+        double row[KMAX > 1 ? KMAX - 1 : 1];
 #pragma unroll
-            for (int t = 0; t < k; t++) {
-                const int a = wrow[t];
-                row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
-            }
-            double dnew = sG[lmpc_tri(j) + j];
-#pragma unroll
-            for (int i = 1; i < k; i++) {
-                double acc = row[i];
-#pragma unroll
-                for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], row[t], acc);
-                row[i] = acc;
-            }
-#pragma unroll
-            for (int i = 0; i < k; i++) {
-                const double q = row[i];
-                const double l = q * Dinv[i];
-                row[i] = l;
-                dnew = __builtin_fma(-l, q, dnew);
-            }
-            if (dnew < P.zero_tol) running = false;            // singular working set: generic kernel
-            double bj = 0.0;
-#pragma unroll
-            for (int q = 0; q < N; q++) bj = (q == j) ? b[q] : bj;
-            wrow[k] = j; wlow[k] = addlow;
-            rhs[k] = addlow ? -(sdl[j] + bj) : -(sdu[j] + bj);
-            D[k] = dnew; Dinv[k] = 1.0 / dnew;
-#pragma unroll
-            for (int t = 0; t < k; t++) SL[lmpc_sl(k, t)] = row[t];
+        for (int t = 0; t < k; t++) {
+            const int a = wrow[t];
+            row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
         }
+        double dnew = sG[lmpc_tri(j) + j];
+#pragma unroll
+        for (int i = 1; i < k; i++) {
+            double acc = row[i];
+#pragma unroll
+            for (int t = 0; t < i; t++) acc = __builtin_fma(-SL[lmpc_sl(i, t)], row[t], acc);
+            row[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) {
+            const double q = row[i];
+            const double l = q * Dinv[i];
+            row[i] = l;
+            dnew = __builtin_fma(-l, q, dnew);
+        }
+        running = running && !(dnew < ztol);                   // singular working set: generic loop
+        double bsel = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; q++) bsel = (q == j) ? b[q] : bsel;
+        wrow[k] = j; wlow[k] = addlow;
+        rhs[k] = addlow ? -(sdl[j] + bsel) : -(sdu[j] + bsel);
+        D[k] = dnew; Dinv[k] = 1.0 / dnew;
+#pragma unroll
+        for (int t = 0; t < k; t++) SL[lmpc_sl(k, t)] = row[t];
         if (!__any(running)) break;
         // ---- iteration k + 2 on the working set of k + 1 rows
-        // (the rows of M and the bounds are re-read from LDS in every tier: hoisted out of the tile loop they
+        // (the rows of M and the bounds are re-read from LDS in every tier: hoisted out of the caller's loop they
         // would sit in ~70 registers for the whole kernel; the empty asm hides that the addresses repeat)
         int ofs = 0;
         asm volatile("" : "+s"(ofs));
@@ -127,11 +134,11 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
         bool blocked = false;
 #pragma unroll
         for (int i = 0; i < na; i++) {
-            const bool ok = wlow[i] ? (ls[i] < P.dual_tol) : (ls[i] > -P.dual_tol);
+            const bool ok = wlow[i] ? (ls[i] < dtol) : (ls[i] > -dtol);
             blocked = blocked || !ok;
         }
-        if (blocked) running = false;                          // a removal: generic kernel
-        // primal iterate and objective (uu: lanes that finished in an earlier tier keep their u)
+        running = running && !blocked;                         // a removal: generic loop
+        // primal iterate and objective
         double uu[N];
 #pragma unroll
         for (int c = 0; c < N; c++) uu[c] = 0.0;
@@ -141,10 +148,10 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
 #pragma unroll
             for (int c = 0; c < N; c++) uu[c] = __builtin_fma(-mi[c], ls[i], uu[c]);
         }
-        fval = 0.0;
+        double fval = 0.0;
 #pragma unroll
         for (int c = 0; c < N; c++) fval = __builtin_fma(uu[c], uu[c], fval);
-        if (fval > P.fval_bound) running = false;              // EXIT_INFEASIBLE: generic kernel reports it
+        running = running && !(fval > fbound);                 // EXIT_INFEASIBLE: the generic loop reports it
         unsigned actmask = 0u;
 #pragma unroll
         for (int i = 0; i < na; i++) actmask |= 1u << wrow[i];
@@ -153,27 +160,29 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
         addlow = false;
         bool broken = false;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
+        for (int jj = 0; jj < N; jj++) {
             double Mu = 0.0;
-            const double *mrow = sMk + j * N;
+            const double *mrow = sMk + jj * N;
 #pragma unroll
             for (int c = 0; c < N; c++) Mu = __builtin_fma(mrow[c], uu[c], Mu);
-            const double vu = (sduk[j] + b[j]) - Mu;
-            const double vl = -((sdlk[j] + b[j]) - Mu);
-            if (!((actmask >> j) & 1u)) {
-                if (vu < min_val) { add = j; addlow = false; min_val = vu; }
-                else if (vl < min_val) { add = j; addlow = true; min_val = vl; }
-            } else if (vu < -ptol || vl < -ptol) {
-                broken = true;
-            }
+            const double vu = (sduk[jj] + b[jj]) - Mu;
+            const double vl = -((sdlk[jj] + b[jj]) - Mu);
+            const bool inact = !((actmask >> jj) & 1u);
+            const bool tu = inact && (vu < min_val);
+            const bool tl = inact && !tu && (vl < min_val);
+            add = (tu || tl) ? jj : add;
+            addlow = tu ? false : (tl ? true : addlow);
+            min_val = tu ? vu : (tl ? vl : min_val);
+            broken = broken || (!inact && (vu < -ptol || vl < -ptol));
         }
-        if (broken) running = false;                           // EXIT_CYCLE: generic kernel reports it
-        if (running && add < 0) {
-            result = EXIT_OPTIMAL; iter = k + 2; nact = na; running = false;
+        running = running && !broken;                          // EXIT_CYCLE: the generic loop reports it
+        const bool fin = running && add < 0;
+        result = fin ? (int)EXIT_OPTIMAL : result;
+        iter = fin ? k + 2 : iter;
+        nact = fin ? na : nact;
 #pragma unroll
-            for (int c = 0; c < N; c++) u[c] = uu[c];
-        }
-        if (k + 1 == KMAX) running = false;                    // wants a further row: generic kernel
+        for (int c = 0; c < N; c++) u[c] = fin ? uu[c] : u[c];
+        running = running && !fin && (k + 1 < KMAX);           // (wants a further row than KMAX: generic loop)
     }
     return result;
 }

@@ -16,6 +16,8 @@ os.environ["LMPC_FAST_TRACE_FILE"] = "/tmp/fast_trace.bin"
 x, ef = qp.solve_device(ths[0])
 torch.cuda.synchronize()
 t = np.fromfile("/tmp/fast_trace.bin", dtype=np.int64).reshape(-1, 4, 8).astype(np.float64)
+# rows by ROLE (role = (wave + workgroup) & 3; roles 0..2 stream, role 3 solves from the start)
+t = np.stack([np.roll(t[b], b & 3, axis=0) for b in range(t.shape[0])])
 t0 = t[:, :, 0][t[:, :, 0] > 0].min()
 us = lambda a: (a - t0) / 100.0
 print("workgroups", t.shape[0])
@@ -29,3 +31,6 @@ wgend = us(t[:, :, 6]).max(1); wgst = st.min(1)
 print("workgroup life  us: med %.2f max %.2f ; last stream end -> wg end: med %.2f max %.2f" % (np.median(wgend - wgst), (wgend - wgst).max(), np.median(wgend - se.max(1)), (wgend - se.max(1)).max()))
 p2 = t[:, 3, 3]; m2 = p2 > 0
 print("solver wave: claim1 -> claim2 us: med %.2f" % np.median((p2[m2] - t[:, 3, 2][m2]) / 100.0))
+s_ = t[:, 3, :]; ok = (s_[:, 2] > 0) & (s_[:, 4] > 0) & (s_[:, 5] > 0) & (s_[:, 3] > 0)
+print("solver wave, first pass: claim -> records loaded and shifts formed %.2f us, -> tiers done %.2f us, -> next claim %.2f us (medians)" % (
+    np.median((s_[ok, 4] - s_[ok, 2]) / 100.0), np.median((s_[ok, 5] - s_[ok, 4]) / 100.0), np.median((s_[ok, 3] - s_[ok, 5]) / 100.0)))
