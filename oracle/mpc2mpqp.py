@@ -137,23 +137,42 @@ class MPCProblem:
         self.uprev0 = uo.copy()                  # mpc.uprev .= uo
         return self
 
-    def move_block(self, block):
-        """setup.jl:202-248 move_block!: the same block vector for every input; padded or clipped to Np;
-        Nc = (sum of all blocks but the last) + 1."""
+    @staticmethod
+    def _format_move_block(block, Np):
+        """setup.jl:236-248 format_move_block: padded or clipped so that the blocks add up to Np."""
         block = [int(b) for b in block]
+        if not block:
+            return []
         tot = sum(block)
-        if tot < self.Np:
-            block[-1] += self.Np - tot
-        elif tot > self.Np:
+        if tot < Np:
+            block[-1] += Np - tot
+        elif tot > Np:
             acc, i = 0, 0
             while True:
                 acc += block[i]
-                if acc >= self.Np:
+                if acc >= Np:
                     break
                 i += 1
             block = block[:i + 1]
-            block[-1] += self.Np - acc
-        self.move_blocks = [list(block) for _ in range(self.nu)]
+            block[-1] += Np - acc
+        return block
+
+    def move_block(self, block):
+        """setup.jl:202-234 move_block!: nothing / empty -> no blocking (Nc = Np); a number -> constant block
+        size (Np // block + 1 blocks, then clipped); one vector -> the same blocks for every input; a list of
+        vectors -> one per input.  Nc = (largest sum of all blocks but the last) + 1."""
+        if block is None or (not np.isscalar(block) and len(block) == 0):
+            self.move_blocks = []
+            self.Nc = self.Np
+            return self
+        if np.isscalar(block):
+            block = [] if block <= 0 else [int(block)] * (self.Np // int(block) + 1)
+            return self.move_block(block)
+        if np.isscalar(block[0]):
+            block = [list(block) for _ in range(self.nu)]
+        if len(block) != self.nu:
+            raise ValueError("Need to have blocks for every control input")
+        self.move_blocks = [self._format_move_block(mb, self.Np) for mb in block]
         self.Nc = max(sum(mb[:-1]) for mb in self.move_blocks) + 1
         return self
 
@@ -747,6 +766,20 @@ def mass_spring_3in(nm=6, Np=10, Nc=10) -> MPCProblem:
     q.add_constraint(Ax=np.hstack([np.eye(nm), np.zeros((nm, nm))]), lb=-4 * np.ones(nm),
                      ub=4 * np.ones(nm), ks=range(2, Nc + 1))
     return q
+
+
+def aircraft(Np=10, Nc=2) -> MPCProblem:
+    """src/mpc_examples.jl:174-205 `aircraft` (the example the reference's move-blocking test uses,
+    test/runtests.jl:138-176): 4 states, 2 inputs, 2 outputs, |u| <= 0.5, soft bound on the second output."""
+    A = np.array([[-0.0151, -60.5651, 0, -32.174], [-0.0001, -1.3411, 0.9929, 0],
+                  [0.00018, 43.2541, -0.86939, 0], [0, 0, 1, 0]])
+    B = np.array([[-2.516, -13.136], [-0.1689, -0.2514], [-17.251, -1.5766], [0, 0]])
+    C = np.array([[0, 1.0, 0, 0], [0, 0, 0, 1]]) / np.array([[1.0], [200.0]])
+    F, G = zoh(A, B, 0.05)
+    p = make_mpc(F, 50 * G, C, Np=Np, Nc=Nc, Q=[100.0, 100.0], R=[0.0, 0.0], Rr=[0.01, 0.01],
+                 umin=[-0.5, -0.5], umax=[0.5, 0.5], Ts=0.05)
+    p.add_constraint(Ax=C[1:2], lb=[-0.5], ub=[0.5], ks=range(2, Np + 1), soft=True)
+    return p
 
 
 def preprocessing_kat() -> MPCProblem:

@@ -27,6 +27,9 @@ mask.  Before anything is written the answers are cross-checked by independent m
     controller's first move equals the uncondensed preview controller's on the test's trajectory, and
     a constant trajectory condenses to itself.
 
+  * refprev_full_kat: reference preview without condensation (/root/reference/test/runtests.jl:627-667), every
+    fourth answer checked by KKT enumeration.
+
   * dist_preview_kat: disturbance preview (/root/reference/test/runtests.jl:735-774): theta = [x; r; vec(d_traj)];
     a constant trajectory reproduces the non-preview controller's answers to 1e-12.
 
@@ -129,6 +132,10 @@ def main():
     L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
     theta = np.vstack([pendulum_theta(rng, 1536), pendulum_theta(rng, 512, hard=True)])
     theta[0] = omm.form_parameter(prob, [5.0, 5.0, 0.0, 0.0])
+    # up to the 10^4 points SURVEY.md section 8(c) asks for (their own generator: the shared one above feeds
+    # every later fixture, whose points must not move)
+    rng_more = np.random.default_rng(20240)
+    theta = np.vstack([theta, pendulum_theta(rng_more, 6000), pendulum_theta(rng_more, 1952, hard=True)])
     X, ef, it, act = oldp.solve_batch(L, theta)
     assert abs(X[0, 0] - 1.7612519326) < 1e-9, X[0]
     assert np.all(ef == 1)
@@ -298,6 +305,29 @@ def main():
     X, ef, it, act = oldp.solve_batch(L, theta)
     save("satellite20_preview", q, L, theta, X, ef, it, act,
          dict(F=prob.F, G=prob.G, rs=rs, closed_loop_u=np.array(us), closed_loop_y=np.array(ys)))
+
+    # ---- "Codegen Reference Preview - Full" (runtests.jl:627-667): the reference compares Julia with its generated
+    # C to 1e-10 on this controller and this trajectory; here the same controller pins mpQP-setup == LDP-setup ==
+    # oracle, and the generated-controller entry point fed with vec(r_traj)
+    prob = omm.make_mpc([[1, 1], [0, 1]], [[0], [1]], np.eye(2), Np=5, Nc=5, Q=[1.0, 1.0], R=[0.1],
+                        umin=[-2.0], umax=[2.0])
+    prob.reference_preview = True
+    q = omm.mpc2mpqp(prob)
+    assert prob.parameter_dims() == (2, 10, 0, 0, 0)
+    L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=q.n)
+    r_traj = np.array([[0.0, 0.5, 1.0, 1.0, 1.0], [0.0, 0.0, 0.0, 0.0, 0.0]])
+    rngp = np.random.default_rng(627)
+    ths = [omm.form_parameter(prob, [0.0, 0.0], r=r_traj)]
+    assert np.array_equal(ths[0][2:], r_traj.T.reshape(-1))       # theta = [x; vec(r_traj)] (column by column)
+    for _ in range(255):
+        ths.append(omm.form_parameter(prob, rngp.uniform(-3, 3, 2), r=rngp.uniform(-2, 2, (2, 5))))
+    theta = np.array(ths)
+    X, ef, it, act = oldp.solve_batch(L, theta)
+    assert np.all(ef == 1)
+    for i in range(0, 256, 4):
+        xe = kkt_enumerate_box(q, theta[i])
+        assert np.abs(xe - X[i]).max() < 2e-6
+    save("refprev_full_kat", q, L, theta, X, ef, it, act, dict(r_traj=r_traj, u_julia_equals_c=X[0, :1]))
 
     # ---- K5: closed-loop end values the reference's tests assert
     # (a) "x0 uncertainty" runtests.jl:1067-1074: x1 -> 0.4 (1e-6); soft output bounds, tightened

@@ -1580,3 +1580,72 @@ def test_one_launch_kernel_respects_the_solver_guards(lmpc):
         x, ef, it, act = _compare(qp, theta, settings=so)
         if lim == 3:
             assert (ef == -4).any()
+
+
+# ------------------------------------------------------------------ reference-held vectors through the device path
+def test_reference_formatting_vectors_on_the_device(lmpc):
+    """/root/reference/test/runtests.jl:1401-1428, number for number, through lmpc_form_parameter_device: the
+    reference / disturbance block of theta the device forms is the vector the reference's test expects."""
+    import torch
+
+    def handle(nx, ny, nd, Np, rp, dp):
+        nth = nx + ny * (Np if rp else 1) + nd * (Np if dp else 1)
+        return lmpc.BatchedQP.from_mpqp(np.eye(1), np.zeros(1), np.zeros((1, nth)), np.zeros((0, 1)), np.ones(1),
+                                        -np.ones(1), np.zeros((1, nth)), nout=1)
+
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, float))).cuda()
+    x2 = cu(np.array([[0.25, -0.5], [1.0, 2.0], [3.0, 4.0]]))
+    qp = handle(2, 2, 0, 4, True, False)
+    for r, want in (([1.0, 2.0], np.tile([1.0, 2.0], 4)),                                                      # :1406
+                    ([[1.0, 2, 3, 4, 5], [10.0, 20, 30, 40, 50]], [1.0, 10.0, 2.0, 20.0, 3.0, 30.0, 4.0, 40.0]),  # :1407
+                    ([[1.0, 2.0], [10.0, 20.0]], [1.0, 10.0, 2.0, 20.0, 2.0, 20.0, 2.0, 20.0])):                # :1409
+        th = qp.form_parameter_device(x2, r=cu(r), r_preview=4)
+        torch.cuda.synchronize()
+        assert np.array_equal(th.cpu().numpy(), np.hstack([x2.cpu().numpy(), np.tile(want, (3, 1))]))
+    plain = handle(2, 2, 0, 4, False, False)
+    th = plain.form_parameter_device(x2, r=cu([[7.0, 8.0, 9.0], [1.0, 2.0, 3.0]]))                              # :1416
+    torch.cuda.synchronize()
+    assert np.array_equal(th.cpu().numpy()[:, 2:], np.tile([7.0, 1.0], (3, 1)))
+    x1 = cu(np.array([[0.5], [1.5]]))
+    dq = handle(1, 1, 1, 4, False, True)
+    r0 = cu([0.0])
+    for d, want in (([3.0], [3.0, 3.0, 3.0, 3.0]), ([[1.0, 2.0]], [1.0, 2.0, 2.0, 2.0])):                       # :1421-1422
+        th = dq.form_parameter_device(x1, r=r0, d=cu(d), d_preview=4)
+        torch.cuda.synchronize()
+        assert np.array_equal(th.cpu().numpy()[:, 2:], np.tile(want, (2, 1)))
+    dplain = handle(1, 1, 1, 4, False, False)
+    th = dplain.form_parameter_device(x1, r=r0, d=cu([[7.0, 8.0, 9.0]]))                                       # :1427
+    torch.cuda.synchronize()
+    assert np.array_equal(th.cpu().numpy()[:, 2:], np.tile([7.0], (2, 1)))
+    # a block of the wrong width is refused (the reference throws, :1411-1413 / :1423-1424)
+    with pytest.raises(lmpc.LmpcError):
+        qp.form_parameter_device(x2, r=cu([1.0]), r_preview=4)
+    with pytest.raises(lmpc.LmpcError):
+        dq.form_parameter_device(x1, r=r0, d=cu(np.ones((2, 2))), d_preview=4)
+
+
+def test_reference_preview_controller_three_ways(lmpc):
+    """/root/reference/test/runtests.jl:627-667 "Codegen Reference Preview - Full": the reference asserts that
+    its Julia path and its generated C agree to 1e-10 on this controller and this trajectory.  Here the same
+    controller through (a) lmpc_setup on the mpQP, (b) lmpc_setup_ldp on the arrays the generator would write
+    (the oracle's numpy transform), (c) the oracle itself -- and (d) the generated controller's entry point fed
+    with the trajectory exactly as the reference's ccall passes it (r_traj, column by column)."""
+    from oracle import ldp as oldp
+    g = load_golden("refprev_full_kat")
+    theta = g["theta"]
+    qa = _qp_from_golden(lmpc, g, 1)
+    xa, efa, ita, acta = _compare(qa, theta)                       # (a) vs (c) on the library's own pack
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+    qb = lmpc.BatchedQP.from_ldp(L.M, L.du0, L.dl0, L.Dth, L.Rout, L.x0, L.Xth, L.sense, ms=L.ms)
+    xb, efb, itb, actb = _compare(qb, theta)                       # (b) vs (c) on the numpy pack
+    assert np.array_equal(efa, efb) and np.array_equal(acta, actb)
+    assert np.abs(xa - xb).max() < 1e-10                           # the bar the reference's test sets
+    assert np.abs(xa[:, 0] - g["X"][:, 0]).max() < 1e-10           # ... and the committed answers
+    assert abs(xa[0, 0] - g["u_julia_equals_c"][0]) < 1e-10
+    # (d) mpc_compute_control(u, x, r_traj, d) as at runtests.jl:659
+    qa.set_parameter_layout(2, 10, 0, 0, 0)
+    N = theta.shape[0]
+    ctrl = np.zeros((N, 1))
+    ef = qa.compute_control(ctrl, theta[:, :2].copy(), reference=theta[:, 2:].copy())
+    assert np.array_equal(ef, efa) and np.array_equal(ctrl, xa)
+    assert np.array_equal(theta[0, 2:], g["r_traj"].T.reshape(-1))

@@ -224,3 +224,102 @@ def test_nonsymmetric_hessian_and_priorities_are_refused(lmpc):
                    np.zeros((2, 1)), np.zeros(2, np.int32), is_symmetric=False)
     with pytest.raises(NotImplementedError, match="is_symmetric"):
         lmpc.MPC(q2, nx=1, nu=1).setup()
+
+
+# ------------------------------------------------------------------ reference-held vectors, verbatim
+def _fmt_mpc(lmpc, nx, ny, nd, Np, rp=False, dp=False):
+    nr = ny * (Np if rp else 1)
+    ndd = nd * (Np if dp else 1)
+    nth = nx + nr + ndd
+    q = lmpc.MPQP(np.eye(1), np.zeros(1), np.zeros((1, nth)), np.zeros((0, 1)), np.ones(1), -np.ones(1),
+                  np.zeros((1, nth)), np.zeros(1, np.int32))
+    return lmpc.MPC(q, nx=nx, nu=1, nr=nr, nd=ndd, Np=Np, reference_preview=rp, disturbance_preview=dp)
+
+
+def test_reference_formatting_vectors_verbatim(lmpc):
+    """/root/reference/test/runtests.jl:1401-1428 "Reference and disturbance formatting helpers", number for
+    number: MPC([1 1; 0 1], [0; 1]; C = I, Np = 4), then the scalar plant with Gd = 1."""
+    mpc = _fmt_mpc(lmpc, 2, 2, 0, 4, rp=True)
+    assert np.allclose(mpc.format_reference([1.0, 2.0]), np.tile([1.0, 2.0], 4))                               # :1406
+    assert np.allclose(mpc.format_reference(np.array([[1.0, 2, 3, 4, 5], [10.0, 20, 30, 40, 50]])),
+                       [1.0, 10.0, 2.0, 20.0, 3.0, 30.0, 4.0, 40.0])                                          # :1407-1408
+    assert np.allclose(mpc.format_reference(np.array([[1.0, 2.0], [10.0, 20.0]])),
+                       [1.0, 10.0, 2.0, 20.0, 2.0, 20.0, 2.0, 20.0])                                          # :1409-1410
+    for bad in ([1.0], np.ones((1, 2)), 1.0):                                                                 # :1411-1413
+        with pytest.raises(ValueError):
+            mpc.format_reference(bad)
+    plain = _fmt_mpc(lmpc, 2, 2, 0, 4, rp=False)
+    assert np.allclose(plain.format_reference(np.array([[7.0, 8.0, 9.0], [1.0, 2.0, 3.0]])), [7.0, 1.0])      # :1415-1416
+    dmpc = _fmt_mpc(lmpc, 1, 1, 1, 4, dp=True)
+    assert np.allclose(dmpc.format_disturbance([3.0]), [3.0, 3.0, 3.0, 3.0])                                   # :1421
+    assert np.allclose(dmpc.format_disturbance(np.array([[1.0, 2.0]])), [1.0, 2.0, 2.0, 2.0])                  # :1422
+    for bad in ([1.0, 2.0], np.ones((2, 2))):                                                                  # :1423-1424
+        with pytest.raises(ValueError):
+            dmpc.format_disturbance(bad)
+    dplain = _fmt_mpc(lmpc, 1, 1, 1, 4, dp=False)
+    assert np.allclose(dplain.format_disturbance(np.array([[7.0, 8.0, 9.0]])), [7.0])                          # :1427
+
+
+def test_reference_parameter_dims_verbatim():
+    """get_parameter_dims as the reference's tests assert it: runtests.jl:253-257 (reference preview),
+    :370-374 (disturbance preview), :1147-1150 (generalised parameter preview with its formatting)."""
+    from oracle import mpc2mpqp as omm
+    F, G = omm.zoh(np.array([[0.0, 1.0], [10.0, 0.0]]), np.array([[0.0], [1.0]]), 0.1)
+    p = omm.make_mpc(F, G, np.eye(2), Np=5, Nc=3, Q=[1.0, 1.0], R=[0.1], Rr=[0.1], umin=[-20.0], umax=[20.0], Ts=0.1)
+    p.reference_preview = True
+    assert p.parameter_dims()[:4] == (2, 2 * 5, 0, 1)                                                          # :253-257
+    assert omm.mpc2mpqp(p).nth == 2 + 10 + 1
+    p = omm.make_mpc([[1.0, 1.0], [0.0, 1.0]], [[0.0], [1.0]], [[1.0, 0.0]], Np=5, Nc=5, Q=[10.0], R=[0.1],
+                     umin=[-0.5], umax=[0.5], Gd=[[0.0], [1.0]])
+    p.disturbance_preview = True
+    assert p.parameter_dims()[:4] == (2, 1, 5, 0)                                                              # :370-374
+    assert omm.mpc2mpqp(p).nth == 8
+    p = omm.make_mpc([[1, 1], [0, 1]], [[0], [1]], np.eye(2), Np=5, Nc=3, Q=[1.0, 1.0], R=[0.1], umin=[-2.0], umax=[2.0])
+    p.Eu = np.array([[1.0]])
+    p.parameter_preview = True
+    assert p.parameter_dims() == (2, 2, 0, 0, 5)                                                               # :1147-1148
+    th = omm.form_parameter(p, [0.0, 0.0], par=np.array([0.25]))
+    assert np.array_equal(th[4:], np.full(5, 0.25))                                                            # :1149
+    th = omm.form_parameter(p, [0.0, 0.0], par=np.array([[0.25, 0.5]]))
+    assert np.array_equal(th[4:], [0.25, 0.5, 0.5, 0.5, 0.5])                                                  # :1150
+
+
+def test_reference_move_block_structure_verbatim():
+    """/root/reference/test/runtests.jl:138-176 "Move blocking" on the `aircraft` example (Np = 10, two inputs):
+    the padded / clipped / per-input block vectors and the number of decision variables."""
+    from oracle import mpc2mpqp as omm
+    p = omm.aircraft(10)
+    p.move_block([])
+    assert len(omm.mpc2mpqp(p).f) == 10 * p.nu                                                                 # :144-146
+    p.move_block([1, 1, 2, 3, 3])
+    assert len(omm.mpc2mpqp(p).f) == 5 * p.nu                                                                  # :148-150
+    for arg, want in (([1, 1], [[1, 9], [1, 9]]),                                                              # :153-155 pad
+                      ([2, 3, 3, 6, 8, 9], [[2, 3, 3, 2], [2, 3, 3, 2]]),                                      # :158-160 clip
+                      (2, [[2, 2, 2, 2, 2], [2, 2, 2, 2, 2]]),                                                 # :162-164
+                      (3, [[3, 3, 3, 1], [3, 3, 3, 1]]),                                                       # :166-168
+                      ([[1, 2, 3], [4, 2]], [[1, 2, 7], [4, 6]]),                                              # :170-172
+                      ([[1, 2, 3, 15, 20], [2]], [[1, 2, 3, 4], [10]])):                                       # :174-176
+        p.move_block(arg)
+        q = omm.mpc2mpqp(p)
+        assert p.move_blocks == want
+        assert len(q.f) == sum(len(mb) for mb in want) and q.H.shape == (len(q.f), len(q.f))
+
+
+def test_marginal_case_report_finds_a_constructed_marginal_point():
+    """oracle.ldp.marginal_report: a parameter point placed 1e-7 inside the boundary where
+    a bound becomes active is counted as primal-marginal; generic points are not."""
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+    th_in = np.zeros(7)                                   # at the origin no bound is active
+    th_out = g["theta"][0]                                # K1: the second move sits on its upper bound
+    lo, hi = 0.0, 1.0
+    for _ in range(80):                                   # bisect for the point where the active set changes
+        mid = 0.5 * (lo + hi)
+        act = oldp.solve_batch(L, (th_in + mid * (th_out - th_in))[None])[3]
+        if act.any():
+            hi = mid
+        else:
+            lo = mid
+    rep = oldp.marginal_report(L, np.vstack([th_in + (lo - 1e-9) * (th_out - th_in), th_in, th_out]))
+    assert rep["primal_marginal"] == 1 and rep["primal_marginal_first"] == [0] and rep["dual_marginal"] == 0
