@@ -14,12 +14,16 @@
 //    sends on its own link).  RCCL is loaded on first use (dlopen), the library has no link-time
 //    dependency on it.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "lmpc_internal.hpp"
@@ -32,13 +36,30 @@ namespace {
 // hipHostRegister pins the pages in place (what the runtime does internally for a large pageable copy,
 // but then the copy call blocks); registered, hipMemcpyAsync returns at once and the stages overlap.
 struct PinScope {
+    std::vector<std::pair<uintptr_t, uintptr_t>> want;      // [begin, end) of the caller's arrays
     std::vector<void *> pinned;
     void pin(const void *p, size_t bytes) {
-        if (!p || bytes == 0) return;
-        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess)
-            pinned.push_back(const_cast<void *>(p));
-        else
-            (void)hipGetLastError();      // already registered by the caller, or not pinnable: copies still work
+        if (p && bytes) want.emplace_back(reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + bytes);
+    }
+    // Pinning works on whole pages, and two of the caller's arrays may share one (exit flags and iteration
+    // counts of a 30 000-problem batch come out of the same malloc arena): registering both would register that
+    // page twice, which the runtime answers with abort().  So: page-round every range, merge what overlaps or
+    // touches, register each merged range once.
+    void commit() {
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        for (auto &r : want) { r.first &= ~(page - 1); r.second = (r.second + page - 1) & ~(page - 1); }
+        std::sort(want.begin(), want.end());
+        std::vector<std::pair<uintptr_t, uintptr_t>> merged;
+        for (auto &r : want) {
+            if (!merged.empty() && r.first <= merged.back().second) merged.back().second = std::max(merged.back().second, r.second);
+            else merged.push_back(r);
+        }
+        want.clear();
+        for (auto &r : merged) {
+            void *p = reinterpret_cast<void *>(r.first);
+            if (hipHostRegister(p, r.second - r.first, hipHostRegisterPortable) == hipSuccess) pinned.push_back(p);
+            else (void)hipGetLastError();     // already registered by the caller, or not pinnable: the copies still work
+        }
     }
     ~PinScope() { for (void *p : pinned) (void)hipHostUnregister(p); }
 };
@@ -193,6 +214,7 @@ void pin_call(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, const v
     pin.pin(iters, sizeof(int32_t) * (size_t)N);
     pin.pin(active, sizeof(uint64_t) * (size_t)N * w);
     pin.pin(warm, sizeof(uint64_t) * (size_t)N * w);
+    pin.commit();
 }
 
 int solve_host(lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag, int32_t *iters,
@@ -272,20 +294,42 @@ int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x
     return solve_host(h, sizeof(float), N, theta, x, exitflag, iters, active, warm, "lmpc_solve_batch_f32");
 }
 
+// ranges pinned through lmpc_pin_host (page-rounded), so that a second request touching the same page is refused
+// instead of reaching the runtime, which aborts on a doubly registered page
+static std::mutex g_pin_mu;
+static std::map<uintptr_t, uintptr_t> g_pins;      // begin -> end
+
 int lmpc_pin_host(void *p, size_t bytes) {
     if (!p || bytes == 0) return LMPC_ERR_BADARG;
-    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
-    if (e == hipSuccess) return LMPC_OK;
-    (void)hipGetLastError();
-    return mfail(nullptr, e == hipErrorNoDevice ? LMPC_ERR_NOGPU : LMPC_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(e));
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
+    const uintptr_t e = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &r : g_pins)
+        if (b < r.second && r.first < e)
+            return mfail(nullptr, LMPC_ERR_BADARG, "lmpc_pin_host: the range shares a page with memory pinned earlier "
+                                                   "(pin each allocation once, or allocate page-aligned)");
+    const hipError_t err = hipHostRegister(reinterpret_cast<void *>(b), e - b, hipHostRegisterPortable);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return mfail(nullptr, err == hipErrorNoDevice ? LMPC_ERR_NOGPU : LMPC_ERR_HIP, std::string("hipHostRegister: ") + hipGetErrorString(err));
+    }
+    g_pins[b] = e;
+    return LMPC_OK;
 }
 
 int lmpc_unpin_host(void *p) {
     if (!p) return LMPC_ERR_BADARG;
-    const hipError_t e = hipHostUnregister(p);
-    if (e == hipSuccess) return LMPC_OK;
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p) & ~(page - 1);
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pins.find(b);
+    if (it == g_pins.end()) return mfail(nullptr, LMPC_ERR_BADARG, "lmpc_unpin_host: not pinned by lmpc_pin_host");
+    const hipError_t err = hipHostUnregister(reinterpret_cast<void *>(b));
+    g_pins.erase(it);
+    if (err == hipSuccess) return LMPC_OK;
     (void)hipGetLastError();
-    return mfail(nullptr, LMPC_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(e));
+    return mfail(nullptr, LMPC_ERR_HIP, std::string("hipHostUnregister: ") + hipGetErrorString(err));
 }
 
 void lmpc_multi_partition(int64_t N, int n_devices, int64_t *offsets) {
