@@ -32,6 +32,11 @@ using namespace lmpc;
 
 namespace {
 
+// ranges pinned through lmpc_pin_host (page-rounded): a second registration that touches one of their pages must
+// not reach the runtime, which aborts on a doubly registered page
+std::mutex g_pin_mu;
+std::map<uintptr_t, uintptr_t> g_pins;      // begin -> end
+
 // ---------------------------------------------------------------- pinned view of the caller's arrays
 // hipHostRegister pins the pages in place (what the runtime does internally for a large pageable copy,
 // but then the copy call blocks); registered, hipMemcpyAsync returns at once and the stages overlap.
@@ -55,7 +60,11 @@ struct PinScope {
             else merged.push_back(r);
         }
         want.clear();
+        std::lock_guard<std::mutex> lk(g_pin_mu);
         for (auto &r : merged) {
+            bool user_pinned = false;            // (pinned by the caller through lmpc_pin_host: nothing to do)
+            for (auto &u : g_pins) user_pinned = user_pinned || (r.first < u.second && u.first < r.second);
+            if (user_pinned) continue;
             void *p = reinterpret_cast<void *>(r.first);
             if (hipHostRegister(p, r.second - r.first, hipHostRegisterPortable) == hipSuccess) pinned.push_back(p);
             else (void)hipGetLastError();     // already registered by the caller, or not pinnable: the copies still work
@@ -293,11 +302,6 @@ int lmpc_solve_batch_f32(lmpc_handle *h, int64_t N, const float *theta, float *x
                          int32_t *iters, uint64_t *active, const uint64_t *warm) {
     return solve_host(h, sizeof(float), N, theta, x, exitflag, iters, active, warm, "lmpc_solve_batch_f32");
 }
-
-// ranges pinned through lmpc_pin_host (page-rounded), so that a second request touching the same page is refused
-// instead of reaching the runtime, which aborts on a doubly registered page
-static std::mutex g_pin_mu;
-static std::map<uintptr_t, uintptr_t> g_pins;      // begin -> end
 
 int lmpc_pin_host(void *p, size_t bytes) {
     if (!p || bytes == 0) return LMPC_ERR_BADARG;

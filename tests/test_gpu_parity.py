@@ -1649,3 +1649,28 @@ def test_reference_preview_controller_three_ways(lmpc):
     ef = qa.compute_control(ctrl, theta[:, :2].copy(), reference=theta[:, 2:].copy())
     assert np.array_equal(ef, efa) and np.array_equal(ctrl, xa)
     assert np.array_equal(theta[0, 2:], g["r_traj"].T.reshape(-1))
+
+
+def test_caller_pinned_arrays(lmpc):
+    # lmpc_pin_host: a caller that reuses its arrays pins them once; the host pipeline then leaves them alone,
+    # a second pin of the same pages is refused (the runtime would abort on a doubly registered page)
+    import ctypes
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    L = lmpc.lib()
+    rng = np.random.default_rng(31)
+    N = 300_000
+    theta = np.ascontiguousarray(np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)),
+                                            rng.uniform(-2, 2, (N, 1))]))
+    x = np.zeros((N, 1)); ef = np.zeros(N, np.int32)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    x_ref, ef_ref, _, _ = qp.solve(theta, want_iters=False, want_active=False)
+    for a_ in (theta, x, ef):
+        assert L.lmpc_pin_host(vp(a_), a_.nbytes) == 1
+    assert L.lmpc_pin_host(vp(theta), 4096) == -100            # same pages again
+    for _ in range(3):
+        assert L.lmpc_solve_batch(qp._h, N, vp(theta), vp(x), vp(ef), None, None, None) == 1
+        assert np.array_equal(x, x_ref) and np.array_equal(ef, ef_ref)
+    for a_ in (theta, x, ef):
+        assert L.lmpc_unpin_host(vp(a_)) == 1
+    assert L.lmpc_unpin_host(vp(theta)) == -100
