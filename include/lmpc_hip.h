@@ -140,10 +140,14 @@ int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
  *   active    N records of lmpc_active_words words (out) or NULL
  *   warm      N records of the same layout: initial working sets (in) or NULL = cold
  *
- * lmpc_solve_batch: HOST pointers; synchronous.  The batch moves through a three-stage pipeline in chunks
- * (each half of what is left, the last one "host_chunk" problems, default 32768): H2D copy of chunk k+1,
- * kernels of chunk k, D2H copy of chunk k-1 on three streams, the caller's arrays pinned in place for the duration of the call
- * (hipHostRegister; "host_register" 0 switches that off), so PCIe runs in both directions at once.
+ * lmpc_solve_batch: HOST pointers; synchronous.  Large batches move through a three-stage pipeline in chunks
+ * (each half of what is left, the last one "host_chunk" problems): H2D copy of chunk k+1, kernels of chunk k,
+ * D2H copy of chunk k-1 on three streams.  With arrays the caller pinned (lmpc_pin_host) every copy is
+ * asynchronous and one thread drives the pipeline (1.17 ms per 10^6 pendulum problems, PCIe-bound: 56 MB in at
+ * 52 GB/s); with pageable arrays, whose copy calls block, the upload and download sides run on two host threads
+ * ("host_threads" 0: one chunk, one thread; 1.25 against 1.30 ms).  "host_register" 1 pins the caller's arrays
+ * for the duration of each call instead -- not the default: registering ordinary heap memory call after call
+ * ended in a GPU memory fault on this runtime after a few hundred calls in one process.
  * lmpc_solve_batch_device: DEVICE pointers on the handle's GPU; enqueues the kernels on
  * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns without
  * synchronising -- this is what bench.py times with inputs resident in HBM.
@@ -164,7 +168,7 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
  * sense at that precision (lmpc_default_settings_f32: primal 1e-4, dual 1e-6, zero 1e-6,
  * progress 1e-4, rho_soft 1e-3; libdaqp's own single-precision defaults live in a header that is
  * not part of the reference tree).  Runs on the wavefront kernel (any handle whose problem it covers:
- * n <= 63, 1 <= m <= 1024), including branch and bound over BINARY rows
+ * n <= 127, 1 <= m <= 1024), including branch and bound over BINARY rows (n <= 64)
  * (BASELINE config 5); LMPC_ERR_UNSUPPORTED otherwise.
  */
 void lmpc_default_settings_f32(lmpc_settings *s);
@@ -176,9 +180,10 @@ int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, f
                                 const uint64_t *warm, void *stream);
 
 /* A caller that reuses its Theta / X / exitflag arrays from call to call (a Monte-Carlo loop, a closed
- * loop over many scenarios) can pin them ONCE: lmpc_solve_batch* then finds them pinned and skips its own
- * per-call hipHostRegister / hipHostUnregister (~0.1 ms per 10^6 pendulum problems).  Unpin before the
- * memory is freed. */
+ * loop over many scenarios) can pin them ONCE: lmpc_solve_batch* then runs fully asynchronous copies on them.
+ * Pinning works on whole pages: give every array pages of its own (a page-aligned allocation, e.g. mmap /
+ * posix_memalign; Julia: Mmap.mmap(Matrix{Float64}, dims)) -- a range that shares a page with memory pinned
+ * earlier is refused with LMPC_ERR_BADARG.  Unpin before the memory is freed. */
 int lmpc_pin_host(void *p, size_t bytes);
 int lmpc_unpin_host(void *p);
 

@@ -88,6 +88,8 @@ int finalize_handle(lmpc_handle *h) {
     h->bnb = anyBinary;
     if (nBinary > 64)    // the B&B stack of a problem lives on the 64 lanes of its wavefront
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: more than 64 binary rows");
+    if (anyBinary && P.n > 64)
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: branch and bound covers n <= 64 variables");
     const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0 && !anyBinary;
     // working-set capacity: n hard rows + 1 (the row that makes it singular) + the soft rows, but never
     // more than the 64 lanes; a problem that wants more rows at once ends with exit flag -7
@@ -96,7 +98,7 @@ int finalize_handle(lmpc_handle *h) {
     if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,
                     "lmpc: problem outside what the kernels cover (lane: n<=12, m<=64, hard rows; "
-                    "wave: n<=63, 1<=m<=1024)");
+                    "wave: n<=127, 1<=m<=1024)");
     // Which kernel by default when both cover the problem: the lane kernels (one QP per lane, screening
     // pass in front) are 5-10x faster on box-constrained problems of every size they are built for, but a
     // lane scans all m rows of general constraints by itself every iteration -- from about m*n = 600 on
@@ -260,7 +262,7 @@ int ensure_f32(lmpc_handle *h) {
     if (h->dCwf) return LMPC_OK;
     if (!h->dCw)
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: the binary32 path runs on the wavefront kernel, which does not "
-                                             "cover this problem (n <= 63, 1 <= m <= 1024)");
+                                             "cover this problem (n <= 127, 1 <= m <= 1024)");
     const HostPack &P = h->P;
     const WaveLayout &Wl = h->W;
     const size_t total = (size_t)Wl.oXth + (size_t)P.nout * P.nth;
@@ -1259,6 +1261,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
     if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "host_threads") == 0) { h->hostThreads = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }

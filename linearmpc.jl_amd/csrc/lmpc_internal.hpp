@@ -19,7 +19,7 @@ constexpr int kLaneSizes[] = {2, 3, 4, 5, 6, 8, 10, 12};
 constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
-constexpr int kWaveMaxN = 63, kWaveMaxCap = 64, kWaveMaxM = 1024;
+constexpr int kWaveMaxN = 127, kWaveMaxCap = 64, kWaveMaxM = 1024;
 constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
 struct EventTriple { hipEvent_t a, mid, b; };
@@ -43,7 +43,8 @@ struct lmpc_handle {
     hipStream_t sUp = nullptr, sRun = nullptr, sDown = nullptr;
     std::vector<hipEvent_t> pipeEv;
     int hostChunk = 32768;      // tuning: smallest (= last) chunk of the pipeline's schedule ("host_chunk")
-    int hostRegister = 1;       // tuning: pin the caller's arrays in place for the call ("host_register")
+    int hostRegister = 0;       // tuning: pin the caller's arrays in place for the call ("host_register"; see lmpc_multi.hip)
+    int hostThreads = 1;        // tuning: pageable arrays: upload and download sides on separate host threads ("host_threads")
     // work list of the problems the screening pass leaves for the iterating kernel
     int32_t *dList = nullptr, *dCount = nullptr;
     int32_t *dList2 = nullptr, *dList3 = nullptr;          // second work list of the scenario-asynchronous closed loop (lists alternate per round)

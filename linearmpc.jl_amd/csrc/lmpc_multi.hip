@@ -19,6 +19,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -145,13 +147,33 @@ std::vector<int64_t> chunk_offsets(int64_t N, int64_t smallest) {
     return off;
 }
 
-// All jobs advance chunk by chunk from ONE host thread: after pinning every call below only enqueues.
-int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh) {
+// is [p, p + bytes) inside memory the caller pinned through lmpc_pin_host?
+bool caller_pinned(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return true;
+    const uintptr_t b = reinterpret_cast<uintptr_t>(p), e = b + bytes;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto &r : g_pins)
+        if (r.first <= b && e <= r.second) return true;
+    return false;
+}
+
+// How the chunks of all jobs are driven:
+//   ASYNC     every array of the call is pinned (by the caller through lmpc_pin_host, or for this call with
+//             "host_register"): hipMemcpyAsync returns at once, ONE thread enqueues everything;
+//   THREADED  pageable arrays: a copy call blocks until its bytes have moved, so the upload side (H2D copy +
+//             kernel launches, one thread per device) and the download side (D2H copies, the calling thread) run
+//             on separate host threads -- PCIe is busy in both directions although every single call blocks;
+//   SINGLE    small calls: one chunk, one thread, no pipeline.
+enum class HostMode { ASYNC, THREADED, SINGLE };
+
+int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh, HostMode mode) {
     int64_t maxN = 0;
     for (auto &j : jobs) maxN = std::max(maxN, j.N);
     if (maxN == 0) return LMPC_OK;
     lmpc_handle *h0 = jobs[0].h;
-    const int64_t smallest = std::max<int64_t>(1024, h0->hostChunk);
+    // (pageable copies pay a pin / unpin inside the runtime per call: fewer, larger chunks -- measured best at 65536)
+    const int64_t smallest = mode == HostMode::SINGLE ? maxN
+                           : std::max<int64_t>(mode == HostMode::THREADED ? 65536 : 1024, h0->hostChunk);
     std::vector<std::vector<int64_t>> sched;
     int64_t nchunks = 0;
     for (auto &j : jobs) {
@@ -166,39 +188,77 @@ int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh) {
         if (rc == LMPC_OK) rc = ensure_pipe(j.h, (size_t)(2 * nchunks));
         if (rc != LMPC_OK) { if (errh != j.h) errh->err = j.h->err; return rc; }
     }
+    // upload side of chunk c of job ji: H2D copies, then the kernels behind them
+    auto upload = [&](size_t ji, int64_t c) -> int {
+        HostJob &j = jobs[ji];
+        lmpc_handle *h = j.h;
+        const int64_t off = sched[ji][c], n = sched[ji][c + 1] - off;
+        const size_t nth = (size_t)h->P.nth, w = (size_t)h->P.words();
+        DeviceScope sc;
+        HIP_TRY(h, sc.enter(h->device));
+        hipEvent_t evUp = h->pipeEv[2 * c], evRun = h->pipeEv[2 * c + 1];
+        if (nth > 0)
+            HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char *>(h->sTheta) + rs * off * nth, j.theta + rs * off * nth,
+                                      rs * n * nth, hipMemcpyHostToDevice, h->sUp));
+        if (j.warm)
+            HIP_TRY(h, hipMemcpyAsync(h->sWarm + off * w, j.warm + off * w, sizeof(uint64_t) * n * w,
+                                      hipMemcpyHostToDevice, h->sUp));
+        HIP_TRY(h, hipEventRecord(evUp, h->sUp));
+        HIP_TRY(h, hipStreamWaitEvent(h->sRun, evUp, 0));
+        const int rc = launch_chunk(h, rs, n, off, j.warm != nullptr);
+        if (rc != LMPC_OK) return rc;
+        HIP_TRY(h, hipEventRecord(evRun, h->sRun));
+        return LMPC_OK;
+    };
+    // download side: D2H copies behind the chunk's kernels
+    auto download = [&](size_t ji, int64_t c) -> int {
+        HostJob &j = jobs[ji];
+        lmpc_handle *h = j.h;
+        const int64_t off = sched[ji][c], n = sched[ji][c + 1] - off;
+        const size_t nout = (size_t)h->P.nout, w = (size_t)h->P.words();
+        DeviceScope sc;
+        HIP_TRY(h, sc.enter(h->device));
+        HIP_TRY(h, hipStreamWaitEvent(h->sDown, h->pipeEv[2 * c + 1], 0));
+        HIP_TRY(h, hipMemcpyAsync(j.x + rs * off * nout, reinterpret_cast<char *>(h->sX) + rs * off * nout,
+                                  rs * n * nout, hipMemcpyDeviceToHost, h->sDown));
+        HIP_TRY(h, hipMemcpyAsync(j.flag + off, h->sFlag + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
+        if (j.iters)
+            HIP_TRY(h, hipMemcpyAsync(j.iters + off, h->sIter + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
+        if (j.active)
+            HIP_TRY(h, hipMemcpyAsync(j.active + off * w, h->sAct + off * w, sizeof(uint64_t) * n * w,
+                                      hipMemcpyDeviceToHost, h->sDown));
+        return LMPC_OK;
+    };
+    auto has = [&](size_t ji, int64_t c) { return c + 1 < (int64_t)sched[ji].size(); };
     int rc = LMPC_OK;
-    for (int64_t c = 0; c < nchunks && rc == LMPC_OK; c++) {
-        for (size_t ji = 0; ji < jobs.size(); ji++) {
-            HostJob &j = jobs[ji];
-            if (c + 1 >= (int64_t)sched[ji].size()) continue;
-            lmpc_handle *h = j.h;
-            const int64_t off = sched[ji][c], n = sched[ji][c + 1] - off;
-            const size_t nth = (size_t)h->P.nth, nout = (size_t)h->P.nout, w = (size_t)h->P.words();
-            DeviceScope sc;
-            HIP_TRY(h, sc.enter(h->device));
-            hipEvent_t evUp = h->pipeEv[2 * c], evRun = h->pipeEv[2 * c + 1];
-            if (nth > 0)
-                HIP_TRY(h, hipMemcpyAsync(reinterpret_cast<char *>(h->sTheta) + rs * off * nth, j.theta + rs * off * nth,
-                                          rs * n * nth, hipMemcpyHostToDevice, h->sUp));
-            if (j.warm)
-                HIP_TRY(h, hipMemcpyAsync(h->sWarm + off * w, j.warm + off * w, sizeof(uint64_t) * n * w,
-                                          hipMemcpyHostToDevice, h->sUp));
-            HIP_TRY(h, hipEventRecord(evUp, h->sUp));
-            HIP_TRY(h, hipStreamWaitEvent(h->sRun, evUp, 0));
-            rc = launch_chunk(h, rs, n, off, j.warm != nullptr);
-            if (rc != LMPC_OK) { if (errh != h) errh->err = h->err; break; }
-            HIP_TRY(h, hipEventRecord(evRun, h->sRun));
-            HIP_TRY(h, hipStreamWaitEvent(h->sDown, evRun, 0));
-            HIP_TRY(h, hipMemcpyAsync(j.x + rs * off * nout, reinterpret_cast<char *>(h->sX) + rs * off * nout,
-                                      rs * n * nout, hipMemcpyDeviceToHost, h->sDown));
-            HIP_TRY(h, hipMemcpyAsync(j.flag + off, h->sFlag + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
-            if (j.iters)
-                HIP_TRY(h, hipMemcpyAsync(j.iters + off, h->sIter + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->sDown));
-            if (j.active)
-                HIP_TRY(h, hipMemcpyAsync(j.active + off * w, h->sAct + off * w, sizeof(uint64_t) * n * w,
-                                          hipMemcpyDeviceToHost, h->sDown));
-        }
+    if (mode != HostMode::THREADED) {
+        for (int64_t c = 0; c < nchunks && rc == LMPC_OK; c++)
+            for (size_t ji = 0; ji < jobs.size() && rc == LMPC_OK; ji++)
+                if (has(ji, c)) { rc = upload(ji, c); if (rc == LMPC_OK) rc = download(ji, c); }
+    } else {
+        std::vector<std::atomic<int64_t>> launched(jobs.size());
+        for (auto &a : launched) a.store(0);
+        std::atomic<int> uerr{LMPC_OK};
+        std::vector<std::thread> up;
+        for (size_t ji = 0; ji < jobs.size(); ji++)
+            up.emplace_back([&, ji]() {
+                for (int64_t c = 0; has(ji, c) && uerr.load() == LMPC_OK; c++) {
+                    const int r = upload(ji, c);
+                    if (r != LMPC_OK) { uerr.store(r); break; }
+                    launched[ji].store(c + 1, std::memory_order_release);
+                }
+            });
+        for (int64_t c = 0; c < nchunks && rc == LMPC_OK; c++)
+            for (size_t ji = 0; ji < jobs.size() && rc == LMPC_OK; ji++) {
+                if (!has(ji, c)) continue;
+                while (launched[ji].load(std::memory_order_acquire) <= c && uerr.load() == LMPC_OK) std::this_thread::yield();
+                if (uerr.load() != LMPC_OK) { rc = uerr.load(); break; }
+                rc = download(ji, c);
+            }
+        if (rc != LMPC_OK) uerr.store(rc);               // stops the upload threads at their next chunk
+        for (auto &t : up) t.join();
     }
+    if (rc != LMPC_OK) for (auto &j : jobs) if (errh != j.h && !j.h->err.empty()) errh->err = j.h->err;
     // drain every device's pipeline, also after an error (nothing may still write into the caller's arrays)
     for (auto &j : jobs) {
         if (j.N == 0) continue;
@@ -213,17 +273,31 @@ int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh) {
     return rc;
 }
 
-void pin_call(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag,
-              int32_t *iters, uint64_t *active, const uint64_t *warm) {
-    if (!h->hostRegister) return;
+// pinned for this call ("host_register" 1), pinned by the caller, or pageable?
+HostMode host_mode(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag,
+                   int32_t *iters, uint64_t *active, const uint64_t *warm);
+
+HostMode host_mode(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag,
+                   int32_t *iters, uint64_t *active, const uint64_t *warm) {
     const size_t w = (size_t)h->P.words();
-    pin.pin(theta, rs * (size_t)N * h->P.nth);
-    pin.pin(x, rs * (size_t)N * h->P.nout);
-    pin.pin(flag, sizeof(int32_t) * (size_t)N);
-    pin.pin(iters, sizeof(int32_t) * (size_t)N);
-    pin.pin(active, sizeof(uint64_t) * (size_t)N * w);
-    pin.pin(warm, sizeof(uint64_t) * (size_t)N * w);
-    pin.commit();
+    const size_t bth = rs * (size_t)N * h->P.nth, bx = rs * (size_t)N * h->P.nout, bf = sizeof(int32_t) * (size_t)N,
+                 ba = sizeof(uint64_t) * (size_t)N * w;
+    // small calls (a closed loop's single solve): a pipeline would cost more than it hides
+    if (bth + bx + bf < ((size_t)4 << 20)) return HostMode::SINGLE;
+    if (caller_pinned(theta, bth) && caller_pinned(x, bx) && caller_pinned(flag, bf) && caller_pinned(iters, iters ? bf : 0) &&
+        caller_pinned(active, active ? ba : 0) && caller_pinned(warm, warm ? ba : 0))
+        return HostMode::ASYNC;
+    if (h->hostRegister) {
+        // Pin the caller's arrays for the duration of this call.  NOT the default: on this runtime (ROCm 7.2,
+        // MI355X) registering and unregistering ordinary heap memory call after call ended, after a few hundred
+        // calls in one process, in a GPU memory access fault on a host address (tests: the whole GPU suite in one
+        // process, two runs of eight).  Caller-pinned, page-aligned, long-lived arrays (lmpc_pin_host) are safe.
+        pin.pin(theta, bth); pin.pin(x, bx); pin.pin(flag, bf);
+        pin.pin(iters, iters ? bf : 0); pin.pin(active, active ? ba : 0); pin.pin(warm, warm ? ba : 0);
+        pin.commit();
+        return HostMode::ASYNC;
+    }
+    return h->hostThreads ? HostMode::THREADED : HostMode::SINGLE;
 }
 
 int solve_host(lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x, int32_t *flag, int32_t *iters,
@@ -237,11 +311,9 @@ int solve_host(lmpc_handle *h, size_t rs, int64_t N, const void *theta, void *x,
         return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
     LMPC_ENTER_DEVICE(h);
     PinScope pin;
-    // small calls (a closed loop's single solve): pinning and three streams would cost more than they hide
-    if ((size_t)N * (rs * (h->P.nth + h->P.nout) + 4) >= ((size_t)1 << 20))
-        pin_call(pin, h, rs, N, theta, x, flag, iters, active, warm);
+    const HostMode mode = host_mode(pin, h, rs, N, theta, x, flag, iters, active, warm);
     std::vector<HostJob> jobs{HostJob{h, N, static_cast<const char *>(theta), static_cast<char *>(x), flag, iters, active, warm}};
-    return run_host_jobs(jobs, rs, h);
+    return run_host_jobs(jobs, rs, h, mode);
 }
 
 // ---------------------------------------------------------------- RCCL, loaded on first use
@@ -391,7 +463,7 @@ int lmpc_solve_batch_multi(lmpc_multi *hm, int64_t N, const double *theta, doubl
     std::vector<int64_t> off((size_t)nd + 1);
     lmpc_multi_partition(N, nd, off.data());
     PinScope pin;
-    pin_call(pin, h0, sizeof(double), N, theta, x, exitflag, iters, active, warm);
+    const HostMode mode = host_mode(pin, h0, sizeof(double), N, theta, x, exitflag, iters, active, warm);
     std::vector<HostJob> jobs;
     for (int d = 0; d < nd; d++) {
         const int64_t o = off[d];
@@ -399,7 +471,7 @@ int lmpc_solve_batch_multi(lmpc_multi *hm, int64_t N, const double *theta, doubl
                                reinterpret_cast<char *>(x + o * nout), exitflag + o, iters ? iters + o : nullptr,
                                active ? active + o * w : nullptr, warm ? warm + o * w : nullptr});
     }
-    const int rc = run_host_jobs(jobs, sizeof(double), h0);
+    const int rc = run_host_jobs(jobs, sizeof(double), h0, mode);
     if (rc != LMPC_OK) hm->err = h0->err;
     return rc;
 }

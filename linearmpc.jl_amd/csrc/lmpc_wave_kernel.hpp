@@ -1,4 +1,4 @@
-// One-QP-per-wavefront dual active-set kernel: the general path (n <= 63 variables, working sets
+// One-QP-per-wavefront dual active-set kernel: the general path (n <= 127 variables, working sets
 // up to 64 rows, m <= 1024 constraints, hard and SOFT rows, BINARY rows by branch and bound),
 // in binary64 or binary32 (the reference's generated C has both: codegen.jl:19,31-37,82 `float_type`).
 //
@@ -121,7 +121,11 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 // BNB: rows flagged BINARY must end up active at one of their bounds -- depth-first branch and
 // bound over them around the same node solver (what the reference gets from daqp_bnb, [EXT]).
 // PACKED: layout of the per-wave factor L, see below.
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
+// NU: register slots per lane for the primal iterate: variable k lives on lane k % 64, slot k / 64 (n <= 64 NU;
+// NU = 2 takes the condensed problems of long horizons, n up to 127 -- the reference's own benchmark sweeps
+// Np = Nc = 50 .. 125 with one input, docs/src/manual/benchmark.md:4).  The working set still lives on the 64
+// lanes: a point whose working set wants more rows ends with EXIT_WSCAP.
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
 __global__ __launch_bounds__(MR >= 8 ? 256 : ((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
@@ -168,7 +172,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const int lrow1 = lane + 1 < cap ? lane + 1 : cap - 1;
     const int lr1 = lrow > 0 ? lrow : 1;                         // row index that is valid in every column read
     const int mycol = cbase(lrow);                               // this lane's own column: L(t, lane) = L[mycol + t]
-    const int lanen = lane < n ? lane : n - 1;
+    int lanen[NU];                                             // this lane's variables, clamped into [0, n)
+#pragma unroll
+    for (int s = 0; s < NU; s++) lanen[s] = lane + 64 * s < n ? lane + 64 * s : n - 1;
 
     int sense0[MR], sense[MR];                       // constraint slots of this lane: as given / of the
     int jc[MR];                                      // current solve (a B&B node adds its fixed binaries)
@@ -221,7 +227,19 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         // registers of working-set position `lane`
         int WSi = 0, possoft = 0, posimm = 0, poslow = 0;
         R lam = (R)0, ls = (R)0, rhs = (R)0, D = (R)0, Dinv = (R)0, y = (R)0;
-        R u = (R)0;                              // lane k < n holds u_k
+        R u[NU];                                 // lane k % 64, slot k / 64 holds u_k
+#pragma unroll
+        for (int s = 0; s < NU; s++) u[s] = (R)0;
+        // u_k for a wave-uniform k
+        auto ubc = [&](int k) -> R {
+            if constexpr (NU == 1) return wv_bcast(u[0], k);
+            else {
+                R v = u[0];
+#pragma unroll
+                for (int s = 1; s < NU; s++) v = (k >> 6) == s ? u[s] : v;
+                return wv_bcast(v, k & 63);
+            }
+        };
         int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT, nsoft_act = 0;
         R best = (R)-1, fval = (R)0, soft_slack = (R)0;
         bool done = false, ydirty = false;
@@ -434,7 +452,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; best = (R)-1; done = false;
         if (!BNB || forced < 0) {
         WSi = 0; possoft = 0; posimm = 0; poslow = 0;
-        lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; u = (R)0; y = (R)0;
+        lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0;
+#pragma unroll
+        for (int s = 0; s < NU; s++) u[s] = (R)0;
         actb = 0u; lowb = 0u;
         na = 0; sing = -1; nsoft_act = 0;
         fval = (R)0; soft_slack = (R)0; ydirty = false;
@@ -517,19 +537,28 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 blocking(false, alpha, rm);
                 if (rm < 0) {
                     // primal iterate u = -M_W' lam* (lane k owns u_k): rows of M eight positions ahead
-                    R uk = (R)0;
-                    for (int i0 = 0; i0 < na; i0 += CH) {
-                        R mv[CH];
+                    R uk[NU];
 #pragma unroll
-                        for (int q = 0; q < CH; q++) {
+                    for (int s = 0; s < NU; s++) uk[s] = (R)0;
+                    constexpr int CHU = NU == 1 ? CH : CH / 2;      // same register budget for either NU
+                    for (int i0 = 0; i0 < na; i0 += CHU) {
+                        R mv[CHU][NU];
+#pragma unroll
+                        for (int q = 0; q < CHU; q++) {
                             const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
-                            mv[q] = Mr[(size_t)w * n + lanen];
+#pragma unroll
+                            for (int s = 0; s < NU; s++) mv[q][s] = Mr[(size_t)w * n + lanen[s]];
                         }
 #pragma unroll
-                        for (int q = 0; q < CH; q++)
-                            if (i0 + q < na) uk = wv_fma(-mv[q], wv_bcast(ls, i0 + q), uk);
+                        for (int q = 0; q < CHU; q++)
+                            if (i0 + q < na) {
+                                const R lq = wv_bcast(ls, i0 + q);
+#pragma unroll
+                                for (int s = 0; s < NU; s++) uk[s] = wv_fma(-mv[q][s], lq, uk[s]);
+                            }
                     }
-                    u = lane < n ? uk : (R)0;
+#pragma unroll
+                    for (int s = 0; s < NU; s++) u[s] = lane + 64 * s < n ? uk[s] : (R)0;
                     // objective u'u and the row values M u in one pass over the variables
                     R fv = (R)0, soft = (R)0;
                     R Mu[MR];
@@ -547,7 +576,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 #pragma unroll
                         for (int q = 0; q < CHM; q++) {
                             if (k0 + q < n) {
-                                const R v = wv_bcast(u, k0 + q);
+                                const R v = ubc(k0 + q);
                                 fv = wv_fma(v, v, fv);
 #pragma unroll
                                 for (int r = 0; r < MR; r++) Mu[r] = wv_fma(mt[q][r], v, Mu[r]);
@@ -644,7 +673,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             for (int r = 0; r < MR; r++) { stk_up[r] = 0ull; stk_lo[r] = 0ull; }
             int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
             bool inplace = false;
-            R ubest = (R)0, bestval = (R)P.fval_bound;
+            R ubest[NU], bestval = (R)P.fval_bound;
+#pragma unroll
+            for (int s = 0; s < NU; s++) ubest[s] = (R)0;
             unsigned bestact = 0u, bestlow = 0u;
             for (;;) {
                 if (nodes >= 100000) { bflag = EXIT_ITERLIMIT; break; }
@@ -690,11 +721,13 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int jb = wv_min(cand);
                     if (jb == 0x7fffffff) {              // leaf: every binary sits on a bound
                         if (!have || fval < bestval) {
-                            have = 1; bestval = fval; ubest = u; bestact = actb; bestlow = lowb;
+                            have = 1; bestval = fval; bestact = actb; bestlow = lowb;
+#pragma unroll
+                            for (int s = 0; s < NU; s++) ubest[s] = u[s];
                         }
                     } else {
                         R Mu = (R)0;
-                        for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], wv_bcast(u, k), Mu);
+                        for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], ubc(k), Mu);
                         R bj = (R)0;
 #pragma unroll
                         for (int r = 0; r < MR; r++) if (r == (jb >> 6)) bj = b[r];
@@ -724,29 +757,31 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     if (lane == depth - 1) { stk_side ^= 1; stk_tried = 2; }
                 }
             }
-            u = have ? ubest : (R)0;
+#pragma unroll
+            for (int s = 0; s < NU; s++) u[s] = have ? ubest[s] : (R)0;
             actb = have ? bestact : 0u;
             lowb = have ? bestlow : 0u;
             flag = have ? (bflag == EXIT_ITERLIMIT ? EXIT_ITERLIMIT : EXIT_OPTIMAL) : bflag;
             iter = total_it;
         }
 
-        // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k writes output k
-        {
+        // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k writes outputs k, k + 64, ...
+        for (int o0 = 0; o0 < P.nout; o0 += 64) {
             R xs = (R)0;
-            const int lout = lane < P.nout ? lane : P.nout - 1;
+            const int ko = o0 + lane;
+            const int lout = ko < P.nout ? ko : P.nout - 1;
             for (int c0 = 0; c0 < n; c0 += CH) {
                 R rv[CH];
 #pragma unroll
                 for (int q = 0; q < CH; q++) rv[q] = C[P.oRout + (size_t)lout * n + (c0 + q < n ? c0 + q : n - 1)];
 #pragma unroll
                 for (int q = 0; q < CH; q++)
-                    if (c0 + q < n) xs = wv_fma(rv[q], wv_bcast(u, c0 + q), xs);
+                    if (c0 + q < n) xs = wv_fma(rv[q], ubc(c0 + q), xs);
             }
-            if (lane < P.nout) {
-                R sh = C[P.ox0 + lane];
-                for (int t = 0; t < nth; t++) sh = wv_fma(C[P.oXth + lane * nth + t], th[t], sh);
-                X[pid * P.nout + lane] = xs + sh;
+            if (ko < P.nout) {
+                R sh = C[P.ox0 + ko];
+                for (int t = 0; t < nth; t++) sh = wv_fma(C[P.oXth + (size_t)ko * nth + t], th[t], sh);
+                X[pid * P.nout + ko] = xs + sh;
             }
         }
         if (active) {

@@ -40,7 +40,7 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
     // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
-    for (int level = (packed || h->P.m > 256) ? 1 : 3; level >= 0; level--) {
+    for (int level = h->P.n > 64 ? 0 : ((packed || h->P.m > 256) ? 1 : 3); level >= 0; level--) {
         if (h->waveLevel >= 0 && level != ((packed || h->P.m > 256) && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
         for (int nwv : {4, 8, 16, 2, 1}) {
             if (nwv > maxNwv) continue;
@@ -65,11 +65,11 @@ inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     return 4 * pk.blocksPerCU * pk.nwv >= 5 * sq.blocksPerCU * sq.nwv ? pk : sq;
 }
 
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED>
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;
-    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED>;
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
     int blocksPerCU = cfg.blocksPerCU;
@@ -112,6 +112,26 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     const int mr = (h->P.m + 63) / 64;
     const WaveConfig cfg = wave_config(h, sizeof(R));
     if (BNB) warm = nullptr;                              // a B&B node takes its start from the search, not the caller
+    // long horizons (64 <= n <= 127): two variable slots per lane; built without LDS staging of the problem data
+    // (M alone is up to 1 MB there) and without branch and bound
+    if (h->P.n > 64) {
+        if constexpr (BNB) {
+            rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: branch and bound covers n <= 64");
+        } else {
+#define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
+                                  : launch_wave_cfg<R, MRR, 0, false, false, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
+            if (mr <= 2) rc = LMPC_WVU(2);
+            else if (mr <= 4) rc = LMPC_WVU(4);
+            else if (mr <= 8) rc = LMPC_WVU(8);
+            else rc = LMPC_WVU(16);
+#undef LMPC_WVU
+        }
+        if (h->prof) {
+            if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+            else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+        }
+        return rc;
+    }
 #define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
 #define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
 #define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \

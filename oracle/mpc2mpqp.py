@@ -731,6 +731,18 @@ def pendulum(Np=50, Nc=5) -> MPCProblem:
                     umin=[-2.0], umax=[2.0], Ts=Ts)
 
 
+def pendulum_benchmark(N=50, soft=True) -> MPCProblem:
+    """The reference's published benchmark problem class (docs/src/manual/benchmark.md:4): the inverted pendulum
+    on a cart with prediction and control horizons swept TOGETHER, Np = Nc = N in {50, 75, 100, 125}, "both input
+    and state constraints imposed".  The benchmark's own script lives in another repository
+    (darnstrom/lmpc-codegen-benchmark) and is not part of the reference tree, so the state constraints here are
+    this build's stand-in: output bounds |cart position| <= 1.5, |angle| <= 0.2 on steps 2..N, soft as
+    set_bounds!(ymin, ymax) makes them by default (setup.jl:94).  n = N variables, 3N - 2 rows."""
+    p = pendulum(Np=N, Nc=N)
+    p.add_constraint(Ax=p.C, lb=[-1.5, -0.2], ub=[1.5, 0.2], ks=range(2, N + 1), soft=soft)
+    return p
+
+
 def mass_spring(nm=6, Np=10, Nc=10, kappa=1.0, lam=0.0) -> MPCProblem:
     """mpc_examples.jl:241-286: chain of nm masses, force on mass 1, |pos| <= 4 for k = 2..Nc."""
     nx = 2 * nm

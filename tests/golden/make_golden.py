@@ -329,6 +329,41 @@ def main():
         assert np.abs(xe - X[i]).max() < 2e-6
     save("refprev_full_kat", q, L, theta, X, ef, it, act, dict(r_traj=r_traj, u_julia_equals_c=X[0, :1]))
 
+    # ---- the reference's published benchmark class: pendulum, Np = Nc = N, input + state constraints
+    # (docs/src/manual/benchmark.md:4-16; oracle/mpc2mpqp.py::pendulum_benchmark).  theta: the closed loops of the
+    # example's two scenarios (mpc_examples.jl:136-139: x0 = [0, 0, 0.15, 0] with r = 0, and x0 = 0 with r = [1, 0];
+    # 200 steps of Ts = 0.01 each) -- the points a closed-loop benchmark visits -- plus perturbed copies
+    for N in (50, 75, 100, 125):
+        name = f"pendulum_N{N}"
+        if ONLY and name not in ONLY:
+            continue
+        prob = omm.pendulum_benchmark(N)
+        q = omm.mpc2mpqp(prob)
+        L = oldp.qp2ldp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=1)
+        ths = []
+        for x0, r in (([0, 0, 0.15, 0], [0.0, 0.0]), ([0, 0, 0, 0], [1.0, 0.0])):
+            x, up = np.array(x0, float), np.zeros(1)
+            for k in range(200):
+                th = omm.form_parameter(prob, x, r=r, uprev=up)
+                ths.append(th)
+                U, e, _, _ = oldp.solve_batch(L, th[None])
+                assert e[0] >= 1
+                up = U[0, :1].copy()
+                x = prob.F @ x + prob.G @ up
+        rngb = np.random.default_rng(1000 + N)
+        base = np.array(ths)
+        pert = base[rngb.integers(0, len(base), 368)] + rngb.normal(size=(368, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.05]
+        theta = np.vstack([base, pert])
+        X, ef, it, act = oldp.solve_batch(L, theta)
+        assert np.all(ef >= 1)
+        if ONLY and name not in ONLY:
+            continue
+        d = dict(H=q.H, f=q.f, f_theta=q.f_theta, A=q.A, bu=q.bu, bl=q.bl, W=q.W, senses=q.senses, nu=q.nu, nx=q.nx,
+                 theta=theta, X=X, exitflag=ef, iters=it, active=act, F=prob.F, G=prob.G, n_closed_loop=len(base))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+        print(f"{name}: n={q.n} m={q.m} N={theta.shape[0]} flags={dict(zip(*np.unique(ef, return_counts=True)))} "
+              f"mean iters={it.mean():.1f} max iters={it.max()}")
+
     # ---- K5: closed-loop end values the reference's tests assert
     # (a) "x0 uncertainty" runtests.jl:1067-1074: x1 -> 0.4 (1e-6); soft output bounds, tightened
     prob = omm.x0_uncertainty_kat()

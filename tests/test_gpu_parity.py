@@ -612,7 +612,12 @@ def test_unconstrained_and_wide_parameter_problems(lmpc):
 
 def test_unsupported_shapes_are_refused_loudly(lmpc):
     rng = np.random.default_rng(22)
-    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 70, 10, 3)       # n > 63
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 130, 10, 3)      # n > 127
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
+    assert e.value.code == -103
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, 70, 10, 3)       # branch and bound stops at n = 64
+    sense = sense.copy(); sense[:4] |= 16
     with pytest.raises(lmpc.LmpcError) as e:
         lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense)
     assert e.value.code == -103
@@ -1662,7 +1667,15 @@ def test_caller_pinned_arrays(lmpc):
     N = 300_000
     theta = np.ascontiguousarray(np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)),
                                             rng.uniform(-2, 2, (N, 1))]))
-    x = np.zeros((N, 1)); ef = np.zeros(N, np.int32)
+    import mmap
+
+    def paged(shape, dtype):          # page-aligned, pages of its own (what lmpc_pin_host asks of the caller)
+        a_ = np.frombuffer(mmap.mmap(-1, int(np.prod(shape)) * np.dtype(dtype).itemsize), dtype=dtype).reshape(shape)
+        a_[...] = 0
+        return a_
+
+    th_p = paged(theta.shape, np.float64); th_p[...] = theta; theta = th_p
+    x = paged((N, 1), np.float64); ef = paged((N,), np.int32)
     vp = lambda a: ctypes.c_void_p(a.ctypes.data)
     x_ref, ef_ref, _, _ = qp.solve(theta, want_iters=False, want_active=False)
     for a_ in (theta, x, ef):
@@ -1674,3 +1687,49 @@ def test_caller_pinned_arrays(lmpc):
     for a_ in (theta, x, ef):
         assert L.lmpc_unpin_host(vp(a_)) == 1
     assert L.lmpc_unpin_host(vp(theta)) == -100
+
+
+# ------------------------------------------------------------------ long horizons: 64 <= n <= 127 (two variable slots per lane)
+@pytest.mark.parametrize("N", [50, 75, 100, 125])
+def test_reference_benchmark_class_long_horizons(lmpc, N):
+    """The reference's published benchmark sweeps the pendulum's horizons together, Np = Nc = N in {50, 75, 100,
+    125}, with input and state constraints (docs/src/manual/benchmark.md:4-16): n = N variables, 3N - 2 rows,
+    2N - 2 of them soft.  theta: the closed loops of the example's scenarios plus perturbed copies (fixture)."""
+    g = load_golden(f"pendulum_N{N}")
+    theta = g["theta"]
+    qp = _qp_from_golden(lmpc, g, 1)
+    assert qp.kernel_name == "wave" and qp.n == N and qp.m == 3 * N - 2
+    x, ef, it, act = _compare(qp, theta)                         # bit-level against the oracle on the library's pack
+    assert np.all(ef >= 1)
+    # against the committed answers (oracle on the numpy pack: 1/rho = 1e6 amplifies the 1e-16 between the packs)
+    assert np.array_equal(ef, g["exitflag"]) and np.abs(x[:, 0] - g["X"][:, 0]).max() < 1e-5
+    # the whole trajectory (nout = n > 64: outputs in blocks of 64 lanes) and a warm start from the final sets
+    qt = _qp_from_golden(lmpc, g)
+    xt, eft, itt, actt = _compare(qt, theta[:200])
+    assert np.array_equal(xt[:, 0], x[:200, 0]) and np.array_equal(actt, act[:200])
+    _compare(qt, theta[:200], warm=actt)
+    # binary32 on the same kernel
+    from oracle import ldp as oldp
+    q32 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1,
+                                   settings=lmpc.default_settings_f32())
+    th32 = theta[:256].astype(np.float32)
+    x32, ef32, it32, act32 = q32.solve_f32(th32)
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(q32.ldp()), th32, oldp.default_settings_f32(), dtype=np.float32)
+    assert np.array_equal(ef32, efo) and np.array_equal(it32, ito) and np.array_equal(act32, acto) and np.array_equal(x32, xo)
+
+
+@pytest.mark.parametrize("n,mg,nsoft", [(64, 20, 0), (65, 10, 3), (90, 200, 20), (127, 60, 0)])
+def test_wave_kernel_two_variable_slots_random_problems(lmpc, n, mg, nsoft):
+    # random problems around the slot boundary (n = 64 is the last single-slot size), hard and soft general rows,
+    # feasible and infeasible points, iteration counts and masks against the oracle
+    rng = np.random.default_rng(7 * n + mg)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, 5)
+    sense = sense.copy()
+    sense[n:n + nsoft] |= 8
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 2 * bu, 2 * bl, 0.3 * W, sense, nout=min(n, 70))
+    assert qp.kernel_name == "wave"
+    theta = rng.uniform(-1.5, 1.5, (160, 5))
+    x, ef, it, act = _compare(qp, theta)
+    ok = ef >= 1
+    if ok.sum() > 4:
+        _compare(qp, theta[ok][:48], warm=act[ok][:48])

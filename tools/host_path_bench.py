@@ -33,13 +33,25 @@ def timeit(fn, reps=12):
     return np.median(ts)
 
 
-for reg in (1, 0):
-    for chunk in (1 << 20, 131072, 65536, 32768, 16384, 8192):
-        qp.set_option("host_register", reg)
-        qp.set_option("host_chunk", chunk)
-        t = timeit(call_single)
-        print(f"lmpc_solve_batch   register={reg} chunk={chunk:8d}: {1e3*t:7.3f} ms per 1e6 = {N/t:.3e} solves/s", flush=True)
-qp.set_option("host_register", 1); qp.set_option("host_chunk", 32768)
+qp.set_option("host_threads", 0)
+t = timeit(call_single)
+print(f"lmpc_solve_batch   pageable, one chunk, one thread:      {1e3*t:7.3f} ms per 1e6 = {N/t:.3e} solves/s", flush=True)
+qp.set_option("host_threads", 1)
+for chunk in (262144, 131072, 65536, 32768, 16384):
+    qp.set_option("host_chunk", chunk)
+    t = timeit(call_single)
+    print(f"lmpc_solve_batch   pageable, two host threads, last chunk {chunk:7d}: {1e3*t:7.3f} ms per 1e6 = {N/t:.3e} solves/s", flush=True)
+import mmap
+
+
+def paged(a):          # page-aligned copy with pages of its own
+    b = np.frombuffer(mmap.mmap(-1, a.nbytes), dtype=a.dtype).reshape(a.shape)
+    b[...] = a
+    return b
+
+
+theta, x, ef = paged(theta), paged(x), paged(ef)
+qp.set_option("host_chunk", 32768)
 for a_ in (theta, x, ef):
     assert L.lmpc_pin_host(vp(a_), a_.nbytes) == 1
 t = timeit(call_single)
