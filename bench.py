@@ -74,6 +74,11 @@ def make_theta(name, n, seed, hard=False):
     if name == "satellite20":   # hybrid MPC, theta = [x(3); r(3)] (reference mpc_examples.jl:533-546, runtests.jl:820-834)
         return np.ascontiguousarray(np.hstack([rng.uniform(-0.3, 0.3, (n, 1)), rng.uniform(-0.5, 0.5, (n, 2)),
                                                rng.uniform(-0.5, 0.5, (n, 1)), np.zeros((n, 2))]))
+    if name.startswith("pendulum_N"):   # the reference's benchmark class: points a closed loop visits, perturbed
+        g = make_problem(name)
+        base = g["theta"][:int(g["n_closed_loop"])]
+        return np.ascontiguousarray(base[rng.integers(0, len(base), n)] +
+                                    rng.normal(size=(n, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.05])
     if name == "soft_doc":      # docs example with soft output bounds (reference docs/src/manual/simple.md:60-83)
         return np.ascontiguousarray(np.hstack([rng.uniform(-1, 2, (n, 2)), rng.uniform(0, 1, (n, 2)),
                                                rng.uniform(-3, 3, (n, 1))]))
@@ -168,7 +173,7 @@ class Workload:
                  options=None):
         self.torch = torch
         self.workload = workload
-        self.name = ("pendulum" if workload.startswith("pendulum") else
+        self.name = ("pendulum" if workload in ("pendulum", "pendulum_hard") else
                      ("satellite20" if workload == "hybrid" else workload))
         self.hard = workload == "pendulum_hard"
         self.f32 = f32
@@ -283,6 +288,10 @@ def describe(w):
         body = "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12)"
     elif w.name == "mass_spring_3in":
         body = f"oscillating masses, 12 states / 3 inputs (synthetic B), Nc=10 (n={qp.n}, m={qp.m}, nth={qp.nth})"
+    elif w.name.startswith("pendulum_N"):
+        body = (f"the reference's published benchmark class (docs/src/manual/benchmark.md:4-16): inverted pendulum, "
+                f"Np = Nc = {qp.n}, input bounds + soft output bounds on every step (n={qp.n}, m={qp.m}, nth={qp.nth}); "
+                "parameter points = the closed loops of the example's two scenarios, perturbed")
     elif w.name == "satellite20":
         body = f"hybrid MPC, satellite Np=Nc=20, 40 binary rows, branch and bound (n={qp.n}, m={qp.m}, nth={qp.nth})"
     else:
@@ -331,7 +340,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc", "hybrid"])
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc", "hybrid",
+                             "pendulum_N50", "pendulum_N75", "pendulum_N100", "pendulum_N125"])
     ap.add_argument("--f32", action="store_true",
                     help="binary32 path (lmpc_solve_batch_f32_device; wavefront kernel; reference codegen float_type=float)")
     ap.add_argument("--wave", action="store_true", help="force the wavefront-per-QP kernel (diagnostic)")
@@ -401,7 +411,7 @@ def main():
     # several batches in flight: 64-lane workgroups for the iterating kernel (its wavefronts then spread
     # over the CUs independently of each other; +3 % over the library's stand-alone choice of 256,
     # which is the better one with a single batch in flight: tools/block_sweep.sh)
-    if not args.lane_block and nstreams > 1 and not args.f32 and not args.wave and args.workload.startswith("pendulum"):
+    if not args.lane_block and nstreams > 1 and not args.f32 and not args.wave and args.workload in ("pendulum", "pendulum_hard"):
         args.lane_block = 64
     if args.lane_block:
         opts["lane_block"] = args.lane_block
@@ -605,6 +615,16 @@ def main():
             cfgs["pendulum_hard"] = side_config(torch, lmpc, "pendulum_hard", BATCH, dev, local_rank, 40, 5, False, want_cpu, 3.0)
             cfgs["mass_spring_3in"] = side_config(torch, lmpc, "mass_spring_3in", BATCH, dev, local_rank, 4, 1, False, want_cpu, 4.0)
             cfgs["hybrid_f32"] = side_config(torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
+            # the reference's only published numbers (plots, unstated hardware, generated C, one solve at a time
+            # in closed loop): quoted beside the batched rate as context, not as a baseline
+            ref_us = {50: 11.0, 75: 16.0, 100: 22.0, 125: 31.0}
+            for n_ in (50, 75, 100, 125):
+                c_ = side_config(torch, lmpc, f"pendulum_N{n_}", 200_000, dev, local_rank, 3, 1, False, want_cpu, 3.0)
+                c_["reference_context"] = {"median_solve_time_us": ref_us[n_], "solves_per_s_one_thread": 1e6 / ref_us[n_],
+                                           "source": "docs/src/assets/benchmark_scaling_time.png (benchmark.md:23), read off the "
+                                                     "plot +-10 %, hardware unstated, state constraints of the benchmark script "
+                                                     "unpublished (this fixture uses its own, see DESIGN.md)"}
+                cfgs[f"pendulum_N{n_}"] = c_
             out["configs"] = cfgs
         print(json.dumps(out), flush=True)
     if world > 1:
