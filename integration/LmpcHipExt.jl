@@ -80,4 +80,36 @@ function compute_control_batch(mpc, bm::BatchedModel, X0::Matrix; R=nothing, Upr
     check && @assert all(flags .>= 1)
     return U, flags
 end
+
+# ---- every GPU of the node behind ONE call (one process, one Θ -- the shape of utils.jl:268-283)
+mutable struct MultiModel
+    hm::Ptr{Cvoid}; nout::Int; nth::Int
+end
+function setup_batched_multi(mpc::LinearMPC.MPC; nout=mpc.model.nu, devices=Cint[])    # empty = all visible GPUs
+    mpc.mpqp_issetup || LinearMPC.setup!(mpc)
+    q = mpc.mpQP
+    isempty(q.break_points) || error("lmpc: prioritised constraints are not supported")
+    q.is_symmetric || error("lmpc: variational objective (is_avi) is not supported")
+    n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
+    hm = Ref{Ptr{Cvoid}}(C_NULL); s = Ref(LmpcSettings(mpc))
+    K = iszero(mpc.K) ? C_NULL : Matrix{Float64}(mpc.K[1:nout, :])
+    flag = ccall((:lmpc_setup_multi, liblmpc), Cint,
+        (Ref{Ptr{Cvoid}}, Cint,Cint,Cint,Cint,Cint, Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},
+         Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cint},Ptr{Cdouble},Cint,Ref{LmpcSettings},Ptr{Cint},Cint),
+        hm, n,m,ms,nth,nout, q.H,q.f,q.f_theta,q.A,q.bu,q.bl,q.W,q.senses, K, mpc.model.nx, s,
+        isempty(devices) ? C_NULL : devices, length(devices))
+    flag == 1 || error("lmpc_setup_multi failed ($flag)")
+    mm = MultiModel(hm[], nout, nth)
+    finalizer(b -> ccall((:lmpc_free_multi, liblmpc), Cvoid, (Ptr{Cvoid},), b.hm), mm)
+    return mm
+end
+"solve(mpc, Θ) across the GPUs: contiguous shards, results straight into X / flags"
+function LinearMPC.solve(mm::MultiModel, Θ::Matrix{Float64}, X::Matrix{Float64}, flags::Vector{Cint})
+    N = size(Θ,2)
+    rc = ccall((:lmpc_solve_batch_multi, liblmpc), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}, Ptr{Cint}, Ptr{UInt64}, Ptr{UInt64}),
+        mm.hm, N, Θ, X, flags, C_NULL, C_NULL, C_NULL)
+    rc == 1 || error("lmpc_solve_batch_multi failed ($rc)")
+    return X, flags
+end
 end

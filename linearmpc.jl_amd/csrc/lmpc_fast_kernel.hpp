@@ -192,6 +192,9 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         if (npass < 2) LMPC_TRC(2 + npass);
         npass++;
 #endif
+#ifdef LMPC_FAST_PRIO
+        __builtin_amdgcn_s_setprio(LMPC_FAST_PRIO);           // a solving pass is a latency chain: ahead of the streamers
+#endif
         const bool mine = lane < n;
         int rel = -1;
         if (mine) {
@@ -262,6 +265,9 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             if (iters) iters[pid] = iter;
             if (active) active[pid * P.words] = (act & ~low) | ((act & low) << N);     // m == N <= 6: one word
         }
+#ifdef LMPC_FAST_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     LMPC_TRC(6);
 #ifdef LMPC_FAST_TRACE

@@ -10,10 +10,14 @@ into the dense multi-parametric QP
 
 exactly the way the reference builds it on the Julia host, so that the fixtures
 fed to the HIP path are the matrices a LinearMPC.jl user would hand over.  Only
-the features the benchmark/known-answer problems exercise are restated (reference preview, move
-blocking, constant offsets in dynamics and outputs yes; no disturbance/parameter preview, no
-reference condensation, no constraint tightening).  Reference lines followed, all under
-/root/reference/src/:
+the features the benchmark / known-answer problems exercise are restated: reference preview
+(mpc2mpqp.jl:535-577, :70-92) and reference condensation (:550-569, traj2setpoint), disturbance preview
+(:48-66, :579-604) and measured disturbances as states (:664-669), generalised parameters with preview
+(:125-145, :478-508), move blocking (:830-857, setup.jl:202-248 incl. scalar and per-input blocks), constant
+offsets in dynamics and outputs (:683-688, :517-530, :393-398), x0-uncertainty tightening (robust.jl:1-29),
+binary inputs.  NOT restated: the variational (game-theoretic) objective (:900-950), prioritised constraints /
+break points beyond the stable sort (:859-866, :890-892), invariant-set terminal constraints.
+Reference lines followed, all under /root/reference/src/:
 
     zoh                     utils.jl:291-295
     Model(A,B,Ts)           model.jl:78-90

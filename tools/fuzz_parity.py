@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Long randomized differential run: random problem shapes / row kinds / bounds, HIP path vs CPU oracle on the
 same pack -- exit flags, iteration counts, active sets bit for bit, x to 1e-10; cold and warm; f64 and (every
-fourth trial, wavefront-kernel shapes) f32.  usage: tools/fuzz_parity.py [trials] [seed]"""
+fourth trial, wavefront-kernel shapes) f32; n up to 100 (two variable slots per lane).  Also prints the MARGINAL
+case report (oracle.ldp.marginal_report): the points whose terminal decision sits inside a tolerance band, where
+libdaqp may legitimately end on another active set.  usage: tools/fuzz_parity.py [trials] [seed]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,6 +17,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 bad = 0
 stats = {"lane": 0, "wave": 0, "refused": 0, "f32": 0}
+marg = {"points": 0, "primal_marginal": 0, "dual_marginal": 0, "trials_with_marginal_points": 0}
 flags_seen = {}
 t0 = time.time()
 
@@ -28,6 +31,8 @@ def copy_settings(s):
 
 for trial in range(trials):
     n = int(rng.integers(1, 40)) if rng.random() < 0.3 else int(rng.integers(1, 15))
+    if trial % 25 == 24:
+        n = int(rng.integers(64, 101))             # long horizons: two variable slots per lane
     mg = int(rng.integers(0, 120)) if rng.random() < 0.3 else int(rng.integers(0, 46))
     ms = n if rng.random() < 0.7 else 0
     nth = int(rng.integers(0, 20))
@@ -94,10 +99,18 @@ for trial in range(trials):
         ok = np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= tol
     for k, c in zip(*np.unique(ef, return_counts=True)):
         flags_seen[int(k)] = flags_seen.get(int(k), 0) + int(c)
+    if not f32 and not bnb:
+        rep = oldp.marginal_report(L, theta)
+        marg["points"] += rep["solved"]
+        marg["primal_marginal"] += rep["primal_marginal"]; marg["dual_marginal"] += rep["dual_marginal"]
+        if rep["primal_marginal"] or rep["dual_marginal"]:
+            marg["trials_with_marginal_points"] += 1
+            print(f"marginal points in trial {trial} (n={n} m={m}): primal {rep['primal_marginal_first']} dual {rep['dual_marginal_first']}", flush=True)
     if not ok:
         bad += 1
         print(f"MISMATCH trial {trial}: n={n} ms={ms} mg={mg} nth={nth} nsoft={nsoft} f32={f32} kernel={qp.kernel_name}", flush=True)
     if trial % 100 == 99:
         print(f"trial {trial + 1}: {bad} mismatches, {stats}, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {trials} trials, {bad} mismatches, {stats}, exit flags {flags_seen}")
+print(f"marginal cases among the solved f64 points: {marg}")
 sys.exit(1 if bad else 0)
