@@ -274,7 +274,8 @@ def marginal_report(ldp: LDP, theta, settings: Settings | None = None, dual_band
     Slacks and multipliers are recomputed here from the final active set by a dense KKT solve in
     numpy (independent of the solver's recursions).  Returns counts and the first `max_list` indices."""
     s = settings if settings is not None else default_settings()
-    theta = np.ascontiguousarray(np.asarray(theta, float).reshape(-1, ldp.nth))
+    theta = np.asarray(theta, float)
+    theta = np.ascontiguousarray(theta.reshape(-1, ldp.nth) if ldp.nth else theta.reshape(len(theta), 0))
     X, ef, it, act = solve_batch(ldp, theta, s)
     m, n = ldp.m, ldp.n
     B = theta @ ldp.Dth.T                                  # shifts b_j per problem

@@ -323,3 +323,20 @@ def test_marginal_case_report_finds_a_constructed_marginal_point():
             lo = mid
     rep = oldp.marginal_report(L, np.vstack([th_in + (lo - 1e-9) * (th_out - th_in), th_in, th_out]))
     assert rep["primal_marginal"] == 1 and rep["primal_marginal_first"] == [0] and rep["dual_marginal"] == 0
+
+
+def test_bench_helpers_cover_every_workload():
+    """bench.py's synthetic inputs and bookkeeping (no GPU): every workload's theta has the width of its fixture,
+    the rotation defeats the 256 MiB Infinity Cache, the marginal report runs on a bench batch."""
+    import bench
+    for w, name in (("pendulum", "pendulum"), ("mass_spring_3in", "mass_spring_3in"), ("hybrid", "satellite20"),
+                    ("soft_doc", "soft_doc"), ("pendulum_N50", "pendulum_N50"), ("pendulum_N125", "pendulum_N125")):
+        g = bench.make_problem(name)
+        th = bench.make_theta(name, 257, 5, hard=False)
+        assert th.shape == (257, g["f_theta"].shape[1]) and th.flags.c_contiguous and np.isfinite(th).all()
+    assert bench.make_theta("pendulum", 64, 1, hard=True).std() > bench.make_theta("pendulum", 64, 1).std()
+    per = bench.algorithmic_bytes(7, 1)
+    assert per == 68
+    nrot = bench.rotation_depth(1_000_000, per)
+    assert nrot * 1_000_000 * per > 1.25 * bench.L3_BYTES and nrot <= 8
+    assert bench.rotation_depth(100, per) == 64           # tiny batches: the cap (everything is cache-resident anyway)
