@@ -408,6 +408,11 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * kernels.  All of them change the execution order only, never a result. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
+/* Staging and scratch buffers of a handle grow with the largest batch it has seen and are kept between calls.
+ * lmpc_release_scratch waits for the handle's GPU and gives them back (the constant pack stays; the next call
+ * allocates what it needs again, and a DAQP_WARMSTART state kept by lmpc_compute_control* is dropped). */
+int lmpc_release_scratch(lmpc_handle *h);
+
 void lmpc_free(lmpc_handle *h);
 
 /* Last error text of this handle (or of the failed setup call when h == NULL). */

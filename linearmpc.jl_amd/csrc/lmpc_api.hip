@@ -1222,7 +1222,15 @@ int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, 
 
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
-    return h->useWave ? "wave" : h->kname.c_str();
+    if (h->useWave) return "wave";
+    // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm
+    // starts, closed loop, generated-controller call) the two-kernel form
+    if (fast_covers(h)) {
+        thread_local std::string name;
+        name = "fast<" + std::to_string(h->laneN) + ">|" + h->kname;
+        return name.c_str();
+    }
+    return h->kname.c_str();
 }
 
 int lmpc_profile(lmpc_handle *h, int enable) {
@@ -1296,6 +1304,21 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         return LMPC_OK;
     }
     return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
+}
+
+int lmpc_release_scratch(lmpc_handle *h) {
+    if (!h) return LMPC_ERR_BADARG;
+    lmpc::DeviceScope scope;
+    if (scope.enter(h->device) != hipSuccess) return fail(h, LMPC_ERR_HIP, "lmpc_release_scratch: hipSetDevice");
+    (void)hipDeviceSynchronize();
+    auto rel = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    rel(h->sTheta); rel(h->sX); rel(h->sFlag); rel(h->sIter); rel(h->sAct); rel(h->sWarm); h->sCap = 0;
+    rel(h->dList); rel(h->dList2); rel(h->dList3); rel(h->dCount); h->listCap = 0; h->countSet = 0;
+    rel(h->simTheta); rel(h->simTheta2); rel(h->simU); rel(h->simFG); rel(h->simFlag); rel(h->simAct); rel(h->simK); h->simCap = 0;
+    rel(h->ccTheta); rel(h->ccAct); rel(h->ccFlag); h->ccCap = 0; h->ccWarmN = -1;
+    rel(h->ccStage); rel(h->ccStageFlag); h->ccStageCap = 0; h->ccStagePer = 0;
+    rel(h->ccObsScratch); h->ccObsCap = 0;
+    return LMPC_OK;
 }
 
 void lmpc_free(lmpc_handle *h) {

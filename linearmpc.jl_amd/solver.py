@@ -499,6 +499,10 @@ class BatchedQP:
         cnt = lib().lmpc_profile_read(self._h, ctypes.byref(ms))
         return cnt, ms[0], ms[1], ms[2]
 
+    def release_scratch(self):
+        """`lmpc_release_scratch`: give the staging / scratch buffers back (they grow with the largest batch)."""
+        check(lib().lmpc_release_scratch(self._h), self._h)
+
     def set_option(self, name: str, value: int):
         check(lib().lmpc_set_option(self._h, name.encode(), int(value)), self._h)
 

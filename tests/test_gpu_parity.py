@@ -1545,7 +1545,7 @@ def test_one_launch_kernel_matches_two_kernel_form_and_oracle(lmpc, n, nth):
     for spread, nout in ((0.3, 1), (1.5, n), (6.0, 1)):
         H, f, f_theta, bu, bl, W = _boxed_problem(rng, n, nth, spread)
         qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, np.zeros((0, n)), bu, bl, W, nout=nout)
-        assert qp.kernel_name.startswith("screen+lane")
+        assert qp.kernel_name.startswith(f"fast<{n}>|screen+lane")
         for N in (1, 63, 64, 65, 1500, 30011):
             theta = rng.normal(size=(N, nth))
             x, ef, it, act = _compare(qp, theta)                     # (fast path on by default) vs the oracle
@@ -1654,6 +1654,20 @@ def test_reference_preview_controller_three_ways(lmpc):
     ef = qa.compute_control(ctrl, theta[:, :2].copy(), reference=theta[:, 2:].copy())
     assert np.array_equal(ef, efa) and np.array_equal(ctrl, xa)
     assert np.array_equal(theta[0, 2:], g["r_traj"].T.reshape(-1))
+
+
+def test_release_scratch_between_batches(lmpc):
+    # staging buffers only grow; lmpc_release_scratch gives them back and the next call allocates again
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    theta = g["theta"]
+    a = qp.solve(theta)
+    out = qp.simulate(theta[:500, :4], 5, np.eye(4), np.zeros((4, 1)), r=theta[:500, 4:6])
+    qp.release_scratch()
+    b = qp.solve(theta)
+    out2 = qp.simulate(theta[:500, :4], 5, np.eye(4), np.zeros((4, 1)), r=theta[:500, 4:6])
+    assert all(np.array_equal(p_, q_) for p_, q_ in zip(a, b))
+    assert np.array_equal(out["U"], out2["U"]) and np.array_equal(out["x"], out2["x"])
 
 
 def test_caller_pinned_arrays(lmpc):

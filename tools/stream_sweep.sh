@@ -1,9 +1,17 @@
 #!/bin/bash
-# batches in flight (bench.py --streams) vs throughput on the headline batch
-for st in 1 2 3 4 5 6 8; do
-  echo -n "streams=$st  "
-  python bench.py --streams $st --no-cpu-baseline --no-single-launch --steps 600 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('value %.4g  ms/step %.5f  frac %.3f  enqueue %.4f' % (d['value'], d['ms_per_step'], r['frac'], r['host_enqueue_ms_per_step']))"
+# batches in flight x streaming wavefronts per workgroup of the one-launch kernel, cold HBM (bench.py's timed region)
+for st in 1 2 3 4 6; do
+  for ns in 3 4; do
+    echo -n "streams=$st fast_nstr=$ns  "
+    python - <<PY
+import sys, os
+sys.path.insert(0, os.getcwd())
+import torch, bench
+import linearmpc_jl_amd as lmpc
+W = bench.Workload(torch, lmpc, "pendulum", bench.BATCH, torch.device("cuda", 0), 0, 0, $st, options={"fast_nstr": $ns, "lane_block": 64})
+W.timed(300, 10)
+el = min(W.timed(900, 10) for _ in range(2))
+print("%.2f us/step = %.4g solves/s" % (1e6 * el / 900, bench.BATCH * 900 / el))
+PY
+  done
 done
