@@ -96,6 +96,15 @@ def rotation_depth(n_local, bytes_per):
     return int(min(64, max(2, math.ceil(1.25 * L3_BYTES / per_batch) + 1)))
 
 
+_T0 = time.perf_counter()
+_NATIVE_FLAGS = None
+
+
+def _phase(msg):
+    """Progress line on stderr (the default run takes a few minutes: GPU legs, then CPU baselines per config)."""
+    print(f"[bench {time.perf_counter() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -113,7 +122,10 @@ def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=
     process may use.  Built with -O3 -march=native on the machine that runs it.  A reported baseline,
     not the product path."""
     from oracle import ldp as oldp
-    flags = oldp.use_native()
+    global _NATIVE_FLAGS
+    if _NATIVE_FLAGS is None:
+        _NATIVE_FLAGS = oldp.use_native()          # compiled once per process
+    flags = _NATIVE_FLAGS
     dt_ = np.float32 if f32 else np.float64
     L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
     probe = min(256, theta.shape[0])
@@ -303,8 +315,10 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     """One of the other single-GPU BASELINE configurations, measured in the same process: one batch in
     flight on one stream (these kernels fill the chip by themselves), rotation past the Infinity Cache,
     roofline from the live HIP-event duration of a call."""
+    _phase(f"config {workload}: setup")
     w = Workload(torch, lmpc, workload, batch, dev, local_rank, 0, 1, f32=f32)
     dist_info, flop = w.work_distribution()
+    _phase(f"config {workload}: timed region")
     el = w.timed(steps, warmup)
     solo = w.single_launch(max(3, min(steps, 20)))
     value = batch * steps / el
@@ -329,6 +343,7 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
            "dtype": dtype, "batch": batch, "kernel": w.kernel, "rotating_batches": w.nrot,
            "workload": describe(w), **dist_info, "roofline": roof}
     if want_cpu:
+        _phase(f"config {workload}: cpu baseline")
         out["cpu_baseline"] = cpu_baseline(w.g, w.theta_h, w.nout, min_seconds=cpu_seconds, f32=f32,
                                            all_cores_seconds=cpu_seconds / 2)
     w.close()
@@ -481,6 +496,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    _phase("headline: buffers ready, warm-up")
     for k in range(args.warmup):
         step(k)
     drain()
@@ -603,8 +619,10 @@ def main():
                        **dist_info},
             "roofline": roof,
         }
+        _phase("headline: timed region and single-launch sections done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W.g, W.theta_h, nout, f32=args.f32, marginal=True)
+            _phase("headline: cpu baseline done")
             if "marginal_cases" in out["cpu_baseline"]:
                 out["config"]["marginal_cases"] = out["cpu_baseline"].pop("marginal_cases")
         # ---- the other single-GPU BASELINE configurations, same process (driver-timed as part of this run)

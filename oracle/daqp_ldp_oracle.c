@@ -606,6 +606,14 @@ void oracle_solve_batch(const oracle_ldp *p, const oracle_settings_abi *sabi, in
     work_free(w);
 }
 
+/* Timing front end (bench.py's cpu_baseline leg): the same batch `reps` times in one call, so that a
+ * many-thread measurement is not paced by the caller's interpreter lock between calls. */
+void ORACLE_NAME(oracle_solve_batch_repeat)(const oracle_ldp *p, const oracle_settings_abi *sabi, int64_t N,
+                                            const real *theta, real *X, int32_t *exitflag, int32_t *iters,
+                                            int32_t reps) {
+    for (int32_t r = 0; r < reps; r++) oracle_solve_batch(p, sabi, N, theta, NULL, X, exitflag, iters, NULL);
+}
+
 /* Closed loop, one scenario after the other: the reference's Simulation loop without observer
  * (/root/reference/src/simulation.jl:93-113): theta = [x; r; uprev] (src/explicit.jl:54-63),
  * u = compute_control, x <- F x + G u (sums in index order, F then G), uprev <- u.

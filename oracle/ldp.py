@@ -213,14 +213,14 @@ def runner(ldp: LDP, theta, settings: Settings | None = None, dtype=np.float64):
     arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (ldp.M, ldp.du0, ldp.dl0, ldp.Dth, ldp.Rout, ldp.x0, ldp.Xth)]
     c = _CLdp(ldp.n, ldp.m, ldp.ms, ldp.nth, ldp.nout, *(a.ctypes.data for a in arrs), ldp.sense.ctypes.data)
     s = settings if settings is not None else (default_settings_f32() if f32 else default_settings())
-    fn = L.oracle_solve_batch_f32 if f32 else L.oracle_solve_batch
-    args = (ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_void_p(theta.ctypes.data), None,
-            ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(ef.ctypes.data), ctypes.c_void_p(it.ctypes.data), None)
+    fn = L.oracle_solve_batch_repeat_f32 if f32 else L.oracle_solve_batch_repeat
+    fn.restype = None
+    args = (ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_void_p(theta.ctypes.data),
+            ctypes.c_void_p(X.ctypes.data), ctypes.c_void_p(ef.ctypes.data), ctypes.c_void_p(it.ctypes.data))
     keep = (theta, X, ef, it, arrs, c, s)
 
     def run(reps=1):
-        for _ in range(reps):
-            fn(*args)
+        fn(*args, ctypes.c_int32(int(reps)))          # ONE C call: the interpreter lock is released for all of it
         return keep[1]
     run.N = N
     return run
