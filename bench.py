@@ -105,6 +105,29 @@ def _phase(msg):
     print(f"[bench {time.perf_counter() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
+def _effective_cpus():
+    """Cores this process may really use: the affinity mask capped by the cgroup's CPU quota (a GPU box hands a
+    job a share of its host -- 16 of 256 logical CPUs for one GPU -- through the quota, not through the mask)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as fh:
+                q, per = parse(fh.read())
+            if per is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    per = fh.read().strip()
+            if q not in ("max", "-1") and float(per) > 0:
+                n = max(1, min(n, int(math.ceil(float(q) / float(per)))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -151,10 +174,7 @@ def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=
     # the same oracle on all host cores this process may use: the sample cut
     # into one contiguous slice per thread; every thread makes `reps` bare C calls over its slice (the C
     # call releases the GIL), all threads start together and the slowest one ends the measurement
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
+    ncores = _effective_cpus()
     if ncores > 1 and all_cores_seconds > 0:
         from concurrent.futures import ThreadPoolExecutor
         rate1 = out["value"]
@@ -171,7 +191,8 @@ def cpu_baseline(g, theta, nout, min_seconds=10.0, f32=False, all_cores_seconds=
             dta = time.perf_counter() - t0
         out["all_cores"] = {"value": reps * theta.shape[0] / dta, "unit": "solves/s", "cores": len(parts),
                             "sample": f"{reps} passes over the first {theta.shape[0]} points, one contiguous slice "
-                                      f"per thread, {len(parts)} threads"}
+                                      f"per thread, {len(parts)} threads = the CPUs this job may use "
+                                      f"(affinity mask capped by the cgroup quota; the host has {os.cpu_count()})"}
     if mrep is not None:
         out["marginal_cases"] = mrep
     return out
@@ -213,20 +234,36 @@ class Workload:
         for r_ in range(1, self.nrot):
             self.thetas.append(torch.from_numpy(make_theta(self.name, n_local, 7919 * r_ + 1234 + rank, self.hard))
                                .to(dev).to(self.tdt))
+        self._bound = {}
         self.nbuf = max(2, nstreams, self.nrot)
         self.xbuf = [torch.empty((n_local, self.nout), dtype=self.tdt, device=dev) for _ in range(self.nbuf)]
         self.fbuf = [torch.empty(n_local, dtype=torch.int32, device=dev) for _ in range(self.nbuf)]
+        if not f32:          # every (handle, batch, buffer) combination a run can meet, bound before any timing
+            for k in range(math.lcm(nstreams, self.nrot, self.nbuf)):
+                key = (k % nstreams, k % self.nrot, k % self.nbuf)
+                self._bound[key] = self.qps[key[0]].bind_device_call(self.thetas[key[1]], self.xbuf[key[2]], self.fbuf[key[2]],
+                                                                     self.stream_handles[key[0]])
 
     @property
     def kernel(self):
         return "wave" if self.f32 else self.qp.kernel_name
 
     def launch(self, k, sidx=None, resident=False):
-        """Enqueue step k on its stream (raw stream handle: no torch context switch)."""
+        """Enqueue step k on its stream (raw stream handle: no torch context switch).  The batches, buffers and
+        streams are a fixed set, so each (handle, batch, buffer) call is validated and marshalled once."""
         sidx = k % self.nstreams if sidx is None else sidx
-        th = self.thetas[0] if resident else self.thetas[k % self.nrot]
+        r_ = 0 if resident else k % self.nrot
         b = (k % max(2, self.nstreams)) if resident else (k % self.nbuf)
-        self.qps[sidx].solve_device(th, x=self.xbuf[b], exitflag=self.fbuf[b], stream=self.stream_handles[sidx])
+        key = (sidx, r_, b)
+        call = self._bound.get(key)
+        if call is None:
+            if self.f32:
+                call = (lambda q_=self.qps[sidx], th=self.thetas[r_], xb=self.xbuf[b], fb=self.fbuf[b], st=self.stream_handles[sidx]:
+                        q_.solve_device(th, x=xb, exitflag=fb, stream=st))
+            else:
+                call = self.qps[sidx].bind_device_call(self.thetas[r_], self.xbuf[b], self.fbuf[b], self.stream_handles[sidx])
+            self._bound[key] = call
+        call()
         return b
 
     def timed(self, steps, warmup, resident=False, nstreams=None):
@@ -286,6 +323,7 @@ class Workload:
                 "active_set_size_hist": np.bincount(nact, minlength=1).tolist()}, flop
 
     def close(self):
+        self._bound = {}
         for q_ in self.qps:
             q_.close()
         self.thetas = self.xbuf = self.fbuf = None
