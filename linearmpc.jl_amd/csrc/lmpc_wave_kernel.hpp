@@ -564,8 +564,18 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     R Mu[MR];
 #pragma unroll
                     for (int r = 0; r < MR; r++) Mu[r] = (R)0;
-                    constexpr int CHM = MR == 1 ? 8 : (MR == 2 ? 4 : 2);   // same register budget for any MR
-                    for (int k0 = 0; k0 < n; k0 += CHM) {
+#ifndef LMPC_WAVE_CHM_BIG
+#define LMPC_WAVE_CHM_BIG 4
+#endif
+                    // rows of M' fetched this many variables ahead of the chain: 8 x MR values in flight for the small
+                    // instantiations; the many-slot ones (MR >= 4: 256-thread workgroups, two wavefronts per SIMD at
+                    // most, M' too large for LDS) read it from L2 and were waiting on those loads for 57 % of their
+                    // cycles with two variables in flight (pendulum N = 125: rocprofv3 SQ_WAIT_ANY)
+                    constexpr int CHM = MR == 1 ? 8 : (MR == 2 ? 4 : (MR <= 8 ? LMPC_WAVE_CHM_BIG : 2));   // (16 slots: 4 would spill)
+                    // An empty working set gives u = +0 exactly, and every chain below then ends at +0 (fma(x, +0, +0)
+                    // = +0): the n-step pass is skipped.  That is the whole first iteration of every cold solve --
+                    // for a closed-loop batch, where most points need one to four iterations, a quarter of the kernel.
+                    for (int k0 = 0; k0 < (na > 0 ? n : 0); k0 += CHM) {
                         R mt[CHM][MR];
 #pragma unroll
                         for (int q = 0; q < CHM; q++) {
@@ -766,11 +776,13 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         }
 
         // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k writes outputs k, k + 64, ...
+        // (an empty final working set means u = +0 exactly: the R^-1 u chain then ends at +0 and is skipped)
+        const int nchain = (!BNB && na == 0) ? 0 : n;
         for (int o0 = 0; o0 < P.nout; o0 += 64) {
             R xs = (R)0;
             const int ko = o0 + lane;
             const int lout = ko < P.nout ? ko : P.nout - 1;
-            for (int c0 = 0; c0 < n; c0 += CH) {
+            for (int c0 = 0; c0 < nchain; c0 += CH) {
                 R rv[CH];
 #pragma unroll
                 for (int q = 0; q < CH; q++) rv[q] = C[P.oRout + (size_t)lout * n + (c0 + q < n ? c0 + q : n - 1)];
