@@ -1747,3 +1747,72 @@ def test_wave_kernel_two_variable_slots_random_problems(lmpc, n, mg, nsoft):
     ok = ef >= 1
     if ok.sum() > 4:
         _compare(qp, theta[ok][:48], warm=act[ok][:48])
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 and 5 at the sizes the bench runs
+def test_mass_spring_3in_full_size_properties(lmpc):
+    """BASELINE config 3 as worded (oscillating masses, 12 states / 3 inputs, Nc = 10) at its full 10^6 points,
+    through size-independent properties: every solved point satisfies all 84 two-sided constraints to primal_tol
+    (in the normalised units the solver works in) and is stationary on its reported active set; unsolved points
+    carry a DAQP failure flag; a strided sample of 3000 points agrees with the oracle bit for bit."""
+    import torch
+    import bench
+    from oracle import ldp as oldp
+    g = load_golden("mass_spring_3in")
+    n, N = g["H"].shape[0], 1_000_000
+    qp = _qp_from_golden(lmpc, g)
+    theta = bench.make_theta("mass_spring_3in", N, 77)
+    th_d = torch.from_numpy(theta).cuda()
+    it_d = torch.empty(N, dtype=torch.int32, device="cuda")
+    ac_d = torch.zeros((N, qp.words), dtype=torch.int64, device="cuda")
+    x_d, ef_d = qp.solve_device(th_d, iters=it_d, active=ac_d)
+    torch.cuda.synchronize()
+    x, ef = x_d.cpu().numpy(), ef_d.cpu().numpy()
+    assert set(np.unique(ef)) <= {1, -1, -2}, np.unique(ef)
+    ok = ef == 1
+    assert 0.2 < ok.mean() < 0.4                      # the bench line's solved_fraction (0.28) for this sampling
+    Afull = np.vstack([np.eye(n)[:qp.ms], g["A"]])
+    sc = np.linalg.norm(Afull @ np.linalg.inv(np.linalg.cholesky(g["H"]).T), axis=1)     # row norms of M before scaling
+    V = x[ok] @ Afull.T
+    hi = (g["bu"] + theta[ok] @ g["W"].T - V) / sc
+    lo = (V - (g["bl"] + theta[ok] @ g["W"].T)) / sc
+    assert min(hi.min(), lo.min()) > -1.01e-6
+    # stationarity on the reported active set, on a sample (dense KKT solve per point)
+    bits = ac_d.cpu().numpy().view(np.uint64)
+    idx = np.nonzero(ok)[0][::997][:300]
+    m = qp.m
+    for i in idx:
+        rows = [j for j in range(m) if (int(bits[i, j >> 6]) >> (j & 63)) & 1 or (int(bits[i, (m + j) >> 6]) >> ((m + j) & 63)) & 1]
+        grad = g["H"] @ x[i] + g["f"] + g["f_theta"] @ theta[i]
+        if rows:
+            lam = np.linalg.lstsq(Afull[rows].T, -grad, rcond=None)[0]
+            grad = grad + Afull[rows].T @ lam
+        assert np.abs(grad).max() < 1e-6 * max(1.0, np.abs(g["H"]).max())
+    sel = np.arange(0, N, 333)[:3000]
+    L = oracle_ldp_from(qp.ldp())
+    xo, efo, ito, acto = oldp.solve_batch(L, theta[sel])
+    assert np.array_equal(ef[sel], efo) and np.array_equal(it_d.cpu().numpy()[sel], ito) and np.array_equal(bits[sel], acto)
+    assert np.abs(x[sel] - xo).max() <= TOL
+
+
+def test_hybrid_f32_bench_size_properties(lmpc):
+    """BASELINE config 5 (hybrid MPC, binary32) at the bench's 10^5 points: every point solved, every binary input
+    on one of its bounds (the reference's own assertion, runtests.jl:831-834, at 1e-5), a sample bit-identical to
+    the binary32 oracle."""
+    import bench
+    from oracle import ldp as oldp
+    g = load_golden("satellite20")
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                  nout=g["H"].shape[0], settings=lmpc.default_settings_f32())
+    N = 100_000
+    theta = bench.make_theta("satellite20", N, 78).astype(np.float32)
+    x, ef, it, act = qp.solve_f32(theta)
+    assert np.all(ef == 1)
+    binary = (g["senses"] & 16) != 0
+    xb = x[:, :len(binary)][:, binary[:x.shape[1]]]
+    bu, bl = g["bu"][binary], g["bl"][binary]
+    assert np.all((np.abs(xb - bu) < 1e-5) | (np.abs(xb - bl) < 1e-5))
+    sel = np.arange(0, N, 211)[:400]
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], oldp.default_settings_f32(), dtype=np.float32)
+    assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
+    assert np.array_equal(x[sel], xo)
