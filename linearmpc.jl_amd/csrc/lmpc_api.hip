@@ -386,7 +386,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         h->asyncX = h->asyncR = h->asyncUp = nullptr;       // only the first pass forms theta
         if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
         return LMPC_OK;
-    } else if (screened && !sim && !gather && warm == nullptr && fast_covers(h)) {
+    } else if (screened && !sim && warm == nullptr && (!gather || active == nullptr) && fast_covers(h)) {
         // small boxed problems, cold plain solve: ONE kernel streams the batch and solves what needs iterations
         // (lmpc_fast_kernel.hpp); no work list, no second launch
         rc = launch_fast(h, nprob, theta, x, flag, iters, active, st);

@@ -24,7 +24,7 @@ bool fast_covers(const lmpc_handle *h) {
            h->S.iter_limit > kmax + 1 && h->S.cycle_tol >= kmax + 1;
 }
 
-template <int NTHMAX, int NT, int N>
+template <int NTHMAX, int NT, int N, bool GATHER>
 static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                          uint64_t *active, hipStream_t st) {
     // R tiles of 64 problems per workgroup: enough that a workgroup's queue fills a 64-problem claim several
@@ -50,7 +50,7 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
         HIP_TRY(h, hipMalloc(&h->dFastErr, eb));
         HIP_TRY(h, hipMemsetAsync(h->dFastErr, 0, eb, st));
     }
-    hipLaunchKernelGGL((fast_kernel<NTHMAX, NT, N>), dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
+    hipLaunchKernelGGL((fast_kernel<NTHMAX, NT, N, GATHER>), dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
                        active, (long long)nprob, R, nstr, h->dFastErr);
     HIP_TRY(h, hipGetLastError());
 #ifdef LMPC_FAST_TRACE
@@ -67,18 +67,19 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
 
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st) {
+    const bool gather = h->L.gat.state != nullptr;        // generated-controller call: theta from the five arrays
 #define LMPC_FN(NM, NT)                                                                                               \
     switch (h->laneN) {                                                                                               \
-        case 2: return launch_fast_t<NM, NT, 2>(h, nprob, theta, x, flag, iters, active, st);    \
-        case 3: return launch_fast_t<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, st);    \
-        case 4: return launch_fast_t<NM, NT, 4>(h, nprob, theta, x, flag, iters, active, st);    \
-        case 5: if constexpr (NT <= 8) return launch_fast_t<NM, NT, 5>(h, nprob, theta, x, flag, iters, active, st); break; \
+        case 2: return gather ? launch_fast_t<NM, NT, 2, true>(h, nprob, theta, x, flag, iters, active, st) : launch_fast_t<NM, NT, 2, false>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 3: return gather ? launch_fast_t<NM, NT, 3, true>(h, nprob, theta, x, flag, iters, active, st) : launch_fast_t<NM, NT, 3, false>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 4: return gather ? launch_fast_t<NM, NT, 4, true>(h, nprob, theta, x, flag, iters, active, st) : launch_fast_t<NM, NT, 4, false>(h, nprob, theta, x, flag, iters, active, st);    \
+        case 5: if constexpr (NT <= 8) return gather ? launch_fast_t<NM, NT, 5, true>(h, nprob, theta, x, flag, iters, active, st) : launch_fast_t<NM, NT, 5, false>(h, nprob, theta, x, flag, iters, active, st); break; \
         default: break;                                                                                               \
     }                                                                                                                 \
     break;
     switch (h->P.nth) {
 #ifdef LMPC_FAST_ONLY_PENDULUM
-        case 7: if (h->laneN == 5) return launch_fast_t<8, 7, 5>(h, nprob, theta, x, flag, iters, active, st); break;
+        case 7: if (h->laneN == 5) return gather ? launch_fast_t<8, 7, 5, true>(h, nprob, theta, x, flag, iters, active, st) : launch_fast_t<8, 7, 5, false>(h, nprob, theta, x, flag, iters, active, st); break;
 #else
         case 1: LMPC_FN(8, 1)   case 2: LMPC_FN(8, 2)   case 3: LMPC_FN(8, 3)   case 4: LMPC_FN(8, 4)
         case 5: LMPC_FN(8, 5)   case 6: LMPC_FN(8, 6)   case 7: LMPC_FN(8, 7)   case 8: LMPC_FN(8, 8)

@@ -49,7 +49,13 @@ __host__ __device__ constexpr size_t fast_lds_bytes(int N, int R) {
     return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64) + sizeof(int32_t) * ((size_t)R * 64 + 4);
 }
 
-template <int NTHMAX, int NT, int N>
+// GATHER: the generated controller's call (lmpc_compute_control*): theta is assembled from the five argument arrays
+// of mpc_compute_control (codegen/mpc_update_parameter.c) instead of read from a buffer, X is the caller's `control`
+// array -- read (previous control, first n_control_prev entries) and overwritten (u*).  A problem's control entries
+// are read by the wavefront that streams it and, if it needs iterations, once more by the lane that solves it; they
+// are written once, by whichever of the two finishes the problem -- after its own reads, so the in/out array needs
+// no copy.
+template <int NTHMAX, int NT, int N, bool GATHER = false>
 __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
@@ -85,9 +91,24 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
 
     auto load_record = [&](long long pid, double *dst) {
         const long long pc = pid < nprob ? pid : nprob - 1;
-        const double *src = theta + pc * nth;
+        if constexpr (GATHER) {
+            const GatherArgs &Ga = P.gat;      // theta = [state; reference; disturbance; control[0:nup]; parameter]; NULL = zeros
+            const int o1 = Ga.nx, o2 = o1 + Ga.nr, o3 = o2 + Ga.nd, o4 = o3 + Ga.nup;
 #pragma unroll
-        for (int t = 0; t < NT; t++) dst[t] = src[t];          // NT == nth (nth <= 16)
+            for (int t = 0; t < NT; t++) {
+                double v = 0.0;
+                if (t < o1) v = Ga.state[pc * Ga.nx + t];
+                else if (t < o2) { if (Ga.reference) v = Ga.reference[pc * Ga.nr + (t - o1)]; }
+                else if (t < o3) { if (Ga.disturbance) v = Ga.disturbance[pc * Ga.nd + (t - o2)]; }
+                else if (t < o4) { if (Ga.control) v = Ga.control[pc * Ga.ncontrol + (t - o3)]; }
+                else { if (Ga.parameter) v = Ga.parameter[pc * Ga.np + (t - o4)]; }
+                dst[t] = v;
+            }
+        } else {
+            const double *src = theta + pc * nth;
+#pragma unroll
+            for (int t = 0; t < NT; t++) dst[t] = src[t];      // NT == nth (nth <= 16)
+        }
     };
     auto write_x = [&](long long pid, const double (&th)[NT], const double (&u)[N], bool with_u) {
         const double *xk = C + P.oXthP;
