@@ -145,7 +145,35 @@ int finalize_handle(lmpc_handle *h) {
         HIP_TRY(h, hipMemcpy(h->dSw, P.sense.data(), sizeof(int32_t) * P.m, hipMemcpyHostToDevice));
     }
     fill_layout(h);
-    if (!laneOk) { h->kname = "wave"; return LMPC_OK; }
+    if (!laneOk) {
+        h->kname = "wave";
+        // The screening pass (lmpc_screen_kernel.hpp) also runs in front of the wavefront kernel: it needs the
+        // padded rows of Dth, the bounds and the output map, nothing else of the lane pack.  Rows that can never
+        // enter the working set get bounds that are never violated (the pass's own mask covers 64 rows).
+        bool initActive = false;
+        for (int j = 0; j < P.m; j++) initActive = initActive || (P.sense[j] & SENSE_ACTIVE);
+        if (anyBinary || initActive || P.nth < 1 || P.nth > 32) return LMPC_OK;
+        h->laneN = 0;
+        fill_layout(h);
+        const PackLayout &L = h->L;
+        std::vector<double> buf(h->nC, 0.0);
+        const int mp = (P.m + 3) & ~3;
+        for (int j = 0; j < mp; j++) {
+            const bool real = j < P.m && !(P.sense[j] & SENSE_IMMUTABLE);
+            if (real)
+                for (int t = 0; t < P.nth; t++) buf[L.oDthP + (size_t)j * L.nthp + t] = P.Dth[(size_t)j * P.nth + t];
+            buf[L.oBnd + 2 * j] = real ? P.du0[j] : 1e300;
+            buf[L.oBnd + 2 * j + 1] = real ? P.dl0[j] : -1e300;
+        }
+        for (int k = 0; k < P.nout; k++) {
+            buf[L.ox0 + k] = P.x0[k];
+            for (int t = 0; t < P.nth; t++) buf[L.oXthP + (size_t)k * L.nthp + t] = P.Xth[(size_t)k * P.nth + t];
+        }
+        HIP_TRY(h, hipMalloc(&h->dC, sizeof(double) * h->nC));
+        HIP_TRY(h, hipMemcpy(h->dC, buf.data(), sizeof(double) * h->nC, hipMemcpyHostToDevice));
+        h->screenPackOnly = true;
+        return LMPC_OK;
+    }
     h->laneN = 0;
     for (int s : kLaneSizes) if (s >= P.n) { h->laneN = s; break; }
     h->kname = "screen+lane<" + std::to_string(h->laneN) + ">";       // lmpc_kernel_name says "wave" while useWave is set
@@ -294,9 +322,81 @@ bool will_screen(const lmpc_handle *h, int64_t nprob) {
            h->P.nth <= 32 && nprob < (int64_t)0x7fffffff;
 }
 
+// ... and in front of the wavefront kernel?  (binary64 solves without binaries and without initially active rows:
+// what the pass finishes is exactly what the wavefront kernel's first iteration would finish, bit for bit)
+bool wave_screens(const lmpc_handle *h, int64_t nprob) {
+    if (!h->useWave || !h->screen || !h->screenWave || h->bnb || h->dC == nullptr) return false;
+    if (h->S.iter_limit <= 1 || h->P.nth < 1 || h->P.nth > 32 || nprob >= (int64_t)0x7fffffff) return false;
+    if (h->screenPackOnly) return true;                  // (checked at setup)
+    return h->L.eq_mask == 0ull;
+}
+
+int ensure_lists(lmpc_handle *h, int64_t nprob, hipStream_t st) {
+    if (nprob <= h->listCap) return LMPC_OK;
+    hipFree(h->dList); hipFree(h->dCount); hipFree(h->dList2); hipFree(h->dList3);
+    h->dList = h->dCount = h->dList2 = h->dList3 = nullptr; h->listCap = 0;
+    const size_t segCap = (size_t)lane_seg_cap(nprob);
+    HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
+    HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 3 * kShards * kCountStride));   // two alternating sets + the parked list's
+    HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st));
+    h->listCap = nprob;
+    h->countSet = 0;
+    return LMPC_OK;
+}
+
+#define LMPC_SCREEN_SWITCH(CALL)                                                                       \
+    switch (h->P.nth <= 16 ? h->P.nth : 32) { /* exact column count up to 16, padded beyond */        \
+        case 1: rc = CALL(8, 1); break;    case 2: rc = CALL(8, 2); break;                             \
+        case 3: rc = CALL(8, 3); break;    case 4: rc = CALL(8, 4); break;                             \
+        case 5: rc = CALL(8, 5); break;    case 6: rc = CALL(8, 6); break;                             \
+        case 7: rc = CALL(8, 7); break;    case 8: rc = CALL(8, 8); break;                             \
+        case 9: rc = CALL(16, 9); break;   case 10: rc = CALL(16, 10); break;                          \
+        case 11: rc = CALL(16, 11); break; case 12: rc = CALL(16, 12); break;                          \
+        case 13: rc = CALL(16, 13); break; case 14: rc = CALL(16, 14); break;                          \
+        case 15: rc = CALL(16, 15); break; case 16: rc = CALL(16, 16); break;                          \
+        default: rc = CALL(32, 32); break;                                                             \
+    }
+
+// wavefront-kernel handles: the streaming pass finishes what needs no iterations, the wavefront kernel walks the rest
+int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
+                         int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const int rc0 = ensure_lists(h, nprob, st);
+    if (rc0 != LMPC_OK) return rc0;
+    EventTriple ev{};
+    if (h->prof) {
+        HIP_TRY(h, pool_event(h, &ev.a));
+        HIP_TRY(h, pool_event(h, &ev.mid));
+        HIP_TRY(h, pool_event(h, &ev.b));
+        HIP_TRY(h, hipEventRecord(ev.a, st));
+    }
+    int32_t *cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+    int32_t *cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+    h->countSet ^= 1;
+    const bool wide = h->P.nout > 1 && h->P.nout <= 16;
+    int rc = LMPC_OK;
+#define LMPC_SCRW(NM, NT) (wide ? launch_screen<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                                : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+    LMPC_SCREEN_SWITCH(LMPC_SCRW)
+#undef LMPC_SCRW
+    if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
+    if (rc == LMPC_OK) {
+        h->waveList.list = h->dList; h->waveList.count = cnt_now; h->waveList.count_next = cnt_next;
+        h->waveList.seg_cap = lane_seg_cap(nprob);
+        rc = launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
+        h->waveList = WaveList{};
+    }
+    if (h->prof) {
+        if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    }
+    return rc;
+}
+
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
-    if (h->useWave) return launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
+    if (h->useWave)
+        return wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
+                                      : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
     // block size: the one that keeps most wavefronts resident per CU under the 160 KiB LDS cap
     int bestB = 0, bestWaves = -1;
     size_t bestLds = 0;
@@ -318,15 +418,9 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     // unconstrained optimum is feasible, everything else is queued with its mask)
     const bool screened = will_screen(h, nprob);
     static_assert((kShards & (kShards - 1)) == 0, "the screening kernel masks the shard index");
-    if (screened && nprob > h->listCap) {
-        hipFree(h->dList); hipFree(h->dCount); hipFree(h->dList2); hipFree(h->dList3);
-        h->dList = h->dCount = h->dList2 = h->dList3 = nullptr; h->listCap = 0;
-        const size_t segCap = (size_t)lane_seg_cap(nprob);
-        HIP_TRY(h, hipMalloc(&h->dList, sizeof(int32_t) * segCap * kShards));
-        HIP_TRY(h, hipMalloc(&h->dCount, sizeof(int32_t) * 3 * kShards * kCountStride));   // two alternating sets + the parked list's
-        HIP_TRY(h, hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st));
-        h->listCap = nprob;
-        h->countSet = 0;
+    if (screened) {
+        const int rc0 = ensure_lists(h, nprob, st);
+        if (rc0 != LMPC_OK) return rc0;
     }
     EventTriple ev{};
     if (h->prof) {
@@ -409,17 +503,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
                          : gather ? launch_screen<NM, NT, 2>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
                          : wide ? launch_screen<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
                                 : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
-        switch (h->P.nth <= 16 ? h->P.nth : 32) {       // exact column count up to 16, padded beyond
-            case 1: rc = LMPC_SCR(8, 1); break;    case 2: rc = LMPC_SCR(8, 2); break;
-            case 3: rc = LMPC_SCR(8, 3); break;    case 4: rc = LMPC_SCR(8, 4); break;
-            case 5: rc = LMPC_SCR(8, 5); break;    case 6: rc = LMPC_SCR(8, 6); break;
-            case 7: rc = LMPC_SCR(8, 7); break;    case 8: rc = LMPC_SCR(8, 8); break;
-            case 9: rc = LMPC_SCR(16, 9); break;   case 10: rc = LMPC_SCR(16, 10); break;
-            case 11: rc = LMPC_SCR(16, 11); break; case 12: rc = LMPC_SCR(16, 12); break;
-            case 13: rc = LMPC_SCR(16, 13); break; case 14: rc = LMPC_SCR(16, 14); break;
-            case 15: rc = LMPC_SCR(16, 15); break; case 16: rc = LMPC_SCR(16, 16); break;
-            default: rc = LMPC_SCR(32, 32); break;
-        }
+        LMPC_SCREEN_SWITCH(LMPC_SCR)
 #undef LMPC_SCR
     }
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
@@ -1266,6 +1350,7 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
 int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "screen_wave") == 0) { h->screenWave = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
     if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }

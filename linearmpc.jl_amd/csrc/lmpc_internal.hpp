@@ -20,9 +20,10 @@ constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
 constexpr int kWaveMaxN = 127, kWaveMaxCap = 64, kWaveMaxM = 1024;
-constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 
 struct EventTriple { hipEvent_t a, mid, b; };
+// work-list mode of the wavefront kernel for one launch (list == nullptr: the whole batch)
+struct WaveList { const int32_t *list = nullptr, *count = nullptr; int32_t *count_next = nullptr; long long seg_cap = 0; };
 }  // namespace lmpc
 
 struct lmpc_handle {
@@ -56,6 +57,9 @@ struct lmpc_handle {
     bool bnb = false;           // rows flagged BINARY: branch and bound in the wavefront kernel
     int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
     bool waveQueue = true;      // tuning: dynamic problem queue of the wave kernel (0 = static split)
+    lmpc::WaveList waveList{};  // set around a launch that follows the screening pass
+    int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
+    bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
     int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)

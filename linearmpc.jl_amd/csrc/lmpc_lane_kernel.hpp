@@ -31,8 +31,6 @@
 
 namespace lmpc {
 
-// work-list counters sit one per 128-byte line
-constexpr int kCountStride = 32;
 
 
 // Closed-loop tail of a finished problem (SimFuse): x+ = F x + G u with the sums in plant_kernel's /

@@ -131,7 +131,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
-    int32_t *__restrict__ queue, int qchunk, long long nprob) {
+    int32_t *__restrict__ queue, int qchunk, long long nprob,
+    const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
+    long long seg_cap) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -198,12 +200,40 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     // a tail of idle SIMDs).  The ticket for the next chunk is drawn at the start of the current one so
     // that its latency is hidden; the host sizes the chunk so that one counter word is never the
     // bottleneck (it serves ~90 atomics per microsecond).
+    //
+    // Work-list mode (list != nullptr): the screening pass in front (lmpc_screen_kernel.hpp) has finished every
+    // problem whose unconstrained optimum is feasible and left the others in the kShards segments of `list`
+    // (segment s: count[s * kCountStride] entries from list[s * seg_cap]).  Lane s holds segment s's count;
+    // a prefix sum over the lanes turns a position in the concatenated list into (segment, offset).  The
+    // problems then go through the same loop, position by position.
     const long long gwaves = (long long)gridDim.x * nwv;
+    long long ntotal = nprob;
+    int seg_end = 0, seg_beg = 0;
+    if (list != nullptr) {
+        static_assert(kShards == 64, "one work-list segment per lane");
+        // the counter set of the NEXT call is cleared here (the screening pass of that call adds to it)
+        if (count_next != nullptr && blockIdx.x == 0 && threadIdx.x < 64) count_next[threadIdx.x * kCountStride] = 0;
+        const int c = count[lane * kCountStride];
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        seg_end = incl; seg_beg = incl - c;
+        ntotal = (long long)__builtin_amdgcn_readlane(incl, 63);
+    }
     long long chunk = (long long)blockIdx.x * nwv + wv;
-    long long pid = chunk * qchunk;
+    long long idx = chunk * qchunk;
     int kin = 0, ticket = 0;
-    while (pid < nprob) {
+    while (idx < ntotal) {
         if (queue != nullptr && kin == 0 && lane == 0) ticket = atomicAdd(queue, 1);
+        long long pid = idx;
+        if (list != nullptr) {
+            const int sg = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(seg_end <= (int)idx)));   // segments that end at or before idx
+            const int off = (int)idx - __builtin_amdgcn_readlane(seg_beg, sg);
+            pid = (long long)__builtin_amdgcn_readfirstlane(list[(long long)sg * seg_cap + off]);
+        }
         const R *th = theta + pid * nth;
         R b[MR];                                 // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
         unsigned actb = 0u, lowb = 0u;           // bit r: slot r active / active at its lower bound
@@ -822,11 +852,11 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             if (iters) iters[pid] = iter;
         }
         if (++kin < qchunk) {
-            pid++;
+            idx++;
         } else {
             kin = 0;
             chunk = queue != nullptr ? gwaves + (long long)__builtin_amdgcn_readfirstlane(ticket) : chunk + gwaves;
-            pid = chunk * qchunk;
+            idx = chunk * qchunk;
         }
     }
 }

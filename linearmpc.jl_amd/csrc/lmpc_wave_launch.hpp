@@ -68,6 +68,7 @@ inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const WaveList &wl = h->waveList;                    // work-list mode (screening pass in front): see launch()
     const WaveLayout &Wl = h->W;
     auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU>;
     if (cfg.lds > 48 * 1024)
@@ -83,7 +84,12 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     // more than two problems per resident wavefront: hand them out through the shared counter
     int32_t *queue = nullptr;
     int qchunk = 1;
-    if (nprob > 2 * grid * cfg.nwv && nprob < (int64_t)0x7fffffff && h->waveQueue) {
+    if (wl.list != nullptr && h->waveQueue) {
+        // work-list mode: the length of the list is only known on the device -- one problem per ticket
+        if (!h->dQueue) HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
+        queue = h->dQueue;
+    } else if (nprob > 2 * grid * cfg.nwv && nprob < (int64_t)0x7fffffff && h->waveQueue) {
         // ~16 tickets per resident wavefront over the whole batch, at most 64 problems per ticket
         qchunk = (int)(nprob / (16 * grid * cfg.nwv));
         qchunk = qchunk < 1 ? 1 : (qchunk > 64 ? 64 : qchunk);
@@ -92,7 +98,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
         queue = h->dQueue;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
-                       iters, active, warm, queue, qchunk, (long long)nprob);
+                       iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }
@@ -101,7 +107,8 @@ template <typename R, bool BNB>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
-    if (h->prof) {
+    const bool prof = h->prof && h->waveList.list == nullptr;     // (behind the screening pass: launch_wave_screened's events)
+    if (prof) {
         HIP_TRY(h, pool_event(h, &ev.a));
         HIP_TRY(h, pool_event(h, &ev.mid));
         HIP_TRY(h, pool_event(h, &ev.b));
@@ -126,7 +133,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             else rc = LMPC_WVU(16);
 #undef LMPC_WVU
         }
-        if (h->prof) {
+        if (prof) {
             if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
             else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
         }
@@ -147,7 +154,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
 #undef LMPC_WV
 #undef LMPC_WV3
 #undef LMPC_WV4
-    if (h->prof) {
+    if (prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     }

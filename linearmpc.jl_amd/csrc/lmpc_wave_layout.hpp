@@ -4,6 +4,9 @@
 
 namespace lmpc {
 
+constexpr int kShards = 64;            // work-list segments (one atomic counter each)
+constexpr int kCountStride = 32;       // ... whose counters sit one per 128-byte line
+
 // Closed-loop mode of the lane / screening kernels (lmpc_simulate*): the kernel that finishes a
 // problem also advances its scenario -- x+ = F x + G u -- and writes the NEXT step's record
 // [x+; r; u] to theta_out, so a closed-loop step is the solve and nothing else.  FG == nullptr: off.

@@ -1816,3 +1816,42 @@ def test_hybrid_f32_bench_size_properties(lmpc):
     xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], oldp.default_settings_f32(), dtype=np.float32)
     assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
     assert np.array_equal(x[sel], xo)
+
+
+# ------------------------------------------------------------------ screening pass in front of the wavefront kernel
+@pytest.mark.parametrize("n,mg,nth,nsoft,nout,imm,seed", [
+    (20, 30, 6, 0, 1, False, 0),       # m = 50: one constraint slot per lane
+    (16, 120, 7, 12, 3, True, 1),      # m = 136, soft rows, immutable rows below and above row 64, transposed stores
+    (40, 300, 20, 0, 20, True, 2),     # m = 340, padded parameter columns (nth > 16), more than 16 outputs
+    (100, 60, 5, 0, 2, False, 3),      # two variable slots per lane
+    (13, 3, 1, 1, 1, False, 4),        # one parameter
+])
+def test_screening_pass_in_front_of_wave_kernel(lmpc, n, mg, nth, nsoft, nout, imm, seed):
+    # A wavefront-kernel problem whose unconstrained optimum is feasible ends in its first iteration; the streaming
+    # pass finishes those and hands the wavefront kernel a work list of the others.  Which kernel finishes a problem
+    # must not change one bit: screened == unscreened == oracle, cold and warm, at batch sizes around the tile edges.
+    rng = np.random.default_rng(4200 + seed)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=nsoft)
+    if imm:
+        sense[[3, n + 70, n + mg - 1]] |= 4        # IMMUTABLE: never enters the working set, may be violated
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nout)
+    assert qp.kernel_name == "wave"
+    for N in (1, 63, 257, 3000):
+        # a mix: most points close to the origin (nothing violated), some far out (iterations needed)
+        theta = rng.standard_normal((N, nth)) * np.where(rng.random(N) < 0.6, 0.05, 1.5)[:, None]
+        qp.set_option("screen_wave", 0)
+        x0, ef0, it0, act0 = qp.solve(theta)
+        qp.set_option("screen_wave", 1)
+        x1, ef1, it1, act1 = _compare(qp, theta)
+        assert np.array_equal(x0, x1) and np.array_equal(ef0, ef1) and np.array_equal(it0, it1)
+        assert np.array_equal(act0, act1)
+        if N == 3000:
+            settled = (it1 == 1) & (ef1 == 1)
+            assert 0.1 < settled.mean() < 0.99, settled.mean()     # both kernels had work
+            ok = ef1 >= 1
+            xw, efw, itw, actw = _compare(qp, theta[ok], warm=act1[ok])
+            assert np.array_equal(efw, ef1[ok])
+    # consecutive calls alternate the two counter sets; a batch with nothing to iterate leaves an empty list
+    xz, efz, itz, actz = qp.solve(np.zeros((500, nth)))
+    assert np.all(efz == 1) and np.all(itz == 1) and not actz.any()
+    _compare(qp, rng.standard_normal((200, nth)) * 2.0)
