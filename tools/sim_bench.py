@@ -23,12 +23,22 @@ ap.add_argument("--fused", type=int, default=1, help="plant step inside the solv
 ap.add_argument("--groups", type=int, default=1,
                 help="split the scenarios into this many groups, each with its own handle, HIP stream and host thread "
                      "(scenarios are independent: the groups' kernels overlap on the chip)")
+ap.add_argument("--problem", default="pendulum",
+                help="golden fixture: pendulum (lane kernels) or pendulum_N50/75/100/125 (long horizon with state "
+                     "constraints: wavefront kernel, lock-step loop)")
+ap.add_argument("--screen-wave", type=int, default=1, help="screening pass in front of the wavefront kernel")
 a = ap.parse_args()
-g = dict(np.load(os.path.join(ROOT, "tests", "golden", "pendulum.npz")))
+g = dict(np.load(os.path.join(ROOT, "tests", "golden", a.problem + ".npz")))
 sys.path.insert(0, ROOT)
-from oracle import mpc2mpqp as omm
-prob = omm.pendulum()
+if "F" in g:
+    class prob: F, G = g["F"], g["G"]
+else:
+    from oracle import mpc2mpqp as omm
+    prob = omm.pendulum()
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+print("kernel:", qp.kernel_name)
+if qp.kernel_name == "wave":
+    qp.set_option("screen_wave", a.screen_wave)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
 qp.set_option("sim_small", a.small)
@@ -37,15 +47,23 @@ if a.blind >= 0:
 rng = np.random.default_rng(0)
 N, T = a.n, a.steps
 dev = torch.device("cuda", 0)
-x0 = torch.from_numpy(rng.uniform([-5, -5, -0.3, -2], [5, 5, 0.3, 2], (N, 4))).to(dev)
-r = torch.from_numpy(np.hstack([rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1))])).to(dev)
+if "n_closed_loop" in g:      # the benchmark class: start from points one closed loop visits, perturbed
+    base = g["theta"][:int(g["n_closed_loop"])]
+    pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+    x0 = torch.from_numpy(np.ascontiguousarray(pick[:, :4])).to(dev)
+    r = torch.from_numpy(np.ascontiguousarray(pick[:, 4:6])).to(dev)
+    up0 = torch.from_numpy(np.ascontiguousarray(pick[:, 6:7])).to(dev)
+else:
+    x0 = torch.from_numpy(rng.uniform([-5, -5, -0.3, -2], [5, 5, 0.3, 2], (N, 4))).to(dev)
+    r = torch.from_numpy(np.hstack([rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1))])).to(dev)
+    up0 = torch.zeros((N, 1), dtype=torch.float64, device=dev)
 F = np.ascontiguousarray(prob.F); G = np.ascontiguousarray(prob.G)
 vp = ctypes.c_void_p
 fm = torch.empty(N, dtype=torch.int32, device=dev)
 Ut = torch.empty((T, N, 1), dtype=torch.float64, device=dev) if a.traj else None
 Xt = torch.empty((T + 1, N, 4), dtype=torch.float64, device=dev) if a.traj else None
 for rep in range(a.reps):
-    x = x0.clone(); up = torch.zeros((N, 1), dtype=torch.float64, device=dev)
+    x = x0.clone(); up = up0.clone()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     check(lib().lmpc_simulate_device(qp._h, N, T, 4, 2, 1, vp(F.ctypes.data), vp(G.ctypes.data), vp(x.data_ptr()),
