@@ -399,7 +399,10 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * runs the iterations underneath (0 = the two-kernel form below); "fast_nstr" 1..4 = streaming wavefronts per
  * workgroup of that kernel (default 3; 4 suits several batches in flight); "lane_straight" (default 1) =
  * straight-line first tier in the boxed iterating kernels.  "screen" (default 1) = run cold-start batches through the streaming
- * screening pass before the iterating kernel; 0 = iterating kernel only.  Results are
+ * screening pass before the iterating kernel; 0 = iterating kernel only.  "screen_wave" (default 1) = the same pass in
+ * front of the wavefront kernel (binary64 problems without binary rows and without initially active rows, 1..32
+ * parameters): it finishes every problem whose unconstrained optimum is feasible -- what the wavefront kernel's first
+ * iteration would do -- and the wavefront kernel walks a work list of the others.  Results are
  * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
  * advance independently of each other (rounds of a streaming kernel and the iterating kernel),
  * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two

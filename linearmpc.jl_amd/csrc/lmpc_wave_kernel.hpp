@@ -125,8 +125,17 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 // NU = 2 takes the condensed problems of long horizons, n up to 127 -- the reference's own benchmark sweeps
 // Np = Nc = 50 .. 125 with one input, docs/src/manual/benchmark.md:4).  The working set still lives on the 64
 // lanes: a point whose working set wants more rows ends with EXIT_WSCAP.
+// threads per workgroup an instantiation is register-budgeted for (512 VGPRs per SIMD lane are shared by the
+// resident wavefronts: 1024 threads -> 4 wavefronts per SIMD, 128 VGPRs; 768 -> 3, 168; 512 -> 2, 256; 256 -> 1)
+#ifndef LMPC_WAVE_LB3
+#define LMPC_WAVE_LB3 768
+#endif
+__host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB) {
+    return MR >= 7 ? 256 : (MR >= 4 || BNB) ? 512 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB);
+}
+
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
-__global__ __launch_bounds__(MR >= 8 ? 256 : ((MR >= 4 || BNB) ? 512 : LMPC_WAVE_LB))
+__global__ __launch_bounds__(wave_launch_bound(MR, BNB))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,

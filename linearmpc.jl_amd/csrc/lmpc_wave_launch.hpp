@@ -15,6 +15,28 @@ inline size_t wave_shared_bytes(const HostPack &P, int level, size_t rs) {
 
 struct WaveConfig { int nwv, level, blocksPerCU; size_t lds; bool packed; };
 
+// constraint slots per lane of the instantiation that takes m rows: 1, 2, 3, 4, 5, 6, 8 or 16 (branch and bound:
+// 1, 2, 4, 8, 16).  Every slot costs registers and a pass over it in each row loop, so 3 / 5 / 6 exist next to the
+// powers of two: the reference's benchmark class has m = 148 / 223 / 298 / 373 rows (Np = 50 / 75 / 100 / 125).
+inline int wave_slots(int m, bool bnb) {
+    const int need = (m + 63) / 64;
+    if (need <= 2) return need < 1 ? 1 : need;
+    if (need == 3) return bnb ? 4 : 3;
+    if (need == 4) return 4;
+    if (need <= 6) return bnb ? 8 : need;
+    return need <= 8 ? 8 : 16;
+}
+// resident wavefronts per CU the instantiation's registers allow (`make asm`, kernel-resource-usage): 128 VGPRs for
+// 1-2 slots (4 per SIMD), 168 for 3 (3 per SIMD), up to 256 for 4-6 (2 per SIMD); 8 slots fit 256 only in the square
+// layout with one variable slot, otherwise -- and with 16 slots -- one wavefront per SIMD
+inline int wave_max_resident(int slots, bool bnb, size_t rs, bool packed, int nu) {
+    if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
+    if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
+    if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
+    if (slots <= 6) return 8;
+    return (slots == 8 && !packed && nu == 1) ? 8 : 4;
+}
+
 // Workgroup shape of the wave kernel: nwv wavefronts (= problems in flight) share one LDS copy of
 // the problem data.  Registers allow 4 wavefronts per SIMD (16 per CU; 12 for the 512-thread
 // instantiations); the per-wave factors and the shared copy compete for the 160 KiB of LDS.
@@ -28,21 +50,17 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     const size_t perWave = rs * (packed ? ((size_t)Wl.cap * (Wl.cap - 1) / 2) : ((size_t)Wl.cap * Wl.ldc));
     // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
     // (more registers per lane, fewer resident wavefronts)
-    const bool big = (h->P.m > 128) || h->bnb;
-    // resident wavefronts per CU the instantiation's registers allow (see `make asm`): 16 for the plain
-    // ones and for binary32 B&B with m <= 64, 12 for binary64 B&B (m <= 128) and binary32 B&B (m <= 128),
-    // 8 beyond
-    const int maxNwv = h->P.m > 256 ? 4 : (big ? 8 : (LMPC_WAVE_LB >= 1024 ? 16 : 8));
-    int maxWaves = LMPC_WAVE_LB >= 1024 ? 16 : 12;
-    if (h->P.m > 256) maxWaves = (h->P.m <= 512 && !h->bnb) ? 8 : 4;   // 8 / 16 slots: 2 / 1 wavefronts per SIMD
-    else if (h->P.m > 128) maxWaves = 8;
-    else if (h->bnb) maxWaves = (rs == 4 && h->P.m <= 64) ? 16 : 12;
+    const int slots = wave_slots(h->P.m, h->bnb);
+    const int maxNwv = wave_launch_bound(slots, h->bnb) / 64;          // workgroup size the kernel is built for
+    const int maxWaves = wave_max_resident(slots, h->bnb, rs, packed, h->P.n > 64 ? 2 : 1);
     WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
     // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
-    for (int level = h->P.n > 64 ? 0 : ((packed || h->P.m > 256) ? 1 : 3); level >= 0; level--) {
-        if (h->waveLevel >= 0 && level != ((packed || h->P.m > 256) && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
-        for (int nwv : {4, 8, 16, 2, 1}) {
+    // (packed, the 3 / 5 / 6-slot instantiations and everything beyond 256 rows are built for levels 0 and 1 only)
+    const bool twoLevels = packed || h->P.m > 256 || slots == 3;
+    for (int level = h->P.n > 64 ? 0 : (twoLevels ? 1 : 3); level >= 0; level--) {
+        if (h->waveLevel >= 0 && level != (twoLevels && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
+        for (int nwv : {4, 8, 16, 12, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
             const size_t lds = perWave * nwv + wave_shared_bytes(h->P, level, rs);
@@ -116,7 +134,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
         HIP_TRY(h, hipEventRecord(ev.mid, st));
     }
     int rc;
-    const int mr = (h->P.m + 63) / 64;
+    const int mr = wave_slots(h->P.m, BNB);
     const WaveConfig cfg = wave_config(h, sizeof(R));
     if (BNB) warm = nullptr;                              // a B&B node takes its start from the search, not the caller
     // long horizons (64 <= n <= 127): two variable slots per lane; built without LDS staging of the problem data
@@ -128,7 +146,10 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
 #define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
                                   : launch_wave_cfg<R, MRR, 0, false, false, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
             if (mr <= 2) rc = LMPC_WVU(2);
-            else if (mr <= 4) rc = LMPC_WVU(4);
+            else if (mr == 3) rc = LMPC_WVU(3);
+            else if (mr == 4) rc = LMPC_WVU(4);
+            else if (mr == 5) rc = LMPC_WVU(5);
+            else if (mr == 6) rc = LMPC_WVU(6);
             else if (mr <= 8) rc = LMPC_WVU(8);
             else rc = LMPC_WVU(16);
 #undef LMPC_WVU
@@ -147,9 +168,14 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
                                   : (cfg.level >= 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
-    else if (mr <= 4) rc = LMPC_WV(4);
-    else if (mr <= 8) rc = LMPC_WVB(8);
-    else rc = LMPC_WVB(16);
+    else if (mr == 4) rc = LMPC_WV(4);
+    else if (mr == 8) rc = LMPC_WVB(8);
+    else if (mr == 16) rc = LMPC_WVB(16);
+    else if constexpr (!BNB) {                            // 3, 5, 6 slots (never chosen for branch and bound)
+        if (mr == 3) rc = LMPC_WVB(3);
+        else if (mr == 5) rc = LMPC_WVB(5);
+        else rc = LMPC_WVB(6);
+    } else rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no wavefront-kernel instantiation");
 #undef LMPC_WVB
 #undef LMPC_WV
 #undef LMPC_WV3
