@@ -130,8 +130,14 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 #ifndef LMPC_WAVE_LB3
 #define LMPC_WAVE_LB3 768
 #endif
+#ifndef LMPC_WAVE_LB4
+#define LMPC_WAVE_LB4 512
+#endif
+#ifndef LMPC_WAVE_CHM5
+#define LMPC_WAVE_CHM5 LMPC_WAVE_CHM_BIG
+#endif
 __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB) {
-    return MR >= 7 ? 256 : (MR >= 4 || BNB) ? 512 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB);
+    return MR >= 7 ? 256 : (MR >= 5 || BNB) ? 512 : (MR == 4 ? LMPC_WAVE_LB4 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB));
 }
 
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
@@ -610,7 +616,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     // instantiations; the many-slot ones (MR >= 4: 256-thread workgroups, two wavefronts per SIMD at
                     // most, M' too large for LDS) read it from L2 and were waiting on those loads for 57 % of their
                     // cycles with two variables in flight (pendulum N = 125: rocprofv3 SQ_WAIT_ANY)
-                    constexpr int CHM = MR == 1 ? 8 : (MR == 2 ? 4 : (MR <= 8 ? LMPC_WAVE_CHM_BIG : 2));   // (16 slots: 4 would spill)
+                    constexpr int CHM = MR == 1 ? 8 : (MR == 2 ? 4 : (MR == 5 ? LMPC_WAVE_CHM5 : (MR <= 8 ? LMPC_WAVE_CHM_BIG : 2)));   // (16 slots: 4 would spill)
                     // An empty working set gives u = +0 exactly, and every chain below then ends at +0 (fma(x, +0, +0)
                     // = +0): the n-step pass is skipped.  That is the whole first iteration of every cold solve --
                     // for a closed-loop batch, where most points need one to four iterations, a quarter of the kernel.

@@ -33,6 +33,7 @@ inline int wave_max_resident(int slots, bool bnb, size_t rs, bool packed, int nu
     if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
     if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
     if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
+    if (slots == 4) return LMPC_WAVE_LB4 >= 768 ? 12 : 8;
     if (slots <= 6) return 8;
     return (slots == 8 && !packed && nu == 1) ? 8 : 4;
 }
