@@ -34,6 +34,8 @@ for trial in range(trials):
     if trial % 25 == 24:
         n = int(rng.integers(64, 101))             # long horizons: two variable slots per lane
     mg = int(rng.integers(0, 120)) if rng.random() < 0.3 else int(rng.integers(0, 46))
+    if trial % 10 == 9:
+        mg = int(rng.integers(120, 380))           # 3 .. 6 constraint slots per lane
     ms = n if rng.random() < 0.7 else 0
     nth = int(rng.integers(0, 20))
     if ms + mg == 0:
