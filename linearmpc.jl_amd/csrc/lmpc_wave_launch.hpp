@@ -27,15 +27,15 @@ inline int wave_slots(int m, bool bnb) {
     return need <= 8 ? 8 : 16;
 }
 // resident wavefronts per CU the instantiation's registers allow (`make asm`, kernel-resource-usage): 128 VGPRs for
-// 1-2 slots (4 per SIMD), 168 for 3 (3 per SIMD), up to 256 for 4-6 (2 per SIMD); 8 slots fit 256 only in the square
-// layout with one variable slot, otherwise -- and with 16 slots -- one wavefront per SIMD
-inline int wave_max_resident(int slots, bool bnb, size_t rs, bool packed, int nu) {
+// 1-2 slots (4 per SIMD), 168 for 3 (3 per SIMD), up to 256 for 4-6 (2 per SIMD); 8 slots fit 256 only
+// with M' staged in LDS (level >= 1) and one variable slot, otherwise -- and with 16 slots -- one wavefront per SIMD
+inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu) {
     if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
     if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
     if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
     if (slots == 4) return LMPC_WAVE_LB4 >= 768 ? 12 : 8;
     if (slots <= 6) return 8;
-    return (slots == 8 && !packed && nu == 1) ? 8 : 4;
+    return (slots == 8 && level >= 1 && nu == 1) ? 8 : 4;
 }
 
 // Workgroup shape of the wave kernel: nwv wavefronts (= problems in flight) share one LDS copy of
@@ -53,7 +53,6 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     // (more registers per lane, fewer resident wavefronts)
     const int slots = wave_slots(h->P.m, h->bnb);
     const int maxNwv = wave_launch_bound(slots, h->bnb) / 64;          // workgroup size the kernel is built for
-    const int maxWaves = wave_max_resident(slots, h->bnb, rs, packed, h->P.n > 64 ? 2 : 1);
     WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
     // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
@@ -61,6 +60,7 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     const bool twoLevels = packed || h->P.m > 256 || slots == 3;
     for (int level = h->P.n > 64 ? 0 : (twoLevels ? 1 : 3); level >= 0; level--) {
         if (h->waveLevel >= 0 && level != (twoLevels && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
+        const int maxWaves = wave_max_resident(slots, h->bnb, rs, level, h->P.n > 64 ? 2 : 1);
         for (int nwv : {4, 8, 16, 12, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
