@@ -348,9 +348,12 @@ def test_wave_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
 
 
 @pytest.mark.parametrize("n,mg,nth,nsoft,seed", [(8, 300, 3, 0, 11), (20, 480, 5, 60, 12), (40, 984, 4, 100, 13),
-                                                 (10, 500, 6, 200, 14)])
+                                                 (10, 500, 6, 200, 14),
+                                                 (20, 150, 6, 0, 15), (70, 100, 5, 0, 16),       # 3 slots, one / two variable slots
+                                                 (30, 270, 6, 30, 17), (80, 230, 4, 0, 18),      # 5 slots
+                                                 (50, 330, 7, 0, 19), (100, 273, 7, 0, 20)])     # 6 slots (N = 125 of the benchmark class: m = 373)
 def test_wave_kernel_many_rows(lmpc, n, mg, nth, nsoft, seed):
-    # 256 < m <= 1024: the 8- and 16-slot instantiations (long prediction horizons with output bounds);
+    # 128 < m <= 1024: the 3-, 5-, 6-, 8- and 16-slot instantiations (long prediction horizons with output bounds);
     # n + 1 + #soft may exceed the 64 lanes as long as the working sets themselves stay below
     rng = np.random.default_rng(seed)
     H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
