@@ -555,15 +555,11 @@ def main():
             gather_to_root(xbuf[0], fbuf[0])
     fence()
     # ---- the timed region: EXACTLY args.steps steps between two barrier + synchronize fences
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    # (nothing but the steps inside: the per-stream event spans behind `stream_call_ms` are taken in an untimed
+    # repeat below -- six event records cost a 20-step run 5 % of its wall time)
     t0 = time.perf_counter()
-    for e_, s_ in zip(ev0, streams):
-        e_.record(s_)
     for k in range(args.steps):
         step(k)
-    for e_, s_ in zip(ev1, streams):
-        e_.record(s_)
     enqueue_s = time.perf_counter() - t0          # host time to issue all steps (diagnostic)
     drain()
     if final_gather and args.steps:
@@ -572,9 +568,21 @@ def main():
         gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
     fence()
     elapsed = time.perf_counter() - t0
-    # average device time of one launch on its stream = event span of the stream / its launches
-    calls_on = [len(range(i_, args.steps, nstreams)) for i_ in range(nstreams)]
-    span_ms = [ev0[i_].elapsed_time(ev1[i_]) for i_ in range(nstreams)]
+    # average device time of one launch on its stream = event span of the stream / its launches (diagnostic,
+    # untimed repeat of the same steps, at most 200 of them)
+    nrep = min(args.steps, 200)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+    for e_, s_ in zip(ev0, streams):
+        e_.record(s_)
+    for k in range(nrep):
+        step(k)
+    for e_, s_ in zip(ev1, streams):
+        e_.record(s_)
+    drain()
+    fence()
+    calls_on = [len(range(i_, nrep, nstreams)) for i_ in range(nstreams)]
+    span_ms = [ev0[i_].elapsed_time(ev1[i_]) if calls_on[i_] else 0.0 for i_ in range(nstreams)]
     stream_call_ms = sum(span_ms) / max(sum(calls_on), 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

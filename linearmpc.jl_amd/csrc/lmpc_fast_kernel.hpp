@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             for (int i = 0; i < KMAX; i++)
                 if (i < nact) { act |= 1ull << wrow[i]; if (wlow[i]) low |= 1ull << wrow[i]; }
         }
+#ifndef LMPC_FAST_NO_FALLBACK      // (diagnostic build without it: what the tiers and the stream need on their own)
         if (mine && !solved) {
             // the generic loop of lane_kernel on the lanes the tiers did not finish (from scratch)
 #pragma unroll
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             for (int c = 0; c < N; c++) u[c] = s.u[c];
             flag = s.flag; iter = s.iter; act = s.act; low = s.low;
         }
+#endif
         if (mine) {
             if (P.nout == 1) {
                 double xs = 0.0;
