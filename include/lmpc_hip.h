@@ -15,9 +15,10 @@
  *  - exit flags per problem use DAQP's sign convention (reference asserts exitflag >= 1,
  *    utils.jl:46):  1 optimal, 2 soft-optimal, -1 infeasible, -2 cycle, -3 unbounded,
  *    -4 iteration limit, -5 non-convex, -6 over-determined initial working set.  One flag is this
- *    library's own: -7 = the working set would have outgrown the 64 rows the wavefront kernel
- *    holds (only problems with n + 1 + #SOFT rows > 64 can get it; like every flag < 1 it fails
- *    the reference's assertion).
+ *    library's own: -7 = the working set outgrew what the kernels hold.  The wavefront kernel keeps 64 rows; a
+ *    point that wants more is re-solved behind it by a one-problem-per-thread kernel with room for 256, so -7 is
+ *    left only beyond 256 rows, for hybrid problems (branch and bound) with n + 1 + #SOFT > 64, and under
+ *    lmpc_set_option("big_path", 0).  Like every flag < 1 it fails the reference's assertion.
  *  - sense bit flags are DAQP's (reference mpc2mpqp.jl:868-885): 1 ACTIVE, 2 LOWER,
  *    4 IMMUTABLE, 5 EQUALITY (=ACTIVE|IMMUTABLE), 8 SOFT, 16 BINARY.  A problem with BINARY rows
  *    (hybrid MPC, mpQP.has_binaries) is solved by branch and bound: every BINARY row ends up
@@ -402,7 +403,9 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * screening pass before the iterating kernel; 0 = iterating kernel only.  "screen_wave" (default 1) = the same pass in
  * front of the wavefront kernel (binary64 problems without binary rows and without initially active rows, 1..32
  * parameters): it finishes every problem whose unconstrained optimum is feasible -- what the wavefront kernel's first
- * iteration would do -- and the wavefront kernel walks a work list of the others.  Results are
+ * iteration would do -- and the wavefront kernel walks a work list of the others.  "big_path" (default 1) = points
+ * whose working set outgrows the wavefront kernel's 64 rows are re-solved by the one-problem-per-thread kernel
+ * (0 = they keep exit flag -7).  Results are
  * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
  * advance independently of each other (rounds of a streaming kernel and the iterating kernel),
  * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two

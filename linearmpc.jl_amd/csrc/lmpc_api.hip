@@ -94,6 +94,7 @@ int finalize_handle(lmpc_handle *h) {
     // working-set capacity: n hard rows + 1 (the row that makes it singular) + the soft rows, but never
     // more than the 64 lanes; a problem that wants more rows at once ends with exit flag -7
     const int cap = std::min(P.n + 1 + P.nsoft, kWaveMaxCap);
+    h->capFull = P.n + 1 + P.nsoft;
     const bool waveOk = P.n <= kWaveMaxN && P.m <= kWaveMaxM && P.m >= 1;
     if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,
@@ -1351,6 +1352,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (!h || !name) return LMPC_ERR_BADARG;
     if (std::strcmp(name, "screen") == 0) { h->screen = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "screen_wave") == 0) { h->screenWave = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "big_path") == 0) { h->bigPath = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
     if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
@@ -1403,6 +1405,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccTheta); rel(h->ccAct); rel(h->ccFlag); h->ccCap = 0; h->ccWarmN = -1;
     rel(h->ccStage); rel(h->ccStageFlag); h->ccStageCap = 0; h->ccStagePer = 0;
     rel(h->ccObsScratch); h->ccObsCap = 0;
+    rel(h->dOvfList); h->ovfCap = 0; rel(h->dBigR); rel(h->dBigI);
     return LMPC_OK;
 }
 
@@ -1414,6 +1417,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
+    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch); hipFree(h->dFastErr);

@@ -61,6 +61,12 @@ struct lmpc_handle {
     int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
     bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;
+    // slow path for working sets beyond the 64 lanes (lmpc_big_kernel.hpp): overflow list + counter, per-thread scratch
+    int capFull = 0;            // n + 1 + #soft: the rows a working set of this problem can hold
+    int32_t *dOvfList = nullptr, *dOvfCount = nullptr, *dBigI = nullptr;
+    void *dBigR = nullptr;
+    int64_t ovfCap = 0;
+    int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
     int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)
     int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)

@@ -148,7 +148,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
     int32_t *__restrict__ queue, int qchunk, long long nprob,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
-    long long seg_cap) {
+    long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -865,6 +865,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if (lane == 0) {
             exitflag[pid] = flag;
             if (iters) iters[pid] = iter;
+            // a working set that outgrew the 64 lanes: queued for the one-problem-per-thread kernel behind this one
+            // (lmpc_big_kernel.hpp), which overwrites the outputs of this problem
+            if (flag == EXIT_WSCAP && ovf_list != nullptr) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
         }
         if (++kin < qchunk) {
             idx++;

@@ -3,6 +3,7 @@
 
 #include "lmpc_internal.hpp"
 #include "lmpc_wave_kernel.hpp"
+#include "lmpc_big_kernel.hpp"
 
 namespace lmpc {
 
@@ -116,9 +117,32 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
         HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
         queue = h->dQueue;
     }
+    // working sets that can outgrow the 64 lanes (n + 1 + #soft > 64): such points are listed by the kernel and
+    // re-solved behind it, one problem per thread (no branch and bound there)
+    const bool big = !BNB && h->bigPath && h->capFull > Wl.cap && nprob < (int64_t)0x7fffffff;
+    const int bigCap = h->capFull < kBigCap ? h->capFull : kBigCap;
+    if (big) {
+        if (nprob > h->ovfCap) {
+            hipFree(h->dOvfList); h->dOvfList = nullptr; h->ovfCap = 0;
+            HIP_TRY(h, hipMalloc(&h->dOvfList, sizeof(int32_t) * (size_t)nprob));
+            h->ovfCap = nprob;
+        }
+        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, 64));
+        if (!h->dBigR) {     // sized for binary64: the binary32 calls of the handle use the same slices
+            HIP_TRY(h, hipMalloc(&h->dBigR, sizeof(double) * (size_t)kBigThreads * (size_t)big_scratch_reals(Wl.n, Wl.m, bigCap)));
+            HIP_TRY(h, hipMalloc(&h->dBigI, sizeof(int32_t) * (size_t)kBigThreads * (size_t)big_scratch_ints(Wl.m, bigCap)));
+        }
+        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t), st));
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
-                       iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap);
+                       iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
+                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr);
     HIP_TRY(h, hipGetLastError());
+    if (big) {
+        hipLaunchKernelGGL(big_kernel<R>, dim3(kBigThreads / 64), dim3(64), 0, st, Wl, dC, h->dSw, theta, x, flag, iters,
+                           active, warm, h->dOvfList, h->dOvfCount, static_cast<R *>(h->dBigR), h->dBigI, bigCap);
+        HIP_TRY(h, hipGetLastError());
+    }
     return LMPC_OK;
 }
 

@@ -375,11 +375,12 @@ def test_wave_kernel_many_rows(lmpc, n, mg, nth, nsoft, seed):
         assert np.abs(xf - xo).max() <= 1e-6
 
 
-def test_working_set_capacity_flag(lmpc):
-    # soft rows never make a working set singular, so a problem with many of them can want more than
-    # 64 rows at once -- more than the wavefront has lanes.  Such a problem ends with exit flag -7
-    # (no DAQP flag; the reference asserts exitflag >= 1, utils.jl:46); every other problem of the
-    # batch is solved exactly as the oracle solves it.
+def test_working_sets_beyond_the_64_lanes(lmpc):
+    # soft rows never make a working set singular, so a problem with many of them can want more than 64 rows at
+    # once -- more than the wavefront has lanes.  The wavefront kernel gives such a point up (its own flag -7, no
+    # DAQP flag) and lists it; the one-problem-per-thread kernel behind it (lmpc_big_kernel.hpp, up to 256 rows)
+    # re-solves it, so the caller gets exactly what the oracle gives -- cold, warm, binary32, and behind the
+    # screening pass.  lmpc_set_option("big_path", 0) shows the flag.
     from oracle import ldp as oldp
     rng = np.random.default_rng(5)
     n, mg, nth = 6, 150, 2
@@ -388,15 +389,41 @@ def test_working_set_capacity_flag(lmpc):
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
     theta = np.vstack([rng.uniform(-1, 1, (200, nth)),
                        np.hstack([rng.uniform(30, 60, (56, 1)), rng.uniform(-1, 1, (56, 1))])])
-    x, ef, it, act = qp.solve(theta)
-    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta)
+    L = oracle_ldp_from(qp.ldp())
+    xo, efo, ito, acto = oldp.solve_batch(L, theta)
     nact = np.array([sum(bin(int(w)).count("1") for w in row) for row in acto])
+    assert (nact > 64).sum() >= 20 and nact.max() <= 157
+    qp.set_option("big_path", 0)
+    x, ef, it, act = qp.solve(theta)
     over = ef == -7
     assert over.any() and (nact[over] >= 60).all()       # given up only where the working set is that large
-    assert (nact[~over] <= 64).all()
     keep = ~over
     assert np.array_equal(ef[keep], efo[keep]) and np.array_equal(it[keep], ito[keep])
     assert np.array_equal(act[keep], acto[keep]) and np.abs(x[keep] - xo[keep]).max() <= TOL
+    qp.set_option("big_path", 1)
+    for scr in (0, 1):
+        qp.set_option("screen_wave", scr)
+        x, ef, it, act = qp.solve(theta)
+        assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto)
+        assert (ef >= 1).all() and np.array_equal(x, xo)
+    # warm start from the final working sets (the large ones included): the same masks come back
+    xw, efw, itw, actw = qp.solve(theta, warm=act)
+    xwo, efwo, itwo, actwo = oldp.solve_batch(L, theta, warm=acto)
+    assert np.array_equal(efw, efwo) and np.array_equal(itw, itwo) and np.array_equal(actw, actwo)
+    assert np.array_equal(xw, xwo)
+    # more overflowing points than the slow path has threads (512): every thread walks several
+    big = np.hstack([rng.uniform(30, 60, (1500, 1)), rng.uniform(-1, 1, (1500, 1))])
+    xb, efb, itb, actb = qp.solve(big)
+    xbo, efbo, itbo, actbo = oldp.solve_batch(L, big)
+    assert np.array_equal(efb, efbo) and np.array_equal(itb, itbo) and np.array_equal(actb, actbo) and np.array_equal(xb, xbo)
+    # binary32 on the same handle's scratch
+    s32 = lmpc.default_settings_f32()
+    qf = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2, settings=s32)
+    th32 = theta.astype(np.float32)
+    xf, eff, itf, actf = qf.solve_f32(th32)
+    xfo, effo, itfo, actfo = oldp.solve_batch(oracle_ldp_from(qf.ldp()), th32, _copy_settings(lmpc, s32), dtype=np.float32)
+    assert np.array_equal(eff, effo) and np.array_equal(itf, itfo) and np.array_equal(actf, actfo)
+    assert np.array_equal(xf, xfo)
 
 
 # ------------------------------------------------------------------ closed-loop batch simulation
