@@ -44,9 +44,25 @@ __device__ __forceinline__ int lds_load(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// bytes of dynamic LDS a workgroup of fast_kernel<.., N> needs for R tiles
-__host__ __device__ constexpr size_t fast_lds_bytes(int N, int R) {
-    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64) + sizeof(int32_t) * ((size_t)R * 64 + 4);
+// Coalesced record loads (LMPC_FAST_COAL): a tile of 64 records is one contiguous run of 64 * nth doubles.  Read
+// record by record -- lane i its own 8 * nth bytes, one 8-byte load per parameter -- every load instruction touches
+// 64 * 8 * nth / 128 different 128-byte lines (28 for the pendulum's 56-byte records) and the L1 has to serve each
+// line once per instruction: nth times the data's worth of line accesses.  Read as 16-byte pieces in address order
+// (lane l piece 64 i + l) an instruction covers 8 whole lines; the pieces go through a wave-private LDS image of
+// the tile and come back as records (ds_read_b64 at a stride of 8 * nth bytes: conflict-free for odd nth, which
+// is where this path is used; theta must be 16-byte aligned, the last, partial tile takes the per-record loads).
+// MEASURED SLOWER and therefore OFF (same-box A/B, 10^6 pendulum points, cold HBM): one call 28.1 -> 31.3 us, three
+// in flight 19.3 -> 22.0 us/step.  The line accesses of the per-record loads hit in L1 while the lines are still
+// arriving -- they were never the limit; the LDS round trip (4 writes, 7 reads, two waits per tile) is pure cost.
+#ifndef LMPC_FAST_COAL
+#define LMPC_FAST_COAL 0
+#endif
+__host__ __device__ constexpr bool fast_coalesced(int NT, bool gather) { return LMPC_FAST_COAL && !gather && (NT & 1) && NT >= 3; }
+
+// bytes of dynamic LDS a workgroup of fast_kernel<.., N> needs for R tiles (tile images: 4 wavefronts x 64 records)
+__host__ __device__ constexpr size_t fast_lds_bytes(int N, int R, int NT = 0, bool gather = true) {
+    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64 + (fast_coalesced(NT, gather) ? 4 * 64 * NT : 0)) +
+           sizeof(int32_t) * ((size_t)R * 64 + 4);
 }
 
 // GATHER: the generated controller's call (lmpc_compute_control*): theta is assembled from the five argument arrays
@@ -65,7 +81,9 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     extern __shared__ __align__(16) double lds[];
     double *sconst = lds;                                      // M, G, du0, dl0 (as in the pack, as lane_kernel keeps them)
     double *sBall = sconst + ((nconst + 1) & ~1);              // b[j][lane] of the four wavefronts (generic loop)
-    int32_t *ring = reinterpret_cast<int32_t *>(sBall + 4 * N * 64);
+    constexpr bool COAL = fast_coalesced(NT, GATHER);
+    double *stiles = sBall + 4 * N * 64;                       // tile images of the four wavefronts (COAL)
+    int32_t *ring = reinterpret_cast<int32_t *>(stiles + (COAL ? 4 * 64 * NT : 0));
     int *ctrl = reinterpret_cast<int *>(ring + R * 64);        // [0] write index, [1] read index, [2] producers done
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,15 +153,52 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         // tile in flight changed nothing: the stream runs at the HBM rate, 14 us for the 68 MB of the headline
         // batch with nine streaming wavefronts per CU; tools/fast_trace.py)
         double nx[NT];
+        constexpr int NPIECE = (NT + 1) / 2;                   // 16-byte pieces per lane of a tile (COAL)
+        double pcx[NPIECE], pcy[NPIECE];
+        const bool coal = COAL && (reinterpret_cast<uintptr_t>(theta) & 15) == 0;
+        double *stile = stiles + wv * 64 * NT;
+        // next tile: in address order if it is a full one, record by record otherwise
+        auto fetch = [&](long long tl) {
+            if (COAL && coal && (tl + 1) * 64 <= nprob) {
+                const double *src = theta + tl * 64 * NT;
+#pragma unroll
+                for (int i = 0; i < NPIECE; i++) {
+                    const int pc = i * 64 + lane;
+                    if (pc < 32 * NT) {
+                        const double2 v = *reinterpret_cast<const double2 *>(src + 2 * pc);
+                        pcx[i] = v.x; pcy[i] = v.y;
+                    }
+                }
+            } else {
+                load_record(tl * 64 + lane, nx);
+            }
+        };
         long long tile = t0 + role;
-        if (tile < t1) load_record(tile * 64 + lane, nx);
+        if (tile < t1) fetch(tile);
         for (; tile < t1; tile += nstr) {
             const long long pid = tile * 64 + lane;
             const bool valid = pid < nprob;
             double th[NT];
+            if (COAL && coal && (tile + 1) * 64 <= nprob) {
+                // pieces -> this wavefront's tile image -> records (LDS keeps a wavefront's accesses in order; the
+                // fences keep the compiler from moving them)
 #pragma unroll
-            for (int t = 0; t < NT; t++) th[t] = nx[t];
-            if (tile + nstr < t1) load_record(pid + (long long)nstr * 64, nx);
+                for (int i = 0; i < NPIECE; i++) {
+                    const int pc = i * 64 + lane;
+                    if (pc < 32 * NT) *reinterpret_cast<double2 *>(stile + 2 * pc) = make_double2(pcx[i], pcy[i]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int t = 0; t < NT; t++) th[t] = stile[lane * NT + t];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; t++) th[t] = nx[t];
+            }
+            if (tile + nstr < t1) fetch(tile + nstr);
             // screening test of screen_kernel: any row of dl + b <= 0 <= du + b violated by more than primal_tol?
             bool hard = false;
             const double *dj = C + P.oDthP;
