@@ -40,7 +40,7 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     if (h->fastTiles > 0) R = h->fastTiles;
     if (R > ntiles) R = (int)(ntiles > 0 ? ntiles : 1);
     const unsigned grid = (unsigned)((ntiles + R - 1) / R);
-    const size_t lds = fast_lds_bytes(N, R, NT, GATHER);
+    const size_t lds = fast_lds_bytes(N, R, NTHMAX);
     if (!h->dFastErr) {
 #ifdef LMPC_FAST_TRACE
         const size_t eb = 64 + sizeof(long long) * 8 * 4 * 65536;

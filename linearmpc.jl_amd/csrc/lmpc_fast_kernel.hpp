@@ -39,29 +39,21 @@ namespace lmpc {
 #define LMPC_FAST_WAVES 3      // wavefronts per SIMD the kernel is register-budgeted for (lane_loop sets the need)
 #endif
 constexpr int kFastSpinLimit = 1 << 22;
+#ifndef LMPC_FAST_AHEAD
+#define LMPC_FAST_AHEAD 1
+#endif
+constexpr int kFastAhead = LMPC_FAST_AHEAD;      // tiles a streaming wavefront requests before it consumes the first
 
 __device__ __forceinline__ int lds_load(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Coalesced record loads (LMPC_FAST_COAL): a tile of 64 records is one contiguous run of 64 * nth doubles.  Read
-// record by record -- lane i its own 8 * nth bytes, one 8-byte load per parameter -- every load instruction touches
-// 64 * 8 * nth / 128 different 128-byte lines (28 for the pendulum's 56-byte records) and the L1 has to serve each
-// line once per instruction: nth times the data's worth of line accesses.  Read as 16-byte pieces in address order
-// (lane l piece 64 i + l) an instruction covers 8 whole lines; the pieces go through a wave-private LDS image of
-// the tile and come back as records (ds_read_b64 at a stride of 8 * nth bytes: conflict-free for odd nth, which
-// is where this path is used; theta must be 16-byte aligned, the last, partial tile takes the per-record loads).
-// MEASURED SLOWER and therefore OFF (same-box A/B, 10^6 pendulum points, cold HBM): one call 28.1 -> 31.3 us, three
-// in flight 19.3 -> 22.0 us/step.  The line accesses of the per-record loads hit in L1 while the lines are still
-// arriving -- they were never the limit; the LDS round trip (4 writes, 7 reads, two waits per tile) is pure cost.
-#ifndef LMPC_FAST_COAL
-#define LMPC_FAST_COAL 0
-#endif
-__host__ __device__ constexpr bool fast_coalesced(int NT, bool gather) { return LMPC_FAST_COAL && !gather && (NT & 1) && NT >= 3; }
-
-// bytes of dynamic LDS a workgroup of fast_kernel<.., N> needs for R tiles (tile images: 4 wavefronts x 64 records)
-__host__ __device__ constexpr size_t fast_lds_bytes(int N, int R, int NT = 0, bool gather = true) {
-    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64 + (fast_coalesced(NT, gather) ? 4 * 64 * NT : 0)) +
+// bytes of dynamic LDS a workgroup of fast_kernel<.., N> needs for R tiles
+// doubles of the screening constants kept in LDS: rows of Dth padded to NTHMAX columns, (du, dl) pairs, the first
+// output's row of Xth, x0 of the first output (+ padding to an even count)
+__host__ __device__ constexpr int fast_scr_doubles(int N, int NTHMAX) { return (N * NTHMAX + 2 * N + NTHMAX + 1 + 1) & ~1; }
+__host__ __device__ constexpr size_t fast_lds_bytes(int N, int R, int NTHMAX) {
+    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64 + fast_scr_doubles(N, NTHMAX)) +
            sizeof(int32_t) * ((size_t)R * 64 + 4);
 }
 
@@ -81,14 +73,17 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     extern __shared__ __align__(16) double lds[];
     double *sconst = lds;                                      // M, G, du0, dl0 (as in the pack, as lane_kernel keeps them)
     double *sBall = sconst + ((nconst + 1) & ~1);              // b[j][lane] of the four wavefronts (generic loop)
-    constexpr bool COAL = fast_coalesced(NT, GATHER);
-    double *stiles = sBall + 4 * N * 64;                       // tile images of the four wavefronts (COAL)
-    int32_t *ring = reinterpret_cast<int32_t *>(stiles + (COAL ? 4 * 64 * NT : 0));
+    double *sScr = sBall + 4 * N * 64;                          // screening constants (see fast_scr_doubles)
+    int32_t *ring = reinterpret_cast<int32_t *>(sScr + fast_scr_doubles(N, NTHMAX));
     int *ctrl = reinterpret_cast<int *>(ring + R * 64);        // [0] write index, [1] read index, [2] producers done
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nth = P.nth;
     for (int i = tid; i < nconst; i += 256) sconst[i] = C[P.oM + i];
+    for (int i = tid; i < N * NTHMAX; i += 256) sScr[i] = C[P.oDthP + i];
+    if (tid < 2 * N) sScr[N * NTHMAX + tid] = C[P.oBnd + tid];
+    if (tid < NTHMAX) sScr[N * NTHMAX + 2 * N + tid] = C[P.oXthP + tid];
+    if (tid == 0) sScr[N * NTHMAX + 2 * N + NTHMAX] = C[P.ox0];
     for (int i = tid; i < R * 64; i += 256) ring[i] = -1;
     if (tid < 4) ctrl[tid] = 0;
     __syncthreads();
@@ -149,60 +144,34 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     const int role = (wv + (int)(blockIdx.x & 3)) & 3;
     // ------------------------------------------------------------------ producer: stream this wavefront's tiles
     if (role < nstr) {
-        // the record of this wavefront's next tile is in flight while the current one is screened (a second
-        // tile in flight changed nothing: the stream runs at the HBM rate, 14 us for the 68 MB of the headline
-        // batch with nine streaming wavefronts per CU; tools/fast_trace.py)
-        double nx[NT];
-        constexpr int NPIECE = (NT + 1) / 2;                   // 16-byte pieces per lane of a tile (COAL)
-        double pcx[NPIECE], pcy[NPIECE];
-        const bool coal = COAL && (reinterpret_cast<uintptr_t>(theta) & 15) == 0;
-        double *stile = stiles + wv * 64 * NT;
-        // next tile: in address order if it is a full one, record by record otherwise
-        auto fetch = [&](long long tl) {
-            if (COAL && coal && (tl + 1) * 64 <= nprob) {
-                const double *src = theta + tl * 64 * NT;
-#pragma unroll
-                for (int i = 0; i < NPIECE; i++) {
-                    const int pc = i * 64 + lane;
-                    if (pc < 32 * NT) {
-                        const double2 v = *reinterpret_cast<const double2 *>(src + 2 * pc);
-                        pcx[i] = v.x; pcy[i] = v.y;
-                    }
-                }
-            } else {
-                load_record(tl * 64 + lane, nx);
-            }
-        };
-        long long tile = t0 + role;
-        if (tile < t1) fetch(tile);
-        for (; tile < t1; tile += nstr) {
+        // A streaming wavefront asks for ONE tile, waits, screens it, asks for the next (kFastAhead = 1).  Measured on
+        // the headline batch with no point needing iterations (tools/stream_floor.py; one call, cold HBM, event-timed):
+        // this form 20.3 us; the next tile requested before the current one is screened (two register sets used
+        // alternately, LMPC_FAST_PP) 21.2 us; two / four / seven tiles requested back to back before the first is
+        // consumed (straight-line code, so that the compiler's waits are vmcnt(4 (T - 1 - d)) instead of the vmcnt(0)
+        // it puts at the head of every loop with stores behind it: loads and stores share one in-order counter)
+        // 22.6 / 22.6 / 26.3 us; each wavefront on a contiguous run of tiles (LMPC_FAST_CONTIG) the same.  More
+        // requests in flight per wavefront make THIS access shape slower, not faster: a record is 56 bytes per lane,
+        // the four load instructions of a tile touch the same 28 lines one after the other and rely on the 32 KB L1
+        // to merge them -- nine streaming wavefronts with one tile each are 31.5 KB.  (Read in address order through a
+        // wave-private LDS image instead -- no reuse of lines across instructions -- a call took 31.3 us: the round
+        // trip through LDS costs more than it saves.  tools/stream_floor.hip has the shapes in isolation: one tile
+        // per wavefront at full occupancy reads the same bytes in 15.7 us, event overhead of 6.3 us included.)
+        double buf[kFastAhead][NT];
+        auto process = [&](long long tile, const double (&th)[NT], bool live) {
             const long long pid = tile * 64 + lane;
-            const bool valid = pid < nprob;
-            double th[NT];
-            if (COAL && coal && (tile + 1) * 64 <= nprob) {
-                // pieces -> this wavefront's tile image -> records (LDS keeps a wavefront's accesses in order; the
-                // fences keep the compiler from moving them)
-#pragma unroll
-                for (int i = 0; i < NPIECE; i++) {
-                    const int pc = i * 64 + lane;
-                    if (pc < 32 * NT) *reinterpret_cast<double2 *>(stile + 2 * pc) = make_double2(pcx[i], pcy[i]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int t = 0; t < NT; t++) th[t] = stile[lane * NT + t];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; t++) th[t] = nx[t];
-            }
-            if (tile + nstr < t1) fetch(tile + nstr);
+            const bool valid = live && pid < nprob;
             // screening test of screen_kernel: any row of dl + b <= 0 <= du + b violated by more than primal_tol?
+            // (the constants come from LDS, uniform addresses, for every tile anew: as scalar loads the compiler
+            // kept all ~110 scalar registers' worth of them live, more than there are, parked the kernel's pointers
+            // in vector-register lanes instead and paid 60-100 v_readlane per tile -- a third of the pass's vector
+            // instructions (436 -> 330 instructions per tile); the empty asm hides that the addresses repeat.
+            // Bitwise | instead of ||: no branch per comparison.)
+            int ofs = 0;
+            asm volatile("" : "+v"(ofs));                     // (a vector register: ONE base address, immediate offsets)
             bool hard = false;
-            const double *dj = C + P.oDthP;
-            const double *bj = C + P.oBnd;
+            const double *dj = sScr + ofs;
+            const double *bj = sScr + N * NTHMAX + ofs;
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 double acc = 0.0;
@@ -210,9 +179,9 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                 for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th[t], acc);
                 const double vu = (bj[2 * j] + acc) - 0.0;
                 const double vl = -((bj[2 * j + 1] + acc) - 0.0);
-                hard = hard || (vu < ntol) || (vl < ntol);
+                hard = hard | (vu < ntol) | (vl < ntol);
             }
-            hard = hard && valid;
+            hard = hard & valid;
             const unsigned long long mask = __ballot(hard);
             if (mask != 0ull) {
                 int base = 0;
@@ -222,15 +191,73 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (valid && !hard) {
-                double u0[N];
+                if (P.nout == 1) {
+                    // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
+                    double sh = sScr[N * NTHMAX + 2 * N + NTHMAX + ofs];
+                    const double *xk = sScr + N * NTHMAX + 2 * N + ofs;
 #pragma unroll
-                for (int c = 0; c < N; c++) u0[c] = 0.0;
-                write_x(pid, th, u0, false);                   // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
+                    for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                    X[pid] = 0.0 + sh;
+                } else {
+                    double u0[N];
+#pragma unroll
+                    for (int c = 0; c < N; c++) u0[c] = 0.0;
+                    write_x(pid, th, u0, false);
+                }
                 exitflag[pid] = EXIT_OPTIMAL;
                 if (iters) iters[pid] = 1;
                 if (active) active[pid * P.words] = 0ull;
             }
+        };
+#ifdef LMPC_FAST_CONTIG     // each streaming wavefront takes a contiguous run of the workgroup's tiles
+        const long long per = (R + nstr - 1) / nstr;
+        const long long s0 = t0 + role * per, s1 = s0 + per < t1 ? s0 + per : t1;
+        for (long long base = s0; base < s1; base += kFastAhead) {
+#pragma unroll
+            for (int d = 0; d < kFastAhead; d++) {
+                const long long tl = base + d;
+                load_record((tl < s1 ? tl : base) * 64 + lane, buf[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < kFastAhead; d++) {
+                const long long tl = base + d;
+                process(tl < s1 ? tl : base, buf[d], tl < s1);
+            }
         }
+#elif defined(LMPC_FAST_PP)    // two register sets used alternately, the next tile requested before the current one is consumed
+        {
+            double bufB[NT];
+            long long tile = t0 + role;
+            if (tile < t1) {
+                load_record(tile * 64 + lane, buf[0]);
+                for (;;) {
+                    long long nxt = tile + nstr < t1 ? tile + nstr : tile;
+                    load_record(nxt * 64 + lane, bufB);
+                    process(tile, buf[0], true);
+                    if (tile + nstr >= t1) break;
+                    tile += nstr;
+                    nxt = tile + nstr < t1 ? tile + nstr : tile;
+                    load_record(nxt * 64 + lane, buf[0]);
+                    process(tile, bufB, true);
+                    if (tile + nstr >= t1) break;
+                    tile += nstr;
+                }
+            }
+        }
+#else
+        for (long long base = t0 + role; base < t1; base += (long long)kFastAhead * nstr) {
+#pragma unroll
+            for (int d = 0; d < kFastAhead; d++) {
+                const long long tl = base + (long long)d * nstr;
+                load_record((tl < t1 ? tl : base) * 64 + lane, buf[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < kFastAhead; d++) {
+                const long long tl = base + (long long)d * nstr;
+                process(tl < t1 ? tl : base, buf[d], tl < t1);
+            }
+        }
+#endif
         // all of this wavefront's reservations are in the LDS queue ahead of this add (LDS keeps a wave's order)
         if (lane == 0) __hip_atomic_fetch_add(&ctrl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         LMPC_TRC(1);
@@ -286,6 +313,8 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         {
             double th0[NT];
             load_record(pid, th0);
+            // (scalar loads here: the LDS copy the streaming pass uses made a call 1.7 us SLOWER on this side --
+            // a solving pass already lives on LDS reads, 26.8 vs 28.5 us same-box)
             const double *dj = C + P.oDthP;
 #pragma unroll
             for (int j = 0; j < N; j++) {

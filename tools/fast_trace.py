@@ -6,9 +6,12 @@ import numpy as np, torch, bench
 import linearmpc_jl_amd as lmpc
 g = bench.make_problem("pendulum")
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+scale = 1.0
 for o in sys.argv[1:]:
-    k, v = o.split("="); qp.set_option(k, int(v))
-ths = [torch.from_numpy(bench.make_theta("pendulum", 1000000, 1234 + i)).cuda() for i in range(6)]
+    k, v = o.split("=")
+    if k == "scale": scale = float(v)      # scale=0.5: no point of the batch needs iterations (the stream alone)
+    else: qp.set_option(k, int(v))
+ths = [torch.from_numpy(bench.make_theta("pendulum", 1000000, 1234 + i) * scale).cuda() for i in range(6)]
 for i in range(12):
     x, ef = qp.solve_device(ths[i % 6])
 torch.cuda.synchronize()
