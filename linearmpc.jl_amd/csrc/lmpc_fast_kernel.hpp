@@ -167,11 +167,13 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             // in vector-register lanes instead and paid 60-100 v_readlane per tile -- a third of the pass's vector
             // instructions (436 -> 330 instructions per tile); the empty asm hides that the addresses repeat.
             // Bitwise | instead of ||: no branch per comparison.)
-            int ofs = 0;
-            asm volatile("" : "+v"(ofs));                     // (a vector register: ONE base address, immediate offsets)
+            typedef const double __attribute__((address_space(3))) *lds_cdp;
+            unsigned scr_off = (unsigned)(size_t)(lds_cdp)sScr;
+            asm volatile("" : "+v"(scr_off));                 // (opaque, in a vector register: ONE base address, immediate offsets)
+            const lds_cdp scr = (lds_cdp)(size_t)scr_off;
             bool hard = false;
-            const double *dj = sScr + ofs;
-            const double *bj = sScr + N * NTHMAX + ofs;
+            const lds_cdp dj = scr;
+            const lds_cdp bj = scr + N * NTHMAX;
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 double acc = 0.0;
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             if (valid && !hard) {
                 if (P.nout == 1) {
                     // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
-                    double sh = sScr[N * NTHMAX + 2 * N + NTHMAX + ofs];
-                    const double *xk = sScr + N * NTHMAX + 2 * N + ofs;
+                    double sh = scr[N * NTHMAX + 2 * N + NTHMAX];
+                    const lds_cdp xk = scr + N * NTHMAX + 2 * N;
 #pragma unroll
                     for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
                     X[pid] = 0.0 + sh;
