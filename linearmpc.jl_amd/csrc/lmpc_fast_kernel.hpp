@@ -52,8 +52,18 @@ __device__ __forceinline__ int lds_load(const int *p) {
 // doubles of the screening constants kept in LDS: rows of Dth padded to NTHMAX columns, (du, dl) pairs, the first
 // output's row of Xth, x0 of the first output (+ padding to an even count)
 __host__ __device__ constexpr int fast_scr_doubles(int N, int NTHMAX) { return (N * NTHMAX + 2 * N + NTHMAX + 1 + 1) & ~1; }
+// Hand-over of a queued problem: the streaming wavefront that found it has its shifts b_j = Dth_j . theta and the
+// output shift x0 + Xth theta in registers; the first kFastPay queue positions of a workgroup carry them in LDS next
+// to the index, so the solving wavefront starts on an LDS read instead of re-reading the record from L2 and
+// re-forming the products (1.2 us of a 6 us pass).  Positions beyond (a batch where most points iterate) take the
+// record from memory as before.  The values are the ones the solving side would compute: same chains, same constants.
+#ifndef LMPC_FAST_PAY
+#define LMPC_FAST_PAY 256
+#endif
+constexpr int kFastPay = LMPC_FAST_PAY;
 __host__ __device__ constexpr size_t fast_lds_bytes(int N, int R, int NTHMAX) {
-    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64 + fast_scr_doubles(N, NTHMAX)) +
+    return sizeof(double) * (size_t)(((N * N + N * (N + 1) / 2 + 2 * N + 1) & ~1) + 4 * N * 64 + fast_scr_doubles(N, NTHMAX) +
+                                     (size_t)kFastPay * (N + 1)) +
            sizeof(int32_t) * ((size_t)R * 64 + 4);
 }
 
@@ -74,7 +84,8 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     double *sconst = lds;                                      // M, G, du0, dl0 (as in the pack, as lane_kernel keeps them)
     double *sBall = sconst + ((nconst + 1) & ~1);              // b[j][lane] of the four wavefronts (generic loop)
     double *sScr = sBall + 4 * N * 64;                          // screening constants (see fast_scr_doubles)
-    int32_t *ring = reinterpret_cast<int32_t *>(sScr + fast_scr_doubles(N, NTHMAX));
+    double *sPay = sScr + fast_scr_doubles(N, NTHMAX);         // (b_0 .. b_{N-1}, x shift) of the first kFastPay queue positions
+    int32_t *ring = reinterpret_cast<int32_t *>(sPay + (size_t)kFastPay * (N + 1));
     int *ctrl = reinterpret_cast<int *>(ring + R * 64);        // [0] write index, [1] read index, [2] producers done
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,32 +185,45 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             bool hard = false;
             const lds_cdp dj = scr;
             const lds_cdp bj = scr + N * NTHMAX;
+            double bq[N];
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 double acc = 0.0;
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th[t], acc);
+                bq[j] = acc;
                 const double vu = (bj[2 * j] + acc) - 0.0;
                 const double vl = -((bj[2 * j + 1] + acc) - 0.0);
                 hard = hard | (vu < ntol) | (vl < ntol);
             }
             hard = hard & valid;
+            // x0 + Xth theta of the first output: stored by a finished lane, handed over by a queued one
+            double sh = scr[N * NTHMAX + 2 * N + NTHMAX];
+            {
+                const lds_cdp xk = scr + N * NTHMAX + 2 * N;
+#pragma unroll
+                for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+            }
             const unsigned long long mask = __ballot(hard);
             if (mask != 0ull) {
                 int base = 0;
                 if (lane == 0) base = __hip_atomic_fetch_add(&ctrl[0], __popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 base = __shfl(base, 0);
-                if (hard) __hip_atomic_store(&ring[base + __popcll(mask & ((1ull << lane) - 1ull))], (int32_t)(pid - t0 * 64),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hard) {
+                    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (pos < kFastPay) {
+                        double *pay = sPay + pos * (N + 1);
+#pragma unroll
+                        for (int j = 0; j < N; j++) pay[j] = bq[j];
+                        pay[N] = sh;
+                    }
+                    // (release: the payload is in LDS before the index that announces it)
+                    __hip_atomic_store(&ring[pos], (int32_t)(pid - t0 * 64), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
             if (valid && !hard) {
                 if (P.nout == 1) {
-                    // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
-                    double sh = scr[N * NTHMAX + 2 * N + NTHMAX];
-                    const lds_cdp xk = scr + N * NTHMAX + 2 * N;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
-                    X[pid] = 0.0 + sh;
+                    X[pid] = 0.0 + sh;                         // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
                 } else {
                     double u0[N];
 #pragma unroll
@@ -304,7 +328,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         int rel = -1;
         if (mine) {
             int sp = 0;
-            while ((rel = __hip_atomic_load(&ring[start + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) {
+            while ((rel = __hip_atomic_load(&ring[start + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) {
                 if (++sp > kFastSpinLimit) break;              // (a reserved slot is written at once: never in practice)
             }
         }
@@ -312,22 +336,33 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         const long long pid = mine ? t0 * 64 + rel : t0 * 64;
         double b[N], u[N];
         double sh0 = C[P.ox0];                                 // x0 + Xth theta of the first output (kept: 2 registers)
-        {
+        const bool handed = start + lane < kFastPay;           // shifts handed over in LDS by the streaming wavefront
+#pragma unroll
+        for (int j = 0; j < N; j++) b[j] = 0.0;
+        if (handed) {
+            const double *pay = sPay + (start + (mine ? lane : 0)) * (N + 1);
+#pragma unroll
+            for (int j = 0; j < N; j++) b[j] = pay[j];
+            sh0 = pay[N];
+        }
+        if (__any(mine && !handed)) {
             double th0[NT];
             load_record(pid, th0);
             // (scalar loads here: the LDS copy the streaming pass uses made a call 1.7 us SLOWER on this side --
             // a solving pass already lives on LDS reads, 26.8 vs 28.5 us same-box)
             const double *dj = C + P.oDthP;
+            double sh1 = C[P.ox0];
 #pragma unroll
             for (int j = 0; j < N; j++) {
                 double acc = 0.0;
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th0[t], acc);
-                b[j] = acc;
+                b[j] = handed ? b[j] : acc;
             }
             const double *xk = C + P.oXthP;
 #pragma unroll
-            for (int t = 0; t < NT; t++) sh0 = __builtin_fma(xk[t], th0[t], sh0);
+            for (int t = 0; t < NT; t++) sh1 = __builtin_fma(xk[t], th0[t], sh1);
+            sh0 = handed ? sh0 : sh1;
         }
 #ifdef LMPC_FAST_TRACE
         if (npass == 1) { if (lane == 0) trc[4] = (long long)(b[0] != 12345.678 ? wall_clock64() : 0); }
