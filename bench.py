@@ -610,8 +610,9 @@ def main():
             cold = W.single_launch(nsolo, resident=False)
             if cold[0] > 0 and cold[1] > 0:
                 roof.update({"achieved": gbs(cold[1]), "frac": gbs(cold[1]) / HBM_PEAK_GBS, "duration_used_ms": cold[1],
-                             "duration": "HIP-event duration of ONE lmpc_solve_batch_device call (screening kernel + "
-                                         "iterating kernel, events recorded by the library on the launch stream), calls "
+                             "duration": "HIP-event duration of ONE lmpc_solve_batch_device call (all its kernels; "
+                                         "timing events without the system-scope fence, hipEventDisableSystemFence, "
+                                         "recorded by the library on the launch stream), calls "
                                          f"issued one at a time on one stream over {W.nrot} rotating batches (cold HBM: "
                                          f"{W.nrot * bytes_call / 2**20:.0f} MiB pass between two uses of a line)",
                              "launches_timed": cold[0], "kernel_ms": cold[1],

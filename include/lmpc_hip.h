@@ -388,7 +388,8 @@ int lmpc_compute_control_observer_device(lmpc_handle *h, int64_t N, double *cont
 const char *lmpc_kernel_name(const lmpc_handle *h);
 
 /* Device time per lmpc_solve_batch* call, measured with HIP events recorded on the launch
- * stream (switch on with lmpc_profile(h, 1)).  lmpc_profile_read waits for the recorded calls,
+ * stream (switch on with lmpc_profile(h, 1); timing-only events, hipEventDisableSystemFence: a default event's
+ * system-scope cache writeback added ~1.7 us to a 24 us call that rocprofv3's kernel trace does not see).  lmpc_profile_read waits for the recorded calls,
  * averages over the calls made since the last read and returns how many there were (<0: error):
  *   avg_ms[0] whole call (screening pass + iterating pass), avg_ms[1] screening kernel,
  *   avg_ms[2] iterating kernel. */

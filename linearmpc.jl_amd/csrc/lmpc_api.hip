@@ -24,7 +24,9 @@ namespace lmpc {
 
 hipError_t pool_event(lmpc_handle *h, hipEvent_t *e) {
     if (!h->eventPool.empty()) { *e = h->eventPool.back(); h->eventPool.pop_back(); return hipSuccess; }
-    return hipEventCreate(e);
+    // timing events only: without the system-scope fence a default event performs when it completes (the fence is
+    // for host visibility of the kernel's writes, which these events are never used to order)
+    return hipEventCreateWithFlags(e, hipEventDisableSystemFence);
 }
 
 int fail(lmpc_handle *h, int code, const std::string &msg) {
