@@ -399,7 +399,8 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
 /* Tuning switches (none of them changes a result): "fast" (default 1) = small box-constrained problems
  * (m == ms == n <= 5, up to 16 parameters -- 8 for n = 5 --, cold start) are solved by ONE kernel that streams the batch and
  * runs the iterations underneath (0 = the two-kernel form below); "fast_nstr" 1..4 = streaming wavefronts per
- * workgroup of that kernel (default 3; 4 suits several batches in flight); "lane_straight" (default 1) =
+ * workgroup of that kernel (default 3; 4 suits several batches in flight), "fast_tiles" = tiles of 64 problems per workgroup
+ * (default: one resident round of workgroups; 28 suits three 10^6-point batches in flight); "lane_straight" (default 1) =
  * straight-line first tier in the boxed iterating kernels.  "screen" (default 1) = run cold-start batches through the streaming
  * screening pass before the iterating kernel; 0 = iterating kernel only.  "screen_wave" (default 1) = the same pass in
  * front of the wavefront kernel (binary64 problems without binary rows and without initially active rows, 1..32
