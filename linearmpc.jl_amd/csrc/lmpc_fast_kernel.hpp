@@ -183,26 +183,42 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             asm volatile("" : "+v"(scr_off));                 // (opaque, in a vector register: ONE base address, immediate offsets)
             const lds_cdp scr = (lds_cdp)(size_t)scr_off;
             bool hard = false;
-            const lds_cdp dj = scr;
-            const lds_cdp bj = scr + N * NTHMAX;
+            // (16-byte reads: ds_read_b128 moves a broadcast pair in half the LDS cycles of the ds_read2_b64 the
+            // compiler picks for 8-byte-aligned doubles; one LDS pipe serves the four SIMDs of a CU)
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            typedef const v2d __attribute__((address_space(3))) *lds_c2p;
+            const lds_c2p c2 = (lds_c2p)(size_t)scr_off;
+            static_assert(NTHMAX % 2 == 0, "rows of pairs");
             double bq[N];
 #pragma unroll
             for (int j = 0; j < N; j++) {
+                double row[NTHMAX];
+#pragma unroll
+                for (int q = 0; q < (NT + 1) / 2; q++) {
+                    const v2d v = c2[j * (NTHMAX / 2) + q];
+                    row[2 * q] = v.x; row[2 * q + 1] = v.y;
+                }
                 double acc = 0.0;
 #pragma unroll
-                for (int t = 0; t < NT; t++) acc = __builtin_fma(dj[j * NTHMAX + t], th[t], acc);
+                for (int t = 0; t < NT; t++) acc = __builtin_fma(row[t], th[t], acc);
                 bq[j] = acc;
-                const double vu = (bj[2 * j] + acc) - 0.0;
-                const double vl = -((bj[2 * j + 1] + acc) - 0.0);
+                const v2d bb = c2[N * (NTHMAX / 2) + j];                   // (du, dl) of row j
+                const double vu = (bb.x + acc) - 0.0;
+                const double vl = -((bb.y + acc) - 0.0);
                 hard = hard | (vu < ntol) | (vl < ntol);
             }
             hard = hard & valid;
             // x0 + Xth theta of the first output: stored by a finished lane, handed over by a queued one
             double sh = scr[N * NTHMAX + 2 * N + NTHMAX];
             {
-                const lds_cdp xk = scr + N * NTHMAX + 2 * N;
+                double row[NTHMAX];
 #pragma unroll
-                for (int t = 0; t < NT; t++) sh = __builtin_fma(xk[t], th[t], sh);
+                for (int q = 0; q < (NT + 1) / 2; q++) {
+                    const v2d v = c2[(N * NTHMAX + 2 * N) / 2 + q];
+                    row[2 * q] = v.x; row[2 * q + 1] = v.y;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) sh = __builtin_fma(row[t], th[t], sh);
             }
             const unsigned long long mask = __ballot(hard);
             if (mask != 0ull) {
