@@ -45,6 +45,26 @@ __host__ __device__ constexpr int lmpc_sl(int i, int t) { return i * (i - 1) / 2
 // results are committed by selects.  (With `if (running) { ... }` blocks the compiler built nested exec-mask
 // regions: 150 branches, saved masks spilling out of the scalar registers through v_writelane / v_readlane,
 // 1000 moves -- a tier pass of 1500 instructions took 5 us on its own.)
+// LEN doubles from base[START ..] with the widest LDS reads the alignment allows (base 16-byte aligned: an odd START
+// takes one 8-byte read first, then 16-byte pairs).  ds_read_b128 costs 4 LDS cycles per 16 bytes a lane, the
+// ds_read2_b64 the compiler picks for pairs of plain doubles 8 -- and one LDS pipe serves the four SIMDs of a CU.
+template <int LEN>
+__device__ __forceinline__ void lmpc_lds_run(const double *base, const int start, double (&dst)[LEN]) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int head = start & 1;                       // (`start` is a constant wherever this is inlined)
+    if (head) dst[0] = base[start];
+#pragma unroll
+    for (int q = 0; q < (LEN + 1) / 2; q++) {
+        const int i = head + 2 * q;
+        if (i + 1 < LEN) {
+            const v2d v = *reinterpret_cast<const v2d *>(base + start + i);
+            dst[i] = v.x; dst[i + 1] = v.y;
+        } else if (i < LEN) {
+            dst[i] = base[start + i];
+        }
+    }
+}
+
 template <int N, int KMAX>
 __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM, const double *sG, const double *sdu,
                                           const double *sdl, const bool mine, const double (&b)[N], double (&u)[N],
@@ -159,14 +179,28 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
         add = -1;
         addlow = false;
         bool broken = false;
+#ifndef LMPC_TIERS_NARROW_LDS
+        // M (N x N, at the 16-byte aligned start of the block), then the Gram triangle, then du0 and dl0
+        constexpr int kDu = N * N + N * (N + 1) / 2;
+        double duv[N], dlv[N];
+        lmpc_lds_run<N>(sMk, kDu, duv);
+        lmpc_lds_run<N>(sMk, kDu + N, dlv);
+#endif
 #pragma unroll
         for (int jj = 0; jj < N; jj++) {
             double Mu = 0.0;
+#ifndef LMPC_TIERS_NARROW_LDS
+            double mrow[N];
+            lmpc_lds_run<N>(sMk, jj * N, mrow);
+            const double duj = duv[jj], dlj = dlv[jj];
+#else
             const double *mrow = sMk + jj * N;
+            const double duj = sduk[jj], dlj = sdlk[jj];
+#endif
 #pragma unroll
             for (int c = 0; c < N; c++) Mu = __builtin_fma(mrow[c], uu[c], Mu);
-            const double vu = (sduk[jj] + b[jj]) - Mu;
-            const double vl = -((sdlk[jj] + b[jj]) - Mu);
+            const double vu = (duj + b[jj]) - Mu;
+            const double vl = -((dlj + b[jj]) - Mu);
             const bool inact = !((actmask >> jj) & 1u);
             const bool tu = inact && (vu < min_val);
             const bool tl = inact && !tu && (vl < min_val);
