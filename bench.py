@@ -427,6 +427,8 @@ def main():
     ap.add_argument("--wave-level", type=int, default=-1, help="wave kernel: LDS staging level 0..3 (tuning)")
     ap.add_argument("--wave-nwv", type=int, default=0, help="wave kernel: wavefronts per workgroup (tuning)")
     ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="lmpc_set_option(NAME, VALUE) on every handle of the headline workload (recorded in config.options)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches kept in flight per GPU (each has its own handle and HIP stream)")
     args = ap.parse_args()
@@ -487,6 +489,9 @@ def main():
         opts["fast_tiles"] = 28
     if args.lane_tier >= 0:
         opts["lane_tier"] = args.lane_tier
+    for kv in args.opt:
+        k_, _, v_ = kv.partition("=")
+        opts[k_.strip()] = int(v_)
     n_local = args.batch
     W = Workload(torch, lmpc, args.workload, n_local, dev, local_rank, rank, nstreams, f32=args.f32,
                  rotate=not args.no_rotate, options=opts)

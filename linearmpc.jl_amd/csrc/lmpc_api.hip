@@ -131,11 +131,15 @@ int finalize_handle(lmpc_handle *h) {
         Wl.oRout = o; o += P.nout * P.n;
         Wl.ox0 = o; o += P.nout;
         Wl.oXth = o; o += P.nout * P.nth;
+        Wl.oGf = o; o += P.m * P.m;                    // (last: the binary32 copy is laid out the same way)
         std::vector<double> wb((size_t)o, 0.0);
         std::memcpy(&wb[Wl.oM], P.M.data(), sizeof(double) * P.M.size());
         for (int j = 0; j < P.m; j++)
             for (int k = 0; k < P.n; k++) wb[Wl.oMt + (size_t)k * P.m + j] = P.M[(size_t)j * P.n + k];
         std::memcpy(&wb[Wl.oG], P.G.data(), sizeof(double) * P.G.size());
+        for (int a = 0; a < P.m; a++)
+            for (int b = 0; b <= a; b++)
+                wb[Wl.oGf + (size_t)a * P.m + b] = wb[Wl.oGf + (size_t)b * P.m + a] = P.G[(size_t)lmpc_tri(a) + b];
         std::memcpy(&wb[Wl.odu], P.du0.data(), sizeof(double) * P.m);
         std::memcpy(&wb[Wl.odl], P.dl0.data(), sizeof(double) * P.m);
         if (P.m * P.nth) std::memcpy(&wb[Wl.oDth], P.Dth.data(), sizeof(double) * P.Dth.size());
@@ -277,8 +281,11 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
 template <typename R>
 int launch_wave_t(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
-    return h->bnb ? launch_wave_inst<R, true>(h, dC, nprob, theta, x, flag, iters, active, warm, st)
-                  : launch_wave_inst<R, false>(h, dC, nprob, theta, x, flag, iters, active, warm, st);
+    if (h->waveGram)
+        return h->bnb ? launch_wave_inst<R, true, true>(h, dC, nprob, theta, x, flag, iters, active, warm, st)
+                      : launch_wave_inst<R, false, true>(h, dC, nprob, theta, x, flag, iters, active, warm, st);
+    return h->bnb ? launch_wave_inst<R, true, false>(h, dC, nprob, theta, x, flag, iters, active, warm, st)
+                  : launch_wave_inst<R, false, false>(h, dC, nprob, theta, x, flag, iters, active, warm, st);
 }
 
 int launch_wave(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
@@ -296,7 +303,7 @@ int ensure_f32(lmpc_handle *h) {
                                              "cover this problem (n <= 127, 1 <= m <= 1024)");
     const HostPack &P = h->P;
     const WaveLayout &Wl = h->W;
-    const size_t total = (size_t)Wl.oXth + (size_t)P.nout * P.nth;
+    const size_t total = (size_t)Wl.oGf + (size_t)P.m * P.m;
     std::vector<float> wb(total ? total : 1, 0.f);
     std::vector<float> Mf((size_t)P.m * P.n);
     for (size_t i = 0; i < Mf.size(); i++) Mf[i] = (float)P.M[i];
@@ -308,6 +315,7 @@ int ensure_f32(lmpc_handle *h) {
             float acc = 0.f;
             for (int k = 0; k < P.n; k++) acc = std::fmaf(Mf[(size_t)a * P.n + k], Mf[(size_t)b * P.n + k], acc);
             wb[Wl.oG + (size_t)lmpc_tri(a) + b] = acc;
+            wb[Wl.oGf + (size_t)a * P.m + b] = wb[Wl.oGf + (size_t)b * P.m + a] = acc;
         }
     for (int j = 0; j < P.m; j++) { wb[Wl.odu + j] = (float)P.du0[j]; wb[Wl.odl + j] = (float)P.dl0[j]; }
     for (size_t i = 0; i < P.Dth.size(); i++) wb[Wl.oDth + i] = (float)P.Dth[i];
@@ -1359,6 +1367,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
     if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "host_threads") == 0) { h->hostThreads = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "gram_scan") == 0) { h->waveGram = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }

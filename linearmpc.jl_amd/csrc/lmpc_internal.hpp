@@ -69,6 +69,7 @@ struct lmpc_handle {
     int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
     int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)
+    int waveGram = 0;           // Gram-scan form of the wavefront kernel ("gram_scan"; lmpc_wave_kernel.hpp GRAM)
     int waveNwv = 0;            // tuning: wavefronts per wave-kernel workgroup (0 = automatic)
     int laneBlock = 0;          // tuning: workgroup size of the lane kernel (0 = automatic)
     int lanePer = 0;            // tuning: work-list workgroups per shard (0 = one resident round)
@@ -160,16 +161,16 @@ int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)
-template <typename R, bool BNB>
+template <typename R, bool BNB, bool GRAM>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st);
-extern template int launch_wave_inst<double, false>(lmpc_handle *, const double *, int64_t, const double *, double *,
-                                                    int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
-extern template int launch_wave_inst<double, true>(lmpc_handle *, const double *, int64_t, const double *, double *,
-                                                   int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
-extern template int launch_wave_inst<float, false>(lmpc_handle *, const float *, int64_t, const float *, float *,
-                                                   int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
-extern template int launch_wave_inst<float, true>(lmpc_handle *, const float *, int64_t, const float *, float *,
-                                                  int32_t *, int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+#define LMPC_WAVE_EXTERN(R, B, G)                                                                                  \
+    extern template int launch_wave_inst<R, B, G>(lmpc_handle *, const R *, int64_t, const R *, R *, int32_t *, \
+                                                  int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+LMPC_WAVE_EXTERN(double, false, false) LMPC_WAVE_EXTERN(double, true, false)
+LMPC_WAVE_EXTERN(float, false, false) LMPC_WAVE_EXTERN(float, true, false)
+LMPC_WAVE_EXTERN(double, false, true) LMPC_WAVE_EXTERN(double, true, true)
+LMPC_WAVE_EXTERN(float, false, true) LMPC_WAVE_EXTERN(float, true, true)
+#undef LMPC_WAVE_EXTERN
 
 }  // namespace lmpc

@@ -1,10 +1,10 @@
 // One instantiation set of the wavefront kernel: real type LMPC_WV_REAL (double | float) with or
-// without branch and bound (LMPC_WV_BNB 0 | 1).  Compiled four times (see Makefile) so that the
-// library's ~100 kernel instantiations build in parallel.
+// without branch and bound (LMPC_WV_BNB 0 | 1), n-chain or Gram-scan form (LMPC_WV_GRAM 0 | 1).  Compiled
+// eight times (see Makefile) so that the library's ~200 kernel instantiations build in parallel.
 #include "lmpc_wave_launch.hpp"
 
 namespace lmpc {
-template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0)>(lmpc_handle *, const LMPC_WV_REAL *, int64_t,
+template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM != 0)>(lmpc_handle *, const LMPC_WV_REAL *, int64_t,
                                                                 const LMPC_WV_REAL *, LMPC_WV_REAL *, int32_t *,
                                                                 int32_t *, uint64_t *, const uint64_t *, hipStream_t);
 }  // namespace lmpc

@@ -99,6 +99,17 @@ template <typename V> __device__ __forceinline__ V wv_min(V v) {
     return wv_min2(wv_min2(a, b), wv_min2(c, d));
 }
 
+// pairwise sum over the 64 lanes, returned wave-uniform: neighbours, pairs of pairs, ... inside the 16-lane rows,
+// then (row0 + row1) + (row2 + row3) -- the order the CPU twin's tree64 restates (oracle/daqp_ldp_oracle.c)
+template <typename V> __device__ __forceinline__ V wv_sum(V v) {
+    v = v + wv_dpp<0xB1>(v);
+    v = v + wv_dpp<0x4E>(v);
+    v = v + wv_dpp<0x141>(v);
+    v = v + wv_dpp<0x140>(v);
+    const V a = wv_bcast(v, 0), b = wv_bcast(v, 16), c = wv_bcast(v, 32), d = wv_bcast(v, 48);
+    return (a + b) + (c + d);
+}
+
 __device__ __forceinline__ double wv_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float wv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -140,7 +151,13 @@ __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB) {
     return MR >= 7 ? 256 : (MR >= 5 || BNB) ? 512 : (MR == 4 ? LMPC_WAVE_LB4 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB));
 }
 
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
+// GRAM: the Gram-scan form ("gram_scan" option).  Same algorithm and decisions, no n-step chain left inside an
+// iteration: row values from Gram columns, M_j u = -sum_{i in W} G(j, W_i) lam*_i (|W| terms instead of n; u itself is
+// formed once, when the solve ends), the dual objective as sum_i y_i z_i from the factorisation, and the two dot
+// products of a row append plus the soft slack as pairwise lane trees (wv_sum) instead of serial chains.  It reads
+// the full symmetric Gram matrix (WaveLayout::oGf; LDSC 1 stages THAT) and neither M' nor the packed triangle.
+// Bit-comparable with the oracle's mode 1 (oracle/daqp_ldp_oracle.c "Gram-scan form"), not with mode 0.
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
 __global__ __launch_bounds__(wave_launch_bound(MR, BNB))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
@@ -166,8 +183,16 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const int lsize = PACKED ? cap * (cap - 1) / 2 : cap * P.ldc;
     R *L = lds + (size_t)wv * lsize;
     auto cbase = [&](int t) -> int { return PACKED ? t * (2 * cap - 1 - t) / 2 - t - 1 : t * P.ldc; };
-    const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG;
-    if (LDSC > 0) {
+    const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG, *Gf = C + P.oGf;
+    if constexpr (GRAM) {
+        if (LDSC > 0) {
+            R *sc = lds + (size_t)nwv * lsize;
+            const int nGf = m * m;
+            for (int i = threadIdx.x; i < nGf; i += blockDim.x) sc[i] = C[P.oGf + i];
+            Gf = sc;
+            __syncthreads();
+        }
+    } else if (LDSC > 0) {
         R *sc = lds + (size_t)nwv * lsize;
         const int nM = m * n, nG = m * (m + 1) / 2;
         for (int i = threadIdx.x; i < nM; i += blockDim.x) sc[i] = C[P.oMt + i];
@@ -291,8 +316,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         R fbound = (R)P.fval_bound;              // a B&B node stops as soon as it is dominated
 
         auto Gat = [&](int a, int c) -> R {
-            return a >= c ? G[(size_t)a * (a + 1) / 2 + c] : G[(size_t)c * (c + 1) / 2 + a];
+            if constexpr (GRAM) return Gf[(size_t)c * m + a];       // symmetric, same bits either way round
+            else return a >= c ? G[(size_t)a * (a + 1) / 2 + c] : G[(size_t)c * (c + 1) / 2 + a];
         };
+        R MuG[GRAM ? MR : 1];                    // GRAM: row values of the last constraint scan (B&B branches on them)
 
         // Column sweeps.  forward: v_i -= L(i,t) v_t for t = 0 .. na-2 in order (lane i holds v_i);
         // lane i reads its row of L eight columns ahead of the chain.
@@ -357,6 +384,11 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             const R rj = lower ? -(C[P.odl + j] + bj) : -(C[P.odu + j] + bj);
             // two serial chains over the old positions: the new pivot and the new entry of y = L^-1 rhs
             R ynew = rj;
+            if constexpr (GRAM) {
+                // lanes >= na hold l = 0 (q masked, Dinv = 0); y may be stale there
+                dnew = dnew - wv_sum(l * q);
+                ynew = rj - wv_sum(lane < na ? l * y : (R)0);
+            } else {
             for (int i0 = 0; i0 < na; i0 += CH) {
 #pragma unroll
                 for (int qq = 0; qq < CH; qq++) {
@@ -367,6 +399,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         ynew = wv_fma(-li, wv_bcast(y, i), ynew);
                     }
                 }
+            }
             }
             dnew = wv_first(dnew);
             const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft_act) >= n);
@@ -468,6 +501,33 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 lowb &= ~(1u << (jrem >> 6));
             }
             nsoft_act -= softrem;
+        };
+
+        // ---- primal iterate u = -M_W' lam* (lane k owns u_k): rows of M eight positions ahead.  Every iteration in
+        // the n-chain form; once, when the solve (or a B&B leaf) ends, in the Gram-scan form
+        auto primal_step = [&]() {
+            R uk[NU];
+#pragma unroll
+            for (int s = 0; s < NU; s++) uk[s] = (R)0;
+            constexpr int CHU = NU == 1 ? CH : CH / 2;      // same register budget for either NU
+            for (int i0 = 0; i0 < na; i0 += CHU) {
+                R mv[CHU][NU];
+#pragma unroll
+                for (int q = 0; q < CHU; q++) {
+                    const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
+#pragma unroll
+                    for (int s = 0; s < NU; s++) mv[q][s] = Mr[(size_t)w * n + lanen[s]];
+                }
+#pragma unroll
+                for (int q = 0; q < CHU; q++)
+                    if (i0 + q < na) {
+                        const R lq = wv_bcast(ls, i0 + q);
+#pragma unroll
+                        for (int s = 0; s < NU; s++) uk[s] = wv_fma(-mv[q][s], lq, uk[s]);
+                    }
+            }
+#pragma unroll
+            for (int s = 0; s < NU; s++) u[s] = lane + 64 * s < n ? uk[s] : (R)0;
         };
 
         // ---- blocking search over the working set: (alpha, rm) = first minimum of the ratios
@@ -581,34 +641,36 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 ls = (lane < na) ? acc : (R)0;
                 blocking(false, alpha, rm);
                 if (rm < 0) {
-                    // primal iterate u = -M_W' lam* (lane k owns u_k): rows of M eight positions ahead
-                    R uk[NU];
-#pragma unroll
-                    for (int s = 0; s < NU; s++) uk[s] = (R)0;
-                    constexpr int CHU = NU == 1 ? CH : CH / 2;      // same register budget for either NU
-                    for (int i0 = 0; i0 < na; i0 += CHU) {
-                        R mv[CHU][NU];
-#pragma unroll
-                        for (int q = 0; q < CHU; q++) {
-                            const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
-#pragma unroll
-                            for (int s = 0; s < NU; s++) mv[q][s] = Mr[(size_t)w * n + lanen[s]];
-                        }
-#pragma unroll
-                        for (int q = 0; q < CHU; q++)
-                            if (i0 + q < na) {
-                                const R lq = wv_bcast(ls, i0 + q);
-#pragma unroll
-                                for (int s = 0; s < NU; s++) uk[s] = wv_fma(-mv[q][s], lq, uk[s]);
-                            }
-                    }
-#pragma unroll
-                    for (int s = 0; s < NU; s++) u[s] = lane + 64 * s < n ? uk[s] : (R)0;
+                    if constexpr (!GRAM) primal_step();
                     // objective u'u and the row values M u in one pass over the variables
                     R fv = (R)0, soft = (R)0;
                     R Mu[MR];
 #pragma unroll
                     for (int r = 0; r < MR; r++) Mu[r] = (R)0;
+                    if constexpr (GRAM) {
+                        // dual objective lam*' K lam* = sum_i y_i z_i (z = D^-1 y is what the backward sweep started from)
+                        fval = wv_sum(lane < na ? y * (y * Dinv) : (R)0);
+                        // row values from Gram columns, working-set order: M_j u = -sum_i G(W_i, j) lam*_i
+                        constexpr int CHG = MR == 1 ? 8 : (MR <= 3 ? 4 : 2);
+                        for (int i0 = 0; i0 < na; i0 += CHG) {
+                            R gv[CHG][MR];
+#pragma unroll
+                            for (int q = 0; q < CHG; q++) {
+                                const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
+#pragma unroll
+                                for (int r = 0; r < MR; r++) gv[q][r] = Gf[(size_t)w * m + jc[r]];
+                            }
+#pragma unroll
+                            for (int q = 0; q < CHG; q++)
+                                if (i0 + q < na) {
+                                    const R lq = wv_bcast(ls, i0 + q);
+#pragma unroll
+                                    for (int r = 0; r < MR; r++) Mu[r] = wv_fma(-gv[q][r], lq, Mu[r]);
+                                }
+                        }
+#pragma unroll
+                        for (int r = 0; r < MR; r++) MuG[r] = Mu[r];
+                    } else {
 #ifndef LMPC_WAVE_CHM_BIG
 #define LMPC_WAVE_CHM_BIG 4
 #endif
@@ -646,6 +708,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                             }
                     soft_slack = wv_first(soft);
                     fval = wv_first(fv) + soft_slack;
+                    }
                     if (fval > fbound) { flag = EXIT_INFEASIBLE; break; }
                     R mval = -primal_tol;
                     int midx = -1;
@@ -666,6 +729,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     }
                     const unsigned long long viol = __ballot(midx >= 0);
                     if (viol == 0ull) {
+                        if constexpr (GRAM)
+                            soft_slack = nsoft_act > 0 ? wv_sum((lane < na && possoft) ? (ls * ls) * rho_soft : (R)0) : (R)0;
                         if (__ballot(broken) != 0ull) flag = EXIT_CYCLE;
                         else flag = (soft_slack > primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
                         break;
@@ -718,6 +783,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         for (int r = 0; r < MR; r++) no_parent[r] = 0ull;
         if (!BNB) {
             solve_node(-1, no_parent, no_parent, false);
+            if constexpr (GRAM) primal_step();
         } else {
             // depth-first branch and bound; stack entry d lives on lane d: the row branched on, the
             // side tried first, and the final working set of the node that branched (what its second
@@ -776,13 +842,20 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int jb = wv_min(cand);
                     if (jb == 0x7fffffff) {              // leaf: every binary sits on a bound
                         if (!have || fval < bestval) {
+                            if constexpr (GRAM) primal_step();
                             have = 1; bestval = fval; bestact = actb; bestlow = lowb;
 #pragma unroll
                             for (int s = 0; s < NU; s++) ubest[s] = u[s];
                         }
                     } else {
                         R Mu = (R)0;
-                        for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], ubc(k), Mu);
+                        if constexpr (GRAM) {
+#pragma unroll
+                            for (int r = 0; r < MR; r++) if (r == (jb >> 6)) Mu = MuG[r];
+                            Mu = wv_bcast(Mu, jb & 63);
+                        } else {
+                            for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], ubc(k), Mu);
+                        }
                         R bj = (R)0;
 #pragma unroll
                         for (int r = 0; r < MR; r++) if (r == (jb >> 6)) bj = b[r];

@@ -9,7 +9,9 @@ namespace lmpc {
 
 // bytes of shared problem data a wave-kernel workgroup keeps in LDS at staging level `level`
 // (1: M transposed, 2: + M, 3: + packed Gram), rs = sizeof(real)
-inline size_t wave_shared_bytes(const HostPack &P, int level, size_t rs) {
+// (Gram-scan form: level 1 = the full m x m Gram matrix, nothing else is read inside an iteration)
+inline size_t wave_shared_bytes(const HostPack &P, int level, size_t rs, bool gram = false) {
+    if (gram) return level >= 1 ? rs * (size_t)P.m * P.m : 0;
     const size_t nM = (size_t)P.m * P.n, nG = (size_t)P.m * (P.m + 1) / 2;
     return rs * (level >= 3 ? 2 * nM + nG : (level == 2 ? 2 * nM : (level == 1 ? nM : 0)));
 }
@@ -58,14 +60,14 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     int bestWaves = -1;
     // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
     // (packed, the 3 / 5 / 6-slot instantiations and everything beyond 256 rows are built for levels 0 and 1 only)
-    const bool twoLevels = packed || h->P.m > 256 || slots == 3;
+    const bool twoLevels = packed || h->P.m > 256 || slots == 3 || h->waveGram;
     for (int level = h->P.n > 64 ? 0 : (twoLevels ? 1 : 3); level >= 0; level--) {
         if (h->waveLevel >= 0 && level != (twoLevels && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
         const int maxWaves = wave_max_resident(slots, h->bnb, rs, level, h->P.n > 64 ? 2 : 1);
         for (int nwv : {4, 8, 16, 12, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;
-            const size_t lds = perWave * nwv + wave_shared_bytes(h->P, level, rs);
+            const size_t lds = perWave * nwv + wave_shared_bytes(h->P, level, rs, h->waveGram != 0);
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
             if (blocks * nwv > maxWaves) blocks = maxWaves / nwv;
@@ -85,12 +87,12 @@ inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     return 4 * pk.blocksPerCU * pk.nwv >= 5 * sq.blocksPerCU * sq.nwv ? pk : sq;
 }
 
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1>
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveList &wl = h->waveList;                    // work-list mode (screening pass in front): see launch()
     const WaveLayout &Wl = h->W;
-    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU>;
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
     int blocksPerCU = cfg.blocksPerCU;
@@ -146,7 +148,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     return LMPC_OK;
 }
 
-template <typename R, bool BNB>
+template <typename R, bool BNB, bool GRAM>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
@@ -168,8 +170,8 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
         if constexpr (BNB) {
             rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: branch and bound covers n <= 64");
         } else {
-#define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
-                                  : launch_wave_cfg<R, MRR, 0, false, false, 2>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
+                                  : launch_wave_cfg<R, MRR, 0, false, false, 2, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
             if (mr <= 2) rc = LMPC_WVU(2);
             else if (mr == 3) rc = LMPC_WVU(3);
             else if (mr == 4) rc = LMPC_WVU(4);
@@ -185,12 +187,24 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
         }
         return rc;
     }
-#define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
+#define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK, 1, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
 #define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
 #define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
                                  : (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))))
 #define LMPC_WVB(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
                                   : (cfg.level >= 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))
+    if constexpr (GRAM) {                                 // the Gram-scan form is built for staging levels 0 and 1
+        if (mr <= 1) rc = LMPC_WVB(1);
+        else if (mr == 2) rc = LMPC_WVB(2);
+        else if (mr == 4) rc = LMPC_WVB(4);
+        else if (mr == 8) rc = LMPC_WVB(8);
+        else if (mr == 16) rc = LMPC_WVB(16);
+        else if constexpr (!BNB) {
+            if (mr == 3) rc = LMPC_WVB(3);
+            else if (mr == 5) rc = LMPC_WVB(5);
+            else rc = LMPC_WVB(6);
+        } else rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no wavefront-kernel instantiation");
+    } else
     if (mr <= 1) rc = LMPC_WV(1);
     else if (mr == 2) rc = LMPC_WV(2);
     else if (mr == 4) rc = LMPC_WV(4);

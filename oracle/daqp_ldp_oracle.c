@@ -100,12 +100,14 @@ typedef struct {
 typedef struct {
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int32_t cycle_tol, iter_limit;
+    int32_t mode, pad_;    /* 0: the n-chain form above; 1: Gram-scan form (ORACLE_MODE_GRAM, see below) */
 } oracle_settings_abi;
 
 /* what the solver compares against: the caller's tolerances rounded to the working precision */
 typedef struct {
     real primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int32_t cycle_tol, iter_limit;
+    int32_t mode;
 } oracle_settings;
 
 static oracle_settings settings_from_abi(const oracle_settings_abi *a) {
@@ -113,6 +115,7 @@ static oracle_settings settings_from_abi(const oracle_settings_abi *a) {
     s.primal_tol = (real)a->primal_tol; s.dual_tol = (real)a->dual_tol; s.zero_tol = (real)a->zero_tol;
     s.progress_tol = (real)a->progress_tol; s.fval_bound = (real)a->fval_bound; s.rho_soft = (real)a->rho_soft;
     s.cycle_tol = a->cycle_tol; s.iter_limit = a->iter_limit;
+    s.mode = a->mode;
     return s;
 }
 
@@ -122,6 +125,9 @@ typedef struct {
     int *WS;
     int32_t *sense;
     real fval, soft_slack;
+    /* Gram-scan form only */
+    int cap64, ydirty;
+    real *Gf, *Mu;
 } work_t;
 
 static work_t *work_new(int n, int m, int nsoft) {
@@ -141,12 +147,14 @@ static work_t *work_new(int n, int m, int nsoft) {
     w->dlower = (real *)calloc(m > 0 ? m : 1, sizeof(real));
     w->WS = (int *)calloc(cap + 1, sizeof(int));
     w->sense = (int32_t *)calloc(m > 0 ? m : 1, sizeof(int32_t));
+    w->cap64 = cap < 64 ? cap : 64;
     return w;
 }
 
 static void work_free(work_t *w) {
     free(w->L); free(w->D); free(w->Dinv); free(w->lam); free(w->lam_star); free(w->xl); free(w->zl);
     free(w->w); free(w->u); free(w->dupper); free(w->dlower); free(w->WS); free(w->sense);
+    free(w->Gf); free(w->Mu);
     free(w);
 }
 
@@ -244,6 +252,7 @@ static void ldl_remove(work_t *w, const oracle_settings *s, int r) {
     }
     w->na = na - 1;
     if (r < w->reuse) w->reuse = r;
+    w->ydirty = 1;
 }
 
 /* Constrained stationary point: solve (L D L') lam* = -d_W. */
@@ -296,6 +305,143 @@ static void primal_and_fval(work_t *w, const oracle_ldp *p, const oracle_setting
     w->fval = fv + soft;
 }
 
+
+/* ======================================================================= Gram-scan form (mode 1)
+ * The twin of the wavefront kernel's GRAM instantiations (lmpc_set_option "gram_scan"): the same
+ * algorithm taking the same decisions, with four sums formed differently so that no n-step chain is
+ * left inside an iteration:
+ *   - row values for the constraint scan from Gram columns,  M_j u = -sum_{i in W} G(j, W_i) lam*_i
+ *     (|W| terms in working-set order instead of n terms; u itself is formed once, at the exit);
+ *   - dual objective from the factorisation,  u'u + rho sum_soft lam*_i^2 = lam*' K lam* = sum_i y_i z_i
+ *     with y = L^-1 rhs, z = D^-1 y  (a 64-leaf pairwise tree, see tree64);
+ *   - the two dot products of a row append (new pivot, new entry of y) and the soft slack as pairwise
+ *     trees over the working-set positions instead of serial chains.
+ * Everything else (triangular sweeps, rank-one removal, ratio tests, selection, guards) is the code
+ * above.  Results differ from mode 0 in the last bits only; a working set that would outgrow 64 rows
+ * is re-solved in mode 0 from scratch (the kernel hands such a point to its slow path, which is mode 0).
+ */
+#define ORACLE_MODE_GRAM 1
+#define EXIT_WSCAP (-7)
+
+/* pairwise sum of 64 leaves in the order of the wavefront reduction: neighbours, pairs of pairs, ... up
+ * to the four 16-lane rows, then (row0 + row1) + (row2 + row3) */
+static real tree64(const real *p) {
+    real a[32], b[16], c[8], d[4];
+    for (int i = 0; i < 32; i++) a[i] = p[2 * i] + p[2 * i + 1];
+    for (int i = 0; i < 16; i++) b[i] = a[2 * i] + a[2 * i + 1];
+    for (int i = 0; i < 8; i++) c[i] = b[2 * i] + b[2 * i + 1];
+    for (int i = 0; i < 4; i++) d[i] = c[2 * i] + c[2 * i + 1];
+    return (d[0] + d[1]) + (d[2] + d[3]);
+}
+
+static void gram_prepare(work_t *w, const oracle_ldp *p) {
+    const int n = p->n, m = p->m;
+    if (w->Gf) return;
+    w->Gf = (real *)calloc((size_t)m * m + 1, sizeof(real));
+    w->Mu = (real *)calloc(m > 0 ? m : 1, sizeof(real));
+    for (int a = 0; a < m; a++)
+        for (int b = 0; b <= a; b++) {
+            real acc = 0.0;
+            for (int k = 0; k < n; k++) acc = RFMA(p->M[(size_t)a * n + k], p->M[(size_t)b * n + k], acc);
+            w->Gf[(size_t)a * m + b] = acc;
+            w->Gf[(size_t)b * m + a] = acc;
+        }
+}
+
+static void ldl_add_gram(work_t *w, const oracle_settings *s, int j) {
+    const int na = w->na, m = w->m;
+    real *row = &w->L[TRI(na)];
+    const real *gj = &w->Gf[(size_t)j * m];
+    real pr[64], py[64];
+    for (int i = 0; i < na; i++) row[i] = gj[w->WS[i]];
+    real dnew = gj[j];
+    if (w->sense[j] & SENSE_SOFT) dnew += s->rho_soft;
+    for (int i = 0; i < na; i++) {          /* q = L \ g */
+        real acc = row[i];
+        const real *li = &w->L[TRI(i)];
+        for (int t = 0; t < i; t++) acc = RFMA(-li[t], row[t], acc);
+        row[i] = acc;
+    }
+    for (int i = 0; i < 64; i++) { pr[i] = 0.0; py[i] = 0.0; }
+    for (int i = 0; i < na; i++) {
+        const real q = row[i], l = q * w->Dinv[i];
+        row[i] = l;
+        pr[i] = l * q;
+        py[i] = l * w->xl[i];
+    }
+    dnew = dnew - tree64(pr);
+    const real rj = (w->sense[j] & SENSE_LOWER) ? -w->dlower[j] : -w->dupper[j];
+    w->xl[na] = rj - tree64(py);            /* new entry of y = L^-1 rhs (meaningless while ydirty: redone then) */
+    row[na] = 1.0;
+    const int is_soft = (w->sense[j] & SENSE_SOFT) != 0;
+    if (dnew < s->zero_tol || (!is_soft && na - w->nsoft_act >= w->n)) {
+        w->D[na] = 0.0; w->Dinv[na] = 0.0; w->sing = na;
+    } else {
+        w->D[na] = dnew; w->Dinv[na] = 1.0 / dnew;
+    }
+    w->WS[na] = j;
+    w->lam[na] = 0.0;
+    w->lam_star[na] = 0.0;
+    w->sense[j] |= SENSE_ACTIVE;
+    w->nsoft_act += is_soft;
+    w->na = na + 1;
+}
+
+static void compute_csp_gram(work_t *w) {
+    const int na = w->na;
+    real pf[64];
+    if (w->ydirty) {                        /* a row left since the last stationary point: y from scratch */
+        for (int i = 0; i < na; i++) {
+            const int j = w->WS[i];
+            real acc = (w->sense[j] & SENSE_LOWER) ? -w->dlower[j] : -w->dupper[j];
+            const real *li = &w->L[TRI(i)];
+            for (int t = 0; t < i; t++) acc = RFMA(-li[t], w->xl[t], acc);
+            w->xl[i] = acc;
+        }
+        w->ydirty = 0;
+    }
+    for (int i = 0; i < 64; i++) pf[i] = 0.0;
+    for (int i = 0; i < na; i++) { w->zl[i] = w->xl[i] * w->Dinv[i]; pf[i] = w->xl[i] * w->zl[i]; }
+    w->fval = tree64(pf);
+    for (int i = na - 1; i >= 0; i--) {
+        real acc = w->zl[i];
+        for (int t = na - 1; t > i; t--) acc = RFMA(-w->L[TRI(t) + i], w->lam_star[t], acc);
+        w->lam_star[i] = acc;
+    }
+}
+
+/* row values of every constraint at the stationary point, from Gram columns */
+static void scan_gram(work_t *w) {
+    const int m = w->m;
+    for (int j = 0; j < m; j++) w->Mu[j] = 0.0;
+    for (int i = 0; i < w->na; i++) {
+        const real *gi = &w->Gf[(size_t)w->WS[i] * m];
+        const real l = w->lam_star[i];
+        for (int j = 0; j < m; j++) w->Mu[j] = RFMA(-gi[j], l, w->Mu[j]);
+    }
+}
+
+static void soft_slack_gram(work_t *w, const oracle_settings *s) {
+    real ps[64];
+    w->soft_slack = 0.0;
+    if (w->nsoft_act <= 0) return;
+    for (int i = 0; i < 64; i++) ps[i] = 0.0;
+    for (int i = 0; i < w->na; i++)
+        if (w->sense[w->WS[i]] & SENSE_SOFT) ps[i] = (w->lam_star[i] * w->lam_star[i]) * s->rho_soft;
+    w->soft_slack = tree64(ps);
+}
+
+/* u = -M_W' lam* over the working set as it stands (formed once, when the solve ends) */
+static void primal_gram(work_t *w, const oracle_ldp *p) {
+    const int n = w->n;
+    for (int k = 0; k < n; k++) w->u[k] = 0.0;
+    for (int i = 0; i < w->na; i++) {
+        const real *mi = &p->M[(size_t)w->WS[i] * n];
+        const real l = w->lam_star[i];
+        for (int k = 0; k < n; k++) w->u[k] = RFMA(-mi[k], l, w->u[k]);
+    }
+}
+
 static void write_outputs(const work_t *w, const oracle_ldp *p, const real *theta,
                           real *xout, uint64_t *active, int nwords) {
     const int n = p->n, nth = p->nth;
@@ -343,12 +489,14 @@ static void shift_bounds(work_t *w, const oracle_ldp *p, const real *theta) {
 static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, const int32_t *sense0,
                       const uint64_t *warm, int two_pass, int forced, int32_t *iters) {
     const int n = p->n, m = p->m;
+    const int gram = s->mode == ORACLE_MODE_GRAM;
     int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
     real best_fval = -1.0;
 
     if (forced < 0) {
         for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
         w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
+        w->ydirty = 0;
         for (int k = 0; k < n; k++) w->u[k] = 0.0;
 
         /* initial working set: rows flagged ACTIVE and, if warm, the given mask */
@@ -362,7 +510,10 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                 }
                 if (!want) { w->sense[j] &= ~SENSE_ACTIVE; continue; }
                 if (lower) w->sense[j] |= SENSE_LOWER;
-                ldl_add(w, p, s, j);
+                if (gram) {
+                    if (w->na >= w->cap64) { exitflag = EXIT_WSCAP; goto done; }
+                    ldl_add_gram(w, s, j);
+                } else ldl_add(w, p, s, j);
                 if (w->sing >= 0) {
                     if (sense0[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
                     /* dependent warm-start row: drop it again */
@@ -375,6 +526,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
     } else {
         const int jf = forced >> 1;
         w->sense[jf] = (sense0[jf] & ~SENSE_LOWER) & ~SENSE_ACTIVE;             /* ldl_add sets ACTIVE */
+        if (gram && iter < s->iter_limit && w->na >= w->cap64) { exitflag = EXIT_WSCAP; goto done; }
     }
 
     for (; iter < s->iter_limit; iter++) {
@@ -385,7 +537,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                 add = forced >> 1; isupper = !(forced & 1);
                 forced = -1;
             } else {
-                compute_csp(w);
+                if (gram) compute_csp_gram(w); else compute_csp(w);
                 for (int i = 0; i < w->na; i++) {
                     const int j = w->WS[i];
                     if (w->sense[j] & SENSE_IMMUTABLE) continue;
@@ -396,7 +548,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                     nblock++;
                 }
                 if (nblock == 0) {
-                    primal_and_fval(w, p, s);
+                    if (gram) scan_gram(w); else primal_and_fval(w, p, s);
                     if (w->fval > s->fval_bound) { exitflag = EXIT_INFEASIBLE; break; }
                     /* most violated constraint, primal_tol margin */
                     real min_val = -s->primal_tol;
@@ -405,7 +557,8 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                         if (w->sense[j] & SENSE_IMMUTABLE) continue;
                         const real *mj = &p->M[(size_t)j * n];
                         real Mu = 0.0;
-                        for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
+                        if (gram) Mu = w->Mu[j];
+                        else for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
                         const real vu = w->dupper[j] - Mu;
                         const real vl = -(w->dlower[j] - Mu);
                         if (w->sense[j] & SENSE_ACTIVE) {
@@ -420,6 +573,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                         else if (vl < min_val) { add = j; isupper = 0; min_val = vl; }
                     }
                     if (add < 0) {
+                        if (gram) soft_slack_gram(w, s);
                         if (broken) exitflag = EXIT_CYCLE;
                         else exitflag = (w->soft_slack > s->primal_tol) ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL;
                         break;
@@ -429,7 +583,10 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
             if (add >= 0) {
                 for (int i = 0; i < w->na; i++) w->lam[i] = w->lam_star[i];
                 if (!isupper) w->sense[add] |= SENSE_LOWER;
-                ldl_add(w, p, s, add);
+                if (gram) {
+                    if (w->na >= w->cap64) { exitflag = EXIT_WSCAP; break; }
+                    ldl_add_gram(w, s, add);
+                } else ldl_add(w, p, s, add);
                 if (w->fval - best_fval < s->progress_tol) {
                     if (++cycle > s->cycle_tol) { exitflag = EXIT_CYCLE; break; }
                 } else { best_fval = w->fval; cycle = 0; }
@@ -440,6 +597,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
             }
         } else {
             singular_direction(w);
+            if (gram) for (int i = w->sing + 1; i < w->na; i++) w->lam_star[i] = 0.0;
             int nblock = 0, rm = -1;
             real alpha = 0.0;
             for (int i = 0; i < w->na; i++) {
@@ -457,6 +615,7 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
         }
     }
 done:
+    if (gram) primal_gram(w, p);
     if (iters) *iters = iter;
     return exitflag;
 }
@@ -465,7 +624,12 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
                      const real *theta, const uint64_t *warm, real *xout,
                      int32_t *iters, uint64_t *active, int nwords) {
     shift_bounds(w, p, theta);
-    const int ef = solve_core(w, p, s, p->sense, warm, 0, -1, iters);
+    int ef = solve_core(w, p, s, p->sense, warm, 0, -1, iters);
+    if (ef == EXIT_WSCAP) {                 /* Gram-scan form only: more than 64 rows wanted -> mode 0 from scratch */
+        oracle_settings s0 = *s;
+        s0.mode = 0;
+        ef = solve_core(w, p, &s0, p->sense, warm, 0, -1, iters);
+    }
     write_outputs(w, p, theta, xout, active, nwords);
     return ef;
 }
@@ -514,6 +678,7 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
         else ef = solve_core(w, p, &sn, sense, depth > 0 ? stk_mask + (size_t)(depth - 1) * nw : NULL, 1, -1, &it);
         nodes++;
         total_it += it;
+        if (ef == EXIT_WSCAP) { flag = EXIT_WSCAP; have = 0; break; }     /* Gram-scan form: as the kernel does */
         int descend = 0;
         if (ef >= 1) {
             int jb = -1;
@@ -533,7 +698,8 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
             } else {
                 const real *mj = &p->M[(size_t)jb * n];
                 real Mu = 0.0;
-                for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
+                if (s->mode == ORACLE_MODE_GRAM) Mu = w->Mu[jb];
+                else for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
                 const int lower_first = (Mu - w->dlower[jb]) < (w->dupper[jb] - Mu);
                 stk_j[depth] = jb; stk_side[depth] = lower_first; stk_tried[depth] = 1;
                 uint64_t *mk = stk_mask + (size_t)depth * nw;       /* this node's final working set */
@@ -576,9 +742,11 @@ void oracle_default_settings(oracle_settings_abi *s) {
 #ifdef ORACLE_F32
     s->primal_tol = 1e-4; s->dual_tol = 1e-6; s->zero_tol = 1e-6; s->progress_tol = 1e-4;
     s->fval_bound = 1e30; s->rho_soft = 1e-3; s->cycle_tol = 10; s->iter_limit = 10000;
+    s->mode = 0; s->pad_ = 0;
 #else
     s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
     s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+    s->mode = 0; s->pad_ = 0;
 #endif
 }
 
@@ -592,6 +760,7 @@ void oracle_solve_batch(const oracle_ldp *p, const oracle_settings_abi *sabi, in
     int nsoft = 0;
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
+    if (s->mode == ORACLE_MODE_GRAM) gram_prepare(w, p);
     int nbin = 0;
     for (int j = 0; j < p->m; j++) nbin += (p->sense[j] & SENSE_BINARY) != 0;
     for (int64_t i = 0; i < N; i++) {
@@ -629,6 +798,7 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings_abi *sabi, int64
     for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) != 0;
     for (int j = 0; j < p->m; j++) nbin += (p->sense[j] & SENSE_BINARY) != 0;
     work_t *w = work_new(p->n, p->m, nsoft);
+    if (s->mode == ORACLE_MODE_GRAM) gram_prepare(w, p);
     real *th = (real *)calloc(nth > 0 ? nth : 1, sizeof(real));
     real *u = (real *)calloc(nu, sizeof(real));
     real *xn = (real *)calloc(nx, sizeof(real));

@@ -106,7 +106,8 @@ class Settings(ctypes.Structure):
     _fields_ = [("primal_tol", ctypes.c_double), ("dual_tol", ctypes.c_double),
                 ("zero_tol", ctypes.c_double), ("progress_tol", ctypes.c_double),
                 ("fval_bound", ctypes.c_double), ("rho_soft", ctypes.c_double),
-                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32)]
+                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32),
+                ("mode", ctypes.c_int32), ("pad_", ctypes.c_int32)]      # mode 1: Gram-scan form (twin of the GRAM kernels)
 
 
 _lib = None

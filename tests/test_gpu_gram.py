@@ -1,0 +1,196 @@
+"""GPU parity tests of the wavefront kernel's Gram-scan form (`lmpc_set_option("gram_scan", 1)`).
+
+The Gram-scan form takes the same decisions as the n-chain form but sums three quantities in a different order
+(row values from Gram columns, the dual objective from the factorisation, pairwise lane trees for the dot
+products of a row append), so its checker is the oracle's mode 1 (oracle/daqp_ldp_oracle.c "Gram-scan form"):
+bit-identical exit flags, iteration counts, active sets and x.  Against the n-chain form (mode 0, what libdaqp
+does per iteration: /root/reference/codegen/mpc_update_qp.c:48) the two agree on every solvable point in flag,
+iteration count and active set and to <= 1e-10 in x on hard-constrained problems; with SOFT rows the 1/rho_soft
+penalty amplifies the rounding of either form, the bound asserted there is 1e-4.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, oracle_ldp_from
+from test_gpu_parity import _qp_from_golden, _random_qp, _copy_settings, lmpc  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _gram_settings(rho=None, f32=False):
+    from oracle import ldp as oldp
+    s = oldp.default_settings_f32() if f32 else oldp.default_settings()
+    s.mode = 1
+    if rho is not None:
+        s.rho_soft = rho
+    return s
+
+
+def _compare_gram(qp, theta, warm=None, settings=None, f32=False):
+    """gram_scan on: the GPU against the oracle's mode 1, bit for bit."""
+    from oracle import ldp as oldp
+    L = oracle_ldp_from(qp.ldp())
+    qp.set_option("gram_scan", 1)
+    s = settings if settings is not None else _gram_settings(f32=f32)
+    assert s.mode == 1
+    if f32:
+        theta = np.asarray(theta, np.float32)
+        x, ef, it, act = qp.solve_f32(theta, warm=warm)
+        xo, efo, ito, acto = oldp.solve_batch(L, theta, s, warm=warm, dtype=np.float32)
+    else:
+        x, ef, it, act = qp.solve(theta, warm=warm)
+        xo, efo, ito, acto = oldp.solve_batch(L, theta, s, warm=warm)
+    assert np.array_equal(ef, efo), np.flatnonzero(ef != efo)[:10]
+    assert np.array_equal(it, ito), np.flatnonzero(it != ito)[:10]
+    assert np.array_equal(act, acto)
+    assert np.array_equal(x, xo), np.abs(x - xo).max()
+    return x, ef, it, act
+
+
+def _against_chain_form(qp, theta, x, ef, it, act, xtol):
+    """... and against the n-chain form on the same handle: same answers wherever a solution exists."""
+    qp.set_option("gram_scan", 0)
+    x0, ef0, it0, act0 = qp.solve(theta)
+    qp.set_option("gram_scan", 1)
+    ok = ef0 >= 1
+    assert np.array_equal(ef >= 1, ok)
+    assert np.array_equal(ef[ok], ef0[ok]) and np.array_equal(it[ok], it0[ok]) and np.array_equal(act[ok], act0[ok])
+    if ok.any():
+        assert np.abs(x[ok] - x0[ok]).max() <= xtol, np.abs(x[ok] - x0[ok]).max()
+
+
+@pytest.mark.parametrize("name", ["pendulum", "mass_spring", "mass_spring_3in", "preprocessing_kat", "x0unc_kat"])
+def test_gram_form_hard_rows(lmpc, name):
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    qp.set_option("wave", 1)
+    assert qp.kernel_name == "wave"
+    x, ef, it, act = _compare_gram(qp, g["theta"])
+    _against_chain_form(qp, g["theta"], x, ef, it, act, 1e-6 if name == "x0unc_kat" else TOL)
+    ok = ef >= 1
+    _compare_gram(qp, g["theta"][ok], warm=act[ok])
+
+
+@pytest.mark.parametrize("name,rho", [("soft_doc", None), ("soft_doc", 1e-3)])
+def test_gram_form_soft_rows(lmpc, name, rho):
+    g = load_golden(name)
+    s = lmpc.default_settings()
+    if rho is not None:
+        s.rho_soft = rho
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+    x, ef, it, act = _compare_gram(qp, g["theta"], settings=_gram_settings(rho))
+    assert (ef == 2).any() and (ef == 1).any()
+    _against_chain_form(qp, g["theta"], x, ef, it, act, 1e-4)
+
+
+@pytest.mark.parametrize("packed,level,nwv", [(0, 0, 2), (0, 1, 8), (1, 0, 8), (1, 1, 2)])
+def test_gram_form_layouts_and_staging_levels_agree(lmpc, packed, level, nwv):
+    for name in ("mass_spring_3in", "soft_doc", "satellite20"):
+        g = load_golden(name)
+        qp = _qp_from_golden(lmpc, g)
+        qp.set_option("gram_scan", 1)
+        ref = qp.solve(g["theta"][:300])
+        qp.set_option("wave_packed", packed)
+        qp.set_option("wave_level", level)
+        qp.set_option("wave_nwv", nwv)
+        out = qp.solve(g["theta"][:300])
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize("N", [50, 75, 100, 125])
+def test_gram_form_reference_benchmark_class(lmpc, N):
+    """docs/src/manual/benchmark.md:4-16: n = N, 3N - 2 rows, 2N - 2 of them soft -- where the Gram-scan form pays:
+    |W| Gram columns per iteration instead of n columns of M'."""
+    g = load_golden(f"pendulum_N{N}")
+    theta = g["theta"]
+    qp = _qp_from_golden(lmpc, g, 1)
+    assert qp.kernel_name == "wave"
+    for scr in (1, 0):
+        qp.set_option("screen_wave", scr)
+        x, ef, it, act = _compare_gram(qp, theta)
+    assert np.all(ef >= 1)
+    _against_chain_form(qp, theta, x, ef, it, act, 1e-4)
+    qt = _qp_from_golden(lmpc, g)                                 # whole trajectory + warm start
+    xt, eft, itt, actt = _compare_gram(qt, theta[:200])
+    assert np.array_equal(xt[:, 0], x[:200, 0])
+    _compare_gram(qt, theta[:200], warm=actt)
+    q32 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1,
+                                   settings=lmpc.default_settings_f32())
+    _compare_gram(q32, theta[:256], f32=True)
+
+
+@pytest.mark.parametrize("n,mg,nth,nsoft,seed", [(20, 30, 6, 0, 0), (30, 90, 8, 10, 1), (63, 100, 5, 0, 2),
+                                                 (12, 200, 4, 40, 3), (3, 5, 2, 2, 4),
+                                                 (8, 300, 3, 0, 11), (20, 480, 5, 60, 12), (40, 984, 4, 100, 13),
+                                                 (70, 100, 5, 0, 16), (30, 270, 6, 30, 17), (100, 273, 7, 0, 20),
+                                                 (127, 60, 4, 0, 21), (90, 200, 5, 20, 22)])
+def test_gram_form_random_problems(lmpc, n, mg, nth, nsoft, seed):
+    rng = np.random.default_rng(seed)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
+    big = mg > 128
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, (2 if big else 1) * bu, (2 if big else 1) * bl,
+                                  (0.3 if big else 1.0) * W, sense, nout=min(n, 4))
+    assert qp.kernel_name == "wave"
+    theta = rng.uniform(-2, 2, (400, nth))
+    x, ef, it, act = _compare_gram(qp, theta)
+    assert (ef >= 1).mean() > 0.05
+    _against_chain_form(qp, theta, x, ef, it, act, 1e-4 if nsoft else 1e-9)
+    ok = ef >= 1
+    _compare_gram(qp, theta[ok][:65], warm=act[ok][:65])
+    if nsoft == 0:
+        s32 = lmpc.default_settings_f32()
+        qf = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, (2 if big else 1) * bu, (2 if big else 1) * bl,
+                                      (0.3 if big else 1.0) * W, sense, nout=min(n, 4), settings=s32)
+        so = _copy_settings(lmpc, s32)
+        so.mode = 1
+        _compare_gram(qf, theta, settings=so, f32=True)
+
+
+@pytest.mark.parametrize("name", ["satellite4", "satellite20", "satellite20_preview"])
+def test_gram_form_hybrid_branch_and_bound(lmpc, name):
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    x, ef, it, act = _compare_gram(qp, g["theta"])
+    assert np.all(ef == 1)
+    bins = np.flatnonzero(g["senses"] & 16)
+    assert np.all(np.minimum(np.abs(x[:, bins] - g["bu"][bins]), np.abs(x[:, bins] - g["bl"][bins])) < 1e-9)
+    assert np.abs(x - g["X"]).max() <= 1e-8
+    q32 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                   settings=lmpc.default_settings_f32())
+    _compare_gram(q32, g["theta"], f32=True)
+
+
+def test_gram_form_working_sets_beyond_the_64_lanes(lmpc):
+    # a point whose working set outgrows the 64 lanes is re-solved by the one-problem-per-thread kernel, which is
+    # the n-chain form; the oracle's mode 1 does the same (mode 0 from scratch)
+    rng = np.random.default_rng(5)
+    n, mg, nth = 6, 150, 2
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=mg)
+    W[n:, 0] = np.abs(W[n:, 0]) + 0.5
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
+    theta = np.vstack([rng.uniform(-1, 1, (200, nth)),
+                       np.hstack([rng.uniform(30, 60, (56, 1)), rng.uniform(-1, 1, (56, 1))])])
+    x, ef, it, act = _compare_gram(qp, theta)
+    nact = np.array([sum(bin(int(w)).count("1") for w in row) for row in act])
+    assert (nact > 64).sum() >= 20 and (ef >= 1).all()
+
+
+def test_gram_form_closed_loop(lmpc):
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    prob = omm.doc_simple_soft()
+    g = load_golden("soft_doc")
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_option("gram_scan", 1)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(9)
+    N, T = 400, 10
+    x0 = rng.uniform(0, 0.5, (N, 2)); x0[0] = 0.0
+    r = np.tile([1.0, 0.0], (N, 1))
+    for warm in (False, True):
+        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=warm, settings=_gram_settings())
+        out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
+        assert np.array_equal(out["flag_min"], ref["flag_min"])
+        assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])

@@ -780,7 +780,7 @@ def _copy_settings(lmpc, s):
     from oracle import ldp as oldp
     so = oldp.Settings()
     for f, _ in so._fields_:
-        setattr(so, f, getattr(s, f))
+        setattr(so, f, getattr(s, f, 0))
     return so
 
 

@@ -25,7 +25,7 @@ t0 = time.time()
 def copy_settings(s):
     so = oldp.Settings()
     for f, _ in so._fields_:
-        setattr(so, f, getattr(s, f))
+        setattr(so, f, getattr(s, f, 0))
     return so
 
 
