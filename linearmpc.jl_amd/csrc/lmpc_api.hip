@@ -132,6 +132,7 @@ int finalize_handle(lmpc_handle *h) {
         Wl.ox0 = o; o += P.nout;
         Wl.oXth = o; o += P.nout * P.nth;
         Wl.oGf = o; o += P.m * P.m;                    // (last: the binary32 copy is laid out the same way)
+        Wl.nC = o;
         std::vector<double> wb((size_t)o, 0.0);
         std::memcpy(&wb[Wl.oM], P.M.data(), sizeof(double) * P.M.size());
         for (int j = 0; j < P.m; j++)

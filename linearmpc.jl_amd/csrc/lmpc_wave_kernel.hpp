@@ -113,6 +113,20 @@ template <typename V> __device__ __forceinline__ V wv_sum(V v) {
 __device__ __forceinline__ double wv_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float wv_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// Constant-pack loads with a per-lane index go through a BUFFER resource: C[soff + voff] with soff wave-uniform (a
+// scalar register) and voff this lane's 32-bit index.  The address is formed by the load unit from the descriptor, so
+// no 64-bit per-lane pointer exists for the compiler to hoist out of the loops and spill (plain pointer arithmetic
+// left the hot loop with four scratch reloads in front of four dependent loads per iteration), and the many bases
+// into the one pack are integer offsets.
+typedef unsigned int wv_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double wv_bufld(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, double) {
+    const wv_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(voff * 8u), (int)(soff * 8u), 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+__device__ __forceinline__ float wv_bufld(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff * 4u), (int)(soff * 4u), 0));
+}
+
 __device__ __forceinline__ bool wv_in(unsigned long long mask) {
     // per-lane predicate from a scalar lane mask: no vector compare
     return __builtin_amdgcn_inverse_ballot_w64(mask);
@@ -181,19 +195,32 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     // it costs ~6 % on small problems (index arithmetic, bank conflicts of the column reads), so the
     // host picks it only where it buys residency.
     const int lsize = PACKED ? cap * (cap - 1) / 2 : cap * P.ldc;
-    R *L = lds + (size_t)wv * lsize;
+    // ... followed by 64 reals per wavefront: the multipliers lam*, written once per iteration and read back as LDS
+    // broadcasts by the loops that multiply by one lam*_i per step (Gram scan, primal step) -- one LDS read instead of
+    // two v_readlane per step on the vector ALU, which is what bounds this kernel
+    const int wsize = lsize + 64;
+    R *L = lds + (size_t)wv * wsize;
+    R *Lam = L + lsize;
+    // ZP (square layout): the factor's storage is kept at exact zeros wherever no entry lives -- on and above the
+    // diagonal, and in the rows at and beyond the working set's size.  A sweep step is then v = fma(-L, v_t, v) on
+    // ALL lanes: fma(-0, v_t, v) = v leaves the lanes the step does not concern as they are (bit for bit, finite v_t),
+    // so the per-step lane mask and the select behind it are gone: 3 vector instructions per step instead of 5.
+    constexpr bool ZP = !PACKED;
+    if constexpr (ZP) {
+        for (int i = lane; i < lsize; i += 64) L[i] = (R)0;
+    }
     auto cbase = [&](int t) -> int { return PACKED ? t * (2 * cap - 1 - t) / 2 - t - 1 : t * P.ldc; };
     const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG, *Gf = C + P.oGf;
     if constexpr (GRAM) {
         if (LDSC > 0) {
-            R *sc = lds + (size_t)nwv * lsize;
+            R *sc = lds + (size_t)nwv * wsize;
             const int nGf = m * m;
             for (int i = threadIdx.x; i < nGf; i += blockDim.x) sc[i] = C[P.oGf + i];
             Gf = sc;
             __syncthreads();
         }
     } else if (LDSC > 0) {
-        R *sc = lds + (size_t)nwv * lsize;
+        R *sc = lds + (size_t)nwv * wsize;
         const int nM = m * n, nG = m * (m + 1) / 2;
         for (int i = threadIdx.x; i < nM; i += blockDim.x) sc[i] = C[P.oMt + i];
         Mt = sc;
@@ -213,19 +240,27 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const int lrow = lane < cap ? lane : cap - 1;                // clamped row/column of L for prefetches
     const int lrow1 = lane + 1 < cap ? lane + 1 : cap - 1;
     const int lr1 = lrow > 0 ? lrow : 1;                         // row index that is valid in every column read
+    const int lz = lane < cap ? lane : 0;                        // ZP: this lane's row; row 0 holds zeros in every column
     const int mycol = cbase(lrow);                               // this lane's own column: L(t, lane) = L[mycol + t]
-    int lanen[NU];                                             // this lane's variables, clamped into [0, n)
+    // Per-lane indices into the constant pack are UNSIGNED 32-bit offsets from wave-uniform bases: the loads then take
+    // the scalar-base + vector-offset form (one offset register each) instead of 64-bit per-lane pointers, which the
+    // compiler hoists out of the loops as register pairs and then spills (the n-chain form's scan reloaded four of
+    // them from scratch in every iteration, each reload one more round trip in front of its load)
+    unsigned lanen[NU];                                        // this lane's variables, clamped into [0, n)
 #pragma unroll
-    for (int s = 0; s < NU; s++) lanen[s] = lane + 64 * s < n ? lane + 64 * s : n - 1;
+    for (int s = 0; s < NU; s++) lanen[s] = (unsigned)(lane + 64 * s < n ? lane + 64 * s : n - 1);
+    const __amdgpu_buffer_rsrc_t crs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(C), 0, P.nC * (int)sizeof(R), 0x00020000);
+    auto ldc = [&](unsigned soff, unsigned voff) -> R { return wv_bufld(crs, voff, soff, R()); };   // C[soff + voff]
 
     int sense0[MR], sense[MR];                       // constraint slots of this lane: as given / of the
-    int jc[MR];                                      // current solve (a B&B node adds its fixed binaries)
+    unsigned jc[MR];                                 // current solve (a B&B node adds its fixed binaries)
 #pragma unroll
     for (int r = 0; r < MR; r++) {
         const int j = lane + 64 * r;
         sense0[r] = (j < m) ? S[j] : SENSE_IMMUTABLE;
         sense[r] = sense0[r];
-        jc[r] = j < m ? j : m - 1;
+        jc[r] = (unsigned)(j < m ? j : m - 1);
     }
     // flags of row j (wave-uniform) from the slot that owns it
     auto sense_of = [&](int j) -> int {
@@ -286,9 +321,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 #pragma unroll
             for (int r = 0; r < MR; r++) {
                 R dv[CH];
-                const R *dj = C + P.oDth + (size_t)jc[r] * nth;
+                const unsigned drow = jc[r] * (unsigned)nth;
 #pragma unroll
-                for (int q = 0; q < CH; q++) dv[q] = dj[t0 + q < nth ? t0 + q : nth - 1];
+                for (int q = 0; q < CH; q++) dv[q] = ldc((unsigned)(P.oDth + (t0 + q < nth ? t0 + q : nth - 1)), drow);
 #pragma unroll
                 for (int q = 0; q < CH; q++)
                     if (t0 + q < nth) b[r] = wv_fma(dv[q], tv[q], b[r]);
@@ -316,8 +351,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         R fbound = (R)P.fval_bound;              // a B&B node stops as soon as it is dominated
 
         auto Gat = [&](int a, int c) -> R {
-            if constexpr (GRAM) return Gf[(size_t)c * m + a];       // symmetric, same bits either way round
-            else return a >= c ? G[(size_t)a * (a + 1) / 2 + c] : G[(size_t)c * (c + 1) / 2 + a];
+            if constexpr (GRAM) {                  // symmetric, same bits either way round
+                if constexpr (LDSC > 0) return Gf[c * m + a];
+                else return ldc((unsigned)(P.oGf + c * m), (unsigned)a);
+            }
+            else {
+                const unsigned gi = (unsigned)(a >= c ? a * (a + 1) / 2 + c : c * (c + 1) / 2 + a);
+                if constexpr (LDSC > 2) return G[gi];
+                else return ldc((unsigned)P.oG, gi);
+            }
         };
         R MuG[GRAM ? MR : 1];                    // GRAM: row values of the last constraint scan (B&B branches on them)
 
@@ -330,14 +372,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
                     const int t = t0 + q < cap ? t0 + q : cap - 1;
-                    Lr[q] = L[cbase(t) + lr1];
+                    Lr[q] = L[cbase(t) + (ZP ? lz : lr1)];
                 }
 #pragma unroll
                 for (int q = 0; q < CH; q++) {
                     const int t = t0 + q;
                     if (t + 1 < na) {
                         const R vt = wv_bcast(v, t);
-                        if (wv_in(rows & (~1ull << t))) v = wv_fma(-Lr[q], vt, v);   // rows t < i < na
+                        if constexpr (ZP) v = wv_fma(-Lr[q], vt, v);                 // L(i,t) = 0 outside t < i < na
+                        else if (wv_in(rows & (~1ull << t))) v = wv_fma(-Lr[q], vt, v);   // rows t < i < na
                     }
                 }
             }
@@ -357,11 +400,21 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     const int t = t1 - q;
                     if (t >= 1) {
                         const R vt = wv_bcast(v, t);
-                        if (wv_in(wv_below63(t))) v = wv_fma(-Lc[q], vt, v);          // columns i < t  (1 <= t <= 63)
+                        if constexpr (ZP) v = wv_fma(-Lc[q], vt, v);                  // L(t,i) = 0 for i >= t
+                        else if (wv_in(wv_below63(t))) v = wv_fma(-Lc[q], vt, v);     // columns i < t  (1 <= t <= 63)
                     }
                 }
             }
             return v;
+        };
+
+        // ZP: rows [from, to) of the factor back to zeros (a row that left the working set, or all of them between
+        // two solves): lane t clears its column's entries
+        auto clear_rows = [&](int from, int to) {
+            if constexpr (ZP) {
+                for (int i = from; i < to; i++)
+                    if (lane < i) L[mycol + i] = (R)0;
+            }
         };
 
         // ---- append constraint j (wave-uniform) to the working set
@@ -461,6 +514,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     w = (R)0;
                 }
             }
+            clear_rows(nao - 1, nao);
             na = nao - 1;
             sing = -1;
             ydirty = true;
@@ -510,20 +564,24 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 #pragma unroll
             for (int s = 0; s < NU; s++) uk[s] = (R)0;
             constexpr int CHU = NU == 1 ? CH : CH / 2;      // same register budget for either NU
+            Lam[lane] = ls;
             for (int i0 = 0; i0 < na; i0 += CHU) {
-                R mv[CHU][NU];
+                R mv[CHU][NU], lq[CHU];
 #pragma unroll
                 for (int q = 0; q < CHU; q++) {
                     const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
 #pragma unroll
-                    for (int s = 0; s < NU; s++) mv[q][s] = Mr[(size_t)w * n + lanen[s]];
+                    for (int s = 0; s < NU; s++) {
+                        if constexpr (!GRAM && LDSC > 1) mv[q][s] = Mr[w * n + (int)lanen[s]];
+                        else mv[q][s] = ldc((unsigned)(P.oM + w * n), lanen[s]);
+                    }
+                    lq[q] = Lam[i0 + q < 64 ? i0 + q : 63];
                 }
 #pragma unroll
                 for (int q = 0; q < CHU; q++)
                     if (i0 + q < na) {
-                        const R lq = wv_bcast(ls, i0 + q);
 #pragma unroll
-                        for (int s = 0; s < NU; s++) uk[s] = wv_fma(-mv[q][s], lq, uk[s]);
+                        for (int s = 0; s < NU; s++) uk[s] = wv_fma(-mv[q][s], lq[q], uk[s]);
                     }
             }
 #pragma unroll
@@ -556,6 +614,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                               bool have_parent) {
         iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; best = (R)-1; done = false;
         if (!BNB || forced < 0) {
+        clear_rows(1, na);                       // (rows of the previous solve / node; row 0 has no entries)
         WSi = 0; possoft = 0; posimm = 0; poslow = 0;
         lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0;
 #pragma unroll
@@ -603,6 +662,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         else {                              // dependent warm-start row: take it out again
                             na--;
                             sing = -1;
+                            clear_rows(na, na + 1);
                             if (lane == na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0; }
                             if (sj & SENSE_SOFT) nsoft_act--;
                             if (lane == (j & 63)) { actb &= ~(1u << (j >> 6)); lowb &= ~(1u << (j >> 6)); }
@@ -652,20 +712,24 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         fval = wv_sum(lane < na ? y * (y * Dinv) : (R)0);
                         // row values from Gram columns, working-set order: M_j u = -sum_i G(W_i, j) lam*_i
                         constexpr int CHG = MR == 1 ? 8 : (MR <= 3 ? 4 : 2);
+                        Lam[lane] = ls;                  // (lanes >= na hold 0)
                         for (int i0 = 0; i0 < na; i0 += CHG) {
-                            R gv[CHG][MR];
+                            R gv[CHG][MR], lq[CHG];
 #pragma unroll
                             for (int q = 0; q < CHG; q++) {
                                 const int w = __builtin_amdgcn_readlane(WSi, i0 + q < na ? i0 + q : na - 1);
 #pragma unroll
-                                for (int r = 0; r < MR; r++) gv[q][r] = Gf[(size_t)w * m + jc[r]];
+                                for (int r = 0; r < MR; r++) {
+                                    if constexpr (LDSC > 0) gv[q][r] = Gf[w * m + (int)jc[r]];
+                                    else gv[q][r] = ldc((unsigned)(P.oGf + w * m), jc[r]);
+                                }
+                                lq[q] = Lam[i0 + q < 64 ? i0 + q : 63];
                             }
 #pragma unroll
                             for (int q = 0; q < CHG; q++)
                                 if (i0 + q < na) {
-                                    const R lq = wv_bcast(ls, i0 + q);
 #pragma unroll
-                                    for (int r = 0; r < MR; r++) Mu[r] = wv_fma(-gv[q][r], lq, Mu[r]);
+                                    for (int r = 0; r < MR; r++) Mu[r] = wv_fma(-gv[q][r], lq[q], Mu[r]);
                                 }
                         }
 #pragma unroll
@@ -688,7 +752,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         for (int q = 0; q < CHM; q++) {
                             const int k = k0 + q < n ? k0 + q : n - 1;
 #pragma unroll
-                            for (int r = 0; r < MR; r++) mt[q][r] = Mt[(size_t)k * m + jc[r]];
+                            for (int r = 0; r < MR; r++) {
+                                if constexpr (LDSC > 0) mt[q][r] = Mt[k * m + (int)jc[r]];
+                                else mt[q][r] = ldc((unsigned)(P.oMt + k * m), jc[r]);
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < CHM; q++) {
@@ -713,12 +780,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     R mval = -primal_tol;
                     int midx = -1;
                     bool broken = false;
+                    R bdu[MR], bdl[MR];                  // (clamped row index: loads without a guard around them)
+#pragma unroll
+                    for (int r = 0; r < MR; r++) { bdu[r] = ldc((unsigned)P.odu, jc[r]); bdl[r] = ldc((unsigned)P.odl, jc[r]); }
 #pragma unroll
                     for (int r = 0; r < MR; r++) {
                         const int j = lane + 64 * r;
                         if (j < m && !(sense[r] & SENSE_IMMUTABLE)) {
-                            const R vu = (C[P.odu + j] + b[r]) - Mu[r];
-                            const R vl = -((C[P.odl + j] + b[r]) - Mu[r]);
+                            const R vu = (bdu[r] + b[r]) - Mu[r];
+                            const R vl = -((bdl[r] + b[r]) - Mu[r]);
                             if (!((actb >> r) & 1u)) {
                                 if (vu < mval) { mval = vu; midx = 2 * j; }
                                 else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
@@ -903,15 +973,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             for (int c0 = 0; c0 < nchain; c0 += CH) {
                 R rv[CH];
 #pragma unroll
-                for (int q = 0; q < CH; q++) rv[q] = C[P.oRout + (size_t)lout * n + (c0 + q < n ? c0 + q : n - 1)];
+                for (int q = 0; q < CH; q++) rv[q] = ldc((unsigned)(P.oRout + (c0 + q < n ? c0 + q : n - 1)), (unsigned)lout * (unsigned)n);
 #pragma unroll
                 for (int q = 0; q < CH; q++)
                     if (c0 + q < n) xs = wv_fma(rv[q], ubc(c0 + q), xs);
             }
             if (ko < P.nout) {
-                R sh = C[P.ox0 + ko];
-                for (int t = 0; t < nth; t++) sh = wv_fma(C[P.oXth + (size_t)ko * nth + t], th[t], sh);
-                X[pid * P.nout + ko] = xs + sh;
+                R sh = ldc((unsigned)P.ox0, (unsigned)ko);
+                for (int t = 0; t < nth; t++) sh = wv_fma(ldc((unsigned)(P.oXth + t), (unsigned)ko * (unsigned)nth), th[t], sh);
+                (X + pid * P.nout)[(unsigned)ko] = xs + sh;
             }
         }
         if (active) {
@@ -942,6 +1012,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             // (lmpc_big_kernel.hpp), which overwrites the outputs of this problem
             if (flag == EXIT_WSCAP && ovf_list != nullptr) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
         }
+        clear_rows(1, na);                       // ZP: the next problem starts on a factor of zeros
         if (++kin < qchunk) {
             idx++;
         } else {

@@ -32,7 +32,10 @@ inline int wave_slots(int m, bool bnb) {
 // resident wavefronts per CU the instantiation's registers allow (`make asm`, kernel-resource-usage): 128 VGPRs for
 // 1-2 slots (4 per SIMD), 168 for 3 (3 per SIMD), up to 256 for 4-6 (2 per SIMD); 8 slots fit 256 only
 // with M' staged in LDS (level >= 1) and one variable slot, otherwise -- and with 16 slots -- one wavefront per SIMD
-inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu) {
+inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu, bool gram = false) {
+    // Gram-scan form without branch and bound (resource_usage_wave_*_gram.txt): <= 128 VGPRs up to 2 slots, <= 168 at
+    // 3 and 4 slots, <= 256 up to 8 slots
+    if (gram && !bnb) return slots <= 2 ? 16 : (slots <= 4 ? 12 : (slots <= 8 ? 8 : 4));
     if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
     if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
     if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
@@ -51,7 +54,8 @@ inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu) 
 inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) {
     const WaveLayout &Wl = h->W;
     // per-wave factor L: square with an odd leading dimension, or packed strict lower triangle
-    const size_t perWave = rs * (packed ? ((size_t)Wl.cap * (Wl.cap - 1) / 2) : ((size_t)Wl.cap * Wl.ldc));
+    // (+ 64 reals: the multipliers, read back as LDS broadcasts)
+    const size_t perWave = rs * ((packed ? ((size_t)Wl.cap * (Wl.cap - 1) / 2) : ((size_t)Wl.cap * Wl.ldc)) + 64);
     // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
     // (more registers per lane, fewer resident wavefronts)
     const int slots = wave_slots(h->P.m, h->bnb);
@@ -63,7 +67,7 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     const bool twoLevels = packed || h->P.m > 256 || slots == 3 || h->waveGram;
     for (int level = h->P.n > 64 ? 0 : (twoLevels ? 1 : 3); level >= 0; level--) {
         if (h->waveLevel >= 0 && level != (twoLevels && h->waveLevel > 1 ? 1 : h->waveLevel)) continue;
-        const int maxWaves = wave_max_resident(slots, h->bnb, rs, level, h->P.n > 64 ? 2 : 1);
+        const int maxWaves = wave_max_resident(slots, h->bnb, rs, level, h->P.n > 64 ? 2 : 1, h->waveGram != 0);
         for (int nwv : {4, 8, 16, 12, 2, 1}) {
             if (nwv > maxNwv) continue;
             if (h->waveNwv > 0 && nwv != h->waveNwv && !(h->waveNwv > maxNwv && nwv == maxNwv)) continue;

@@ -54,6 +54,7 @@ struct WaveLayout {
     int cap, ldc;                                   // working-set capacity, leading dim of L
     int oM, oMt, oG, odu, odl, oDth, oRout, ox0, oXth;
     int oGf;                                        // full symmetric Gram matrix, m x m (Gram-scan form)
+    int nC;                                         // reals in the pack (bounds of the kernels' buffer resource)
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int cycle_tol, iter_limit;
 };

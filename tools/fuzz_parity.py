@@ -3,7 +3,9 @@
 same pack -- exit flags, iteration counts, active sets bit for bit, x to 1e-10; cold and warm; f64 and (every
 fourth trial, wavefront-kernel shapes) f32; n up to 100 (two variable slots per lane).  Also prints the MARGINAL
 case report (oracle.ldp.marginal_report): the points whose terminal decision sits inside a tolerance band, where
-libdaqp may legitimately end on another active set.  usage: tools/fuzz_parity.py [trials] [seed]"""
+libdaqp may legitimately end on another active set.  usage: tools/fuzz_parity.py [trials] [seed] [gram]
+("gram": the wavefront kernel's Gram-scan form against the oracle's mode 1, plus its agreement with the n-chain form
+on every solved point: flags, iteration counts, active sets, and the largest |dx|)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +16,8 @@ from oracle import ldp as oldp
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+gram = len(sys.argv) > 3 and sys.argv[3] == "gram"
+gram_vs_chain = {"solved_points": 0, "decisions_differ": 0, "max_dx_hard": 0.0, "max_dx_soft": 0.0, "failed_flag_differs": 0}
 rng = np.random.default_rng(seed)
 bad = 0
 stats = {"lane": 0, "wave": 0, "refused": 0, "f32": 0}
@@ -77,15 +81,19 @@ for trial in range(trials):
         continue
     theta = rng.uniform(-2, 2, (193, nth))
     L = oracle_ldp_from(qp.ldp())
+    so = copy_settings(st) if f32 else oldp.default_settings()
+    if gram:
+        qp.set_option("gram_scan", 1)
+        so.mode = 1
     try:
         if f32:
             x, ef, it, act = qp.solve_f32(theta.astype(np.float32))
-            xo, efo, ito, acto = oldp.solve_batch(L, theta.astype(np.float32), copy_settings(st), dtype=np.float32)
+            xo, efo, ito, acto = oldp.solve_batch(L, theta.astype(np.float32), so, dtype=np.float32)
             tol = 1e-5
             stats["f32"] += 1
         else:
             x, ef, it, act = qp.solve(theta)
-            xo, efo, ito, acto = oldp.solve_batch(L, theta)
+            xo, efo, ito, acto = oldp.solve_batch(L, theta, so)
             tol = 1e-10
             stats["wave" if qp.kernel_name == "wave" else "lane"] += 1
     except lmpc.LmpcError as e:
@@ -97,10 +105,24 @@ for trial in range(trials):
     if ok and not f32 and not bnb and (ef >= 1).sum() >= 8:
         sel = ef >= 1
         xw, efw, itw, actw = qp.solve(theta[sel][:64], warm=act[sel][:64])
-        xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], warm=act[sel][:64])
+        xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], so, warm=act[sel][:64])
         ok = np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= tol
     for k, c in zip(*np.unique(ef, return_counts=True)):
         flags_seen[int(k)] = flags_seen.get(int(k), 0) + int(c)
+    if gram and not f32 and qp.kernel_name == "wave":
+        qp.set_option("gram_scan", 0)
+        x0, ef0, it0, act0 = qp.solve(theta)
+        s0 = ef0 >= 1
+        gram_vs_chain["solved_points"] += int(s0.sum())
+        dd = (ef[s0] != ef0[s0]) | (it[s0] != it0[s0]) | (act[s0] != act0[s0]).any(axis=1)
+        gram_vs_chain["decisions_differ"] += int(dd.sum())
+        gram_vs_chain["failed_flag_differs"] += int((ef[~s0] != ef0[~s0]).sum())
+        same = np.flatnonzero(s0)[~dd]
+        if len(same):
+            key = "max_dx_soft" if nsoft else "max_dx_hard"
+            gram_vs_chain[key] = max(gram_vs_chain[key], float(np.abs(x[same] - x0[same]).max()))
+        if dd.any():
+            print(f"gram/chain decisions differ in trial {trial} (n={n} m={m} nsoft={nsoft}): {int(dd.sum())} points", flush=True)
     if not f32 and not bnb:
         rep = oldp.marginal_report(L, theta)
         marg["points"] += rep["solved"]
@@ -115,4 +137,6 @@ for trial in range(trials):
         print(f"trial {trial + 1}: {bad} mismatches, {stats}, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {trials} trials, {bad} mismatches, {stats}, exit flags {flags_seen}")
 print(f"marginal cases among the solved f64 points: {marg}")
+if gram:
+    print(f"Gram-scan form against the n-chain form on the same handle: {gram_vs_chain}")
 sys.exit(1 if bad else 0)
