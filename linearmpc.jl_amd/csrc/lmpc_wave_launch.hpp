@@ -83,12 +83,15 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     return best;
 }
 
-// square L unless the packed layout keeps at least a quarter more wavefronts resident
+// square L unless the packed layout keeps at least 1.75x the wavefronts resident (round 3: the square layout's sweeps
+// run on a zero-padded factor, three vector instructions per step instead of five, so it takes more than a quarter
+// more wavefronts to beat it -- hybrid f32, n = 60: 10 wavefronts per CU square 1.54e6/s, 16 packed 1.40e6/s; f64:
+// 5 square 6.9e5/s, 10 packed 8.4e5/s; the benchmark class at cap = 64: 4 square against 9 packed, packed 1.5x faster)
 inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     const WaveConfig sq = wave_config_for(h, rs, false), pk = wave_config_for(h, rs, true);
     if (h->wavePacked == 0) return sq;
     if (h->wavePacked == 1) return pk;
-    return 4 * pk.blocksPerCU * pk.nwv >= 5 * sq.blocksPerCU * sq.nwv ? pk : sq;
+    return 4 * pk.blocksPerCU * pk.nwv >= 7 * sq.blocksPerCU * sq.nwv ? pk : sq;
 }
 
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
