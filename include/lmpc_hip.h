@@ -416,6 +416,21 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * kernels.  All of them change the execution order only, never a result. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
+/* Per-problem exit flags are DAQP's (1 optimal, 2 soft optimal, -1 infeasible, -2 cycle, -4 iteration limit, -6
+ * over-determined initial working set) plus two of this library's own:
+ *   -7  the working set outgrew what the kernels hold (wavefront kernel: 64 rows, slow path: 256 rows);
+ *   -8  LMPC_EXIT_UNFINISHED: the problem was queued inside the one-launch kernel and never solved because one of that
+ *       kernel's bounded waits ran out (not expected to happen; the provisional flag every queued problem carries until
+ *       its solving lane overwrites it -- so a failure can never be read as success, /root/reference/src/utils.jl:46
+ *       `@assert exitflag>=1`).
+ * The *_device entry points are asynchronous, so such a failure is reported by the handle afterwards: the next call on
+ * the handle, lmpc_profile_read, lmpc_release_scratch and lmpc_check return LMPC_ERR_HIP once (text in
+ * lmpc_last_error); the host-pointer entry points (lmpc_solve_batch, ...) report it from the call itself.
+ * lmpc_check waits for the handle's GPU first, i.e. it answers for everything enqueued so far.
+ * ("fast_spin_limit" k > 0 of lmpc_set_option is the test hook: the waits give up after k - 1 polls.) */
+#define LMPC_EXIT_UNFINISHED (-8)
+int lmpc_check(lmpc_handle *h);
+
 /* Staging and scratch buffers of a handle grow with the largest batch it has seen and are kept between calls.
  * lmpc_release_scratch waits for the handle's GPU and gives them back (the constant pack stays; the next call
  * allocates what it needs again, and a DAQP_WARMSTART state kept by lmpc_compute_control* is dropped). */

@@ -30,7 +30,7 @@ SYMBOLS = (
     "lmpc_profile", "lmpc_profile_read", "lmpc_set_option", "lmpc_free", "lmpc_last_error",
     "lmpc_setup_multi", "lmpc_multi_devices", "lmpc_multi_handle", "lmpc_multi_partition",
     "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
-    "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch",
+    "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch", "lmpc_check",
 )
 
 
@@ -168,6 +168,9 @@ def lib():
     L.lmpc_free_multi.restype = None
     L.lmpc_release_scratch.argtypes = [vp]
     L.lmpc_release_scratch.restype = i32
+    if hasattr(L, "lmpc_check"):              # (an older build selected with LMPC_HIP_LIB for an A/B lacks it)
+        L.lmpc_check.argtypes = [vp]
+        L.lmpc_check.restype = i32
     L.lmpc_pin_host.argtypes = [vp, ctypes.c_size_t]
     L.lmpc_pin_host.restype = i32
     L.lmpc_unpin_host.argtypes = [vp]

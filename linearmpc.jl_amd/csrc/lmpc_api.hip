@@ -495,16 +495,13 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
     } else if (screened && !sim && warm == nullptr && (!gather || active == nullptr) && fast_covers(h)) {
         // small boxed problems, cold plain solve: ONE kernel streams the batch and solves what needs iterations
         // (lmpc_fast_kernel.hpp); no work list, no second launch
-        rc = launch_fast(h, nprob, theta, x, flag, iters, active, st);
+        // (an error word raised by an EARLIER call on this handle is reported here, before anything new is enqueued)
+        rc = check_fast_err(h);
+        if (rc == LMPC_OK) rc = launch_fast(h, nprob, theta, x, flag, iters, active, st);
         if (h->prof) {       // one kernel: no event between "the two kernels" (each record is a packet the queue retires)
             h->eventPool.push_back(ev.mid); ev.mid = nullptr;
             if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
             else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
-        }
-        if (rc == LMPC_OK && std::getenv("LMPC_DEBUG_FAST") != nullptr) {          // diagnostic: the kernel's error flag
-            int32_t e = 0;
-            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&e, h->dFastErr, sizeof(e), hipMemcpyDeviceToHost) == hipSuccess)
-                std::fprintf(stderr, "lmpc fast kernel: error flag %d\n", e);
         }
         return rc;
     } else if (screened) {
@@ -1356,6 +1353,7 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]) {
     avg_ms[0] = cnt ? tot / cnt : 0.0;
     avg_ms[1] = cnt ? scr / cnt : 0.0;
     avg_ms[2] = cnt ? itr / cnt : 0.0;
+    if (check_fast_err(h) != LMPC_OK) return LMPC_ERR_HIP;     // (the timed calls have completed: their error word is final)
     return cnt;
 }
 
@@ -1384,6 +1382,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "lane_straight") == 0) { h->laneStraight = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "fast_tiles") == 0) { h->fastTiles = value < 0 ? 0 : (value > 256 ? 256 : value); return LMPC_OK; }
     if (std::strcmp(name, "fast_nstr") == 0) { h->fastNstr = value; return LMPC_OK; }
+    if (std::strcmp(name, "fast_spin_limit") == 0) { h->fastSpinLimit = value < 0 ? 0 : value; return LMPC_OK; }
     if (std::strcmp(name, "sim_fused") == 0) { h->simFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
@@ -1418,7 +1417,16 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccStage); rel(h->ccStageFlag); h->ccStageCap = 0; h->ccStagePer = 0;
     rel(h->ccObsScratch); h->ccObsCap = 0;
     rel(h->dOvfList); h->ovfCap = 0; rel(h->dBigR); rel(h->dBigI);
-    return LMPC_OK;
+    return check_fast_err(h);
+}
+
+int lmpc_check(lmpc_handle *h) {
+    if (!h) return LMPC_ERR_BADARG;
+    lmpc::DeviceScope scope;
+    if (scope.enter(h->device) != hipSuccess) return fail(h, LMPC_ERR_HIP, "lmpc_check: hipSetDevice");
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return fail(h, LMPC_ERR_HIP, std::string("lmpc_check: ") + hipGetErrorString(e));
+    return check_fast_err(h);
 }
 
 void lmpc_free(lmpc_handle *h) {
@@ -1432,7 +1440,11 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
-    hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch); hipFree(h->dFastErr);
+    hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);
+    if (h->hFastErr) {
+        if (*h->hFastErr != 0) std::fprintf(stderr, "lmpc_free: unreported error word %d of the one-launch kernel\n", (int)*h->hFastErr);
+        hipHostFree(const_cast<int32_t *>(h->hFastErr));
+    } else hipFree(h->dFastErr);
     for (auto &e : h->pipeEv) hipEventDestroy(e);
     if (h->sUp) hipStreamDestroy(h->sUp);
     if (h->sRun) hipStreamDestroy(h->sRun);

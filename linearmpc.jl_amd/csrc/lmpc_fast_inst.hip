@@ -35,23 +35,38 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     // wavefronts each): with 652 workgroups on 768 slots the CUs that got three were still streaming 5 us
     // after those that got two had finished (tools/fast_trace.py)
     long long slots = (long long)h->numCU * LMPC_FAST_WAVES;
-    int R = (int)((ntiles + slots - 1) / slots);
-    if (R < 8) R = 8;
-    if (h->fastTiles > 0) R = h->fastTiles;
-    if (R > ntiles) R = (int)(ntiles > 0 ? ntiles : 1);
+    long long Rl = (ntiles + slots - 1) / slots;
+    if (Rl < 8) Rl = 8;
+    if (h->fastTiles > 0) Rl = h->fastTiles;
+    // The workgroup's queue holds one index per problem of its R tiles (256 R bytes of LDS next to ~23 KB of fixed
+    // data): R is capped so that three workgroups keep fitting one CU (kFastMaxTiles = 96: 47 KB per workgroup);
+    // beyond ~6e6 points per call the grid grows past one resident round instead (tests: N = 3e7)
+    if (Rl > kFastMaxTiles) Rl = kFastMaxTiles;
+    if (Rl > ntiles) Rl = ntiles > 0 ? ntiles : 1;
+    const int R = (int)Rl;
     const unsigned grid = (unsigned)((ntiles + R - 1) / R);
     const size_t lds = fast_lds_bytes(N, R, NTHMAX);
+    auto kern = fast_kernel<NTHMAX, NT, N, GATHER>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (!h->dFastErr) {
 #ifdef LMPC_FAST_TRACE
         const size_t eb = 64 + sizeof(long long) * 8 * 4 * 65536;
-#else
-        const size_t eb = sizeof(int32_t);
-#endif
         HIP_TRY(h, hipMalloc(&h->dFastErr, eb));
         HIP_TRY(h, hipMemsetAsync(h->dFastErr, 0, eb, st));
+#else
+        // the kernel's error word lives in pinned host memory mapped into the device: the kernel writes it in the
+        // (never expected) case that one of its bounded waits runs out, the host reads it without a copy or a
+        // synchronisation at the handle's next call and in lmpc_check / lmpc_profile_read / lmpc_release_scratch
+        int32_t *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
+        *hp = 0;
+        h->hFastErr = hp;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dFastErr), hp, 0));
+#endif
     }
-    hipLaunchKernelGGL((fast_kernel<NTHMAX, NT, N, GATHER>), dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
-                       active, (long long)nprob, R, nstr, h->dFastErr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
+                       active, (long long)nprob, R, nstr, h->dFastErr, h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit);
     HIP_TRY(h, hipGetLastError());
 #ifdef LMPC_FAST_TRACE
     if (const char *f = std::getenv("LMPC_FAST_TRACE_FILE")) {
@@ -63,6 +78,16 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     }
 #endif
     return LMPC_OK;
+}
+
+int check_fast_err(lmpc_handle *h) {
+    if (!h->hFastErr) return LMPC_OK;
+    const int32_t e = *h->hFastErr;
+    if (e == 0) return LMPC_OK;
+    *h->hFastErr = 0;                                      // reported once
+    return fail(h, LMPC_ERR_HIP, "lmpc: the one-launch kernel gave up a bounded wait (code " + std::to_string(e) +
+                                 ") in an earlier call on this handle: problems it had queued keep exit flag -8 "
+                                 "(LMPC_EXIT_UNFINISHED), their x is not a solution");
 }
 
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,

@@ -39,6 +39,7 @@ namespace lmpc {
 #define LMPC_FAST_WAVES 3      // wavefronts per SIMD the kernel is register-budgeted for (lane_loop sets the need)
 #endif
 constexpr int kFastSpinLimit = 1 << 22;
+constexpr int kFastMaxTiles = 96;          // tiles of 64 problems per workgroup at most (LDS queue: 256 bytes per tile)
 #ifndef LMPC_FAST_AHEAD
 #define LMPC_FAST_AHEAD 1
 #endif
@@ -77,7 +78,7 @@ template <int NTHMAX, int NT, int N, bool GATHER = false>
 __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag) {
+    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit) {
     constexpr int KMAX = LMPC_FAST_KMAX < N ? LMPC_FAST_KMAX : N;
     constexpr int nconst = N * N + N * (N + 1) / 2 + 2 * N;
     extern __shared__ __align__(16) double lds[];
@@ -246,10 +247,13 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                     for (int c = 0; c < N; c++) u0[c] = 0.0;
                     write_x(pid, th, u0, false);
                 }
-                exitflag[pid] = EXIT_OPTIMAL;
                 if (iters) iters[pid] = 1;
                 if (active) active[pid * P.words] = 0ull;
             }
+            // every problem gets a flag HERE, queued ones the provisional EXIT_UNFINISHED that the solving lane
+            // overwrites: should a bounded wait below ever run out, no caller reads a stale flag as success (the
+            // reference asserts exitflag >= 1, utils.jl:46); an unmasked store of whole lines, as screen_kernel's
+            if (valid) exitflag[pid] = hard ? EXIT_UNFINISHED : EXIT_OPTIMAL;
         };
 #ifdef LMPC_FAST_CONTIG     // each streaming wavefront takes a contiguous run of the workgroup's tiles
         const long long per = (R + nstr - 1) / nstr;
@@ -326,12 +330,13 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                 } else {
                     __builtin_amdgcn_s_sleep(8);
                 }
-                if (++spins > kFastSpinLimit) { n = -2; break; }
+                if (++spins > spinLimit) { n = -2; break; }
             }
         }
         start = __builtin_amdgcn_readfirstlane(start);
         n = __builtin_amdgcn_readfirstlane(n);
-        if (n == -2 && lane == 0 && errflag) *errflag = 1;
+        // (system scope: the word lives in host memory, the host looks at it without a copy -- lmpc_check)
+        if (n == -2 && lane == 0 && errflag) __hip_atomic_store(errflag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (n < 0) break;
 #ifdef LMPC_FAST_TRACE
         if (npass < 2) LMPC_TRC(2 + npass);
@@ -345,10 +350,13 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
         if (mine) {
             int sp = 0;
             while ((rel = __hip_atomic_load(&ring[start + lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < 0) {
-                if (++sp > kFastSpinLimit) break;              // (a reserved slot is written at once: never in practice)
+                if (++sp > spinLimit) break;                   // (a reserved slot is written at once: never in practice)
             }
         }
-        if (__any(mine && rel < 0)) { if (lane == 0 && errflag) *errflag = 2; break; }
+        if (__any(mine && rel < 0)) {
+            if (lane == 0 && errflag) __hip_atomic_store(errflag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         const long long pid = mine ? t0 * 64 + rel : t0 * 64;
         double b[N], u[N];
         double sh0 = C[P.ox0];                                 // x0 + Xth theta of the first output (kept: 2 registers)

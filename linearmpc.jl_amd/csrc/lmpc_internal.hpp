@@ -78,7 +78,9 @@ struct lmpc_handle {
     int fastPath = 1;           // tuning: one-launch kernel for small boxed problems ("fast", lmpc_fast_kernel.hpp)
     int fastTiles = 0;          // tuning: tiles of 64 problems per workgroup of that kernel (0 = 24)
     int fastNstr = 0;           // tuning: streaming wavefronts per workgroup of that kernel, 1..4 (0 = 3)
-    int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected)
+    int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected):
+    volatile int32_t *hFastErr = nullptr;   // ... a word of pinned host memory, dFastErr its device address
+    int fastSpinLimit = 0;         // test hook ("fast_spin_limit"): k > 0 = the kernel's waits give up after k - 1 polls
     lmpc::WaveLayout W{};
     double *dCw = nullptr;
     float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
@@ -130,6 +132,8 @@ namespace lmpc {
 
 hipError_t pool_event(lmpc_handle *h, hipEvent_t *e);
 int fail(lmpc_handle *h, int code, const std::string &msg);
+// the one-launch kernel's error word (lmpc_fast_inst.hip): LMPC_OK, or LMPC_ERR_HIP once per raised error
+int check_fast_err(lmpc_handle *h);
 
 #define HIP_TRY(h, call)                                                                     \
     do {                                                                                     \

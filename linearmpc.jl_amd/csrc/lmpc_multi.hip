@@ -270,6 +270,12 @@ int run_host_jobs(std::vector<HostJob> &jobs, size_t rs, lmpc_handle *errh, Host
             rc = fail(errh, LMPC_ERR_HIP, std::string("lmpc: host pipeline: ") +
                                               hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
     }
+    // everything this call enqueued has completed: the one-launch kernel's error word is final (lmpc_fast_inst.hip)
+    for (auto &j : jobs) {
+        if (rc != LMPC_OK || j.N == 0) continue;
+        rc = check_fast_err(j.h);
+        if (rc != LMPC_OK && errh != j.h) errh->err = j.h->err;
+    }
     return rc;
 }
 

@@ -17,7 +17,9 @@ enum : int32_t { SENSE_ACTIVE = 1, SENSE_LOWER = 2, SENSE_IMMUTABLE = 4, SENSE_S
 enum : int32_t {
     EXIT_SOFT_OPTIMAL = 2, EXIT_OPTIMAL = 1, EXIT_INFEASIBLE = -1, EXIT_CYCLE = -2,
     EXIT_UNBOUNDED = -3, EXIT_ITERLIMIT = -4, EXIT_NONCONVEX = -5, EXIT_OVERDETERMINED = -6,
-    EXIT_WSCAP = -7           // not a DAQP flag: the working set would have outgrown the 64 lanes of the wavefront
+    EXIT_WSCAP = -7,          // not a DAQP flag: the working set would have outgrown the 64 lanes of the wavefront
+    EXIT_UNFINISHED = -8      // not a DAQP flag: queued inside the one-launch kernel and never solved (a bounded wait of
+                              // that kernel ran out; the handle reports LMPC_ERR_HIP at its next check, lmpc_check)
 };
 
 // All matrices row-major.  G is the packed lower triangle of M M' (index a>=b: a(a+1)/2+b),

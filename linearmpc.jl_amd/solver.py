@@ -529,6 +529,11 @@ class BatchedQP:
     def set_option(self, name: str, value: int):
         check(lib().lmpc_set_option(self._h, name.encode(), int(value)), self._h)
 
+    def check(self):
+        """`lmpc_check`: wait for the handle's GPU, then raise if a kernel reported an internal failure
+        (problems with exit flag -8) since the last check."""
+        check(lib().lmpc_check(self._h), self._h)
+
     def close(self):
         if self._h:
             lib().lmpc_free(self._h)

@@ -1617,6 +1617,110 @@ def test_one_launch_kernel_respects_the_solver_guards(lmpc):
             assert (ef == -4).any()
 
 
+def test_one_launch_kernel_failure_is_visible(lmpc):
+    """The one-launch kernel's bounded waits are never expected to run out; if one does, nothing may look like
+    success (/root/reference/src/utils.jl:46 asserts exitflag >= 1): every queued problem carries the provisional
+    flag -8 until its solving lane overwrites it, and the handle reports LMPC_ERR_HIP at its next check.  The test
+    hook "fast_spin_limit" makes the waits give up at their first poll."""
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    assert "fast" in qp.kernel_name
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(33)
+    N = 200_000
+    theta = np.hstack([rng.uniform(-20, 20, (N, 4)), rng.uniform(-20, 20, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    xo, efo, ito, acto = oldp.solve_batch(L, theta)
+    th_d = torch.from_numpy(theta).to("cuda:0")
+    raised = 0
+    for trial in range(6):
+        qp.set_option("fast_spin_limit", 1)              # give up at the first poll that finds nothing to claim
+        x_d = torch.full((N, 1), float("nan"), dtype=torch.float64, device="cuda:0")
+        ef_d = torch.full((N,), 12345, dtype=torch.int32, device="cuda:0")
+        qp.solve_device(th_d, x=x_d, exitflag=ef_d)
+        try:
+            qp.check()                                   # waits for the GPU, then reports the kernel's error word
+            err = None
+        except lmpc.LmpcError as e:
+            err = e
+        ef, x = ef_d.cpu().numpy(), x_d.cpu().numpy()
+        assert not (ef == 12345).any()                   # every problem has a flag of this call
+        done = ef != -8
+        assert np.array_equal(ef[done], efo[done]) and np.array_equal(x[done], xo[done])
+        if err is not None:
+            raised += 1
+            assert err.code == -102 and "one-launch kernel" in str(err)
+        else:
+            assert done.all()                            # no error word => nothing left unfinished
+        if not done.all():
+            assert err is not None                       # unfinished problems never come without the error
+        qp.check()                                       # reported once
+    assert raised >= 1
+    # the error also stops the NEXT call on the handle when nobody checked in between
+    qp.set_option("fast_spin_limit", 1)
+    for _ in range(20):
+        qp.solve_device(th_d, x=x_d, exitflag=ef_d)
+        torch.cuda.synchronize()
+        qp.set_option("fast_spin_limit", 0)
+        try:
+            qp.solve_device(th_d, x=x_d, exitflag=ef_d)
+        except lmpc.LmpcError as e:
+            assert e.code == -102
+            break
+        qp.set_option("fast_spin_limit", 1)
+    else:
+        raise AssertionError("the error word was never raised")
+    # back to normal
+    qp.set_option("fast_spin_limit", 0)
+    qp.solve_device(th_d, x=x_d, exitflag=ef_d)
+    qp.check()
+    assert np.array_equal(ef_d.cpu().numpy(), efo) and np.array_equal(x_d.cpu().numpy(), xo)
+    # host-pointer entry point: the failure comes back from the call itself
+    qp.set_option("fast_spin_limit", 1)
+    seen = 0
+    for _ in range(10):
+        try:
+            qp.solve(theta)
+        except lmpc.LmpcError as e:
+            assert e.code == -102
+            seen += 1
+    assert seen >= 1
+    qp.set_option("fast_spin_limit", 0)
+    x, ef, it, act = qp.solve(theta)
+    assert np.array_equal(ef, efo) and np.array_equal(x, xo)
+
+
+def test_one_launch_kernel_very_large_batch(lmpc):
+    """3e7 points in one call: the workgroup's LDS queue is capped (96 tiles) and the grid grows past one resident
+    round instead of the queue past the LDS limit.  Size-independent checks + an oracle sample."""
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    L = oracle_ldp_from(qp.ldp())
+    N = 30_000_011
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    lo = torch.tensor([-5, -5, -0.3, -2, -5, 0, -2], dtype=torch.float64, device="cuda:0")
+    hi = torch.tensor([5, 5, 0.3, 2, 5, 0, 2], dtype=torch.float64, device="cuda:0")
+    th_d = lo + (hi - lo) * torch.rand((N, 7), dtype=torch.float64, device="cuda:0", generator=gen)
+    x_d = torch.full((N, 1), float("nan"), dtype=torch.float64, device="cuda:0")
+    ef_d = torch.full((N,), 12345, dtype=torch.int32, device="cuda:0")
+    qp.solve_device(th_d, x=x_d, exitflag=ef_d)
+    qp.check()
+    assert bool((ef_d == 1).all()) and bool(torch.isfinite(x_d).all())
+    assert float(x_d.abs().max()) <= 2.0 + 1e-5                       # |u| <= 2 (input bound of the example) up to primal_tol
+    idx = torch.cat([torch.arange(0, 4000, device="cuda:0"), torch.arange(N - 4000, N, device="cuda:0"),
+                     torch.randint(0, N, (12000,), device="cuda:0", generator=gen)])
+    xo, efo, _, _ = oldp.solve_batch(L, th_d[idx].cpu().numpy())
+    assert np.array_equal(x_d[idx].cpu().numpy(), xo) and np.array_equal(ef_d[idx].cpu().numpy(), efo)
+    qp.set_option("fast_tiles", 256)                                  # the option is clamped to the same cap
+    x2 = torch.empty_like(x_d); f2 = torch.empty_like(ef_d)
+    qp.solve_device(th_d[:3_000_000], x=x2[:3_000_000], exitflag=f2[:3_000_000])
+    qp.check()
+    assert bool((x2[:3_000_000] == x_d[:3_000_000]).all())
+
+
 # ------------------------------------------------------------------ reference-held vectors through the device path
 def test_reference_formatting_vectors_on_the_device(lmpc):
     """/root/reference/test/runtests.jl:1401-1428, number for number, through lmpc_form_parameter_device: the
