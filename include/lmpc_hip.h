@@ -396,7 +396,14 @@ const char *lmpc_kernel_name(const lmpc_handle *h);
 int lmpc_profile(lmpc_handle *h, int enable);
 int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
 
-/* Tuning switches (none of them changes a result): "fast" (default 1) = small box-constrained problems
+/* Tuning switches (none of them changes a result): "in_flight" k = a HINT: the caller keeps k independent batches in
+ * flight on this GPU (one handle and one stream each; default 1).  From k = 2 on the kernels take the workgroup shapes
+ * that suit a shared chip ("fast_nstr" 4, "fast_tiles" 28, "lane_block" 64) instead of the stand-alone ones.
+ * "fast_dma" = how the one-launch kernel's streaming wavefronts take their records: 2 (default with up to three
+ * streaming wavefronts per workgroup) = by LDS-DMA (global_load_lds_dwordx4, nontemporal) into a ring of two tiles per
+ * wavefront, 0 = through registers.  "gram_scan" (default 0) is NOT one of them: it selects the wavefront kernel's
+ * Gram-scan form, whose results differ from the default form in the last bits (see lmpc_wave_kernel.hpp; checker: the
+ * oracle's mode 1).  "fast" (default 1) = small box-constrained problems
  * (m == ms == n <= 5, up to 16 parameters -- 8 for n = 5 --, cold start) are solved by ONE kernel that streams the batch and
  * runs the iterations underneath (0 = the two-kernel form below); "fast_nstr" 1..4 = streaming wavefronts per
  * workgroup of that kernel (default 3; 4 suits several batches in flight), "fast_tiles" = tiles of 64 problems per workgroup

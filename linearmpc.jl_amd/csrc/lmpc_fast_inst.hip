@@ -45,7 +45,14 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     if (Rl > ntiles) Rl = ntiles > 0 ? ntiles : 1;
     const int R = (int)Rl;
     const unsigned grid = (unsigned)((ntiles + R - 1) / R);
-    const size_t lds = fast_lds_bytes(N, R, NTHMAX);
+    // streaming wavefronts take their records by LDS-DMA into a ring of dk tile slots each ("fast_dma": 0 = through
+    // registers, 2 / 3 = ring depth; default LMPC_FAST_DMA_DEPTH); the generated controller's gather stays on registers
+    // (default: a ring of two tiles with three streaming wavefronts; with four of them -- the shape for several batches
+    // in flight -- the rings would cost the third workgroup per CU its LDS: registers there)
+    int dk = GATHER ? 0 : (h->fastDma >= 0 ? h->fastDma : (nstr <= 3 ? LMPC_FAST_DMA_DEPTH : 0));
+    if (dk == 1 || dk > 3) dk = dk == 1 ? 0 : 3;
+    if (nprob * (int64_t)NT * 8 < 16) dk = 0;
+    const size_t lds = dk ? fast_lds_bytes_dma(N, R, NTHMAX, NT, nstr, dk) : fast_lds_bytes(N, R, NTHMAX);
     auto kern = fast_kernel<NTHMAX, NT, N, GATHER>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -66,7 +73,8 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
 #endif
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
-                       active, (long long)nprob, R, nstr, h->dFastErr, h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit);
+                       active, (long long)nprob, R, nstr, h->dFastErr, h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit,
+                       dk);
     HIP_TRY(h, hipGetLastError());
 #ifdef LMPC_FAST_TRACE
     if (const char *f = std::getenv("LMPC_FAST_TRACE_FILE")) {

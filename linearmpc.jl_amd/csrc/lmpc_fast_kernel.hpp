@@ -45,6 +45,25 @@ constexpr int kFastMaxTiles = 96;          // tiles of 64 problems per workgroup
 #endif
 constexpr int kFastAhead = LMPC_FAST_AHEAD;      // tiles a streaming wavefront requests before it consumes the first
 
+// One LDS-DMA piece: every active lane moves 16 bytes from its own global address straight into LDS at
+// lds_dst + 16 * lane (lds_dst wave-uniform, in M0) -- no vector register on the way, 1 KiB per wave-instruction.
+// Inline assembly on purpose: the compiler would drain a DMA it knows about with vmcnt(0) in front of the next LDS
+// read, and the point of the ring below is to keep the NEXT tile's pieces in flight across that read.
+#ifndef LMPC_FAST_DMA_POLICY
+#define LMPC_FAST_DMA_POLICY " nt"         // "" default cache policy, " nt" nontemporal
+#endif
+__device__ __forceinline__ void fast_dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" LMPC_FAST_DMA_POLICY
+                 "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#ifndef LMPC_FAST_DMA_DEPTH
+#define LMPC_FAST_DMA_DEPTH 2              // tiles per streaming wavefront in its LDS ring (0 = records through registers)
+#endif
+// bytes of one ring slot = one tile of 64 records
+__host__ __device__ constexpr size_t fast_tile_bytes(int NT) { return (size_t)64 * NT * sizeof(double); }
+
 __device__ __forceinline__ int lds_load(const int *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -67,6 +86,10 @@ __host__ __device__ constexpr size_t fast_lds_bytes(int N, int R, int NTHMAX) {
                                      (size_t)kFastPay * (N + 1)) +
            sizeof(int32_t) * ((size_t)R * 64 + 4);
 }
+// ... plus the streaming wavefronts' LDS-DMA rings behind it (dk slots of one tile per streaming wavefront)
+__host__ __device__ constexpr size_t fast_lds_bytes_dma(int N, int R, int NTHMAX, int NT, int nstr, int dk) {
+    return fast_lds_bytes(N, R, NTHMAX) + (size_t)dk * nstr * fast_tile_bytes(NT);
+}
 
 // GATHER: the generated controller's call (lmpc_compute_control*): theta is assembled from the five argument arrays
 // of mpc_compute_control (codegen/mpc_update_parameter.c) instead of read from a buffer, X is the caller's `control`
@@ -78,7 +101,8 @@ template <int NTHMAX, int NT, int N, bool GATHER = false>
 __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit) {
+    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit,
+    int dk) {
     constexpr int KMAX = LMPC_FAST_KMAX < N ? LMPC_FAST_KMAX : N;
     constexpr int nconst = N * N + N * (N + 1) / 2 + 2 * N;
     extern __shared__ __align__(16) double lds[];
@@ -240,7 +264,11 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             }
             if (valid && !hard) {
                 if (P.nout == 1) {
+#ifdef LMPC_FAST_NT_STORES
+                    __builtin_nontemporal_store(0.0 + sh, &X[pid]);
+#else
                     X[pid] = 0.0 + sh;                         // x = x0 + Xth theta (screen_kernel's `0.0 + sh`)
+#endif
                 } else {
                     double u0[N];
 #pragma unroll
@@ -253,7 +281,11 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             // every problem gets a flag HERE, queued ones the provisional EXIT_UNFINISHED that the solving lane
             // overwrites: should a bounded wait below ever run out, no caller reads a stale flag as success (the
             // reference asserts exitflag >= 1, utils.jl:46); an unmasked store of whole lines, as screen_kernel's
+#ifdef LMPC_FAST_NT_STORES
+            if (valid) __builtin_nontemporal_store(hard ? EXIT_UNFINISHED : EXIT_OPTIMAL, &exitflag[pid]);
+#else
             if (valid) exitflag[pid] = hard ? EXIT_UNFINISHED : EXIT_OPTIMAL;
+#endif
         };
 #ifdef LMPC_FAST_CONTIG     // each streaming wavefront takes a contiguous run of the workgroup's tiles
         const long long per = (R + nstr - 1) / nstr;
@@ -291,6 +323,57 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             }
         }
 #else
+        if (!GATHER && dk >= 2) {
+            // Records by LDS-DMA (round 3).  The wavefront owns a ring of dk tile slots in LDS; a tile (64 records,
+            // 64 NT 8 bytes, contiguous in theta) is moved by ceil(bytes / 1 KiB) wave-instructions of 16 bytes per
+            // lane -- fully coalesced, no vector register involved -- and the lane then reads ITS record from the slot
+            // (NT 8-byte LDS reads at a stride of NT doubles).  The pieces of the next dk - 1 tiles are in flight while
+            // this one is screened: twice (dk = 2) the bytes in flight of the register path at no register cost, which
+            // is what the stream was short of (4.7 TB/s with one 3.5 KB tile per streaming wavefront in flight).
+            // Vector-memory operations complete in order, so "all but the youngest (dk - 1) tiles' pieces" = this
+            // tile's pieces and every store issued before them: a counted s_waitcnt vmcnt.
+            constexpr unsigned TB = (unsigned)fast_tile_bytes(NT);
+            constexpr int PIECES = (int)((TB + 1023) / 1024);
+            constexpr unsigned LASTB = TB - (PIECES - 1) * 1024u;            // bytes of the last piece (16 per lane)
+            typedef const double __attribute__((address_space(3))) *lds_cdp;
+            char *dring = reinterpret_cast<char *>(ctrl + 4) + (size_t)role * dk * TB;
+            const unsigned dbase = (unsigned)(size_t)(lds_cdp) reinterpret_cast<double *>(dring);
+            const char *tbytes = reinterpret_cast<const char *>(theta);
+            // whole tiles only: the batch's last, partial tile (one per call) takes the register path below
+            const long long tfull = nprob / 64;
+            const long long te = t1 < tfull ? t1 : tfull;
+            auto issue = [&](long long tile, int slot) {
+                const char *src = tbytes + tile * (long long)TB + lane * 16;
+#pragma unroll
+                for (int p = 0; p < PIECES; p++) {
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(dbase + (unsigned)slot * TB + (unsigned)p * 1024u);
+                    if (p + 1 < PIECES || LASTB == 1024u || lane * 16 < (int)LASTB) fast_dma16(src + p * 1024, dst);
+                }
+            };
+            const long long first = t0 + role;
+            long long ahead = first;                                         // next tile to request
+            int sa = 0;                                                      // ... and its slot
+            for (int d = 0; d < dk - 1 && ahead < te; d++, ahead += nstr) { issue(ahead, sa); sa = sa + 1 == dk ? 0 : sa + 1; }
+            int sc = 0;
+            long long tile = first;
+            for (; tile < te; tile += nstr) {
+                if (ahead < te) { issue(ahead, sa); sa = sa + 1 == dk ? 0 : sa + 1; ahead += nstr; }
+                // pieces still allowed in flight: those of the tiles requested after this one
+                const long long younger = (ahead - tile) / nstr - 1;
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PIECES) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const double *rec = reinterpret_cast<const double *>(dring + (size_t)sc * TB) + lane * NT;
+#pragma unroll
+                for (int t = 0; t < NT; t++) buf[0][t] = rec[t];
+                sc = sc + 1 == dk ? 0 : sc + 1;
+                process(tile, buf[0], true);
+            }
+            if (tile < t1) {                                                 // (tile == tfull: the partial one)
+                load_record(tile * 64 + lane, buf[0]);
+                process(tile, buf[0], true);
+            }
+        } else
         for (long long base = t0 + role; base < t1; base += (long long)kFastAhead * nstr) {
 #pragma unroll
             for (int d = 0; d < kFastAhead; d++) {

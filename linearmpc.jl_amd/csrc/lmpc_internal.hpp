@@ -78,6 +78,7 @@ struct lmpc_handle {
     int fastPath = 1;           // tuning: one-launch kernel for small boxed problems ("fast", lmpc_fast_kernel.hpp)
     int fastTiles = 0;          // tuning: tiles of 64 problems per workgroup of that kernel (0 = 24)
     int fastNstr = 0;           // tuning: streaming wavefronts per workgroup of that kernel, 1..4 (0 = 3)
+    int fastDma = -1;           // tuning: LDS-DMA ring depth of its streaming wavefronts (-1 = default, 0 = registers, 2, 3)
     int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected):
     volatile int32_t *hFastErr = nullptr;   // ... a word of pinned host memory, dFastErr its device address
     int fastSpinLimit = 0;         // test hook ("fast_spin_limit"): k > 0 = the kernel's waits give up after k - 1 polls
