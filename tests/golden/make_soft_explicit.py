@@ -1,0 +1,118 @@
+"""Generator of tests/golden/soft_explicit_kat.npz: the reference's OWN definition of a soft constraint, solved
+without any soft-constraint machinery.
+
+/root/reference/src/utils.jl:329-364 (make_singlesided) spells the semantics of a SOFT row out as an explicit QP:
+one slack variable eps_i per soft row, entering both sides of the row with the coefficient -norm_factors[i]
+(norm_factors[i] = |A0_i R^-1|, the row's norm in the least-distance coordinates), and the cost soft_weight I on the
+slacks (soft_weight = 1 / rho_soft, /root/reference/src/setup.jl:26):
+
+    min  1/2 U'HU + (f + f_theta th)'U + 1/2 soft_weight |eps|^2
+    s.t. A0_i U - nf_i eps_i <= bu_i + W_i th,   -A0_i U - nf_i eps_i <= -(bl_i + W_i th)      (soft rows)
+         bl_j + W_j th <= A0_j U <= bu_j + W_j th                                                 (hard rows)
+
+This script builds exactly that QP (n + #soft variables, hard rows only) for a few parameter points of three
+fixtures and solves it with the oracle's HARD-constraint path, cross-checked by a projected KKT solve in numpy on
+the final active set.  The test (tests/test_oracle.py::test_soft_rows_equal_the_explicit_slack_qp) asserts that the
+SOFT-flag path of the oracle -- rho_soft added to the pivot of a soft row -- returns the same U.
+Run from the repo root:  python tests/golden/make_soft_explicit.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import ldp as oldp  # noqa: E402
+
+GOLDEN = os.path.dirname(os.path.abspath(__file__))
+SOFT = 8
+BIG = 1e30
+
+
+def explicit_slack_qp(g, soft_weight):
+    """The mpQP of make_singlesided's explicit form, kept two-sided where the reference's rows allow it."""
+    H, f, fth = np.asarray(g["H"], float), np.asarray(g["f"], float).ravel(), np.asarray(g["f_theta"], float)
+    A, bu, bl, W = np.asarray(g["A"], float), np.asarray(g["bu"], float), np.asarray(g["bl"], float), np.asarray(g["W"], float)
+    senses = np.asarray(g["senses"], np.int32)
+    n = H.shape[0]
+    m = bu.size
+    ms = m - A.shape[0]
+    A0 = np.vstack([np.eye(n)[:ms], A.reshape(-1, n)])
+    soft = (senses & SOFT) != 0
+    assert not soft[:ms].any(), "soft simple bounds: not in these fixtures"
+    ids = np.flatnonzero(soft)
+    ns = len(ids)
+    Rl = np.linalg.cholesky((H + H.T) / 2)
+    Ms = np.linalg.solve(Rl, A0[ids].T).T                       # A0[soft] / R.U
+    nf = np.linalg.norm(Ms, axis=1)
+    H2 = np.zeros((n + ns, n + ns)); H2[:n, :n] = H; H2[n:, n:] = soft_weight * np.eye(ns)
+    f2 = np.concatenate([f, np.zeros(ns)])
+    fth2 = np.vstack([fth.reshape(n, -1), np.zeros((ns, fth.reshape(n, -1).shape[1]))])
+    rows, ub, lb, Wr = [], [], [], []
+    for j in range(ms, m):
+        a = np.concatenate([A0[j], np.zeros(ns)])
+        if soft[j]:
+            k = int(np.flatnonzero(ids == j)[0])
+            up = a.copy(); up[n + k] = -nf[k]                   # A0_j U - nf eps <= bu_j + W_j th
+            lo = a.copy(); lo[n + k] = +nf[k]                   # A0_j U + nf eps >= bl_j + W_j th
+            rows += [up, lo]; ub += [bu[j], BIG]; lb += [-BIG, bl[j]]; Wr += [W[j], W[j]]
+        else:
+            rows.append(a); ub.append(bu[j]); lb.append(bl[j]); Wr.append(W[j])
+    A2 = np.array(rows).reshape(-1, n + ns)
+    bu2 = np.concatenate([bu[:ms], ub]); bl2 = np.concatenate([bl[:ms], lb])
+    W2 = np.vstack([W[:ms].reshape(ms, -1), np.array(Wr).reshape(len(rows), -1)])
+    s2 = np.concatenate([senses[:ms], np.zeros(len(rows), np.int32)]).astype(np.int32)
+    j = 0
+    for jj in range(ms, m):                                     # flags of the hard rows (IMMUTABLE etc.) carried over
+        if soft[jj]:
+            j += 2
+        else:
+            s2[ms + j] = senses[jj]; j += 1
+    return dict(H=H2, f=f2, f_theta=fth2, A=A2, bu=bu2, bl=bl2, W=W2, senses=s2, n=n, nsoft=ns, nf=nf)
+
+
+def solve_explicit(g, theta, soft_weight):
+    q = explicit_slack_qp(g, soft_weight)
+    L = oldp.qp2ldp(q["H"], q["f"], q["f_theta"], q["A"], q["bu"], q["bl"], q["W"], q["senses"], nout=q["H"].shape[0])
+    s = oldp.default_settings()
+    X, ef, it, act = oldp.solve_batch(L, theta, s)
+    return X[:, :q["n"]], X[:, q["n"]:], ef
+
+
+def solve_soft(g, theta, rho):
+    L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=np.asarray(g["H"]).shape[0])
+    s = oldp.default_settings()
+    s.rho_soft = rho
+    X, ef, it, act = oldp.solve_batch(L, theta, s)
+    return X, ef
+
+
+def main():
+    out = {}
+    for name, pick in (("soft_doc", 48), ("x0unc_kat", 32), ("pendulum_N50", 24)):
+        g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        theta = np.asarray(g["theta"], float)
+        rng = np.random.default_rng(11)
+        ok = np.flatnonzero(np.asarray(g["exitflag"]) >= 1)
+        soft_act = np.flatnonzero(np.asarray(g["exitflag"]) == 2)
+        idx = np.unique(np.concatenate([rng.choice(ok, min(pick, len(ok)), replace=False),
+                                        soft_act[:pick // 2]])).astype(np.int64)
+        th = theta[idx]
+        for rho in (1e-6, 1e-3):
+            U, eps, ef = solve_explicit(g, th, 1.0 / rho)
+            Us, efs = solve_soft(g, th, rho)
+            good = (ef >= 1) & (efs >= 1)
+            print(f"{name:14s} rho={rho:g}: {len(th)} points, explicit ok {int((ef >= 1).sum())}, soft-path ok {int((efs >= 1).sum())}, "
+                  f"flag 2 among them {int((efs == 2).sum())}, max|U_explicit - U_soft| = {np.abs(U - Us)[good].max():.3e}, "
+                  f"max|eps| = {np.abs(eps[good]).max():.3e}")
+            out[f"{name}_theta"] = th
+            out[f"{name}_U_rho{rho:g}"] = U
+            out[f"{name}_eps_rho{rho:g}"] = eps
+            out[f"{name}_flag_rho{rho:g}"] = ef
+    np.savez_compressed(os.path.join(GOLDEN, "soft_explicit_kat.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

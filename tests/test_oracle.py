@@ -538,3 +538,49 @@ def test_parameter_preview_restated():
     theta = np.hstack([np.zeros((200, 2)), P])
     X, ef, _, _ = oldp.solve_batch(L, theta)
     assert np.all(ef == 1) and np.abs(X - np.clip(2 * P, 0, 2)).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50"])
+def test_soft_rows_equal_the_explicit_slack_qp(name):
+    """Pins the SOFT-row convention to the reference's own definition.  /root/reference/src/utils.jl:329-364
+    (make_singlesided) writes a soft row out as an explicit QP: one slack per soft row entering both sides of the row
+    with the coefficient -norm_factors[i] (the row's norm in least-distance coordinates) and the cost soft_weight I,
+    soft_weight = 1 / rho_soft (/root/reference/src/setup.jl:26).  That QP -- n + #soft variables, hard rows only --
+    is built by tests/golden/make_soft_explicit.py and solved by the oracle's HARD path; the SOFT-flag path
+    (rho_soft added to the pivot of a soft row in normalised-row units, oracle/daqp_ldp_oracle.c ldl_add) must give
+    the same U.  Conditioning: the slack weight 1 / rho amplifies rounding, observed 1e-8 at rho = 1e-3 and 1e-5 at
+    1e-6 (ratio = the ratio of the weights); a WRONG unit (slack measured in the un-normalised row, nf = 1) is off
+    by > 1e-3 at either weight, which the last assertion shows, so the bound discriminates."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("make_soft_explicit",
+                                                  os.path.join(os.path.dirname(__file__), "golden", "make_soft_explicit.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = load_golden(name)
+    kat = load_golden("soft_explicit_kat")
+    th = kat[f"{name}_theta"]
+    n = g["H"].shape[0]
+    for rho, tol in ((1e-3, 1e-7), (1e-6, 1e-4)):
+        Us, efs = mk.solve_soft(g, th, rho)
+        assert np.all(efs >= 1)
+        # (a) against the committed explicit-slack answers
+        Uk = kat[f"{name}_U_rho{rho:g}"]
+        assert np.all(kat[f"{name}_flag_rho{rho:g}"] >= 1)
+        assert np.abs(Us - Uk).max() <= tol, (rho, np.abs(Us - Uk).max())
+        # (b) ... which this checkout reproduces from the reference's definition
+        U, eps, ef = mk.solve_explicit(g, th, 1.0 / rho)
+        assert np.all(ef >= 1) and np.abs(U - Uk).max() <= tol
+        # exit flag 2 (soft optimal) <=> rho sum lam_i^2 > primal_tol, and the explicit slack of a soft row in
+        # normalised-row units is eps_i = rho lam_i: the same quantity from the explicit QP is sum eps_i^2 / rho
+        ssq = (eps ** 2).sum(axis=1) / rho
+        assert np.all(ssq[efs == 1] <= 1.5e-6) and np.all(ssq[efs == 2] > 0.67e-6)
+    # discriminating power: the same explicit QP with the slack in UN-normalised row units is a different problem
+    if name != "pendulum_N50":                       # (its sampled points barely touch the soft rows)
+        q = mk.explicit_slack_qp(g, 1e3)
+        A = q["A"].copy()
+        A[:, n:] = np.sign(A[:, n:])                 # nf = 1
+        L = oldp.qp2ldp(q["H"], q["f"], q["f_theta"], A, q["bu"], q["bl"], q["W"], q["senses"], nout=n)
+        Xw, efw, _, _ = oldp.solve_batch(L, th)
+        Us, efs = mk.solve_soft(g, th, 1e-3)
+        assert np.abs(Xw - Us)[(efw >= 1) & (efs == 2)].max() > 1e-3
