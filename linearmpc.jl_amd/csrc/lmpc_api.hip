@@ -223,8 +223,9 @@ size_t lane_lds_bytes(const HostPack &P, int N, int B) {
 // capacity of one work-list segment: the problems of all screening workgroups with the same
 // (blockIdx % kShards), each covering kScreenTPB tiles of 256
 long long lane_seg_cap(long long nprob) {
-    // screening kernel: workgroup b (256 problems) -> shard b % kShards; fast kernel: wavefront g (64 T problems,
-    // T <= 32) -> shard g % kShards.  One bound for both: an even share plus one unit of either kind, rounded up.
+    // screening kernel: workgroup b (kScreenTPB tiles of 256 problems) -> shard b % kShards.  A shard's segment holds
+    // an even share of the batch plus one workgroup's worth, rounded up (the one-launch kernel writes no list).
+    static_assert(kScreenTPB * 256 <= 64 * 32 + 256, "a screening workgroup's problems must fit the segment's slack");
     return (((nprob + kShards - 1) / kShards + 64 * 32 + 256) + 255) & ~255ll;
 }
 

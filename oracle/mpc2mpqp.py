@@ -785,8 +785,12 @@ def mass_spring_3in(nm=6, Np=10, Nc=10) -> MPCProblem:
 
 
 def aircraft(Np=10, Nc=2) -> MPCProblem:
-    """src/mpc_examples.jl:174-205 `aircraft` (the example the reference's move-blocking test uses,
-    test/runtests.jl:138-176): 4 states, 2 inputs, 2 outputs, |u| <= 0.5, soft bound on the second output."""
+    """A two-input fixture for the move-blocking SIZE checks (test/runtests.jl:138-176 run them on the `aircraft`
+    example), built from that example's plant (src/mpc_examples.jl:174-205: A, B, C, Ts, scaling, weights, |u| <=
+    0.5).  It is NOT the reference's example problem: the measured-disturbance feedthrough Dd is left out and the
+    output bound is a soft bound on the second output over steps 2..Np, where the reference bounds both outputs at
+    step 2 only (`ks = 2:2`).  The move-block structure the test counts depends on nu and the blocks alone; no
+    golden or parity vector is generated from this fixture."""
     A = np.array([[-0.0151, -60.5651, 0, -32.174], [-0.0001, -1.3411, 0.9929, 0],
                   [0.00018, 43.2541, -0.86939, 0], [0, 0, 1, 0]])
     B = np.array([[-2.516, -13.136], [-0.1689, -0.2514], [-17.251, -1.5766], [0, 0]])
