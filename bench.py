@@ -289,9 +289,9 @@ class Workload:
         torch = self.torch
         # the one-launch kernel's shape options set for several batches in flight do not suit a call issued alone:
         # this section runs the library's own defaults and puts the others back afterwards
-        shaped = {k_: v_ for k_, v_ in self.options.items() if k_ in ("fast_nstr", "fast_tiles")}
+        shaped = {k_: v_ for k_, v_ in self.options.items() if k_ in ("fast_nstr", "fast_tiles", "in_flight")}
         for k_ in shaped:
-            self.qp.set_option(k_, 0)
+            self.qp.set_option(k_, 1 if k_ == "in_flight" else 0)
         for k in range(4):
             self.launch(k, 0, resident)
         torch.cuda.synchronize(self.dev)
@@ -304,6 +304,38 @@ class Workload:
         for k_, v_ in shaped.items():
             self.qp.set_option(k_, v_)
         return solo
+
+    def verify_steps(self, ks, per_step=4096, seed=99):
+        """Output check behind a timed region: for each step k in ks, a seeded sample of the buffers that step wrote
+        against the CPU oracle on the same parameter points (the oracle is the checker here, nothing timed).  Returns
+        a dict with `verified` (all sampled points bit-identical in exit flag, <= 1e-10 in x; binary32: the binary32
+        oracle, 1e-6)."""
+        from oracle import ldp as oldp
+        torch = self.torch
+        pk = self.qp.ldp()
+        L = oldp.LDP(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["M"], pk["du"], pk["dl"], pk["Dth"],
+                     pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"]))
+        so = oldp.default_settings_f32() if self.f32 else oldp.default_settings()
+        so.mode = 1 if self.options.get("gram_scan") else 0
+        rng = np.random.default_rng(seed)
+        worst, nflag, npts = 0.0, 0, 0
+        for k in ks:
+            b = k % self.nbuf
+            r_ = k % self.nrot
+            idx = torch.from_numpy(np.sort(rng.choice(self.n_local, min(per_step, self.n_local), replace=False))).to(self.dev)
+            th = self.thetas[r_][idx].cpu().numpy()
+            x = self.xbuf[b][idx].cpu().numpy()
+            ef = self.fbuf[b][idx].cpu().numpy()
+            xo, efo, _, _ = oldp.solve_batch(L, th, so, dtype=np.float32 if self.f32 else np.float64)
+            nflag += int((ef != efo).sum())
+            ok = efo >= 1
+            if ok.any():
+                worst = max(worst, float(np.abs(x[ok] - xo[ok]).max()))
+            npts += len(idx)
+        tol = 1e-6 if self.f32 else 1e-10
+        return {"verified": bool(nflag == 0 and worst <= tol), "points": npts, "steps_checked": [int(k) for k in ks],
+                "exit_flag_mismatches": nflag, "max_abs_dx": worst, "tolerance": tol,
+                "against": "oracle/daqp_ldp_oracle.c (mode %d) on the same parameter points, after the timed region" % so.mode}
 
     def work_distribution(self):
         """Iteration and active-set-size histograms of batch 0 (untimed extra solve) and the algorithmic
@@ -358,15 +390,72 @@ def describe(w):
     return f"{w.workload}: {body}, {w.n_local} parameter points per GPU, cold start, first move u0 returned"
 
 
+def multi_abi_check(torch, lmpc, g, nout, n_per_dev, seed):
+    """The C ABI's one-process multi-device entry point (lmpc_solve_batch_multi_device: resident shards, RCCL gather to
+    the first device over xGMI), executed across every GPU this process sees: the gathered solutions and exit flags
+    must equal the per-device shards bit for bit, and a sample of every shard the oracle.  Untimed part of the run;
+    reported as config.multi_abi.  With one visible device there is nothing to gather: says so."""
+    nd = torch.cuda.device_count()
+    out = {"n_devices": nd}
+    if nd < 2:
+        out["skipped"] = "one visible GPU: the nd > 1 branch (ncclCommInitAll, ncclSend/ncclRecv) cannot run here"
+        return out
+    try:
+        from oracle import ldp as oldp
+        mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+        hosts = [make_theta("pendulum", n_per_dev, seed + 31 * d) for d in range(nd)]
+        shards = [torch.from_numpy(hosts[d]).to(f"cuda:{d}") for d in range(nd)]
+        mq.solve_device(shards, gather=True)                      # first gather: librccl load + ncclCommInitAll
+        for d in range(nd):
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        xs, fs, xr, fr = mq.solve_device(shards, gather=True)
+        for d in range(nd):
+            torch.cuda.synchronize(d)
+        out["ms"] = 1e3 * (time.perf_counter() - t0)
+        off = np.cumsum([0] + [n_per_dev] * nd)
+        xr_h, fr_h = xr.cpu().numpy(), fr.cpu().numpy()
+        same = all(np.array_equal(xr_h[off[d]:off[d + 1]], xs[d].cpu().numpy()) and
+                   np.array_equal(fr_h[off[d]:off[d + 1]], fs[d].cpu().numpy()) for d in range(nd))
+        pk = mq.parts[0].ldp()
+        L = oldp.LDP(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["M"], pk["du"], pk["dl"], pk["Dth"],
+                     pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"]))
+        ok_oracle = True
+        for d in range(nd):
+            xo, efo, _, _ = oldp.solve_batch(L, hosts[d][:2048])
+            ok_oracle = ok_oracle and np.array_equal(xr_h[off[d]:off[d] + 2048], xo) and np.array_equal(fr_h[off[d]:off[d] + 2048], efo)
+        out.update({"identical": bool(same), "oracle_sample_identical": bool(ok_oracle), "points_per_device": n_per_dev,
+                    "solves_per_s_incl_gather": nd * n_per_dev / (out["ms"] * 1e-3),
+                    "note": "ONE call of lmpc_solve_batch_multi_device from one process: every device solves its resident "
+                            "shard, then an RCCL gather (ncclSend/ncclRecv in one group) of x and exit flags to device 0; "
+                            "wall time of the call incl. the gather and the host's launch loop"})
+        mq.close()
+    except Exception as e:                                        # reported, never fatal for the bench line
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def _forms_agreement(xa, fa, xb, fb):
+    ok = fa >= 1
+    both = ok & (fb >= 1)
+    return {"solved_fraction": float(ok.mean()), "solved_status_flips": int((ok != (fb >= 1)).sum()),
+            "exit_flags_differ_among_failed": int(((fa != fb) & ~ok).sum()),
+            "max_abs_dx_on_solved": float(np.abs(xa[both] - xb[both]).max()) if both.any() else 0.0,
+            "solved_points_with_dx_above_1e-6": int((np.abs(xa[both] - xb[both]).max(axis=1) > 1e-6).sum()) if both.any() else 0}
+
+
 def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f32, want_cpu, cpu_seconds=4.0):
     """One of the other single-GPU BASELINE configurations, measured in the same process: one batch in
     flight on one stream (these kernels fill the chip by themselves), rotation past the Infinity Cache,
-    roofline from the live HIP-event duration of a call."""
+    roofline from the live HIP-event duration of a call.  Wavefront-kernel workloads are measured in both of the
+    kernel's forms: the n-chain form (library default; `value`) and the Gram-scan form (`gram_scan`)."""
     _phase(f"config {workload}: setup")
     w = Workload(torch, lmpc, workload, batch, dev, local_rank, 0, 1, f32=f32)
     dist_info, flop = w.work_distribution()
+    x_chain, f_chain = w.xbuf[0].cpu().numpy().copy(), w.fbuf[0].cpu().numpy().copy()
     _phase(f"config {workload}: timed region")
     el = w.timed(steps, warmup)
+    verification = w.verify_steps([steps - 1], per_step=2048)
     solo = w.single_launch(max(3, min(steps, 20)))
     value = batch * steps / el
     wave = w.kernel == "wave"
@@ -388,12 +477,46 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
                 "fp64_flop_per_solve_est": flop}
     out = {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
            "dtype": dtype, "batch": batch, "kernel": w.kernel, "rotating_batches": w.nrot,
-           "workload": describe(w), **dist_info, "roofline": roof}
+           "workload": describe(w), **dist_info, "roofline": roof, "verified": verification["verified"],
+           "verification": verification, "options": dict(w.options)}
     if want_cpu:
         _phase(f"config {workload}: cpu baseline")
         out["cpu_baseline"] = cpu_baseline(w.g, w.theta_h, w.nout, min_seconds=cpu_seconds, f32=f32,
                                            all_cores_seconds=cpu_seconds / 2)
+        if not f32:     # marginal points of a bounded sample (oracle + dense KKT per distinct active set)
+            from oracle import ldp as oldp
+            Lm = oldp.qp2ldp(w.g["H"], w.g["f"], w.g["f_theta"], w.g["A"], w.g["bu"], w.g["bl"], w.g["W"], w.g["senses"], nout=w.nout)
+            out["marginal_cases"] = oldp.marginal_report(Lm, w.theta_h[:4000])
+    theta_h, gg, nout_ = w.theta_h, w.g, w.nout
     w.close()
+    if wave:
+        _phase(f"config {workload}: Gram-scan form")
+        wg = Workload(torch, lmpc, workload, batch, dev, local_rank, 0, 1, f32=f32, options={"gram_scan": 1})
+        dist_g, _ = wg.work_distribution()
+        x_gram, f_gram = wg.xbuf[0].cpu().numpy().copy(), wg.fbuf[0].cpu().numpy().copy()
+        elg = wg.timed(steps, warmup)
+        ver_g = wg.verify_steps([steps - 1], per_step=2048)
+        solog = wg.single_launch(max(3, min(steps, 20)))
+        achg = flop * batch / (solog[1] * 1e-3) / 1e12 if solog[1] > 0 else 0.0
+        out["gram_scan"] = {
+            "value": batch * steps / elg, "unit": "solves/s", "ms_per_step": 1e3 * elg / steps,
+            "speedup_over_n_chain_form": (batch * steps / elg) / value,
+            "options": {"gram_scan": 1}, "verified": ver_g["verified"], "verification": ver_g,
+            "mean_iterations": dist_g["mean_iterations"], "solved_fraction": dist_g["solved_fraction"],
+            "roofline": {"bound": "valu", "achieved": achg, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                         "frac": achg / VALU_PEAK_TFLOPS[dtype], "traffic": None, "duration_used_ms": solog[1],
+                         "flop_per_solve_est": flop,
+                         "note": "same unit of work as the n-chain form: SURVEY 8(d)'s flop count of the reference "
+                                 "algorithm per solve (2mn + 2|W|n + 2|W|^2 per iteration) at the n-chain form's "
+                                 "iteration counts; the Gram-scan form itself executes fewer (2m|W| for the scan)"},
+            "agreement_with_n_chain_form": _forms_agreement(x_chain, f_chain, x_gram, f_gram),
+            "note": "lmpc_set_option('gram_scan', 1): row values from |W| Gram columns instead of n columns of M', "
+                    "dual objective from the factorisation, pairwise lane trees for the append's dot products; "
+                    "bit-identical to the oracle's mode 1; against the n-chain form: same exit flags, iteration counts "
+                    "and active sets on solvable points (tests/test_gpu_gram.py), x to rounding (amplified by 1/rho_soft "
+                    "on SOFT rows); on infeasible, nearly dependent problems the two forms may stop with different "
+                    "failure flags (-1 / -2)"}
+        wg.close()
     return out
 
 
@@ -474,19 +597,13 @@ def main():
         opts["wave_level"] = args.wave_level
     if args.wave_nwv:
         opts["wave_nwv"] = args.wave_nwv
-    # several batches in flight: 64-lane workgroups for the iterating kernel (its wavefronts then spread
-    # over the CUs independently of each other; +3 % over the library's stand-alone choice of 256,
-    # which is the better one with a single batch in flight: tools/block_sweep.sh)
-    if not args.lane_block and nstreams > 1 and not args.f32 and not args.wave and args.workload in ("pendulum", "pendulum_hard"):
-        args.lane_block = 64
+    # several batches in flight: the library is TOLD so (lmpc_set_option "in_flight", include/lmpc_hip.h) and picks
+    # its own workgroup shapes for a shared chip; everything else runs on library defaults.  Every option set on the
+    # handles of the timed region is recorded in config.options.
+    if nstreams > 1 and not args.f32 and not args.wave and args.workload in ("pendulum", "pendulum_hard"):
+        opts["in_flight"] = nstreams
     if args.lane_block:
         opts["lane_block"] = args.lane_block
-    if nstreams > 1 and args.workload == "pendulum" and not args.f32 and not args.wave:
-        # one-launch kernel with several batches in flight: all four wavefronts of a workgroup stream and a workgroup
-        # takes 28 tiles instead of one resident round's 21 (same-box sweep, three in flight, cold: 18.3 us/step at the
-        # defaults, 17.0 with fast_nstr 4, 16.0 with both)
-        opts["fast_nstr"] = 4
-        opts["fast_tiles"] = 28
     if args.lane_tier >= 0:
         opts["lane_tier"] = args.lane_tier
     for kv in args.opt:
@@ -589,6 +706,10 @@ def main():
         gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
     fence()
     elapsed = time.perf_counter() - t0
+    # ---- what the timed region wrote, checked against the oracle (untimed): the last steps of every stream
+    verification = None
+    if rank == 0 and args.steps and not do_gather:
+        verification = W.verify_steps(list(range(max(0, args.steps - max(nstreams, 2)), args.steps)))
     exchange_ms = None
     if after_gather and args.steps:
         # the exchange a single consumer of all shards would add: one batch's solutions and flags to rank 0
@@ -636,7 +757,7 @@ def main():
                             f"({nstreams} batches in flight)"}
         # ---- one call at a time, cold HBM: THE roofline figure
         if args.steps and not args.no_single_launch:
-            nsolo = int(min(120, max(24, args.steps)))
+            nsolo = int(min(200, max(100, args.steps)))      # (23 us each: a hundred calls cost nothing and settle the clocks)
             cold = W.single_launch(nsolo, resident=False)
             if cold[0] > 0 and cold[1] > 0:
                 roof.update({"achieved": gbs(cold[1]), "frac": gbs(cold[1]) / HBM_PEAK_GBS, "duration_used_ms": cold[1],
@@ -683,11 +804,20 @@ def main():
             "metric": "condensed-MPC QP solves/sec (batch 1e6 params), pendulum Nc=5"
                       if args.workload == "pendulum" else f"condensed-MPC QP solves/sec ({args.workload})",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            # `value` = the timed region: `batches_in_flight` independent batches kept in flight (a pipeline figure);
+            # next to it the same workload ONE call at a time on one stream (cold HBM), which is what
+            # roofline.achieved / frac are computed from
+            "value_one_call_at_a_time": (world * n_local / (roof["kernel_ms"] * 1e-3)) if roof.get("kernel_ms") else None,
+            "verified": (verification or {}).get("verified"),
             "warmup": args.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": describe(W), "batch_per_gpu": n_local, "kernel": W.kernel,
                        "batches_in_flight": nstreams, "rotating_batches": W.nrot,
+                       "options": {**W.options, "_note": "every lmpc_set_option of the timed region's handles; all else "
+                                                          "library defaults.  in_flight = k is the documented hint "
+                                                          "'k batches in flight on this GPU' (include/lmpc_hip.h)"},
+                       "verification": verification,
                        "inputs": ("cold HBM: every step reads a batch that has been evicted from the Infinity Cache"
                                   if W.nrot > 1 else "cache-resident: one theta buffer reused"),
                        "gather": ("all_gather(x, exitflag) over RCCL after every step, overlapped" if do_gather
@@ -703,6 +833,13 @@ def main():
                        **dist_info},
             "roofline": roof,
         }
+        if args.workload == "pendulum" and not args.f32 and not args.wave:
+            if world == 1:
+                _phase("headline: multi-device ABI check")
+                out["config"]["multi_abi"] = multi_abi_check(torch, lmpc, W.g, nout, min(n_local, 1_000_000), 4242)
+            else:
+                out["config"]["multi_abi"] = {"skipped": "torch.distributed run: the one-process multi-device entry point is "
+                                                         "exercised in the N = 1 invocation when it sees several GPUs"}
         _phase("headline: timed region and single-launch sections done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W.g, W.theta_h, nout, f32=args.f32, marginal=True)

@@ -1989,3 +1989,44 @@ def test_screening_pass_in_front_of_wave_kernel(lmpc, n, mg, nth, nsoft, nout, i
     xz, efz, itz, actz = qp.solve(np.zeros((500, nth)))
     assert np.all(efz == 1) and np.all(itz == 1) and not actz.any()
     _compare(qp, rng.standard_normal((200, nth)) * 2.0)
+
+
+def test_benched_configuration_is_parity_checked(lmpc):
+    """The exact shape bench.py times: three handles on three HIP streams, each told
+    `in_flight = 3`, six rotating 1e6-point batches and as many output buffers, launches enqueued back to back
+    without synchronisation in between -- then every buffer against the oracle on a sample, and two full batches
+    against the one-call-at-a-time results of a fresh handle on library defaults."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    W = bench.Workload(torch, lmpc, "pendulum", bench.BATCH, dev, 0, 0, 3, options={"in_flight": 3})
+    assert W.nrot >= 6 and W.nstreams == 3 and "fast" in W.kernel
+    steps = 2 * W.nbuf + 1
+    for k in range(steps):
+        W.launch(k)
+    torch.cuda.synchronize(dev)
+    for q_ in W.qps:
+        q_.check()
+    ver = W.verify_steps(list(range(steps - W.nbuf, steps)), per_step=3000)
+    assert ver["verified"] and ver["exit_flag_mismatches"] == 0 and ver["max_abs_dx"] == 0.0
+    ref = _qp_from_golden(lmpc, load_golden("pendulum"), 1)
+    for k in (steps - 1, steps - 2):
+        xr, fr = ref.solve_device(W.thetas[k % W.nrot])
+        torch.cuda.synchronize(dev)
+        assert bool((xr == W.xbuf[k % W.nbuf]).all()) and bool((fr == W.fbuf[k % W.nbuf]).all())
+    W.close()
+
+
+def test_multi_device_rccl_gather_with_several_gpus(lmpc):
+    """lmpc_solve_batch_multi_device with MORE than one device: ncclCommInitAll in this process, one ncclSend /
+    ncclRecv pair per shard inside a group, gather to the first device (csrc/lmpc_multi.hip).  Needs at least two
+    visible GPUs; the single-GPU boxes of this pool skip it (bench.py runs the same check as config.multi_abi)."""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("one visible GPU: the nd > 1 branch of lmpc_solve_batch_multi_device cannot run here")
+    import bench
+    g = load_golden("pendulum")
+    out = bench.multi_abi_check(torch, lmpc, g, 1, 300_000, 77)
+    assert "error" not in out, out
+    assert out["n_devices"] == nd and out["identical"] and out["oracle_sample_identical"]
