@@ -435,6 +435,74 @@ def multi_abi_check(torch, lmpc, g, nout, n_per_dev, seed):
     return out
 
 
+def region_discovery_config(torch, lmpc, dev, local_rank, nsamples, want_cpu, reps=5):
+    """BASELINE config 4 on one GPU as a measured workload: sampling-based discovery of the pendulum's critical regions
+    over the example's +-20 ParameterRange (/root/reference/src/mpc_examples.jl:128-134; caller side of
+    /root/reference/src/explicit.jl:23-48).  A step = draw nothing new: the resident sample is solved with the
+    active-set masks kept on the device (lmpc_solve_batch_device), reduced there to the distinct masks
+    (lmpc_distinct_active_sets_device) and the distinct sets are read back; samples / wall second, host in the loop."""
+    from linearmpc_jl_amd import explicit
+    g = make_problem("pendulum")
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], device=local_rank)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0])
+    ub = np.array([20.0] * 4 + [20.0, 0.0] + [2.0])
+    first = explicit.discover_regions_device(qp, lb, ub, nsamples, seed=4)
+    theta = first["theta"]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = explicit.discover_regions_device(qp, lb, ub, nsamples, theta=theta)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / reps
+    # the solve alone (masks written), device-timed by wall clock around a synchronised call
+    act = torch.empty((nsamples, qp.words), dtype=torch.int64, device=dev)
+    qp.solve_device(theta, active=act); torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        qp.solve_device(theta, active=act)
+    torch.cuda.synchronize(dev)
+    solve_ms = 1e3 * (time.perf_counter() - t1) / reps
+    res = {"value": nsamples / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "samples": nsamples,
+           "distinct_active_sets": int(len(out["masks"])), "n_solved": int(out["n_solved"]),
+           "solve_with_masks_ms": solve_ms, "kernel": qp.kernel_name, "dtype": "f64",
+           "bytes_read_back": int(len(out["masks"]) * (qp.words + 2) * 8),
+           "workload": "pendulum Nc=5 (BASELINE config 4, one GPU): sample of the +-20 parameter range resident on the "
+                       "device -> batched solve with active-set masks -> distinct masks on the device -> host",
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "achieved": nsamples * (8 * qp.nth + 8 * qp.nout + 4 + 8 * qp.words + 8 * qp.words + 4) / dt / 1e9,
+                        "frac": nsamples * (8 * qp.nth + 8 * qp.nout + 4 + 8 * qp.words + 8 * qp.words + 4) / dt / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None,
+                        "note": "algorithmic bytes per sample: theta in, x / flag / mask out, mask + flag in again for the "
+                                "reduction; divided by the WALL time of a step, which includes the host's launches, two "
+                                "synchronisations and the read-back"}}
+    # cross-check against the host path on a slice
+    th_h = theta[:100000].cpu().numpy()
+    ref = explicit.discover_regions(qp.solve, th_h)
+    dv = explicit.discover_regions_device(qp, None, None, 0, theta=theta[:100000].contiguous())
+    keyf = lambda d: sorted((tuple(int(w) for w in m), int(c)) for m, c in zip(d["masks"], d["counts"]))
+    res["verified"] = bool(keyf(ref) == keyf(dv))
+    if want_cpu:
+        from oracle import ldp as oldp
+        global _NATIVE_FLAGS
+        if _NATIVE_FLAGS is None:
+            _NATIVE_FLAGS = oldp.use_native()
+        L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=qp.nout)
+        ns = 200000
+        th_c = theta[:ns].cpu().numpy()
+        t2 = time.perf_counter()
+        npass = 0
+        while time.perf_counter() - t2 < 3.0:
+            _, efc, _, actc = oldp.solve_batch(L, th_c)
+            np.unique(actc[efc >= 1], axis=0, return_counts=True)
+            npass += 1
+        dtc = time.perf_counter() - t2
+        res["cpu_baseline"] = {"value": npass * ns / dtc, "unit": "samples/s", "cores": 1, "kind": "port",
+                               "sample": f"{npass} passes over the first {ns} samples: oracle/daqp_ldp_oracle.c solve with "
+                                         f"active sets + numpy.unique over the masks, 1 thread ({_cpu_model()}) {_NATIVE_FLAGS}"}
+    qp.close()
+    return res
+
+
 def _forms_agreement(xa, fa, xb, fb):
     ok = fa >= 1
     both = ok & (fb >= 1)
@@ -864,6 +932,8 @@ def main():
                                                      "plot +-10 %, hardware unstated, state constraints of the benchmark script "
                                                      "unpublished (this fixture uses its own, see DESIGN.md)"}
                 cfgs[f"pendulum_N{n_}"] = c_
+            _phase("config region_discovery")
+            cfgs["region_discovery"] = region_discovery_config(torch, lmpc, dev, local_rank, BATCH, want_cpu)
             out["configs"] = cfgs
         print(json.dumps(out), flush=True)
     if world > 1:

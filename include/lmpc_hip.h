@@ -423,6 +423,20 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * kernels.  All of them change the execution order only, never a result. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
+/* Distinct optimal active sets of a solved batch, reduced on the device: the caller side of a sampling-based
+ * explicit-MPC region discovery / complexity certificate (/root/reference/src/explicit.jl:23-48 hands the mpQP to
+ * ParametricDAQP for an exact enumeration; what the batched backend contributes is the sample: solve, then one entry per
+ * critical region the sample hit).  `active` and `exitflag` are lmpc_solve_batch_device's outputs (device pointers;
+ * exitflag == NULL: every problem counts, else those with exitflag >= 1).  Outputs, device pointers, dense in
+ * [0, *n_sets): set_masks[k * words ..] the mask, set_count[k] how many problems ended on it, set_first[k] the
+ * smallest problem index that did.  `capacity` = room in the three arrays; more distinct sets than that raise the
+ * overflow word (lmpc_distinct_active_sets_overflowed: 0 / nonzero, synchronises the stream) and *n_sets then counts
+ * the claims, not the stored sets.  Order of the sets is unspecified (sort on the host).  Asynchronous on `stream`. */
+int lmpc_distinct_active_sets_device(lmpc_handle *h, int64_t N, const uint64_t *active, const int32_t *exitflag,
+                                     int32_t capacity, uint64_t *set_masks, int64_t *set_count, int64_t *set_first,
+                                     int32_t *n_sets, void *stream);
+int lmpc_distinct_active_sets_overflowed(lmpc_handle *h, void *stream);
+
 /* Per-problem exit flags are DAQP's (1 optimal, 2 soft optimal, -1 infeasible, -2 cycle, -4 iteration limit, -6
  * over-determined initial working set) plus two of this library's own:
  *   -7  the working set outgrew what the kernels hold (wavefront kernel: 64 rows, slow path: 256 rows);

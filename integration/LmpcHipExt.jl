@@ -3,13 +3,23 @@
 # C client that is built and run by the test-suite).
 module LmpcHipExt
 using LinearMPC, LinearAlgebra
+import DAQP
 const liblmpc = get(ENV, "LMPC_HIP_LIB", "liblmpc_hip.so")
 
 struct LmpcSettings            # == lmpc_settings (include/lmpc_hip.h)
     primal_tol::Cdouble; dual_tol::Cdouble; zero_tol::Cdouble; progress_tol::Cdouble
     fval_bound::Cdouble; rho_soft::Cdouble; cycle_tol::Cint; iter_limit::Cint
 end
-LmpcSettings(mpc) = LmpcSettings(1e-6, 1e-12, 1e-11, 1e-6, 1e30, 1/mpc.settings.soft_weight, 10, 10000)
+# The solver settings the user has put on mpc.opt_model with DAQP.settings(mpc.opt_model, Dict(...))
+# (/root/reference/docs/src/manual/solver.md:19-22) are read back from the DAQP model, not assumed: DAQP.settings(model)
+# returns the C struct DAQPSettings with these field names.  rho_soft is what setup! itself wrote there,
+# 1 / mpc.settings.soft_weight (/root/reference/src/setup.jl:26).  (eps_prox / eta_prox / pivot_tol and the B&B
+# tolerances have no counterpart in the batched backend: proximal iterations for a semidefinite H are refused at setup.)
+function LmpcSettings(mpc::LinearMPC.MPC)
+    d = DAQP.settings(mpc.opt_model)
+    return LmpcSettings(d.primal_tol, d.dual_tol, d.zero_tol, d.progress_tol, d.fval_bound, d.rho_soft,
+                        d.cycle_tol, d.iter_limit)
+end
 
 mutable struct BatchedModel    # stands next to mpc.opt_model
     h::Ptr{Cvoid}; n::Int; nout::Int; nth::Int; words::Int
@@ -46,6 +56,37 @@ function LinearMPC.solve(bm::BatchedModel, Θ::Matrix{Float64})
     rc == 1 || error("lmpc_solve_batch failed ($rc)")
     return X, flags
 end
+
+# ---- the literal drop-in: solve(mpc, θ) for ONE parameter vector, the call compute_control / Simulation make
+# (/root/reference/src/utils.jl:43-51, :268-283; /root/reference/src/simulation.jl:106).  A method on (MPC, AbstractVector)
+# is more specific than the package's own solve(mpc::MPC, θ), so after `using LmpcHipExt` the unchanged
+# compute_control(mpc, x), compute_control_trajectory and Simulation(mpc; ...) run on lmpc_solve_one.
+# Returns what DAQP.solve returns: (x*, fval, exitflag, info); fval = 1/2 x'Hx + (f + f_θ θ)'x is formed on the host
+# from x* (the reference reads x* and exitflag only, utils.jl:45-48).  One handle per MPC object, with nout = n
+# (compute_control subtracts K·x itself, utils.jl:48-49) and the user's DAQP settings; setup!(mpc) drops it.
+const _models = IdDict{Any,BatchedModel}()
+function _model_for(mpc::LinearMPC.MPC)
+    mpc.mpqp_issetup || LinearMPC.setup!(mpc)
+    bm = get(_models, mpc, nothing)
+    if bm === nothing || bm.n != size(mpc.mpQP.H,1) || bm.nth != size(mpc.mpQP.f_theta,2)
+        K = mpc.K; mpc.K = zero(K)                      # nout = n handle without the feedback folded in
+        try bm = setup_batched(mpc; nout=size(mpc.mpQP.H,1)) finally mpc.K = K end
+        _models[mpc] = bm
+    end
+    return bm
+end
+function LinearMPC.solve(mpc::LinearMPC.MPC, θ::AbstractVector{<:Real})
+    bm = _model_for(mpc)
+    th = Vector{Float64}(θ); x = Vector{Float64}(undef, bm.nout)
+    flag = ccall((:lmpc_solve_one, liblmpc), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), bm.h, th, x)
+    flag <= -100 && error("lmpc_solve_one failed ($flag): ",
+                          unsafe_string(ccall((:lmpc_last_error, liblmpc), Cstring, (Ptr{Cvoid},), bm.h)))
+    q = mpc.mpQP
+    fval = 0.5*dot(x, q.H, x) + dot(q.f .+ q.f_theta*th, x)
+    return x, fval, Int(flag), (status = flag >= 1 ? :Solved : :Failed, exitflag = Int(flag))
+end
+"forget the handle of an MPC whose problem data changed (call after setup!(mpc) / set_*!)"
+reset_batched!(mpc::LinearMPC.MPC) = (delete!(_models, mpc); nothing)
 
 "single-precision twin (the reference's codegen float_type=\"float\" build of the same path)"
 function solve_f32(bm::BatchedModel, Θ::Matrix{Float32})

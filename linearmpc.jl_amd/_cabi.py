@@ -31,6 +31,7 @@ SYMBOLS = (
     "lmpc_setup_multi", "lmpc_multi_devices", "lmpc_multi_handle", "lmpc_multi_partition",
     "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
     "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch", "lmpc_check",
+    "lmpc_distinct_active_sets_device", "lmpc_distinct_active_sets_overflowed",
 )
 
 
@@ -168,6 +169,11 @@ def lib():
     L.lmpc_free_multi.restype = None
     L.lmpc_release_scratch.argtypes = [vp]
     L.lmpc_release_scratch.restype = i32
+    if hasattr(L, "lmpc_distinct_active_sets_device"):
+        L.lmpc_distinct_active_sets_device.argtypes = [vp, ctypes.c_int64, vp, vp, i32, vp, vp, vp, vp, vp]
+        L.lmpc_distinct_active_sets_device.restype = i32
+        L.lmpc_distinct_active_sets_overflowed.argtypes = [vp, vp]
+        L.lmpc_distinct_active_sets_overflowed.restype = i32
     if hasattr(L, "lmpc_check"):              # (an older build selected with LMPC_HIP_LIB for an A/B lacks it)
         L.lmpc_check.argtypes = [vp]
         L.lmpc_check.restype = i32

@@ -1449,7 +1449,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI);
+    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);

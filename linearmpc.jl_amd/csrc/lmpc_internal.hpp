@@ -61,6 +61,8 @@ struct lmpc_handle {
     int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
     bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;
+    int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
+    int regCap = 0;
     // slow path for working sets beyond the 64 lanes (lmpc_big_kernel.hpp): overflow list + counter, per-thread scratch
     int capFull = 0;            // n + 1 + #soft: the rows a working set of this problem can hold
     int32_t *dOvfList = nullptr, *dOvfCount = nullptr, *dBigI = nullptr;

@@ -9,7 +9,9 @@ region that the sample hit) and derive each region's affine control law from the
 that active set.  This is a candidate generator, NOT a replacement for exact enumeration: regions
 the sample misses are not found, and no region boundaries are certified.
 
-Everything here is host-side bookkeeping around `BatchedQP.solve`; the solve itself is the HIP path.
+`discover_regions` / `certify_sampled` are host-side bookkeeping around `BatchedQP.solve`; `discover_regions_device`
+keeps the whole per-sample part on the GPU (sample, solve, reduction to the distinct masks:
+`lmpc_distinct_active_sets_device`, csrc/lmpc_regions.hip) and brings back one row per region.
 """
 from __future__ import annotations
 
@@ -100,6 +102,41 @@ def discover_regions(solve_fn, theta, group=None):
         masks, counts, first = um[order], uc[order], None
         solved = sum(g[2] for g in gathered)
     return {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved}
+
+
+def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=65536, theta=None):
+    """`discover_regions` with everything per-sample on the GPU: the sample of the box [lb, ub] is drawn on the device
+    (torch generator, seeded), solved by `lmpc_solve_batch_device` with the active-set masks kept there, and reduced to
+    its distinct masks by `lmpc_distinct_active_sets_device`; what crosses PCIe is one row per region that was hit.
+    `theta`: a ready-made (N, nth) float64 CUDA tensor instead of the drawn sample.  With a torch.distributed `group`
+    every rank passes its own seed / shard and the per-rank sets (a few kB) are merged on every rank."""
+    import torch
+    dev = torch.device("cuda", qp.device if hasattr(qp, "device") and qp.device is not None else torch.cuda.current_device())
+    if theta is None:
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(seed))
+        lo = torch.as_tensor(np.asarray(lb, float).reshape(-1), dtype=torch.float64, device=dev)
+        hi = torch.as_tensor(np.asarray(ub, float).reshape(-1), dtype=torch.float64, device=dev)
+        theta = lo + (hi - lo) * torch.rand((int(nsamples), lo.numel()), dtype=torch.float64, device=dev, generator=gen)
+    act = torch.empty((theta.shape[0], qp.words), dtype=torch.int64, device=theta.device)
+    x, ef = qp.solve_device(theta, active=act)
+    masks, counts, first = qp.distinct_active_sets_device(act, ef, capacity=capacity)
+    solved = int(counts.sum())
+    out = {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved, "theta": theta}
+    if group is not None:
+        import torch.distributed as dist
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, (masks, counts, solved), group=group)
+        nonempty = [g for g in gathered if len(g[0])]
+        if nonempty:
+            allm = np.concatenate([g[0] for g in nonempty], 0)
+            allc = np.concatenate([g[1] for g in nonempty])
+            um, inv = np.unique(allm, axis=0, return_inverse=True)
+            uc = np.bincount(inv.reshape(-1), weights=allc, minlength=len(um)).astype(np.int64)
+            order = np.argsort(-uc, kind="stable")
+            out.update({"masks": um[order], "counts": uc[order], "first_index": None})
+        out["n_solved"] = sum(g[2] for g in gathered)
+    return out
 
 
 def certify_sampled(solve_fn, theta, group=None):

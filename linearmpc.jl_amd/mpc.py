@@ -192,18 +192,38 @@ class MPC:
             raise ValueError(f"Generalized parameters must have length {self.np}")
         return np.concatenate([x, r, d, up, p])
 
+    # docs/src/manual/solver.md:19-22 -- DAQP.settings(mpc.opt_model, Dict(:iter_limit => 2000, ...))
+    def solver_settings(self, **changes):
+        """The mirror of `DAQP.settings(mpc.opt_model[, Dict])`: without arguments the settings in force, with
+        keyword arguments (primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft, cycle_tol,
+        iter_limit) they are changed on the MPC and on every handle it has set up -- the batched backend reads the
+        user's solver settings, it does not assume DAQP's defaults."""
+        for k, v in changes.items():
+            if not hasattr(self.settings, k):
+                raise KeyError(f"unknown solver setting {k}")
+            setattr(self.settings, k, type(getattr(self.settings, k))(v))
+        if changes:
+            for model in (self.opt_model, self._ctrl_model):
+                if model is not None:
+                    model.set_settings(self.settings)
+        return {k: getattr(self.settings, k) for k, _ in self.settings._fields_}
+
     # utils.jl:268-283
     def solve(self, theta):
-        """-> (xdaqp, fval, exitflag, info) like DAQP.solve; the reference reads x and exitflag only."""
+        """-> (xdaqp, fval, exitflag, info) like DAQP.solve: ONE parameter vector through `lmpc_solve_one`, the
+        call the Julia glue's `LinearMPC.solve(mpc::MPC, θ::AbstractVector)` makes (integration/LmpcHipExt.jl), so
+        that compute_control / compute_control_trajectory / a Simulation loop run on it unchanged.  fval =
+        1/2 x'Hx + (f + f_theta θ)'x is formed on the host from x* (the reference reads x* and exitflag only,
+        utils.jl:45-48)."""
         if not self.mpqp_issetup:
             self.setup()
         theta = np.asarray(theta, float).reshape(-1)
-        x, ef, it, act = self.opt_model.solve(theta[None, :])
+        x, flag = self.opt_model.solve_one(theta)
         q = self.mpQP
         fth = q.f + q.f_theta @ theta
-        fval = 0.5 * x[0] @ q.H @ x[0] + fth @ x[0]
-        info = {"iterations": int(it[0]), "active": act[0].copy()}
-        return x[0].copy(), float(fval), int(ef[0]), info
+        fval = 0.5 * x @ q.H @ x + fth @ x
+        info = {"exitflag": int(flag), "status": "Solved" if flag >= 1 else "Failed"}
+        return x.copy(), float(fval), int(flag), info
 
     # utils.jl:43-51
     def compute_control(self, x, r=None, d=None, uprev=None, p=None, check=True):

@@ -529,6 +529,45 @@ class BatchedQP:
     def set_option(self, name: str, value: int):
         check(lib().lmpc_set_option(self._h, name.encode(), int(value)), self._h)
 
+    def distinct_active_sets_device(self, active, exitflag=None, capacity=65536, stream=None):
+        """`lmpc_distinct_active_sets_device`: the distinct rows of a solved batch's `active` tensor (N x words int64
+        CUDA tensor, as `solve_device(..., active=...)` fills it), reduced ON the device; only the distinct sets come
+        back.  Returns (masks (R x words uint64), counts (R), first_index (R)) as numpy arrays sorted by decreasing
+        count, ties by first index -- the order `explicit.unique_active_sets` gives."""
+        import torch
+        dev = active.device
+        N = int(active.shape[0])
+        if not (active.is_cuda and active.is_contiguous() and active.dtype in _mask_dtypes() and
+                active.numel() == N * self.words):
+            raise ValueError("active must be a contiguous (N, words) 64-bit integer CUDA tensor")
+        if exitflag is not None and not (exitflag.is_cuda and exitflag.dtype == torch.int32 and exitflag.numel() == N):
+            raise ValueError("exitflag must be an int32 CUDA tensor of length N")
+        st = 0 if stream is None else int(stream)
+        while True:
+            masks = torch.empty((capacity, self.words), dtype=torch.int64, device=dev)
+            counts = torch.empty(capacity, dtype=torch.int64, device=dev)
+            first = torch.empty(capacity, dtype=torch.int64, device=dev)
+            nset = torch.zeros(1, dtype=torch.int32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()         # (buffers above come from torch's stream)
+            check(lib().lmpc_distinct_active_sets_device(
+                self._h, N, _vp(active.data_ptr()), _vp(exitflag.data_ptr()) if exitflag is not None else None,
+                int(capacity), _vp(masks.data_ptr()), _vp(counts.data_ptr()), _vp(first.data_ptr()),
+                _vp(nset.data_ptr()), _vp(st) if st else None), self._h)
+            over = lib().lmpc_distinct_active_sets_overflowed(self._h, _vp(st) if st else None)
+            if over < 0:
+                check(over, self._h)
+            if over == 0:
+                break
+            if over == 2:
+                raise LmpcError(_cabi.LMPC_ERR_HIP, "lmpc_distinct_active_sets_device: table slot never published")
+            capacity *= 4                                        # more regions than room: once more with more
+        R = int(nset.item())
+        m = masks[:R].cpu().numpy().view(np.uint64)
+        c = counts[:R].cpu().numpy()
+        f = first[:R].cpu().numpy()
+        order = np.lexsort((f, -c))
+        return m[order], c[order], f[order]
+
     def check(self):
         """`lmpc_check`: wait for the handle's GPU, then raise if a kernel reported an internal failure
         (problems with exit flag -8) since the last check."""

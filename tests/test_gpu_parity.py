@@ -2030,3 +2030,77 @@ def test_multi_device_rccl_gather_with_several_gpus(lmpc):
     out = bench.multi_abi_check(torch, lmpc, g, 1, 300_000, 77)
     assert "error" not in out, out
     assert out["n_devices"] == nd and out["identical"] and out["oracle_sample_identical"]
+
+
+def test_solve_mpc_theta_drop_in_and_user_settings(lmpc):
+    """`solve(mpc, θ)` (/root/reference/src/utils.jl:268-283) for one parameter vector returns DAQP.solve's tuple
+    (x*, fval, exitflag, info) through lmpc_solve_one -- what the glue's LinearMPC.solve(mpc::MPC, θ::AbstractVector)
+    calls -- and `compute_control` (utils.jl:43-51) runs on it unchanged; solver settings the user changes
+    (`DAQP.settings(mpc.opt_model, Dict(...))`, docs/src/manual/solver.md:19-22) reach the handle."""
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    q = lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"])
+    mpc = lmpc.MPC(q, nx=4, nu=1, nr=2, nuprev=1)
+    th = mpc.form_parameter([5.0, 5, 0, 0], uprev=[0.0])
+    x, fval, flag, info = mpc.solve(th)
+    assert flag == 1 and info["status"] == "Solved" and abs(x[0] - 1.7612519326) < 1e-6      # K1, runtests.jl:62-66
+    # fval is the QP's objective at x*, and x* minimises it over the feasible set: any feasible perturbation is worse
+    obj = lambda z: 0.5 * z @ q.H @ z + (q.f + q.f_theta @ th) @ z
+    assert abs(fval - obj(x)) < 1e-12
+    L = oracle_ldp_from(mpc.opt_model.ldp())
+    xo, efo, _, _ = oldp.solve_batch(L, th[None])
+    assert np.array_equal(x, xo[0]) and flag == efo[0]
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        z = np.clip(x + 1e-3 * rng.standard_normal(5), g["bl"][:5], g["bu"][:5])
+        assert obj(z) >= fval - 1e-12
+    # the user's solver settings are the handle's: an iteration limit of 2 makes this 3-iteration point fail
+    assert mpc.solver_settings()["iter_limit"] == 10000
+    mpc.solver_settings(iter_limit=2)
+    _, _, flag2, info2 = mpc.solve(th)
+    assert flag2 == -4 and info2["status"] == "Failed"
+    with pytest.raises(AssertionError):
+        mpc.compute_control([5.0, 5, 0, 0])                       # @assert exitflag >= 1, utils.jl:46
+    mpc.solver_settings(iter_limit=2000, primal_tol=1e-8)
+    u = mpc.compute_control([5.0, 5, 0, 0])
+    assert abs(u[0] - 1.7612519326) < 1e-6
+    with pytest.raises(KeyError):
+        mpc.solver_settings(eps_prox=1e-3)                        # proximal iterations: not in this backend
+
+
+def test_region_discovery_device_pipeline(lmpc):
+    """BASELINE config 4 with the per-sample part on the GPU: sample drawn on the device, solved
+    with the masks kept there, reduced to the distinct masks by lmpc_distinct_active_sets_device -- against the host
+    path (np.unique over all masks) on the SAME sample: same sets, same counts, same representative samples."""
+    import torch
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g)
+    lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0])
+    ub = np.array([20.0] * 4 + [20.0, 0.0] + [2.0])
+    out = lmpc.explicit.discover_regions_device(qp, lb, ub, 1_000_000, seed=3)
+    theta = out["theta"].cpu().numpy()
+    ref = lmpc.explicit.discover_regions(qp.solve, theta)
+    assert out["n_solved"] == ref["n_solved"] == 1_000_000 and 44 <= len(out["masks"]) <= 243
+    assert np.array_equal(out["counts"], ref["counts"][np.lexsort((ref["first_index"], -ref["counts"]))])
+    key = lambda d: sorted((tuple(int(w) for w in m), int(c), int(f)) for m, c, f in zip(d["masks"], d["counts"], d["first_index"]))
+    assert key(out) == key(ref)
+    # law of the most frequent region reproduces the solver at its representative sample (KKT law check)
+    i = int(out["first_index"][0])
+    Fz, gz = lmpc.explicit.affine_law(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], out["masks"][0])
+    x, ef, _, act = qp.solve(theta[i][None])
+    assert np.array_equal(act[0], out["masks"][0]) and np.abs(Fz @ theta[i] + gz - x[0]).max() < 1e-8
+    # a small capacity overflows and is retried with more room; failed problems do not count
+    m2, c2, f2 = qp.distinct_active_sets_device(torch.from_numpy(np.ascontiguousarray(ref_act(qp, theta[:50000]))).to("cuda:0"),
+                                                capacity=8)
+    assert len(m2) == len(np.unique(ref_act(qp, theta[:50000]), axis=0)) and c2.sum() == 50000
+    # multi-word masks (m = 84 rows: three words) with infeasible points in the batch
+    g3 = load_golden("mass_spring_3in")
+    q3 = _qp_from_golden(lmpc, g3)
+    th3 = torch.from_numpy(np.ascontiguousarray(np.random.default_rng(5).uniform(-4, 4, (60000, 12)))).to("cuda:0")
+    o3 = lmpc.explicit.discover_regions_device(q3, None, None, 0, theta=th3)
+    r3 = lmpc.explicit.discover_regions(q3.solve, th3.cpu().numpy())
+    assert q3.words == 3 and key(o3) == key(r3) and o3["n_solved"] == r3["n_solved"] < 60000
+
+
+def ref_act(qp, theta):
+    return qp.solve(theta)[3].view(np.int64)
