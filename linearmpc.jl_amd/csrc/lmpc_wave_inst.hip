@@ -8,3 +8,15 @@ template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM !=
                                                                 const LMPC_WV_REAL *, LMPC_WV_REAL *, int32_t *,
                                                                 int32_t *, uint64_t *, const uint64_t *, hipStream_t);
 }  // namespace lmpc
+
+#ifdef LMPC_WAVE_TRACE
+// diagnostic build only: per-phase shader-clock sums of THIS translation unit's kernels (see lmpc_wave_kernel.hpp)
+extern "C" int lmpc_debug_wave_trace(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lmpc::g_wave_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lmpc::g_wave_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -48,6 +48,23 @@
 
 namespace lmpc {
 
+// Diagnostic build (-DLMPC_WAVE_TRACE, tools/wave_trace.sh): shader-clock stamps at the phase boundaries of an
+// iteration, summed per phase over all wavefronts into g_wave_trace (read back by lmpc_debug_wave_trace).  The stamps
+// are scalar memory instructions with a wait behind them, so they stretch what they measure; shares, not absolutes.
+#ifdef LMPC_WAVE_TRACE
+__device__ unsigned long long g_wave_trace[16];
+#define WVT_DECL long long wvt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wvt_prev = (long long)clock64()
+#define WVT(k) do { const long long t__ = (long long)clock64(); wvt_acc[k] += t__ - wvt_prev; wvt_prev = t__; } while (0)
+#define WVT_COUNT(k) do { wvt_acc[k] += 1; } while (0)
+#define WVT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 12; q__++) atomicAdd(&g_wave_trace[q__], (unsigned long long)wvt_acc[q__]); } \
+                       for (int q__ = 0; q__ < 12; q__++) wvt_acc[q__] = 0; } while (0)
+#else
+#define WVT_DECL do { } while (0)
+#define WVT(k) do { } while (0)
+#define WVT_COUNT(k) do { } while (0)
+#define WVT_FLUSH do { } while (0)
+#endif
+
 // ---- wave-level helpers, for double and float ---------------------------------------------------
 __device__ __forceinline__ double wv_bcast(double v, int src) {
     // `src` is wave-uniform: two v_readlane_b32
@@ -301,6 +318,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     long long chunk = (long long)blockIdx.x * nwv + wv;
     long long idx = chunk * qchunk;
     int kin = 0, ticket = 0;
+    WVT_DECL;
     while (idx < ntotal) {
         if (queue != nullptr && kin == 0 && lane == 0) ticket = atomicAdd(queue, 1);
         long long pid = idx;
@@ -329,6 +347,12 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     if (t0 + q < nth) b[r] = wv_fma(dv[q], tv[q], b[r]);
             }
         }
+        // the shifted bounds of this lane's rows, once per problem: dupper_j = du_j + b_j, dlower_j = dl_j + b_j
+        // (mpc_update_qp.c:7-8).  They used to be re-formed from a load of du / dl in every iteration's violation test
+        // and in every row append -- two to four global round trips on the critical path of each iteration.
+        R dub[MR], dlb[MR];
+#pragma unroll
+        for (int r = 0; r < MR; r++) { dub[r] = ldc((unsigned)P.odu, jc[r]) + b[r]; dlb[r] = ldc((unsigned)P.odl, jc[r]) + b[r]; }
         // registers of working-set position `lane`
         int WSi = 0, possoft = 0, posimm = 0, poslow = 0;
         R lam = (R)0, ls = (R)0, rhs = (R)0, D = (R)0, Dinv = (R)0, y = (R)0;
@@ -430,11 +454,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             R dnew = na < 64 ? gjj : Gat(j, j);
             if (is_soft) dnew += rho_soft;
             // bound of row j from the slot that owns it
-            R bj = (R)0;
+            R bj = (R)0;                             // the bound of row j that enters: from the slot that owns the row
 #pragma unroll
-            for (int r = 0; r < MR; r++) if (r == (j >> 6)) bj = b[r];
-            bj = wv_bcast(bj, j & 63);
-            const R rj = lower ? -(C[P.odl + j] + bj) : -(C[P.odu + j] + bj);
+            for (int r = 0; r < MR; r++) if (r == (j >> 6)) bj = lower ? dlb[r] : dub[r];
+            const R rj = -wv_bcast(bj, j & 63);
             // two serial chains over the old positions: the new pivot and the new entry of y = L^-1 rhs
             R ynew = rj;
             if constexpr (GRAM) {
@@ -685,8 +708,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         }
 
         // ---- dual active-set iterations
+        WVT(0);
         while (!done) {
             if (iter >= P.iter_limit) { flag = EXIT_ITERLIMIT; break; }
+            WVT_COUNT(10);
             int rm = -1;
             R alpha = (R)0;
             if (sing < 0) {
@@ -696,10 +721,13 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 if (ydirty) {
                     y = sweep_fwd((lane < na) ? rhs : (R)0);
                     ydirty = false;
+                    WVT(1);
                 }
                 const R acc = sweep_bwd(y * Dinv, na - 1);
                 ls = (lane < na) ? acc : (R)0;
+                WVT(2);
                 blocking(false, alpha, rm);
+                WVT(3);
                 if (rm < 0) {
                     if constexpr (!GRAM) primal_step();
                     // objective u'u and the row values M u in one pass over the variables
@@ -776,19 +804,17 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     soft_slack = wv_first(soft);
                     fval = wv_first(fv) + soft_slack;
                     }
+                    WVT(4);
                     if (fval > fbound) { flag = EXIT_INFEASIBLE; break; }
                     R mval = -primal_tol;
                     int midx = -1;
                     bool broken = false;
-                    R bdu[MR], bdl[MR];                  // (clamped row index: loads without a guard around them)
-#pragma unroll
-                    for (int r = 0; r < MR; r++) { bdu[r] = ldc((unsigned)P.odu, jc[r]); bdl[r] = ldc((unsigned)P.odl, jc[r]); }
 #pragma unroll
                     for (int r = 0; r < MR; r++) {
                         const int j = lane + 64 * r;
                         if (j < m && !(sense[r] & SENSE_IMMUTABLE)) {
-                            const R vu = (bdu[r] + b[r]) - Mu[r];
-                            const R vl = -((bdl[r] + b[r]) - Mu[r]);
+                            const R vu = dub[r] - Mu[r];
+                            const R vl = -(dlb[r] - Mu[r]);
                             if (!((actb >> r) & 1u)) {
                                 if (vu < mval) { mval = vu; midx = 2 * j; }
                                 else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
@@ -820,13 +846,16 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     // them (n + 1 + #soft > 64 rows possible, more than 64 wanted at once) is given up
                     if (na >= cap) { flag = EXIT_WSCAP; break; }
                     lam = ls;
+                    WVT(5);
                     ldl_add(midx >> 1, (midx & 1) != 0);
+                    WVT(6);
                     if (fval - best < progress_tol) {
                         if (++cyc > P.cycle_tol) { flag = EXIT_CYCLE; break; }
                     } else { best = fval; cyc = 0; }
                 } else {
                     lam = wv_fma(alpha, ls - lam, lam);
                     ldl_remove(rm);
+                    WVT(7);
                 }
                 }
             } else {
@@ -842,7 +871,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 blocking(true, alpha, rm);
                 if (rm < 0) { flag = EXIT_INFEASIBLE; break; }
                 lam = wv_fma(alpha, ls, lam);
+                WVT(8);
                 ldl_remove(rm);
+                WVT(7);
             }
             iter++;
         }
@@ -926,11 +957,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         } else {
                             for (int k = 0; k < n; k++) Mu = wv_fma(Mr[(size_t)jb * n + k], ubc(k), Mu);
                         }
-                        R bj = (R)0;
+                        R blo = (R)0, bup = (R)0;
 #pragma unroll
-                        for (int r = 0; r < MR; r++) if (r == (jb >> 6)) bj = b[r];
-                        bj = wv_bcast(bj, jb & 63);
-                        const R dlo = C[P.odl + jb] + bj, dup = C[P.odu + jb] + bj;
+                        for (int r = 0; r < MR; r++) if (r == (jb >> 6)) { blo = dlb[r]; bup = dub[r]; }
+                        const R dlo = wv_bcast(blo, jb & 63), dup = wv_bcast(bup, jb & 63);
                         const int lower_first = (wv_first(Mu) - dlo) < (dup - wv_first(Mu)) ? 1 : 0;
                         unsigned long long nup[MR], nlo[MR];
 #pragma unroll
@@ -1013,6 +1043,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             if (flag == EXIT_WSCAP && ovf_list != nullptr) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
         }
         clear_rows(1, na);                       // ZP: the next problem starts on a factor of zeros
+        WVT(9);
+        WVT_COUNT(11);
+        WVT_FLUSH;
         if (++kin < qchunk) {
             idx++;
         } else {
