@@ -178,7 +178,11 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 #ifndef LMPC_WAVE_CHM5
 #define LMPC_WAVE_CHM5 LMPC_WAVE_CHM_BIG
 #endif
-__host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB) {
+#ifndef LMPC_WAVE_LB4G
+#define LMPC_WAVE_LB4G 768     // Gram-scan form at 4 / 5 slots: built for three wavefronts per SIMD (168 registers)
+#endif
+__host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB, bool GRAM = false) {
+    if (GRAM && !BNB && (MR == 4 || MR == 5)) return LMPC_WAVE_LB4G;
     return MR >= 7 ? 256 : (MR >= 5 || BNB) ? 512 : (MR == 4 ? LMPC_WAVE_LB4 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB));
 }
 
@@ -189,7 +193,7 @@ __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB) {
 // the full symmetric Gram matrix (WaveLayout::oGf; LDSC 1 stages THAT) and neither M' nor the packed triangle.
 // Bit-comparable with the oracle's mode 1 (oracle/daqp_ldp_oracle.c "Gram-scan form"), not with mode 0.
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
-__global__ __launch_bounds__(wave_launch_bound(MR, BNB))
+__global__ __launch_bounds__(wave_launch_bound(MR, BNB, GRAM))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,

@@ -35,7 +35,7 @@ inline int wave_slots(int m, bool bnb) {
 inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu, bool gram = false) {
     // Gram-scan form without branch and bound (resource_usage_wave_*_gram.txt): <= 128 VGPRs up to 2 slots, <= 168 at
     // 3 and 4 slots, <= 256 up to 8 slots
-    if (gram && !bnb) return slots <= 2 ? 16 : (slots <= 4 ? 12 : (slots <= 8 ? 8 : 4));
+    if (gram && !bnb) return slots <= 2 ? 16 : (slots <= 5 ? (LMPC_WAVE_LB4G >= 768 || slots == 3 ? 12 : 8) : (slots <= 8 ? 8 : 4));
     if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
     if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
     if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
@@ -59,7 +59,7 @@ inline WaveConfig wave_config_for(const lmpc_handle *h, size_t rs, bool packed) 
     // instantiations with many constraint slots or the B&B state are built for 512-thread workgroups
     // (more registers per lane, fewer resident wavefronts)
     const int slots = wave_slots(h->P.m, h->bnb);
-    const int maxNwv = wave_launch_bound(slots, h->bnb) / 64;          // workgroup size the kernel is built for
+    const int maxNwv = wave_launch_bound(slots, h->bnb, h->waveGram != 0) / 64;   // workgroup size the kernel is built for
     WaveConfig best{1, 0, 1, perWave, packed};
     int bestWaves = -1;
     // packed, and everything beyond 256 rows (256-thread instantiations), is instantiated for levels 0, 1
