@@ -405,11 +405,69 @@ int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, dou
     return rc;
 }
 
+// Scenario-asynchronous closed loop, streaming half (lmpc_simrun_kernel.hpp): every scenario -- first round -- or the
+// scenarios of the round before's list run ahead in registers to their next step that needs iterations; those go on
+// the work list the iterating half (lane kernel or wavefront kernel) consumes.
+int launch_sim_run(lmpc_handle *h, int64_t nprob, const double *theta, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    { const int rc0 = ensure_lists(h, nprob, st); if (rc0 != LMPC_OK) return rc0; }
+    int32_t *cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+    int32_t *cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+    h->countSet ^= 1;
+    h->asyncCntNow = cnt_now; h->asyncCntNext = cnt_next;
+    const long long segCap = lane_seg_cap(nprob);
+    if (!h->dList2) HIP_TRY(h, hipMalloc(&h->dList2, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
+    if (!h->dList3) HIP_TRY(h, hipMalloc(&h->dList3, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
+    int32_t *parkCnt = h->dCount + 2 * (size_t)kShards * kCountStride;
+    // first round: every scenario; later rounds: the scenarios of the round before's list, compacted
+    const int32_t *lin = h->asyncListIn, *cin = h->asyncCntIn;
+    int32_t *lout = (lin == h->dList) ? h->dList2 : h->dList;   // (the parked list as input: the work list is empty)
+    h->asyncListOut = lout;
+    const unsigned grid = lin ? (unsigned)(((h->asyncMaxIn + 255) / 256) * kShards) : (unsigned)((nprob + 255) / 256);
+    const SimFuse &Sf = h->L.sim;
+    const int nthp_ = h->L.nthp;
+    const size_t mp_ = ((size_t)h->P.m + 7) & ~(size_t)7;
+    const size_t ldsr = sizeof(double) * (mp_ * nthp_ + 2 * mp_ + (size_t)kMaxSimU * nthp_ + kMaxSimU + 64 + 8 * kMaxSimU);
+    const bool small_ = h->simSmall && Sf.nx <= 4 && Sf.nu == 1 && h->P.m >= 1 && h->P.m <= 8 && h->P.nth <= 8;
+#define LMPC_SRUN_(NM, NT, SM) hipLaunchKernelGGL((sim_run_kernel<NM, NT, SM>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
+        const_cast<double *>(theta), Sf.kstep, h->asyncT, active, warm != nullptr ? 1 : 0, Sf.utraj, Sf.xtraj_base, \
+        Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt, \
+        h->asyncX, h->asyncR, h->asyncUp)
+#define LMPC_SRUN(NM, NT) do { if constexpr (NT <= 8) { if (small_) LMPC_SRUN_(NM, NT, true); else LMPC_SRUN_(NM, NT, false); } \
+                            else LMPC_SRUN_(NM, NT, false); } while (0)
+    switch (h->P.nth) {
+        case 1: LMPC_SRUN(8, 1); break;    case 2: LMPC_SRUN(8, 2); break;    case 3: LMPC_SRUN(8, 3); break;
+        case 4: LMPC_SRUN(8, 4); break;    case 5: LMPC_SRUN(8, 5); break;    case 6: LMPC_SRUN(8, 6); break;
+        case 7: LMPC_SRUN(8, 7); break;    case 8: LMPC_SRUN(8, 8); break;    case 9: LMPC_SRUN(16, 9); break;
+        case 10: LMPC_SRUN(16, 10); break; case 11: LMPC_SRUN(16, 11); break; case 12: LMPC_SRUN(16, 12); break;
+        case 13: LMPC_SRUN(16, 13); break; case 14: LMPC_SRUN(16, 14); break; case 15: LMPC_SRUN(16, 15); break;
+        case 16: LMPC_SRUN(16, 16); break;
+        default: return fail(h, LMPC_ERR_BADARG, "lmpc: sim_run needs nth <= 16");
+    }
+#undef LMPC_SRUN
+#undef LMPC_SRUN_
+    HIP_TRY(h, hipGetLastError());
+    h->asyncX = h->asyncR = h->asyncUp = nullptr;       // only the first pass forms theta
+    if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
+    return LMPC_OK;
+}
+
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
-    if (h->useWave)
+    if (h->useWave) {
+        // scenario-asynchronous closed loop on the wavefront path: streaming half = sim_run_kernel on the handle's
+        // screening pack, iterating half = the wavefront kernel on that pass's work list (it advances the scenarios
+        // it solves, WaveSim)
+        if (h->asyncPhase == 1) return launch_sim_run(h, nprob, theta, active, warm, st);
+        if (h->asyncPhase == 2) {
+            h->waveList.list = h->asyncListOut; h->waveList.count = h->asyncCntNow; h->waveList.count_next = h->asyncCntNext;
+            h->waveList.seg_cap = lane_seg_cap(nprob);
+            const int rcw = launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
+            h->waveList = WaveList{};
+            return rcw;
+        }
         return wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
                                       : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
+    }
     // block size: the one that keeps most wavefronts resident per CU under the 160 KiB LDS cap
     int bestB = 0, bestWaves = -1;
     size_t bestLds = 0;
@@ -454,45 +512,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         cnt_now = h->asyncCntNow;                  // list and its counters come from the sim_run pass before
         cnt_next = h->asyncCntNext;
     } else if (screened && h->asyncPhase == 1) {   // ... streaming half: sim_run_kernel instead of the screening pass
-        cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
-        cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
-        h->countSet ^= 1;
-        h->asyncCntNow = cnt_now; h->asyncCntNext = cnt_next;
-        const long long segCap = lane_seg_cap(nprob);
-        if (!h->dList2) HIP_TRY(h, hipMalloc(&h->dList2, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
-        if (!h->dList3) HIP_TRY(h, hipMalloc(&h->dList3, sizeof(int32_t) * (size_t)lane_seg_cap(h->listCap) * kShards));
-        int32_t *parkCnt = h->dCount + 2 * (size_t)kShards * kCountStride;
-        // first round: every scenario; later rounds: the scenarios of the round before's list, compacted
-        const int32_t *lin = h->asyncListIn, *cin = h->asyncCntIn;
-        int32_t *lout = (lin == h->dList) ? h->dList2 : h->dList;   // (the parked list as input: the work list is empty)
-        h->asyncListOut = lout;
-        const unsigned grid = lin ? (unsigned)(((h->asyncMaxIn + 255) / 256) * kShards) : (unsigned)((nprob + 255) / 256);
-        const SimFuse &Sf = h->L.sim;
-        const int nthp_ = h->L.nthp;
-        const size_t mp_ = ((size_t)h->P.m + 7) & ~(size_t)7;
-        const size_t ldsr = sizeof(double) * (mp_ * nthp_ + 2 * mp_ + (size_t)kMaxSimU * nthp_ + kMaxSimU + 64 + 8 * kMaxSimU);
-        const bool small_ = h->simSmall && Sf.nx <= 4 && Sf.nu == 1 && h->P.m >= 1 && h->P.m <= 8 && h->P.nth <= 8;
-#define LMPC_SRUN_(NM, NT, SM) hipLaunchKernelGGL((sim_run_kernel<NM, NT, SM>), dim3(grid), dim3(256), ldsr, st, h->L, h->dC, \
-            const_cast<double *>(theta), Sf.kstep, h->asyncT, active, warm != nullptr ? 1 : 0, Sf.utraj, Sf.xtraj_base, \
-            Sf.flag_min, lout, cnt_now, segCap, kShards, (long long)nprob, lin, cin, h->asyncCap, h->dList3, parkCnt, \
-            h->asyncX, h->asyncR, h->asyncUp)
-#define LMPC_SRUN(NM, NT) do { if constexpr (NT <= 8) { if (small_) LMPC_SRUN_(NM, NT, true); else LMPC_SRUN_(NM, NT, false); } \
-                                else LMPC_SRUN_(NM, NT, false); } while (0)
-        switch (h->P.nth) {
-            case 1: LMPC_SRUN(8, 1); break;    case 2: LMPC_SRUN(8, 2); break;    case 3: LMPC_SRUN(8, 3); break;
-            case 4: LMPC_SRUN(8, 4); break;    case 5: LMPC_SRUN(8, 5); break;    case 6: LMPC_SRUN(8, 6); break;
-            case 7: LMPC_SRUN(8, 7); break;    case 8: LMPC_SRUN(8, 8); break;    case 9: LMPC_SRUN(16, 9); break;
-            case 10: LMPC_SRUN(16, 10); break; case 11: LMPC_SRUN(16, 11); break; case 12: LMPC_SRUN(16, 12); break;
-            case 13: LMPC_SRUN(16, 13); break; case 14: LMPC_SRUN(16, 14); break; case 15: LMPC_SRUN(16, 15); break;
-            case 16: LMPC_SRUN(16, 16); break;
-            default: return fail(h, LMPC_ERR_BADARG, "lmpc: sim_run needs nth <= 16");
-        }
-#undef LMPC_SRUN
-#undef LMPC_SRUN_
-        HIP_TRY(h, hipGetLastError());
-        h->asyncX = h->asyncR = h->asyncUp = nullptr;       // only the first pass forms theta
-        if (h->asyncResetPark) HIP_TRY(h, hipMemsetAsync(parkCnt, 0, sizeof(int32_t) * kShards * kCountStride, st));
-        return LMPC_OK;
+        return launch_sim_run(h, nprob, theta, active, warm, st);
     } else if (screened && !sim && warm == nullptr && (!gather || active == nullptr) && fast_covers(h)) {
         // small boxed problems, cold plain solve: ONE kernel streams the batch and solves what needs iterations
         // (lmpc_fast_kernel.hpp); no work list, no second launch
@@ -715,7 +735,18 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     const unsigned grid = (unsigned)((N + 255) / 256);
     // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
     // (the scenario-asynchronous loop forms it in its first streaming pass)
-    const bool asyncLoop = !h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N);
+    // (round 3: also on the wavefront-kernel path -- soft rows, many rows: the same streaming half on the handle's
+    // screening pack, the wavefront kernel as the iterating half; binary64, no branch and bound)
+    const size_t simLds = sizeof(double) * ((((size_t)h->P.m + 7) & ~(size_t)7) * (h->L.nthp + 2) + (size_t)kMaxSimU * h->L.nthp + kMaxSimU + 64 + 8 * kMaxSimU);
+    // It is OPT-IN there ("sim_async" 2): measured on the benchmark class (pendulum N = 50, 2e5 scenarios x 100 steps,
+    // tools/sim_bench.py) the rounds lose to the lock-step loop -- 4.9e8 against 5.3e8 scenario-steps/s from
+    // closed-loop-visited starts, 1.17e9 against 1.31e9 with 90 % of the scenarios at rest: what costs the time is the
+    // wavefront kernel on the transient's problems, which both loops run, and a round adds a launch and a host round
+    // trip where the lock-step loop adds a 25 us screening pass.
+    const bool waveAsync = h->useWave && h->simAsync >= 2 && !h->bnb && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 &&
+                           wave_screens(h, N) && simLds <= 48 * 1024;
+    const bool asyncLoop = waveAsync ||
+                           (!h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N));
     if (!asyncLoop)
         hipLaunchKernelGGL(form_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, x, r, uprev, nx, nr,
                            nuprev, (long long)N);
@@ -738,6 +769,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         h->asyncT = T;
         h->L.sim = SimFuse{h->simFG, h->simTheta, flag_min, nullptr, nx, nu, nr, nuprev, 0, h->simK, U_traj, X_traj,
                            (long long)N};
+        if (h->useWave) h->waveSim = WaveSim{h->simFG, h->simK, U_traj, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N};
         constexpr int kBurst = 2;   // steps a scenario of a (short) work list may run ahead before it is parked
         const size_t setLen = (size_t)kShards * kCountStride;
         std::vector<int32_t> hc(3 * setLen);
@@ -803,6 +835,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         // the last streaming pass queued nothing, so no iterating kernel cleared the other counter set
         if (h->dCount) { hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st); h->countSet = 0; }
         h->L.sim = SimFuse{};
+        h->waveSim = WaveSim{};
         h->prof = prof;
         if (rc != LMPC_OK) return rc;
         hipLaunchKernelGGL(unpack_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, nuprev > 0 ? uprev : nullptr,
@@ -1399,7 +1432,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_blind") == 0) { h->simBlind = value < 0 ? 0 : value; return LMPC_OK; }
-    if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value < 0 ? 0 : (value > 2 ? 2 : value); return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
             return fail(h, LMPC_ERR_BADARG, "lmpc_set_option: lane_block must be 0, 64, 128 or 256");

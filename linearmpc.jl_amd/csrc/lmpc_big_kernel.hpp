@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void big_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S, const R *__restrict__ theta,
     R *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
     const uint64_t *__restrict__ warm, const int32_t *__restrict__ ovf_list, const int32_t *__restrict__ ovf_count,
-    R *__restrict__ scratch_r, int32_t *__restrict__ scratch_i, int cap) {
+    R *__restrict__ scratch_r, int32_t *__restrict__ scratch_i, int cap, const WaveSim sim) {
     const int n = P.n, m = P.m, nth = P.nth;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long long)gridDim.x * blockDim.x;
     const long long total = *ovf_count;
@@ -288,11 +288,37 @@ __global__ __launch_bounds__(64) void big_kernel(
         }
 
         // ---- x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22), flags, working set
+        double xsim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < P.nout; k++) {
             R xs = (R)0, sh = C[P.ox0 + k];
             for (int c = 0; c < n; c++) xs = big_fma<R>(C[P.oRout + (size_t)k * n + c], u[c], xs);
             for (int t = 0; t < nth; t++) sh = big_fma<R>(C[P.oXth + (size_t)k * nth + t], th[t], sh);
-            X[pid * P.nout + k] = xs + sh;
+            const R xk = xs + sh;
+            if (X != nullptr) X[pid * P.nout + k] = xk;
+            if (k < 8) xsim[k] = (double)xk;
+        }
+        if constexpr (sizeof(R) == 8) {
+            if (sim.kstep != nullptr) {          // scenario-asynchronous closed loop: advance in place (WaveSim)
+                const int snx = sim.nx, snu = sim.nu, ks = sim.kstep[pid];
+                double xn[8];
+                for (int a = 0; a < snx; a++) {
+                    double acc = 0.0;
+                    for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[a * snx + c], (double)th[c], acc);
+                    for (int l = 0; l < snu; l++) acc = __builtin_fma(sim.FG[snx * snx + a * snu + l], xsim[l], acc);
+                    xn[a] = acc;
+                }
+                double *to = const_cast<double *>(reinterpret_cast<const double *>(theta)) + pid * nth;
+                for (int a = 0; a < snx; a++) {
+                    to[a] = xn[a];
+                    if (sim.xtraj) sim.xtraj[((long long)(ks + 1) * sim.nscen + pid) * snx + a] = xn[a];
+                }
+                for (int l = 0; l < snu; l++) {
+                    if (l < sim.nup) to[snx + sim.nr + l] = xsim[l];
+                    if (sim.utraj) sim.utraj[((long long)ks * sim.nscen + pid) * snu + l] = xsim[l];
+                }
+                if (sim.flag_min) sim.flag_min[pid] = ks == 0 ? flag : (flag < sim.flag_min[pid] ? flag : sim.flag_min[pid]);
+                sim.kstep[pid] = ks + 1;
+            }
         }
         if (active) {
             uint64_t *ap = active + pid * P.words;
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(64) void big_kernel(
                 ap[bit >> 6] |= 1ull << (bit & 63);
             }
         }
-        exitflag[pid] = flag;
+        if (exitflag != nullptr) exitflag[pid] = flag;
         if (iters) iters[pid] = iter;
     }
 }

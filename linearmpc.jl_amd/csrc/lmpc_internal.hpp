@@ -58,6 +58,7 @@ struct lmpc_handle {
     int waveCap = 0;            // tuning: wavefronts per CU for the wave kernel's grid (0 = 16)
     bool waveQueue = true;      // tuning: dynamic problem queue of the wave kernel (0 = static split)
     lmpc::WaveList waveList{};  // set around a launch that follows the screening pass
+    lmpc::WaveSim waveSim{};    // scenario-asynchronous closed loop on the wavefront path (kstep == nullptr: off)
     int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
     bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void sim_run_kernel(
     for (int i = tid; i < mp * NTHMAX; i += blockDim.x) sD[i] = i < m * NTHMAX ? C[P.oDthP + i] : 0.0;
     for (int i = tid; i < 2 * mp; i += blockDim.x) {
         const int j = i >> 1;
-        const bool live = j < m && !((P.imm_mask >> j) & 1ull);
+        // (imm_mask covers the first 64 rows; a wavefront-kernel handle's screening pack has the never-violated
+        // bounds of its IMMUTABLE rows written in already, whatever their index)
+        const bool live = j < m && !(j < 64 && ((P.imm_mask >> j) & 1ull));
         sBnd[i] = live ? C[P.oBnd + i] : ((i & 1) ? -1e300 : 1e300);
     }
     for (int i = tid; i < kMaxSimU * NTHMAX; i += blockDim.x) sXth[i] = i < nu * NTHMAX ? C[P.oXthP + i] : 0.0;

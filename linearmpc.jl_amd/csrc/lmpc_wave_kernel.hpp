@@ -200,7 +200,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
     int32_t *__restrict__ queue, int qchunk, long long nprob,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
-    long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count) {
+    long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -1012,10 +1012,35 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 for (int q = 0; q < CH; q++)
                     if (c0 + q < n) xs = wv_fma(rv[q], ubc(c0 + q), xs);
             }
+            R xo = (R)0;
             if (ko < P.nout) {
                 R sh = ldc((unsigned)P.ox0, (unsigned)ko);
                 for (int t = 0; t < nth; t++) sh = wv_fma(ldc((unsigned)(P.oXth + t), (unsigned)ko * (unsigned)nth), th[t], sh);
-                (X + pid * P.nout)[(unsigned)ko] = xs + sh;
+                xo = xs + sh;
+                if (X != nullptr) (X + pid * P.nout)[(unsigned)ko] = xo;
+            }
+            if constexpr (sizeof(R) == 8 && !BNB) {
+                // scenario-asynchronous closed loop: advance this scenario in place (WaveSim; lane a < nx forms x+_a,
+                // lane l < nu holds u_l).  A point handed to the slow path is advanced there, after its re-solve.
+                if (o0 == 0 && sim.kstep != nullptr && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
+                    const int snx = sim.nx, snu = sim.nu;
+                    const int k = sim.kstep[pid];
+                    const int ar = lane < snx ? lane : 0;
+                    double acc = 0.0;
+                    for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[ar * snx + c], (double)th[c], acc);
+                    for (int l = 0; l < snu; l++) acc = __builtin_fma(sim.FG[snx * snx + ar * snu + l], (double)wv_bcast(xo, l), acc);
+                    double *to = const_cast<double *>(reinterpret_cast<const double *>(theta)) + pid * nth;
+                    if (lane < snx) {
+                        to[lane] = acc;
+                        if (sim.xtraj) sim.xtraj[((long long)(k + 1) * sim.nscen + pid) * snx + lane] = acc;
+                    }
+                    if (lane < sim.nup) to[snx + sim.nr + lane] = (double)xo;
+                    if (lane < snu && sim.utraj) sim.utraj[((long long)k * sim.nscen + pid) * snu + lane] = (double)xo;
+                    if (lane == 0) {
+                        if (sim.flag_min) sim.flag_min[pid] = k == 0 ? flag : (flag < sim.flag_min[pid] ? flag : sim.flag_min[pid]);
+                        sim.kstep[pid] = k + 1;
+                    }
+                }
             }
         }
         if (active) {
@@ -1040,7 +1065,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     if (q < P.words) active[pid * P.words + q] = wd[q];
         }
         if (lane == 0) {
-            exitflag[pid] = flag;
+            if (exitflag != nullptr) exitflag[pid] = flag;
             if (iters) iters[pid] = iter;
             // a working set that outgrew the 64 lanes: queued for the one-problem-per-thread kernel behind this one
             // (lmpc_big_kernel.hpp), which overwrites the outputs of this problem

@@ -145,11 +145,11 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
                        iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
-                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr);
+                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr, h->waveSim);
     HIP_TRY(h, hipGetLastError());
     if (big) {
         hipLaunchKernelGGL(big_kernel<R>, dim3(kBigThreads / 64), dim3(64), 0, st, Wl, dC, h->dSw, theta, x, flag, iters,
-                           active, warm, h->dOvfList, h->dOvfCount, static_cast<R *>(h->dBigR), h->dBigI, bigCap);
+                           active, warm, h->dOvfList, h->dOvfCount, static_cast<R *>(h->dBigR), h->dBigI, bigCap, h->waveSim);
         HIP_TRY(h, hipGetLastError());
     }
     return LMPC_OK;

@@ -49,6 +49,19 @@ struct PackLayout {
     GatherArgs gat;
 };
 
+// Scenario-asynchronous closed loop on the wavefront-kernel path (lmpc_simulate*, kstep != nullptr): the kernel that
+// solves a listed scenario's step also advances the scenario IN PLACE -- x+ = F x + G u (sums in the oracle's order,
+// F then G), theta <- [x+; r; u], its step counter + 1, trajectories at the scenario's own step -- exactly what
+// sim_advance does on the lane path (lmpc_lane_kernel.hpp).  Binary64 only.
+struct WaveSim {
+    const double *FG;            // F (nx*nx) then G (nx*nu), row-major
+    int *kstep;                  // per-scenario step counters; nullptr = off
+    double *utraj, *xtraj;       // (T, N, nu) / (T + 1, N, nx) or nullptr
+    int *flag_min;               // smallest exit flag over the steps so far, or nullptr
+    int nx, nu, nr, nup;
+    long long nscen;
+};
+
 struct WaveLayout {
     int n, m, ms, nth, nout, words;
     int cap, ldc;                                   // working-set capacity, leading dim of L

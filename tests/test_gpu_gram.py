@@ -194,3 +194,41 @@ def test_gram_form_closed_loop(lmpc):
         out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
         assert np.array_equal(out["flag_min"], ref["flag_min"])
         assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])
+
+
+@pytest.mark.parametrize("name,gram", [("pendulum_N50", 0), ("pendulum_N50", 1), ("soft_doc", 0), ("soft_doc", 1)])
+def test_wave_path_closed_loop_asynchronous_rounds(lmpc, name, gram):
+    """Closed loop on the wavefront-kernel path (soft rows): scenario-asynchronous rounds (round 3) against the
+    lock-step loop and the oracle's closed loop, bit for bit -- trajectories, final states, smallest flags; warm and
+    cold; in both forms of the kernel (the oracle's mode follows the form)."""
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_option("gram_scan", gram)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(17)
+    if name == "soft_doc":
+        prob = omm.doc_simple_soft()
+        F, G = prob.F, prob.G
+        N, T = 3000, 25
+        x0 = rng.uniform(-0.2, 0.7, (N, 2)); x0[0] = 0.0
+        r = np.tile([1.0, 0.0], (N, 1)); r[N // 2:] = [0.3, 0.0]
+    else:
+        F, G = g["F"], g["G"]
+        N, T = 4000, 40
+        base = g["theta"][:int(g["n_closed_loop"])]
+        pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+        x0, r = pick[:, :4].copy(), pick[:, 4:6].copy()
+    so = _gram_settings() if gram else oldp.default_settings()
+    for warm in (True, False):
+        ref = oldp.simulate(L, x0, T, F, G, r=r, warm=warm, settings=so)
+        outs = []
+        for asyn in (2, 0):                        # 2: asynchronous rounds on the wavefront-kernel path too
+            qp.set_option("sim_async", asyn)
+            outs.append(qp.simulate(x0, T, F, G, r=r, warm=warm))
+        for out in outs:
+            assert np.array_equal(out["flag_min"], ref["flag_min"])
+            assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])
+            assert np.array_equal(out["x"], ref["x"])
+        assert (ref["flag_min"] >= 1).mean() > 0.5

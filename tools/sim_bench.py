@@ -15,7 +15,7 @@ ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warm", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1) or lock-step (0)")
+ap.add_argument("--async", dest="asyn", type=int, default=1, help="scenario-asynchronous closed loop (1; 2 = also on the wavefront-kernel path) or lock-step (0)")
 ap.add_argument("--blind", type=int, default=-1, help="rounds enqueued between two counter reads (library default if < 0)")
 ap.add_argument("--traj", type=int, default=0, help="also record the U (T x N x nu) and X ((T+1) x N x nx) trajectories")
 ap.add_argument("--small", type=int, default=1, help="all-in-registers streaming kernel (1) or the general one (0)")
@@ -27,6 +27,8 @@ ap.add_argument("--problem", default="pendulum",
                 help="golden fixture: pendulum (lane kernels) or pendulum_N50/75/100/125 (long horizon with state "
                      "constraints: wavefront kernel, lock-step loop)")
 ap.add_argument("--screen-wave", type=int, default=1, help="screening pass in front of the wavefront kernel")
+ap.add_argument("--settled", type=float, default=0.0, help="fraction of the scenarios that start at rest on their reference (no step of theirs needs iterations)")
+ap.add_argument("--gram", type=int, default=0, help="wavefront kernel: Gram-scan form (lmpc_set_option gram_scan)")
 a = ap.parse_args()
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", a.problem + ".npz")))
 sys.path.insert(0, ROOT)
@@ -39,6 +41,7 @@ qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["
 print("kernel:", qp.kernel_name)
 if qp.kernel_name == "wave":
     qp.set_option("screen_wave", a.screen_wave)
+    qp.set_option("gram_scan", a.gram)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
 qp.set_option("sim_small", a.small)
@@ -50,6 +53,9 @@ dev = torch.device("cuda", 0)
 if "n_closed_loop" in g:      # the benchmark class: start from points one closed loop visits, perturbed
     base = g["theta"][:int(g["n_closed_loop"])]
     pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+    if a.settled > 0:
+        ns = int(a.settled * N)
+        pick[:ns, :4] = 0.0; pick[:ns, 4:6] = 0.0; pick[:ns, 6] = 0.0
     x0 = torch.from_numpy(np.ascontiguousarray(pick[:, :4])).to(dev)
     r = torch.from_numpy(np.ascontiguousarray(pick[:, 4:6])).to(dev)
     up0 = torch.from_numpy(np.ascontiguousarray(pick[:, 6:7])).to(dev)
