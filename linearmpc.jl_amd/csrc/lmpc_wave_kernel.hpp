@@ -117,7 +117,7 @@ template <typename V> __device__ __forceinline__ V wv_min(V v) {
 }
 
 // pairwise sum over the 64 lanes, returned wave-uniform: neighbours, pairs of pairs, ... inside the 16-lane rows,
-// then (row0 + row1) + (row2 + row3) -- the order the CPU twin's tree64 restates (oracle/daqp_ldp_oracle.c)
+// then (row0 + row1) + (row2 + row3) -- the order the CPU checker restates (its tree64, mode 1)
 template <typename V> __device__ __forceinline__ V wv_sum(V v) {
     v = v + wv_dpp<0xB1>(v);
     v = v + wv_dpp<0x4E>(v);
@@ -191,7 +191,7 @@ __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB, bool GRAM 
 // formed once, when the solve ends), the dual objective as sum_i y_i z_i from the factorisation, and the two dot
 // products of a row append plus the soft slack as pairwise lane trees (wv_sum) instead of serial chains.  It reads
 // the full symmetric Gram matrix (WaveLayout::oGf; LDSC 1 stages THAT) and neither M' nor the packed triangle.
-// Bit-comparable with the oracle's mode 1 (oracle/daqp_ldp_oracle.c "Gram-scan form"), not with mode 0.
+// Bit-comparable with the CPU checker in its mode 1 ("Gram-scan form"), not with mode 0.
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
 __global__ __launch_bounds__(wave_launch_bound(MR, BNB, GRAM))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(

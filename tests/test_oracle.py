@@ -584,3 +584,38 @@ def test_soft_rows_equal_the_explicit_slack_qp(name):
         Xw, efw, _, _ = oldp.solve_batch(L, th)
         Us, efs = mk.solve_soft(g, th, 1e-3)
         assert np.abs(Xw - Us)[(efw >= 1) & (efs == 2)].max() > 1e-3
+
+
+@pytest.mark.parametrize("name,xtol", [("pendulum", 1e-10), ("mass_spring", 1e-10), ("mass_spring_3in", 1e-9),
+                                       ("preprocessing_kat", 1e-10), ("soft_doc", 1e-4), ("pendulum_N75", 1e-4),
+                                       ("x0unc_kat", 1e-6)])
+def test_gram_scan_twin_takes_the_same_decisions(name, xtol):
+    """The oracle's mode 1 (the checker of the wavefront kernel's Gram-scan form: row values from Gram columns, dual
+    objective from the factorisation, pairwise 64-leaf trees for the append's dot products) against mode 0 (the
+    n-chain form, what libdaqp does per iteration) on the committed fixtures: on every solvable point the same exit
+    flag, iteration count and final active set, x to rounding (the 1 / rho_soft penalty amplifies it on SOFT rows);
+    and mode 1 reproduces the committed answers like mode 0 does.  On infeasible, nearly dependent problems the two
+    forms may end with different FAILURE flags (-1 / -2: the guard against a broken working set looks at different
+    roundings), never on different sides of 'solved'."""
+    g = load_golden(name)
+    L = oracle_ldp_from(g) if "M" in g else oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"],
+                                                         g["senses"], nout=int(g["nu"]))
+    th = np.asarray(g["theta"], float)[:1500]
+    s0, s1 = oldp.default_settings(), oldp.default_settings()
+    s1.mode = 1
+    X0, e0, i0, a0 = oldp.solve_batch(L, th, s0)
+    X1, e1, i1, a1 = oldp.solve_batch(L, th, s1)
+    ok = e0 >= 1
+    assert np.array_equal(ok, e1 >= 1)
+    assert np.array_equal(e0[ok], e1[ok]) and np.array_equal(i0[ok], i1[ok]) and np.array_equal(a0[ok], a1[ok])
+    assert np.abs(X0[ok] - X1[ok]).max() <= xtol
+    assert set(np.unique(e1[~ok])) <= {-1, -2}
+    assert np.array_equal(e1[ok], np.asarray(g["exitflag"])[:1500][ok])
+    # warm start from the final sets: the same sets come back in one iteration-equivalent
+    Xw, ew, iw, aw = oldp.solve_batch(L, th[ok][:200], s1, warm=a1[ok][:200])
+    assert np.array_equal(ew, e1[ok][:200]) and np.array_equal(aw, a1[ok][:200])
+    # binary32 build of the same mode
+    s32 = oldp.default_settings_f32(); s32.mode = 1
+    Xf, ef, _, _ = oldp.solve_batch(L, th[:300].astype(np.float32), s32, dtype=np.float32)
+    Xc, ec, _, _ = oldp.solve_batch(L, th[:300].astype(np.float32), oldp.default_settings_f32(), dtype=np.float32)
+    assert Xf.dtype == np.float32 and ((ef >= 1) == (ec >= 1)).mean() > 0.9
