@@ -1417,6 +1417,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "fast_tiles") == 0) { h->fastTiles = value < 0 ? 0 : (value > 256 ? 256 : value); return LMPC_OK; }
     if (std::strcmp(name, "fast_nstr") == 0) { h->fastNstr = value; return LMPC_OK; }
     if (std::strcmp(name, "fast_dma") == 0) { h->fastDma = value; return LMPC_OK; }
+    if (std::strcmp(name, "fast_dyn") == 0) { h->fastDyn = value; return LMPC_OK; }
     if (std::strcmp(name, "in_flight") == 0) {
         // hint: how many independent batches the caller keeps in flight on this GPU (one handle and stream each).
         // From two on a call no longer owns the chip: the one-launch kernel then runs with all four wavefronts of
@@ -1482,7 +1483,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable);
+    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);

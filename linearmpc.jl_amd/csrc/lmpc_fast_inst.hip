@@ -45,6 +45,14 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     if (Rl > ntiles) Rl = ntiles > 0 ? ntiles : 1;
     const int R = (int)Rl;
     const unsigned grid = (unsigned)((ntiles + R - 1) / R);
+    // static share + dynamic tail ("fast_dyn": tiles per workgroup handed out through global tickets instead of owned;
+    // the queue then needs room for Rs + Dcap tiles).  OFF by default: it levels the streams' ends across the XCDs as
+    // intended (tools/fast_trace_cu.py: all eight XCDs within 0.5 us of each other instead of up to 4 us apart) but the
+    // levelled end is 1.3 us LATER than the static split's median, and a call takes 23.25 us instead of 22.2
+    // (tools/hot_ab.py, same box) -- the tickets' device-scope atomics cost what the levelling saves.
+    int D = GATHER ? 0 : (h->fastDyn >= 0 ? h->fastDyn : 0);
+    if (R < 12 || nprob >= (int64_t)0x7fffff00 || D >= R) D = 0;
+    const int Rs = R - D, Dcap = 3 * D, Rq = D ? Rs + Dcap + 1 : R;      // (+ 1: the batch's partial tile, first workgroup)
     // streaming wavefronts take their records by LDS-DMA into a ring of dk tile slots each ("fast_dma": 0 = through
     // registers, 2 / 3 = ring depth; default LMPC_FAST_DMA_DEPTH); the generated controller's gather stays on registers
     // (default: a ring of two tiles with three streaming wavefronts; with four of them -- the shape for several batches
@@ -52,7 +60,17 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     int dk = GATHER ? 0 : (h->fastDma >= 0 ? h->fastDma : (nstr <= 3 ? LMPC_FAST_DMA_DEPTH : 0));
     if (dk == 1 || dk > 3) dk = dk == 1 ? 0 : 3;
     if (nprob * (int64_t)NT * 8 < 16) dk = 0;
-    const size_t lds = dk ? fast_lds_bytes_dma(N, R, NTHMAX, NT, nstr, dk) : fast_lds_bytes(N, R, NTHMAX);
+    const size_t lds = dk ? fast_lds_bytes_dma(N, Rq, NTHMAX, NT, nstr, dk) : fast_lds_bytes(N, Rq, NTHMAX);
+    int32_t *ctrNow = nullptr, *ctrNext = nullptr;
+    if (D) {
+        if (!h->dFastCtr) {
+            HIP_TRY(h, hipMalloc(&h->dFastCtr, sizeof(int32_t) * 2 * kFastCtrs * 32));
+            HIP_TRY(h, hipMemsetAsync(h->dFastCtr, 0, sizeof(int32_t) * 2 * kFastCtrs * 32, st));
+        }
+        ctrNow = h->dFastCtr + (size_t)h->fastCtrSet * kFastCtrs * 32;
+        ctrNext = h->dFastCtr + (size_t)(h->fastCtrSet ^ 1) * kFastCtrs * 32;
+        h->fastCtrSet ^= 1;
+    }
     auto kern = fast_kernel<NTHMAX, NT, N, GATHER>;
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -73,8 +91,8 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
 #endif
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, h->L, h->dC, theta, x, flag, iters,
-                       active, (long long)nprob, R, nstr, h->dFastErr, h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit,
-                       dk);
+                       active, (long long)nprob, Rq, nstr, h->dFastErr, h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit,
+                       dk, Rs, Dcap, ctrNow, ctrNext);
     HIP_TRY(h, hipGetLastError());
 #ifdef LMPC_FAST_TRACE
     if (const char *f = std::getenv("LMPC_FAST_TRACE_FILE")) {

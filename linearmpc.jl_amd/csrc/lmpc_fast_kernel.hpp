@@ -39,6 +39,7 @@ namespace lmpc {
 #define LMPC_FAST_WAVES 3      // wavefronts per SIMD the kernel is register-budgeted for (lane_loop sets the need)
 #endif
 constexpr int kFastSpinLimit = 1 << 22;
+constexpr int kFastCtrs = 16;              // ticket counters of the dynamic tail (a power of two)
 constexpr int kFastMaxTiles = 96;          // tiles of 64 problems per workgroup at most (LDS queue: 256 bytes per tile)
 #ifndef LMPC_FAST_AHEAD
 #define LMPC_FAST_AHEAD 1
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit,
-    int dk) {
+    int dk, int Rs, int Dcap, int32_t *__restrict__ tctr, int32_t *__restrict__ tctr_next) {
     constexpr int KMAX = LMPC_FAST_KMAX < N ? LMPC_FAST_KMAX : N;
     constexpr int nconst = N * N + N * (N + 1) / 2 + 2 * N;
     extern __shared__ __align__(16) double lds[];
@@ -135,8 +136,20 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
 #define LMPC_TRC(i) do { } while (0)
 #endif
     LMPC_TRC(0);
-    const long long t0 = (long long)blockIdx.x * R;
-    const long long t1 = t0 + R < ntiles ? t0 + R : ntiles;
+    // Static share + dynamic tail (round 3, tctr != nullptr).  Streams end 12 - 16 us after the launch depending on
+    // the XCD a workgroup landed on (tools/fast_trace_cu.py: per-XCD means 11.7 ... 16.4 us in one call, different
+    // XCDs slow from batch to batch), and the kernel ends one solving pass after the LAST of them.  A workgroup
+    // therefore owns only Rs of its R tiles; the batch's remaining tiles [nstat, ntiles) are handed out one at a time
+    // through kFastCtrs global counters (tile = nstat + ticket * kFastCtrs + counter; 128 bytes apart, ~190 tickets
+    // each) to the streaming wavefronts that finish their share early.  Tickets are drawn while the previous tile is
+    // processed; a workgroup takes at most Dcap of them (its LDS queue has room for Rs + Dcap tiles).  The counter
+    // set of the NEXT launch on this handle is cleared here (two sets alternate: no memset in front of the kernel).
+    const bool dyn = tctr != nullptr;
+    const long long nstat = dyn ? ((long long)gridDim.x * Rs < ntiles ? (long long)gridDim.x * Rs : ntiles) : ntiles;
+    if (dyn && blockIdx.x == 0 && tid < kFastCtrs) tctr_next[tid * 32] = 0;
+    const long long t0 = (long long)blockIdx.x * (dyn ? Rs : R);
+    const long long t1 = t0 + (dyn ? Rs : R) < nstat ? t0 + (dyn ? Rs : R) : nstat;
+    const long long base0 = dyn ? 0 : t0 * 64;               // queue entries are problem indices relative to this
 
     auto load_record = [&](long long pid, double *dst) {
         const long long pc = pid < nprob ? pid : nprob - 1;
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                         pay[N] = sh;
                     }
                     // (release: the payload is in LDS before the index that announces it)
-                    __hip_atomic_store(&ring[pos], (int32_t)(pid - t0 * 64), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&ring[pos], (int32_t)(pid - base0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             if (valid && !hard) {
@@ -350,6 +363,60 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                     if (p + 1 < PIECES || LASTB == 1024u || lane * 16 < (int)LASTB) fast_dma16(src + p * 1024, dst);
                 }
             };
+            // ticket of the dynamic tail (see `dyn` above; the lambda is shared with the register path's loop below)
+            int cc = (int)((blockIdx.x * (unsigned)nstr + (unsigned)role) & (kFastCtrs - 1));
+            auto take = [&]() -> long long {
+                int t = -1;
+                if (lane == 0) {
+                    if (__hip_atomic_fetch_add(&ctrl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < Dcap)
+                        t = atomicAdd(&tctr[cc * 32], 1);
+                }
+                t = __builtin_amdgcn_readfirstlane(t);
+                const long long tile = nstat + (long long)t * kFastCtrs + cc;
+                return (t >= 0 && tile < ntiles) ? tile : -1;
+            };
+            if (dk == 2) {
+                // Two-slot pipeline over "this wavefront's static tiles, then tickets": while tile `cur` is screened the
+                // pieces of `nxt` are in flight and -- in the dynamic tail -- the ticket for the tile after it is being
+                // drawn (one returning atomic: a vector-memory operation like the pieces, counted with them below).
+                // Whole tiles only (the ticket range ends at tfull): the batch's partial tile is handled behind the loop.
+                long long sidx = t0 + role, tk = -1;
+                bool drew = false;                                           // a ticket's atomic was issued in this iteration
+                auto take_full = [&]() -> long long { const long long t = take(); return t < tfull ? t : -1; };
+                if (dyn && sidx >= te) tk = take_full();
+                auto peek = [&]() -> long long { return sidx < te ? sidx : (dyn ? tk : -1); };
+                auto advance = [&]() {                                       // hand the peeked tile out; prefetch behind it
+                    drew = false;
+                    if (sidx < te) { sidx += nstr; if (dyn && sidx >= te) { tk = take_full(); drew = true; } }
+                    else if (dyn && tk >= 0) { tk = take_full(); drew = true; }
+                };
+                long long cur = peek();
+                int sc = 0;
+                if (cur >= 0) { issue(cur, 0); advance(); }
+                // (the prologue's atomic, if any, is older than everything the loop counts: harmless)
+                while (cur >= 0) {
+                    const long long nxt = peek();
+                    const bool nd = nxt >= 0;
+                    if (nd) { issue(nxt, sc ^ 1); advance(); } else drew = false;
+                    // all but the youngest operations: the pieces of `nxt` (if requested) and this iteration's ticket
+                    if (nd && drew) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES + 1) : "memory");
+                    else if (nd) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PIECES) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const double *rec = reinterpret_cast<const double *>(dring + (size_t)sc * TB) + lane * NT;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) buf[0][t] = rec[t];
+                    process(cur, buf[0], true);
+                    cur = nxt;
+                    sc ^= 1;
+                }
+                // the batch's last, partial tile: its static owner, or (dynamic tail) the first workgroup's first streamer
+                const long long part = dyn ? ((blockIdx.x == 0 && role == 0 && tfull < ntiles) ? tfull : -1)
+                                           : ((sidx < t1 && sidx == tfull) ? tfull : -1);
+                if (part >= 0) {
+                    load_record(part * 64 + lane, buf[0]);
+                    process(part, buf[0], true);
+                }
+            } else {
             const long long first = t0 + role;
             long long ahead = first;                                         // next tile to request
             int sa = 0;                                                      // ... and its slot
@@ -373,6 +440,16 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                 load_record(tile * 64 + lane, buf[0]);
                 process(tile, buf[0], true);
             }
+            if (dyn) {                                                       // deeper rings: the tail one tile at a time
+                long long tl = take();
+                while (tl >= 0) {
+                    load_record(tl * 64 + lane, buf[0]);
+                    const long long nx = take();
+                    process(tl, buf[0], true);
+                    tl = nx;
+                }
+            }
+            }
         } else
         for (long long base = t0 + role; base < t1; base += (long long)kFastAhead * nstr) {
 #pragma unroll
@@ -387,6 +464,27 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             }
         }
 #endif
+        if (dyn && !(!GATHER && dk >= 2)) {
+            // dynamic tail (register path): one tile per ticket, the next ticket in flight while this tile is screened
+            int cc = (int)((blockIdx.x * (unsigned)nstr + (unsigned)role) & (kFastCtrs - 1));
+            auto take = [&]() -> long long {
+                int t = -1;
+                if (lane == 0) {
+                    if (__hip_atomic_fetch_add(&ctrl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < Dcap)
+                        t = atomicAdd(&tctr[cc * 32], 1);
+                }
+                t = __builtin_amdgcn_readfirstlane(t);
+                const long long tile = nstat + (long long)t * kFastCtrs + cc;
+                return (t >= 0 && tile < ntiles) ? tile : -1;
+            };
+            long long tile = take();
+            while (tile >= 0) {
+                load_record(tile * 64 + lane, buf[0]);
+                const long long nxt = take();
+                process(tile, buf[0], true);
+                tile = nxt;
+            }
+        }
         // all of this wavefront's reservations are in the LDS queue ahead of this add (LDS keeps a wave's order)
         if (lane == 0) __hip_atomic_fetch_add(&ctrl[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         LMPC_TRC(1);
@@ -440,7 +538,7 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
             if (lane == 0 && errflag) __hip_atomic_store(errflag, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
-        const long long pid = mine ? t0 * 64 + rel : t0 * 64;
+        const long long pid = mine ? base0 + rel : base0;
         double b[N], u[N];
         double sh0 = C[P.ox0];                                 // x0 + Xth theta of the first output (kept: 2 registers)
         const bool handed = start + lane < kFastPay;           // shifts handed over in LDS by the streaming wavefront
@@ -522,7 +620,9 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
     }
     LMPC_TRC(6);
 #ifdef LMPC_FAST_TRACE
-    if (lane == 0) trc[7] = npass;
+    // (+ where the wavefront ran: HW_REG_HW_ID (4) and HW_REG_XCC_ID (20), for per-CU / per-XCD statistics)
+    if (lane == 0) trc[7] = (long long)npass | ((long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16) |
+                            ((long long)((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xffu) << 48);
 #endif
 #undef LMPC_TRC
 }

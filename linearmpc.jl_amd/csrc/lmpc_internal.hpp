@@ -81,6 +81,9 @@ struct lmpc_handle {
     int fastPath = 1;           // tuning: one-launch kernel for small boxed problems ("fast", lmpc_fast_kernel.hpp)
     int fastTiles = 0;          // tuning: tiles of 64 problems per workgroup of that kernel (0 = 24)
     int fastNstr = 0;           // tuning: streaming wavefronts per workgroup of that kernel, 1..4 (0 = 3)
+    int fastDyn = -1;           // tuning: tiles per workgroup of that kernel handed out through global tickets (-1 = default 4)
+    int32_t *dFastCtr = nullptr;   // ... their counters: two alternating sets of kFastCtrs, 128 bytes apart
+    int fastCtrSet = 0;
     int fastDma = -1;           // tuning: LDS-DMA ring depth of its streaming wavefronts (-1 = default, 0 = registers, 2, 3)
     int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected):
     volatile int32_t *hFastErr = nullptr;   // ... a word of pinned host memory, dFastErr its device address
