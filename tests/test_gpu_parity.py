@@ -2104,3 +2104,28 @@ def test_region_discovery_device_pipeline(lmpc):
 
 def ref_act(qp, theta):
     return qp.solve(theta)[3].view(np.int64)
+
+
+@pytest.mark.parametrize("opts", [{"fast_dyn": 4}, {"fast_dyn": 6, "fast_dma": 0}, {"fast_dyn": 3, "fast_dma": 3},
+                                  {"fast_dma": 0}, {"fast_dma": 3}, {"fast_dyn": 4, "fast_nstr": 4, "fast_tiles": 28}])
+def test_one_launch_kernel_record_paths_and_dynamic_tail(lmpc, opts):
+    """The one-launch kernel's ways of taking its records -- through registers, by LDS-DMA into a ring of two or three
+    tiles -- and of splitting the batch -- static, or a static share plus a dynamic tail of tiles handed out through
+    global tickets -- change the execution order only: every combination gives the oracle's bits, at batch sizes
+    with and without a partial last tile and with fewer tiles than workgroups could hold."""
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    for k, v in opts.items():
+        qp.set_option(k, v)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(44)
+    for N in (63, 64, 1000, 30011, 400_000, 1_000_003):
+        theta = np.hstack([rng.uniform(-9, 9, (N, 4)), rng.uniform(-9, 9, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+        x, ef, it, act = qp.solve(theta)
+        sel = np.arange(N) if N <= 30011 else np.concatenate([np.arange(3000), np.arange(N - 3000, N), rng.integers(0, N, 6000)])
+        xo, efo, ito, acto = oldp.solve_batch(L, theta[sel])
+        assert np.array_equal(x[sel], xo) and np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito)
+        assert np.array_equal(act[sel], acto)
+        assert (ef >= 1).all()
+    qp.check()
