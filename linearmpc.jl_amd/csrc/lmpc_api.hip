@@ -30,7 +30,8 @@ hipError_t pool_event(lmpc_handle *h, hipEvent_t *e) {
 }
 
 int fail(lmpc_handle *h, int code, const std::string &msg) {
-    if (h) h->err = msg; else g_setup_err = msg;
+    if (h) { std::lock_guard<std::mutex> lk(h->errMu); h->err = msg; }
+    else g_setup_err = msg;
     return code;
 }
 

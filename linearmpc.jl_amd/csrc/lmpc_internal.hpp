@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,9 @@ struct lmpc_handle {
     double *dC = nullptr;       // constant pack on the GPU
     size_t nC = 0;
     std::string err, kname;
+    std::mutex errMu;           // `err` is written through fail() only: the host pipeline's upload thread and the caller's
+                                // thread can both fail on one handle; everything else of a handle is
+                                // single-caller state -- one thread at a time per handle, as for a DAQP workspace
     // staging for the host-pointer entry point
     double *sTheta = nullptr, *sX = nullptr;
     int32_t *sFlag = nullptr, *sIter = nullptr;
