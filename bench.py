@@ -503,6 +503,30 @@ def region_discovery_config(torch, lmpc, dev, local_rank, nsamples, want_cpu, re
     return res
 
 
+def multi_abi_isolated(torch, n_per_dev, timeout_s=180):
+    """multi_abi_check in a CHILD process (`bench.py --multi-abi-only N`): the nd > 1 branch of the library has never
+    run on hardware, so whatever it does the first time -- raise, hang, crash inside librccl -- must not take the
+    bench line with it.  One visible GPU: answered here, no child."""
+    import subprocess
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        return {"n_devices": nd,
+                "skipped": "one visible GPU: the nd > 1 branch (ncclCommInitAll, ncclSend/ncclRecv) cannot run here"}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-abi-only", str(int(n_per_dev))],
+                           capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                res = json.loads(line)
+                res["isolated"] = f"child process, exit code {r.returncode}"
+                return res
+        return {"n_devices": nd, "error": f"child process exit code {r.returncode}, no result line; stderr tail: {r.stderr[-400:]}"}
+    except subprocess.TimeoutExpired:
+        return {"n_devices": nd, "error": f"child process still running after {timeout_s} s (killed)"}
+    except Exception as e:
+        return {"n_devices": nd, "error": f"{type(e).__name__}: {e}"}
+
+
 def _forms_agreement(xa, fa, xb, fb):
     ok = fa >= 1
     both = ok & (fb >= 1)
@@ -618,6 +642,10 @@ def main():
     ap.add_argument("--wave-level", type=int, default=-1, help="wave kernel: LDS staging level 0..3 (tuning)")
     ap.add_argument("--wave-nwv", type=int, default=0, help="wave kernel: wavefronts per workgroup (tuning)")
     ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning)")
+    ap.add_argument("--multi-abi-only", type=int, default=0, metavar="N_PER_DEVICE",
+                    help="run only the one-process multi-device entry-point check (lmpc_solve_batch_multi_device over every "
+                         "visible GPU) and print its result as one JSON line; what the bench line's config.multi_abi runs "
+                         "in a child process")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="lmpc_set_option(NAME, VALUE) on every handle of the headline workload (recorded in config.options)")
     ap.add_argument("--streams", type=int, default=3,
@@ -628,6 +656,9 @@ def main():
     import torch.distributed as dist
     import linearmpc_jl_amd as lmpc
 
+    if args.multi_abi_only > 0:
+        print(json.dumps(multi_abi_check(torch, lmpc, make_problem("pendulum"), 1, args.multi_abi_only, 4242)), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -904,7 +935,7 @@ def main():
         if args.workload == "pendulum" and not args.f32 and not args.wave:
             if world == 1:
                 _phase("headline: multi-device ABI check")
-                out["config"]["multi_abi"] = multi_abi_check(torch, lmpc, W.g, nout, min(n_local, 1_000_000), 4242)
+                out["config"]["multi_abi"] = multi_abi_isolated(torch, min(n_local, 1_000_000))
             else:
                 out["config"]["multi_abi"] = {"skipped": "torch.distributed run: the one-process multi-device entry point is "
                                                          "exercised in the N = 1 invocation when it sees several GPUs"}

@@ -743,7 +743,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         // dual objective lam*' K lam* = sum_i y_i z_i (z = D^-1 y is what the backward sweep started from)
                         fval = wv_sum(lane < na ? y * (y * Dinv) : (R)0);
                         // row values from Gram columns, working-set order: M_j u = -sum_i G(W_i, j) lam*_i
-                        constexpr int CHG = MR == 1 ? 8 : (MR <= 3 ? 4 : 2);
+#ifndef LMPC_WAVE_CHG_SCALE
+#define LMPC_WAVE_CHG_SCALE 1
+#endif
+                        constexpr int CHG = LMPC_WAVE_CHG_SCALE * (MR == 1 ? 8 : (MR <= 3 ? 4 : 2));
                         Lam[lane] = ls;                  // (lanes >= na hold 0)
                         for (int i0 = 0; i0 < na; i0 += CHG) {
                             R gv[CHG][MR], lq[CHG];
