@@ -60,6 +60,9 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     int dk = GATHER ? 0 : (h->fastDma >= 0 ? h->fastDma : (nstr <= 3 ? LMPC_FAST_DMA_DEPTH : 0));
     if (dk == 1 || dk > 3) dk = dk == 1 ? 0 : 3;
     if (nprob * (int64_t)NT * 8 < 16) dk = 0;
+    // 16-byte pieces: a batch that does not start on a 16-byte boundary (a view into a larger array) or whose tiles
+    // are not multiples of 16 bytes takes its records through registers
+    if ((reinterpret_cast<uintptr_t>(theta) & 15u) != 0 || (fast_tile_bytes(NT) & 15u) != 0) dk = 0;
     const size_t lds = dk ? fast_lds_bytes_dma(N, Rq, NTHMAX, NT, nstr, dk) : fast_lds_bytes(N, Rq, NTHMAX);
     int32_t *ctrNow = nullptr, *ctrNext = nullptr;
     if (D) {

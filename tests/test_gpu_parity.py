@@ -2129,3 +2129,24 @@ def test_one_launch_kernel_record_paths_and_dynamic_tail(lmpc, opts):
         assert np.array_equal(act[sel], acto)
         assert (ef >= 1).all()
     qp.check()
+
+
+def test_one_launch_kernel_unaligned_batch(lmpc):
+    # a batch that starts 8 bytes into an allocation (a view): the LDS-DMA pieces need 16-byte alignment, the library
+    # falls back to the register path by itself; results are the oracle's either way
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden("pendulum")
+    qp = _qp_from_golden(lmpc, g, 1)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(8)
+    N = 100_003
+    theta = np.hstack([rng.uniform(-9, 9, (N, 4)), rng.uniform(-9, 9, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    flat = torch.zeros(N * 7 + 1, dtype=torch.float64, device="cuda:0")
+    flat[1:] = torch.from_numpy(theta.reshape(-1)).to("cuda:0")
+    view = flat[1:].view(N, 7)
+    assert view.data_ptr() % 16 == 8
+    x, ef = qp.solve_device(view)
+    qp.check()
+    xo, efo, _, _ = oldp.solve_batch(L, theta)
+    assert np.array_equal(x.cpu().numpy(), xo) and np.array_equal(ef.cpu().numpy(), efo)
