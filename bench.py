@@ -805,10 +805,6 @@ def main():
         gather_to_root(xbuf[last_b[0]], fbuf[last_b[0]])
     fence()
     elapsed = time.perf_counter() - t0
-    # ---- what the timed region wrote, checked against the oracle (untimed): the last steps of every stream
-    verification = None
-    if rank == 0 and args.steps and not do_gather:
-        verification = W.verify_steps(list(range(max(0, args.steps - max(nstreams, 2)), args.steps)))
     exchange_ms = None
     if after_gather and args.steps:
         # the exchange a single consumer of all shards would add: one batch's solutions and flags to rank 0
@@ -818,6 +814,11 @@ def main():
         tgl = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
         dist.all_reduce(tgl, op=dist.ReduceOp.MAX)
         exchange_ms = 1e3 * float(tgl.item())
+    # ---- what the timed region wrote, checked against the oracle (untimed; behind the exchange measurement so that
+    # rank 0's check does not sit inside the other ranks' gather time): the last steps of every stream
+    verification = None
+    if rank == 0 and args.steps and not do_gather:
+        verification = W.verify_steps(list(range(max(0, args.steps - max(nstreams, 2)), args.steps)))
     # average device time of one launch on its stream = event span of the stream / its launches (diagnostic,
     # untimed repeat of the same steps, at most 200 of them)
     nrep = min(args.steps, 200)
