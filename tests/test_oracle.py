@@ -619,3 +619,65 @@ def test_gram_scan_twin_takes_the_same_decisions(name, xtol):
     Xf, ef, _, _ = oldp.solve_batch(L, th[:300].astype(np.float32), s32, dtype=np.float32)
     Xc, ec, _, _ = oldp.solve_batch(L, th[:300].astype(np.float32), oldp.default_settings_f32(), dtype=np.float32)
     assert Xf.dtype == np.float32 and ((ef >= 1) == (ec >= 1)).mean() > 0.9
+
+
+@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50"])
+def test_soft_path_solution_is_a_kkt_point_of_the_explicit_slack_qp(name):
+    """A certificate that involves no solver at all.  For the reference's explicit-slack QP (utils.jl:329-364: slack
+    eps_i per soft row with coefficient -nf_i on both sides, cost soft_weight I) the KKT conditions at a point U are
+        eps_i = max(0, violation_i) / nf_i                      (the slack a violated soft row needs, zero otherwise)
+        mu_i  = soft_weight * eps_i / nf_i                       (stationarity in eps_i: the multiplier is DETERMINED)
+        H U + f(theta) + sum_soft +-A_i' mu_i + sum_hard-active +-A_j' mu_j = 0,  mu_j >= 0   (stationarity in U)
+    so for the U the SOFT-flag path returns, the residual  -(H U + f) - (soft terms)  must lie in the cone of the
+    active HARD rows' normals: a non-negative least-squares problem whose optimum must be ~0, and every hard row must
+    hold.  Checked at rho_soft = 1e-3 (the same semantics as 1e-6, without its 1e6 amplification of rounding)."""
+    from scipy.optimize import nnls
+    g = load_golden(name)
+    kat = load_golden("soft_explicit_kat")
+    th = kat[f"{name}_theta"][:40]
+    rho = 1e-3
+    w = 1.0 / rho
+    H, f, fth = np.asarray(g["H"], float), np.asarray(g["f"], float).ravel(), np.asarray(g["f_theta"], float)
+    n = H.shape[0]
+    A = np.asarray(g["A"], float).reshape(-1, n)
+    bu, bl, W = np.asarray(g["bu"], float), np.asarray(g["bl"], float), np.asarray(g["W"], float)
+    m = bu.size
+    ms = m - A.shape[0]
+    A0 = np.vstack([np.eye(n)[:ms], A])
+    soft = (np.asarray(g["senses"]) & 8) != 0
+    imm = (np.asarray(g["senses"]) & 4) != 0
+    Rl = np.linalg.cholesky((H + H.T) / 2)
+    nf = np.linalg.norm(np.linalg.solve(Rl, A0.T).T, axis=1)
+    L = oldp.qp2ldp(H, f, fth, A, bu, bl, W, g["senses"], nout=n)
+    s = oldp.default_settings(); s.rho_soft = rho
+    U, ef, _, _ = oldp.solve_batch(L, th, s)
+    assert np.all(ef >= 1)
+    worst = 0.0
+    for k in range(len(th)):
+        u = U[k]
+        up = bu + W @ th[k]; lo = bl + W @ th[k]
+        Au = A0 @ u
+        vu, vl = Au - up, lo - Au                                   # > 0: violated
+        hard = ~soft & ~imm
+        scale = 1.0 + np.abs(Au)
+        assert (vu[hard] <= 2e-6 * scale[hard] * np.maximum(nf[hard], 1)).all() and (vl[hard] <= 2e-6 * scale[hard] * np.maximum(nf[hard], 1)).all()
+        grad = H @ u + f + fth.reshape(n, -1) @ th[k]
+        res = -grad
+        cols = [A0[j] for j in np.flatnonzero(hard & (np.abs(vu) <= 1e-5 * np.maximum(nf, 1)))] + \
+               [-A0[j] for j in np.flatnonzero(hard & (np.abs(vl) <= 1e-5 * np.maximum(nf, 1)))]
+        for i in np.flatnonzero(soft):
+            # clearly violated soft row: its multiplier is determined by the violation; a soft row ON its bound --
+            # within the solver's primal_tol (1e-6 in normalised-row units = 1e-6 nf_i here), where "violated" and
+            # "satisfied" are the same answer and w v / nf^2 would turn the tolerance into a force -- may carry any
+            # multiplier >= 0: it joins the cone
+            tv = 2e-6 * nf[i]
+            if vu[i] > tv: res -= A0[i] * (w * vu[i] / nf[i] ** 2)
+            elif vu[i] >= -tv: cols.append(A0[i])
+            if vl[i] > tv: res += A0[i] * (w * vl[i] / nf[i] ** 2)
+            elif vl[i] >= -tv: cols.append(-A0[i])
+        if cols:
+            _, rn = nnls(np.array(cols).T, res)
+        else:
+            rn = np.linalg.norm(res)
+        worst = max(worst, rn / (1.0 + np.linalg.norm(grad)))
+    assert worst <= 1e-5, worst
