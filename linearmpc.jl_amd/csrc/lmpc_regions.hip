@@ -55,28 +55,35 @@ __global__ __launch_bounds__(256) void distinct_masks_kernel(
             const unsigned long long cnt = (unsigned long long)__popcll(same);
             int slot = (int)(hsh & (unsigned long long)tcap_mask);
             for (int probes = 0; probes <= tcap_mask; probes++) {
-                int s = __hip_atomic_load(&table[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (s == -1) {
-                    int expect = -1;
-                    if (__hip_atomic_compare_exchange_strong(&table[slot], &expect, -2, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)) {
-                        const int k = atomicAdd(n_sets, 1);
-                        if (k >= capacity) {                               // more distinct sets than the caller made room for
-                            atomicExch(overflow, 1);
-                            __hip_atomic_store(&table[slot], -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int s = -1;
+                bool done = false;
+                for (int spins = 0; spins < (1 << 20); spins++) {
+                    s = __hip_atomic_load(&table[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (s == -1) {
+                        int expect = -1;
+                        if (__hip_atomic_compare_exchange_strong(&table[slot], &expect, -2, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+                            const int k = atomicAdd(n_sets, 1);
+                            if (k >= capacity) {                           // more distinct sets than the caller made room for:
+                                atomicExch(overflow, 1);                   // the host retries with more (slot given back)
+                                __hip_atomic_store(&table[slot], -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                for (int q = 0; q < words; q++) set_masks[(long long)k * words + q] = lead[q];
+                                set_count[k] = cnt;
+                                set_first[k] = lidx;
+                                __hip_atomic_store(&table[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            done = true;
                             break;
                         }
-                        for (int q = 0; q < words; q++) set_masks[(long long)k * words + q] = lead[q];
-                        set_count[k] = cnt;
-                        set_first[k] = lidx;
-                        __hip_atomic_store(&table[slot], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+                        continue;                                          // somebody else took it: look again
                     }
-                    s = expect;                                            // somebody else took it: look at what they put
+                    if (s >= 0) break;                                     // published: compare below
+                    // s == -2: being filled by another wavefront -- unless the call has overflowed anyway
+                    if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { done = true; break; }
                 }
-                int spins = 0;
-                while (s == -2 && spins++ < (1 << 20)) s = __hip_atomic_load(&table[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                if (s < 0) { atomicExch(overflow, 2); break; }            // (a slot never stays "being filled")
+                if (done) break;
+                if (s < 0) { atomicCAS(overflow, 0, 2); break; }          // (a slot never stays "being filled")
                 bool match = true;
                 for (int q = 0; q < words; q++)
                     match = match && (__hip_atomic_load(&set_masks[(long long)s * words + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == lead[q]);

@@ -559,7 +559,7 @@ class BatchedQP:
             if over == 0:
                 break
             if over == 2:
-                raise LmpcError(_cabi.LMPC_ERR_HIP, "lmpc_distinct_active_sets_device: table slot never published")
+                raise LmpcError(-102, "lmpc_distinct_active_sets_device: table slot never published")
             capacity *= 4                                        # more regions than room: once more with more
         R = int(nset.item())
         m = masks[:R].cpu().numpy().view(np.uint64)

@@ -2150,3 +2150,27 @@ def test_one_launch_kernel_unaligned_batch(lmpc):
     qp.check()
     xo, efo, _, _ = oldp.solve_batch(L, theta)
     assert np.array_equal(x.cpu().numpy(), xo) and np.array_equal(ef.cpu().numpy(), efo)
+
+
+def test_distinct_active_sets_edge_cases(lmpc):
+    import torch
+    g = load_golden("mass_spring")
+    qp = _qp_from_golden(lmpc, g, 1)
+    # empty batch
+    act0 = torch.zeros((0, qp.words), dtype=torch.int64, device="cuda:0")
+    m0, c0, f0 = qp.distinct_active_sets_device(act0)
+    assert len(m0) == 0 and len(c0) == 0
+    # no exit flags given: every row counts, duplicates far apart in the batch are merged
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 2 ** 62, (7, qp.words)).astype(np.int64)
+    pick = rng.integers(0, 7, 100_000)
+    act = torch.from_numpy(base[pick]).to("cuda:0")
+    m1, c1, f1 = qp.distinct_active_sets_device(act, capacity=16)
+    assert len(m1) == len(np.unique(pick)) and c1.sum() == 100_000
+    for mask, cnt, first in zip(m1, c1, f1):
+        k = int(np.flatnonzero((base.view(np.uint64) == mask).all(axis=1))[0])
+        assert cnt == (pick == k).sum() and first == np.flatnonzero(pick == k)[0]
+    # every problem failed: nothing to report
+    ef = torch.full((100_000,), -1, dtype=torch.int32, device="cuda:0")
+    m2, c2, f2 = qp.distinct_active_sets_device(act, ef)
+    assert len(m2) == 0
