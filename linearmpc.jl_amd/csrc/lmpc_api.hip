@@ -89,6 +89,7 @@ int finalize_handle(lmpc_handle *h) {
     for (int j = 0; j < P.m; j++) nBinary += (P.sense[j] & SENSE_BINARY) ? 1 : 0;
     const bool anyBinary = nBinary > 0;
     h->bnb = anyBinary;
+    h->nBinary = nBinary;
     if (nBinary > 64)    // the B&B stack of a problem lives on the 64 lanes of its wavefront
         return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: more than 64 binary rows");
     if (anyBinary && P.n > 64)
@@ -1464,6 +1465,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccStage); rel(h->ccStageFlag); h->ccStageCap = 0; h->ccStagePer = 0;
     rel(h->ccObsScratch); h->ccObsCap = 0;
     rel(h->dOvfList); h->ovfCap = 0; rel(h->dBigR); rel(h->dBigI);
+    rel(h->dBnbR); rel(h->dBnbI); h->bnbBytesR = h->bnbBytesI = 0;
     return check_fast_err(h);
 }
 
@@ -1485,6 +1487,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
+    hipFree(h->dBnbR); hipFree(h->dBnbI);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);

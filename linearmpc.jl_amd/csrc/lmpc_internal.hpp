@@ -73,6 +73,11 @@ struct lmpc_handle {
     int32_t *dOvfList = nullptr, *dOvfCount = nullptr, *dBigI = nullptr;
     void *dBigR = nullptr;
     int64_t ovfCap = 0;
+    // branch and bound: per-wavefront snapshots of a node's state, one slot per search depth (lmpc_wave_kernel.hpp)
+    void *dBnbR = nullptr;
+    int32_t *dBnbI = nullptr;
+    size_t bnbBytesR = 0, bnbBytesI = 0;
+    int nBinary = 0;            // rows flagged BINARY = the search's largest depth
     int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)
     int waveLevel = -1;         // tuning: LDS staging level of the wave kernel (-1 = automatic)

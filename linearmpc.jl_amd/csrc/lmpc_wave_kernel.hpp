@@ -200,7 +200,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
     int32_t *__restrict__ queue, int qchunk, long long nprob,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
-    long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim) {
+    long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim,
+    R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -631,14 +632,12 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         };
 
         // ---- one LDP solve with the flags in sense[].
-        // forced < 0: fresh start; the initial working set is the rows flagged ACTIVE (equalities,
-        // fixed binaries) plus a warm-start mask -- the caller's (closed loop), or, for a B&B node
-        // reached by backtracking, its parent's final working set (pup/plo; flagged rows go in first
-        // so that a dependent warm row is dropped instead of making a fixed row look over-determined).
-        // forced >= 0: continue IN PLACE from the parent node's optimal working set and multipliers;
+        // forced < 0: fresh start; the initial working set is the rows flagged ACTIVE (equalities) plus the
+        // caller's warm-start mask (closed loop).
+        // forced >= 0 (B&B): continue IN PLACE from the parent node's optimal working set, factorisation and
+        // multipliers -- as they stand (first child) or as restored from the node's snapshot (second child);
         // row forced>>1 (side forced&1) has just been fixed and enters like a violated row would.
-        auto solve_node = [&](int forced, const unsigned long long (&pup)[MR], const unsigned long long (&plo)[MR],
-                              bool have_parent) {
+        auto solve_node = [&](int forced) {
         iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; best = (R)-1; done = false;
         if (!BNB || forced < 0) {
         clear_rows(1, na);                       // (rows of the previous solve / node; row 0 has no entries)
@@ -649,7 +648,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         actb = 0u; lowb = 0u;
         na = 0; sing = -1; nsoft_act = 0;
         fval = (R)0; soft_slack = (R)0; ydirty = false;
-        for (int pass = 0; pass < (BNB ? 2 : 1) && !done; pass++) {
+        {
             unsigned long long wm[MR], lm[MR];
 #pragma unroll
             for (int r = 0; r < MR; r++) {
@@ -657,15 +656,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 const int sj = sense[r];
                 const bool flagged = (j < m) && (sj & SENSE_ACTIVE) != 0;
                 bool want = flagged, lower = flagged && (sj & SENSE_LOWER) != 0;
-                if (BNB) {
-                    if (pass == 1) {
-                        want = false; lower = false;
-                        if (have_parent && j < m && !flagged && !(sj & SENSE_IMMUTABLE)) {
-                            if ((pup[r] >> lane) & 1ull) want = true;
-                            else if ((plo[r] >> lane) & 1ull) { want = true; lower = true; }
-                        }
-                    }
-                } else if (warm != nullptr && j < m && !(sj & SENSE_IMMUTABLE)) {
+                if (!BNB && warm != nullptr && j < m && !(sj & SENSE_IMMUTABLE)) {
                     const uint64_t *wp = warm + pid * P.words;
                     if ((wp[j >> 6] >> (j & 63)) & 1ull) want = true;
                     else if ((wp[(m + j) >> 6] >> ((m + j) & 63)) & 1ull) { want = true; lower = true; }
@@ -886,20 +877,49 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         }
         };   // solve_node
 
-        unsigned long long no_parent[MR];
-#pragma unroll
-        for (int r = 0; r < MR; r++) no_parent[r] = 0ull;
         if (!BNB) {
-            solve_node(-1, no_parent, no_parent, false);
+            solve_node(-1);
             if constexpr (GRAM) primal_step();
         } else {
-            // depth-first branch and bound; stack entry d lives on lane d: the row branched on, the
-            // side tried first, and the final working set of the node that branched (what its second
-            // child restarts from; the first child continues in place)
+            // Depth-first branch and bound; stack entry d lives on lane d: the row branched on, the side tried
+            // first.  BOTH children of a node continue in place from its optimal state: the first right away, the
+            // second from a SNAPSHOT of that state taken when the node branched (round 3; until then the second
+            // child rebuilt the parent's working set row by row -- 41 rebuilds of ~30 appends per parameter point
+            // of the satellite problem, two thirds of the kernel's time).  A snapshot = the registers of the
+            // working-set positions, the rows' activity bits and the strict lower triangle of L, in this
+            // wavefront's slice of global scratch (one slot per depth; a few KB, written once and read once).
             int stk_j = 0, stk_side = 0, stk_tried = 0;
-            unsigned long long stk_up[MR], stk_lo[MR];
-#pragma unroll
-            for (int r = 0; r < MR; r++) { stk_up[r] = 0ull; stk_lo[r] = 0ull; }
+            const long long slot = (long long)blockIdx.x * nwv + wv;
+            const int snapR = 6 * 64 + cap * (cap - 1) / 2, snapI = 5 * 64;
+            R *const snr0 = bnb_r + slot * (long long)bnb_depth * snapR;
+            int32_t *const sni0 = bnb_i + slot * (long long)bnb_depth * snapI;
+            auto pk = [&](int t) -> int { return t * (2 * cap - 1 - t) / 2 - t - 1; };   // column t of the packed triangle
+            auto snapshot = [&](int d) {
+                R *sr = snr0 + (long long)d * snapR;
+                int32_t *si = sni0 + (long long)d * snapI;
+                sr[lane] = ls; sr[64 + lane] = rhs; sr[128 + lane] = D; sr[192 + lane] = Dinv; sr[256 + lane] = y;
+                si[lane] = WSi; si[64 + lane] = possoft | (posimm << 1) | (poslow << 2);
+                si[128 + lane] = (int32_t)actb; si[192 + lane] = (int32_t)lowb;
+                if (lane == 0) { sr[320] = fval; si[256] = na; si[257] = nsoft_act; }
+                for (int t = 0; t + 1 < na; t++)
+                    if (lane > t && lane < na) sr[384 + pk(t) + lane] = L[cbase(t) + lane];
+            };
+            auto restore = [&](int d) {
+                const R *sr = snr0 + (long long)d * snapR;
+                const int32_t *si = sni0 + (long long)d * snapI;
+                clear_rows(1, na);
+                ls = sr[lane]; rhs = sr[64 + lane]; D = sr[128 + lane]; Dinv = sr[192 + lane]; y = sr[256 + lane];
+                WSi = si[lane];
+                const int fl = si[64 + lane];
+                possoft = fl & 1; posimm = (fl >> 1) & 1; poslow = (fl >> 2) & 1;
+                actb = (unsigned)si[128 + lane]; lowb = (unsigned)si[192 + lane];
+                fval = wv_first(sr[320]);
+                na = __builtin_amdgcn_readfirstlane(si[256]);
+                nsoft_act = __builtin_amdgcn_readfirstlane(si[257]);
+                for (int t = 0; t + 1 < na; t++)
+                    if (lane > t && lane < na) L[cbase(t) + lane] = sr[384 + pk(t) + lane];
+                lam = (R)0; sing = -1; ydirty = false;
+            };
             int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
             bool inplace = false;
             R ubest[NU], bestval = (R)P.fval_bound;
@@ -920,21 +940,11 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     }
                 }
                 fbound = bestval;
-                unsigned long long pup[MR], plo[MR];
                 const int dpar = depth > 0 ? depth - 1 : 0;
-#pragma unroll
-                for (int r = 0; r < MR; r++) {
-                    const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(stk_up[r] & 0xffffffffull), dpar);
-                    const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(stk_up[r] >> 32), dpar);
-                    const unsigned lo32b = (unsigned)__builtin_amdgcn_readlane((int)(stk_lo[r] & 0xffffffffull), dpar);
-                    const unsigned hi32b = (unsigned)__builtin_amdgcn_readlane((int)(stk_lo[r] >> 32), dpar);
-                    pup[r] = ((unsigned long long)hi32 << 32) | lo32;
-                    plo[r] = ((unsigned long long)hi32b << 32) | lo32b;
-                }
                 int forced = -1;
                 if (inplace)
                     forced = 2 * __builtin_amdgcn_readlane(stk_j, dpar) + __builtin_amdgcn_readlane(stk_side, dpar);
-                solve_node(forced, pup, plo, depth > 0);
+                solve_node(forced);
                 nodes++;
                 total_it += iter;
                 if (flag == EXIT_WSCAP) { bflag = EXIT_WSCAP; have = 0; break; }
@@ -969,18 +979,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         for (int r = 0; r < MR; r++) if (r == (jb >> 6)) { blo = dlb[r]; bup = dub[r]; }
                         const R dlo = wv_bcast(blo, jb & 63), dup = wv_bcast(bup, jb & 63);
                         const int lower_first = (wv_first(Mu) - dlo) < (dup - wv_first(Mu)) ? 1 : 0;
-                        unsigned long long nup[MR], nlo[MR];
-#pragma unroll
-                        for (int r = 0; r < MR; r++) {
-                            const bool a = (actb >> r) & 1u, lo = (lowb >> r) & 1u;
-                            nup[r] = __ballot(a && !lo);
-                            nlo[r] = __ballot(a && lo);
-                        }
-                        if (lane == depth) {
-                            stk_j = jb; stk_side = lower_first; stk_tried = 1;
-#pragma unroll
-                            for (int r = 0; r < MR; r++) { stk_up[r] = nup[r]; stk_lo[r] = nlo[r]; }
-                        }
+                        if (lane == depth) { stk_j = jb; stk_side = lower_first; stk_tried = 1; }
+                        snapshot(depth);                 // this node's optimal state, for its second child
                         depth++;
                         descend = true;
                     }
@@ -990,6 +990,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     while (depth > 0 && __builtin_amdgcn_readlane(stk_tried, depth - 1) == 2) depth--;
                     if (depth == 0) break;
                     if (lane == depth - 1) { stk_side ^= 1; stk_tried = 2; }
+                    restore(depth - 1);                  // back to that node's optimal state: its second child, in place
+                    inplace = true;
                 }
             }
 #pragma unroll

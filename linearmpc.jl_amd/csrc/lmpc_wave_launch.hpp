@@ -143,9 +143,30 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
         }
         HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t), st));
     }
+    // branch and bound: room for one snapshot of a node's state per search depth and resident wavefront (sized for
+    // binary64; the binary32 calls of the handle use the same slices)
+    R *bnbR = nullptr;
+    int32_t *bnbI = nullptr;
+    if constexpr (BNB) {
+        const size_t snapR = 6 * 64 + (size_t)Wl.cap * (Wl.cap - 1) / 2, snapI = 5 * 64;
+        const size_t slots = (size_t)grid * cfg.nwv, depth = (size_t)(h->nBinary > 0 ? h->nBinary : 1);
+        const size_t needR = sizeof(double) * slots * depth * snapR, needI = sizeof(int32_t) * slots * depth * snapI;
+        if (needR > h->bnbBytesR) {
+            hipFree(h->dBnbR); h->dBnbR = nullptr; h->bnbBytesR = 0;
+            HIP_TRY(h, hipMalloc(&h->dBnbR, needR));
+            h->bnbBytesR = needR;
+        }
+        if (needI > h->bnbBytesI) {
+            hipFree(h->dBnbI); h->dBnbI = nullptr; h->bnbBytesI = 0;
+            HIP_TRY(h, hipMalloc(&h->dBnbI, needI));
+            h->bnbBytesI = needI;
+        }
+        bnbR = static_cast<R *>(h->dBnbR);
+        bnbI = h->dBnbI;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
                        iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
-                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr, h->waveSim);
+                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr, h->waveSim, bnbR, bnbI, h->nBinary);
     HIP_TRY(h, hipGetLastError());
     if (big) {
         hipLaunchKernelGGL(big_kernel<R>, dim3(kBigThreads / 64), dim3(64), 0, st, Wl, dC, h->dSw, theta, x, flag, iters,

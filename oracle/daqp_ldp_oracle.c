@@ -644,14 +644,34 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
  *     as the node is dominated;
  *   - branch on the lowest-index binary row that is not in the relaxation's final working set,
  *     first to the bound its row value M_j u is closer to, then to the other;
- *   - the FIRST child continues in place from its parent's optimal working set and multipliers (the
- *     newly fixed row enters like a violated row would: solve_core's `forced`); the SECOND child is
- *     reached by backtracking, when that state is gone: it restarts from the parent's final working
- *     set, kept on the stack as a mask (solve_core's two-pass warm start);
+ *   - BOTH children continue in place from their parent's optimal working set, factorisation and
+ *     multipliers (the newly fixed row enters like a violated row would: solve_core's `forced`): the
+ *     first child right away, the second -- reached by backtracking, when the first child's subtree has
+ *     overwritten that state -- from a SNAPSHOT of it taken when the node branched (one per depth).
+ *     (Until round 3 the second child rebuilt the parent's working set row by row from a mask: for the
+ *     satellite problem 41 such rebuilds of ~30 rows per parameter point, most of the search's time.)
  *   - a node whose binaries are all active is a leaf; it replaces the incumbent if strictly better.
  * iters returns the iterations summed over all nodes; the flag is 1 if an incumbent exists,
  * -1 if none, -4 if the node limit ran out first. */
 #define BNB_NODE_LIMIT 100000
+/* solver state of a node (what continuing in place needs): a deep copy between two work areas of equal shape */
+static void work_copy(work_t *dst, const work_t *src) {
+    const int cap = src->cap, n = src->n, m = src->m;
+    dst->na = src->na; dst->sing = src->sing; dst->reuse = src->reuse; dst->nsoft_act = src->nsoft_act;
+    dst->fval = src->fval; dst->soft_slack = src->soft_slack; dst->ydirty = src->ydirty;
+    memcpy(dst->L, src->L, sizeof(real) * (size_t)TRI(cap + 1));
+    memcpy(dst->D, src->D, sizeof(real) * (cap + 1));
+    memcpy(dst->Dinv, src->Dinv, sizeof(real) * (cap + 1));
+    memcpy(dst->lam, src->lam, sizeof(real) * (cap + 1));
+    memcpy(dst->lam_star, src->lam_star, sizeof(real) * (cap + 1));
+    memcpy(dst->xl, src->xl, sizeof(real) * (cap + 1));
+    memcpy(dst->zl, src->zl, sizeof(real) * (cap + 1));
+    memcpy(dst->u, src->u, sizeof(real) * (n > 0 ? n : 1));
+    memcpy(dst->WS, src->WS, sizeof(int) * (cap + 1));
+    memcpy(dst->sense, src->sense, sizeof(int32_t) * (m > 0 ? m : 1));
+    if (src->Mu && dst->Mu) memcpy(dst->Mu, src->Mu, sizeof(real) * (m > 0 ? m : 1));
+}
+
 static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, const real *theta,
                      real *xout, int32_t *iters, uint64_t *active, int nwords) {
     const int n = p->n, m = p->m;
@@ -659,7 +679,9 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
     int32_t *sense = (int32_t *)malloc(sizeof(int32_t) * (m > 0 ? m : 1));
     int *stk_j = (int *)malloc(sizeof(int) * (m + 1)), *stk_side = (int *)malloc(sizeof(int) * (m + 1)),
         *stk_tried = (int *)malloc(sizeof(int) * (m + 1));
-    uint64_t *stk_mask = (uint64_t *)calloc((size_t)nw * (m + 1), sizeof(uint64_t));
+    work_t **snap = (work_t **)calloc((size_t)m + 1, sizeof(work_t *));   /* snap[d]: state of the node that branched at depth d */
+    int nsoft_rows = 0;
+    for (int j = 0; j < m; j++) nsoft_rows += (p->sense[j] & SENSE_SOFT) != 0;
     real *ubest = (real *)calloc(n, sizeof(real));
     uint64_t *abest = (uint64_t *)calloc(nw, sizeof(uint64_t));
     oracle_settings sn = *s;
@@ -675,7 +697,7 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
         int32_t it = 0;
         int ef;
         if (inplace) ef = solve_core(w, p, &sn, sense, NULL, 0, 2 * stk_j[depth - 1] + stk_side[depth - 1], &it);
-        else ef = solve_core(w, p, &sn, sense, depth > 0 ? stk_mask + (size_t)(depth - 1) * nw : NULL, 1, -1, &it);
+        else ef = solve_core(w, p, &sn, sense, NULL, 0, -1, &it);                   /* the root */
         nodes++;
         total_it += it;
         if (ef == EXIT_WSCAP) { flag = EXIT_WSCAP; have = 0; break; }     /* Gram-scan form: as the kernel does */
@@ -702,13 +724,11 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
                 else for (int k = 0; k < n; k++) Mu = RFMA(mj[k], w->u[k], Mu);
                 const int lower_first = (Mu - w->dlower[jb]) < (w->dupper[jb] - Mu);
                 stk_j[depth] = jb; stk_side[depth] = lower_first; stk_tried[depth] = 1;
-                uint64_t *mk = stk_mask + (size_t)depth * nw;       /* this node's final working set */
-                for (int q = 0; q < nw; q++) mk[q] = 0;
-                for (int i = 0; i < w->na; i++) {
-                    const int j = w->WS[i];
-                    const int bit = (w->sense[j] & SENSE_LOWER) ? m + j : j;
-                    mk[bit >> 6] |= (uint64_t)1 << (bit & 63);
+                if (!snap[depth]) {                                 /* this node's final state, for its second child */
+                    snap[depth] = work_new(n, m, nsoft_rows);
+                    if (s->mode == ORACLE_MODE_GRAM) snap[depth]->Mu = (real *)calloc(m > 0 ? m : 1, sizeof(real));
                 }
+                work_copy(snap[depth], w);
                 depth++;
                 descend = 1;
             }
@@ -719,6 +739,8 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
             if (depth == 0) break;
             stk_side[depth - 1] ^= 1;
             stk_tried[depth - 1] = 2;
+            work_copy(w, snap[depth - 1]);              /* back to the parent's optimal state: second child, in place */
+            inplace = 1;
         }
     }
     if (have) {
@@ -731,7 +753,9 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
     write_outputs(w, p, theta, xout, NULL, 0);
     if (active) for (int q = 0; q < nwords; q++) active[q] = have ? abest[q] : 0;
     if (iters) *iters = total_it;
-    free(sense); free(stk_j); free(stk_side); free(stk_tried); free(stk_mask); free(ubest); free(abest);
+    for (int d = 0; d <= m; d++) if (snap[d]) work_free(snap[d]);
+    (void)nw;
+    free(snap); free(sense); free(stk_j); free(stk_side); free(stk_tried); free(ubest); free(abest);
     return flag;
 }
 
