@@ -389,8 +389,10 @@ int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, dou
     h->countSet ^= 1;
     const bool wide = h->P.nout > 1 && h->P.nout <= 16;
     int rc = LMPC_OK;
-#define LMPC_SCRW(NM, NT) (wide ? launch_screen<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
-                                : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
+    const bool simf = h->L.sim.FG != nullptr;     // closed loop, plant step fused in (lmpc_simulate_device)
+#define LMPC_SCRW(NM, NT) (simf ? launch_screen<NM, NT, 1>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                           : wide ? launch_screen<NM, NT, 3>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st) \
+                                  : launch_screen<NM, NT, 0>(h, nprob, theta, x, flag, iters, active, warm, cnt_now, st))
     LMPC_SCREEN_SWITCH(LMPC_SCRW)
 #undef LMPC_SCRW
     if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
@@ -867,20 +869,66 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         HIP_TRY(h, hipGetLastError());
         return LMPC_OK;
     }
+    // Wavefront path, warm: every scenario's final working set stays on the device WITH its factorisation, in its
+    // order (2 x 64 + cap (cap - 1) / 2 reals and 320 ints per scenario: 17 KB at cap 64), so that a warm step
+    // starts from the factor as it stands -- what DAQP_WARMSTART means in libdaqp, whose workspace is simply not
+    // cleared between two calls (codegen/mpc_update_qp.c:44-54) -- instead of re-appending the rows of the mask one
+    // by one.  Option "sim_keep_factor" 0 (or no memory for it): the mask-based warm start of the other paths.
+    h->keepOn = false;
+    if (h->useWave && warm && !h->bnb && h->simKeep && T > 1) {
+        const size_t keepR = 2 * 64 + (size_t)h->W.cap * (h->W.cap - 1) / 2, keepI = 5 * 64;
+        if (N > h->keepCap) {
+            hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
+            if (hipMalloc(&h->dKeepR, sizeof(double) * keepR * (size_t)N) == hipSuccess &&
+                hipMalloc(&h->dKeepI, sizeof(int32_t) * keepI * (size_t)N) == hipSuccess) h->keepCap = N;
+            else { hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; (void)hipGetLastError(); }
+        }
+        if (N <= h->keepCap) {
+            // nothing kept yet: the size word of every scenario's state to -1
+            HIP_TRY(h, hipMemset2DAsync(h->dKeepI + 256, sizeof(int32_t) * keepI, 0xFF, sizeof(int32_t), (size_t)N, st));
+            h->keepOn = true;
+        }
+    }
+    // Wavefront path with its screening pass in front: the plant step is fused into the three kernels of a step like
+    // on the lane path -- the screening pass advances the scenarios it finishes (SimFuse), the wavefront kernel and its
+    // slow path advance theirs in place (WaveSim with the step number) -- so a step is those launches and nothing
+    // else: no plant kernel (16 us at 2e5 scenarios), no input / flag arrays in between.
+    if (h->useWave && h->simFused && !h->bnb && nu <= kMaxSimU && nx <= 8 && wave_screens(h, N)) {
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG, F, sizeof(double) * nx * nx, hipMemcpyHostToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(h->dC + h->L.oFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
+        int rc = LMPC_OK;
+        for (int k = 0; k < T && rc == LMPC_OK; k++) {
+            h->L.sim = SimFuse{h->simFG, h->simTheta, flag_min, X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
+                               nx, nu, nr, nuprev, k == 0 ? 1 : 0};
+            h->waveSim = WaveSim{h->simFG, nullptr, nullptr, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N, k};
+            const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
+            rc = launch(h, N, h->simTheta, U_traj ? U_traj + (size_t)k * N * nu : nullptr, nullptr, nullptr,
+                        warm ? h->simAct : nullptr, wm, st);
+        }
+        h->L.sim = SimFuse{};
+        h->waveSim = WaveSim{};
+        h->keepOn = false;
+        if (rc != LMPC_OK) return rc;
+        hipLaunchKernelGGL(unpack_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, nuprev > 0 ? uprev : nullptr,
+                           nx, nr, nuprev, (long long)N);
+        HIP_TRY(h, hipGetLastError());
+        return LMPC_OK;
+    }
     for (int k = 0; k < T; k++) {
         // warm start = previous step's final working set (reference codegen DAQP_WARMSTART,
         // codegen/mpc_update_qp.c:44-47); the first step is always cold
         const uint64_t *wm = (warm && k > 0) ? h->simAct : nullptr;
         int rc = launch(h, N, h->simTheta, h->simU, h->simFlag, nullptr, warm ? h->simAct : nullptr, wm, st);
-        if (rc != LMPC_OK) return rc;
+        if (rc != LMPC_OK) { h->keepOn = false; return rc; }
         const bool last = k == T - 1;
         hipLaunchKernelGGL(plant_theta_kernel<double>, dim3(grid), dim3(256), 0, st, h->simTheta, h->P.nth, nr, h->simU,
                            h->simFlag, h->simFG, nx, nu, nuprev,
                            X_traj ? X_traj + (size_t)(k + 1) * N * nx : nullptr,
                            U_traj ? U_traj + (size_t)k * N * nu : nullptr, flag_min, k == 0 ? 1 : 0,
                            last ? x : nullptr, (last && nuprev > 0) ? uprev : nullptr, (long long)N);
-        HIP_TRY(h, hipGetLastError());
+        if (hipGetLastError() != hipSuccess) { h->keepOn = false; return fail(h, LMPC_ERR_HIP, "lmpc_simulate_device: plant step launch"); }
     }
+    h->keepOn = false;
     return LMPC_OK;
 }
 
@@ -1435,6 +1483,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_blind") == 0) { h->simBlind = value < 0 ? 0 : value; return LMPC_OK; }
+    if (std::strcmp(name, "sim_keep_factor") == 0) { h->simKeep = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value < 0 ? 0 : (value > 2 ? 2 : value); return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {
         if (value != 0 && value != 64 && value != 128 && value != 256)
@@ -1466,6 +1515,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccObsScratch); h->ccObsCap = 0;
     rel(h->dOvfList); h->ovfCap = 0; rel(h->dBigR); rel(h->dBigI);
     rel(h->dBnbR); rel(h->dBnbI); h->bnbBytesR = h->bnbBytesI = 0;
+    rel(h->dKeepR); rel(h->dKeepI); h->keepCap = 0;
     return check_fast_err(h);
 }
 
@@ -1487,7 +1537,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
-    hipFree(h->dBnbR); hipFree(h->dBnbI);
+    hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);

@@ -298,8 +298,8 @@ __global__ __launch_bounds__(64) void big_kernel(
             if (k < 8) xsim[k] = (double)xk;
         }
         if constexpr (sizeof(R) == 8) {
-            if (sim.kstep != nullptr) {          // scenario-asynchronous closed loop: advance in place (WaveSim)
-                const int snx = sim.nx, snu = sim.nu, ks = sim.kstep[pid];
+            if (sim.FG != nullptr) {             // closed loop with the plant step fused in: advance in place (WaveSim)
+                const int snx = sim.nx, snu = sim.nu, ks = sim.kfix >= 0 ? sim.kfix : sim.kstep[pid];
                 double xn[8];
                 for (int a = 0; a < snx; a++) {
                     double acc = 0.0;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void big_kernel(
                     if (sim.utraj) sim.utraj[((long long)ks * sim.nscen + pid) * snu + l] = xsim[l];
                 }
                 if (sim.flag_min) sim.flag_min[pid] = ks == 0 ? flag : (flag < sim.flag_min[pid] ? flag : sim.flag_min[pid]);
-                sim.kstep[pid] = ks + 1;
+                if (sim.kfix < 0) sim.kstep[pid] = ks + 1;
             }
         }
         if (active) {

@@ -66,6 +66,7 @@ struct lmpc_handle {
     int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
     bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;
+    int waveCtrSet = 0;         // which of the two (ticket, overflow) counter pairs the next wavefront-kernel launch uses
     int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
     int regCap = 0;
     // slow path for working sets beyond the 64 lanes (lmpc_big_kernel.hpp): overflow list + counter, per-thread scratch
@@ -77,6 +78,12 @@ struct lmpc_handle {
     void *dBnbR = nullptr;
     int32_t *dBnbI = nullptr;
     size_t bnbBytesR = 0, bnbBytesI = 0;
+    // closed loop on the wavefront path: per-scenario working set + factor kept between two steps ("sim_keep_factor")
+    void *dKeepR = nullptr;
+    int32_t *dKeepI = nullptr;
+    int64_t keepCap = 0;
+    bool keepOn = false;
+    int simKeep = 1;
     int nBinary = 0;            // rows flagged BINARY = the search's largest depth
     int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)

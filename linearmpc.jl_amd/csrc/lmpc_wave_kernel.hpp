@@ -53,11 +53,11 @@ namespace lmpc {
 // are scalar memory instructions with a wait behind them, so they stretch what they measure; shares, not absolutes.
 #ifdef LMPC_WAVE_TRACE
 __device__ unsigned long long g_wave_trace[16];
-#define WVT_DECL long long wvt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wvt_prev = (long long)clock64()
+#define WVT_DECL long long wvt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long wvt_prev = (long long)clock64()
 #define WVT(k) do { const long long t__ = (long long)clock64(); wvt_acc[k] += t__ - wvt_prev; wvt_prev = t__; } while (0)
 #define WVT_COUNT(k) do { wvt_acc[k] += 1; } while (0)
-#define WVT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 12; q__++) atomicAdd(&g_wave_trace[q__], (unsigned long long)wvt_acc[q__]); } \
-                       for (int q__ = 0; q__ < 12; q__++) wvt_acc[q__] = 0; } while (0)
+#define WVT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 16; q__++) atomicAdd(&g_wave_trace[q__], (unsigned long long)wvt_acc[q__]); } \
+                       } while (0)
 #else
 #define WVT_DECL do { } while (0)
 #define WVT(k) do { } while (0)
@@ -66,6 +66,15 @@ __device__ unsigned long long g_wave_trace[16];
 #endif
 
 // ---- wave-level helpers, for double and float ---------------------------------------------------
+// a wave-uniform pointer the compiler can see as such: scalar base + per-lane 32-bit offset addressing instead of a
+// 64-bit pointer per lane (which it hoists out of the problem loop and then spills)
+template <typename T>
+__device__ __forceinline__ T *wv_uniform_ptr(T *p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wv_bcast(double v, int src) {
     // `src` is wave-uniform: two v_readlane_b32
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -201,7 +210,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     int32_t *__restrict__ queue, int qchunk, long long nprob,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
     long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim,
-    R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth) {
+    R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth,
+    int32_t *__restrict__ queue_next, int32_t *__restrict__ ovf_next) {
+    // the ticket and overflow counters of the NEXT launch on this handle (the other pair: see the launcher)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *queue_next = 0; *ovf_next = 0; }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -232,6 +244,14 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         for (int i = lane; i < lsize; i += 64) L[i] = (R)0;
     }
     auto cbase = [&](int t) -> int { return PACKED ? t * (2 * cap - 1 - t) / 2 - t - 1 : t * P.ldc; };
+    // entry e of the strict lower triangle stored row after row: (row i, column t), e = i (i - 1) / 2 + t
+    auto tri_row = [&](int e, int &i, int &t) {
+        int ii = (int)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)e)) * 0.5f);
+        if (ii * (ii - 1) / 2 > e) ii--;
+        else if ((ii + 1) * ii / 2 <= e) ii++;
+        i = ii; t = e - ii * (ii - 1) / 2;
+    };
+    constexpr int kKeepI = 5 * 64;                   // ints of a kept closed-loop state (layout of a B&B snapshot's)
     const R *Mr = C + P.oM, *Mt = C + P.oMt, *G = C + P.oG, *Gf = C + P.oGf;
     if constexpr (GRAM) {
         if (LDSC > 0) {
@@ -325,6 +345,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     int kin = 0, ticket = 0;
     WVT_DECL;
     while (idx < ntotal) {
+        WVT(15);                                 // (trace: loop overhead)
         if (queue != nullptr && kin == 0 && lane == 0) ticket = atomicAdd(queue, 1);
         long long pid = idx;
         if (list != nullptr) {
@@ -358,6 +379,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         R dub[MR], dlb[MR];
 #pragma unroll
         for (int r = 0; r < MR; r++) { dub[r] = ldc((unsigned)P.odu, jc[r]) + b[r]; dlb[r] = ldc((unsigned)P.odl, jc[r]) + b[r]; }
+        WVT(12);                                 // (trace: record, bounds, b = Dth theta)
         // registers of working-set position `lane`
         int WSi = 0, possoft = 0, posimm = 0, poslow = 0;
         R lam = (R)0, ls = (R)0, rhs = (R)0, D = (R)0, Dinv = (R)0, y = (R)0;
@@ -648,7 +670,61 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         actb = 0u; lowb = 0u;
         na = 0; sing = -1; nsoft_act = 0;
         fval = (R)0; soft_slack = (R)0; ydirty = false;
-        {
+        // Closed loop with a kept factorisation (bnb_r / bnb_i double as the per-scenario state of a solve without
+        // binaries): the previous step's final working set comes back IN ITS ORDER with its L and D -- what libdaqp's
+        // DAQP_WARMSTART does by simply not clearing its workspace (/root/reference/codegen/mpc_update_qp.c:44-54) --
+        // instead of being re-appended row by row from the mask.  Only the bounds changed: rhs per position from the
+        // shifted bounds, y = L^-1 rhs redone by the first stationary point, multipliers restart at zero.
+        // (The state is read and written with nontemporal accesses: 2 KB per listed scenario and step streaming through
+        // an L2 that should keep the Gram matrix -- with plain accesses every constraint scan got 1.5x slower.)
+        bool kept = false;
+        if constexpr (!BNB) {
+            if (bnb_i != nullptr && warm != nullptr) {
+                const int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
+                const R *sr = wv_uniform_ptr(bnb_r + pid * (long long)(2 * 64 + cap * (cap - 1) / 2));
+                const int pna = __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(si + 256));
+                if (pna >= 0) {
+                    kept = true;
+                    WSi = __builtin_nontemporal_load(si + lane);
+                    const int fl = __builtin_nontemporal_load(si + 64 + lane);
+                    possoft = fl & 1; posimm = (fl >> 1) & 1; poslow = (fl >> 2) & 1;
+                    actb = (unsigned)__builtin_nontemporal_load(si + 128 + lane);
+                    lowb = (unsigned)__builtin_nontemporal_load(si + 192 + lane);
+                    D = __builtin_nontemporal_load(sr + lane); Dinv = __builtin_nontemporal_load(sr + 64 + lane);
+                    na = pna;
+                    nsoft_act = (int)__popcll(__ballot(lane < na && possoft));
+                    const int ne = na * (na - 1) / 2;            // the triangle, row after row, is one contiguous run
+                    for (int e0 = 0; e0 < ne; e0 += 256) {
+                        R tv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int e = e0 + 64 * q + lane;
+                            tv[q] = e < ne ? __builtin_nontemporal_load(sr + 128 + e) : (R)0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int e = e0 + 64 * q + lane;
+                            if (e < ne) {
+                                int i, t;
+                                tri_row(e, i, t);
+                                L[cbase(t) + i] = tv[q];
+                            }
+                        }
+                    }
+                    for (int i = 0; i < na; i++) {
+                        const int j = __builtin_amdgcn_readlane(WSi, i);
+                        const int lw = __builtin_amdgcn_readlane(poslow, i);
+                        R bj = (R)0;
+#pragma unroll
+                        for (int r = 0; r < MR; r++) if (r == (j >> 6)) bj = lw ? dlb[r] : dub[r];
+                        const R rj = -wv_bcast(bj, j & 63);
+                        if (lane == i) rhs = rj;
+                    }
+                    ydirty = na > 0;
+                }
+            }
+        }
+        if (!kept) {
             unsigned long long wm[MR], lm[MR];
 #pragma unroll
             for (int r = 0; r < MR; r++) {
@@ -1025,11 +1101,11 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 if (X != nullptr) (X + pid * P.nout)[(unsigned)ko] = xo;
             }
             if constexpr (sizeof(R) == 8 && !BNB) {
-                // scenario-asynchronous closed loop: advance this scenario in place (WaveSim; lane a < nx forms x+_a,
+                // closed loop with the plant step fused in: advance this scenario in place (WaveSim; lane a < nx forms x+_a,
                 // lane l < nu holds u_l).  A point handed to the slow path is advanced there, after its re-solve.
-                if (o0 == 0 && sim.kstep != nullptr && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
+                if (o0 == 0 && sim.FG != nullptr && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
                     const int snx = sim.nx, snu = sim.nu;
-                    const int k = sim.kstep[pid];
+                    const int k = sim.kfix >= 0 ? sim.kfix : sim.kstep[pid];
                     const int ar = lane < snx ? lane : 0;
                     double acc = 0.0;
                     for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[ar * snx + c], (double)th[c], acc);
@@ -1042,12 +1118,14 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     if (lane < sim.nup) to[snx + sim.nr + lane] = (double)xo;
                     if (lane < snu && sim.utraj) sim.utraj[((long long)k * sim.nscen + pid) * snu + lane] = (double)xo;
                     if (lane == 0) {
-                        if (sim.flag_min) sim.flag_min[pid] = k == 0 ? flag : (flag < sim.flag_min[pid] ? flag : sim.flag_min[pid]);
-                        sim.kstep[pid] = k + 1;
+                        // (smallest flag so far: an atomic, so that nothing waits for the old value to come back)
+                        if (sim.flag_min) { if (k == 0) sim.flag_min[pid] = flag; else atomicMin(&sim.flag_min[pid], flag); }
+                        if (sim.kfix < 0) sim.kstep[pid] = k + 1;
                     }
                 }
             }
         }
+        WVT(13);                                 // (trace: primal step, outputs, plant step)
         if (active) {
             unsigned long long wd[2 * MR + 1];
 #pragma unroll
@@ -1076,10 +1154,33 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             // (lmpc_big_kernel.hpp), which overwrites the outputs of this problem
             if (flag == EXIT_WSCAP && ovf_list != nullptr) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
         }
+        if constexpr (!BNB) {
+            if (bnb_i != nullptr) {                  // closed loop: this step's final working set and factor, kept
+                int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
+                R *sr = wv_uniform_ptr(bnb_r + pid * (long long)(2 * 64 + cap * (cap - 1) / 2));
+                if (flag >= 1) {
+                    __builtin_nontemporal_store(WSi, si + lane);
+                    __builtin_nontemporal_store(possoft | (posimm << 1) | (poslow << 2), si + 64 + lane);
+                    __builtin_nontemporal_store((int32_t)actb, si + 128 + lane);
+                    __builtin_nontemporal_store((int32_t)lowb, si + 192 + lane);
+                    __builtin_nontemporal_store(D, sr + lane);
+                    __builtin_nontemporal_store(Dinv, sr + 64 + lane);
+                    if (lane == 0) { __builtin_nontemporal_store(na, si + 256); __builtin_nontemporal_store(nsoft_act, si + 257); }
+                    const int ne = na * (na - 1) / 2;
+                    for (int e = lane; e < ne; e += 64) {
+                        int i, t;
+                        tri_row(e, i, t);
+                        __builtin_nontemporal_store(L[cbase(t) + i], sr + 128 + e);
+                    }
+                } else if (lane == 0) {
+                    __builtin_nontemporal_store(-1, si + 256);      // failed or handed to the slow path: the next step starts from the mask
+                }
+            }
+        }
+        WVT(14);                                 // (trace: masks, flags, kept state)
         clear_rows(1, na);                       // ZP: the next problem starts on a factor of zeros
         WVT(9);
         WVT_COUNT(11);
-        WVT_FLUSH;
         if (++kin < qchunk) {
             idx++;
         } else {
@@ -1088,6 +1189,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             idx = chunk * qchunk;
         }
     }
+    WVT_FLUSH;                                   // (trace: once per wavefront -- per problem the 16 atomics per flush, all
+                                                 // wavefronts on the same 16 words, held up the next problem's loads)
 }
 
 }  // namespace lmpc

@@ -110,21 +110,29 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     long long grid = (long long)h->numCU * blocksPerCU;
     const long long need = (nprob + cfg.nwv - 1) / cfg.nwv;
     if (grid > need) grid = need;
+    // The ticket counter and the overflow counter exist twice and are used alternately: the kernel of call k clears
+    // the pair of call k + 1 (nobody touches that pair during call k; calls on a handle are stream-ordered), so no
+    // launch needs a memset in front of it -- two 5 us fill kernels per launch, 4 % of a closed-loop step.
+    if (!h->dQueue) {
+        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, 64, st));
+        HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
+        h->waveCtrSet = 0;
+    }
+    int32_t *const ovfCount = h->dOvfCount + 8 * h->waveCtrSet;
+    int32_t *const queueNext = h->dQueue + 8 * (h->waveCtrSet ^ 1), *const ovfNext = h->dOvfCount + 8 * (h->waveCtrSet ^ 1);
     // more than two problems per resident wavefront: hand them out through the shared counter
     int32_t *queue = nullptr;
     int qchunk = 1;
     if (wl.list != nullptr && h->waveQueue) {
         // work-list mode: the length of the list is only known on the device -- one problem per ticket
-        if (!h->dQueue) HIP_TRY(h, hipMalloc(&h->dQueue, 64));
-        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
-        queue = h->dQueue;
+        queue = h->dQueue + 8 * h->waveCtrSet;
     } else if (nprob > 2 * grid * cfg.nwv && nprob < (int64_t)0x7fffffff && h->waveQueue) {
         // ~16 tickets per resident wavefront over the whole batch, at most 64 problems per ticket
         qchunk = (int)(nprob / (16 * grid * cfg.nwv));
         qchunk = qchunk < 1 ? 1 : (qchunk > 64 ? 64 : qchunk);
-        if (!h->dQueue) HIP_TRY(h, hipMalloc(&h->dQueue, 64));
-        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, sizeof(int32_t), st));
-        queue = h->dQueue;
+        queue = h->dQueue + 8 * h->waveCtrSet;
     }
     // working sets that can outgrow the 64 lanes (n + 1 + #soft > 64): such points are listed by the kernel and
     // re-solved behind it, one problem per thread (no branch and bound there)
@@ -136,12 +144,10 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
             HIP_TRY(h, hipMalloc(&h->dOvfList, sizeof(int32_t) * (size_t)nprob));
             h->ovfCap = nprob;
         }
-        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, 64));
         if (!h->dBigR) {     // sized for binary64: the binary32 calls of the handle use the same slices
             HIP_TRY(h, hipMalloc(&h->dBigR, sizeof(double) * (size_t)kBigThreads * (size_t)big_scratch_reals(Wl.n, Wl.m, bigCap)));
             HIP_TRY(h, hipMalloc(&h->dBigI, sizeof(int32_t) * (size_t)kBigThreads * (size_t)big_scratch_ints(Wl.m, bigCap)));
         }
-        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t), st));
     }
     // branch and bound: room for one snapshot of a node's state per search depth and resident wavefront (sized for
     // binary64; the binary32 calls of the handle use the same slices)
@@ -163,14 +169,21 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
         }
         bnbR = static_cast<R *>(h->dBnbR);
         bnbI = h->dBnbI;
+    } else if (h->keepOn && sizeof(R) == 8) {
+        // closed loop (lmpc_simulate_device, step-synchronous): every scenario's final working set and factor stay on
+        // the device between two steps, indexed by scenario
+        bnbR = static_cast<R *>(h->dKeepR);
+        bnbI = h->dKeepI;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
                        iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
-                       big ? h->dOvfList : nullptr, big ? h->dOvfCount : nullptr, h->waveSim, bnbR, bnbI, h->nBinary);
+                       big ? h->dOvfList : nullptr, big ? ovfCount : nullptr, h->waveSim, bnbR, bnbI, h->nBinary,
+                       queueNext, ovfNext);
+    h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());
     if (big) {
         hipLaunchKernelGGL(big_kernel<R>, dim3(kBigThreads / 64), dim3(64), 0, st, Wl, dC, h->dSw, theta, x, flag, iters,
-                           active, warm, h->dOvfList, h->dOvfCount, static_cast<R *>(h->dBigR), h->dBigI, bigCap, h->waveSim);
+                           active, warm, h->dOvfList, ovfCount, static_cast<R *>(h->dBigR), h->dBigI, bigCap, h->waveSim);
         HIP_TRY(h, hipGetLastError());
     }
     return LMPC_OK;

@@ -55,11 +55,12 @@ struct PackLayout {
 // sim_advance does on the lane path (lmpc_lane_kernel.hpp).  Binary64 only.
 struct WaveSim {
     const double *FG;            // F (nx*nx) then G (nx*nu), row-major
-    int *kstep;                  // per-scenario step counters; nullptr = off
+    int *kstep;                  // per-scenario step counters (scenario-asynchronous rounds); FG == nullptr = off
     double *utraj, *xtraj;       // (T, N, nu) / (T + 1, N, nx) or nullptr
     int *flag_min;               // smallest exit flag over the steps so far, or nullptr
     int nx, nu, nr, nup;
     long long nscen;
+    int kfix = -1;               // step-synchronous loop: the step every scenario is at (no counters); -1: kstep[]
 };
 
 struct WaveLayout {

@@ -108,6 +108,7 @@ typedef struct {
     real primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int32_t cycle_tol, iter_limit;
     int32_t mode;
+    int32_t cap_check;     /* internal: the n-chain form also stops (EXIT_WSCAP) where a working set would outgrow 64 rows */
 } oracle_settings;
 
 static oracle_settings settings_from_abi(const oracle_settings_abi *a) {
@@ -116,6 +117,7 @@ static oracle_settings settings_from_abi(const oracle_settings_abi *a) {
     s.progress_tol = (real)a->progress_tol; s.fval_bound = (real)a->fval_bound; s.rho_soft = (real)a->rho_soft;
     s.cycle_tol = a->cycle_tol; s.iter_limit = a->iter_limit;
     s.mode = a->mode;
+    s.cap_check = 0;
     return s;
 }
 
@@ -485,6 +487,11 @@ static void shift_bounds(work_t *w, const oracle_ldp *p, const real *theta) {
  *     enters the working set as the first step, exactly as a violated row would -- the dual iterate
  *     of the parent stays feasible for the child, which is what makes a dual active-set method cheap
  *     inside branch and bound (the reference gets this from daqp_bnb, [EXT]).
+ *   forced == -2: continue from the working set AND factorisation left in w by the previous solve of the same
+ *     problem family (closed loop with a kept factor, oracle_simulate warm == 2): only the bounds have moved.
+ *     This is libdaqp's DAQP_WARMSTART as the generated code uses it -- the workspace is not cleared between two
+ *     calls, only the cached forward solve is (reuse_ind = 0; /root/reference/codegen/mpc_update_qp.c:44-54).
+ *     The multipliers restart at zero (dual feasible for any bounds).
  * Leaves the iterate in w (u, fval, working set) and returns the DAQP-style exit flag. */
 static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, const int32_t *sense0,
                       const uint64_t *warm, int two_pass, int forced, int32_t *iters) {
@@ -493,7 +500,12 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
     int exitflag = EXIT_ITERLIMIT, iter = 1, cycle = 0;
     real best_fval = -1.0;
 
-    if (forced < 0) {
+    const int capped = gram || s->cap_check;
+    if (forced == -2) {
+        w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->ydirty = 1;
+        for (int k = 0; k < n; k++) w->u[k] = 0.0;
+        for (int i = 0; i < w->na; i++) { w->lam[i] = 0.0; w->lam_star[i] = 0.0; }
+    } else if (forced < 0) {
         for (int j = 0; j < m; j++) w->sense[j] = sense0[j] & ~SENSE_LOWER;
         w->na = 0; w->sing = -1; w->reuse = 0; w->fval = 0.0; w->soft_slack = 0.0; w->nsoft_act = 0;
         w->ydirty = 0;
@@ -510,10 +522,9 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
                 }
                 if (!want) { w->sense[j] &= ~SENSE_ACTIVE; continue; }
                 if (lower) w->sense[j] |= SENSE_LOWER;
-                if (gram) {
-                    if (w->na >= w->cap64) { exitflag = EXIT_WSCAP; goto done; }
-                    ldl_add_gram(w, s, j);
-                } else ldl_add(w, p, s, j);
+                if (capped && w->na >= w->cap64) { exitflag = EXIT_WSCAP; goto done; }
+                if (gram) ldl_add_gram(w, s, j);
+                else ldl_add(w, p, s, j);
                 if (w->sing >= 0) {
                     if (sense0[j] & SENSE_IMMUTABLE) { exitflag = EXIT_OVERDETERMINED_INITIAL; goto done; }
                     /* dependent warm-start row: drop it again */
@@ -583,10 +594,9 @@ static int solve_core(work_t *w, const oracle_ldp *p, const oracle_settings *s, 
             if (add >= 0) {
                 for (int i = 0; i < w->na; i++) w->lam[i] = w->lam_star[i];
                 if (!isupper) w->sense[add] |= SENSE_LOWER;
-                if (gram) {
-                    if (w->na >= w->cap64) { exitflag = EXIT_WSCAP; break; }
-                    ldl_add_gram(w, s, add);
-                } else ldl_add(w, p, s, add);
+                if (capped && w->na >= w->cap64) { exitflag = EXIT_WSCAP; break; }
+                if (gram) ldl_add_gram(w, s, add);
+                else ldl_add(w, p, s, add);
                 if (w->fval - best_fval < s->progress_tol) {
                     if (++cycle > s->cycle_tol) { exitflag = EXIT_CYCLE; break; }
                 } else { best_fval = w->fval; cycle = 0; }
@@ -631,6 +641,29 @@ static int solve_one(work_t *w, const oracle_ldp *p, const oracle_settings *s,
         ef = solve_core(w, p, &s0, p->sense, warm, 0, -1, iters);
     }
     write_outputs(w, p, theta, xout, active, nwords);
+    return ef;
+}
+
+/* One step of a closed loop that keeps the factorisation (oracle_simulate warm == 2; the twin of the wavefront
+ * kernel's kept state, lmpc_simulate_device on that path).  *kept != 0: w holds the final working set, L and D of this
+ * scenario's previous step -> continue from them (solve_core forced == -2).  Otherwise the mask-based start of
+ * solve_one.  A working set that would outgrow 64 rows is re-solved from the mask in the n-chain form without the
+ * limit (the kernel hands such a point to its slow path) and nothing is kept after it; nothing is kept after a
+ * failed solve either. */
+static int solve_one_keep(work_t *w, const oracle_ldp *p, const oracle_settings *s, const real *theta,
+                          const uint64_t *warm, int *kept, real *xout, int32_t *iters, uint64_t *active, int nwords) {
+    oracle_settings sc = *s;
+    sc.cap_check = 1;
+    shift_bounds(w, p, theta);
+    int ef = solve_core(w, p, &sc, p->sense, *kept ? NULL : warm, 0, *kept ? -2 : -1, iters);
+    int fellback = 0;
+    if (ef == EXIT_WSCAP) {
+        sc.mode = 0; sc.cap_check = 0;
+        ef = solve_core(w, p, &sc, p->sense, warm, 0, -1, iters);
+        fellback = 1;
+    }
+    write_outputs(w, p, theta, xout, active, nwords);
+    *kept = ef >= 1 && !fellback;
     return ef;
 }
 
@@ -811,7 +844,9 @@ void ORACLE_NAME(oracle_solve_batch_repeat)(const oracle_ldp *p, const oracle_se
  * (/root/reference/src/simulation.jl:93-113): theta = [x; r; uprev] (src/explicit.jl:54-63),
  * u = compute_control, x <- F x + G u (sums in index order, F then G), uprev <- u.
  * warm != 0 reuses the previous step's final working set (generated-C DAQP_WARMSTART,
- * /root/reference/codegen/mpc_update_qp.c:44-47); the first step is cold.  nout must equal nu. */
+ * /root/reference/codegen/mpc_update_qp.c:44-47); the first step is cold: warm == 1 re-appends its rows in
+ * index order from the mask, warm == 2 continues from the kept factorisation in working-set order
+ * (solve_one_keep).  nout must equal nu. */
 void oracle_simulate(const oracle_ldp *p, const oracle_settings_abi *sabi, int64_t N, int32_t T, int32_t nx,
                      int32_t nr, int32_t nup, const real *F, const real *G, real *x,
                      const real *r, real *uprev, real *U, real *X, int32_t *flag_min,
@@ -827,6 +862,7 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings_abi *sabi, int64
     real *u = (real *)calloc(nu, sizeof(real));
     real *xn = (real *)calloc(nx, sizeof(real));
     uint64_t *act = (uint64_t *)calloc(nw, sizeof(uint64_t));
+    int kept = 0;
     for (int64_t i = 0; i < N; i++) {
         real *xi = x + i * nx;
         if (X) for (int a = 0; a < nx; a++) X[(size_t)i * nx + a] = xi[a];
@@ -835,8 +871,12 @@ void oracle_simulate(const oracle_ldp *p, const oracle_settings_abi *sabi, int64
             for (int a = 0; a < nr; a++) th[nx + a] = r ? r[i * nr + a] : 0.0;
             for (int a = 0; a < nup; a++) th[nx + nr + a] = uprev ? uprev[i * nup + a] : 0.0;
             int32_t it = 0;
-            int ef = nbin ? solve_bnb(w, p, s, th, u, &it, act, nw)      /* B&B nodes start cold */
-                          : solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
+            int ef;
+            if (nbin) ef = solve_bnb(w, p, s, th, u, &it, act, nw);      /* B&B nodes start cold */
+            else if (warm == 2) {
+                if (k == 0) kept = 0;
+                ef = solve_one_keep(w, p, s, th, k > 0 ? act : NULL, &kept, u, &it, act, nw);
+            } else ef = solve_one(w, p, s, th, (warm && k > 0) ? act : NULL, u, &it, act, nw);
             for (int a = 0; a < nx; a++) {
                 real acc = 0.0;
                 for (int c = 0; c < nx; c++) acc = RFMA(F[a * nx + c], xi[c], acc);

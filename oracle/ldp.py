@@ -257,7 +257,7 @@ def simulate(ldp: LDP, x0, T, F, G, r=None, uprev=None, settings: Settings | Non
     fn(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), ctypes.c_int32(T), ctypes.c_int32(nx),
        ctypes.c_int32(nr), ctypes.c_int32(nup), vp(F.ctypes.data), vp(G.ctypes.data), vp(x.ctypes.data),
        vp(rr.ctypes.data) if rr is not None else None, vp(up.ctypes.data), vp(U.ctypes.data),
-       vp(X.ctypes.data), vp(fm.ctypes.data), ctypes.c_int32(int(bool(warm))))
+       vp(X.ctypes.data), vp(fm.ctypes.data), ctypes.c_int32(int(warm) if isinstance(warm, int) and not isinstance(warm, bool) else int(bool(warm))))
     return dict(x=x, U=U, X=X, uprev=up[:, :nup], flag_min=fm)
 
 

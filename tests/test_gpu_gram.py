@@ -190,7 +190,8 @@ def test_gram_form_closed_loop(lmpc):
     x0 = rng.uniform(0, 0.5, (N, 2)); x0[0] = 0.0
     r = np.tile([1.0, 0.0], (N, 1))
     for warm in (False, True):
-        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=warm, settings=_gram_settings())
+        # (the wavefront path's warm loop keeps every scenario's factorisation: the oracle's warm == 2)
+        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=2 if warm else False, settings=_gram_settings())
         out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
         assert np.array_equal(out["flag_min"], ref["flag_min"])
         assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])
@@ -221,6 +222,7 @@ def test_wave_path_closed_loop_asynchronous_rounds(lmpc, name, gram):
         pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
         x0, r = pick[:, :4].copy(), pick[:, 4:6].copy()
     so = _gram_settings() if gram else oldp.default_settings()
+    qp.set_option("sim_keep_factor", 0)            # the mask-based warm start: what the asynchronous rounds use
     for warm in (True, False):
         ref = oldp.simulate(L, x0, T, F, G, r=r, warm=warm, settings=so)
         outs = []
@@ -232,3 +234,47 @@ def test_wave_path_closed_loop_asynchronous_rounds(lmpc, name, gram):
             assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])
             assert np.array_equal(out["x"], ref["x"])
         assert (ref["flag_min"] >= 1).mean() > 0.5
+
+
+@pytest.mark.parametrize("name,gram", [("pendulum_N50", 0), ("pendulum_N50", 1), ("soft_doc", 0), ("soft_doc", 1)])
+def test_wave_path_closed_loop_keeps_the_factorisation(lmpc, name, gram):
+    """The wavefront path's warm closed loop (default): every scenario's final working set stays on the device with
+    its L and D, in its order, and the next step continues from it (what DAQP_WARMSTART means for libdaqp's workspace,
+    /root/reference/codegen/mpc_update_qp.c:44-54).  Bit for bit the oracle's warm == 2 in both forms; the same
+    optimum as the mask-based warm start and as the cold loop (K6's 1e-9 criterion, test/runtests.jl:85-117); fewer
+    iterations than the mask-based start never hurts correctness, so only the results are compared."""
+    from oracle import ldp as oldp
+    from oracle import mpc2mpqp as omm
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_option("gram_scan", gram)
+    L = oracle_ldp_from(qp.ldp())
+    rng = np.random.default_rng(23)
+    if name == "soft_doc":
+        prob = omm.doc_simple_soft()
+        F, G = prob.F, prob.G
+        N, T = 3000, 25
+        x0 = rng.uniform(-0.2, 0.7, (N, 2)); x0[0] = 0.0
+        r = np.tile([1.0, 0.0], (N, 1)); r[N // 2:] = [0.3, 0.0]
+    else:
+        F, G = g["F"], g["G"]
+        N, T = 4000, 40
+        base = g["theta"][:int(g["n_closed_loop"])]
+        pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+        x0, r = pick[:, :4].copy(), pick[:, 4:6].copy()
+    so = _gram_settings() if gram else oldp.default_settings()
+    ref = oldp.simulate(L, x0, T, F, G, r=r, warm=2, settings=so)
+    out = qp.simulate(x0, T, F, G, r=r, warm=True)
+    again = qp.simulate(x0, T, F, G, r=r, warm=True)       # (the kept states of the first run are not reused)
+    for o in (out, again):
+        assert np.array_equal(o["flag_min"], ref["flag_min"])
+        assert np.array_equal(o["U"], ref["U"]) and np.array_equal(o["X"], ref["X"]) and np.array_equal(o["x"], ref["x"])
+    assert (ref["flag_min"] >= 1).mean() > 0.5
+    qp.set_option("sim_keep_factor", 0)
+    mask = qp.simulate(x0, T, F, G, r=r, warm=True)
+    cold = qp.simulate(x0, T, F, G, r=r, warm=False)
+    ok = (ref["flag_min"] >= 1) & (mask["flag_min"] >= 1) & (cold["flag_min"] >= 1)
+    assert ok.mean() > 0.5
+    # the same optimum up to the tolerances: a soft row inside the primal_tol band (1e-6) may end on either side of it,
+    # depending on where the iterations started (4e-7 in u among 4000 x 40 steps of the N = 50 problem)
+    assert np.abs(out["U"][:, ok] - mask["U"][:, ok]).max() < 1e-5 and np.abs(out["U"][:, ok] - cold["U"][:, ok]).max() < 1e-5

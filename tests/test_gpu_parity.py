@@ -531,7 +531,8 @@ def test_closed_loop_simulation_soft_problem_wave_kernel(lmpc):
     x0 = rng.uniform(0, 0.5, (N, 2)); x0[0] = 0.0
     r = np.tile([1.0, 0.0], (N, 1))
     for warm in (False, True):
-        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=warm)
+        # (warm on the wavefront path: the factorisation is kept between two steps -- the oracle's warm == 2)
+        ref = oldp.simulate(L, x0, T, prob.F, prob.G, r=r, warm=2 if warm else False)
         out = qp.simulate(x0, T, prob.F, prob.G, r=r, warm=warm)
         assert np.array_equal(out["flag_min"], ref["flag_min"])
         assert np.abs(out["U"] - ref["U"]).max() <= TOL and np.abs(out["X"] - ref["X"]).max() <= TOL

@@ -29,6 +29,7 @@ ap.add_argument("--problem", default="pendulum",
 ap.add_argument("--screen-wave", type=int, default=1, help="screening pass in front of the wavefront kernel")
 ap.add_argument("--settled", type=float, default=0.0, help="fraction of the scenarios that start at rest on their reference (no step of theirs needs iterations)")
 ap.add_argument("--gram", type=int, default=0, help="wavefront kernel: Gram-scan form (lmpc_set_option gram_scan)")
+ap.add_argument("--keep", type=int, default=1, help="wavefront path, warm: keep every scenario's factorisation between two steps (lmpc_set_option sim_keep_factor)")
 a = ap.parse_args()
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", a.problem + ".npz")))
 sys.path.insert(0, ROOT)
@@ -42,6 +43,7 @@ print("kernel:", qp.kernel_name)
 if qp.kernel_name == "wave":
     qp.set_option("screen_wave", a.screen_wave)
     qp.set_option("gram_scan", a.gram)
+    qp.set_option("sim_keep_factor", a.keep)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
 qp.set_option("sim_small", a.small)
