@@ -238,7 +238,12 @@ int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
  * u = compute_control (the batched solve of this handle, which must have been set up with
  * nout = nu and, if used, the prestabilising feedback folded in), x <- F x + G u, uprev <- u.
  * warm != 0 starts each solve from the previous step's final working set (the reference's
- * DAQP_WARMSTART build, codegen/mpc_update_qp.c:44-47); the first step is cold.
+ * DAQP_WARMSTART build, codegen/mpc_update_qp.c:44-47); the first step is cold.  On the wavefront-kernel
+ * path (binary64, no binaries) the working set comes back WITH its factorisation, in its order -- libdaqp's
+ * workspace under DAQP_WARMSTART is simply not cleared between two calls (mpc_update_qp.c:44-54) -- kept per
+ * scenario in device memory (17 KB at the largest capacity); lmpc_set_option "sim_keep_factor" 0 re-appends the
+ * rows of the previous step's mask instead, as the lane kernels and the binary32 loop do.  Either way the
+ * inputs are those of the cold loop up to the tolerances (K6, test/runtests.jl:85-117).
  *
  *   nx + nr + nuprev must equal nth.  F[nx*nx], G[nx*nu] row-major HOST arrays (the plant).
  *   x      N records of nx: in = initial states, out = states after T steps
@@ -421,7 +426,12 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two
  * reads of the work-list counters; "sim_small" (default 1) = the all-in-registers instantiation
  * of the streaming kernel for single-input problems with nx <= 4, m <= 8; "sim_fused" (default 1) = plant step inside the solve's
- * kernels.  All of them change the execution order only, never a result. */
+ * kernels (lane kernels; round 3: the wavefront-kernel path's lock-step loop too).  All of them change the execution
+ * order only, never a result.  "sim_keep_factor" (default 1; wavefront-kernel path, warm closed loop) = continue each
+ * step from the kept factorisation instead of re-appending the previous mask's rows: same optimum up to the
+ * tolerances, last bits of u may differ (checker: oracle_simulate warm = 2 against warm = 1).
+ * hipGraph capture of calls on one handle: the work-list and ticket counters alternate between two sets, each call
+ * clearing the set of the next one -- capture an EVEN number of calls per handle. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
 
 /* Distinct optimal active sets of a solved batch, reduced on the device: the caller side of a sampling-based
