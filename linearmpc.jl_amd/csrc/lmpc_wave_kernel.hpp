@@ -1126,7 +1126,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             }
         }
         WVT(13);                                 // (trace: primal step, outputs, plant step)
-        if (active) {
+        // (a point handed to the slow path keeps its mask: in a closed loop `active` IS the warm-start buffer the slow
+        // path is about to start from, and what this kernel holds is a working set that was cut off at 64 rows)
+        if (active && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
             unsigned long long wd[2 * MR + 1];
 #pragma unroll
             for (int q = 0; q < 2 * MR + 1; q++) wd[q] = 0ull;

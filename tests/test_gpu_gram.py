@@ -278,3 +278,89 @@ def test_wave_path_closed_loop_keeps_the_factorisation(lmpc, name, gram):
     # the same optimum up to the tolerances: a soft row inside the primal_tol band (1e-6) may end on either side of it,
     # depending on where the iterations started (4e-7 in u among 4000 x 40 steps of the N = 50 problem)
     assert np.abs(out["U"][:, ok] - mask["U"][:, ok]).max() < 1e-5 and np.abs(out["U"][:, ok] - cold["U"][:, ok]).max() < 1e-5
+
+
+@pytest.mark.parametrize("gram", [0, 1])
+def test_wave_path_closed_loop_random_shapes_keep_and_mask_start(lmpc, gram):
+    """Random controllers on the wavefront path -- general rows, soft rows, one to three inputs, with and without a
+    previous-control block, up to three constraint slots per lane, scenario counts that are no multiple of a
+    wavefront -- closed loop against the oracle bit for bit: the kept factorisation (oracle warm = 2), the mask start
+    (`sim_keep_factor` 0, oracle warm = 1), the cold loop; fused plant step and the unfused loop agree bit for bit."""
+    from oracle import ldp as oldp
+    from test_gpu_parity import _random_qp
+    rng = np.random.default_rng(1234 + gram)
+    shapes = [(2, 1, 0, 1, 6, 20, 4), (4, 1, 2, 1, 8, 60, 0), (3, 2, 1, 2, 10, 30, 6), (6, 2, 1, 0, 12, 130, 10),
+              (5, 3, 0, 3, 9, 45, 3), (8, 1, 2, 1, 20, 70, 12), (4, 1, 0, 0, 30, 100, 0)]
+    for nx, nu, nr, nup, n, mg, nsoft in shapes:
+        nth = nx + nr + nup
+        H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=nsoft)
+        f_theta *= 0.6
+        qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+        qp.set_option("wave", 1)
+        assert qp.kernel_name == "wave"
+        qp.set_option("gram_scan", gram)
+        Fm = rng.standard_normal((nx, nx))
+        Fm *= 0.9 / np.abs(np.linalg.eigvals(Fm)).max()
+        Gm = 0.5 * rng.standard_normal((nx, nu))
+        N, T = 333, 20
+        x0 = rng.uniform(-2, 2, (N, nx))
+        r = rng.uniform(-1, 1, (N, nr)) if nr else None
+        L = oracle_ldp_from(qp.ldp())
+        so = _gram_settings() if gram else oldp.default_settings()
+        for keep, owarm, warm in ((1, 2, True), (0, 1, True), (1, False, False)):
+            qp.set_option("sim_keep_factor", keep)
+            ref = oldp.simulate(L, x0, T, Fm, Gm, r=r, warm=owarm, settings=so)
+            outs = []
+            for fused in (1, 0):
+                qp.set_option("sim_fused", fused)
+                outs.append(qp.simulate(x0, T, Fm, Gm, r=r, warm=warm))
+            qp.set_option("sim_fused", 1)
+            for out in outs:
+                for key in ("U", "X", "x", "flag_min"):
+                    assert np.array_equal(out[key], ref[key]), (nx, nu, nr, nup, n, mg, nsoft, keep, warm, key)
+            assert (outs[0]["U"] != 0).any()
+
+
+@pytest.mark.parametrize("gram", [0, 1])
+def test_wave_path_closed_loop_kept_factor_through_the_64_row_limit(lmpc, gram):
+    """Closed loop whose working sets cross the wavefront kernel's 64 rows: scenarios start with 60..150 soft rows active
+    and decay into the small-working-set regime.  A step that wants more than 64 rows is re-solved by the slow path
+    from the mask (n-chain arithmetic) and keeps nothing; the step after it starts from that mask; later steps keep
+    their factorisation again.  The oracle's warm = 2 takes the same decisions (`solve_one_keep`)."""
+    from oracle import ldp as oldp
+    from test_gpu_parity import _random_qp
+    rng = np.random.default_rng(5)
+    n, mg, nth = 6, 150, 2
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=mg)
+    W[n:, 0] = np.abs(W[n:, 0]) + 0.5                    # theta_0 >> 0 pushes every soft row over its bound
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
+    qp.set_option("gram_scan", gram)
+    assert qp.kernel_name == "wave"
+    N, T = 150, 30
+    x0 = np.vstack([rng.uniform(-1, 1, (60, 2)), np.hstack([rng.uniform(20, 60, (N - 60, 1)), rng.uniform(-1, 1, (N - 60, 1))])])
+    Fm = np.array([[0.8, 0.05], [0.0, 0.7]])
+    Gm = 0.05 * rng.standard_normal((2, 2))
+    L = oracle_ldp_from(qp.ldp())
+    so = _gram_settings() if gram else oldp.default_settings()
+    ref = oldp.simulate(L, x0, T, Fm, Gm, warm=2, settings=so)
+    # the run really crosses the limit, in both directions
+    th = np.hstack([x0])
+    _, _, _, act0 = oldp.solve_batch(L, th, so)
+    nact0 = np.array([sum(bin(int(w)).count("1") for w in row) for row in act0])
+    assert (nact0 > 64).sum() >= 30 and (nact0 <= 64).sum() >= 30
+    xT = ref["x"]
+    _, _, _, actT = oldp.solve_batch(L, xT, so)
+    assert max(sum(bin(int(w)).count("1") for w in row) for row in actT) <= 64
+    for fused in (1, 0):
+        qp.set_option("sim_fused", fused)
+        out = qp.simulate(x0, T, Fm, Gm, warm=True)
+        for key in ("U", "X", "x", "flag_min"):
+            assert np.array_equal(out[key], ref[key]), (fused, key)
+    assert (ref["flag_min"] >= 1).all()
+    # the mask start through the same run (until round 3 the wavefront kernel overwrote the mask of a point it handed to
+    # the slow path with its cut-off working set -- in a closed loop that mask is what the slow path starts from)
+    qp.set_option("sim_keep_factor", 0)
+    ref1 = oldp.simulate(L, x0, T, Fm, Gm, warm=1, settings=so)
+    out1 = qp.simulate(x0, T, Fm, Gm, warm=True)
+    for key in ("U", "X", "x", "flag_min"):
+        assert np.array_equal(out1[key], ref1[key]), key
