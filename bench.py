@@ -503,6 +503,79 @@ def region_discovery_config(torch, lmpc, dev, local_rank, nsamples, want_cpu, re
     return res
 
 
+def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, gram=0, reps=2, ncheck=48):
+    """SURVEY 8(f-1) as a measured workload: `nscen` closed loops of `T` steps on the device (lmpc_simulate_device,
+    warm; theta = [x; r; uprev] -> solve -> x <- F x + G u, /root/reference/src/simulation.jl:93-113), scenario-steps
+    per second.  name "pendulum": the headline problem (lane kernels, scenario-asynchronous loop); "pendulum_N50": the
+    benchmark class's N = 50 problem (soft state rows; wavefront kernel, step-synchronous loop that keeps every
+    scenario's factorisation between steps).  Verified: the first `ncheck` scenarios against the CPU checker's closed
+    loop bit for bit (scenarios are independent of each other)."""
+    import ctypes
+    from linearmpc_jl_amd._cabi import lib as _lib, check as _check
+    g = make_problem(name)
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1,
+                                  device=local_rank)
+    if qp.kernel_name == "wave":
+        qp.set_option("gram_scan", gram)
+    rng = np.random.default_rng(0)
+    if "n_closed_loop" in g:
+        base = g["theta"][:int(g["n_closed_loop"])]
+        pick = base[rng.integers(0, len(base), nscen)] + rng.normal(size=(nscen, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+        x0, r0 = np.ascontiguousarray(pick[:, :4]), np.ascontiguousarray(pick[:, 4:6])
+        F, G = g["F"], g["G"]
+    else:
+        from oracle import mpc2mpqp as omm
+        prob = omm.pendulum()
+        F, G = prob.F, prob.G
+        x0 = rng.uniform([-5, -5, -.3, -2], [5, 5, .3, 2], (nscen, 4))
+        r0 = np.stack([rng.uniform(-2, 2, nscen), np.zeros(nscen)], 1)
+    nx, nu = F.shape[0], 1
+    Fc = np.ascontiguousarray(F, np.float64); Gc = np.ascontiguousarray(np.asarray(G, np.float64).reshape(nx, nu))
+    vp = lambda a: ctypes.c_void_p(a)
+    xd0 = torch.from_numpy(x0).to(dev); rd = torch.from_numpy(r0).to(dev)
+    fm = torch.empty(nscen, dtype=torch.int32, device=dev)
+    L_ = _lib()
+    def run():
+        xd = xd0.clone(); up = torch.zeros((nscen, 1), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _check(L_.lmpc_simulate_device(qp._h, nscen, T, nx, 2, 1, vp(Fc.ctypes.data), vp(Gc.ctypes.data), vp(xd.data_ptr()),
+                                       vp(rd.data_ptr()), vp(up.data_ptr()), None, None, vp(fm.data_ptr()), 1, None), qp._h)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, xd, up
+    run()
+    best, xd, up = min((run() for _ in range(reps)), key=lambda t: t[0])
+    res = {"value": nscen * T / best, "unit": "scenario-steps/s", "ms_per_step": 1e3 * best / T, "scenarios": nscen, "steps": T,
+           "kernel": qp.kernel_name, "dtype": "f64", "warm": True, "min_flag": int(fm.min().item()),
+           "options": ({"gram_scan": gram} if qp.kernel_name == "wave" else {}),
+           "workload": f"{name}: closed loop, states and references resident on the device, no trajectories recorded"}
+    # verification against the checker's closed loop on the first scenarios
+    from oracle import ldp as oldp
+    global _NATIVE_FLAGS
+    if _NATIVE_FLAGS is None:
+        _NATIVE_FLAGS = oldp.use_native()
+    pk = qp.ldp()                      # the handle's own LDP (what the tests compare on): same pack, same bits
+    Lq = oldp.LDP(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["M"], pk["du"], pk["dl"], pk["Dth"],
+                  pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"]))
+    so = oldp.default_settings(); so.mode = 1 if (gram and qp.kernel_name == "wave") else 0
+    owarm = 2 if qp.kernel_name == "wave" else True
+    t1 = time.perf_counter()
+    ref = oldp.simulate(Lq, x0[:ncheck], T, F, G, r=r0[:ncheck], uprev=np.zeros((ncheck, 1)), settings=so, warm=owarm)
+    dtc = time.perf_counter() - t1
+    xg = xd[:ncheck].cpu().numpy(); ug = up[:ncheck].cpu().numpy()
+    if os.environ.get("LMPC_BENCH_DEBUG"): print("closed loop check:", np.abs(xg - ref["x"]).max(), np.abs(ug - ref["uprev"]).max(), fm[:ncheck].cpu().numpy(), ref["flag_min"], file=sys.stderr)
+    res["verified"] = bool(np.array_equal(xg, ref["x"]) and np.array_equal(ug, ref["uprev"])
+                           and np.array_equal(fm[:ncheck].cpu().numpy(), ref["flag_min"]))
+    res["verification"] = {"scenarios": ncheck, "against": f"oracle_simulate warm={owarm!r} mode={so.mode}",
+                           "final_states_and_inputs_bit_identical": res["verified"]}
+    if want_cpu:
+        res["cpu_baseline"] = {"value": ncheck * T / dtc, "unit": "scenario-steps/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {ncheck} scenarios x {T} steps: oracle/daqp_ldp_oracle.c oracle_simulate, "
+                                         f"1 thread ({_cpu_model()}) {_NATIVE_FLAGS}"}
+    qp.close()
+    return res
+
+
 def multi_abi_isolated(torch, n_per_dev, timeout_s=180):
     """multi_abi_check in a CHILD process (`bench.py --multi-abi-only N`): the nd > 1 branch of the library has never
     run on hardware, so whatever it does the first time -- raise, hang, crash inside librccl -- must not take the
@@ -964,6 +1037,11 @@ def main():
                                                      "plot +-10 %, hardware unstated, state constraints of the benchmark script "
                                                      "unpublished (this fixture uses its own, see DESIGN.md)"}
                 cfgs[f"pendulum_N{n_}"] = c_
+            _phase("config closed_loop")
+            cfgs["closed_loop_pendulum"] = closed_loop_config(torch, lmpc, "pendulum", BATCH, 100, dev, local_rank, want_cpu)
+            cfgs["closed_loop_pendulum_N50"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev, local_rank, want_cpu)
+            cfgs["closed_loop_pendulum_N50"]["gram_scan_form"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev,
+                                                                                    local_rank, False, gram=1)
             _phase("config region_discovery")
             cfgs["region_discovery"] = region_discovery_config(torch, lmpc, dev, local_rank, BATCH, want_cpu)
             out["configs"] = cfgs
