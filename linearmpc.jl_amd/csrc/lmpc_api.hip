@@ -879,7 +879,13 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         const size_t keepR = 2 * 64 + (size_t)h->W.cap * (h->W.cap - 1) / 2, keepI = 5 * 64;
         if (N > h->keepCap) {
             hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
-            if (hipMalloc(&h->dKeepR, sizeof(double) * keepR * (size_t)N) == hipSuccess &&
+            // (17 GB for 1e6 scenarios at capacity 64: only while it is at most half of what the device has free --
+            // beyond that the loop runs on masks rather than crowding out the caller)
+            size_t freeB = 0, totalB = 0;
+            const size_t needB = (sizeof(double) * keepR + sizeof(int32_t) * keepI) * (size_t)N;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+            if (needB <= freeB / 2 &&
+                hipMalloc(&h->dKeepR, sizeof(double) * keepR * (size_t)N) == hipSuccess &&
                 hipMalloc(&h->dKeepI, sizeof(int32_t) * keepI * (size_t)N) == hipSuccess) h->keepCap = N;
             else { hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; (void)hipGetLastError(); }
         }
