@@ -392,6 +392,14 @@ int lmpc_compute_control_observer_device(lmpc_handle *h, int64_t N, double *cont
 /* Which kernel variant the handle dispatches to (for benchmark reports), e.g. "lane<5>". */
 const char *lmpc_kernel_name(const lmpc_handle *h);
 
+/* Working-set statistics of the wavefront kernel, as the handle last saw them (cumulative over its launches, a launch or
+ * two behind; read from mapped host memory, no synchronisation): out[0] problems the kernel finished, out[1..3] of them
+ * those whose working set never held more than 24 / 32 / 48 rows, out[4] the working-set capacity of the first pass the
+ * next call would use (0 = one pass).  This is what decides whether a batch first runs at a smaller capacity
+ * (lmpc_set_option "wave_two_pass"); reported for benchmark logs and tests.  Returns LMPC_OK (all zeros before the
+ * first wavefront-kernel launch). */
+int lmpc_wave_stats(lmpc_handle *h, unsigned long long out[5]);
+
 /* Device time per lmpc_solve_batch* call, measured with HIP events recorded on the launch
  * stream (switch on with lmpc_profile(h, 1); timing-only events, hipEventDisableSystemFence: a default event's
  * system-scope cache writeback added ~1.7 us to a 24 us call that rocprofv3's kernel trace does not see).  lmpc_profile_read waits for the recorded calls,
@@ -430,6 +438,11 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * order only, never a result.  "sim_keep_factor" (default 1; wavefront-kernel path, warm closed loop) = continue each
  * step from the kept factorisation instead of re-appending the previous mask's rows: same optimum up to the
  * tolerances, last bits of u may differ (checker: oracle_simulate warm = 2 against warm = 1).
+ * Wavefront kernel, working-set capacity: "wave_two_pass" (default -1 = decided by the handle's statistics, see
+ * lmpc_wave_stats; 0 = never; 1 = always, at "wave_cap1" rows, default 24) = run a batch first at a smaller capacity
+ * (more wavefronts resident) and hand the points that outgrow it to a second launch at the full capacity;
+ * "wave_cap" c (8 .. 64, 0 = the problem's own) = the full capacity itself, points beyond it go to the slow path.
+ * Neither changes a result.
  * hipGraph capture of calls on one handle: the work-list and ticket counters alternate between two sets, each call
  * clearing the set of the next one -- capture an EVEN number of calls per handle. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);

@@ -31,7 +31,7 @@ SYMBOLS = (
     "lmpc_setup_multi", "lmpc_multi_devices", "lmpc_multi_handle", "lmpc_multi_partition",
     "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
     "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch", "lmpc_check",
-    "lmpc_distinct_active_sets_device", "lmpc_distinct_active_sets_overflowed",
+    "lmpc_distinct_active_sets_device", "lmpc_distinct_active_sets_overflowed", "lmpc_wave_stats",
 )
 
 
@@ -174,6 +174,9 @@ def lib():
         L.lmpc_distinct_active_sets_device.restype = i32
         L.lmpc_distinct_active_sets_overflowed.argtypes = [vp, vp]
         L.lmpc_distinct_active_sets_overflowed.restype = i32
+    if hasattr(L, "lmpc_wave_stats"):
+        L.lmpc_wave_stats.argtypes = [vp, vp]
+        L.lmpc_wave_stats.restype = i32
     if hasattr(L, "lmpc_check"):              # (an older build selected with LMPC_HIP_LIB for an A/B lacks it)
         L.lmpc_check.argtypes = [vp]
         L.lmpc_check.restype = i32

@@ -123,6 +123,7 @@ int finalize_handle(lmpc_handle *h) {
         WaveLayout &Wl = h->W;
         Wl.n = P.n; Wl.m = P.m; Wl.ms = P.ms; Wl.nth = P.nth; Wl.nout = P.nout; Wl.words = P.words();
         Wl.cap = cap; Wl.ldc = cap | 1;
+        Wl.keepStride = 2 * 64 + cap * (cap - 1) / 2;
         int o = 0;
         Wl.oM = o; o += P.m * P.n;
         Wl.oMt = o; o += P.m * P.n;
@@ -876,7 +877,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // by one.  Option "sim_keep_factor" 0 (or no memory for it): the mask-based warm start of the other paths.
     h->keepOn = false;
     if (h->useWave && warm && !h->bnb && h->simKeep && T > 1) {
-        const size_t keepR = 2 * 64 + (size_t)h->W.cap * (h->W.cap - 1) / 2, keepI = 5 * 64;
+        const size_t keepR = (size_t)h->W.keepStride, keepI = 5 * 64;
         if (N > h->keepCap) {
             hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
             // (17 GB for 1e6 scenarios at capacity 64: only while it is at most half of what the device has free --
@@ -1403,6 +1404,13 @@ int lmpc_simulate(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, 
     return rc;
 }
 
+int lmpc_wave_stats(lmpc_handle *h, unsigned long long out[5]) {
+    if (!h || !out) return LMPC_ERR_BADARG;
+    wave_stat_read(h, out);
+    out[4] = (unsigned long long)wave_first_pass_cap(h, (int64_t)1 << 20);
+    return LMPC_OK;
+}
+
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
     if (h->useWave) return "wave";
@@ -1457,6 +1465,19 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "host_threads") == 0) { h->hostThreads = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "gram_scan") == 0) { h->waveGram = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "wave_two_pass") == 0) { h->waveTwoPass = value < 0 ? -1 : (value != 0); return LMPC_OK; }
+    if (std::strcmp(name, "wave_cap1") == 0) { h->waveCap1 = value <= 0 ? 0 : (value < 8 ? 8 : (value > 64 ? 64 : value)); return LMPC_OK; }
+    if (std::strcmp(name, "wave_cap") == 0) {
+        // working-set rows the wavefront kernel holds per problem (8 .. 64, at most n + 1 + #soft): a smaller factor in
+        // LDS keeps more wavefronts resident; a point that wants more goes to the slow path
+        const int full = h->capFull < kWaveMaxCap ? h->capFull : kWaveMaxCap;
+        int c = value <= 0 ? full : (value < 8 ? 8 : value);
+        if (c > full) c = full;
+        h->W.cap = c; h->W.ldc = c | 1;
+        h->W.keepStride = 2 * 64 + c * (c - 1) / 2;
+        hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
+        return LMPC_OK;
+    }
     if (std::strcmp(name, "wave_packed") == 0) { h->wavePacked = value < 0 ? -1 : (value ? 1 : 0); return LMPC_OK; }
     if (std::strcmp(name, "wave_queue") == 0) { h->waveQueue = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_level") == 0) { h->waveLevel = value > 3 ? 3 : value; return LMPC_OK; }
@@ -1519,7 +1540,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccTheta); rel(h->ccAct); rel(h->ccFlag); h->ccCap = 0; h->ccWarmN = -1;
     rel(h->ccStage); rel(h->ccStageFlag); h->ccStageCap = 0; h->ccStagePer = 0;
     rel(h->ccObsScratch); h->ccObsCap = 0;
-    rel(h->dOvfList); h->ovfCap = 0; rel(h->dBigR); rel(h->dBigI);
+    rel(h->dOvfList); h->ovfCap = 0; rel(h->dOvfList1); h->ovfCap1 = 0; rel(h->dBigR); rel(h->dBigI);
     rel(h->dBnbR); rel(h->dBnbI); h->bnbBytesR = h->bnbBytesI = 0;
     rel(h->dKeepR); rel(h->dKeepI); h->keepCap = 0;
     return check_fast_err(h);
@@ -1543,7 +1564,9 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
-    hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI);
+    hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
+    if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
+    hipFree(h->dStat);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);
     hipFree(h->ccStage); hipFree(h->ccStageFlag); hipFree(h->ccObsScratch);

@@ -66,6 +66,15 @@ struct lmpc_handle {
     int screenWave = 1;         // tuning: screening pass in front of the wavefront kernel where it applies ("screen_wave")
     bool screenPackOnly = false;   // the lane-style pack holds only what the screening pass reads (wave-only problem)
     int32_t *dQueue = nullptr;
+    int waveOvfSet = 0;         // ... and which pair of overflow counters this CALL uses
+    int wavePass = 0;           // set by launch_wave_inst around its launches: 0 one pass, 1 / 2 first / second of two
+    int waveTwoPass = -1;       // option "wave_two_pass": -1 auto, 0 off, 1 whenever the capacity allows
+    int waveCap1 = 24;          // option "wave_cap1": working-set capacity of the first pass when "wave_two_pass" is 1
+    int32_t *dOvfList1 = nullptr;
+    int64_t ovfCap1 = 0;
+    unsigned long long *dStat = nullptr;             // working-set statistics of the wavefront kernel (device, cumulative)
+    volatile unsigned long long *hStat = nullptr;    // ... their copy in mapped host memory, written by every launch
+    unsigned long long *dStatHost = nullptr;         // ... and its device address
     int waveCtrSet = 0;         // which of the two (ticket, overflow) counter pairs the next wavefront-kernel launch uses
     int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
     int regCap = 0;
@@ -185,6 +194,11 @@ struct DeviceScope {
 bool fast_covers(const lmpc_handle *h);
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st);
+
+// capacity of the first of two passes the wavefront kernel would run a batch of nprob problems at (0: one pass;
+// lmpc_wave_launch.hpp, compiled into the binary64 translation unit)
+int wave_first_pass_cap(lmpc_handle *h, int64_t nprob);
+void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

@@ -7,6 +7,11 @@ namespace lmpc {
 template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM != 0)>(lmpc_handle *, const LMPC_WV_REAL *, int64_t,
                                                                 const LMPC_WV_REAL *, LMPC_WV_REAL *, int32_t *,
                                                                 int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+#ifdef LMPC_WV_HELPERS
+// (one translation unit carries the launcher's non-template helpers the API file needs)
+int wave_first_pass_cap(lmpc_handle *h, int64_t nprob) { return wave_first_pass_cap_impl(h, nprob, sizeof(double)); }
+void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]) { wave_stat_sums(h, out); }
+#endif
 }  // namespace lmpc
 
 #ifdef LMPC_WAVE_TRACE

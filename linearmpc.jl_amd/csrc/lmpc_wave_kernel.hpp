@@ -211,9 +211,27 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
     long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim,
     R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth,
-    int32_t *__restrict__ queue_next, int32_t *__restrict__ ovf_next) {
+    int32_t *__restrict__ queue_next, int32_t *__restrict__ ovf_next, unsigned long long *__restrict__ stat,
+    volatile unsigned long long *__restrict__ stat_host) {
     // the ticket and overflow counters of the NEXT launch on this handle (the other pair: see the launcher)
     if (blockIdx.x == 0 && threadIdx.x == 0) { *queue_next = 0; *ovf_next = 0; }
+    // How large did working sets get?  stat (device, cumulative over the handle's launches; sharded): problems finished by
+    // this kernel by the largest size their working set reached: up to 24 / 32 / 48 rows / more.  Every launch first
+    // copies the counters as they stand into mapped host memory, where the launcher reads them -- without a copy or a
+    // synchronisation -- to decide whether a first pass at a smaller capacity pays (lmpc_wave_launch.hpp).
+    // (64 shards of four counters, 128 bytes apart: a few thousand wavefronts adding to ONE word at their ends cost a
+    // closed-loop step 45 us -- a word takes about 90 atomics per microsecond)
+    // (the shards are summed here: four stores into host memory per launch -- 256 of them, one per shard counter, took a
+    // launch 10 us to retire over PCIe)
+    if (stat != nullptr && stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+        unsigned long long sum = 0ull;
+        for (int sidx = 0; sidx < 64; sidx++) sum += stat[sidx * 16 + threadIdx.x];
+        stat_host[threadIdx.x] = sum;
+    }
+
+    // Without binaries bnb_depth carries a flag instead: bit 0 = this is the FIRST of two passes (a smaller working-set
+    // capacity, more wavefronts resident); a point that outgrows it is listed for the second pass, which starts it again
+    // from the same warm start / kept state -- so this pass leaves both alone.
     extern __shared__ __align__(16) unsigned char lds_raw[];
     R *lds = reinterpret_cast<R *>(lds_raw);
     constexpr int CH = 8;                            // steps fetched ahead of a serial chain
@@ -397,6 +415,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             }
         };
         int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT, nsoft_act = 0;
+        int napk = 0;                            // largest working set of this solve (statistics)
         R best = (R)-1, fval = (R)0, soft_slack = (R)0;
         bool done = false, ydirty = false;
         R fbound = (R)P.fval_bound;              // a B&B node stops as soon as it is dominated
@@ -520,6 +539,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             if (singular) sing = na;
             nsoft_act += is_soft ? 1 : 0;
             na++;
+            napk = na > napk ? na : napk;
         };
 
         // ---- drop working-set position r (wave-uniform): compact L, rank-one update of the tail
@@ -681,9 +701,12 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if constexpr (!BNB) {
             if (bnb_i != nullptr && warm != nullptr) {
                 const int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
-                const R *sr = wv_uniform_ptr(bnb_r + pid * (long long)(2 * 64 + cap * (cap - 1) / 2));
+                const R *sr = wv_uniform_ptr(bnb_r + pid * (long long)P.keepStride);
                 const int pna = __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(si + 256));
-                if (pna >= 0) {
+                if (pna > cap) {                     // (kept by a pass with a larger capacity: that pass takes it again)
+                    kept = true;
+                    flag = EXIT_WSCAP; done = true;
+                } else if (pna >= 0) {
                     kept = true;
                     WSi = __builtin_nontemporal_load(si + lane);
                     const int fl = __builtin_nontemporal_load(si + 64 + lane);
@@ -692,6 +715,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     lowb = (unsigned)__builtin_nontemporal_load(si + 192 + lane);
                     D = __builtin_nontemporal_load(sr + lane); Dinv = __builtin_nontemporal_load(sr + 64 + lane);
                     na = pna;
+                    napk = pna;
                     nsoft_act = (int)__popcll(__ballot(lane < na && possoft));
                     const int ne = na * (na - 1) / 2;            // the triangle, row after row, is one contiguous run
                     for (int e0 = 0; e0 < ne; e0 += 256) {
@@ -1159,7 +1183,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if constexpr (!BNB) {
             if (bnb_i != nullptr) {                  // closed loop: this step's final working set and factor, kept
                 int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
-                R *sr = wv_uniform_ptr(bnb_r + pid * (long long)(2 * 64 + cap * (cap - 1) / 2));
+                R *sr = wv_uniform_ptr(bnb_r + pid * (long long)P.keepStride);
                 if (flag >= 1) {
                     __builtin_nontemporal_store(WSi, si + lane);
                     __builtin_nontemporal_store(possoft | (posimm << 1) | (poslow << 2), si + 64 + lane);
@@ -1174,11 +1198,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         tri_row(e, i, t);
                         __builtin_nontemporal_store(L[cbase(t) + i], sr + 128 + e);
                     }
-                } else if (lane == 0) {
+                } else if (lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr && (bnb_depth & 1))) {
                     __builtin_nontemporal_store(-1, si + 256);      // failed or handed to the slow path: the next step starts from the mask
                 }
             }
         }
+        // (one fire-and-forget atomic per finished problem, on the wavefront's shard: counters kept in registers across
+        // the problems of a wavefront cost the kernel more -- spills -- than these)
+        if (stat != nullptr && lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr))
+            atomicAdd(&stat[((blockIdx.x * nwv + wv) & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
         WVT(14);                                 // (trace: masks, flags, kept state)
         clear_rows(1, na);                       // ZP: the next problem starts on a factor of zeros
         WVT(9);

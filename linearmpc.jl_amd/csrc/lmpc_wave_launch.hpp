@@ -94,11 +94,43 @@ inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     return 4 * pk.blocksPerCU * pk.nwv >= 7 * sq.blocksPerCU * sq.nwv ? pk : sq;
 }
 
+// the handle's working-set statistics (four buckets in mapped host memory, see the kernel) as cumulative counts
+inline void wave_stat_sums(const lmpc_handle *h, unsigned long long out[4]) {
+    for (int q = 0; q < 4; q++) out[q] = 0ull;
+    if (!h->hStat) return;
+    unsigned long long b[4];                                     // buckets: <= 24, <= 32, <= 48, more
+    for (int q = 0; q < 4; q++) b[q] = h->hStat[q];
+    out[0] = b[0] + b[1] + b[2] + b[3]; out[1] = b[0]; out[2] = b[0] + b[1]; out[3] = b[0] + b[1] + b[2];
+}
+
+// capacity of the first of two passes for a batch of nprob problems on this handle, 0 = one pass (see launch_wave_inst)
+inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
+    if (h->bnb || h->waveTwoPass == 0 || !h->bigPath || h->W.cap < 40 || nprob >= (int64_t)0x7fffffff) return 0;
+    int c1 = 0;
+    if (h->waveTwoPass > 0) c1 = h->waveCap1;
+    else if (h->hStat && nprob >= 4096) {
+        unsigned long long sum[4];
+        wave_stat_sums(h, sum);
+        const int caps[3] = {24, 32, 48};
+        for (int q = 0; q < 3 && c1 == 0 && sum[0] >= 1000ull; q++)
+            if ((sum[0] - sum[1 + q]) * 100ull <= 3ull * sum[0]) c1 = caps[q];
+    }
+    if (c1 >= h->W.cap) c1 = 0;
+    if (c1 > 0 && h->waveTwoPass < 0) {                   // only where the smaller factor buys residency or staging
+        const WaveConfig full = wave_config(h, rs);
+        const int capW = h->W.cap, ldcW = h->W.ldc;
+        h->W.cap = c1; h->W.ldc = c1 | 1;
+        const WaveConfig t = wave_config(h, rs);
+        h->W.cap = capW; h->W.ldc = ldcW;
+        if (!(t.nwv * t.blocksPerCU > full.nwv * full.blocksPerCU || t.level > full.level)) c1 = 0;
+    }
+    return c1;
+}
+
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
-    const WaveList &wl = h->waveList;                    // work-list mode (screening pass in front): see launch()
-    const WaveLayout &Wl = h->W;
+    const WaveLayout &Wl = h->W;                         // (work-list mode, screening pass in front: h->waveList, see launch())
     auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
@@ -110,18 +142,32 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     long long grid = (long long)h->numCU * blocksPerCU;
     const long long need = (nprob + cfg.nwv - 1) / cfg.nwv;
     if (grid > need) grid = need;
-    // The ticket counter and the overflow counter exist twice and are used alternately: the kernel of call k clears
-    // the pair of call k + 1 (nobody touches that pair during call k; calls on a handle are stream-ordered), so no
-    // launch needs a memset in front of it -- two 5 us fill kernels per launch, 4 % of a closed-loop step.
+    // The ticket counter and the overflow counters exist twice and are used alternately: a kernel clears the ones of the
+    // launch / call after it (nobody touches those while it runs; calls on a handle are stream-ordered), so no launch
+    // needs a memset in front of it -- two 5 us fill kernels per launch, 4 % of a closed-loop step.  Tickets alternate per
+    // LAUNCH; the overflow counters per CALL (h->waveOvfSet, toggled by launch_wave_inst), because the second of two
+    // passes reads the first one's as the length of its work list.  Layout of dOvfCount (ints): two first-pass sets
+    // shaped like a work list's counters (kShards words kCountStride apart, only word 0 ever non-zero), then the two
+    // words of the last pass's overflow (the slow path's list).
+    constexpr int kP1 = kShards * kCountStride;
     if (!h->dQueue) {
-        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, 64));
-        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, 64, st));
+        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, sizeof(int32_t) * (2 * kP1 + 64)));
+        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t) * (2 * kP1 + 64), st));
         HIP_TRY(h, hipMalloc(&h->dQueue, 64));
         HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
-        h->waveCtrSet = 0;
+        h->waveCtrSet = 0; h->waveOvfSet = 0;
     }
-    int32_t *const ovfCount = h->dOvfCount + 8 * h->waveCtrSet;
-    int32_t *const queueNext = h->dQueue + 8 * (h->waveCtrSet ^ 1), *const ovfNext = h->dOvfCount + 8 * (h->waveCtrSet ^ 1);
+    const int pass = BNB ? 0 : h->wavePass;              // 0: the only pass; 1: first of two (smaller capacity); 2: second
+    const int os = h->waveOvfSet;
+    int32_t *const p1Count = h->dOvfCount + os * kP1, *const p1Next = h->dOvfCount + (os ^ 1) * kP1;
+    int32_t *const ovfCount = h->dOvfCount + 2 * kP1 + 8 * os, *const p2Next = h->dOvfCount + 2 * kP1 + 8 * (os ^ 1);
+    int32_t *const queueNext = h->dQueue + 8 * (h->waveCtrSet ^ 1);
+    int32_t *const ovfNext = pass == 1 ? p1Next : p2Next;
+    WaveList wl2{};
+    if (pass == 2) {                                     // the first pass's overflow list IS this pass's work list
+        wl2.list = h->dOvfList1; wl2.count = p1Count; wl2.count_next = nullptr; wl2.seg_cap = (long long)nprob;
+    }
+    const WaveList &wl = pass == 2 ? wl2 : h->waveList;
     // more than two problems per resident wavefront: hand them out through the shared counter
     int32_t *queue = nullptr;
     int qchunk = 1;
@@ -136,8 +182,22 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     }
     // working sets that can outgrow the 64 lanes (n + 1 + #soft > 64): such points are listed by the kernel and
     // re-solved behind it, one problem per thread (no branch and bound there)
-    const bool big = !BNB && h->bigPath && h->capFull > Wl.cap && nprob < (int64_t)0x7fffffff;
+    const bool big = pass != 1 && !BNB && h->bigPath && h->capFull > Wl.cap && nprob < (int64_t)0x7fffffff;
     const int bigCap = h->capFull < kBigCap ? h->capFull : kBigCap;
+    if (pass == 1 && nprob > h->ovfCap1) {
+        hipFree(h->dOvfList1); h->dOvfList1 = nullptr; h->ovfCap1 = 0;
+        HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
+        h->ovfCap1 = nprob;
+    }
+    if (!BNB && !h->hStat) {                             // working-set statistics: device counters + their mapped host copy
+        unsigned long long *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
+        for (int q = 0; q < 8; q++) hp[q] = 0ull;
+        h->hStat = hp;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dStatHost), hp, 0));
+        HIP_TRY(h, hipMalloc(&h->dStat, sizeof(unsigned long long) * 64 * 16));
+        HIP_TRY(h, hipMemsetAsync(h->dStat, 0, sizeof(unsigned long long) * 64 * 16, st));
+    }
     if (big) {
         if (nprob > h->ovfCap) {
             hipFree(h->dOvfList); h->dOvfList = nullptr; h->ovfCap = 0;
@@ -177,8 +237,9 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
                        iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
-                       big ? h->dOvfList : nullptr, big ? ovfCount : nullptr, h->waveSim, bnbR, bnbI, h->nBinary,
-                       queueNext, ovfNext);
+                       pass == 1 ? h->dOvfList1 : (big ? h->dOvfList : nullptr), pass == 1 ? p1Count : (big ? ovfCount : nullptr),
+                       h->waveSim, bnbR, bnbI, BNB ? h->nBinary : (pass == 1 ? 1 : 0), queueNext, ovfNext,
+                       BNB ? nullptr : h->dStat, BNB ? nullptr : h->dStatHost);
     h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());
     if (big) {
@@ -203,8 +264,25 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     }
     int rc;
     const int mr = wave_slots(h->P.m, BNB);
-    const WaveConfig cfg = wave_config(h, sizeof(R));
     if (BNB) warm = nullptr;                              // a B&B node takes its start from the search, not the caller
+    // Two passes (no binaries): the factor of a 64-row working set takes 16-33 KB of LDS per wavefront, which is what
+    // limits residency (and the staging level of the n-chain form) for every problem with n + 1 + #soft > 40 -- while
+    // the working sets of an MPC problem in normal operation stay far below that.  So the batch first runs at a SMALLER
+    // capacity (24, 32 or 48 rows: square factor, 12 wavefronts per CU instead of 9, M' staged again where it had not
+    // fit); a point that outgrows it is listed and started again -- same warm start, same kept state -- by a second
+    // launch at the full capacity, whose own overflow goes to the slow path as before.  Results do not depend on the
+    // split (a solve's arithmetic does not depend on the capacity).  Whether, and at which capacity, is decided from
+    // what the handle has seen: every wavefront-kernel launch counts how large the working sets of the problems it
+    // finished became (cumulative device counters, copied by each launch into mapped host memory and read here without
+    // a copy or a synchronisation) -- the smallest of 24 / 32 / 48 rows that would have held 97 % of them, if the
+    // launch configuration at that capacity is the better one (more wavefronts per CU or a higher staging level); one
+    // pass until 1000 problems have been seen, for small batches, and if no capacity qualifies.
+    // "wave_two_pass" 0 = never, 1 = always at "wave_cap1" rows (default 24), -1 (default) = as described.
+    WaveConfig cfg = wave_config(h, sizeof(R));
+    const int c1 = BNB ? 0 : wave_first_pass_cap_impl(h, nprob, sizeof(R));
+    const int capW = h->W.cap, ldcW = h->W.ldc;
+    auto dispatch = [&]() -> int {
+    int rc;
     // long horizons (64 <= n <= 127): two variable slots per lane; built without LDS staging of the problem data
     // (M alone is up to 1 MB there) and without branch and bound
     if (h->P.n > 64) {
@@ -221,10 +299,6 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             else if (mr <= 8) rc = LMPC_WVU(8);
             else rc = LMPC_WVU(16);
 #undef LMPC_WVU
-        }
-        if (prof) {
-            if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
-            else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
         }
         return rc;
     }
@@ -260,6 +334,20 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
 #undef LMPC_WV
 #undef LMPC_WV3
 #undef LMPC_WV4
+    return rc;
+    };   // dispatch
+    if (c1 > 0) {
+        h->W.cap = c1; h->W.ldc = c1 | 1; h->wavePass = 1;
+        cfg = wave_config(h, sizeof(R));
+        rc = dispatch();
+        h->W.cap = capW; h->W.ldc = ldcW; h->wavePass = 2;
+        cfg = wave_config(h, sizeof(R));
+        if (rc == LMPC_OK) rc = dispatch();
+        h->wavePass = 0;
+    } else {
+        rc = dispatch();
+    }
+    h->waveOvfSet ^= 1;
     if (prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
         else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }

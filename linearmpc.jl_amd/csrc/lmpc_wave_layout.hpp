@@ -69,6 +69,8 @@ struct WaveLayout {
     int oM, oMt, oG, odu, odl, oDth, oRout, ox0, oXth;
     int oGf;                                        // full symmetric Gram matrix, m x m (Gram-scan form)
     int nC;                                         // reals in the pack (bounds of the kernels' buffer resource)
+    int keepStride;                                 // reals of one scenario's kept closed-loop state: 2 x 64 + c (c - 1) / 2 at
+                                                    // the handle's LARGEST capacity c (a first pass may run at a smaller cap)
     double primal_tol, dual_tol, zero_tol, progress_tol, fval_bound, rho_soft;
     int cycle_tol, iter_limit;
 };

@@ -143,6 +143,15 @@ class BatchedQP:
     def kernel_name(self) -> str:
         return lib().lmpc_kernel_name(self._h).decode()
 
+    def wave_stats(self):
+        """Working-set statistics of the wavefront kernel as the handle last saw them (lmpc_wave_stats): dict with the
+        problems finished, how many of them stayed within 24 / 32 / 48 rows, and the first-pass capacity of the next
+        call (0 = one pass)."""
+        out = (ctypes.c_ulonglong * 5)()
+        check(lib().lmpc_wave_stats(self._h, out), self._h)
+        return {"problems": int(out[0]), "within_24": int(out[1]), "within_32": int(out[2]), "within_48": int(out[3]),
+                "first_pass_rows": int(out[4])}
+
     def ldp(self):
         """The constant pack the kernels use (row-major) -- what tests hand to the oracle."""
         out = dict(M=np.empty((self.m, self.n)), du=np.empty(self.m), dl=np.empty(self.m),

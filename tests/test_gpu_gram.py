@@ -364,3 +364,56 @@ def test_wave_path_closed_loop_kept_factor_through_the_64_row_limit(lmpc, gram):
     out1 = qp.simulate(x0, T, Fm, Gm, warm=True)
     for key in ("U", "X", "x", "flag_min"):
         assert np.array_equal(out1[key], ref1[key]), key
+
+
+@pytest.mark.parametrize("gram", [0, 1])
+def test_two_passes_of_the_wavefront_kernel(lmpc, gram):
+    """A first pass at a smaller working-set capacity (more wavefronts resident, M' staged again), a second one at the
+    full capacity for the points that outgrew it, the slow path behind that: decided by the handle's own statistics
+    (`lmpc_wave_stats`), and never visible in a result.  (a) the N = 50 benchmark problem: after a few calls the handle
+    runs its batches at 24 rows first; every call equals the single-pass result and the oracle bit for bit, cold and
+    warm.  (b) a problem whose working sets spread from 0 to 150 rows, first pass forced: points finished by the first
+    pass, by the second, and by the slow path in one batch, all as the oracle has them."""
+    from oracle import ldp as oldp
+    from test_gpu_parity import _random_qp
+    so = _gram_settings() if gram else oldp.default_settings()
+    g = load_golden("pendulum_N50")
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_option("gram_scan", gram)
+    rng = np.random.default_rng(3)
+    theta = np.tile(g["theta"], (40, 1))[:8192] + rng.normal(size=(8192, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
+    L = oracle_ldp_from(qp.ldp())
+    xo, efo, ito, acto = oldp.solve_batch(L, theta, so)
+    qp.set_option("wave_two_pass", 0)
+    x1, ef1, it1, act1 = qp.solve(theta)
+    assert qp.wave_stats()["first_pass_rows"] == 0
+    qp.set_option("wave_two_pass", -1)
+    outs = [qp.solve(theta) for _ in range(4)]
+    st = qp.wave_stats()
+    assert st["problems"] > 1000 and st["within_24"] >= 0.97 * st["problems"] and st["first_pass_rows"] == 24
+    for x, ef, it, act in outs:
+        assert np.array_equal(x, x1) and np.array_equal(ef, ef1) and np.array_equal(it, it1) and np.array_equal(act, act1)
+    assert np.array_equal(ef1, efo) and np.array_equal(it1, ito) and np.array_equal(act1, acto) and np.abs(x1 - xo).max() <= 1e-10
+    ok = efo >= 1
+    xw, efw, itw, actw = qp.solve(theta[ok], warm=acto[ok])
+    xq, efq, itq, actq = oldp.solve_batch(L, theta[ok], so, warm=acto[ok])
+    assert np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= 1e-10
+    # (b)
+    rng = np.random.default_rng(5)
+    n, mg, nth = 6, 150, 2
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=mg)
+    W[n:, 0] = np.abs(W[n:, 0]) + 0.5
+    qb = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
+    qb.set_option("gram_scan", gram)
+    qb.set_option("wave_two_pass", 1)                     # forced, at the default 24 rows
+    thb = np.vstack([rng.uniform(-1, 1, (3000, nth)), np.hstack([rng.uniform(0, 2.5, (6000, 1)), rng.uniform(-1, 1, (6000, 1))]),
+                     np.hstack([rng.uniform(5, 60, (1000, 1)), rng.uniform(-1, 1, (1000, 1))])])
+    Lb = oracle_ldp_from(qb.ldp())
+    xo, efo, ito, acto = oldp.solve_batch(Lb, thb, so)
+    nact = np.array([sum(bin(int(w)).count("1") for w in row) for row in acto])
+    assert (nact <= 20).sum() > 500 and ((nact > 24) & (nact <= 60)).sum() > 500 and (nact > 64).sum() > 500
+    for _ in range(2):
+        x, ef, it, act = qb.solve(thb)
+        assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto)
+        assert np.abs(x - xo).max() <= 1e-10
+    assert qb.wave_stats()["first_pass_rows"] == 24 and qb.wave_stats()["within_48"] < qb.wave_stats()["problems"]

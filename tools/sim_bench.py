@@ -29,6 +29,8 @@ ap.add_argument("--problem", default="pendulum",
 ap.add_argument("--screen-wave", type=int, default=1, help="screening pass in front of the wavefront kernel")
 ap.add_argument("--settled", type=float, default=0.0, help="fraction of the scenarios that start at rest on their reference (no step of theirs needs iterations)")
 ap.add_argument("--gram", type=int, default=0, help="wavefront kernel: Gram-scan form (lmpc_set_option gram_scan)")
+ap.add_argument("--wave-cap", type=int, default=0, help="wavefront kernel: working-set rows held per problem (lmpc_set_option wave_cap; 0 = library default)")
+ap.add_argument("--two-pass", type=int, default=-1, help="wavefront kernel: first pass at a smaller working-set capacity (lmpc_set_option wave_two_pass; -1 = by the handle's statistics)")
 ap.add_argument("--keep", type=int, default=1, help="wavefront path, warm: keep every scenario's factorisation between two steps (lmpc_set_option sim_keep_factor)")
 a = ap.parse_args()
 g = dict(np.load(os.path.join(ROOT, "tests", "golden", a.problem + ".npz")))
@@ -44,6 +46,8 @@ if qp.kernel_name == "wave":
     qp.set_option("screen_wave", a.screen_wave)
     qp.set_option("gram_scan", a.gram)
     qp.set_option("sim_keep_factor", a.keep)
+    if a.wave_cap: qp.set_option("wave_cap", a.wave_cap)
+    qp.set_option("wave_two_pass", a.two_pass)
 qp.set_option("sim_fused", a.fused)
 qp.set_option("sim_async", a.asyn)
 qp.set_option("sim_small", a.small)
@@ -82,7 +86,8 @@ for rep in range(a.reps):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"N={N} T={T} warm={a.warm}: {N*T/(t2-t0):.3e} scenario-steps/s, {1e6*(t2-t0)/T:.1f} us/step "
-          f"(host enqueue {1e6*(t1-t0)/T:.1f} us/step), min flag {int(fm.min())}")
+          f"(host enqueue {1e6*(t1-t0)/T:.1f} us/step), min flag {int(fm.min())}"
+          + (f", wave stats {qp.wave_stats()}" if qp.kernel_name == "wave" else ""))
 
 
 if a.groups > 1:

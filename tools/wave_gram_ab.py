@@ -20,7 +20,10 @@ for spec in specs:
     row = []
     outs = []
     for gram in (0, 1):
-        W = bench.Workload(torch, lmpc, name, n, dev, 0, 0, 1, f32=f32, rotate=False, options={"gram_scan": gram})
+        opts = {"gram_scan": gram}
+        if os.environ.get("LMPC_WAVE_CAP"):          # working-set rows held per problem (lmpc_set_option wave_cap)
+            opts["wave_cap"] = int(os.environ["LMPC_WAVE_CAP"])
+        W = bench.Workload(torch, lmpc, name, n, dev, 0, 0, 1, f32=f32, rotate=False, options=opts)
         sec = W.timed(3, 1, nstreams=1) / 3
         torch.cuda.synchronize()
         outs.append((W.xbuf[0].cpu().numpy().copy(), W.fbuf[0].cpu().numpy().copy()))
