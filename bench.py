@@ -644,6 +644,8 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
            "dtype": dtype, "batch": batch, "kernel": w.kernel, "rotating_batches": w.nrot,
            "workload": describe(w), **dist_info, "roofline": roof, "verified": verification["verified"],
            "verification": verification, "options": dict(w.options)}
+    if w.kernel == "wave" and hasattr(w.qp, "wave_stats"):
+        out["wave_stats"] = w.qp.wave_stats()       # working-set sizes seen; first_pass_rows > 0: two passes
     if want_cpu:
         _phase(f"config {workload}: cpu baseline")
         out["cpu_baseline"] = cpu_baseline(w.g, w.theta_h, w.nout, min_seconds=cpu_seconds, f32=f32,
@@ -1031,7 +1033,9 @@ def main():
             # in closed loop): quoted beside the batched rate as context, not as a baseline
             ref_us = {50: 11.0, 75: 16.0, 100: 22.0, 125: 31.0}
             for n_ in (50, 75, 100, 125):
-                c_ = side_config(torch, lmpc, f"pendulum_N{n_}", 200_000, dev, local_rank, 3, 1, False, want_cpu, 3.0)
+                # (three untimed calls first: a fresh handle decides from its own statistics, a launch or two behind,
+                # whether its batches first run at a smaller working-set capacity -- DESIGN.md, two passes)
+                c_ = side_config(torch, lmpc, f"pendulum_N{n_}", 200_000, dev, local_rank, 3, 3, False, want_cpu, 3.0)
                 c_["reference_context"] = {"median_solve_time_us": ref_us[n_], "solves_per_s_one_thread": 1e6 / ref_us[n_],
                                            "source": "docs/src/assets/benchmark_scaling_time.png (benchmark.md:23), read off the "
                                                      "plot +-10 %, hardware unstated, state constraints of the benchmark script "
