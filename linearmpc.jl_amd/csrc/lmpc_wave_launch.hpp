@@ -116,13 +116,19 @@ inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
             if ((sum[0] - sum[1 + q]) * 100ull <= 3ull * sum[0]) c1 = caps[q];
     }
     if (c1 >= h->W.cap) c1 = 0;
-    if (c1 > 0 && h->waveTwoPass < 0) {                   // only where the smaller factor buys residency or staging
+    if (c1 > 0 && h->waveTwoPass < 0) {                   // only where the smaller factor buys residency, layout or staging
         const WaveConfig full = wave_config(h, rs);
         const int capW = h->W.cap, ldcW = h->W.ldc;
         h->W.cap = c1; h->W.ldc = c1 | 1;
         const WaveConfig t = wave_config(h, rs);
         h->W.cap = capW; h->W.ldc = ldcW;
-        if (!(t.nwv * t.blocksPerCU > full.nwv * full.blocksPerCU || t.level > full.level)) c1 = 0;
+        // (a wavefront on the square factor counts 1.75 times one on the packed triangle: the weight wave_config itself
+        // chooses the layout by -- N = 125 at 48 rows: 8 square against 8 packed, 10 % faster)
+        const int st = t.nwv * t.blocksPerCU * (t.packed ? 4 : 7), sf = full.nwv * full.blocksPerCU * (full.packed ? 4 : 7);
+        // (n-chain form: only for a higher staging level -- its iterations read M' from L2 when it is not staged, and more
+        // resident wavefronts then cost as much as they bring: N = 75 at 32 rows was 8 % slower, N = 50 with M' staged
+        // again 1.8x faster)
+        if (!((h->waveGram && st > sf) || t.level > full.level)) c1 = 0;
     }
     return c1;
 }
