@@ -748,8 +748,13 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // closed-loop-visited starts, 1.17e9 against 1.31e9 with 90 % of the scenarios at rest: what costs the time is the
     // wavefront kernel on the transient's problems, which both loops run, and a round adds a launch and a host round
     // trip where the lock-step loop adds a 25 us screening pass.
-    const bool waveAsync = h->useWave && h->simAsync >= 2 && !h->bnb && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 &&
-                           wave_screens(h, N) && simLds <= 48 * 1024;
+    // (end of round 3: with RUN-AHEAD -- a scenario's consecutive steps that need iterations stay inside the wavefront
+    // kernel, warm on the factor as it stands in LDS -- the rounds win on every workload but the six-slot problems:
+    // 1.28e9 against 8.7e8 on that benchmark, 2.7e9 against 2.1e9 with 90 % at rest, 1.6e9 against 1.2e9 at 1e6
+    // scenarios.  Default from then on whenever run-ahead applies: warm with "sim_keep_factor" 1, or cold.)
+    const bool runAhead = h->simRunAhead && (!warm || h->simKeep);
+    const bool waveAsync = h->useWave && (h->simAsync >= 2 || (h->simAsync >= 1 && runAhead)) && !h->bnb && nu <= kMaxSimU &&
+                           nx <= 8 && h->P.nth <= 16 && wave_screens(h, N) && simLds <= 48 * 1024;
     const bool asyncLoop = waveAsync ||
                            (!h->useWave && h->simFused && h->simAsync && nu <= kMaxSimU && nx <= 8 && h->P.nth <= 16 && will_screen(h, N));
     if (!asyncLoop)
@@ -774,7 +779,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         h->asyncT = T;
         h->L.sim = SimFuse{h->simFG, h->simTheta, flag_min, nullptr, nx, nu, nr, nuprev, 0, h->simK, U_traj, X_traj,
                            (long long)N};
-        if (h->useWave) h->waveSim = WaveSim{h->simFG, h->simK, U_traj, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N};
+        if (h->useWave) h->waveSim = WaveSim{h->simFG, h->simK, U_traj, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N, -1, runAhead ? T : 0};
         constexpr int kBurst = 2;   // steps a scenario of a (short) work list may run ahead before it is parked
         const size_t setLen = (size_t)kShards * kCountStride;
         std::vector<int32_t> hc(3 * setLen);
@@ -1510,6 +1515,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "cc_fused") == 0) { h->ccFused = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_small") == 0) { h->simSmall = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_blind") == 0) { h->simBlind = value < 0 ? 0 : value; return LMPC_OK; }
+    if (std::strcmp(name, "sim_run_ahead") == 0) { h->simRunAhead = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_keep_factor") == 0) { h->simKeep = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "sim_async") == 0) { h->simAsync = value < 0 ? 0 : (value > 2 ? 2 : value); return LMPC_OK; }
     if (std::strcmp(name, "lane_block") == 0) {

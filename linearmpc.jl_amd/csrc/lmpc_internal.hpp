@@ -93,6 +93,7 @@ struct lmpc_handle {
     int64_t keepCap = 0;
     bool keepOn = false;
     int simKeep = 1;
+    int simRunAhead = 1;        // scenario-asynchronous loop on the wavefront path: consecutive steps of a scenario inside the kernel
     int nBinary = 0;            // rows flagged BINARY = the search's largest depth
     int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")
     int wavePacked = -1;        // tuning: layout of the wave kernel's factor (-1 automatic, 0 square, 1 packed)

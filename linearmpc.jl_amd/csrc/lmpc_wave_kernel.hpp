@@ -372,14 +372,26 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             pid = (long long)__builtin_amdgcn_readfirstlane(list[(long long)sg * seg_cap + off]);
         }
         const R *th = theta + pid * nth;
-        R b[MR];                                 // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
+        // Run-ahead (scenario-asynchronous closed loop, WaveSim with step counters and a horizon): a scenario whose step
+        // ended with a non-empty working set stays with this wavefront for its next step -- no work-list round trip,
+        // no record, bounds, kept-state traffic in between, and (warm) the factor continues as it stands in LDS, which is
+        // what the kept-state restart of the step-synchronous loop does through memory.  These live across its steps:
+        int WSi = 0, possoft = 0, posimm = 0, poslow = 0;   // registers of working-set position `lane`
+        R D = (R)0, Dinv = (R)0;
         unsigned actb = 0u, lowb = 0u;           // bit r: slot r active / active at its lower bound
+        int na = 0, nsoft_act = 0;
+        bool again = false, cont = false;        // again: a further step of the same scenario; cont: ... on the factor as it stands
+        int kcur = -1;                           // the scenario's step counter once it has been read
+        // (a later step reads the record this wavefront has just written: past its own L1)
+        auto thld = [&](int t) -> R { return again ? __hip_atomic_load(th + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : th[t]; };
+        for (;;) {
+        R b[MR];                                 // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
 #pragma unroll
         for (int r = 0; r < MR; r++) b[r] = (R)0;
         for (int t0 = 0; t0 < nth; t0 += CH) {
             R tv[CH];
 #pragma unroll
-            for (int q = 0; q < CH; q++) tv[q] = th[t0 + q < nth ? t0 + q : nth - 1];
+            for (int q = 0; q < CH; q++) tv[q] = thld(t0 + q < nth ? t0 + q : nth - 1);
 #pragma unroll
             for (int r = 0; r < MR; r++) {
                 R dv[CH];
@@ -398,9 +410,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 #pragma unroll
         for (int r = 0; r < MR; r++) { dub[r] = ldc((unsigned)P.odu, jc[r]) + b[r]; dlb[r] = ldc((unsigned)P.odl, jc[r]) + b[r]; }
         WVT(12);                                 // (trace: record, bounds, b = Dth theta)
-        // registers of working-set position `lane`
-        int WSi = 0, possoft = 0, posimm = 0, poslow = 0;
-        R lam = (R)0, ls = (R)0, rhs = (R)0, D = (R)0, Dinv = (R)0, y = (R)0;
+        R lam = (R)0, ls = (R)0, rhs = (R)0, y = (R)0;   // (further registers of working-set position `lane`)
         R u[NU];                                 // lane k % 64, slot k / 64 holds u_k
 #pragma unroll
         for (int s = 0; s < NU; s++) u[s] = (R)0;
@@ -414,8 +424,8 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 return wv_bcast(v, k & 63);
             }
         };
-        int na = 0, sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT, nsoft_act = 0;
-        int napk = 0;                            // largest working set of this solve (statistics)
+        int sing = -1, iter = 1, cyc = 0, flag = EXIT_ITERLIMIT;
+        int napk = na;                           // largest working set of this solve (statistics)
         R best = (R)-1, fval = (R)0, soft_slack = (R)0;
         bool done = false, ydirty = false;
         R fbound = (R)P.fval_bound;              // a B&B node stops as soon as it is dominated
@@ -682,13 +692,17 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         auto solve_node = [&](int forced) {
         iter = 1; cyc = 0; flag = EXIT_ITERLIMIT; best = (R)-1; done = false;
         if (!BNB || forced < 0) {
+        if (!cont) {
         clear_rows(1, na);                       // (rows of the previous solve / node; row 0 has no entries)
         WSi = 0; possoft = 0; posimm = 0; poslow = 0;
-        lam = (R)0; ls = (R)0; rhs = (R)0; D = (R)0; Dinv = (R)0; y = (R)0;
+        D = (R)0; Dinv = (R)0;
+        actb = 0u; lowb = 0u;
+        na = 0; nsoft_act = 0;
+        }
+        lam = (R)0; ls = (R)0; rhs = (R)0; y = (R)0;
 #pragma unroll
         for (int s = 0; s < NU; s++) u[s] = (R)0;
-        actb = 0u; lowb = 0u;
-        na = 0; sing = -1; nsoft_act = 0;
+        sing = -1;
         fval = (R)0; soft_slack = (R)0; ydirty = false;
         // Closed loop with a kept factorisation (bnb_r / bnb_i double as the per-scenario state of a solve without
         // binaries): the previous step's final working set comes back IN ITS ORDER with its L and D -- what libdaqp's
@@ -698,8 +712,21 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         // (The state is read and written with nontemporal accesses: 2 KB per listed scenario and step streaming through
         // an L2 that should keep the Gram matrix -- with plain accesses every constraint scan got 1.5x slower.)
         bool kept = false;
+        if (cont) {                                  // run-ahead: the factor is where the previous step left it
+            kept = true;
+            for (int i = 0; i < na; i++) {
+                const int j = __builtin_amdgcn_readlane(WSi, i);
+                const int lw = __builtin_amdgcn_readlane(poslow, i);
+                R bj = (R)0;
+#pragma unroll
+                for (int r = 0; r < MR; r++) if (r == (j >> 6)) bj = lw ? dlb[r] : dub[r];
+                const R rj = -wv_bcast(bj, j & 63);
+                if (lane == i) rhs = rj;
+            }
+            ydirty = na > 0;
+        }
         if constexpr (!BNB) {
-            if (bnb_i != nullptr && warm != nullptr) {
+            if (!cont && bnb_i != nullptr && warm != nullptr) {
                 const int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
                 const R *sr = wv_uniform_ptr(bnb_r + pid * (long long)P.keepStride);
                 const int pna = __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(si + 256));
@@ -1120,7 +1147,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             R xo = (R)0;
             if (ko < P.nout) {
                 R sh = ldc((unsigned)P.ox0, (unsigned)ko);
-                for (int t = 0; t < nth; t++) sh = wv_fma(ldc((unsigned)(P.oXth + t), (unsigned)ko * (unsigned)nth), th[t], sh);
+                for (int t = 0; t < nth; t++) sh = wv_fma(ldc((unsigned)(P.oXth + t), (unsigned)ko * (unsigned)nth), thld(t), sh);
                 xo = xs + sh;
                 if (X != nullptr) (X + pid * P.nout)[(unsigned)ko] = xo;
             }
@@ -1129,10 +1156,11 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 // lane l < nu holds u_l).  A point handed to the slow path is advanced there, after its re-solve.
                 if (o0 == 0 && sim.FG != nullptr && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
                     const int snx = sim.nx, snu = sim.nu;
-                    const int k = sim.kfix >= 0 ? sim.kfix : sim.kstep[pid];
+                    const int k = sim.kfix >= 0 ? sim.kfix : (kcur >= 0 ? kcur : sim.kstep[pid]);
+                    kcur = k + 1;
                     const int ar = lane < snx ? lane : 0;
                     double acc = 0.0;
-                    for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[ar * snx + c], (double)th[c], acc);
+                    for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[ar * snx + c], (double)thld(c), acc);
                     for (int l = 0; l < snu; l++) acc = __builtin_fma(sim.FG[snx * snx + ar * snu + l], (double)wv_bcast(xo, l), acc);
                     double *to = const_cast<double *>(reinterpret_cast<const double *>(theta)) + pid * nth;
                     if (lane < snx) {
@@ -1208,9 +1236,17 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if (stat != nullptr && lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr))
             atomicAdd(&stat[((blockIdx.x * nwv + wv) & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
         WVT(14);                                 // (trace: masks, flags, kept state)
-        clear_rows(1, na);                       // ZP: the next problem starts on a factor of zeros
+        bool more = false;
+        if constexpr (sizeof(R) == 8 && !BNB) {
+            more = sim.FG != nullptr && sim.kfix < 0 && kcur >= 0 && kcur < sim.T && flag >= 1 && na > 0;
+        }
+        cont = more && warm != nullptr;
+        if (!cont) clear_rows(1, na);            // ZP: the next solve starts on a factor of zeros
         WVT(9);
         WVT_COUNT(11);
+        if (!more) break;
+        again = true;
+        }   // steps of one scenario
         if (++kin < qchunk) {
             idx++;
         } else {

@@ -61,6 +61,8 @@ struct WaveSim {
     int nx, nu, nr, nup;
     long long nscen;
     int kfix = -1;               // step-synchronous loop: the step every scenario is at (no counters); -1: kstep[]
+    int T = 0;                   // scenario-asynchronous loop: steps per scenario -- a scenario whose step ends with a
+                                 // non-empty working set runs on inside the wavefront kernel (0: one step per visit)
 };
 
 struct WaveLayout {

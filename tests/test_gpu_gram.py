@@ -222,7 +222,9 @@ def test_wave_path_closed_loop_asynchronous_rounds(lmpc, name, gram):
         pick = base[rng.integers(0, len(base), N)] + rng.normal(size=(N, 7)) * [0.02, 0.05, 0.005, 0.05, 0.02, 0.0, 0.0]
         x0, r = pick[:, :4].copy(), pick[:, 4:6].copy()
     so = _gram_settings() if gram else oldp.default_settings()
-    qp.set_option("sim_keep_factor", 0)            # the mask-based warm start: what the asynchronous rounds use
+    # one step per visit of the wavefront kernel and the mask-based warm start: the oracle's warm = 1
+    qp.set_option("sim_keep_factor", 0)
+    qp.set_option("sim_run_ahead", 0)
     for warm in (True, False):
         ref = oldp.simulate(L, x0, T, F, G, r=r, warm=warm, settings=so)
         outs = []
@@ -234,6 +236,18 @@ def test_wave_path_closed_loop_asynchronous_rounds(lmpc, name, gram):
             assert np.array_equal(out["U"], ref["U"]) and np.array_equal(out["X"], ref["X"])
             assert np.array_equal(out["x"], ref["x"])
         assert (ref["flag_min"] >= 1).mean() > 0.5
+    # run-ahead (default): a scenario's consecutive steps that need iterations stay inside the wavefront kernel, warm on
+    # the factor as it stands -- the kept factorisation of the step-synchronous loop without the trip through memory:
+    # the oracle's warm = 2; cold, every step starts from nothing either way
+    qp.set_option("sim_keep_factor", 1)
+    qp.set_option("sim_run_ahead", 1)
+    for warm, owarm in ((True, 2), (False, False)):
+        ref = oldp.simulate(L, x0, T, F, G, r=r, warm=owarm, settings=so)
+        for asyn in (2, 0):
+            qp.set_option("sim_async", asyn)
+            out = qp.simulate(x0, T, F, G, r=r, warm=warm)
+            for key in ("U", "X", "x", "flag_min"):
+                assert np.array_equal(out[key], ref[key]), (warm, asyn, key)
 
 
 @pytest.mark.parametrize("name,gram", [("pendulum_N50", 0), ("pendulum_N50", 1), ("soft_doc", 0), ("soft_doc", 1)])
