@@ -428,10 +428,12 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * iteration would do -- and the wavefront kernel walks a work list of the others.  "big_path" (default 1) = points
  * whose working set outgrows the wavefront kernel's 64 rows are re-solved by the one-problem-per-thread kernel
  * (0 = they keep exit flag -7).  Results are
- * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1; 2 = also on the wavefront-kernel
- * path, where the lock-step loop is the faster one on the workloads measured: DESIGN.md) = scenarios
- * advance independently of each other (rounds of a streaming kernel and the iterating kernel),
- * 0 = all scenarios step by step together; "sim_blind" (default 2) = rounds enqueued between two
+ * bit-identical either way.  Closed loop (lmpc_simulate*): "sim_async" (default 1) = scenarios
+ * advance independently of each other (rounds of a streaming kernel and the iterating kernel; on the wavefront-kernel
+ * path whenever "sim_run_ahead" applies, 2 = there in any case), 0 = all scenarios step by step together;
+ * "sim_run_ahead" (default 1; wavefront-kernel path) = a scenario whose step ends with a non-empty working set stays
+ * inside the wavefront kernel for its next step, warm on the factorisation as it stands (cold: from nothing) -- same
+ * results as the step-synchronous loop with "sim_keep_factor" 1; "sim_blind" (default 2) = rounds enqueued between two
  * reads of the work-list counters; "sim_small" (default 1) = the all-in-registers instantiation
  * of the streaming kernel for single-input problems with nx <= 4, m <= 8; "sim_fused" (default 1) = plant step inside the solve's
  * kernels (lane kernels; round 3: the wavefront-kernel path's lock-step loop too).  All of them change the execution
