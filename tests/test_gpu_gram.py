@@ -431,3 +431,50 @@ def test_two_passes_of_the_wavefront_kernel(lmpc, gram):
         assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto)
         assert np.abs(x - xo).max() <= 1e-10
     assert qb.wave_stats()["first_pass_rows"] == 24 and qb.wave_stats()["within_48"] < qb.wave_stats()["problems"]
+
+
+def test_closed_loop_run_ahead_is_exact_after_the_handle_has_statistics(lmpc):
+    """A handle that has already solved batches (its statistics would send a plain batch through a first pass at a small
+    capacity) runs its closed loops with run-ahead in ONE pass: a step that outgrew a first pass would have to restart
+    from the factor of the step before, which run-ahead keeps nowhere.  Working sets here pass 24 and 32 rows during
+    the transient; trajectories equal the checker's bit for bit on the first and on later calls."""
+    from oracle import ldp as oldp
+    from test_gpu_parity import _random_qp
+    rng = np.random.default_rng(77)
+    nx, nu, n, mg, nsoft = 4, 1, 40, 90, 90
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nx, nsoft=nsoft)
+    W[n:, 0] = np.abs(W[n:, 0])
+    f_theta *= 0.6
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
+    qp.set_option("gram_scan", 1)
+    assert qp.kernel_name == "wave"
+    Fm = np.diag([0.9, 0.8, 0.7, 0.6]) + 0.02 * rng.standard_normal((4, 4))
+    Gm = 0.3 * rng.standard_normal((4, 1))
+    N, T = 6000, 15
+    x0 = rng.uniform(-1, 1, (N, nx)); x0[:, 0] = rng.uniform(0, 3, N)
+    L = oracle_ldp_from(qp.ldp())
+    so = _gram_settings()
+    # batches first: statistics with most working sets small
+    th = rng.uniform(-0.3, 0.3, (8192, nx))
+    for _ in range(4):
+        qp.solve(th)
+    ref = oldp.simulate(L, x0, T, Fm, Gm, warm=2, settings=so)
+    _, _, _, act0 = oldp.solve_batch(L, x0, so)
+    nact0 = np.array([sum(bin(int(w)).count("1") for w in row) for row in act0])
+    assert (nact0 > 32).sum() > 200 and (nact0 <= 24).sum() > 200
+    for _ in range(2):
+        out = qp.simulate(x0, T, Fm, Gm, warm=True)
+        for key in ("U", "X", "x", "flag_min"):
+            assert np.array_equal(out[key], ref[key]), key
+    assert (ref["flag_min"] >= 1).mean() > 0.9
+    # the step-synchronous loop DOES run in two passes (forced here, 24 rows first): a point that outgrows the first
+    # pass leaves its kept state alone, a kept working set larger than the first pass's capacity goes straight on,
+    # and the second pass restores it -- same trajectories
+    qp.set_option("sim_async", 0)
+    qp.set_option("wave_two_pass", 1)
+    for fused in (1, 0):
+        qp.set_option("sim_fused", fused)
+        out = qp.simulate(x0, T, Fm, Gm, warm=True)
+        for key in ("U", "X", "x", "flag_min"):
+            assert np.array_equal(out[key], ref[key]), (fused, key)
+    assert qp.wave_stats()["first_pass_rows"] == 24
