@@ -719,3 +719,33 @@ def test_closed_loop_with_a_kept_factorisation_soft_rows_and_many_scenarios():
             # side of it depending on where the iterations started (2e-7 in u on the N = 50 problem)
             assert np.abs(mask["U"][:, ok] - kept["U"][:, ok]).max() < 1e-5, (name, mode)
             assert np.abs(cold["U"][:, ok] - kept["U"][:, ok]).max() < 1e-5, (name, mode)
+
+
+def test_kept_factorisation_through_the_64_row_limit_on_the_cpu():
+    """oracle_simulate warm = 2 where working sets cross 64 rows (the wavefront kernel's capacity, which the twin
+    mirrors): a step that wants more rows is re-solved from the mask in the n-chain form and nothing is kept after it;
+    the loop stays on the optimum of the cold loop (soft rows: up to the primal tolerance band) in both forms."""
+    rng = np.random.default_rng(5)
+    n, mg, nth = 6, 150, 2
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + n * np.eye(n)
+    A = rng.standard_normal((mg, n)); m = n + mg
+    bu = rng.uniform(0.5, 2.0, m); bl = -rng.uniform(0.5, 2.0, m)
+    W = 0.3 * rng.standard_normal((m, nth)); W[:n] = 0.0
+    W[n:, 0] = np.abs(W[n:, 0]) + 0.5
+    f_theta = rng.standard_normal((n, nth))
+    sense = np.zeros(m, np.int32); sense[n:] = 8
+    L = oldp.qp2ldp(H, np.zeros(n), f_theta, A, bu, bl, W, sense, nout=2)
+    N, T = 40, 25
+    x0 = np.vstack([rng.uniform(-1, 1, (10, 2)), np.hstack([rng.uniform(20, 60, (N - 10, 1)), rng.uniform(-1, 1, (N - 10, 1))])])
+    Fm = np.array([[0.8, 0.05], [0.0, 0.7]])
+    Gm = 0.05 * rng.standard_normal((2, 2))
+    _, _, _, act0 = oldp.solve_batch(L, x0)
+    nact0 = np.array([sum(bin(int(w)).count("1") for w in row) for row in act0])
+    assert (nact0 > 64).sum() >= 20
+    for mode in (0, 1):
+        so = oldp.default_settings(); so.mode = mode
+        cold = oldp.simulate(L, x0, T, Fm, Gm, warm=False, settings=so)
+        kept = oldp.simulate(L, x0, T, Fm, Gm, warm=2, settings=so)
+        mask = oldp.simulate(L, x0, T, Fm, Gm, warm=1, settings=so)
+        assert (cold["flag_min"] >= 1).all() and (kept["flag_min"] >= 1).all() and (mask["flag_min"] >= 1).all()
+        assert np.abs(kept["U"] - cold["U"]).max() < 1e-5 and np.abs(mask["U"] - cold["U"]).max() < 1e-5
