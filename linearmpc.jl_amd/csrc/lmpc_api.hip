@@ -721,6 +721,30 @@ int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
     return rc == LMPC_OK ? flag : rc;
 }
 
+// per-scenario kept closed-loop state of the wavefront path (working set + factorisation, lmpc_wave_kernel.hpp): makes
+// room for N scenarios if the device has it to spare, marks every state "nothing kept", sets h->keepOn
+static int ensure_keep(lmpc_handle *h, int64_t N, hipStream_t st) {
+    const size_t keepR = (size_t)h->W.keepStride, keepI = 5 * 64;
+    if (N > h->keepCap) {
+        hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
+        // (17 GB for 1e6 scenarios at capacity 64: only while it is at most half of what the device has free --
+        // beyond that the loop runs on masks rather than crowding out the caller)
+        size_t freeB = 0, totalB = 0;
+        const size_t needB = (sizeof(double) * keepR + sizeof(int32_t) * keepI) * (size_t)N;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+        if (needB <= freeB / 2 &&
+            hipMalloc(&h->dKeepR, sizeof(double) * keepR * (size_t)N) == hipSuccess &&
+            hipMalloc(&h->dKeepI, sizeof(int32_t) * keepI * (size_t)N) == hipSuccess) h->keepCap = N;
+        else { hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; (void)hipGetLastError(); }
+    }
+    if (N <= h->keepCap) {
+        // nothing kept yet: the size word of every scenario's state to -1
+        HIP_TRY(h, hipMemset2DAsync(h->dKeepI + 256, sizeof(int32_t) * keepI, 0xFF, sizeof(int32_t), (size_t)N, st));
+        h->keepOn = true;
+    }
+    return LMPC_OK;
+}
+
 int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int nuprev, const double *F,
                          const double *G, double *x, const double *r, double *uprev, double *U_traj,
                          double *X_traj, int32_t *flag_min, int warm, void *stream) {
@@ -752,7 +776,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // kernel, warm on the factor as it stands in LDS -- the rounds win on every workload but the six-slot problems:
     // 1.28e9 against 8.7e8 on that benchmark, 2.7e9 against 2.1e9 with 90 % at rest, 1.6e9 against 1.2e9 at 1e6
     // scenarios.  Default from then on whenever run-ahead applies: warm with "sim_keep_factor" 1, or cold.)
-    const bool runAhead = h->simRunAhead && (!warm || h->simKeep);
+    const bool runAhead = h->simRunAhead && (!warm || h->simKeep) && (h->P.m + 63) / 64 <= kWaveRunAheadSlots;
     const bool waveAsync = h->useWave && (h->simAsync >= 2 || (h->simAsync >= 1 && runAhead)) && !h->bnb && nu <= kMaxSimU &&
                            nx <= 8 && h->P.nth <= 16 && wave_screens(h, N) && simLds <= 48 * 1024;
     const bool asyncLoop = waveAsync ||
@@ -779,6 +803,13 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         h->asyncT = T;
         h->L.sim = SimFuse{h->simFG, h->simTheta, flag_min, nullptr, nx, nu, nr, nuprev, 0, h->simK, U_traj, X_traj,
                            (long long)N};
+        h->keepOn = false; h->raWarm = warm != 0;
+        if (h->useWave && runAhead && warm && T > 1 && wave_first_pass_cap(h, N) > 0) {
+            // (a first pass at a smaller capacity is in sight: it writes every scenario's state out after each step, so
+            // that a step which outgrows it restarts exactly where the step-synchronous loop would)
+            const int rck = ensure_keep(h, N, st);
+            if (rck != LMPC_OK) return rck;
+        }
         if (h->useWave) h->waveSim = WaveSim{h->simFG, h->simK, U_traj, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N, -1, runAhead ? T : 0};
         constexpr int kBurst = 2;   // steps a scenario of a (short) work list may run ahead before it is parked
         const size_t setLen = (size_t)kShards * kCountStride;
@@ -846,6 +877,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
         if (h->dCount) { hipMemsetAsync(h->dCount, 0, sizeof(int32_t) * 3 * kShards * kCountStride, st); h->countSet = 0; }
         h->L.sim = SimFuse{};
         h->waveSim = WaveSim{};
+        h->keepOn = false; h->raWarm = false;
         h->prof = prof;
         if (rc != LMPC_OK) return rc;
         hipLaunchKernelGGL(unpack_theta_kernel, dim3(grid), dim3(256), 0, st, h->simTheta, x, nuprev > 0 ? uprev : nullptr,
@@ -882,24 +914,8 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // by one.  Option "sim_keep_factor" 0 (or no memory for it): the mask-based warm start of the other paths.
     h->keepOn = false;
     if (h->useWave && warm && !h->bnb && h->simKeep && T > 1) {
-        const size_t keepR = (size_t)h->W.keepStride, keepI = 5 * 64;
-        if (N > h->keepCap) {
-            hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; h->keepCap = 0;
-            // (17 GB for 1e6 scenarios at capacity 64: only while it is at most half of what the device has free --
-            // beyond that the loop runs on masks rather than crowding out the caller)
-            size_t freeB = 0, totalB = 0;
-            const size_t needB = (sizeof(double) * keepR + sizeof(int32_t) * keepI) * (size_t)N;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
-            if (needB <= freeB / 2 &&
-                hipMalloc(&h->dKeepR, sizeof(double) * keepR * (size_t)N) == hipSuccess &&
-                hipMalloc(&h->dKeepI, sizeof(int32_t) * keepI * (size_t)N) == hipSuccess) h->keepCap = N;
-            else { hipFree(h->dKeepR); hipFree(h->dKeepI); h->dKeepR = nullptr; h->dKeepI = nullptr; (void)hipGetLastError(); }
-        }
-        if (N <= h->keepCap) {
-            // nothing kept yet: the size word of every scenario's state to -1
-            HIP_TRY(h, hipMemset2DAsync(h->dKeepI + 256, sizeof(int32_t) * keepI, 0xFF, sizeof(int32_t), (size_t)N, st));
-            h->keepOn = true;
-        }
+        const int rck = ensure_keep(h, N, st);
+        if (rck != LMPC_OK) return rck;
     }
     // Wavefront path with its screening pass in front: the plant step is fused into the three kernels of a step like
     // on the lane path -- the screening pass advances the scenarios it finishes (SimFuse), the wavefront kernel and its

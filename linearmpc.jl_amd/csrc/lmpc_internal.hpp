@@ -93,6 +93,7 @@ struct lmpc_handle {
     int64_t keepCap = 0;
     bool keepOn = false;
     int simKeep = 1;
+    bool raWarm = false;        // the run-ahead loop in progress is a warm one
     int simRunAhead = 1;        // scenario-asynchronous loop on the wavefront path: consecutive steps of a scenario inside the kernel
     int nBinary = 0;            // rows flagged BINARY = the search's largest depth
     int bigPath = 1;            // tuning: 0 = leave such points at exit flag -7 ("big_path")

@@ -383,7 +383,13 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         bool again = false, cont = false;        // again: a further step of the same scenario; cont: ... on the factor as it stands
         int kcur = -1;                           // the scenario's step counter once it has been read
         // (a later step reads the record this wavefront has just written: past its own L1)
-        auto thld = [&](int t) -> R { return again ? __hip_atomic_load(th + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : th[t]; };
+        // (built for up to six constraint slots per lane: beyond that the registers are gone -- the eight-slot
+        // instantiation dropped from two wavefronts per SIMD to one with it; lmpc_simulate_device knows)
+        constexpr bool RUNAHEAD = sizeof(R) == 8 && !BNB && MR <= kWaveRunAheadSlots;
+        auto thld = [&](int t) -> R {
+            if constexpr (RUNAHEAD) return again ? __hip_atomic_load(th + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : th[t];
+            else return th[t];
+        };
         for (;;) {
         R b[MR];                                 // b_j = Dth_j . theta   (mpc_update_qp.c:5-6)
 #pragma unroll
@@ -1160,6 +1166,9 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                     kcur = k + 1;
                     const int ar = lane < snx ? lane : 0;
                     double acc = 0.0;
+                    // (tried: F's row, G's row and the state requested in one batch in front of this chain, likewise the
+                    // columns of Xth above -- the exit is a third of a run-ahead step -- but the 40 registers of the batch
+                    // spill elsewhere: 1.28e9 -> 1.10e9 scenario-steps/s, n-chain form 1.10e9 -> 7.6e8)
                     for (int c = 0; c < snx; c++) acc = __builtin_fma(sim.FG[ar * snx + c], (double)thld(c), acc);
                     for (int l = 0; l < snu; l++) acc = __builtin_fma(sim.FG[snx * snx + ar * snu + l], (double)wv_bcast(xo, l), acc);
                     double *to = const_cast<double *>(reinterpret_cast<const double *>(theta)) + pid * nth;
@@ -1208,8 +1217,15 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             // (lmpc_big_kernel.hpp), which overwrites the outputs of this problem
             if (flag == EXIT_WSCAP && ovf_list != nullptr) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
         }
+        bool more = false;                       // run-ahead: this scenario's next step follows right here
+        if constexpr (RUNAHEAD) {
+            more = sim.FG != nullptr && sim.kfix < 0 && kcur >= 0 && kcur < sim.T && flag >= 1 && na > 0;
+        }
         if constexpr (!BNB) {
-            if (bnb_i != nullptr) {                  // closed loop: this step's final working set and factor, kept
+            // closed loop: this step's final working set and factor, kept.  (Run-ahead keeps them in LDS; it writes them
+            // out when the scenario leaves the kernel, and after every step of a FIRST pass -- a later step that
+            // outgrows that pass's capacity restarts from here in the second pass)
+            if (bnb_i != nullptr && (!more || (bnb_depth & 1))) {
                 int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
                 R *sr = wv_uniform_ptr(bnb_r + pid * (long long)P.keepStride);
                 if (flag >= 1) {
@@ -1236,10 +1252,6 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if (stat != nullptr && lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr))
             atomicAdd(&stat[((blockIdx.x * nwv + wv) & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
         WVT(14);                                 // (trace: masks, flags, kept state)
-        bool more = false;
-        if constexpr (sizeof(R) == 8 && !BNB) {
-            more = sim.FG != nullptr && sim.kfix < 0 && kcur >= 0 && kcur < sim.T && flag >= 1 && na > 0;
-        }
         cont = more && warm != nullptr;
         if (!cont) clear_rows(1, na);            // ZP: the next solve starts on a factor of zeros
         WVT(9);

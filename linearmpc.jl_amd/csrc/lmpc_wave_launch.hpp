@@ -106,9 +106,10 @@ inline void wave_stat_sums(const lmpc_handle *h, unsigned long long out[4]) {
 // capacity of the first of two passes for a batch of nprob problems on this handle, 0 = one pass (see launch_wave_inst)
 inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
     if (h->bnb || h->waveTwoPass == 0 || !h->bigPath || h->W.cap < 40 || nprob >= (int64_t)0x7fffffff) return 0;
-    // run-ahead (closed loop, consecutive steps of a scenario on the factor in LDS): a step that outgrew a first pass
-    // would have to restart from the factor of the step before it, which is not kept anywhere -- one pass there
-    if (h->waveSim.FG != nullptr && h->waveSim.T > 0) return 0;
+    // run-ahead (closed loop, consecutive steps of a scenario on the factor in LDS), warm: a step that outgrows a first
+    // pass restarts from the factor of the step before it -- which the first pass then has to write out after every
+    // step (the kept-state buffers of the step-synchronous loop); without them, one pass
+    if (h->waveSim.FG != nullptr && h->waveSim.T > 0 && h->raWarm && !h->keepOn) return 0;
     int c1 = 0;
     if (h->waveTwoPass > 0) c1 = h->waveCap1;
     else if (h->hStat && nprob >= 4096) {

@@ -4,6 +4,7 @@
 
 namespace lmpc {
 
+constexpr int kWaveRunAheadSlots = 6;  // wavefront-kernel instantiations (constraint slots per lane) built with run-ahead
 constexpr int kShards = 64;            // work-list segments (one atomic counter each)
 constexpr int kCountStride = 32;       // ... whose counters sit one per 128-byte line
 
