@@ -211,10 +211,13 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
     long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim,
     R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth,
-    int32_t *__restrict__ queue_next, int32_t *__restrict__ ovf_next, unsigned long long *__restrict__ stat,
-    volatile unsigned long long *__restrict__ stat_host) {
-    // the ticket and overflow counters of the NEXT launch on this handle (the other pair: see the launcher)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *queue_next = 0; *ovf_next = 0; }
+    int32_t *__restrict__ queue_next, int32_t *__restrict__ ovf_next, int32_t *__restrict__ ovf_next1,
+    unsigned long long *__restrict__ stat, volatile unsigned long long *__restrict__ stat_host) {
+    // the ticket counter of the NEXT launch and BOTH overflow counters of the next call on this handle (the other set:
+    // see the launcher).  Both, whatever this call is: a call in one pass followed by one in two must not leave the
+    // first pass's counter of the set after next uncleared (found by tools/fuzz_closed_loop.py: stale count, list read
+    // past its entries)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *queue_next = 0; *ovf_next = 0; *ovf_next1 = 0; }
     // How large did working sets get?  stat (device, cumulative over the handle's launches; sharded): problems finished by
     // this kernel by the largest size their working set reached: up to 24 / 32 / 48 rows / more.  Every launch first
     // copies the counters as they stand into mapped host memory, where the launcher reads them -- without a copy or a

@@ -172,7 +172,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     int32_t *const p1Count = h->dOvfCount + os * kP1, *const p1Next = h->dOvfCount + (os ^ 1) * kP1;
     int32_t *const ovfCount = h->dOvfCount + 2 * kP1 + 8 * os, *const p2Next = h->dOvfCount + 2 * kP1 + 8 * (os ^ 1);
     int32_t *const queueNext = h->dQueue + 8 * (h->waveCtrSet ^ 1);
-    int32_t *const ovfNext = pass == 1 ? p1Next : p2Next;
+
     WaveList wl2{};
     if (pass == 2) {                                     // the first pass's overflow list IS this pass's work list
         wl2.list = h->dOvfList1; wl2.count = p1Count; wl2.count_next = nullptr; wl2.seg_cap = (long long)nprob;
@@ -248,7 +248,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * cfg.nwv), cfg.lds, st, Wl, dC, h->dSw, theta, x, flag,
                        iters, active, warm, queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
                        pass == 1 ? h->dOvfList1 : (big ? h->dOvfList : nullptr), pass == 1 ? p1Count : (big ? ovfCount : nullptr),
-                       h->waveSim, bnbR, bnbI, BNB ? h->nBinary : (pass == 1 ? 1 : 0), queueNext, ovfNext,
+                       h->waveSim, bnbR, bnbI, BNB ? h->nBinary : (pass == 1 ? 1 : 0), queueNext, p2Next, p1Next,
                        BNB ? nullptr : h->dStat, BNB ? nullptr : h->dStatHost);
     h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());

@@ -431,6 +431,13 @@ def test_two_passes_of_the_wavefront_kernel(lmpc, gram):
         assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto)
         assert np.abs(x - xo).max() <= 1e-10
     assert qb.wave_stats()["first_pass_rows"] == 24 and qb.wave_stats()["within_48"] < qb.wave_stats()["problems"]
+    # calls in one pass and in two, alternating on the same handle (the counters of the first pass's overflow list are
+    # cleared by the call before: a one-pass call has to do that too -- tools/fuzz_closed_loop.py found it did not)
+    for tp in (0, 1, 0, 0, 1, 1, 0, 1):
+        qb.set_option("wave_two_pass", tp)
+        x, ef, it, act = qb.solve(thb)
+        assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto), tp
+        assert np.abs(x - xo).max() <= 1e-10
 
 
 def test_closed_loop_run_ahead_is_exact_after_the_handle_has_statistics(lmpc):
