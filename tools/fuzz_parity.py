@@ -5,7 +5,8 @@ fourth trial, wavefront-kernel shapes) f32; n up to 100 (two variable slots per 
 case report (oracle.ldp.marginal_report): the points whose terminal decision sits inside a tolerance band, where
 libdaqp may legitimately end on another active set.  usage: tools/fuzz_parity.py [trials] [seed] [gram]
 ("gram": the wavefront kernel's Gram-scan form against the oracle's mode 1, plus its agreement with the n-chain form
-on every solved point: flags, iteration counts, active sets, and the largest |dx|)"""
+on every solved point: flags, iteration counts, active sets, and the largest |dx|).  Wavefront-kernel trials also
+re-solve in two passes at random first-pass capacities, alternating with one pass on the same handle: identical arrays."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -107,6 +108,20 @@ for trial in range(trials):
         xw, efw, itw, actw = qp.solve(theta[sel][:64], warm=act[sel][:64])
         xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], so, warm=act[sel][:64])
         ok = np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= tol
+    if ok and not bnb and (f32 or qp.kernel_name == "wave"):
+        # the wavefront kernel in two passes, forced at a random first-pass capacity, alternating with one pass on the same
+        # handle: never visible in a result
+        for tp, c1 in ((1, int(rng.choice([8, 12, 16, 24, 32, 48]))), (0, 0), (1, int(rng.choice([8, 16, 24, 40]))), (1, 24), (0, 0)):
+            qp.set_option("wave_two_pass", tp)
+            if tp:
+                qp.set_option("wave_cap1", c1)
+            x2, ef2, it2, act2 = qp.solve_f32(theta.astype(np.float32)) if f32 else qp.solve(theta)
+            same = np.array_equal(ef2, ef) and np.array_equal(it2, it) and np.array_equal(act2, act) and np.array_equal(x2, x)
+            if not same:
+                ok = False
+                print(f"two-pass differs in trial {trial}: two_pass={tp} cap1={c1}", flush=True)
+        qp.set_option("wave_two_pass", -1)
+        stats["two_pass_legs"] = stats.get("two_pass_legs", 0) + 5
     for k, c in zip(*np.unique(ef, return_counts=True)):
         flags_seen[int(k)] = flags_seen.get(int(k), 0) + int(c)
     if gram and not f32 and qp.kernel_name == "wave":
