@@ -485,3 +485,25 @@ def test_closed_loop_run_ahead_is_exact_after_the_handle_has_statistics(lmpc):
         for key in ("U", "X", "x", "flag_min"):
             assert np.array_equal(out[key], ref[key]), (fused, key)
     assert qp.wave_stats()["first_pass_rows"] == 24
+
+
+@pytest.mark.parametrize("gram", [0, 1])
+def test_wave_path_closed_loop_edge_sizes(lmpc, gram):
+    """One scenario, one step, fewer scenarios than a wavefront has lanes, a horizon of two: the wavefront path's default
+    closed loop (rounds with run-ahead) and the step-synchronous one against the checker's warm = 2, bit for bit."""
+    from oracle import ldp as oldp
+    g = load_golden("pendulum_N50")
+    qp = _qp_from_golden(lmpc, g, 1)
+    qp.set_option("gram_scan", gram)
+    L = oracle_ldp_from(qp.ldp())
+    so = _gram_settings() if gram else oldp.default_settings()
+    base = g["theta"][:int(g["n_closed_loop"])]
+    for N, T in ((1, 1), (1, 40), (3, 2), (65, 2), (130, 7)):
+        pick = base[(np.arange(N) * 7) % len(base)]
+        x0, r = pick[:, :4].copy(), pick[:, 4:6].copy()
+        ref = oldp.simulate(L, x0, T, g["F"], g["G"], r=r, warm=2, settings=so)
+        for asyn in (1, 0):
+            qp.set_option("sim_async", asyn)
+            out = qp.simulate(x0, T, g["F"], g["G"], r=r, warm=True)
+            for key in ("U", "X", "x", "uprev", "flag_min"):
+                assert np.array_equal(out[key], ref[key]), (N, T, asyn, key)
