@@ -33,6 +33,7 @@
 #ifndef LMPC_HIP_H
 #define LMPC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -27,6 +27,20 @@ def test_library_exports_every_declared_symbol(lmpc):
     assert L.lmpc_abi_version() == 1
 
 
+def test_public_header_is_self_contained_c(tmp_path):
+    # the boundary is a C ABI: the header must compile on its own as plain C (a maintainer's cgo / ccall / ctypes
+    # generator reads nothing else) -- it used size_t without <stddef.h> until round 3
+    import shutil, subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "lmpc_hip.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_default_settings_match_reference_docs(lmpc):
     # /root/reference/docs/src/manual/solver.md:49-56
     s = lmpc.default_settings()
