@@ -71,6 +71,8 @@ def make_theta(name, n, seed, hard=False):
             r = rng.uniform(-5, 5, (n, 1))
         return np.ascontiguousarray(np.hstack([x, r, np.zeros((n, 1)), rng.uniform(-2, 2, (n, 1))]))
     if name in ("mass_spring", "mass_spring_3in"):
+        if hard == "feasible":   # feasible-dominated companion of SURVEY 8(d)'s prescribed +-4 sample
+            return np.ascontiguousarray(rng.uniform(-1.5, 1.5, (n, 12)))
         return np.ascontiguousarray(rng.uniform(-4, 4, (n, 12)))
     if name == "satellite20":   # hybrid MPC, theta = [x(3); r(3)] (reference mpc_examples.jl:533-546, runtests.jl:820-834)
         return np.ascontiguousarray(np.hstack([rng.uniform(-0.3, 0.3, (n, 1)), rng.uniform(-0.5, 0.5, (n, 2)),
@@ -208,8 +210,8 @@ class Workload:
         self.torch = torch
         self.workload = workload
         self.name = ("pendulum" if workload in ("pendulum", "pendulum_hard") else
-                     ("satellite20" if workload == "hybrid" else workload))
-        self.hard = workload == "pendulum_hard"
+                     ("satellite20" if workload == "hybrid" else workload.replace("_feasible", "")))
+        self.hard = "feasible" if workload.endswith("_feasible") else workload == "pendulum_hard"
         self.f32 = f32
         self.g = make_problem(self.name)
         self.nout = int(self.g["nu"])
@@ -376,9 +378,11 @@ def describe(w):
         body = ("inverted pendulum on cart, 4 states / 1 input, Np=50 Nc=5 (n=5 vars, 5 two-sided input bounds, "
                 "theta=[x;r;u_prev] nth=7)" + (", parameters from the example's +-20 range" if w.hard else ""))
     elif w.name == "mass_spring":
-        body = "mass-spring chain nm=6, Np=Nc=10 (n=10, m=63, nth=12)"
+        body = ("the reference's mass_spring example (mpc_examples.jl:241-286): nm=6, 1 input, Np=Nc=10 "
+                f"(n={qp.n}, m={qp.m}, nth={qp.nth}), x ~ U(-4,4)^12")
     elif w.name == "mass_spring_3in":
-        body = f"oscillating masses, 12 states / 3 inputs (synthetic B), Nc=10 (n={qp.n}, m={qp.m}, nth={qp.nth})"
+        body = (f"oscillating masses, 12 states / 3 inputs (synthetic B), Nc=10 (n={qp.n}, m={qp.m}, nth={qp.nth}), "
+                + ("x ~ U(-1.5,1.5)^12 (feasible-dominated companion sample)" if w.hard == "feasible" else "x ~ U(-4,4)^12 (SURVEY 8d)"))
     elif w.name.startswith("pendulum_N"):
         body = (f"the reference's published benchmark class (docs/src/manual/benchmark.md:4-16): inverted pendulum, "
                 f"Np = Nc = {qp.n}, input bounds + soft output bounds on every step (n={qp.n}, m={qp.m}, nth={qp.nth}); "
@@ -688,12 +692,102 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     return out
 
 
+PRIME_CALLS = 3      # untimed calls before a side configuration's timed region (warm-up)
+LINE_LIMIT = 8192    # the bench line must stay far below what the driver keeps of stdout
+
+
+def _r(v, sig=6):
+    """Round floats to `sig` significant digits (line size), leave the rest alone."""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if math.isfinite(v) else None
+    return v
+
+
+def compact_line(out):
+    """The ONE bench line of the driver contract, cut down to what the contract names (a few KB): headline fields,
+    roofline, cpu_baseline, and per-config summaries {value, unit, frac, verified[, gram_value, gram_frac]}.  The full
+    report (every histogram, verification block and note) goes to bench_full.json and to stderr."""
+    cfg = out.get("config", {})
+    roof = out.get("roofline", {})
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                          "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value_one_call_at_a_time"] = _r(out.get("value_one_call_at_a_time"))
+    line["verified"] = out.get("verified")
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:400], "batch_per_gpu": cfg.get("batch_per_gpu"),
+                      "kernel": cfg.get("kernel"), "batches_in_flight": cfg.get("batches_in_flight"),
+                      "options": {k: v for k, v in (cfg.get("options") or {}).items() if not k.startswith("_")}}
+    if "exchange" in cfg:
+        line["config"]["exchange_ms"] = _r(cfg["exchange"].get("ms"))
+    if isinstance(cfg.get("multi_abi"), dict):
+        ma = cfg["multi_abi"]
+        line["config"]["multi_abi"] = {k: _r(ma[k]) for k in ("n_devices", "identical", "oracle_sample_identical",
+                                                               "loopback_identical", "transport") if k in ma}
+    line["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
+                                                       "algorithmic_bytes_per_solve")}
+    if isinstance(roof.get("pipelined"), dict):
+        line["roofline"]["pipelined_frac"] = _r(roof["pipelined"].get("frac"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:200]}
+        if "all_cores" in cb:
+            line["cpu_baseline"]["all_cores"] = {"value": _r(cb["all_cores"].get("value")), "cores": cb["all_cores"].get("cores")}
+    if "configs" in out:
+        cs = {}
+        for name, c in out["configs"].items():
+            e = {"value": _r(c.get("value")), "unit": c.get("unit"), "verified": c.get("verified")}
+            r_ = c.get("roofline") or {}
+            if "frac" in r_:
+                e["frac"] = _r(r_.get("frac"), 4)
+                e["bound"] = r_.get("bound")
+            if "error" in c:
+                e["error"] = str(c["error"])[:120]
+            gs = c.get("gram_scan")
+            if isinstance(gs, dict):
+                e["gram_value"] = _r(gs.get("value"))
+                e["gram_verified"] = gs.get("verified")
+                gr = gs.get("roofline") or {}
+                if "frac" in gr:
+                    e["gram_frac"] = _r(gr.get("frac"), 4)
+                if "frac_executed" in gr:
+                    e["gram_frac_executed"] = _r(gr.get("frac_executed"), 4)
+            if isinstance(c.get("cpu_baseline"), dict):
+                e["cpu_1core"] = _r(c["cpu_baseline"].get("value"), 4)
+            if "first_run_value" in c:
+                e["first_run_value"] = _r(c.get("first_run_value"), 4)
+            cs[name] = e
+        line["configs"] = cs
+    line["full_report"] = "bench_full.json"
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) > LINE_LIMIT:          # never let the line outgrow the driver's window: drop the optional parts
+        line.pop("configs", None)
+        line["truncated"] = "configs dropped (line limit); see bench_full.json"
+        txt = json.dumps(line, separators=(",", ":"))
+    return txt
+
+
+def emit(out, final):
+    """Print the compact line on stdout (flush); on the final call also write the full report to bench_full.json (repo
+    root and gpurun_out/ when present) and to stderr."""
+    print(compact_line(out), flush=True)
+    if final:
+        full = json.dumps(out)
+        for d_ in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d_):
+                try:
+                    with open(os.path.join(d_, "bench_full.json"), "w") as fh:
+                        fh.write(full + "\n")
+                except OSError:
+                    pass
+        print("[bench full report] " + full, file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "soft_doc", "hybrid",
+    ap.add_argument("--workload", default="pendulum", choices=["pendulum", "pendulum_hard", "mass_spring", "mass_spring_3in", "mass_spring_3in_feasible", "soft_doc", "hybrid",
                              "pendulum_N50", "pendulum_N75", "pendulum_N100", "pendulum_N125"])
     ap.add_argument("--f32", action="store_true",
                     help="binary32 path (lmpc_solve_batch_f32_device; wavefront kernel; reference codegen float_type=float)")
@@ -1022,35 +1116,48 @@ def main():
             _phase("headline: cpu baseline done")
             if "marginal_cases" in out["cpu_baseline"]:
                 out["config"]["marginal_cases"] = out["cpu_baseline"].pop("marginal_cases")
+        # the headline line goes out NOW (and again, with the per-config summaries, as the last line): a failure or a
+        # timeout in a side configuration cannot lose it
+        run_configs = world == 1 and args.workload == "pendulum" and not args.no_configs and not args.f32 and not args.wave
+        emit(out, final=not run_configs)
         # ---- the other single-GPU BASELINE configurations, same process (driver-timed as part of this run)
-        if world == 1 and args.workload == "pendulum" and not args.no_configs and not args.f32 and not args.wave:
+        if run_configs:
             W.close()
             want_cpu = not args.no_cpu_baseline
             cfgs = {}
-            cfgs["pendulum_hard"] = side_config(torch, lmpc, "pendulum_hard", BATCH, dev, local_rank, 40, 5, False, want_cpu, 3.0)
-            cfgs["mass_spring_3in"] = side_config(torch, lmpc, "mass_spring_3in", BATCH, dev, local_rank, 4, 1, False, want_cpu, 4.0)
-            cfgs["hybrid_f32"] = side_config(torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
+
+            def cfg(name, fn, *a, **kw):
+                try:
+                    cfgs[name] = fn(*a, **kw)
+                except Exception as e:                        # reported in the line, never fatal for it
+                    cfgs[name] = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
+                    _phase(f"config {name}: FAILED {cfgs[name]['error']}")
+                return cfgs[name]
+            cfg("pendulum_hard", side_config, torch, lmpc, "pendulum_hard", BATCH, dev, local_rank, 40, 5, False, want_cpu, 3.0)
+            cfg("mass_spring", side_config, torch, lmpc, "mass_spring", BATCH, dev, local_rank, 20, 3, False, want_cpu, 3.0)
+            cfg("mass_spring_3in", side_config, torch, lmpc, "mass_spring_3in", BATCH, dev, local_rank, 4, 1, False, want_cpu, 4.0)
+            cfg("mass_spring_3in_feasible", side_config, torch, lmpc, "mass_spring_3in_feasible", BATCH, dev, local_rank, 4, 1, False, want_cpu, 3.0)
+            cfg("hybrid_f32", side_config, torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
             # the reference's only published numbers (plots, unstated hardware, generated C, one solve at a time
             # in closed loop): quoted beside the batched rate as context, not as a baseline
             ref_us = {50: 11.0, 75: 16.0, 100: 22.0, 125: 31.0}
             for n_ in (50, 75, 100, 125):
-                # (three untimed calls first: a fresh handle decides from its own statistics, a launch or two behind,
-                # whether its batches first run at a smaller working-set capacity -- DESIGN.md, two passes)
-                c_ = side_config(torch, lmpc, f"pendulum_N{n_}", 200_000, dev, local_rank, 3, 3, False, want_cpu, 3.0)
+                c_ = cfg(f"pendulum_N{n_}", side_config, torch, lmpc, f"pendulum_N{n_}", 200_000, dev, local_rank, 3, PRIME_CALLS, False, want_cpu, 3.0)
                 c_["reference_context"] = {"median_solve_time_us": ref_us[n_], "solves_per_s_one_thread": 1e6 / ref_us[n_],
                                            "source": "docs/src/assets/benchmark_scaling_time.png (benchmark.md:23), read off the "
                                                      "plot +-10 %, hardware unstated, state constraints of the benchmark script "
                                                      "unpublished (this fixture uses its own, see DESIGN.md)"}
-                cfgs[f"pendulum_N{n_}"] = c_
             _phase("config closed_loop")
-            cfgs["closed_loop_pendulum"] = closed_loop_config(torch, lmpc, "pendulum", BATCH, 100, dev, local_rank, want_cpu)
-            cfgs["closed_loop_pendulum_N50"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev, local_rank, want_cpu)
-            cfgs["closed_loop_pendulum_N50"]["gram_scan_form"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev,
-                                                                                    local_rank, False, gram=1)
+            cfg("closed_loop_pendulum", closed_loop_config, torch, lmpc, "pendulum", BATCH, 100, dev, local_rank, want_cpu)
+            c_ = cfg("closed_loop_pendulum_N50", closed_loop_config, torch, lmpc, "pendulum_N50", 200_000, 100, dev, local_rank, want_cpu)
+            try:
+                c_["gram_scan"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev, local_rank, False, gram=1)
+            except Exception as e:
+                c_["gram_scan"] = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
             _phase("config region_discovery")
-            cfgs["region_discovery"] = region_discovery_config(torch, lmpc, dev, local_rank, BATCH, want_cpu)
+            cfg("region_discovery", region_discovery_config, torch, lmpc, dev, local_rank, BATCH, want_cpu)
             out["configs"] = cfgs
-        print(json.dumps(out), flush=True)
+            emit(out, final=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

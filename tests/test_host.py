@@ -349,8 +349,38 @@ def test_bench_helpers_cover_every_workload():
         th = bench.make_theta(name, 257, 5, hard=False)
         assert th.shape == (257, g["f_theta"].shape[1]) and th.flags.c_contiguous and np.isfinite(th).all()
     assert bench.make_theta("pendulum", 64, 1, hard=True).std() > bench.make_theta("pendulum", 64, 1).std()
+    assert bench.make_theta("mass_spring", 9, 1).shape == (9, bench.make_problem("mass_spring")["f_theta"].shape[1])
+    assert np.abs(bench.make_theta("mass_spring_3in", 64, 1, hard="feasible")).max() <= 1.5
     per = bench.algorithmic_bytes(7, 1)
     assert per == 68
     nrot = bench.rotation_depth(1_000_000, per)
     assert nrot * 1_000_000 * per > 1.25 * bench.L3_BYTES and nrot <= 8
     assert bench.rotation_depth(100, per) == 64           # tiny batches: the cap (everything is cache-resident anyway)
+
+
+def test_bench_line_is_compact_and_strict_json():
+    """The driver keeps only a tail of stdout: the bench line must stay a few KB whatever the full report holds
+    (round 3's line grew to 37 KB and was not parsed).  Built here from a full report of every configuration with
+    padded notes; strict JSON (no NaN / Infinity), the contract's keys present, under the limit."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_final.json")))
+    full["roofline"]["frac"] = float("nan")                # a non-finite number must not reach the line as NaN
+    full["config"]["notes"] = "x" * 50000                   # whatever the full report grows to
+    for c in full["configs"].values():
+        c["verification"] = {"blob": list(range(3000))}
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT and len(line) < 4096 + 2048
+    obj = json.loads(line, parse_constant=lambda s: (_ for _ in ()).throw(ValueError(s)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in obj, k
+    assert obj["roofline"]["frac"] is None and obj["roofline"]["peak"] == 8000.0
+    assert set(obj["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(obj["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert "model" not in obj["config"] and obj["config"]["workload"].startswith("pendulum")
+    assert set(obj["configs"]) == set(full["configs"])
+    # a report with very many configurations still yields a line under the limit (configs dropped, said so)
+    full["configs"] = {f"c{i}": dict(full["configs"]["pendulum_N50"]) for i in range(200)}
+    line2 = bench.compact_line(full)
+    assert len(line2) < bench.LINE_LIMIT and "truncated" in json.loads(line2)
