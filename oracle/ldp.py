@@ -116,7 +116,7 @@ _lib = None
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                              for f in ("daqp_ldp_oracle.c", "daqp_ldp_oracle_f32.c", "Makefile")):
+                                              for f in ("daqp_ldp_oracle.c", "daqp_ldp_oracle_f32.c", "daqp_avi_oracle.c", "Makefile")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 

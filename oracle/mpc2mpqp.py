@@ -15,8 +15,10 @@ the features the benchmark / known-answer problems exercise are restated: refere
 (:48-66, :579-604) and measured disturbances as states (:664-669), generalised parameters with preview
 (:125-145, :478-508), move blocking (:830-857, setup.jl:202-248 incl. scalar and per-input blocks), constant
 offsets in dynamics and outputs (:683-688, :517-530, :393-398), x0-uncertainty tightening (robust.jl:1-29),
-binary inputs.  NOT restated: the variational (game-theoretic) objective (:900-950), prioritised constraints /
-break points beyond the stable sort (:859-866, :890-892), invariant-set terminal constraints.
+binary inputs, the variational (game-theoretic) objective of several players (:900-950, setup.jl:137-151), whose
+non-symmetric H makes the problem an affine variational inequality (setup.jl:13 is_avi).  NOT restated:
+prioritised constraints / break points beyond the stable sort (:859-866, :890-892), invariant-set terminal
+constraints.
 Reference lines followed, all under /root/reference/src/:
 
     zoh                     utils.jl:291-295
@@ -26,6 +28,7 @@ Reference lines followed, all under /root/reference/src/:
     create_extended_cost    mpc2mpqp.jl:692-731
     state_predictor         mpc2mpqp.jl:20-46
     create_objective        mpc2mpqp.jl:407-533
+    create_variational_objective  mpc2mpqp.jl:900-950   (set_objective!(mpc, uids; ...) setup.jl:137-151)
     create_controlbounds    mpc2mpqp.jl:206-245
     create_general_constraints mpc2mpqp.jl:249-354
     create_constraints      mpc2mpqp.jl:358-402
@@ -116,6 +119,22 @@ class MPCProblem:
     Dd: Optional[np.ndarray] = None         #                       y  = C x + Dd d       (model.jl:28)
     binary_controls: Sequence[int] = ()     # 0-based inputs restricted to {umin, umax} (setup.jl:277-281)
     Nc_binary: int = -1                     # "binary control horizon" (-1 = whole control horizon)
+    objectives: list = field(default_factory=list)   # mpc.objectives (types.jl:159): one (weights, uids) per player
+
+    def add_objective(self, uids, Q=None, R=None, Rr=None, S=None, Qf=None):
+        """setup.jl:137-151 set_objective!(mpc, uids; ...): the cost of the player that owns inputs `uids` (0-based
+        here).  Unset weights are zero (not the MPC's defaults), Qf defaults to Q; mpc.weights.Rr[uids,uids] is
+        set too so that get_parameter_dims keeps u_prev in theta (:149)."""
+        uids = [int(u) for u in uids]
+        nui = len(uids)
+        w = {"Q": np.zeros((self.ny, self.ny)) if Q is None else _as_weight(Q, self.ny),
+             "R": np.zeros((nui, nui)) if R is None else _as_weight(R, nui),
+             "Rr": np.zeros((nui, nui)) if Rr is None else _as_weight(Rr, nui),
+             "S": np.zeros((self.nx, nui)) if S is None else np.asarray(S, float).reshape(self.nx, nui)}
+        w["Qf"] = w["Q"].copy() if Qf is None else _as_weight(Qf, self.ny)
+        self.Rr[np.ix_(uids, uids)] = w["Rr"]
+        self.objectives.append((w, uids))
+        return self
 
     def np_base(self):
         """utils.jl:207-216 get_affine_parameter_base_dim (largest column count among Eu / Ap)."""
@@ -456,6 +475,71 @@ def dense_objective(p: MPCProblem, F, Phi, Gam, C, Q, R, S, Qf):
     return (H + H.T) / 2, f, f_theta, H_theta
 
 
+def extended_cost_player(p: MPCProblem, w, uids):
+    """mpc2mpqp.jl:692-731 create_extended_cost(mpc, weights; uids): one player's Q, R, S, Qf on the extended
+    system; S has one column per input of the player."""
+    nx, nr, nd, nuprev, _ = p.parameter_dims()
+    nu, ny, nui = p.nu, p.ny, len(uids)
+    K = p.gain()
+    Q, R, Rr, S = w["Q"].copy(), w["R"].copy(), w["Rr"].copy(), w["S"].copy()
+    Qf = Q.copy() if not np.any(w["Qf"]) else w["Qf"].copy()                  # :694 (Qfx is not restated)
+    if nr > 0 and not p.reference_preview:
+        S = np.vstack([S, np.zeros((ny, nui))])
+    if p.nd > 0 and not p.disturbance_preview:
+        S = np.vstack([S, np.zeros((p.nd, nui))])
+    if nuprev > 0:
+        Rrfull = np.zeros((nu, nu))
+        Rrfull[np.ix_(uids, uids)] = Rr
+        Q = block_diag(Q, Rrfull)
+        Qf = block_diag(Qf, np.zeros((nu, nu)))
+        S = np.vstack([S, -Rrfull[:, uids]])
+        S[:nx] -= K[uids].T @ Rr
+        R = R + Rr
+    if np.any(R != 0) and np.any(K != 0):
+        Rfull = np.zeros((nu, nu))
+        Rfull[np.ix_(uids, uids)] = w["R"]
+        Q = block_diag(Q, Rfull)
+        Qf = block_diag(Qf, np.zeros((nu, nu)))
+        S[:nx] -= K[uids].T @ w["R"]
+    if p.has_f_offset():
+        S = np.vstack([S, np.zeros((1, nui))])
+    return Q, R, S, Qf
+
+
+def variational_objective(p: MPCProblem, Phi, Gam, C):
+    """mpc2mpqp.jl:900-950 create_variational_objective: block row i of H is the gradient of player i's cost with
+    respect to its OWN inputs, Gam_i' CQC_i [Gam_1 ... Gam_P] (+ R_i on its own block) -- not symmetric unless the
+    players' costs agree; f = 0, f_theta row block i = Gam_i' CQC_i Phi (+ S terms)."""
+    N, Nc, nu = p.Np, p.Nc, p.nu
+    ws = [extended_cost_player(p, w, uids) for w, uids in p.objectives]
+    uids = [u for _, u in p.objectives]
+    flat = sorted(u for us in uids for u in us)
+    if flat != list(range(nu)):
+        raise ValueError("The controls have to be fully partitioned")
+    nU, nxe = Gam.shape[1], Phi.shape[1]
+    # (Julia: vec(uids .+ (0:nu:nU-nu)') -- all inputs of the player at step 0, then step 1, ...)
+    Uids = [np.asarray([u + k for k in range(0, nU - nu + 1, nu) for u in us]) for us in uids]
+    Gs = [Gam[:, U] for U in Uids]
+    H = np.zeros((nU, nU))
+    f_theta = np.zeros((nU, nxe))
+    for i, (Q, R, S, Qf) in enumerate(ws):
+        nui = len(uids[i])
+        CQC = block_diag(np.kron(np.eye(N), C.T @ Q @ C), C.T @ Qf @ C)
+        for j in range(len(ws)):
+            H[np.ix_(Uids[i], Uids[j])] = Gs[i].T @ CQC @ Gs[j]
+            if i == j:
+                H[np.ix_(Uids[i], Uids[i])] += np.kron(np.eye(Nc), R)
+                last = Uids[i][-nui:]
+                H[np.ix_(last, last)] += (N - Nc) * R
+        f_theta[Uids[i]] = Gs[i].T @ CQC @ Phi
+        Stot = np.vstack([np.kron(np.eye(Nc), S), np.zeros(((N - Nc + 1) * nxe, Nc * nui))])
+        Stot[Nc * nxe:N * nxe, -nui:] = np.tile(S, (N - Nc, 1))
+        GS = Gs[i].T @ Stot
+        H[np.ix_(Uids[i], Uids[i])] += GS + GS.T
+        f_theta[Uids[i]] += Stot.T @ Phi
+    return H, np.zeros(nU), f_theta, np.zeros((0, 0))
+
+
 def apply_move_block(p, H, f, f_theta, cons):
     """mpc2mpqp.jl:830-857: U = T V with one column of T per block; bounds of dropped moves go."""
     A, bu, bl, W, soft, prio = cons
@@ -675,6 +759,7 @@ class MPQP:
     prio: np.ndarray
     nu: int = 1
     nx: int = 0
+    is_symmetric: bool = True            # types.jl:91: isapprox(H, H', rtol = 1e-9); false -> DAQP's is_avi (setup.jl:13)
 
     @property
     def n(self):
@@ -697,8 +782,11 @@ def mpc2mpqp(p: MPCProblem) -> MPQP:
     """mpc2mpqp.jl:612-647."""
     F, G, C = extended_system(p)
     Phi, Gam = state_predictor(F, G, p.Np, p.Nc)
-    Q, R, S, Qf = extended_cost(p)
-    H, f, f_theta, H_theta = dense_objective(p, F, Phi, Gam, C, Q, R, S, Qf)
+    if not p.objectives:                         # normal, single-objective MPC
+        Q, R, S, Qf = extended_cost(p)
+        H, f, f_theta, H_theta = dense_objective(p, F, Phi, Gam, C, Q, R, S, Qf)
+    else:
+        H, f, f_theta, H_theta = variational_objective(p, Phi, Gam, C)
     cons = dense_constraints(p, Phi, Gam)
     if p.move_blocks:
         H, f, f_theta, cons = apply_move_block(p, H, f, f_theta, cons)
@@ -720,7 +808,8 @@ def mpc2mpqp(p: MPCProblem) -> MPQP:
         senses[:nsimple][brow[:nsimple]] += BINARY
     bu = np.clip(bu, -1e30, 1e30)
     bl = np.clip(bl, -1e30, 1e30)
-    return MPQP(H, f, H_theta, f_theta, A, bu, bl, W, senses, prio.astype(np.int32), p.nu, p.nx)
+    sym = bool(np.linalg.norm(H - H.T) <= 1e-9 * max(np.linalg.norm(H), np.linalg.norm(H.T)))   # mpc2mpqp.jl:897
+    return MPQP(H, f, H_theta, f_theta, A, bu, bl, W, senses, prio.astype(np.int32), p.nu, p.nx, sym)
 
 
 # --------------------------------------------------------------------------- named problems
@@ -941,6 +1030,16 @@ def moveblock_kat() -> MPCProblem:
     [2,2,2,4], Nc = 7, four moves), Q = 1, R = Rr = 0, no bounds; y reaches r = 5."""
     p = make_mpc([[0.77880078307]], [[1.0]], [[2.211992169]], Np=10, Q=[1.0], R=[0.0], Rr=[0.0], Ts=100.0)
     return p.move_block([2, 2, 2, 24])
+
+
+def game_kat() -> MPCProblem:
+    """test/runtests.jl:1337-1358 "Game-theoretic MPC": double integrator with two inputs, one player per input
+    (player 1 tracks x1, player 2 tracks x2, both Rr = 1e3), |u| <= 1, move blocks [1,1,8]; the closed loop from
+    x0 = [10,10] with r = [10,0] ends at y = [10, 0] (atol 1e-4) and mpQP.H is not symmetric."""
+    p = make_mpc([[1, 0.1], [0, 1]], [[0, 0], [1, 1]], np.eye(2), Np=10, umin=[-1.0, -1.0], umax=[1.0, 1.0])
+    p.add_objective([0], Q=[1.0, 0.0], Rr=1e3)
+    p.add_objective([1], Q=[0.0, 1.0], Rr=1e3)
+    return p.move_block([1, 1, 8])
 
 
 def form_parameter(p: MPCProblem, x, r=None, uprev=None, par=None, d=None):
