@@ -94,6 +94,35 @@ int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
                const lmpc_settings *s, int device);
 
 /*
+ * The same setup with the two keywords the reference passes to DAQP.setup next to the matrices
+ * (/root/reference/src/setup.jl:11-13):
+ *
+ *   break_points[n_break_points]  mpQP.break_points (Cint; /root/reference/src/mpc2mpqp.jl:890-892): the ends of the
+ *          constraint priority levels (`prio` of set_bounds! / add_constraint!, setup.jl:50-97).  Empty (NULL, 0) for
+ *          every controller without priorities.  A non-empty list asks DAQP for its hierarchical mode, which the
+ *          batched backend does not implement: LMPC_ERR_UNSUPPORTED (never silently ignored).
+ *   is_avi  !mpQP.is_symmetric: H is NOT symmetric (several objectives, one per player: set_objective!(mpc, uids; ...),
+ *          setup.jl:137-151, mpc2mpqp.jl:900-950) and the problem is the affine variational inequality
+ *              find x in the constraint set with (H x + f + f_theta theta)'(y - x) >= 0 for every feasible y
+ *          (H + H' must be positive definite: LMPC_ERR_NONCONVEX otherwise).  Solved by the library's AVI kernel
+ *          (one problem per lane, recursive L D U factorisation; binary64; no BINARY rows); every entry point that
+ *          takes a handle works on it except the binary32 ones and the Gram-scan option.  is_avi == 0 with a
+ *          non-symmetric H is LMPC_ERR_BADARG.
+ * lmpc_setup itself decides is_avi from H exactly as the reference decides mpQP.is_symmetric
+ * (isapprox(H, H', rtol = 1e-9), mpc2mpqp.jl:897) and has no priorities.
+ * lmpc_is_avi: 1 / 0.  lmpc_get_avi: the AVI pack's second matrix MR[m*n] (row j = (H^-1 ML_j')', ML = what
+ * lmpc_get_ldp returns as M) and the full Gram matrix G[m*m] = ML MR' (row-major; either may be NULL).
+ */
+int lmpc_setup_ex(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
+                  const double *H, const double *f, const double *f_theta,
+                  const double *A, const double *bu, const double *bl, const double *W,
+                  const int32_t *sense, const double *Kfb, int nx,
+                  const lmpc_settings *s, const int32_t *break_points, int n_break_points,
+                  int is_avi, int device);
+int lmpc_is_avi(const lmpc_handle *h);
+int lmpc_get_avi(const lmpc_handle *h, double *MR, double *G);
+
+/*
  * Setup from an already-transformed least-distance problem -- the data the reference's code
  * generator writes into C arrays (codegen.jl:183-189: Dth, du, dl, Uth_offset, u_offset, plus
  * DAQP's M) -- all ROW-major:
@@ -118,6 +147,16 @@ int lmpc_transform(int n, int m, int ms, int nth, int nout,
                    const int32_t *sense, const double *Kfb, int nx,
                    double *M, double *du, double *dl, double *Dth,
                    double *Rout, double *x0, double *Xth);
+
+/* Host-only half of an is_avi setup (no GPU touched): the transform described at lmpc_setup_ex, outputs row-major --
+ * ML[m*n], MR[m*n], G[m*m], du[m], dl[m], Dth[m*nth], Rout[nout*n] (leading rows of I), x0[nout], Xth[nout*nth];
+ * any output may be NULL.  LMPC_ERR_NONCONVEX if H + H' is not positive definite. */
+int lmpc_transform_avi(int n, int m, int ms, int nth, int nout,
+                       const double *H, const double *f, const double *f_theta,
+                       const double *A, const double *bu, const double *bl, const double *W,
+                       const int32_t *sense, const double *Kfb, int nx,
+                       double *ML, double *MR, double *G, double *du, double *dl, double *Dth,
+                       double *Rout, double *x0, double *Xth);
 
 /* Copies the constant pack held by the handle back to the caller (row-major, sizes as in
  * lmpc_setup_ldp); any pointer may be NULL.  Lets a test feed the SAME pack to the oracle. */

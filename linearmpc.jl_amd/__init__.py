@@ -10,11 +10,11 @@ one-process-per-GPU sharding helpers (shard).  Importing the package does not ne
 setting up or solving does, and there is no CPU fallback.
 """
 from ._cabi import LIB_PATH, SYMBOLS, LmpcError, Settings, default_settings, default_settings_f32, lib  # noqa: F401
-from .solver import BatchedQP, MultiQP, transform  # noqa: F401
+from .solver import BatchedQP, MultiQP, transform, transform_avi  # noqa: F401
 from .mpc import MPC, MPQP, GeneratedController  # noqa: F401
 from .shard import gather_shards, shard_bounds, shard_counts, solve_sharded  # noqa: F401
 from . import explicit  # noqa: F401
 
-__all__ = ["BatchedQP", "MultiQP", "transform", "MPC", "MPQP", "GeneratedController", "Settings", "default_settings", "default_settings_f32", "LmpcError",
+__all__ = ["BatchedQP", "MultiQP", "transform", "transform_avi", "MPC", "MPQP", "GeneratedController", "Settings", "default_settings", "default_settings_f32", "LmpcError",
            "gather_shards", "shard_bounds", "shard_counts", "solve_sharded", "explicit", "lib", "LIB_PATH",
            "SYMBOLS"]

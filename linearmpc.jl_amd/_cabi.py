@@ -32,6 +32,7 @@ SYMBOLS = (
     "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
     "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch", "lmpc_check",
     "lmpc_distinct_active_sets_device", "lmpc_distinct_active_sets_overflowed", "lmpc_wave_stats",
+    "lmpc_setup_ex", "lmpc_is_avi", "lmpc_get_avi", "lmpc_transform_avi",
 )
 
 
@@ -88,6 +89,14 @@ def lib():
     L.lmpc_default_settings.restype = None
     L.lmpc_setup.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32, vp, i32]
     L.lmpc_setup.restype = i32
+    L.lmpc_setup_ex.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32, vp, vp, i32, i32, i32]
+    L.lmpc_setup_ex.restype = i32
+    L.lmpc_transform_avi.argtypes = [i32] * 5 + [vp] * 9 + [i32] + [vp] * 9
+    L.lmpc_transform_avi.restype = i32
+    L.lmpc_is_avi.argtypes = [vp]
+    L.lmpc_is_avi.restype = i32
+    L.lmpc_get_avi.argtypes = [vp, vp, vp]
+    L.lmpc_get_avi.restype = i32
     L.lmpc_setup_ldp.argtypes = [ctypes.POINTER(vp)] + [i32] * 5 + [vp] * 9 + [i32]
     L.lmpc_setup_ldp.restype = i32
     L.lmpc_transform.argtypes = [i32] * 5 + [vp] * 9 + [i32] + [vp] * 7

@@ -76,6 +76,7 @@ void fill_layout(lmpc_handle *h) {
     Wl.primal_tol = S.primal_tol; Wl.dual_tol = S.dual_tol; Wl.zero_tol = S.zero_tol;
     Wl.progress_tol = S.progress_tol; Wl.fval_bound = S.fval_bound; Wl.rho_soft = S.rho_soft;
     Wl.cycle_tol = S.cycle_tol; Wl.iter_limit = S.iter_limit;
+    if (h->avi) avi_fill_settings(h);
 }
 
 // choose the kernel variant and upload the constant pack
@@ -458,6 +459,21 @@ int launch_sim_run(lmpc_handle *h, int64_t nprob, const double *theta, uint64_t 
 
 int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag,
            int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    if (h->avi) {
+        // non-symmetric H (variational objective): its own kernel; timing events around the one launch
+        EventTriple ev{};
+        if (h->prof) {
+            HIP_TRY(h, pool_event(h, &ev.a));
+            HIP_TRY(h, pool_event(h, &ev.b));
+            HIP_TRY(h, hipEventRecord(ev.a, st));
+        }
+        const int rca = launch_avi(h, nprob, theta, x, flag, iters, active, warm, st);
+        if (h->prof) {
+            if (rca == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+            else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+        }
+        return rca;
+    }
     if (h->useWave) {
         // scenario-asynchronous closed loop on the wavefront path: streaming half = sim_run_kernel on the handle's
         // screening pack, iterating half = the wavefront kernel on that pass's work list (it advances the scenarios
@@ -598,19 +614,63 @@ void lmpc_default_settings_f32(lmpc_settings *s) {
     s->fval_bound = 1e30; s->rho_soft = 1e-3; s->cycle_tol = 10; s->iter_limit = 10000;
 }
 
+static int setup_common(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
+                        const double *f, const double *f_theta, const double *A, const double *bu,
+                        const double *bl, const double *W, const int32_t *sense, const double *Kfb, int nx,
+                        const lmpc_settings *s, const int32_t *break_points, int n_break_points, int is_avi, int device) {
+    if (!out) return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup: out is NULL");
+    *out = nullptr;
+    if (n_break_points < 0 || (n_break_points > 0 && !break_points))
+        return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_ex: break_points is NULL");
+    if (n_break_points > 0)
+        // priority levels of the constraints (reference setup.jl:12, mpc2mpqp.jl:890-892): DAQP then solves a
+        // hierarchy of problems, one per level; that mode is not built -- refuse rather than ignore the levels
+        return fail(nullptr, LMPC_ERR_UNSUPPORTED, "lmpc_setup_ex: prioritised constraints (mpQP.break_points non-empty) "
+                                                   "are not supported by the batched backend");
+    if (!H || n <= 0) return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup: bad dimensions or NULL array");
+    const bool sym = h_is_symmetric(H, n);
+    if (is_avi < 0) is_avi = sym ? 0 : 1;         // lmpc_setup: decided as the reference decides it (mpc2mpqp.jl:897)
+    if (!is_avi && !sym)
+        return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_ex: H is not symmetric but is_avi is 0 (the reference passes "
+                                              "is_avi = !mpQP.is_symmetric, setup.jl:13)");
+    lmpc_handle *h = new lmpc_handle();
+    if (s) h->S = *s; else lmpc_default_settings(&h->S);
+    h->device = device;
+    int rc;
+    if (is_avi) {
+        rc = qp_to_avi(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->err);
+        if (rc == LMPC_OK) rc = finalize_avi(h);
+        if (rc == LMPC_OK) fill_layout(h);
+    } else {
+        rc = qp_to_ldp(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->err);
+        if (rc == LMPC_OK) rc = finalize_handle(h);
+    }
+    if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
+    *out = h;
+    return LMPC_OK;
+}
+
 int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
                const double *f, const double *f_theta, const double *A, const double *bu,
                const double *bl, const double *W, const int32_t *sense, const double *Kfb, int nx,
                const lmpc_settings *s, int device) {
-    if (!out) return fail(nullptr, LMPC_ERR_BADARG, "lmpc_setup: out is NULL");
-    *out = nullptr;
-    lmpc_handle *h = new lmpc_handle();
-    if (s) h->S = *s; else lmpc_default_settings(&h->S);
-    h->device = device;
-    int rc = qp_to_ldp(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->err);
-    if (rc == LMPC_OK) rc = finalize_handle(h);
-    if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
-    *out = h;
+    return setup_common(out, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, s, nullptr, 0, -1, device);
+}
+
+int lmpc_setup_ex(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
+                  const double *f, const double *f_theta, const double *A, const double *bu,
+                  const double *bl, const double *W, const int32_t *sense, const double *Kfb, int nx,
+                  const lmpc_settings *s, const int32_t *break_points, int n_break_points, int is_avi, int device) {
+    return setup_common(out, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, s, break_points,
+                        n_break_points, is_avi != 0 ? 1 : 0, device);
+}
+
+int lmpc_is_avi(const lmpc_handle *h) { return h ? (h->avi ? 1 : 0) : LMPC_ERR_BADARG; }
+
+int lmpc_get_avi(const lmpc_handle *h, double *MR, double *G) {
+    if (!h || !h->avi) return LMPC_ERR_BADARG;
+    if (MR) std::memcpy(MR, h->P.MR.data(), sizeof(double) * h->P.MR.size());
+    if (G) std::memcpy(G, h->P.Gf.data(), sizeof(double) * h->P.Gf.size());
     return LMPC_OK;
 }
 
@@ -656,6 +716,22 @@ int lmpc_transform(int n, int m, int ms, int nth, int nout, const double *H, con
         if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size());
     };
     cp(M, P.M); cp(du, P.du0); cp(dl, P.dl0); cp(Dth, P.Dth); cp(Rout, P.Rout); cp(x0, P.x0); cp(Xth, P.Xth);
+    return LMPC_OK;
+}
+
+int lmpc_transform_avi(int n, int m, int ms, int nth, int nout, const double *H, const double *f,
+                       const double *f_theta, const double *A, const double *bu, const double *bl,
+                       const double *W, const int32_t *sense, const double *Kfb, int nx, double *ML, double *MR,
+                       double *G, double *du, double *dl, double *Dth, double *Rout, double *x0, double *Xth) {
+    HostPack P;
+    std::string err;
+    int rc = qp_to_avi(P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, err);
+    if (rc != LMPC_OK) return fail(nullptr, rc, err);
+    auto cp = [](double *dst, const std::vector<double> &src) {
+        if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size());
+    };
+    cp(ML, P.M); cp(MR, P.MR); cp(G, P.Gf); cp(du, P.du0); cp(dl, P.dl0); cp(Dth, P.Dth); cp(Rout, P.Rout);
+    cp(x0, P.x0); cp(Xth, P.Xth);
     return LMPC_OK;
 }
 
@@ -913,7 +989,7 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     // cleared between two calls (codegen/mpc_update_qp.c:44-54) -- instead of re-appending the rows of the mask one
     // by one.  Option "sim_keep_factor" 0 (or no memory for it): the mask-based warm start of the other paths.
     h->keepOn = false;
-    if (h->useWave && warm && !h->bnb && h->simKeep && T > 1) {
+    if (h->useWave && !h->avi && warm && !h->bnb && h->simKeep && T > 1) {
         const int rck = ensure_keep(h, N, st);
         if (rck != LMPC_OK) return rck;
     }
@@ -1434,6 +1510,7 @@ int lmpc_wave_stats(lmpc_handle *h, unsigned long long out[5]) {
 
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
+    if (h->avi) return "avi";
     if (h->useWave) return "wave";
     // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm
     // starts, closed loop, generated-controller call) the two-kernel form
@@ -1540,7 +1617,9 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         h->laneBlock = value;
         return LMPC_OK;
     }
+    if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "wave") == 0) {
+        if (h->avi) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: a variational-inequality handle has one kernel");
         if (value && !h->dCw) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: wavefront kernel does not cover this problem");
         if (!value && (h->laneN == 0 || h->bnb))
             return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
@@ -1565,6 +1644,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->dOvfList); h->ovfCap = 0; rel(h->dOvfList1); h->ovfCap1 = 0; rel(h->dBigR); rel(h->dBigI);
     rel(h->dBnbR); rel(h->dBnbI); h->bnbBytesR = h->bnbBytesI = 0;
     rel(h->dKeepR); rel(h->dKeepI); h->keepCap = 0;
+    avi_release(h, false);
     return check_fast_err(h);
 }
 
@@ -1580,7 +1660,8 @@ int lmpc_check(lmpc_handle *h) {
 void lmpc_free(lmpc_handle *h) {
     if (!h) return;
     lmpc::DeviceScope scope;
-    if (h->dC || h->dCw || h->sTheta) scope.enter(h->device);
+    if (h->dC || h->dCw || h->dCa || h->sTheta) scope.enter(h->device);
+    avi_release(h, true);
     for (auto &ev : h->events) { hipEventDestroy(ev.a); if (ev.mid) hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);

@@ -1,0 +1,118 @@
+// Affine-variational-inequality mode of a handle (non-symmetric H; reference setup.jl:11-13 is_avi): constant pack,
+// launch of avi_kernel (lmpc_avi_kernel.hpp), scratch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "lmpc_avi_kernel.hpp"
+#include "lmpc_internal.hpp"
+
+namespace lmpc {
+
+constexpr int kAviMaxN = 128, kAviMaxM = 1024, kAviMaxCap = 160;
+constexpr size_t kAviLdsPack = 64 * 1024;      // the constant pack is staged in LDS up to this size
+
+void avi_fill_settings(lmpc_handle *h) {
+    AviLayout &A = h->A;
+    A.primal_tol = h->S.primal_tol; A.dual_tol = h->S.dual_tol; A.zero_tol = h->S.zero_tol; A.rho_soft = h->S.rho_soft;
+    A.iter_limit = h->S.iter_limit;
+}
+
+int finalize_avi(lmpc_handle *h) {
+    const HostPack &P = h->P;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    if (h->device < 0 || h->device >= ndev) return fail(h, LMPC_ERR_BADARG, "lmpc: bad device ordinal");
+    const int cap = P.n + 1 + P.nsoft;
+    if (P.n > kAviMaxN || P.m > kAviMaxM || P.m < 1 || cap > kAviMaxCap)
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: variational objective: problem outside what the kernel covers "
+                                             "(n <= 128, 1 <= m <= 1024, n + 1 + #soft <= 160)");
+    h->avi = true;
+    h->useWave = true;                 // keeps every lane / screening shortcut of the QP kernels off this handle
+    h->capFull = cap;
+    h->kname = "avi";
+    LMPC_ENTER_DEVICE(h);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->numCU = prop.multiProcessorCount;
+    }
+    AviLayout &A = h->A;
+    A.n = P.n; A.m = P.m; A.nth = P.nth; A.nout = P.nout; A.words = P.words(); A.cap = cap;
+    int o = 0;
+    A.oML = o; o += P.m * P.n;
+    A.oMR = o; o += P.m * P.n;
+    A.oG = o; o += P.m * P.m;
+    A.odu = o; o += P.m;
+    A.odl = o; o += P.m;
+    A.oDth = o; o += P.m * P.nth;
+    A.oRout = o; o += P.nout * P.n;
+    A.ox0 = o; o += P.nout;
+    A.oXth = o; o += P.nout * P.nth;
+    A.nC = o;
+    avi_fill_settings(h);
+    std::vector<double> buf((size_t)o, 0.0);
+    std::memcpy(&buf[A.oML], P.M.data(), sizeof(double) * P.M.size());
+    std::memcpy(&buf[A.oMR], P.MR.data(), sizeof(double) * P.MR.size());
+    std::memcpy(&buf[A.oG], P.Gf.data(), sizeof(double) * P.Gf.size());
+    std::memcpy(&buf[A.odu], P.du0.data(), sizeof(double) * P.m);
+    std::memcpy(&buf[A.odl], P.dl0.data(), sizeof(double) * P.m);
+    if (P.m * P.nth) std::memcpy(&buf[A.oDth], P.Dth.data(), sizeof(double) * P.Dth.size());
+    std::memcpy(&buf[A.oRout], P.Rout.data(), sizeof(double) * P.Rout.size());
+    std::memcpy(&buf[A.ox0], P.x0.data(), sizeof(double) * P.x0.size());
+    if (P.nout * P.nth) std::memcpy(&buf[A.oXth], P.Xth.data(), sizeof(double) * P.Xth.size());
+    HIP_TRY(h, hipMalloc(&h->dCa, sizeof(double) * buf.size()));
+    HIP_TRY(h, hipMemcpy(h->dCa, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->dSa, sizeof(int32_t) * P.m));
+    HIP_TRY(h, hipMemcpy(h->dSa, P.sense.data(), sizeof(int32_t) * P.m, hipMemcpyHostToDevice));
+    return LMPC_OK;
+}
+
+int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+               uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    const AviLayout &A = h->A;
+    if (!x || !flag) return fail(h, LMPC_ERR_BADARG, "lmpc: the variational-inequality kernel needs x and exitflag arrays");
+    // one wavefront per workgroup, 64 problems per wavefront and round; resident wavefronts bounded by the scratch a
+    // slab takes (at most 1 GiB in all)
+    const size_t slabR = (size_t)avi_scratch_reals(A.n, A.m, A.cap) * 64, slabI = (size_t)avi_scratch_ints(A.m, A.cap) * 64;
+    const long long tiles = (nprob + 63) / 64;
+    long long grid = (long long)h->numCU * (h->aviWaves > 0 ? h->aviWaves : 16);
+    const long long fit = (long long)(((size_t)1 << 30) / (sizeof(double) * slabR + sizeof(int32_t) * slabI));
+    grid = std::min(grid, std::max(1ll, fit));
+    grid = std::min(grid, tiles);
+    if (grid > h->aviSlabs) {
+        // (grows with the largest batch seen; stream-ordered work of earlier calls on this handle finishes first)
+        if (h->dAviR || h->dAviI) { (void)hipStreamSynchronize(st); hipFree(h->dAviR); hipFree(h->dAviI); }
+        h->dAviR = nullptr; h->dAviI = nullptr; h->aviSlabs = 0;
+        HIP_TRY(h, hipMalloc(&h->dAviR, sizeof(double) * slabR * (size_t)grid));
+        HIP_TRY(h, hipMalloc(&h->dAviI, sizeof(int32_t) * slabI * (size_t)grid));
+        h->aviSlabs = (int)grid;
+    }
+    const size_t packBytes = sizeof(double) * (size_t)A.nC;
+    if (packBytes <= kAviLdsPack) {
+        if (packBytes > 48 * 1024)
+            HIP_TRY(h, hipFuncSetAttribute((const void *)avi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)packBytes));
+        hipLaunchKernelGGL(avi_kernel<true>, dim3((unsigned)grid), dim3(64), packBytes, st, A, h->dCa, h->dSa, theta, x, flag,
+                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);
+    } else {
+        hipLaunchKernelGGL(avi_kernel<false>, dim3((unsigned)grid), dim3(64), 0, st, A, h->dCa, h->dSa, theta, x, flag,
+                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+void avi_release(lmpc_handle *h, bool pack_too) {
+    if (h->dAviR) { (void)hipFree(h->dAviR); h->dAviR = nullptr; }
+    if (h->dAviI) { (void)hipFree(h->dAviI); h->dAviI = nullptr; }
+    h->aviSlabs = 0;
+    if (pack_too) {
+        if (h->dCa) { (void)hipFree(h->dCa); h->dCa = nullptr; }
+        if (h->dSa) { (void)hipFree(h->dSa); h->dSa = nullptr; }
+    }
+}
+
+}  // namespace lmpc

@@ -115,6 +115,15 @@ struct lmpc_handle {
     int32_t *dFastErr = nullptr;   // raised by that kernel if one of its bounded waits ran out (never expected):
     volatile int32_t *hFastErr = nullptr;   // ... a word of pinned host memory, dFastErr its device address
     int fastSpinLimit = 0;         // test hook ("fast_spin_limit"): k > 0 = the kernel's waits give up after k - 1 polls
+    // affine variational inequality (non-symmetric H, is_avi): its own kernel, pack and scratch (lmpc_avi.hip)
+    bool avi = false;
+    lmpc::AviLayout A{};
+    double *dCa = nullptr;
+    int32_t *dSa = nullptr;
+    double *dAviR = nullptr;
+    int32_t *dAviI = nullptr;
+    int aviSlabs = 0;           // wavefront slabs of scratch allocated
+    int aviWaves = 0;           // tuning: wavefronts per CU of its grid ("avi_waves", 0 = 16)
     lmpc::WaveLayout W{};
     double *dCw = nullptr;
     float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
@@ -191,6 +200,13 @@ struct DeviceScope {
     ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 #define LMPC_ENTER_DEVICE(h) lmpc::DeviceScope lmpc_dev_scope__; HIP_TRY(h, lmpc_dev_scope__.enter((h)->device))
+
+// affine-variational-inequality mode (lmpc_avi.hip): pack upload, settings, launch, scratch release
+int finalize_avi(lmpc_handle *h);
+void avi_fill_settings(lmpc_handle *h);
+int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+               uint64_t *active, const uint64_t *warm, hipStream_t st);
+void avi_release(lmpc_handle *h, bool pack_too);
 
 // one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
 bool fast_covers(const lmpc_handle *h);

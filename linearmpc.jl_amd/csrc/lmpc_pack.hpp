@@ -29,6 +29,10 @@ struct HostPack {
     int n = 0, m = 0, ms = 0, nth = 0, nout = 0, nsoft = 0;
     std::vector<double> M, G, du0, dl0, Dth, Rout, x0, Xth;
     std::vector<int32_t> sense;
+    // affine variational inequality (non-symmetric H, DAQP's is_avi; lmpc_avi_kernel.hpp): M holds ML = [I;A] scaled,
+    // MR row j = (H^-1 ML_j')', Gf = ML MR' in full (m x m, not symmetric); G (the packed triangle) stays empty
+    bool avi = false;
+    std::vector<double> MR, Gf;
     int words() const { return (2 * m + 63) / 64; }
 };
 
@@ -38,6 +42,17 @@ int qp_to_ldp(HostPack &P, int n, int m, int ms, int nth, int nout,
               const double *H, const double *f, const double *f_theta, const double *A,
               const double *bu, const double *bl, const double *W, const int32_t *sense,
               const double *Kfb, int nx, std::string &err);
+
+// The same boundary for a NON-symmetric H with H + H' positive definite (several objectives: reference
+// mpc2mpqp.jl:900-950; setup.jl:13 is_avi): fills the AVI pack (see HostPack).  LMPC_ERR_NONCONVEX if the symmetric
+// part of H is not positive definite.
+int qp_to_avi(HostPack &P, int n, int m, int ms, int nth, int nout,
+              const double *H, const double *f, const double *f_theta, const double *A,
+              const double *bu, const double *bl, const double *W, const int32_t *sense,
+              const double *Kfb, int nx, std::string &err);
+
+// isapprox(H, H', rtol = 1e-9) as the reference decides mpQP.is_symmetric (mpc2mpqp.jl:897); H column-major n x n
+bool h_is_symmetric(const double *H, int n);
 
 // Fills P.G and P.nsoft from P.M / P.sense; validates shapes.
 int finish_pack(HostPack &P, std::string &err);

@@ -78,4 +78,12 @@ struct WaveLayout {
     int cycle_tol, iter_limit;
 };
 
+// Affine-variational-inequality kernel (lmpc_avi_kernel.hpp): offsets into its constant pack
+struct AviLayout {
+    int n, m, nth, nout, words, cap;
+    int oML, oMR, oG, odu, odl, oDth, oRout, ox0, oXth, nC;
+    double primal_tol, dual_tol, zero_tol, rho_soft;
+    int iter_limit;
+};
+
 }  // namespace lmpc

@@ -74,25 +74,54 @@ class MPC:
         self.mpqp_issetup = False
         self.opt_model: BatchedQP | None = None             # stands where DAQP.Model stands
         self._ctrl_model: BatchedQP | None = None           # nout = nu, K folded in (batched path)
+        # what the handles were built from / last given -- the glue's cache key (integration/LmpcHipExt.jl
+        # `_model_for`): the mpQP OBJECT (setup! makes a new one, setup.jl:9) and the solver settings
+        self._opt_mpqp = None
+        self._ctrl_mpqp = None
+        self._pushed_settings = None
 
     # setup.jl:7-29
     def setup(self):
+        """`setup!`: DAQP.setup(model, H, f, A, bu, bl, senses; break_points = mpQP.break_points,
+        is_avi = !mpQP.is_symmetric) (setup.jl:11-13) -> lmpc_setup_ex with the same two keywords.  A non-empty
+        break_points (prioritised constraints) is refused by the library with LMPC_ERR_UNSUPPORTED -- loudly, never by
+        solving a different problem; a non-symmetric H sets the handle up for the variational inequality."""
         q = self.mpQP
-        # setup.jl:11-13 passes break_points (constraint priority levels: hierarchical soft constraints) and
-        # is_avi = !is_symmetric (variational objective) to DAQP.setup.  Neither mode is built in the HIP
-        # backend: refuse loudly rather than return the answer of a different problem.
-        if np.size(q.break_points) > 0:
-            raise NotImplementedError("mpQP.break_points is non-empty (prioritised constraints): the batched "
-                                      "backend does not implement DAQP's hierarchical mode")
-        if not q.is_symmetric:
-            raise NotImplementedError("mpQP.is_symmetric is false (variational objective): the batched backend "
-                                      "does not implement DAQP's is_avi mode")
+        old = self.opt_model
         self.opt_model = BatchedQP.from_mpqp(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses,
-                                             nout=q.H.shape[0], settings=self.settings,
-                                             device=self.device)
+                                             nout=q.H.shape[0], settings=self.settings, device=self.device,
+                                             break_points=np.asarray(q.break_points, np.int32),
+                                             is_avi=not q.is_symmetric)
+        if old is not None:
+            old.close()
+        if self._ctrl_model is not None:
+            self._ctrl_model.close()
         self._ctrl_model = None
+        self._opt_mpqp = q
+        self._pushed_settings = self._settings_key()
         self.mpqp_issetup = True
         return self
+
+    def _settings_key(self):
+        return tuple(getattr(self.settings, k) for k, _ in self.settings._fields_)
+
+    def _model_for(self) -> BatchedQP:
+        """The handle `solve` runs on -- the logic of the Julia glue's `_model_for` (integration/LmpcHipExt.jl), kept
+        identical here so that the test-suite exercises it: (1) an MPC whose data changed (`set_*!` sets
+        mpqp_issetup = false, /root/reference/src/setup.jl:36-160) is set up again first, as `solve` does
+        (utils.jl:269); (2) a handle built from ANOTHER mpQP object than the MPC now holds is stale -- `setup!`
+        always makes a new mpQP (setup.jl:9), whoever called it -- and is rebuilt, the old one freed; (3) the solver
+        settings on the model are compared with what the handle was last given and pushed if they differ
+        (`DAQP.settings(mpc.opt_model, Dict(...))` after the first solve)."""
+        if not self.mpqp_issetup or self.opt_model is None or self._opt_mpqp is not self.mpQP:
+            self.setup()
+        key = self._settings_key()
+        if key != self._pushed_settings:
+            for model in (self.opt_model, self._ctrl_model):
+                if model is not None:
+                    model.set_settings(self.settings)
+            self._pushed_settings = key
+        return self.opt_model
 
     def get_parameter_dims(self):
         return self.nx, self.nr, self.nd, self.nuprev, self.np
@@ -206,6 +235,7 @@ class MPC:
             for model in (self.opt_model, self._ctrl_model):
                 if model is not None:
                     model.set_settings(self.settings)
+            self._pushed_settings = self._settings_key()
         return {k: getattr(self.settings, k) for k, _ in self.settings._fields_}
 
     # utils.jl:268-283
@@ -215,10 +245,9 @@ class MPC:
         that compute_control / compute_control_trajectory / a Simulation loop run on it unchanged.  fval =
         1/2 x'Hx + (f + f_theta θ)'x is formed on the host from x* (the reference reads x* and exitflag only,
         utils.jl:45-48)."""
-        if not self.mpqp_issetup:
-            self.setup()
+        model = self._model_for()
         theta = np.asarray(theta, float).reshape(-1)
-        x, flag = self.opt_model.solve_one(theta)
+        x, flag = model.solve_one(theta)
         q = self.mpQP
         fth = q.f + q.f_theta @ theta
         fval = 0.5 * x @ q.H @ x + fth @ x
@@ -246,12 +275,16 @@ class MPC:
     # ---------------------------------------------------------------- batched entry points
     def control_model(self) -> BatchedQP:
         """Handle whose outputs are the first nu entries of U* minus K x (utils.jl:48-49 folded in)."""
-        if self._ctrl_model is None:
+        self._model_for()                         # (stale-handle and settings checks; drops a stale _ctrl_model)
+        if self._ctrl_model is None or self._ctrl_mpqp is not self.mpQP:
             q = self.mpQP
+            if self._ctrl_model is not None:
+                self._ctrl_model.close()
             self._ctrl_model = BatchedQP.from_mpqp(
                 q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=self.nu,
                 K=self.K if np.any(self.K) else None, nx=self.nx, settings=self.settings,
-                device=self.device)
+                device=self.device, break_points=np.asarray(q.break_points, np.int32), is_avi=not q.is_symmetric)
+            self._ctrl_mpqp = q
         return self._ctrl_model
 
     def form_parameter_batch(self, X, R=None, D=None, Uprev=None, P=None):
@@ -271,9 +304,7 @@ class MPC:
 
     def solve_batch(self, Theta):
         """Batched `solve`: (X* (N x n), exitflag, iterations, active-set masks)."""
-        if not self.mpqp_issetup:
-            self.setup()
-        return self.opt_model.solve(Theta)
+        return self._model_for().solve(Theta)
 
     def compute_control_batch(self, X, R=None, D=None, Uprev=None, P=None, check=True):
         """Batched `compute_control`; stateless (uprev is an input, nothing is stored)."""

@@ -55,6 +55,34 @@ def transform(H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0)
     return out
 
 
+def transform_avi(H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0):
+    """Host-only transform of a NON-symmetric problem (`lmpc_transform_avi`; what an is_avi setup precomputes):
+    dict with row-major ML, MR, G, du, dl, Dth, Rout, x0, Xth (+ dims)."""
+    H = _f64(H, "F")
+    n = H.shape[0]
+    f_theta = _f64(np.asarray(f_theta, float).reshape(n, -1), "F")
+    nth = f_theta.shape[1]
+    bu = _f64(np.asarray(bu, float).reshape(-1))
+    bl = _f64(np.asarray(bl, float).reshape(-1))
+    m = bu.size
+    A = _f64(np.asarray(A, float).reshape(-1, n), "F")
+    ms = m - A.shape[0]
+    W = _f64(np.asarray(W, float).reshape(m, nth), "F")
+    f = _f64(np.zeros(n) if f is None else np.asarray(f, float).reshape(n))
+    nout = n if nout is None else int(nout)
+    sense = np.ascontiguousarray(np.zeros(m, np.int32) if senses is None else senses, dtype=np.int32)
+    Kf = None if K is None else _f64(np.asarray(K, float).reshape(nout, -1), "F")
+    out = dict(ML=np.empty((m, n)), MR=np.empty((m, n)), G=np.empty((m, m)), du=np.empty(m), dl=np.empty(m),
+               Dth=np.empty((m, nth)), Rout=np.empty((nout, n)), x0=np.empty(nout), Xth=np.empty((nout, nth)))
+    rc = lib().lmpc_transform_avi(n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta), _ptr(A),
+                                  _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense), _ptr(Kf) if Kf is not None else None,
+                                  int(nx if K is not None else 0),
+                                  *[_ptr(out[k]) for k in ("ML", "MR", "G", "du", "dl", "Dth", "Rout", "x0", "Xth")])
+    check(rc)
+    out.update(n=n, m=m, ms=ms, nth=nth, nout=nout, sense=sense)
+    return out
+
+
 def _dev_arg(t, name, dtype, numel, device, optional=True):
     """Validate a CUDA tensor handed to a *_device entry point as a raw pointer: the kernels write
     through it with a fixed element size and a dense layout, so a wrong dtype, a strided view or a
@@ -92,8 +120,10 @@ class BatchedQP:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_mpqp(cls, H, f, f_theta, A, bu, bl, W, senses=None, nout=None, K=None, nx=0,
-                  settings: Settings | None = None, device=0):
-        """DAQP.setup + DAQP.settings equivalent (reference setup.jl:11-13,26)."""
+                  settings: Settings | None = None, device=0, break_points=None, is_avi=None):
+        """DAQP.setup + DAQP.settings equivalent (reference setup.jl:11-13,26).  `break_points` / `is_avi` are the two
+        keywords the reference passes to DAQP.setup (mpQP.break_points, !mpQP.is_symmetric): given, the call goes
+        through lmpc_setup_ex; left None, lmpc_setup decides is_avi from H the way the reference does."""
         H = _f64(H, "F")
         n = H.shape[0]
         f_theta = _f64(np.asarray(f_theta, float).reshape(n, -1), "F")
@@ -109,11 +139,17 @@ class BatchedQP:
         sense = np.ascontiguousarray(np.zeros(m, np.int32) if senses is None else senses, dtype=np.int32)
         Kf = None if K is None else _f64(np.asarray(K, float).reshape(nout, -1), "F")
         h = _vp()
-        rc = lib().lmpc_setup(ctypes.byref(h), n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta),
-                              _ptr(A), _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense),
-                              _ptr(Kf) if Kf is not None else None, int(nx if K is not None else 0),
-                              ctypes.cast(ctypes.pointer(settings), _vp) if settings is not None else None,
-                              int(device))
+        sp = ctypes.cast(ctypes.pointer(settings), _vp) if settings is not None else None
+        if break_points is None and is_avi is None:
+            rc = lib().lmpc_setup(ctypes.byref(h), n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta),
+                                  _ptr(A), _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense),
+                                  _ptr(Kf) if Kf is not None else None, int(nx if K is not None else 0), sp, int(device))
+        else:
+            bp = np.ascontiguousarray(np.zeros(0, np.int32) if break_points is None else break_points, dtype=np.int32)
+            rc = lib().lmpc_setup_ex(ctypes.byref(h), n, m, ms, nth, nout, _ptr(H), _ptr(f), _ptr(f_theta),
+                                     _ptr(A), _ptr(bu), _ptr(bl), _ptr(W), _ptr(sense),
+                                     _ptr(Kf) if Kf is not None else None, int(nx if K is not None else 0), sp,
+                                     _ptr(bp) if bp.size else None, int(bp.size), int(bool(is_avi)), int(device))
         check(rc)
         return cls(h, device)
 
@@ -161,6 +197,21 @@ class BatchedQP:
         check(lib().lmpc_get_ldp(self._h, *[_ptr(out[k]) for k in ("M", "du", "dl", "Dth", "Rout", "x0", "Xth")],
                                  _ptr(sense)), self._h)
         out.update(sense=sense, n=self.n, m=self.m, ms=self.ms, nth=self.nth, nout=self.nout)
+        return out
+
+    @property
+    def is_avi(self) -> bool:
+        """The handle was set up for a non-symmetric H (variational objective; reference setup.jl:13 is_avi)."""
+        return bool(lib().lmpc_is_avi(self._h))
+
+    def avi_pack(self):
+        """The constant pack of a variational-inequality handle: ldp() (M = the scaled rows ML) plus MR and the full
+        non-symmetric Gram matrix G -- what tests hand to the oracle's AVI solver."""
+        out = self.ldp()
+        out["ML"] = out["M"]
+        out["MR"] = np.empty((self.m, self.n))
+        out["G"] = np.empty((self.m, self.m))
+        check(lib().lmpc_get_avi(self._h, _ptr(out["MR"]), _ptr(out["G"])), self._h)
         return out
 
     def set_settings(self, settings: Settings):

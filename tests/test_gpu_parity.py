@@ -2175,3 +2175,102 @@ def test_distinct_active_sets_edge_cases(lmpc):
     ef = torch.full((100_000,), -1, dtype=torch.int32, device="cuda:0")
     m2, c2, f2 = qp.distinct_active_sets_device(act, ef)
     assert len(m2) == 0
+
+
+# ------------------------------------------------------------------ variational objective (is_avi)
+def _avi_oracle_pack(qp):
+    from oracle import avi as oavi
+    pk = qp.avi_pack()
+    return oavi.AVI(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["ML"], pk["MR"], pk["G"], pk["du"], pk["dl"],
+                    pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"])).contiguous()
+
+
+def test_game_theoretic_mpc_golden_vectors_and_same_pack_parity(lmpc):
+    """The reference's game-theoretic MPC (test/runtests.jl:1337-1358; non-symmetric H -> is_avi, setup.jl:13)
+    through lmpc_setup (which decides is_avi from H as the reference does): kernel `avi`, the committed answers to
+    1e-10 with identical active sets, and bit-identical to the oracle on the handle's own pack, cold and warm."""
+    from oracle import avi as oavi
+    g = load_golden("game_kat")
+    qp = _qp_from_golden(lmpc, g)
+    assert qp.is_avi and qp.kernel_name == "avi"
+    x, ef, it, act = qp.solve(g["theta"])
+    assert np.array_equal(ef, g["exitflag"]) and np.array_equal(act, g["active"])
+    assert np.abs(x - g["X"]).max() <= TOL
+    P = _avi_oracle_pack(qp)
+    xo, efo, ito, acto = oavi.solve_batch(P, g["theta"])
+    assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto) and np.array_equal(x, xo)
+    # warm start from a shuffled neighbour's active set: same answers, the oracle's iteration counts
+    warm = np.roll(act, 7, axis=0)
+    xw, efw, itw, actw = qp.solve(g["theta"], warm=warm)
+    xow, efow, itow, actow = oavi.solve_batch(P, g["theta"], warm=warm)
+    assert np.array_equal(efw, efow) and np.array_equal(itw, itow) and np.array_equal(actw, actow) and np.array_equal(xw, xow)
+    assert np.abs(xw - x).max() <= 1e-9
+    # ragged sizes: 1, 63, 64, 65 problems
+    for nq in (1, 63, 64, 65):
+        xq, efq, _, _ = qp.solve(g["theta"][:nq])
+        assert np.array_equal(xq, x[:nq]) and np.array_equal(efq, ef[:nq])
+    # explicit keyword form of the reference's DAQP.setup call
+    qp2 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                   break_points=np.zeros(0, np.int32), is_avi=True)
+    x2, ef2, _, _ = qp2.solve(g["theta"][:500])
+    assert np.array_equal(x2, x[:500])
+    with pytest.raises(lmpc.LmpcError):                               # no binary32 build of this mode
+        qp.solve_f32(g["theta"][:4].astype(np.float32))
+
+
+def test_game_theoretic_mpc_closed_loop_reproduces_the_reference_pins(lmpc):
+    """test/runtests.jl:1345-1354: Simulation(mpc; x0 = 10*ones(2), r = [10,0], N = 500) ends at y = [10, 0] (atol
+    1e-4).  Three ways: the literal one-theta drop-in (MPC.compute_control -> solve -> lmpc_solve_one, step by step
+    on the host like the reference's Simulation), the batched closed loop on the device (lmpc_simulate, 256 scenarios
+    around the reference's start), and the oracle's closed loop -- the last two bit for bit."""
+    from oracle import avi as oavi
+    g = load_golden("game_kat")
+    F, G = g["F"], g["G"]
+    q = lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], is_symmetric=False)
+    mpc = lmpc.MPC(q, nx=2, nu=2, nr=2, nuprev=2)
+    x = np.array([10.0, 10.0])
+    ys = []
+    for _ in range(500):
+        ys.append(x.copy())
+        u = mpc.compute_control(x, r=[10.0, 0.0])
+        x = F @ x + G @ u
+    assert abs(ys[-1][0] - 10.0) < 1e-4 and abs(ys[-1][1]) < 1e-4
+    assert np.abs(ys[-1] - g["y_end"]).max() < 1e-9
+    rng = np.random.default_rng(2)
+    N = 256
+    x0 = np.array([10.0, 10.0]) + rng.normal(size=(N, 2)); x0[0] = [10.0, 10.0]
+    r = np.tile([10.0, 0.0], (N, 1))
+    qp = mpc.control_model()
+    assert qp.is_avi
+    for warm in (False, True):
+        out = qp.simulate(x0, 500, F, G, r=r, uprev=np.zeros((N, 2)), warm=warm)
+        ref = oavi.simulate(_avi_oracle_pack(qp), x0, 500, F, G, r=r, uprev=np.zeros((N, 2)), warm=warm)
+        assert np.array_equal(out["x"], ref["x"]) and np.array_equal(out["U"], ref["U"])
+        assert np.array_equal(out["flag_min"], ref["flag_min"]) and (out["flag_min"] == 1).all()
+        assert abs(out["X"][499, 0, 0] - 10.0) < 1e-4 and abs(out["X"][499, 0, 1]) < 1e-4
+        assert np.abs(out["X"][499] - [10.0, 0.0]).max() < 1e-3         # every scenario settles at the reference
+
+
+def test_variational_problems_with_general_and_soft_rows(lmpc):
+    """Random non-symmetric problems with general, one-sided and SOFT rows, feasible and infeasible points: the AVI
+    kernel against the oracle on the handle's pack, bit for bit (flags incl. -1, iterations, active sets, x)."""
+    from oracle import avi as oavi
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        n = int(rng.integers(2, 13)); mg = int(rng.integers(1, 20)); ms = int(rng.integers(0, n + 1)); nth = int(rng.integers(1, 6))
+        B = rng.normal(size=(n, n)); K = rng.normal(size=(n, n)) * rng.uniform(0, 2)
+        H = B @ B.T + 0.3 * np.eye(n) + (K - K.T)
+        A = rng.normal(size=(mg, n)); m = ms + mg
+        bu, bl = rng.uniform(0.1, 2, m), -rng.uniform(0.1, 2, m)
+        bl[rng.random(m) < 0.2] = -1e30
+        sense = np.zeros(m, np.int32); sense[ms:][rng.random(mg) < 0.3] = 8
+        qp = lmpc.BatchedQP.from_mpqp(H, rng.normal(size=n), rng.normal(size=(n, nth)), A, bu, bl,
+                                      rng.normal(size=(m, nth)) * 0.3, sense, nout=min(n, 3))
+        assert qp.is_avi
+        th = rng.normal(size=(777, nth)) * rng.uniform(0.5, 4)
+        x, ef, it, act = qp.solve(th)
+        xo, efo, ito, acto = oavi.solve_batch(_avi_oracle_pack(qp), th)
+        assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto), trial
+        ok = efo >= 1
+        assert np.array_equal(x[ok], xo[ok]), trial
+        qp.close()

@@ -224,20 +224,61 @@ def test_multi_setup_refused_without_gpu(lmpc, has_gpu):
     assert e.value.code == -101
 
 
-def test_nonsymmetric_hessian_and_priorities_are_refused(lmpc):
-    # setup.jl:11-13: is_avi = !is_symmetric and break_points go to DAQP.setup; neither mode is built here
-    H = np.array([[2.0, 0.5], [0.0, 2.0]])
-    with pytest.raises(lmpc.LmpcError) as e:
-        lmpc.transform(H, np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2), np.zeros((2, 1)))
+def test_setup_keywords_of_the_reference(lmpc, has_gpu):
+    """setup.jl:11-13: DAQP.setup(...; break_points = mpQP.break_points, is_avi = !mpQP.is_symmetric).  The C entry
+    lmpc_setup_ex carries both; what each combination answers WITHOUT a device (argument checks and the host
+    transform run before the GPU is touched)."""
+    H = np.array([[2.0, 0.5], [0.0, 2.0]])                      # not symmetric, symmetric part positive definite
+    args = (np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2), np.zeros((2, 1)))
+    with pytest.raises(lmpc.LmpcError) as e:                    # the QP -> LDP transform does not apply to it
+        lmpc.transform(H, *args)
     assert e.value.code == -103
-    q = lmpc.MPQP(np.eye(2), np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
-                  np.zeros((2, 1)), np.zeros(2, np.int32), break_points=np.array([1, 2], np.int32))
-    with pytest.raises(NotImplementedError, match="break_points"):
+    # prioritised constraints: refused loudly, by the library, whatever else is asked
+    q = lmpc.MPQP(np.eye(2), *args, np.zeros(2, np.int32), break_points=np.array([1, 2], np.int32))
+    with pytest.raises(lmpc.LmpcError) as e:
         lmpc.MPC(q, nx=1, nu=1).setup()
-    q2 = lmpc.MPQP(H, np.zeros(2), np.zeros((2, 1)), np.zeros((0, 2)), np.ones(2), -np.ones(2),
-                   np.zeros((2, 1)), np.zeros(2, np.int32), is_symmetric=False)
-    with pytest.raises(NotImplementedError, match="is_symmetric"):
-        lmpc.MPC(q2, nx=1, nu=1).setup()
+    assert e.value.code == -103 and "break_points" in str(e.value)
+    # is_avi = 0 with a non-symmetric H: the caller contradicts itself
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(H, *args, is_avi=False)
+    assert e.value.code == -100
+    # H + H' not positive definite: DAQP's non-convex flag
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(np.array([[1.0, 3.0], [0.0, 1.0]]), *args, is_avi=True)
+    assert e.value.code == -5
+    # a proper variational problem passes every host-side check: without a GPU the answer is NOGPU, not UNSUPPORTED
+    q2 = lmpc.MPQP(H, *args, np.zeros(2, np.int32), is_symmetric=False)
+    if not has_gpu:
+        with pytest.raises(lmpc.LmpcError) as e:
+            lmpc.MPC(q2, nx=1, nu=1).setup()
+        assert e.value.code == -101
+        with pytest.raises(lmpc.LmpcError) as e:                # lmpc_setup decides is_avi from H by itself
+            lmpc.BatchedQP.from_mpqp(H, *args)
+        assert e.value.code == -101
+
+
+def test_host_transform_of_a_variational_problem_matches_the_oracle(lmpc):
+    """lmpc_transform_avi (what an is_avi setup precomputes on the host) against the oracle's qp2avi on the
+    reference's game-theoretic test problem (test/runtests.jl:1337-1358) and on a random problem with general rows."""
+    from oracle import avi as oavi, mpc2mpqp as omm
+    p = omm.game_kat()
+    q = omm.mpc2mpqp(p)
+    assert not q.is_symmetric and q.n == 6 and q.m == 6 and q.nth == 6
+    rng = np.random.default_rng(3)
+    n, mg, ms, nth = 5, 7, 3, 4
+    B = rng.normal(size=(n, n)); K = rng.normal(size=(n, n))
+    Hr = B @ B.T + np.eye(n) + (K - K.T)
+    cases = [(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, 2, None, 0),
+             (Hr, rng.normal(size=n), rng.normal(size=(n, nth)), rng.normal(size=(mg, n)), rng.uniform(1, 2, ms + mg),
+              -rng.uniform(1, 2, ms + mg), rng.normal(size=(ms + mg, nth)), np.zeros(ms + mg, np.int32), 2,
+              rng.normal(size=(2, 2)), 2)]
+    for (H, f, fth, A, bu, bl, W, sn, nout, Kfb, nx) in cases:
+        got = lmpc.transform_avi(H, f, fth, A, bu, bl, W, sn, nout=nout, K=Kfb, nx=nx)
+        ref = oavi.qp2avi(H, f, fth, A, bu, bl, W, sn, nout=nout, K=Kfb)
+        for k, r in (("ML", ref.ML), ("MR", ref.MR), ("G", ref.G), ("du", ref.du0), ("dl", ref.dl0), ("Dth", ref.Dth),
+                     ("Rout", ref.Rout), ("x0", ref.x0), ("Xth", ref.Xth)):
+            assert np.allclose(got[k], r, rtol=1e-10, atol=1e-11), k
+        assert np.allclose(np.diag(got["G"]), 1.0, atol=1e-12) and not np.allclose(got["G"], got["G"].T)
 
 
 # ------------------------------------------------------------------ reference-held vectors, verbatim

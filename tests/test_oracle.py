@@ -749,3 +749,93 @@ def test_kept_factorisation_through_the_64_row_limit_on_the_cpu():
         mask = oldp.simulate(L, x0, T, Fm, Gm, warm=1, settings=so)
         assert (cold["flag_min"] >= 1).all() and (kept["flag_min"] >= 1).all() and (mask["flag_min"] >= 1).all()
         assert np.abs(kept["U"] - cold["U"]).max() < 1e-5 and np.abs(mask["U"] - cold["U"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ variational objective (is_avi)
+def test_game_theoretic_mpc_is_pinned_by_the_reference_test():
+    """/root/reference/test/runtests.jl:1337-1358: two players on a double integrator; mpQP.H is not symmetric
+    (:1349) and the closed loop from x0 = [10,10] with r = [10,0], N = 500, ends at y = [10, 0] (atol 1e-4, :1353-1354).
+    The condensing restatement (mpc2mpqp.jl:900-950) + the AVI oracle reproduce both; the fixture holds the same."""
+    from oracle import avi as oavi
+    p = omm.game_kat()
+    q = omm.mpc2mpqp(p)
+    assert not q.is_symmetric and not np.allclose(q.H, q.H.T)
+    assert (q.n, q.m, q.ms, q.nth) == (6, 6, 6, 6)                     # move blocks [1,1,8] x 2 inputs; theta = [x; r; uprev]
+    assert omm.mpc2mpqp(omm.pendulum()).is_symmetric
+    P = oavi.qp2avi(q.H, q.f, q.f_theta, q.A, q.bu, q.bl, q.W, q.senses, nout=p.nu)
+    sim = oavi.simulate(P, [[10.0, 10.0]], 500, p.F, p.G, r=[[10.0, 0.0]], uprev=[[0.0, 0.0]])
+    y_end = sim["X"][499, 0]                                           # ys[:, end]: the state at the last step
+    assert abs(y_end[0] - 10.0) < 1e-4 and abs(y_end[1] - 0.0) < 1e-4 and sim["flag_min"][0] == 1
+    g = load_golden("game_kat")
+    assert np.allclose(g["H"], q.H, rtol=0, atol=1e-12) and np.allclose(g["y_end"], y_end, atol=1e-12)
+    # warm starts change the path, not the answer (unique solution)
+    simw = oavi.simulate(P, [[10.0, 10.0]], 500, p.F, p.G, r=[[10.0, 0.0]], uprev=[[0.0, 0.0]], warm=True)
+    assert np.abs(simw["X"] - sim["X"]).max() < 1e-9
+
+
+def test_avi_oracle_against_the_golden_vectors_and_a_projection_iteration():
+    """The AVI oracle reproduces the committed answers bit for bit from the committed pack; a sample of them is
+    re-derived by a method that shares nothing with it: the fixed point of x <- clip(x - tau (Hx + f(theta)), bl, bu)."""
+    from oracle import avi as oavi
+    g = load_golden("game_kat")
+    P = oavi.qp2avi(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=6)
+    X, ef, it, act = oavi.solve_batch(P, g["theta"])
+    assert np.array_equal(ef, g["exitflag"]) and np.array_equal(act, g["active"]) and np.array_equal(it, g["iters"])
+    assert np.abs(X - g["X"]).max() <= 1e-12
+    H = g["H"]
+    tau = np.linalg.eigvalsh((H + H.T) / 2)[0] / np.linalg.norm(H, 2) ** 2
+    nact = np.array([bin(int(a)).count("1") for a in act[:, 0]])
+    for i in [int(np.nonzero(nact == k)[0][0]) for k in range(7)]:    # one point per active-set size 0 .. 6
+        fth = g["f"] + g["f_theta"] @ g["theta"][i]
+        x = np.zeros(6)
+        for _ in range(300000):
+            xn = np.clip(x - tau * (H @ x + fth), g["bl"], g["bu"])
+            if np.abs(xn - x).max() < 1e-15:
+                break
+            x = xn
+        assert np.abs(x - X[i]).max() < 1e-9, (i, nact[i])
+
+
+def test_avi_oracle_kkt_and_infeasibility_on_random_problems():
+    """Random non-symmetric problems with simple, general, one-sided and SOFT rows: every answer flagged solved
+    satisfies the KKT conditions of the variational inequality (stationarity, primal feasibility of hard rows,
+    multiplier signs; oracle.avi.kkt_residual -- dense algebra, nothing of the solver's recursions), every answer
+    flagged infeasible has an empty hard constraint set (LP), and nothing ends on the iteration limit -- the plain
+    QP loop cycles on such problems (no dual objective), the principal-pivoting step rule does not."""
+    from scipy.optimize import linprog
+    from oracle import avi as oavi
+    rng = np.random.default_rng(11)
+    S_ = oldp.default_settings()
+    S_.rho_soft = 1e-2                       # (keeps the certificate's slack / rho step well conditioned)
+    nsolved = ninf = 0
+    for trial in range(60):
+        n = int(rng.integers(2, 9)); mg = int(rng.integers(0, 12)); ms = int(rng.integers(0, n + 1)); nth = int(rng.integers(1, 5))
+        if ms + mg == 0:
+            ms = 1
+        B = rng.normal(size=(n, n)); K = rng.normal(size=(n, n)) * rng.uniform(0, 2)
+        H = B @ B.T + 0.3 * np.eye(n) + (K - K.T)
+        f, fth = rng.normal(size=n), rng.normal(size=(n, nth))
+        A = rng.normal(size=(mg, n)); m = ms + mg
+        bu, bl = rng.uniform(0.1, 2, m), -rng.uniform(0.1, 2, m)
+        bl[rng.random(m) < 0.2] = -1e30
+        W = rng.normal(size=(m, nth)) * 0.3
+        sense = np.zeros(m, np.int32); sense[ms:][rng.random(mg) < 0.3] = 8
+        P = oavi.qp2avi(H, f, fth, A, bu, bl, W, sense, nout=n)
+        th = rng.normal(size=(32, nth)) * rng.uniform(0.5, 4)
+        X, ef, it, act = oavi.solve_batch(P, th, S_)
+        assert set(np.unique(ef)) <= {1, 2, -1}, np.unique(ef)
+        assert it.max() < 200
+        Aext = np.vstack([np.eye(n)[:ms], A]); hard = (sense & 8) == 0
+        sc = max(1.0, np.abs(H).max())
+        for i in range(32):
+            if ef[i] >= 1:
+                st, pv, sg = oavi.kkt_residual(H, f, fth, A, bu, bl, W, sense, th[i], X[i], act[i], rho_soft=1e-2)
+                assert st < 1e-7 * sc and pv < 2e-6 and sg < 1e-6 * sc, (trial, i, st, pv, sg)
+                nsolved += 1
+            elif i % 4 == 0:
+                b = W @ th[i]
+                r = linprog(np.zeros(n), A_ub=np.vstack([Aext[hard], -Aext[hard]]),
+                            b_ub=np.concatenate([(bu + b)[hard], -(bl + b)[hard]]), bounds=[(None, None)] * n, method="highs")
+                assert r.status == 2, (trial, i, r.status)
+                ninf += 1
+    assert nsolved > 1000 and ninf > 20
