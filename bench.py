@@ -581,6 +581,80 @@ def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, g
     return res
 
 
+def avi_config(torch, lmpc, dev, local_rank, batch, steps, warmup, want_cpu, cpu_seconds=3.0):
+    """The reference's game-theoretic MPC (test/runtests.jl:1337-1358: two players, non-symmetric H, DAQP's is_avi
+    mode, /root/reference/src/setup.jl:11-13) as a measured workload: `batch` parameter points (the fixture's
+    sampling: 0 .. 6 active bounds) resident on the device, lmpc_solve_batch_device on the AVI kernel, first move of
+    both players returned.  Verified against the oracle's AVI solver on a sample, bit for bit."""
+    from oracle import avi as oavi, ldp as oldp
+    g = make_problem("game_kat")
+    nout = int(g["nu"])
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout,
+                                  device=local_rank)
+    rng = np.random.default_rng(1234)
+    th_h = np.ascontiguousarray(np.hstack([rng.uniform(-30, 30, (batch, 4)), rng.uniform(-1, 1, (batch, 2))]))
+    bytes_per = algorithmic_bytes(qp.nth, nout)
+    nrot = rotation_depth(batch, bytes_per)
+    thetas = [torch.from_numpy(th_h).to(dev)] + [torch.from_numpy(np.ascontiguousarray(np.roll(th_h, 1 + r_, axis=0))).to(dev)
+                                                  for r_ in range(nrot - 1)]
+    xb = torch.empty((batch, nout), dtype=torch.float64, device=dev)
+    fb = torch.empty(batch, dtype=torch.int32, device=dev)
+    itb = torch.empty(batch, dtype=torch.int32, device=dev)
+    for k in range(warmup):
+        qp.solve_device(thetas[k % nrot], x=xb, exitflag=fb)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        qp.solve_device(thetas[k % nrot], x=xb, exitflag=fb)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    qp.profile(True)
+    for k in range(max(3, steps)):
+        qp.solve_device(thetas[k % nrot], x=xb, exitflag=fb)
+    torch.cuda.synchronize(dev)
+    solo = qp.profile_read()
+    qp.profile(False)
+    qp.solve_device(thetas[0], x=xb, exitflag=fb, iters=itb)
+    torch.cuda.synchronize(dev)
+    pk = qp.avi_pack()
+    P = oavi.AVI(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["ML"], pk["MR"], pk["G"], pk["du"], pk["dl"],
+                 pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"])).contiguous()
+    idx = np.sort(np.random.default_rng(99).choice(batch, min(4096, batch), replace=False))
+    xo, efo, ito, _ = oavi.solve_batch(P, th_h[idx])
+    ti = torch.from_numpy(idx).to(dev)
+    ok = bool(np.array_equal(xb[ti].cpu().numpy(), xo) and np.array_equal(fb[ti].cpu().numpy(), efo)
+              and np.array_equal(itb[ti].cpu().numpy(), ito))
+    call_ms = solo[1]
+    ach = bytes_per * batch / (call_ms * 1e-3) / 1e9 if call_ms > 0 else 0.0
+    it_h = itb.cpu().numpy()
+    res = {"value": batch * steps / el, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
+           "dtype": "f64", "batch": batch, "kernel": qp.kernel_name, "rotating_batches": nrot, "verified": ok,
+           "workload": f"game_kat: two-player game-theoretic MPC (non-symmetric H, is_avi; n={qp.n}, m={qp.m}, nth={qp.nth}), "
+                       f"{batch} parameter points, cold start, first move of both players returned",
+           "solved_fraction": float((fb.cpu().numpy() >= 1).mean()), "mean_iterations": float(it_h.mean()),
+           "max_iterations": int(it_h.max()),
+           "verification": {"points": int(len(idx)), "against": "oracle/daqp_avi_oracle.c on the handle's pack: x, exit flag "
+                                                                 "and iteration count bit-identical"},
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": None, "duration_used_ms": call_ms, "algorithmic_bytes_per_solve": bytes_per,
+                        "note": "algorithmic bytes (theta in, u0 and flag out) over the HIP-event duration of one call; the "
+                                "kernel itself is bound by the latency of its own per-lane scratch (L D U factor, "
+                                "multipliers), not by these bytes"}}
+    if want_cpu:
+        ns = min(batch, 200000)
+        t1 = time.perf_counter()
+        npass = 0
+        while time.perf_counter() - t1 < cpu_seconds:
+            oavi.solve_batch(P, th_h[:ns])
+            npass += 1
+        dtc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": npass * ns / dtc, "unit": "solves/s", "cores": 1, "kind": "port",
+                               "sample": f"{npass} passes over the first {ns} points, 1 thread ({_cpu_model()}), "
+                                         "oracle/daqp_avi_oracle.c, portable -O3 build"}
+    qp.close()
+    return res
+
+
 def multi_abi_isolated(torch, n_per_dev, timeout_s=180):
     """multi_abi_check in a CHILD process (`bench.py --multi-abi-only N`): the nd > 1 branch of the library has never
     run on hardware, so whatever it does the first time -- raise, hang, crash inside librccl -- must not take the
@@ -1137,6 +1211,8 @@ def main():
             cfg("mass_spring", side_config, torch, lmpc, "mass_spring", BATCH, dev, local_rank, 20, 3, False, want_cpu, 3.0)
             cfg("mass_spring_3in", side_config, torch, lmpc, "mass_spring_3in", BATCH, dev, local_rank, 4, 1, False, want_cpu, 4.0)
             cfg("mass_spring_3in_feasible", side_config, torch, lmpc, "mass_spring_3in_feasible", BATCH, dev, local_rank, 4, 1, False, want_cpu, 3.0)
+            _phase("config game_avi")
+            cfg("game_avi", avi_config, torch, lmpc, dev, local_rank, BATCH, 10, 2, want_cpu)
             cfg("hybrid_f32", side_config, torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
             # the reference's only published numbers (plots, unstated hardware, generated C, one solve at a time
             # in closed loop): quoted beside the batched rate as context, not as a baseline

@@ -23,26 +23,32 @@ end
 
 mutable struct BatchedModel    # stands next to mpc.opt_model
     h::Ptr{Cvoid}; n::Int; nout::Int; nth::Int; words::Int
+    mpqp::Any                  # the mpQP OBJECT the handle was built from (setup! always makes a new one, setup.jl:9)
+    settings::LmpcSettings     # the solver settings the handle was last given
 end
+free!(bm::BatchedModel) = (bm.h == C_NULL || ccall((:lmpc_free, liblmpc), Cvoid, (Ptr{Cvoid},), bm.h); bm.h = C_NULL; nothing)
 
 "setup!(mpc) for the batched backend: same inputs DAQP.setup gets (setup.jl:11-13)"
 function setup_batched(mpc::LinearMPC.MPC; nout=mpc.model.nu, device=0)
     mpc.mpqp_issetup || LinearMPC.setup!(mpc)
     q = mpc.mpQP
-    # setup.jl:11-13 hands break_points / is_avi to DAQP.setup; the batched backend implements neither mode
-    isempty(q.break_points) || error("lmpc: prioritised constraints (mpQP.break_points) are not supported")
-    q.is_symmetric || error("lmpc: variational objective (is_avi) is not supported")
+    # setup.jl:11-13: DAQP.setup(model, H, f, A, bu, bl, senses; break_points = mpQP.break_points,
+    # is_avi = !mpQP.is_symmetric) -- lmpc_setup_ex takes the same two keywords.  A non-symmetric H (several
+    # objectives) sets the handle up for the variational inequality; a non-empty break_points (prioritised
+    # constraints) is answered with LMPC_ERR_UNSUPPORTED (-103) by the library, never ignored.
     n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
-    h = Ref{Ptr{Cvoid}}(C_NULL); s = Ref(LmpcSettings(mpc))
+    h = Ref{Ptr{Cvoid}}(C_NULL); st = LmpcSettings(mpc); s = Ref(st)
     K = iszero(mpc.K) ? C_NULL : Matrix{Float64}(mpc.K[1:nout, :])
-    flag = ccall((:lmpc_setup, liblmpc), Cint,
+    bp = Vector{Cint}(q.break_points)
+    flag = ccall((:lmpc_setup_ex, liblmpc), Cint,
         (Ref{Ptr{Cvoid}}, Cint,Cint,Cint,Cint,Cint, Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},
-         Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cint},Ptr{Cdouble},Cint,Ref{LmpcSettings},Cint),
-        h, n,m,ms,nth,nout, q.H,q.f,q.f_theta,q.A,q.bu,q.bl,q.W,q.senses, K, mpc.model.nx, s, device)
-    flag == 1 || error("lmpc_setup failed ($flag): ", unsafe_string(ccall((:lmpc_last_error, liblmpc), Cstring, (Ptr{Cvoid},), C_NULL)))
+         Ptr{Cdouble},Ptr{Cdouble},Ptr{Cdouble},Ptr{Cint},Ptr{Cdouble},Cint,Ref{LmpcSettings},Ptr{Cint},Cint,Cint,Cint),
+        h, n,m,ms,nth,nout, q.H,q.f,q.f_theta,q.A,q.bu,q.bl,q.W,q.senses, K, mpc.model.nx, s,
+        isempty(bp) ? C_NULL : bp, length(bp), !q.is_symmetric, device)
+    flag == 1 || error("lmpc_setup_ex failed ($flag): ", unsafe_string(ccall((:lmpc_last_error, liblmpc), Cstring, (Ptr{Cvoid},), C_NULL)))
     words = ccall((:lmpc_active_words, liblmpc), Cint, (Ptr{Cvoid},), h[])
-    bm = BatchedModel(h[], n, nout, nth, words)
-    finalizer(b -> ccall((:lmpc_free, liblmpc), Cvoid, (Ptr{Cvoid},), b.h), bm)
+    bm = BatchedModel(h[], n, nout, nth, words, q, st)
+    finalizer(free!, bm)
     return bm
 end
 
@@ -63,15 +69,32 @@ end
 # compute_control(mpc, x), compute_control_trajectory and Simulation(mpc; ...) run on lmpc_solve_one.
 # Returns what DAQP.solve returns: (x*, fval, exitflag, info); fval = 1/2 x'Hx + (f + f_θ θ)'x is formed on the host
 # from x* (the reference reads x* and exitflag only, utils.jl:45-48).  One handle per MPC object, with nout = n
-# (compute_control subtracts K·x itself, utils.jl:48-49) and the user's DAQP settings; setup!(mpc) drops it.
-const _models = IdDict{Any,BatchedModel}()
+# (compute_control subtracts K·x itself, utils.jl:48-49) and the user's DAQP settings.
+# The cache: one handle per live MPC object (WeakKeyDict: an MPC that is garbage collected takes its handle along,
+# the BatchedModel's finalizer frees it).  A handle is STALE as soon as the MPC holds another mpQP object than the one
+# it was built from: every set_*! only clears mpc.mpqp_issetup (setup.jl:36-160) and the next setup! -- called by
+# solve (utils.jl:269), by us, or by the user -- builds a NEW mpQP of possibly the same dimensions (setup.jl:9), so
+# dimensions say nothing; object identity does.  The solver settings on mpc.opt_model are re-read on every solve
+# (a struct of eight numbers) and pushed with lmpc_set_settings when they differ from what the handle was last
+# given, so DAQP.settings(mpc.opt_model, Dict(...)) after the first solve reaches the GPU path too.
+# (The Python mirror linearmpc.jl_amd/mpc.py::MPC._model_for is this logic line for line; the test-suite runs the
+# failing sequences on it: tests/test_gpu_parity.py::test_solve_mpc_theta_drop_in_and_user_settings.)
+const _models = WeakKeyDict{Any,BatchedModel}()
 function _model_for(mpc::LinearMPC.MPC)
     mpc.mpqp_issetup || LinearMPC.setup!(mpc)
+    mpc.mpqp_issetup || throw("Could not setup optimization problem")      # as utils.jl:270
     bm = get(_models, mpc, nothing)
-    if bm === nothing || bm.n != size(mpc.mpQP.H,1) || bm.nth != size(mpc.mpQP.f_theta,2)
+    if bm === nothing || bm.mpqp !== mpc.mpQP
+        bm === nothing || free!(bm)                     # the stale handle goes now, not at some later GC
         K = mpc.K; mpc.K = zero(K)                      # nout = n handle without the feedback folded in
         try bm = setup_batched(mpc; nout=size(mpc.mpQP.H,1)) finally mpc.K = K end
         _models[mpc] = bm
+    end
+    st = LmpcSettings(mpc)
+    if st != bm.settings
+        rc = ccall((:lmpc_set_settings, liblmpc), Cint, (Ptr{Cvoid}, Ref{LmpcSettings}), bm.h, Ref(st))
+        rc == 1 || error("lmpc_set_settings failed ($rc)")
+        bm.settings = st
     end
     return bm
 end
@@ -85,8 +108,8 @@ function LinearMPC.solve(mpc::LinearMPC.MPC, θ::AbstractVector{<:Real})
     fval = 0.5*dot(x, q.H, x) + dot(q.f .+ q.f_theta*th, x)
     return x, fval, Int(flag), (status = flag >= 1 ? :Solved : :Failed, exitflag = Int(flag))
 end
-"forget the handle of an MPC whose problem data changed (call after setup!(mpc) / set_*!)"
-reset_batched!(mpc::LinearMPC.MPC) = (delete!(_models, mpc); nothing)
+"drop (and free) the handle of an MPC now; never needed for correctness -- _model_for notices a new mpQP by itself"
+reset_batched!(mpc::LinearMPC.MPC) = (bm = pop!(_models, mpc, nothing); bm === nothing || free!(bm); nothing)
 
 "single-precision twin (the reference's codegen float_type=\"float\" build of the same path)"
 function solve_f32(bm::BatchedModel, Θ::Matrix{Float32})
@@ -129,8 +152,8 @@ end
 function setup_batched_multi(mpc::LinearMPC.MPC; nout=mpc.model.nu, devices=Cint[])    # empty = all visible GPUs
     mpc.mpqp_issetup || LinearMPC.setup!(mpc)
     q = mpc.mpQP
+    # (lmpc_setup_multi has no keyword form: it decides is_avi from H like lmpc_setup; priorities are refused here)
     isempty(q.break_points) || error("lmpc: prioritised constraints are not supported")
-    q.is_symmetric || error("lmpc: variational objective (is_avi) is not supported")
     n = size(q.H,1); m = length(q.bu); ms = m - size(q.A,1); nth = size(q.f_theta,2)
     hm = Ref{Ptr{Cvoid}}(C_NULL); s = Ref(LmpcSettings(mpc))
     K = iszero(mpc.K) ? C_NULL : Matrix{Float64}(mpc.K[1:nout, :])
