@@ -506,6 +506,55 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             }
         };
 
+        // ---- branch and bound: snapshots of a node's optimal state, one slot per search depth in this wavefront's slice
+        // of global scratch.  A node's factor is written out LAZILY: appends never touch the rows already there, so as
+        // long as no row below the node's working-set size has been removed since it branched, its factor IS the leading
+        // block of the factor in LDS -- its second child then starts by truncating (no triangle read back), and a subtree
+        // that never removes such a row never writes the triangle at all.  The first removal that would break this
+        // saves the triangles of the nodes concerned just before it (snap_clean / snap_saved, one bit per depth;
+        // stk_na on lane d: that node's working-set size).
+        constexpr int kSnapUn = 8;
+        int stk_na = 0, bdepth = 0;
+        unsigned long long snap_clean = 0ull, snap_saved = 0ull;
+        const int snapR = 6 * 64 + cap * (cap - 1) / 2, snapI = 5 * 64;
+        R *snr0 = nullptr;
+        int32_t *sni0 = nullptr;
+        if constexpr (BNB) {
+            const long long slot = (long long)blockIdx.x * nwv + wv;
+            snr0 = wv_uniform_ptr(bnb_r + slot * (long long)bnb_depth * snapR);
+            sni0 = wv_uniform_ptr(bnb_i + slot * (long long)bnb_depth * snapI);
+        }
+        // rows [0, nd) of the factor as it stands -> slot d.  Whole-wavefront block copies: entry e = i (i - 1) / 2 + t of
+        // the strict lower triangle (row after row) goes to word e, 64 consecutive words per instruction, kSnapUn
+        // instructions in flight (round 3 copied column by column, 1 .. na lanes each, every load of a restore waited
+        // for before the next was issued: the search spent most of its time waiting for its own scratch).
+        auto save_tri = [&](int d, int nd) {
+            R *sr = snr0 + (long long)d * snapR;
+            int32_t *si = sni0 + (long long)d * snapI;
+            // ... and the registers of the node's working-set positions, which are still the node's own for lanes < nd
+            // (appends write position na only); behind them a node holds zeros
+            const bool in = lane < nd;
+            sr[64 + lane] = in ? rhs : (R)0; sr[128 + lane] = in ? D : (R)0; sr[192 + lane] = in ? Dinv : (R)0;
+            if constexpr (!GRAM) sr[256 + lane] = y;
+            si[lane] = in ? WSi : 0; si[64 + lane] = in ? (possoft | (posimm << 1) | (poslow << 2)) : 0;
+            const int ne = nd * (nd - 1) / 2;
+            for (int e0 = 0; e0 < ne; e0 += 64 * kSnapUn) {
+                R v[kSnapUn];
+#pragma unroll
+                for (int q = 0; q < kSnapUn; q++) {
+                    const int e = e0 + 64 * q + lane;
+                    int i, t;
+                    tri_row(e < ne ? e : 0, i, t);
+                    v[q] = L[cbase(t) + i];
+                }
+#pragma unroll
+                for (int q = 0; q < kSnapUn; q++) {
+                    const int e = e0 + 64 * q + lane;
+                    if (e < ne) sr[384 + e] = v[q];
+                }
+            }
+        };
+
         // ---- append constraint j (wave-uniform) to the working set
         auto ldl_add = [&](int j, bool lower) {
             const int sj = sense_of(j);
@@ -563,6 +612,18 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
 
         // ---- drop working-set position r (wave-uniform): compact L, rank-one update of the tail
         auto ldl_remove = [&](int r) {
+            if constexpr (BNB) {
+                // nodes on the current path whose factor is still the leading block of this one and reaches beyond row r
+                const unsigned long long hit = __ballot(stk_na > r) & wv_below(bdepth) & snap_clean;
+                unsigned long long todo = hit & ~snap_saved;
+                while (todo != 0ull) {
+                    const int d = (int)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    save_tri(d, __builtin_amdgcn_readlane(stk_na, d));
+                }
+                snap_saved |= hit;
+                snap_clean &= ~hit;
+            }
             const int nao = na;
             R w = L[cbase(r) + lr1];                 // old row index = lane
             w = (lane > r && lane < nao) ? w : (R)0;
@@ -1025,35 +1086,62 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             // working-set positions, the rows' activity bits and the strict lower triangle of L, in this
             // wavefront's slice of global scratch (one slot per depth; a few KB, written once and read once).
             int stk_j = 0, stk_side = 0, stk_tried = 0;
-            const long long slot = (long long)blockIdx.x * nwv + wv;
-            const int snapR = 6 * 64 + cap * (cap - 1) / 2, snapI = 5 * 64;
-            R *const snr0 = bnb_r + slot * (long long)bnb_depth * snapR;
-            int32_t *const sni0 = bnb_i + slot * (long long)bnb_depth * snapI;
-            auto pk = [&](int t) -> int { return t * (2 * cap - 1 - t) / 2 - t - 1; };   // column t of the packed triangle
+            // eagerly, a node writes only what an append changes: the multipliers lam*, the rows' activity bits, the scalars
             auto snapshot = [&](int d) {
                 R *sr = snr0 + (long long)d * snapR;
                 int32_t *si = sni0 + (long long)d * snapI;
-                sr[lane] = ls; sr[64 + lane] = rhs; sr[128 + lane] = D; sr[192 + lane] = Dinv; sr[256 + lane] = y;
-                si[lane] = WSi; si[64 + lane] = possoft | (posimm << 1) | (poslow << 2);
+                sr[lane] = ls;
+                // (Gram-scan form: an entry of y = L^-1 rhs formed at its row's append -- a lane tree -- and the same entry
+                // after a later removal re-ran the forward sweep -- a serial chain -- differ in the last bit, so there y
+                // is part of what an append-only subtree can change)
+                if constexpr (GRAM) sr[256 + lane] = y;
                 si[128 + lane] = (int32_t)actb; si[192 + lane] = (int32_t)lowb;
                 if (lane == 0) { sr[320] = fval; si[256] = na; si[257] = nsoft_act; }
-                for (int t = 0; t + 1 < na; t++)
-                    if (lane > t && lane < na) sr[384 + pk(t) + lane] = L[cbase(t) + lane];
+                if (lane == d) stk_na = na;
+                snap_clean |= 1ull << d;             // everything else stays where it is (see save_tri / ldl_remove)
+                snap_saved &= ~(1ull << d);
             };
             auto restore = [&](int d) {
                 const R *sr = snr0 + (long long)d * snapR;
                 const int32_t *si = sni0 + (long long)d * snapI;
-                clear_rows(1, na);
-                ls = sr[lane]; rhs = sr[64 + lane]; D = sr[128 + lane]; Dinv = sr[192 + lane]; y = sr[256 + lane];
-                WSi = si[lane];
-                const int fl = si[64 + lane];
-                possoft = fl & 1; posimm = (fl >> 1) & 1; poslow = (fl >> 2) & 1;
+                const int naold = na;
+                const bool clean = (snap_clean >> d) & 1ull;
+                if (!clean) clear_rows(1, naold);
+                ls = sr[lane];
+                if constexpr (GRAM) y = sr[256 + lane];
                 actb = (unsigned)si[128 + lane]; lowb = (unsigned)si[192 + lane];
                 fval = wv_first(sr[320]);
                 na = __builtin_amdgcn_readfirstlane(si[256]);
                 nsoft_act = __builtin_amdgcn_readfirstlane(si[257]);
-                for (int t = 0; t + 1 < na; t++)
-                    if (lane > t && lane < na) L[cbase(t) + lane] = sr[384 + pk(t) + lane];
+                if (clean) {
+                    // the node's factor and positions are the leading part of what is here: cut what lies behind them
+                    clear_rows(na > 1 ? na : 1, naold);
+                    if (lane >= na) { WSi = 0; possoft = 0; posimm = 0; poslow = 0; rhs = (R)0; D = (R)0; Dinv = (R)0; }
+                } else {
+                    rhs = sr[64 + lane]; D = sr[128 + lane]; Dinv = sr[192 + lane];
+                    if constexpr (!GRAM) y = sr[256 + lane];
+                    WSi = si[lane];
+                    const int fl = si[64 + lane];
+                    possoft = fl & 1; posimm = (fl >> 1) & 1; poslow = (fl >> 2) & 1;
+                    const int ne = na * (na - 1) / 2;
+                    for (int e0 = 0; e0 < ne; e0 += 64 * kSnapUn) {
+                        R v[kSnapUn];
+#pragma unroll
+                        for (int q = 0; q < kSnapUn; q++) {
+                            const int e = e0 + 64 * q + lane;
+                            v[q] = sr[384 + (e < ne ? e : 0)];
+                        }
+#pragma unroll
+                        for (int q = 0; q < kSnapUn; q++) {
+                            const int e = e0 + 64 * q + lane;
+                            int i, t;
+                            tri_row(e < ne ? e : 0, i, t);
+                            if (e < ne) L[cbase(t) + i] = v[q];
+                        }
+                    }
+                }
+                // (a node is restored once, for its second child: from here on nobody needs slot d's triangle)
+                snap_clean &= ~(1ull << d);
                 lam = (R)0; sing = -1; ydirty = false;
             };
             int depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE;
@@ -1118,12 +1206,14 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                         if (lane == depth) { stk_j = jb; stk_side = lower_first; stk_tried = 1; }
                         snapshot(depth);                 // this node's optimal state, for its second child
                         depth++;
+                        bdepth = depth;
                         descend = true;
                     }
                 }
                 inplace = descend;
                 if (!descend) {                          // backtrack to the next untried side
                     while (depth > 0 && __builtin_amdgcn_readlane(stk_tried, depth - 1) == 2) depth--;
+                    bdepth = depth;
                     if (depth == 0) break;
                     if (lane == depth - 1) { stk_side ^= 1; stk_tried = 2; }
                     restore(depth - 1);                  // back to that node's optimal state: its second child, in place

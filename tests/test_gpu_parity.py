@@ -2069,6 +2069,45 @@ def test_solve_mpc_theta_drop_in_and_user_settings(lmpc):
         mpc.solver_settings(eps_prox=1e-3)                        # proximal iterations: not in this backend
 
 
+def test_glue_cache_follows_the_mpqp_object_and_the_model_settings(lmpc):
+    """The two traps of a per-MPC handle cache (integration/LmpcHipExt.jl `_model_for`, mirrored by MPC._model_for):
+    (1) set_bounds! / set_objective! clear mpc.mpqp_issetup and the next setup! -- whoever calls it -- builds a NEW
+    mpQP of the SAME dimensions (/root/reference/src/setup.jl:9,36-160; utils.jl:269): the handle must follow the
+    object, not the dimensions; (2) DAQP.settings(mpc.opt_model, Dict(...)) after the first solve must reach the
+    handle.  Here: solve, change a bound, solve -> the new answer (both orders of `setup!`), then a setting written
+    straight onto the model's settings object."""
+    g = load_golden("pendulum")
+    mk = lambda ub: lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], np.full(5, ub), np.full(5, -ub), g["W"], g["senses"])
+    mpc = lmpc.MPC(mk(2.0), nx=4, nu=1, nr=2, nuprev=1)
+    u2 = mpc.compute_control([5.0, 5, 0, 0], uprev=[0.0])
+    assert abs(u2[0] - 1.7612519326) < 1e-6
+    first_handle = mpc.opt_model
+    # set_bounds!(mpc; umax = 1): the reference only clears the flag; the next solve sets up again (utils.jl:269)
+    mpc.mpQP = mk(1.0)
+    mpc.mpqp_issetup = False
+    u1 = mpc.compute_control([5.0, 5, 0, 0], uprev=[0.0])
+    assert abs(u1[0] - 1.0) < 1e-9 and mpc.opt_model is not first_handle and first_handle._h is None   # rebuilt, old one freed
+    # the user calls setup!(mpc) THEMSELVES after another change: flag true again, mpQP new, same dimensions --
+    # exactly the sequence a dimension-keyed cache answers with the OLD bounds
+    mpc.mpQP = mk(0.5)
+    mpc.mpqp_issetup = True
+    u05 = mpc.compute_control([5.0, 5, 0, 0], uprev=[0.0])
+    assert abs(u05[0] - 0.5) < 1e-9
+    Ub, efb = mpc.compute_control_batch(np.array([[5.0, 5, 0, 0]]), Uprev=np.zeros((1, 1)))
+    assert abs(Ub[0, 0] - 0.5) < 1e-9                                 # the batched control handle followed too
+    mpc.mpQP = mk(2.0)
+    mpc.mpqp_issetup = True
+    Ub, efb = mpc.compute_control_batch(np.array([[5.0, 5, 0, 0]]), Uprev=np.zeros((1, 1)))
+    assert abs(Ub[0, 0] - 1.7612519326) < 1e-6
+    # DAQP.settings(mpc.opt_model, Dict(:iter_limit => 2)) after the first solve: written on the model, not through
+    # any method of ours -- the next solve must see it
+    mpc.settings.iter_limit = 2
+    _, _, flag, _ = mpc.solve(mpc.form_parameter([5.0, 5, 0, 0], uprev=[0.0]))
+    assert flag == -4
+    mpc.settings.iter_limit = 10000
+    assert mpc.solve(mpc.form_parameter([5.0, 5, 0, 0], uprev=[0.0]))[2] == 1
+
+
 def test_region_discovery_device_pipeline(lmpc):
     """BASELINE config 4 with the per-sample part on the GPU: sample drawn on the device, solved
     with the masks kept there, reduced to the distinct masks by lmpc_distinct_active_sets_device -- against the host
