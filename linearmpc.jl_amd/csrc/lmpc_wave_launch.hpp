@@ -91,6 +91,10 @@ inline WaveConfig wave_config(const lmpc_handle *h, size_t rs) {
     const WaveConfig sq = wave_config_for(h, rs, false), pk = wave_config_for(h, rs, true);
     if (h->wavePacked == 0) return sq;
     if (h->wavePacked == 1) return pk;
+    // (round 4, branch and bound with lazy snapshots: the truncating restore and the zero-padded sweeps favour the square
+    // layout further -- hybrid n = 60 binary64: 5 square 1.06e6/s against 10 packed 7.5e5/s, Gram-scan form 1.89e6
+    // against 1.24e6; binary32: 10 square 2.24e6 against 16 packed 9.6e5 -- so there packed needs 3x the wavefronts)
+    if (h->bnb) return pk.blocksPerCU * pk.nwv >= 3 * sq.blocksPerCU * sq.nwv ? pk : sq;
     return 4 * pk.blocksPerCU * pk.nwv >= 7 * sq.blocksPerCU * sq.nwv ? pk : sq;
 }
 
