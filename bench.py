@@ -662,8 +662,33 @@ def multi_abi_isolated(torch, n_per_dev, timeout_s=180):
     import subprocess
     nd = torch.cuda.device_count()
     if nd < 2:
-        return {"n_devices": nd,
-                "skipped": "one visible GPU: the nd > 1 branch (ncclCommInitAll, ncclSend/ncclRecv) cannot run here"}
+        # one GPU: everything of the n_devices > 1 path except RCCL itself -- two shards on device 0, gather by
+        # event-ordered peer copies (LMPC_MULTI_TRANSPORT=copy, include/lmpc_hip.h lmpc_multi_set_option)
+        out = {"n_devices": nd, "transport": "copy",
+               "note": "one visible GPU: RCCL (ncclCommInitAll, ncclSend/ncclRecv) cannot run here; the multi-device "
+                       "control flow ran as two shards on device 0 with the gather as peer copies"}
+        try:
+            import linearmpc_jl_amd as lmpc
+            g = make_problem("pendulum")
+            os.environ["LMPC_MULTI_TRANSPORT"] = "copy"
+            try:
+                mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                            nout=1, devices=[0, 0])
+            finally:
+                del os.environ["LMPC_MULTI_TRANSPORT"]
+            n2 = int(min(n_per_dev, 250_000))
+            hosts = [make_theta("pendulum", n2, 4242 + 31 * d) for d in range(2)]
+            shards = [torch.from_numpy(h_).to("cuda:0") for h_ in hosts]
+            xs, fs, xr, fr = mq.solve_device(shards, gather=True)
+            qp1 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+            x1, f1 = qp1.solve_device(torch.cat(shards))
+            torch.cuda.synchronize()
+            out["loopback_identical"] = bool(torch.equal(xr, x1) and torch.equal(fr, f1) and torch.equal(xs[1], x1[n2:]))
+            out["points_per_shard"] = n2
+            mq.close(); qp1.close()
+        except Exception as e:
+            out["error"] = f"{type(e).__name__}: {e}"[:300]
+        return out
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-abi-only", str(int(n_per_dev))],
                            capture_output=True, text=True, timeout=timeout_s)
@@ -885,7 +910,7 @@ def main():
     ap.add_argument("--lane-block", type=int, default=0, help="lane-kernel workgroup size (tuning)")
     ap.add_argument("--wave-level", type=int, default=-1, help="wave kernel: LDS staging level 0..3 (tuning)")
     ap.add_argument("--wave-nwv", type=int, default=0, help="wave kernel: wavefronts per workgroup (tuning)")
-    ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning)")
+    ap.add_argument("--wave-cap", type=int, default=0, help="wave kernel: wavefronts per CU of the grid (tuning; option wave_waves)")
     ap.add_argument("--multi-abi-only", type=int, default=0, metavar="N_PER_DEVICE",
                     help="run only the one-process multi-device entry-point check (lmpc_solve_batch_multi_device over every "
                          "visible GPU) and print its result as one JSON line; what the bench line's config.multi_abi runs "
@@ -935,7 +960,7 @@ def main():
     if args.lane_per:
         opts["lane_per"] = args.lane_per
     if args.wave_cap:
-        opts["wave_cap"] = args.wave_cap
+        opts["wave_waves"] = args.wave_cap
     if args.wave_level >= 0:
         opts["wave_level"] = args.wave_level
     if args.wave_nwv:

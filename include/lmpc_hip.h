@@ -252,6 +252,13 @@ int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout,
                      const int32_t *sense, const double *Kfb, int nx,
                      const lmpc_settings *s, const int *devices, int n_devices);
 int lmpc_multi_devices(const lmpc_multi *hm);
+/* "transport": how lmpc_solve_batch_multi_device gathers the shards on the first device -- 0 (default) RCCL
+ * ncclSend / ncclRecv pairs, every device on its own xGMI link; 1 = event-ordered peer copies issued by the first
+ * device's stream (hipMemcpyPeerAsync: the copy engines; needs no RCCL).  With the environment variable
+ * LMPC_MULTI_TRANSPORT=copy at setup time transport 1 is the default AND the device list may name a device more than
+ * once: several shards, handles, streams and host threads on one GPU -- the way the n_devices > 1 code is exercised on
+ * a machine with a single GPU (tests/test_gpu_parity.py::test_multi_device_control_flow_on_one_gpu). */
+int lmpc_multi_set_option(lmpc_multi *hm, const char *name, int value);
 lmpc_handle *lmpc_multi_handle(lmpc_multi *hm, int i);      /* device i's handle (options, inspection) */
 void lmpc_multi_partition(int64_t N, int n_devices, int64_t *offsets /* n_devices + 1 */);
 int lmpc_solve_batch_multi(lmpc_multi *hm, int64_t N, const double *theta, double *x,

@@ -1585,7 +1585,9 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         h->waveNwv = value;
         return LMPC_OK;
     }
-    if (std::strcmp(name, "wave_cap") == 0) { h->waveCap = value; return LMPC_OK; }
+    // (wavefronts per CU of the wavefront kernel's grid; "wave_cap" above is the working-set CAPACITY -- until round 4
+    // both answered to that name and this one was unreachable)
+    if (std::strcmp(name, "wave_waves") == 0) { h->waveCap = value < 0 ? 0 : value; return LMPC_OK; }
     if (std::strcmp(name, "lane_tier") == 0) { h->laneTier = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "fast") == 0) { h->fastPath = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_straight") == 0) { h->laneStraight = value ? 1 : 0; return LMPC_OK; }

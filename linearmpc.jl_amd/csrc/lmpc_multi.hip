@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -359,6 +360,9 @@ struct lmpc_multi {
     std::vector<int> dev;
     std::vector<hipStream_t> stream;   // device-resident path: one stream per device
     std::vector<ncclComm_t> comm;      // created on the first gather
+    std::vector<hipEvent_t> done;      // transport 1: "shard d is solved", recorded on stream d, awaited by stream 0
+    int transport = 0;                 // 0: RCCL send / receive pairs; 1: event-ordered peer copies issued by device 0
+    bool repeats = false;              // the device list names a device more than once (transport 1 only)
     std::string err;
 };
 
@@ -433,12 +437,19 @@ int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout, 
         return mfail(nullptr, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
     if (n_devices <= 0) { n_devices = ndev; devices = nullptr; }      // all visible devices
     lmpc_multi *hm = new lmpc_multi();
+    // LMPC_MULTI_TRANSPORT=copy: the gather runs as peer copies instead of RCCL pairs (lmpc_multi_set_option
+    // "transport" 1), and only then may a device appear more than once in the list -- several shards, handles, streams
+    // and host threads on ONE GPU: how the n_devices > 1 control flow is exercised on a one-GPU machine
+    const char *tenv = std::getenv("LMPC_MULTI_TRANSPORT");
+    if (tenv && std::strcmp(tenv, "copy") == 0) hm->transport = 1;
     for (int d = 0; d < n_devices; d++) {
         const int dev = devices ? devices[d] : d;
-        if (dev < 0 || dev >= ndev || std::find(hm->dev.begin(), hm->dev.end(), dev) != hm->dev.end()) {
+        const bool seen = std::find(hm->dev.begin(), hm->dev.end(), dev) != hm->dev.end();
+        if (dev < 0 || dev >= ndev || (seen && hm->transport != 1)) {
             lmpc_free_multi(hm);
             return mfail(nullptr, LMPC_ERR_BADARG, "lmpc_setup_multi: bad or repeated device ordinal");
         }
+        hm->repeats = hm->repeats || seen;
         lmpc_handle *h = nullptr;
         const int rc = lmpc_setup(&h, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, s, dev);
         if (rc != LMPC_OK) { lmpc_free_multi(hm); return rc; }       // (the text is lmpc_last_error(NULL))
@@ -450,6 +461,18 @@ int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout, 
 }
 
 int lmpc_multi_devices(const lmpc_multi *hm) { return hm ? (int)hm->h.size() : LMPC_ERR_BADARG; }
+
+int lmpc_multi_set_option(lmpc_multi *hm, const char *name, int value) {
+    if (!hm || !name) return LMPC_ERR_BADARG;
+    if (std::strcmp(name, "transport") == 0) {
+        if (value != 0 && value != 1) return mfail(hm, LMPC_ERR_BADARG, "lmpc_multi_set_option: transport must be 0 (RCCL) or 1 (peer copies)");
+        if (value == 0 && hm->repeats)
+            return mfail(hm, LMPC_ERR_BADARG, "lmpc_multi_set_option: RCCL needs distinct devices (this handle repeats one)");
+        hm->transport = value;
+        return LMPC_OK;
+    }
+    return mfail(hm, LMPC_ERR_BADARG, std::string("lmpc_multi_set_option: unknown option ") + name);
+}
 
 lmpc_handle *lmpc_multi_handle(lmpc_multi *hm, int i) {
     return (hm && i >= 0 && i < (int)hm->h.size()) ? hm->h[i] : nullptr;
@@ -497,7 +520,17 @@ int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const do
         }
     }
     const bool gather = x_root != nullptr || exitflag_root != nullptr;
-    if (gather && nd > 1 && hm->comm.empty()) {
+    if (gather && nd > 1 && hm->transport == 1 && hm->done.empty()) {
+        hm->done.assign((size_t)nd, nullptr);
+        for (int d = 0; d < nd; d++) {
+            DeviceScope sc;
+            if (sc.enter(hm->dev[d]) != hipSuccess || hipEventCreateWithFlags(&hm->done[d], hipEventDisableTiming) != hipSuccess) {
+                hm->done.clear();
+                return mfail(hm, LMPC_ERR_HIP, "lmpc_solve_batch_multi_device: cannot create the gather events");
+            }
+        }
+    }
+    if (gather && nd > 1 && hm->transport == 0 && hm->comm.empty()) {
         if (!g_rccl.load(hm->err)) return LMPC_ERR_UNSUPPORTED;
         hm->comm.assign((size_t)nd, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(hm->comm.data(), nd, hm->dev.data());
@@ -531,7 +564,33 @@ int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const do
                 hipMemcpyAsync(exitflag_root, exitflag[0], sizeof(int32_t) * N_dev[0], hipMemcpyDeviceToDevice, hm->stream[0]) != hipSuccess)
                 rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: local copy of shard 0");
         }
-        if (rc == LMPC_OK && nd > 1) {
+        if (rc == LMPC_OK && nd > 1 && hm->transport == 1) {
+            // peer copies: shard d's solve is marked by an event on its stream; device 0's stream waits for it and pulls
+            // the shard into its place (hipMemcpyPeerAsync: the copy engines over xGMI between two devices, a plain
+            // device-to-device copy when both ends are the same GPU)
+            for (int d = 1; d < nd && rc == LMPC_OK; d++) {
+                if (N_dev[d] == 0) continue;
+                {
+                    DeviceScope sc;
+                    if (sc.enter(hm->dev[d]) != hipSuccess || hipEventRecord(hm->done[d], hm->stream[d]) != hipSuccess) {
+                        rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: recording a shard's event");
+                        break;
+                    }
+                }
+                DeviceScope sc0;
+                if (sc0.enter(hm->dev[0]) != hipSuccess || hipStreamWaitEvent(hm->stream[0], hm->done[d], 0) != hipSuccess) {
+                    rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: waiting for a shard's event");
+                    break;
+                }
+                if (x_root && hipMemcpyPeerAsync(x_root + off[d] * nout, hm->dev[0], x[d], hm->dev[d],
+                                                 sizeof(double) * (size_t)N_dev[d] * nout, hm->stream[0]) != hipSuccess)
+                    rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: peer copy of the solutions");
+                if (rc == LMPC_OK && exitflag_root &&
+                    hipMemcpyPeerAsync(exitflag_root + off[d], hm->dev[0], exitflag[d], hm->dev[d],
+                                       sizeof(int32_t) * (size_t)N_dev[d], hm->stream[0]) != hipSuccess)
+                    rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: peer copy of the exit flags");
+            }
+        } else if (rc == LMPC_OK && nd > 1) {
             ncclResult_t r = g_rccl.GroupStart();
             for (int d = 1; d < nd && r == ncclSuccess; d++) {
                 if (N_dev[d] == 0) continue;
@@ -563,6 +622,10 @@ int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const do
 void lmpc_free_multi(lmpc_multi *hm) {
     if (!hm) return;
     for (ncclComm_t c : hm->comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+    for (size_t d = 0; d < hm->done.size(); d++) {
+        DeviceScope sc;
+        if (hm->done[d] && sc.enter(hm->dev[d]) == hipSuccess) hipEventDestroy(hm->done[d]);
+    }
     for (size_t d = 0; d < hm->stream.size(); d++) {
         DeviceScope sc;
         if (hm->stream[d] && sc.enter(hm->dev[d]) == hipSuccess) hipStreamDestroy(hm->stream[d]);

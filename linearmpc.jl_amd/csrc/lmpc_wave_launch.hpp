@@ -156,6 +156,21 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     long long grid = (long long)h->numCU * blocksPerCU;
     const long long need = (nprob + cfg.nwv - 1) / cfg.nwv;
     if (grid > need) grid = need;
+    if constexpr (BNB) {
+        // branch and bound keeps one snapshot slot per search depth and resident wavefront (see below): at most half of
+        // what the device has free -- a smaller grid (fewer wavefronts in flight) before an allocation that crowds out
+        // the caller or fails (the slots already held count as free: they are replaced)
+        const size_t perWave = (size_t)(h->nBinary > 0 ? h->nBinary : 1) *
+                               (sizeof(double) * (6 * 64 + (size_t)Wl.cap * (Wl.cap - 1) / 2) + sizeof(int32_t) * 5 * 64);
+        size_t freeB = 0, totalB = 0;
+        if (perWave * (size_t)grid * cfg.nwv > h->bnbBytesR + h->bnbBytesI) {
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+            const size_t budget = (freeB + h->bnbBytesR + h->bnbBytesI) / 2;
+            while (grid > 1 && perWave * (size_t)grid * cfg.nwv > budget) grid = (grid + 1) / 2;
+            if (perWave * (size_t)grid * cfg.nwv > budget)
+                return fail(h, LMPC_ERR_HIP, "lmpc: not enough free device memory for the branch-and-bound snapshots");
+        }
+    }
     // The ticket counter and the overflow counters exist twice and are used alternately: a kernel clears the ones of the
     // launch / call after it (nobody touches those while it runs; calls on a handle are stream-ordered), so no launch
     // needs a memset in front of it -- two 5 us fill kernels per launch, 4 % of a closed-loop step.  Tickets alternate per

@@ -691,6 +691,12 @@ class MultiQP:
         if rc != _cabi.LMPC_OK:
             raise LmpcError(rc, (lib().lmpc_multi_last_error(self._hm) or b"").decode())
 
+    def set_option(self, name: str, value: int):
+        """`lmpc_multi_set_option` ("transport": 0 RCCL pairs, 1 event-ordered peer copies)."""
+        lib().lmpc_multi_set_option.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int]
+        lib().lmpc_multi_set_option.restype = ctypes.c_int
+        self._check(lib().lmpc_multi_set_option(self._hm, name.encode(), int(value)))
+
     @staticmethod
     def partition(N, ndev):
         """`lmpc_multi_partition`: shard d = [off[d], off[d+1])."""

@@ -2033,6 +2033,48 @@ def test_multi_device_rccl_gather_with_several_gpus(lmpc):
     assert out["n_devices"] == nd and out["identical"] and out["oracle_sample_identical"]
 
 
+def test_multi_device_control_flow_on_one_gpu(lmpc, monkeypatch):
+    """The n_devices > 1 code of csrc/lmpc_multi.hip -- partitioning, one handle / stream / host thread per shard,
+    gather offsets, events -- executed on ONE GPU: with LMPC_MULTI_TRANSPORT=copy the device list may repeat a device
+    and the gather runs as event-ordered peer copies instead of ncclSend / ncclRecv (the only part left to a machine
+    with several GPUs, test_multi_device_rccl_gather_with_several_gpus).  Three shards of unequal size, incl. an empty
+    one, bit for bit against the single-device call; RCCL on a repeated device is refused."""
+    import torch
+    g = load_golden("pendulum")
+    monkeypatch.setenv("LMPC_MULTI_TRANSPORT", "copy")
+    mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1,
+                                devices=[0, 0, 0])
+    monkeypatch.delenv("LMPC_MULTI_TRANSPORT")
+    assert mq.ndev == 3
+    with pytest.raises(lmpc.LmpcError):
+        mq.set_option("transport", 0)                       # RCCL needs distinct devices
+    with pytest.raises(lmpc.LmpcError):                     # ... and without the hook a repeated device is an error
+        lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1, devices=[0, 0])
+    qp = _qp_from_golden(lmpc, g, 1)
+    rng = np.random.default_rng(13)
+    N = 300_001
+    theta = np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+    x1, ef1, it1, act1 = qp.solve(theta)
+    # host arrays, three shards through the chunked pipelines of three handles
+    for q_ in mq.parts:
+        q_.set_option("host_chunk", 20000)
+    x, ef, it, act = mq.solve(theta)
+    assert np.array_equal(x, x1) and np.array_equal(ef, ef1) and np.array_equal(it, it1) and np.array_equal(act, act1)
+    off = lmpc.MultiQP.partition(N, 3)
+    assert off == [0, 100001, 200001, 300001]
+    # resident shards of unequal sizes (one of them empty), gathered on the "first device"
+    for cuts in ([0, 150000, 150000, N], [0, 1, 200000, N], off):
+        shards = [torch.from_numpy(theta[cuts[d]:cuts[d + 1]]).to("cuda:0") for d in range(3)]
+        xs, fs, xr, fr = mq.solve_device(shards, gather=True)
+        assert np.array_equal(xr.cpu().numpy(), x1) and np.array_equal(fr.cpu().numpy(), ef1), cuts
+        for d in range(3):
+            assert np.array_equal(xs[d].cpu().numpy(), x1[cuts[d]:cuts[d + 1]])
+    # no gather asked for: shards only
+    xs, fs, xr, fr = mq.solve_device(shards, gather=False)
+    assert xr is None and np.array_equal(fs[2].cpu().numpy(), ef1[off[2]:])
+    mq.close()
+
+
 def test_solve_mpc_theta_drop_in_and_user_settings(lmpc):
     """`solve(mpc, θ)` (/root/reference/src/utils.jl:268-283) for one parameter vector returns DAQP.solve's tuple
     (x*, fval, exitflag, info) through lmpc_solve_one -- what the glue's LinearMPC.solve(mpc::MPC, θ::AbstractVector)
