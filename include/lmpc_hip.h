@@ -510,6 +510,20 @@ int lmpc_distinct_active_sets_device(lmpc_handle *h, int64_t N, const uint64_t *
                                      int32_t *n_sets, void *stream);
 int lmpc_distinct_active_sets_overflowed(lmpc_handle *h, void *stream);
 
+/* One step of a sampling-based region discovery in ONE enqueue: lmpc_solve_batch_device on the resident sample with the
+ * active-set masks kept on the device, lmpc_distinct_active_sets_device on them, and a last kernel that writes the
+ * distinct sets into a block of mapped host memory owned by the handle -- no copy call, no synchronisation inside.
+ * theta / x / exitflag / active and the four set arrays are DEVICE pointers as in the two calls it chains.
+ * *result_host (valid until the next call of this function on the handle or lmpc_free) is read after ONE
+ * synchronisation of `stream`: 64-bit words
+ *     [0] sets found (more than `capacity`: the call overflowed, repeat with more room; -1: not finished yet)
+ *     [1] overflow word   [2] problems counted (exit flag >= 1)   [3] unused
+ *     then per set k < min([0], capacity): `words` words of mask, its count, the smallest problem index that hit it.
+ * The sets come in no particular order (sort on the host).  Caller side of /root/reference/src/explicit.jl:23-48. */
+int lmpc_discover_regions_device(lmpc_handle *h, int64_t N, const double *theta, double *x, int32_t *exitflag,
+                                 uint64_t *active, int32_t capacity, uint64_t *set_masks, int64_t *set_count,
+                                 int64_t *set_first, int32_t *n_sets, const long long **result_host, void *stream);
+
 /* Per-problem exit flags are DAQP's (1 optimal, 2 soft optimal, -1 infeasible, -2 cycle, -4 iteration limit, -6
  * over-determined initial working set) plus two of this library's own:
  *   -7  the working set outgrew what the kernels hold (wavefront kernel: 64 rows, slow path: 256 rows);

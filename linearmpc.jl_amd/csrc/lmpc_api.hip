@@ -1619,6 +1619,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         h->laneBlock = value;
         return LMPC_OK;
     }
+    if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "wave") == 0) {
         if (h->avi) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: a variational-inequality handle has one kernel");
@@ -1671,6 +1672,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
+    if (h->hRegOut) hipHostFree(h->hRegOut);
     hipFree(h->dStat);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);

@@ -78,6 +78,10 @@ struct lmpc_handle {
     int waveCtrSet = 0;         // which of the two (ticket, overflow) counter pairs the next wavefront-kernel launch uses
     int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
     int regCap = 0;
+    int regBlocks = 0;          // tuning: workgroups per CU of the two-level distinct-mask reduction ("region_blocks", 0 = 1)
+    long long *hRegOut = nullptr;   // lmpc_discover_regions_device: result block in mapped host memory ...
+    long long *dRegOut = nullptr;   // ... and its device address; regOutWords = its size in 64-bit words
+    size_t regOutWords = 0;
     // slow path for working sets beyond the 64 lanes (lmpc_big_kernel.hpp): overflow list + counter, per-thread scratch
     int capFull = 0;            // n + 1 + #soft: the rows a working set of this problem can hold
     int32_t *dOvfList = nullptr, *dOvfCount = nullptr, *dBigI = nullptr;

@@ -104,6 +104,86 @@ def discover_regions(solve_fn, theta, group=None):
     return {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved}
 
 
+class DeviceRegionSampler:
+    """One step of the sampling-based region discovery as ONE enqueue (`lmpc_discover_regions_device`): solve the
+    resident sample with the masks kept on the device, reduce them to the distinct sets there, publish the sets into a
+    block of mapped host memory; the host synchronises once and reads the block.  All device buffers are allocated
+    here, once, for `nsamples` samples; `enqueue` / `result` can be used apart (enqueue the next sample's draw in
+    between), `run` is both.  A step that finds more distinct sets than there is room for is repeated with four times
+    the room."""
+
+    def __init__(self, qp, nsamples, capacity=4096, device=None):
+        import torch
+        self.qp, self.N, self.capacity = qp, int(nsamples), int(capacity)
+        self.dev = torch.device("cuda", qp.device if getattr(qp, "device", None) is not None else torch.cuda.current_device()) \
+            if device is None else device
+        d = self.dev
+        self.x = torch.empty((self.N, qp.nout), dtype=torch.float64, device=d)
+        self.ef = torch.empty(self.N, dtype=torch.int32, device=d)
+        self.act = torch.empty((self.N, qp.words), dtype=torch.int64, device=d)
+        self._alloc_sets()
+        self._res = None
+        self._theta = None
+
+    def _alloc_sets(self):
+        import torch
+        d, c = self.dev, self.capacity
+        self.masks = torch.empty((c, self.qp.words), dtype=torch.int64, device=d)
+        self.counts = torch.empty(c, dtype=torch.int64, device=d)
+        self.first = torch.empty(c, dtype=torch.int64, device=d)
+        self.nset = torch.zeros(1, dtype=torch.int32, device=d)
+        torch.cuda.synchronize(d)
+
+    def enqueue(self, theta, stream=None):
+        import ctypes
+        from ._cabi import lib, check
+        if not (theta.is_cuda and theta.is_contiguous() and theta.shape == (self.N, self.qp.nth)):
+            raise ValueError("theta must be a contiguous (nsamples, nth) float64 CUDA tensor")
+        vp = ctypes.c_void_p
+        res = ctypes.c_void_p()
+        L = lib()
+        L.lmpc_discover_regions_device.restype = ctypes.c_int
+        check(L.lmpc_discover_regions_device(
+            self.qp._h, ctypes.c_int64(self.N),
+            vp(theta.data_ptr()), vp(self.x.data_ptr()), vp(self.ef.data_ptr()),
+            vp(self.act.data_ptr()), ctypes.c_int32(self.capacity), vp(self.masks.data_ptr()), vp(self.counts.data_ptr()),
+            vp(self.first.data_ptr()), vp(self.nset.data_ptr()), ctypes.byref(res),
+            vp(int(stream)) if stream else None), self.qp._h)
+        self._res, self._theta, self._stream = res.value, theta, stream
+
+    def result(self):
+        """-> (masks (R x words uint64), counts, first_index, n_solved), sets sorted by decreasing count, ties by first
+        index (the order `unique_active_sets` gives)."""
+        import ctypes
+        import torch
+        if self._stream:
+            torch.cuda.ExternalStream(int(self._stream), device=self.dev).synchronize()
+        else:
+            torch.cuda.synchronize(self.dev)
+        w = self.qp.words
+        head = np.ctypeslib.as_array((ctypes.c_longlong * 4).from_address(self._res))
+        nfound, over = int(head[0]), int(head[1])
+        if over == 2:
+            from ._cabi import LmpcError
+            raise LmpcError(-102, "lmpc_discover_regions_device: table slot never published")
+        if nfound > self.capacity or over != 0:
+            self.capacity *= 4
+            self._alloc_sets()
+            self.enqueue(self._theta, self._stream)
+            return self.result()
+        solved = int(head[2])
+        rows = np.ctypeslib.as_array((ctypes.c_longlong * (nfound * (w + 2))).from_address(self._res + 32)).reshape(nfound, w + 2).copy() \
+            if nfound else np.zeros((0, w + 2), np.int64)
+        m = np.ascontiguousarray(rows[:, :w]).view(np.uint64)
+        c, f = rows[:, w].copy(), rows[:, w + 1].copy()
+        order = np.lexsort((f, -c))
+        return m[order], c[order], f[order], solved
+
+    def run(self, theta, stream=None):
+        self.enqueue(theta, stream)
+        return self.result()
+
+
 def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=65536, theta=None):
     """`discover_regions` with everything per-sample on the GPU: the sample of the box [lb, ub] is drawn on the device
     (torch generator, seeded), solved by `lmpc_solve_batch_device` with the active-set masks kept there, and reduced to
@@ -118,10 +198,8 @@ def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=6
         lo = torch.as_tensor(np.asarray(lb, float).reshape(-1), dtype=torch.float64, device=dev)
         hi = torch.as_tensor(np.asarray(ub, float).reshape(-1), dtype=torch.float64, device=dev)
         theta = lo + (hi - lo) * torch.rand((int(nsamples), lo.numel()), dtype=torch.float64, device=dev, generator=gen)
-    act = torch.empty((theta.shape[0], qp.words), dtype=torch.int64, device=theta.device)
-    x, ef = qp.solve_device(theta, active=act)
-    masks, counts, first = qp.distinct_active_sets_device(act, ef, capacity=capacity)
-    solved = int(counts.sum())
+    sampler = DeviceRegionSampler(qp, int(theta.shape[0]), capacity=min(int(capacity), 4096))
+    masks, counts, first, solved = sampler.run(theta)
     out = {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved, "theta": theta}
     if group is not None:
         import torch.distributed as dist
