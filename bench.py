@@ -229,6 +229,8 @@ class Workload:
             for k_, v_ in (options or {}).items():
                 q_.set_option(k_, v_)
         self.qp = self.qps[0]
+        for q_ in self.qps:
+            q_.reserve(n_local)             # (setup: scratch for this batch size allocated before anything is timed)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         self.stream_handles = [s_.cuda_stream for s_ in self.streams]
         self.bytes_per = algorithmic_bytes(self.qp.nth, self.nout, 4 if f32 else 8)
@@ -727,6 +729,13 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     kernel's forms: the n-chain form (library default; `value`) and the Gram-scan form (`gram_scan`)."""
     _phase(f"config {workload}: setup")
     w = Workload(torch, lmpc, workload, batch, dev, local_rank, 0, 1, f32=f32)
+    # the very FIRST call on the fresh handle, timed by itself (allocations, and on the wavefront path the probe that
+    # decides the launch shape -- lmpc_set_option "wave_probe"): what a one-shot caller gets
+    torch.cuda.synchronize(dev)
+    t_first = time.perf_counter()
+    w.launch(0)
+    torch.cuda.synchronize(dev)
+    first_call_s = time.perf_counter() - t_first
     dist_info, flop = w.work_distribution()
     x_chain, f_chain = w.xbuf[0].cpu().numpy().copy(), w.fbuf[0].cpu().numpy().copy()
     _phase(f"config {workload}: timed region")
@@ -754,7 +763,8 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     out = {"value": value, "unit": "solves/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "warmup": warmup,
            "dtype": dtype, "batch": batch, "kernel": w.kernel, "rotating_batches": w.nrot,
            "workload": describe(w), **dist_info, "roofline": roof, "verified": verification["verified"],
-           "verification": verification, "options": dict(w.options)}
+           "verification": verification, "options": dict(w.options),
+           "first_run_value": batch / first_call_s, "first_call_ms": 1e3 * first_call_s}
     if w.kernel == "wave" and hasattr(w.qp, "wave_stats"):
         out["wave_stats"] = w.qp.wave_stats()       # working-set sizes seen; first_pass_rows > 0: two passes
     if want_cpu:
@@ -798,7 +808,8 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     return out
 
 
-PRIME_CALLS = 3      # untimed calls before a side configuration's timed region (warm-up)
+PRIME_CALLS = 1      # untimed calls before a side configuration's timed region (plain warm-up; a fresh handle shapes its
+                     # launches from a probe of its first batch, not from earlier calls)
 LINE_LIMIT = 8192    # the bench line must stay far below what the driver keeps of stdout
 
 

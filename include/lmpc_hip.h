@@ -539,6 +539,16 @@ int lmpc_discover_regions_device(lmpc_handle *h, int64_t N, const double *theta,
 #define LMPC_EXIT_UNFINISHED (-8)
 int lmpc_check(lmpc_handle *h);
 
+/* lmpc_reserve: allocate NOW what the *_device entry points would allocate lazily inside their first call on a batch of
+ * N problems (work lists, overflow lists, counters, the slow path's scratch), so that the first call enqueues kernels
+ * and nothing else.  Optional; asynchronous on `stream` (a few memsets).  What a first call on a fresh
+ * wavefront-kernel handle still does by itself, once: it solves the leading 16 384 points of its own batch in front
+ * into scratch outputs, waits for that launch and reads the working-set sizes it saw, so that the batch runs in the
+ * launch shape a warmed-up handle would choose (lmpc_set_option "wave_probe" 0: never; such a handle's first calls run
+ * in one pass until its statistics exist).  The statistics behind that choice cover the most recent one to two
+ * million problems, not the handle's whole life. */
+int lmpc_reserve(lmpc_handle *h, int64_t N, void *stream);
+
 /* Staging and scratch buffers of a handle grow with the largest batch it has seen and are kept between calls.
  * lmpc_release_scratch waits for the handle's GPU and gives them back (the constant pack stays; the next call
  * allocates what it needs again, and a DAQP_WARMSTART state kept by lmpc_compute_control* is dropped). */

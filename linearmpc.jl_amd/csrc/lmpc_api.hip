@@ -411,6 +411,50 @@ int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, dou
     return rc;
 }
 
+// First large batch of a FRESH wavefront-kernel handle: whether a batch first runs at a smaller working-set capacity (two
+// passes, lmpc_wave_launch.hpp) is decided from the working-set sizes the handle has seen -- and a fresh handle has
+// seen none, so its first calls ran in one pass (pendulum N = 50: 7.2e7 against 1.3e8 solves/s) until a launch or two
+// had reported.  Instead the first call solves the leading kProbe points of ITS OWN batch once more in front, into
+// scratch outputs (cold, no closed-loop side effects), waits for that one small launch and reads the counters it left:
+// the batch itself then runs in the configuration a warmed-up handle would choose.  Once per handle, only where two
+// passes are possible at all; results are not affected (they never depend on the split).  Not inside a hipGraph
+// capture: make one call before capturing, or lmpc_set_option("wave_probe", 0).
+constexpr int64_t kProbe = 16384;
+int wave_probe(lmpc_handle *h, const double *theta, int64_t nprob, hipStream_t st) {
+    if (h->waveProbed || !h->waveProbe || !h->useWave || h->avi || h->bnb || h->waveTwoPass >= 0 || !h->bigPath ||
+        h->W.cap < 40 || nprob < 4 * kProbe || theta == nullptr)
+        return LMPC_OK;
+    h->waveProbed = true;
+    double *px = nullptr;
+    int32_t *pf = nullptr;
+    HIP_TRY(h, hipMalloc(&px, sizeof(double) * (size_t)kProbe * h->P.nout));
+    if (hipMalloc(&pf, sizeof(int32_t) * (size_t)kProbe) != hipSuccess) { hipFree(px); return fail(h, LMPC_ERR_HIP, "lmpc: probe scratch"); }
+    // the probe is a plain cold solve: closed-loop fusion, work lists, kept factors and profiling stay out of it
+    const SimFuse sim = h->L.sim; const WaveSim wsim = h->waveSim; const WaveList wl = h->waveList;
+    const int phase = h->asyncPhase; const bool keep = h->keepOn, prof = h->prof;
+    h->L.sim = SimFuse{}; h->waveSim = WaveSim{}; h->waveList = WaveList{}; h->asyncPhase = 0; h->keepOn = false; h->prof = false;
+    int rc = LMPC_OK;
+    if (wave_screens(h, nprob)) rc = ensure_lists(h, nprob, st);          // (sized for the batch that follows, once)
+    if (rc == LMPC_OK)
+        rc = wave_screens(h, kProbe) ? launch_wave_screened(h, kProbe, theta, px, pf, nullptr, nullptr, nullptr, st)
+                                     : launch_wave(h, kProbe, theta, px, pf, nullptr, nullptr, nullptr, st);
+    h->L.sim = sim; h->waveSim = wsim; h->waveList = wl; h->asyncPhase = phase; h->keepOn = keep; h->prof = prof;
+    if (rc == LMPC_OK && h->dStat && h->hStat) {
+        unsigned long long raw[64 * 16];
+        if (hipMemcpyAsync(raw, h->dStat, sizeof(raw), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+            for (int q = 0; q < 4; q++) {
+                unsigned long long sum = 0ull;
+                for (int sh = 0; sh < 64; sh++) sum += raw[sh * 16 + q];
+                h->hStat[q] = sum;                    // what the next launch would have published by itself
+            }
+        } else { (void)hipGetLastError(); }
+    } else if (rc == LMPC_OK) {
+        (void)hipStreamSynchronize(st);
+    }
+    (void)hipFree(px); (void)hipFree(pf);
+    return rc;
+}
+
 // Scenario-asynchronous closed loop, streaming half (lmpc_simrun_kernel.hpp): every scenario -- first round -- or the
 // scenarios of the round before's list run ahead in registers to their next step that needs iterations; those go on
 // the work list the iterating half (lane kernel or wavefront kernel) consumes.
@@ -485,6 +529,10 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             const int rcw = launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
             h->waveList = WaveList{};
             return rcw;
+        }
+        if (!h->waveProbed && h->L.sim.FG == nullptr && h->waveSim.FG == nullptr) {
+            const int rcp = wave_probe(h, theta, nprob, st);
+            if (rcp != LMPC_OK) return rcp;
         }
         return wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
                                       : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
@@ -838,6 +886,15 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
     HIP_TRY(h, hipMemcpyAsync(h->simFG + nx * nx, G, sizeof(double) * nx * nu, hipMemcpyHostToDevice, st));
     if (X_traj) HIP_TRY(h, hipMemcpyAsync(X_traj, x, sizeof(double) * (size_t)N * nx, hipMemcpyDeviceToDevice, st));
     const unsigned grid = (unsigned)((N + 255) / 256);
+    if (h->useWave && !h->avi && !h->waveProbed && N >= 4 * kProbe) {
+        // fresh handle: the working-set sizes of the first step's problems decide how the loop's launches are shaped
+        // (wave_probe) -- on the records of the leading scenarios, formed here and formed again with all the others below
+        hipLaunchKernelGGL(form_theta_kernel<double>, dim3((unsigned)((kProbe + 255) / 256)), dim3(256), 0, st, h->simTheta, x, r,
+                           uprev, nx, nr, nuprev, (long long)kProbe);
+        HIP_TRY(h, hipGetLastError());
+        const int rcp = wave_probe(h, h->simTheta, N, st);
+        if (rcp != LMPC_OK) return rcp;
+    }
     // theta = [x; r; uprev] is formed once; from then on every scenario's state lives in its record
     // (the scenario-asynchronous loop forms it in its first streaming pass)
     // (round 3: also on the wavefront-kernel path -- soft rows, many rows: the same streaming half on the handle's
@@ -1619,6 +1676,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         h->laneBlock = value;
         return LMPC_OK;
     }
+    if (std::strcmp(name, "wave_probe") == 0) { h->waveProbe = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "wave") == 0) {
@@ -1630,6 +1688,20 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         return LMPC_OK;
     }
     return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
+}
+
+int lmpc_reserve(lmpc_handle *h, int64_t N, void *stream) {
+    if (!h || N < 0) return LMPC_ERR_BADARG;
+    if (N == 0) return LMPC_OK;
+    LMPC_ENTER_DEVICE(h);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->avi) return LMPC_OK;                          // (its slabs depend on the launch shape only: first launch)
+    if (h->useWave) {
+        if (wave_screens(h, N)) { const int rc = ensure_lists(h, N, st); if (rc != LMPC_OK) return rc; }
+        return wave_reserve(h, N, st);
+    }
+    if (will_screen(h, N)) return ensure_lists(h, N, st);
+    return LMPC_OK;
 }
 
 int lmpc_release_scratch(lmpc_handle *h) {

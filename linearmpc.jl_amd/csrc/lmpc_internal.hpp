@@ -75,6 +75,10 @@ struct lmpc_handle {
     unsigned long long *dStat = nullptr;             // working-set statistics of the wavefront kernel (device, cumulative)
     volatile unsigned long long *hStat = nullptr;    // ... their copy in mapped host memory, written by every launch
     unsigned long long *dStatHost = nullptr;         // ... and its device address
+    bool waveProbed = false;    // a fresh handle's first large batch has been probed for its working-set sizes (wave_probe)
+    int waveProbe = 1;          // option "wave_probe": 0 = never probe (first calls run in one pass until statistics exist)
+    unsigned long long statA[4] = {0, 0, 0, 0}, statB[4] = {0, 0, 0, 0};   // window of the statistics: snapshots of the
+                                // cumulative counters about 2^20 problems apart; decisions use (now - statA)
     int waveCtrSet = 0;         // which of the two (ticket, overflow) counter pairs the next wavefront-kernel launch uses
     int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
     int regCap = 0;
@@ -221,6 +225,7 @@ int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
 // lmpc_wave_launch.hpp, compiled into the binary64 translation unit)
 int wave_first_pass_cap(lmpc_handle *h, int64_t nprob);
 void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]);
+int wave_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

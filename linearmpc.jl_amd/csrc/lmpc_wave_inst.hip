@@ -11,6 +11,7 @@ template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM !=
 // (one translation unit carries the launcher's non-template helpers the API file needs)
 int wave_first_pass_cap(lmpc_handle *h, int64_t nprob) { return wave_first_pass_cap_impl(h, nprob, sizeof(double)); }
 void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]) { wave_stat_sums(h, out); }
+int wave_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st) { return wave_reserve_impl(h, nprob, st); }
 #endif
 }  // namespace lmpc
 

@@ -107,6 +107,21 @@ inline void wave_stat_sums(const lmpc_handle *h, unsigned long long out[4]) {
     out[0] = b[0] + b[1] + b[2] + b[3]; out[1] = b[0]; out[2] = b[0] + b[1]; out[3] = b[0] + b[1] + b[2];
 }
 
+// ... over a WINDOW of the most recent one to two million problems (the counters of a handle's whole life
+// kept a small first pass long after the parameter batches had turned hard).  statB follows the cumulative counters in
+// steps of 2^20 problems, statA is the statB before it; what a decision sees is (now - statA).
+inline void wave_stat_window(lmpc_handle *h, unsigned long long out[4]) {
+    unsigned long long cur[4];
+    wave_stat_sums(h, cur);
+    if (cur[0] < h->statB[0]) {                                  // (counters restarted: lmpc_release_scratch does not, but be safe)
+        for (int q = 0; q < 4; q++) h->statA[q] = h->statB[q] = 0ull;
+    }
+    if (cur[0] - h->statB[0] >= (1ull << 20)) {
+        for (int q = 0; q < 4; q++) { h->statA[q] = h->statB[q]; h->statB[q] = cur[q]; }
+    }
+    for (int q = 0; q < 4; q++) out[q] = cur[q] - h->statA[q];
+}
+
 // capacity of the first of two passes for a batch of nprob problems on this handle, 0 = one pass (see launch_wave_inst)
 inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
     if (h->bnb || h->waveTwoPass == 0 || !h->bigPath || h->W.cap < 40 || nprob >= (int64_t)0x7fffffff) return 0;
@@ -118,7 +133,7 @@ inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
     if (h->waveTwoPass > 0) c1 = h->waveCap1;
     else if (h->hStat && nprob >= 4096) {
         unsigned long long sum[4];
-        wave_stat_sums(h, sum);
+        wave_stat_window(h, sum);
         const int caps[3] = {24, 32, 48};
         for (int q = 0; q < 3 && c1 == 0 && sum[0] >= 1000ull; q++)
             if ((sum[0] - sum[1 + q]) * 100ull <= 3ull * sum[0]) c1 = caps[q];
@@ -139,6 +154,48 @@ inline int wave_first_pass_cap_impl(lmpc_handle *h, int64_t nprob, size_t rs) {
         if (!((h->waveGram && st > sf) || t.level > full.level)) c1 = 0;
     }
     return c1;
+}
+
+// lmpc_reserve: everything a wavefront-kernel launch on a batch of nprob problems would allocate lazily (ticket and
+// overflow counters, working-set statistics, the overflow lists of both passes, the slow path's scratch), allocated
+// now -- the launch paths then find it in place.  Branch-and-bound snapshots depend on the launch shape and stay lazy.
+inline int wave_reserve_impl(lmpc_handle *h, int64_t nprob, hipStream_t st) {
+    constexpr int kP1 = kShards * kCountStride;
+    if (!h->dQueue) {
+        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, sizeof(int32_t) * (2 * kP1 + 64)));
+        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t) * (2 * kP1 + 64), st));
+        HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
+        h->waveCtrSet = 0; h->waveOvfSet = 0;
+    }
+    if (h->bnb || nprob >= (int64_t)0x7fffffff) return LMPC_OK;
+    if (!h->hStat) {
+        unsigned long long *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
+        for (int q = 0; q < 8; q++) hp[q] = 0ull;
+        h->hStat = hp;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dStatHost), hp, 0));
+        HIP_TRY(h, hipMalloc(&h->dStat, sizeof(unsigned long long) * 64 * 16));
+        HIP_TRY(h, hipMemsetAsync(h->dStat, 0, sizeof(unsigned long long) * 64 * 16, st));
+    }
+    if (h->bigPath && h->W.cap >= 40 && h->waveTwoPass != 0 && nprob > h->ovfCap1) {      // a first pass may run
+        hipFree(h->dOvfList1); h->dOvfList1 = nullptr; h->ovfCap1 = 0;
+        HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
+        h->ovfCap1 = nprob;
+    }
+    if (h->bigPath && h->capFull > h->W.cap) {                                            // the slow path may run
+        if (nprob > h->ovfCap) {
+            hipFree(h->dOvfList); h->dOvfList = nullptr; h->ovfCap = 0;
+            HIP_TRY(h, hipMalloc(&h->dOvfList, sizeof(int32_t) * (size_t)nprob));
+            h->ovfCap = nprob;
+        }
+        if (!h->dBigR) {
+            const int bigCap = h->capFull < kBigCap ? h->capFull : kBigCap;
+            HIP_TRY(h, hipMalloc(&h->dBigR, sizeof(double) * (size_t)kBigThreads * (size_t)big_scratch_reals(h->W.n, h->W.m, bigCap)));
+            HIP_TRY(h, hipMalloc(&h->dBigI, sizeof(int32_t) * (size_t)kBigThreads * (size_t)big_scratch_ints(h->W.m, bigCap)));
+        }
+    }
+    return LMPC_OK;
 }
 
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>

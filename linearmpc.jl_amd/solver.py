@@ -582,6 +582,12 @@ class BatchedQP:
         cnt = lib().lmpc_profile_read(self._h, ctypes.byref(ms))
         return cnt, ms[0], ms[1], ms[2]
 
+    def reserve(self, n, stream=None):
+        """`lmpc_reserve`: allocate now what the first device call on a batch of n problems would allocate lazily."""
+        lib().lmpc_reserve.argtypes = [_vp, ctypes.c_int64, _vp]
+        lib().lmpc_reserve.restype = ctypes.c_int
+        check(lib().lmpc_reserve(self._h, int(n), _vp(int(stream)) if stream else None), self._h)
+
     def release_scratch(self):
         """`lmpc_release_scratch`: give the staging / scratch buffers back (they grow with the largest batch)."""
         check(lib().lmpc_release_scratch(self._h), self._h)
