@@ -941,7 +941,11 @@ int lmpc_simulate_device(lmpc_handle *h, int64_t N, int T, int nx, int nr, int n
             // (a first pass at a smaller capacity is in sight: it writes every scenario's state out after each step, so
             // that a step which outgrows it restarts exactly where the step-synchronous loop would)
             const int rck = ensure_keep(h, N, st);
-            if (rck != LMPC_OK) return rck;
+            if (rck != LMPC_OK) {                     // (leave the handle as an ordinary solve expects it)
+                h->L.sim = SimFuse{}; h->waveSim = WaveSim{}; h->raWarm = false; h->asyncT = 0; h->prof = prof;
+                h->asyncX = h->asyncR = h->asyncUp = nullptr;
+                return rck;
+            }
         }
         if (h->useWave) h->waveSim = WaveSim{h->simFG, h->simK, U_traj, X_traj, flag_min, nx, nu, nr, nuprev, (long long)N, -1, runAhead ? T : 0};
         constexpr int kBurst = 2;   // steps a scenario of a (short) work list may run ahead before it is parked

@@ -259,6 +259,16 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                 for (int t = 0; t < NT; t++) sh = __builtin_fma(row[t], th[t], sh);
             }
             const unsigned long long mask = __ballot(hard);
+            // every problem gets a flag HERE -- BEFORE a queued problem is published in the ring, so that the release below
+            // orders this store in front of the solving lane's final one (issued after the publish, the
+            // provisional flag could land last and leave a solved problem at -8) --, queued ones the provisional
+            // EXIT_UNFINISHED that the solving lane overwrites: should a bounded wait below ever run out, no caller reads a stale flag as success (the
+            // reference asserts exitflag >= 1, utils.jl:46); an unmasked store of whole lines, as screen_kernel's
+#ifdef LMPC_FAST_NT_STORES
+            if (valid) __builtin_nontemporal_store(hard ? EXIT_UNFINISHED : EXIT_OPTIMAL, &exitflag[pid]);
+#else
+            if (valid) exitflag[pid] = hard ? EXIT_UNFINISHED : EXIT_OPTIMAL;
+#endif
             if (mask != 0ull) {
                 int base = 0;
                 if (lane == 0) base = __hip_atomic_fetch_add(&ctrl[0], __popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -291,14 +301,6 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                 if (iters) iters[pid] = 1;
                 if (active) active[pid * P.words] = 0ull;
             }
-            // every problem gets a flag HERE, queued ones the provisional EXIT_UNFINISHED that the solving lane
-            // overwrites: should a bounded wait below ever run out, no caller reads a stale flag as success (the
-            // reference asserts exitflag >= 1, utils.jl:46); an unmasked store of whole lines, as screen_kernel's
-#ifdef LMPC_FAST_NT_STORES
-            if (valid) __builtin_nontemporal_store(hard ? EXIT_UNFINISHED : EXIT_OPTIMAL, &exitflag[pid]);
-#else
-            if (valid) exitflag[pid] = hard ? EXIT_UNFINISHED : EXIT_OPTIMAL;
-#endif
         };
 #ifdef LMPC_FAST_CONTIG     // each streaming wavefront takes a contiguous run of the workgroup's tiles
         const long long per = (R + nstr - 1) / nstr;
