@@ -198,6 +198,27 @@ inline int wave_reserve_impl(lmpc_handle *h, int64_t nprob, hipStream_t st) {
     return LMPC_OK;
 }
 
+// Branch and bound in two passes (round 4): the search's working sets hold the fixed binaries plus a few more rows -- far
+// fewer than the n + 1 rows the factor is sized for (satellite: 40 binaries, capacity 61) -- and what bounds the search
+// is issue latency at the residency the factor's LDS allows.  So the batch first runs at the smallest of 24 / 32 / 48
+// rows that leaves eight rows beyond the binaries, IF that keeps more wavefronts resident; a point that outgrows it
+// (exit flag -7 inside the pass) is listed and searched again from scratch at the full capacity.  The search is
+// deterministic, so the result does not depend on the split.  "wave_two_pass" 0 switches it off.
+inline int bnb_first_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
+    if (!h->bnb || h->waveTwoPass == 0 || nprob >= (int64_t)0x7fffffff || nprob < 4096) return 0;
+    int c1 = 0;
+    for (int c : {24, 32, 48})
+        if (c1 == 0 && c >= h->nBinary + 8) c1 = c;
+    if (h->waveTwoPass > 0 && h->waveCap1 > 0) c1 = h->waveCap1;
+    if (c1 == 0 || c1 + 4 > h->W.cap) return 0;
+    const WaveConfig full = wave_config(h, rs);
+    const int capW = h->W.cap, ldcW = h->W.ldc;
+    h->W.cap = c1; h->W.ldc = c1 | 1;
+    const WaveConfig t = wave_config(h, rs);
+    h->W.cap = capW; h->W.ldc = ldcW;
+    return t.nwv * t.blocksPerCU > full.nwv * full.blocksPerCU ? c1 : 0;
+}
+
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
@@ -243,7 +264,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
         HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
         h->waveCtrSet = 0; h->waveOvfSet = 0;
     }
-    const int pass = BNB ? 0 : h->wavePass;              // 0: the only pass; 1: first of two (smaller capacity); 2: second
+    const int pass = h->wavePass;                        // 0: the only pass; 1: first of two (smaller capacity); 2: second
     const int os = h->waveOvfSet;
     int32_t *const p1Count = h->dOvfCount + os * kP1, *const p1Next = h->dOvfCount + (os ^ 1) * kP1;
     int32_t *const ovfCount = h->dOvfCount + 2 * kP1 + 8 * os, *const p2Next = h->dOvfCount + 2 * kP1 + 8 * (os ^ 1);
@@ -365,7 +386,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     // pass until 1000 problems have been seen, for small batches, and if no capacity qualifies.
     // "wave_two_pass" 0 = never, 1 = always at "wave_cap1" rows (default 24), -1 (default) = as described.
     WaveConfig cfg = wave_config(h, sizeof(R));
-    const int c1 = BNB ? 0 : wave_first_pass_cap_impl(h, nprob, sizeof(R));
+    const int c1 = BNB ? bnb_first_pass_cap(h, nprob, sizeof(R)) : wave_first_pass_cap_impl(h, nprob, sizeof(R));
     const int capW = h->W.cap, ldcW = h->W.ldc;
     auto dispatch = [&]() -> int {
     int rc;
