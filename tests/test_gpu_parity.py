@@ -1953,6 +1953,45 @@ def test_hybrid_f32_bench_size_properties(lmpc):
     assert np.array_equal(x[sel], xo)
 
 
+def test_branch_and_bound_in_two_passes_is_the_same_search(lmpc):
+    """Round 4: a hybrid batch first runs at a smaller working-set capacity (more wavefronts resident) and the points
+    that outgrow it are searched again at the full one (lmpc_wave_launch.hpp, bnb_first_pass_cap).  One pass
+    ("wave_two_pass" 0), the default split (48 rows for the satellite's 40 binaries: nothing overflows) and a first
+    pass forced so small that most points overflow (42 rows) must return the same arrays, binary64 and binary32; a
+    sample against the oracle's search.  Also the lazy snapshots of a node's factor (written only when a removal
+    would break the leading-block property) against the oracle's eager ones."""
+    import bench
+    from oracle import ldp as oldp
+    g = load_golden("satellite20")
+    N = 12_288
+    theta = bench.make_theta("satellite20", N, 5)
+    outs = {}
+    for name, opts in (("one", {"wave_two_pass": 0}), ("default", {}), ("forced42", {"wave_two_pass": 1, "wave_cap1": 42})):
+        qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=3)
+        for k, v in opts.items():
+            qp.set_option(k, v)
+        outs[name] = qp.solve(theta)
+        qp32 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=3,
+                                        settings=lmpc.default_settings_f32())
+        for k, v in opts.items():
+            qp32.set_option(k, v)
+        outs[name + "32"] = qp32.solve_f32(theta.astype(np.float32))
+        if name == "one":
+            L = oracle_ldp_from(qp.ldp())
+        qp.close(); qp32.close()
+    for suf in ("", "32"):
+        a = outs["one" + suf]
+        assert np.all(a[1] == 1)
+        for other in ("default", "forced42"):
+            b = outs[other + suf]
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v), (other, suf)
+    sel = np.arange(0, N, 97)[:100]
+    xo, efo, ito, acto = oldp.solve_batch(L, theta[sel])
+    x, ef, it, act = outs["default"]
+    assert np.array_equal(x[sel], xo) and np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
+
+
 # ------------------------------------------------------------------ screening pass in front of the wavefront kernel
 @pytest.mark.parametrize("n,mg,nth,nsoft,nout,imm,seed", [
     (20, 30, 6, 0, 1, False, 0),       # m = 50: one constraint slot per lane
