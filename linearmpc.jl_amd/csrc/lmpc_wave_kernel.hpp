@@ -201,7 +201,10 @@ __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB, bool GRAM 
 // products of a row append plus the soft slack as pairwise lane trees (wv_sum) instead of serial chains.  It reads
 // the full symmetric Gram matrix (WaveLayout::oGf; LDSC 1 stages THAT) and neither M' nor the packed triangle.
 // Bit-comparable with the CPU checker in its mode 1 ("Gram-scan form"), not with mode 0.
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
+// SIM (binary64 without branch and bound only): the closed-loop machinery is compiled in -- plant step fused behind the
+// solve, run-ahead of a scenario's consecutive steps, the kept factorisation between steps.  A plain batched solve
+// runs the instantiation without it (round 4: the hot loop of the plain solve carried that state through its spills).
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false, bool SIM = true>
 __global__ __launch_bounds__(wave_launch_bound(MR, BNB, GRAM))
 __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
@@ -388,7 +391,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         // (a later step reads the record this wavefront has just written: past its own L1)
         // (built for up to six constraint slots per lane: beyond that the registers are gone -- the eight-slot
         // instantiation dropped from two wavefronts per SIMD to one with it; lmpc_simulate_device knows)
-        constexpr bool RUNAHEAD = sizeof(R) == 8 && !BNB && MR <= kWaveRunAheadSlots;
+        constexpr bool RUNAHEAD = SIM && sizeof(R) == 8 && !BNB && MR <= kWaveRunAheadSlots;
         auto thld = [&](int t) -> R {
             if constexpr (RUNAHEAD) return again ? __hip_atomic_load(th + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : th[t];
             else return th[t];
@@ -795,7 +798,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
             }
             ydirty = na > 0;
         }
-        if constexpr (!BNB) {
+        if constexpr (!BNB && SIM) {
             if (!cont && bnb_i != nullptr && warm != nullptr) {
                 const int32_t *si = wv_uniform_ptr(bnb_i + pid * kKeepI);
                 const R *sr = wv_uniform_ptr(bnb_r + pid * (long long)P.keepStride);
@@ -1250,7 +1253,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
                 xo = xs + sh;
                 if (X != nullptr) (X + pid * P.nout)[(unsigned)ko] = xo;
             }
-            if constexpr (sizeof(R) == 8 && !BNB) {
+            if constexpr (sizeof(R) == 8 && !BNB && SIM) {
                 // closed loop with the plant step fused in: advance this scenario in place (WaveSim; lane a < nx forms x+_a,
                 // lane l < nu holds u_l).  A point handed to the slow path is advanced there, after its re-solve.
                 if (o0 == 0 && sim.FG != nullptr && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
@@ -1314,7 +1317,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         if constexpr (RUNAHEAD) {
             more = sim.FG != nullptr && sim.kfix < 0 && kcur >= 0 && kcur < sim.T && flag >= 1 && na > 0;
         }
-        if constexpr (!BNB) {
+        if constexpr (!BNB && SIM) {
             // closed loop: this step's final working set and factor, kept.  (Run-ahead keeps them in LDS; it writes them
             // out when the scenario leaves the kernel, and after every step of a FIRST pass -- a later step that
             // outgrows that pass's capacity restarts from here in the second pass)

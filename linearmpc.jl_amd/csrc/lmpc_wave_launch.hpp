@@ -223,7 +223,11 @@ template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool 
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;                         // (work-list mode, screening pass in front: h->waveList, see launch())
-    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM>;
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, true>;
+    if constexpr (!BNB && sizeof(R) == 8) {
+        // plain batched solve (no plant step to fuse, no kept factorisation): the instantiation without the closed loop
+        if (h->waveSim.FG == nullptr && !h->keepOn) kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, false>;
+    }
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
     int blocksPerCU = cfg.blocksPerCU;
