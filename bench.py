@@ -520,7 +520,7 @@ def region_discovery_config(torch, lmpc, dev, local_rank, nsamples, want_cpu, re
     return res
 
 
-def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, gram=0, reps=2, ncheck=48):
+def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, gram=0, reps=2, ncheck=512):
     """SURVEY 8(f-1) as a measured workload: `nscen` closed loops of `T` steps on the device (lmpc_simulate_device,
     warm; theta = [x; r; uprev] -> solve -> x <- F x + G u, /root/reference/src/simulation.jl:93-113), scenario-steps
     per second.  name "pendulum": the headline problem (lane kernels, scenario-asynchronous loop); "pendulum_N50": the

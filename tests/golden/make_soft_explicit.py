@@ -91,15 +91,22 @@ def solve_soft(g, theta, rho):
 
 def main():
     out = {}
-    for name, pick in (("soft_doc", 48), ("x0unc_kat", 32), ("pendulum_N50", 24)):
-        g = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    for name, pick in (("soft_doc", 48), ("x0unc_kat", 32), ("pendulum_N50", 24), ("pendulum_N50_active", 24)):
+        g = dict(np.load(os.path.join(GOLDEN, name.replace("_active", "") + ".npz")))
         theta = np.asarray(g["theta"], float)
         rng = np.random.default_rng(11)
-        ok = np.flatnonzero(np.asarray(g["exitflag"]) >= 1)
-        soft_act = np.flatnonzero(np.asarray(g["exitflag"]) == 2)
-        idx = np.unique(np.concatenate([rng.choice(ok, min(pick, len(ok)), replace=False),
-                                        soft_act[:pick // 2]])).astype(np.int64)
-        th = theta[idx]
+        if name.endswith("_active"):
+            # the benchmark class WITH its soft output bounds at work (|cart position| <= 1.5, |angle| <= 0.2 on every
+            # step; VERDICT round 3: the closed-loop sample above barely touches them): starts beyond the bounds
+            th = np.column_stack([rng.uniform(1.3, 2.4, pick) * rng.choice([-1, 1], pick), rng.uniform(-1, 1, pick),
+                                  rng.uniform(0.1, 0.3, pick) * rng.choice([-1, 1], pick), rng.uniform(-1, 1, pick),
+                                  rng.uniform(-1, 1, pick), np.zeros(pick), rng.uniform(-1, 1, pick)])
+        else:
+            ok = np.flatnonzero(np.asarray(g["exitflag"]) >= 1)
+            soft_act = np.flatnonzero(np.asarray(g["exitflag"]) == 2)
+            idx = np.unique(np.concatenate([rng.choice(ok, min(pick, len(ok)), replace=False),
+                                            soft_act[:pick // 2]])).astype(np.int64)
+            th = theta[idx]
         for rho in (1e-6, 1e-3):
             U, eps, ef = solve_explicit(g, th, 1.0 / rho)
             Us, efs = solve_soft(g, th, rho)

@@ -546,7 +546,7 @@ def test_parameter_preview_restated():
     assert np.all(ef == 1) and np.abs(X - np.clip(2 * P, 0, 2)).max() < 1e-12
 
 
-@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50"])
+@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50", "pendulum_N50_active"])
 def test_soft_rows_equal_the_explicit_slack_qp(name):
     """Pins the SOFT-row convention to the reference's own definition.  /root/reference/src/utils.jl:329-364
     (make_singlesided) writes a soft row out as an explicit QP: one slack per soft row entering both sides of the row
@@ -563,7 +563,10 @@ def test_soft_rows_equal_the_explicit_slack_qp(name):
                                                   os.path.join(os.path.dirname(__file__), "golden", "make_soft_explicit.py"))
     mk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mk)
-    g = load_golden(name)
+    # ("pendulum_N50_active": the reference's benchmark class, N = 50, from starts BEYOND its soft output bounds --
+    # 23 of its 24 points end soft-optimal with slacks up to 2e2 in normalised-row units; the closed-loop sample of
+    # "pendulum_N50" barely touches those rows)
+    g = load_golden(name.replace("_active", ""))
     kat = load_golden("soft_explicit_kat")
     th = kat[f"{name}_theta"]
     n = g["H"].shape[0]
@@ -627,7 +630,7 @@ def test_gram_scan_twin_takes_the_same_decisions(name, xtol):
     assert Xf.dtype == np.float32 and ((ef >= 1) == (ec >= 1)).mean() > 0.9
 
 
-@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50"])
+@pytest.mark.parametrize("name", ["soft_doc", "x0unc_kat", "pendulum_N50", "pendulum_N50_active"])
 def test_soft_path_solution_is_a_kkt_point_of_the_explicit_slack_qp(name):
     """A certificate that involves no solver at all.  For the reference's explicit-slack QP (utils.jl:329-364: slack
     eps_i per soft row with coefficient -nf_i on both sides, cost soft_weight I) the KKT conditions at a point U are
@@ -638,7 +641,7 @@ def test_soft_path_solution_is_a_kkt_point_of_the_explicit_slack_qp(name):
     active HARD rows' normals: a non-negative least-squares problem whose optimum must be ~0, and every hard row must
     hold.  Checked at rho_soft = 1e-3 (the same semantics as 1e-6, without its 1e6 amplification of rounding)."""
     from scipy.optimize import nnls
-    g = load_golden(name)
+    g = load_golden(name.replace("_active", ""))
     kat = load_golden("soft_explicit_kat")
     th = kat[f"{name}_theta"][:40]
     rho = 1e-3
