@@ -2371,6 +2371,35 @@ def test_game_theoretic_mpc_closed_loop_reproduces_the_reference_pins(lmpc):
         assert np.abs(out["X"][499] - [10.0, 0.0]).max() < 1e-3         # every scenario settles at the reference
 
 
+def test_generated_controller_call_on_a_variational_handle(lmpc):
+    """The batched `mpc_compute_control(control, state, reference, ...)` (reference codegen/mpc_update_qp.c:29-54) and
+    the multi-device entry points on an is_avi handle: same numbers as solving the assembled theta directly."""
+    import torch
+    g = load_golden("game_kat")
+    q = lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], is_symmetric=False)
+    mpc = lmpc.MPC(q, nx=2, nu=2, nr=2, nuprev=2)
+    gc = lmpc.GeneratedController(mpc)
+    rng = np.random.default_rng(8)
+    N = 5000
+    state = rng.uniform(-20, 20, (N, 2)); ref = rng.uniform(-20, 20, (N, 2)); prev = rng.uniform(-1, 1, (N, 2))
+    control = prev.copy()
+    ef = gc.mpc_compute_control(control, state, ref)
+    theta = np.hstack([state, ref, prev])
+    x, ef2, _, _ = mpc.control_model().solve(theta)
+    assert np.array_equal(ef, ef2) and np.all(ef == 1) and np.array_equal(control, x)
+    U, efb = mpc.compute_control_batch(state, R=ref, Uprev=prev)
+    assert np.array_equal(U, x)
+    # every GPU behind one call (here: however many this box shows) on the same problem
+    mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=2)
+    xm, efm, _, _ = mq.solve(theta)
+    assert np.array_equal(xm, x) and np.array_equal(efm, ef)
+    mq.close()
+    # distinct optimal active sets of the sample, reduced on the device (region discovery works on this mode too)
+    out = lmpc.explicit.discover_regions_device(mpc.control_model(), None, None, 0, theta=torch.from_numpy(theta).to("cuda:0"))
+    _, _, _, act = mpc.control_model().solve(theta)
+    assert len(out["masks"]) == len(np.unique(act, axis=0)) and out["n_solved"] == N
+
+
 def test_variational_problems_with_general_and_soft_rows(lmpc):
     """Random non-symmetric problems with general, one-sided and SOFT rows, feasible and infeasible points: the AVI
     kernel against the oracle on the handle's pack, bit for bit (flags incl. -1, iterations, active sets, x)."""
