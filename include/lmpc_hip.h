@@ -55,6 +55,15 @@ typedef struct lmpc_settings {
     double rho_soft;     /* 1e-6  */
     int32_t cycle_tol;   /* 10    */
     int32_t iter_limit;  /* 10000 */
+    /* ABI version 2: DAQP's proximal-point settings.  eps_prox > 0 AT SETUP selects the proximal-point mode, the one
+     * that accepts a merely positive SEMIdefinite (symmetric) H -- without it such an H is answered with -5, as by
+     * DAQP.setup (/root/reference/src/setup.jl:18-19):  x_{k+1} = argmin 1/2 x'Hx + f(theta)'x + eps_prox/2 |x - x_k|^2
+     * over the constraint set, x_0 = 0, until |x_{k+1} - x_k|_inf < eta_prox; every subproblem is solved by the
+     * library's L D U kernel on the Hessian H + eps_prox I, warm from the previous one's working set; iteration counts
+     * add up against iter_limit.  The limit is a KKT point of the ORIGINAL problem (not unique if H is singular).
+     * Changing eps_prox on a live handle (lmpc_set_settings) is refused: the factorisation depends on it. */
+    double eps_prox;     /* 0     */
+    double eta_prox;     /* 1e-6  */
 } lmpc_settings;
 
 /* status codes of the API itself (solver outcomes are the per-problem exit flags) */
@@ -121,6 +130,11 @@ int lmpc_setup_ex(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
                   int is_avi, int device);
 int lmpc_is_avi(const lmpc_handle *h);
 int lmpc_get_avi(const lmpc_handle *h, double *MR, double *G);
+/* The extra arrays of a handle in proximal-point mode (lmpc_settings.eps_prox > 0 at setup; its subproblems' pack is
+ * what lmpc_get_ldp / lmpc_get_avi return, for H + eps_prox I): Hinv[n*n] = (H + eps_prox I)^-1, x0f[n] and
+ * Xthf[n*nth] = the full-length affine map of the unconstrained optimum, Kth[nout*nth] = the outputs' feedback term.
+ * LMPC_ERR_BADARG on any other handle. */
+int lmpc_get_prox(const lmpc_handle *h, double *Hinv, double *x0f, double *Xthf, double *Kth);
 
 /*
  * Setup from an already-transformed least-distance problem -- the data the reference's code

@@ -9,16 +9,17 @@ const liblmpc = get(ENV, "LMPC_HIP_LIB", "liblmpc_hip.so")
 struct LmpcSettings            # == lmpc_settings (include/lmpc_hip.h)
     primal_tol::Cdouble; dual_tol::Cdouble; zero_tol::Cdouble; progress_tol::Cdouble
     fval_bound::Cdouble; rho_soft::Cdouble; cycle_tol::Cint; iter_limit::Cint
+    eps_prox::Cdouble; eta_prox::Cdouble
 end
 # The solver settings the user has put on mpc.opt_model with DAQP.settings(mpc.opt_model, Dict(...))
 # (/root/reference/docs/src/manual/solver.md:19-22) are read back from the DAQP model, not assumed: DAQP.settings(model)
 # returns the C struct DAQPSettings with these field names.  rho_soft is what setup! itself wrote there,
-# 1 / mpc.settings.soft_weight (/root/reference/src/setup.jl:26).  (eps_prox / eta_prox / pivot_tol and the B&B
-# tolerances have no counterpart in the batched backend: proximal iterations for a semidefinite H are refused at setup.)
+# 1 / mpc.settings.soft_weight (/root/reference/src/setup.jl:26).  eps_prox / eta_prox select the backend's
+# proximal-point mode (a semidefinite H); pivot_tol and the B&B tolerances have no counterpart.
 function LmpcSettings(mpc::LinearMPC.MPC)
     d = DAQP.settings(mpc.opt_model)
     return LmpcSettings(d.primal_tol, d.dual_tol, d.zero_tol, d.progress_tol, d.fval_bound, d.rho_soft,
-                        d.cycle_tol, d.iter_limit)
+                        d.cycle_tol, d.iter_limit, d.eps_prox, d.eta_prox)
 end
 
 mutable struct BatchedModel    # stands next to mpc.opt_model
@@ -84,7 +85,8 @@ function _model_for(mpc::LinearMPC.MPC)
     mpc.mpqp_issetup || LinearMPC.setup!(mpc)
     mpc.mpqp_issetup || throw("Could not setup optimization problem")      # as utils.jl:270
     bm = get(_models, mpc, nothing)
-    if bm === nothing || bm.mpqp !== mpc.mpQP
+    if bm === nothing || bm.mpqp !== mpc.mpQP || LmpcSettings(mpc).eps_prox != bm.settings.eps_prox
+        # (eps_prox is part of the factorisation: a handle set up with another value is as stale as one of another mpQP)
         bm === nothing || free!(bm)                     # the stale handle goes now, not at some later GC
         K = mpc.K; mpc.K = zero(K)                      # nout = n handle without the feedback folded in
         try bm = setup_batched(mpc; nout=size(mpc.mpQP.H,1)) finally mpc.K = K end

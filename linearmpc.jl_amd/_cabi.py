@@ -32,7 +32,7 @@ SYMBOLS = (
     "lmpc_solve_batch_multi", "lmpc_solve_batch_multi_device", "lmpc_multi_last_error", "lmpc_free_multi",
     "lmpc_pin_host", "lmpc_unpin_host", "lmpc_release_scratch", "lmpc_check",
     "lmpc_distinct_active_sets_device", "lmpc_distinct_active_sets_overflowed", "lmpc_wave_stats",
-    "lmpc_setup_ex", "lmpc_is_avi", "lmpc_get_avi", "lmpc_transform_avi", "lmpc_multi_set_option", "lmpc_discover_regions_device", "lmpc_reserve",
+    "lmpc_setup_ex", "lmpc_is_avi", "lmpc_get_avi", "lmpc_transform_avi", "lmpc_multi_set_option", "lmpc_discover_regions_device", "lmpc_reserve", "lmpc_get_prox",
 )
 
 
@@ -47,7 +47,8 @@ class Settings(ctypes.Structure):
     _fields_ = [("primal_tol", ctypes.c_double), ("dual_tol", ctypes.c_double),
                 ("zero_tol", ctypes.c_double), ("progress_tol", ctypes.c_double),
                 ("fval_bound", ctypes.c_double), ("rho_soft", ctypes.c_double),
-                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32)]
+                ("cycle_tol", ctypes.c_int32), ("iter_limit", ctypes.c_int32),
+                ("eps_prox", ctypes.c_double), ("eta_prox", ctypes.c_double)]
 
 
 class Block(ctypes.Structure):

@@ -648,18 +648,20 @@ int ensure_sim(lmpc_handle *h, int64_t N) {
 
 extern "C" {
 
-int lmpc_abi_version(void) { return 1; }
+int lmpc_abi_version(void) { return 2; }     // 2: lmpc_settings grew eps_prox / eta_prox
 
 void lmpc_default_settings(lmpc_settings *s) {
     if (!s) return;
     s->primal_tol = 1e-6; s->dual_tol = 1e-12; s->zero_tol = 1e-11; s->progress_tol = 1e-6;
     s->fval_bound = 1e30; s->rho_soft = 1e-6; s->cycle_tol = 10; s->iter_limit = 10000;
+    s->eps_prox = 0.0; s->eta_prox = 1e-6;
 }
 
 void lmpc_default_settings_f32(lmpc_settings *s) {
     if (!s) return;
     s->primal_tol = 1e-4; s->dual_tol = 1e-6; s->zero_tol = 1e-6; s->progress_tol = 1e-4;
     s->fval_bound = 1e30; s->rho_soft = 1e-3; s->cycle_tol = 10; s->iter_limit = 10000;
+    s->eps_prox = 0.0; s->eta_prox = 1e-6;
 }
 
 static int setup_common(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
@@ -685,7 +687,13 @@ static int setup_common(lmpc_handle **out, int n, int m, int ms, int nth, int no
     if (s) h->S = *s; else lmpc_default_settings(&h->S);
     h->device = device;
     int rc;
-    if (is_avi) {
+    if (h->S.eps_prox > 0.0) {
+        // DAQP's proximal-point iterations (a merely semidefinite H): the subproblems run on the L D U kernel
+        if (is_avi) rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_setup: eps_prox > 0 together with a non-symmetric H (is_avi) is not supported");
+        else rc = qp_to_prox(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->S.eps_prox, h->err);
+        if (rc == LMPC_OK) rc = finalize_avi(h);
+        if (rc == LMPC_OK) fill_layout(h);
+    } else if (is_avi) {
         rc = qp_to_avi(h->P, n, m, ms, nth, nout, H, f, f_theta, A, bu, bl, W, sense, Kfb, nx, h->err);
         if (rc == LMPC_OK) rc = finalize_avi(h);
         if (rc == LMPC_OK) fill_layout(h);
@@ -767,6 +775,15 @@ int lmpc_transform(int n, int m, int ms, int nth, int nout, const double *H, con
     return LMPC_OK;
 }
 
+int lmpc_get_prox(const lmpc_handle *h, double *Hinv, double *x0f, double *Xthf, double *Kth) {
+    if (!h || !h->P.prox) return LMPC_ERR_BADARG;
+    auto cp = [](double *dst, const std::vector<double> &src) {
+        if (dst && !src.empty()) std::memcpy(dst, src.data(), sizeof(double) * src.size());
+    };
+    cp(Hinv, h->P.Hinv); cp(x0f, h->P.x0f); cp(Xthf, h->P.Xthf); cp(Kth, h->P.Kth);
+    return LMPC_OK;
+}
+
 int lmpc_transform_avi(int n, int m, int ms, int nth, int nout, const double *H, const double *f,
                        const double *f_theta, const double *A, const double *bu, const double *bl,
                        const double *W, const int32_t *sense, const double *Kfb, int nx, double *ML, double *MR,
@@ -806,6 +823,8 @@ int lmpc_active_words(const lmpc_handle *h) { return h ? h->P.words() : LMPC_ERR
 
 int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s) {
     if (!h || !s) return LMPC_ERR_BADARG;
+    if (s->eps_prox != h->S.eps_prox)
+        return fail(h, LMPC_ERR_BADARG, "lmpc_set_settings: eps_prox is fixed at setup (the factorisation depends on it): set up again");
     h->S = *s;
     fill_layout(h);
     return LMPC_OK;

@@ -18,6 +18,8 @@ void avi_fill_settings(lmpc_handle *h) {
     AviLayout &A = h->A;
     A.primal_tol = h->S.primal_tol; A.dual_tol = h->S.dual_tol; A.zero_tol = h->S.zero_tol; A.rho_soft = h->S.rho_soft;
     A.iter_limit = h->S.iter_limit;
+    A.eps_prox = h->P.prox ? h->P.eps_prox : 0.0;      // (fixed at setup: the pack was factorised with it)
+    A.eta_prox = h->S.eta_prox > 0.0 ? h->S.eta_prox : 1e-6;
 }
 
 int finalize_avi(lmpc_handle *h) {
@@ -33,7 +35,7 @@ int finalize_avi(lmpc_handle *h) {
     h->avi = true;
     h->useWave = true;                 // keeps every lane / screening shortcut of the QP kernels off this handle
     h->capFull = cap;
-    h->kname = "avi";
+    h->kname = P.prox ? "avi+prox" : "avi";
     LMPC_ENTER_DEVICE(h);
     {
         hipDeviceProp_t prop;
@@ -52,6 +54,13 @@ int finalize_avi(lmpc_handle *h) {
     A.oRout = o; o += P.nout * P.n;
     A.ox0 = o; o += P.nout;
     A.oXth = o; o += P.nout * P.nth;
+    A.oHinv = A.ox0f = A.oXthf = A.oKth = 0;
+    if (P.prox) {
+        A.oHinv = o; o += P.n * P.n;
+        A.ox0f = o; o += P.n;
+        A.oXthf = o; o += P.n * P.nth;
+        A.oKth = o; o += P.nout * P.nth;
+    }
     A.nC = o;
     avi_fill_settings(h);
     std::vector<double> buf((size_t)o, 0.0);
@@ -64,6 +73,12 @@ int finalize_avi(lmpc_handle *h) {
     std::memcpy(&buf[A.oRout], P.Rout.data(), sizeof(double) * P.Rout.size());
     std::memcpy(&buf[A.ox0], P.x0.data(), sizeof(double) * P.x0.size());
     if (P.nout * P.nth) std::memcpy(&buf[A.oXth], P.Xth.data(), sizeof(double) * P.Xth.size());
+    if (P.prox) {
+        std::memcpy(&buf[A.oHinv], P.Hinv.data(), sizeof(double) * P.Hinv.size());
+        std::memcpy(&buf[A.ox0f], P.x0f.data(), sizeof(double) * P.x0f.size());
+        if (P.n * P.nth) std::memcpy(&buf[A.oXthf], P.Xthf.data(), sizeof(double) * P.Xthf.size());
+        if (P.nout * P.nth) std::memcpy(&buf[A.oKth], P.Kth.data(), sizeof(double) * P.Kth.size());
+    }
     HIP_TRY(h, hipMalloc(&h->dCa, sizeof(double) * buf.size()));
     HIP_TRY(h, hipMemcpy(h->dCa, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc(&h->dSa, sizeof(int32_t) * P.m));
@@ -92,15 +107,19 @@ int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, in
         h->aviSlabs = (int)grid;
     }
     const size_t packBytes = sizeof(double) * (size_t)A.nC;
+#define LMPC_AVI_GO(PK, PX, LDSB)                                                                                          \
+    do {                                                                                                                  \
+        if ((LDSB) > 48 * 1024)                                                                                           \
+            HIP_TRY(h, hipFuncSetAttribute((const void *)avi_kernel<PK, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
+        hipLaunchKernelGGL((avi_kernel<PK, PX>), dim3((unsigned)grid), dim3(64), (LDSB), st, A, h->dCa, h->dSa, theta, x, flag, \
+                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);                                     \
+    } while (0)
     if (packBytes <= kAviLdsPack) {
-        if (packBytes > 48 * 1024)
-            HIP_TRY(h, hipFuncSetAttribute((const void *)avi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)packBytes));
-        hipLaunchKernelGGL(avi_kernel<true>, dim3((unsigned)grid), dim3(64), packBytes, st, A, h->dCa, h->dSa, theta, x, flag,
-                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);
+        if (h->P.prox) LMPC_AVI_GO(true, true, packBytes); else LMPC_AVI_GO(true, false, packBytes);
     } else {
-        hipLaunchKernelGGL(avi_kernel<false>, dim3((unsigned)grid), dim3(64), 0, st, A, h->dCa, h->dSa, theta, x, flag,
-                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);
+        if (h->P.prox) LMPC_AVI_GO(false, true, (size_t)0); else LMPC_AVI_GO(false, false, (size_t)0);
     }
+#undef LMPC_AVI_GO
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }

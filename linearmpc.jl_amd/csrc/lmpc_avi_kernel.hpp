@@ -35,11 +35,17 @@ namespace lmpc {
 
 __host__ __device__ constexpr long long avi_tri(long long i) { return i * (i + 1) / 2; }
 __host__ __device__ inline long long avi_scratch_reals(int n, int m, int cap) {
-    return 2 * avi_tri(cap + 1) + 8ll * (cap + 1) + 2ll * n + 2ll * m;
+    return 2 * avi_tri(cap + 1) + 8ll * (cap + 1) + 4ll * n + 2ll * m;      // (2 n of them: the proximal iterates)
 }
 __host__ __device__ inline long long avi_scratch_ints(int m, int cap) { return (cap + 1) + (long long)m; }
 
-template <bool LDSC>
+// PROX: proximal-point iterations around the solve (DAQP's eps_prox; a symmetric positive SEMIdefinite H, which the
+// reference's setup! otherwise answers with "-5 nonconvex", /root/reference/src/setup.jl:18-19): subproblem k has the
+// Hessian H + eps I (that is the pack) and the linear term moved by -eps x_k, i.e. bounds d0 - eps MR x_k and the
+// unconstrained optimum x_unc0 + eps (H + eps I)^-1 x_k; it starts from the previous subproblem's final working set;
+// the loop ends when |x_{k+1} - x_k|_inf < eta_prox.  The CPU checker's oracle_avi_prox_solve_batch statement for
+// statement.
+template <bool LDSC, bool PROX = false>
 __global__ __launch_bounds__(64) void avi_kernel(
     const AviLayout P, const double *__restrict__ C, const int32_t *__restrict__ S, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
@@ -72,7 +78,9 @@ __global__ __launch_bounds__(64) void avi_kernel(
     const long long oUc = o; o += n;
     const long long oUt = o; o += n;
     const long long oDup = o; o += m;
-    const long long oDlo = o;
+    const long long oDlo = o; o += m;
+    const long long oXk = o; o += n;
+    const long long oXn = o;
 #define RS(off, i) sr[((off) + (i)) * 64]
 #define WSI(i) si[(long long)(i) * 64]
 #define SEN(j) si[((long long)(cap + 1) + (j)) * 64]
@@ -82,17 +90,12 @@ __global__ __launch_bounds__(64) void avi_kernel(
         const long long pid = base + lane;
         if (pid >= nprob) continue;               // (no barrier below: lanes of the last tile may leave)
         const double *th = theta + pid * nth;
-        for (int j = 0; j < m; j++) {             // bounds of this parameter point   (mpc_update_qp.c:1-10)
-            double sh = 0.0;
-            for (int t = 0; t < nth; t++) sh = __builtin_fma(cst(P.oDth + j * nth + t), th[t], sh);
-            RS(oDup, j) = cst(P.odu + j) + sh;
-            RS(oDlo, j) = cst(P.odl + j) + sh;
-        }
         int na = 0, sing = -1, reuse = 0, nsoft_act = 0;
         int flag = EXIT_ITERLIMIT, iter = 1;
         double soft_slack = 0.0;
         bool done = false;
-        for (int k = 0; k < n; k++) RS(oUc, k) = 0.0;
+        int total = 0, outer = 0;                 // PROX: iterations of all subproblems so far, subproblems solved
+        if constexpr (PROX) { for (int k = 0; k < n; k++) RS(oXk, k) = 0.0; }
 
         auto ldu_add = [&](int j) {
             const long long rl = oL + avi_tri(na), ru = oU + avi_tri(na);
@@ -179,16 +182,36 @@ __global__ __launch_bounds__(64) void avi_kernel(
             if (r < reuse) reuse = r;
         };
 
-        // ---- initial working set: rows flagged ACTIVE and the caller's warm-start mask, in row order
-        for (int j = 0; j < m; j++) SEN(j) = S[j] & ~SENSE_LOWER;
-        const uint64_t *wp = warm ? warm + pid * P.words : nullptr;
+        for (;;) {                                // (one trip unless PROX: the proximal-point iterations)
+        for (int j = 0; j < m; j++) {             // bounds of this parameter point   (mpc_update_qp.c:1-10)
+            double sh = 0.0;
+            for (int t = 0; t < nth; t++) sh = __builtin_fma(cst(P.oDth + j * nth + t), th[t], sh);
+            double du_ = cst(P.odu + j) + sh, dl_ = cst(P.odl + j) + sh;
+            if constexpr (PROX) {
+                double acc = 0.0;
+                for (int c = 0; c < n; c++) acc = __builtin_fma(cst(P.oMR + j * n + c), RS(oXk, c), acc);
+                du_ = du_ - P.eps_prox * acc;
+                dl_ = dl_ - P.eps_prox * acc;
+            }
+            RS(oDup, j) = du_;
+            RS(oDlo, j) = dl_;
+        }
+        na = 0; sing = -1; reuse = 0; nsoft_act = 0; flag = EXIT_ITERLIMIT; iter = 1; soft_slack = 0.0; done = false;
+        for (int k = 0; k < n; k++) RS(oUc, k) = 0.0;
+        const int ilimit = PROX ? P.iter_limit - total : P.iter_limit;
+        // ---- initial working set: rows flagged ACTIVE, the caller's warm-start mask and (PROX, later subproblems) the
+        // previous subproblem's final working set, in row order
+        const uint64_t *wp = (warm && outer == 0) ? warm + pid * P.words : nullptr;
         for (int j = 0; j < m && !done; j++) {
             const int s0 = S[j];
+            const int prev = (PROX && outer > 0) ? SEN(j) : 0;
+            SEN(j) = s0 & ~SENSE_LOWER;
             bool want = (s0 & SENSE_ACTIVE) != 0, lower = want && (s0 & SENSE_LOWER);
             if (wp && !(s0 & SENSE_IMMUTABLE)) {
                 if ((wp[j >> 6] >> (j & 63)) & 1ull) want = true;
                 else if ((wp[(m + j) >> 6] >> ((m + j) & 63)) & 1ull) { want = true; lower = true; }
             }
+            if ((prev & SENSE_ACTIVE) && !(s0 & SENSE_IMMUTABLE)) { want = true; lower = (prev & SENSE_LOWER) != 0; }
             if (!want) { SEN(j) &= ~SENSE_ACTIVE; continue; }
             if (lower) SEN(j) |= SENSE_LOWER;
             if (na >= cap) { flag = EXIT_WSCAP; done = true; break; }
@@ -200,8 +223,10 @@ __global__ __launch_bounds__(64) void avi_kernel(
                 SEN(j) &= ~(SENSE_ACTIVE | SENSE_LOWER);
             }
         }
+        // (a start that ends early leaves the rows behind it with the flags of this lane's previous problem: nothing
+        // reads them -- the outputs go through the working set, and no further subproblem follows a failed one)
 
-        for (; !done && iter < P.iter_limit; iter++) {
+        for (; !done && iter < ilimit; iter++) {
             if (sing < 0) {
                 int nblock = 0, rm = -1, add = -1;
                 bool isupper = false;
@@ -324,24 +349,51 @@ __global__ __launch_bounds__(64) void avi_kernel(
             }
         }
 
+        if constexpr (!PROX) break;
+        else {
+            total += iter;
+            if (flag < 1) break;
+            double diff = 0.0;
+            for (int k = 0; k < n; k++) {
+                double a = cst(P.ox0f + k), b = 0.0;
+                for (int t = 0; t < nth; t++) a = __builtin_fma(cst(P.oXthf + k * nth + t), th[t], a);
+                for (int c = 0; c < n; c++) b = __builtin_fma(cst(P.oHinv + k * n + c), RS(oXk, c), b);
+                const double xv = (RS(oUc, k) + a) + P.eps_prox * b;
+                RS(oXn, k) = xv;
+                const double d = __builtin_fabs(xv - RS(oXk, k));
+                if (d > diff) diff = d;
+            }
+            for (int k = 0; k < n; k++) RS(oXk, k) = RS(oXn, k);
+            outer++;
+            if (diff < P.eta_prox) break;
+            if (total >= P.iter_limit) { flag = EXIT_ITERLIMIT; break; }
+        }
+        }   // proximal-point iterations
+
         // ---- x = Rout u + x0 + Xth theta   (mpc_update_qp.c:14-22), flags, working set
         for (int k = 0; k < P.nout; k++) {
-            double xs = 0.0, sh = cst(P.ox0 + k);
-            for (int c = 0; c < n; c++) xs = __builtin_fma(cst(P.oRout + k * n + c), RS(oUc, c), xs);
-            for (int t = 0; t < nth; t++) sh = __builtin_fma(cst(P.oXth + k * nth + t), th[t], sh);
-            X[pid * P.nout + k] = xs + sh;
+            if constexpr (PROX) {
+                double sh = 0.0;
+                for (int t = 0; t < nth; t++) sh = __builtin_fma(cst(P.oKth + k * nth + t), th[t], sh);
+                X[pid * P.nout + k] = RS(oXk, k) + sh;
+            } else {
+                double xs = 0.0, sh = cst(P.ox0 + k);
+                for (int c = 0; c < n; c++) xs = __builtin_fma(cst(P.oRout + k * n + c), RS(oUc, c), xs);
+                for (int t = 0; t < nth; t++) sh = __builtin_fma(cst(P.oXth + k * nth + t), th[t], sh);
+                X[pid * P.nout + k] = xs + sh;
+            }
         }
         if (active) {
             uint64_t *ap = active + pid * P.words;
             for (int w = 0; w < P.words; w++) ap[w] = 0ull;
-            for (int i = 0; i < na; i++) {
+            for (int i = 0; i < ((PROX && flag < 1) ? 0 : na); i++) {
                 const int j = WSI(i);
                 const int bit = (SEN(j) & SENSE_LOWER) ? m + j : j;
                 ap[bit >> 6] |= 1ull << (bit & 63);
             }
         }
         exitflag[pid] = flag;
-        if (iters) iters[pid] = iter;
+        if (iters) iters[pid] = PROX ? total : iter;
     }
 #undef RS
 #undef WSI

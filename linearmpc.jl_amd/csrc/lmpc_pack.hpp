@@ -33,6 +33,12 @@ struct HostPack {
     // MR row j = (H^-1 ML_j')', Gf = ML MR' in full (m x m, not symmetric); G (the packed triangle) stays empty
     bool avi = false;
     std::vector<double> MR, Gf;
+    // proximal-point mode (eps_prox > 0; a symmetric positive semidefinite H): the AVI pack of H + eps I plus
+    // Hinv = (H + eps I)^-1 (n x n), x0f / Xthf = the full-length affine map of the unconstrained optimum, Kth = the
+    // feedback term of the outputs (nout x nth)
+    bool prox = false;
+    double eps_prox = 0.0;
+    std::vector<double> Hinv, x0f, Xthf, Kth;
     int words() const { return (2 * m + 63) / 64; }
 };
 
@@ -50,6 +56,12 @@ int qp_to_avi(HostPack &P, int n, int m, int ms, int nth, int nout,
               const double *H, const double *f, const double *f_theta, const double *A,
               const double *bu, const double *bl, const double *W, const int32_t *sense,
               const double *Kfb, int nx, std::string &err);
+
+// Proximal-point mode: qp_to_avi on H + eps I (H symmetric) + the arrays of the outer iteration.
+int qp_to_prox(HostPack &P, int n, int m, int ms, int nth, int nout,
+               const double *H, const double *f, const double *f_theta, const double *A,
+               const double *bu, const double *bl, const double *W, const int32_t *sense,
+               const double *Kfb, int nx, double eps, std::string &err);
 
 // isapprox(H, H', rtol = 1e-9) as the reference decides mpQP.is_symmetric (mpc2mpqp.jl:897); H column-major n x n
 bool h_is_symmetric(const double *H, int n);

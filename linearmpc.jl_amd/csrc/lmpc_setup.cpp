@@ -190,6 +190,70 @@ int qp_to_avi(HostPack &P, int n, int m, int ms, int nth, int nout,
     return LMPC_OK;
 }
 
+int qp_to_prox(HostPack &P, int n, int m, int ms, int nth, int nout,
+               const double *H, const double *f, const double *f_theta, const double *A,
+               const double *bu, const double *bl, const double *W, const int32_t *sense,
+               const double *Kfb, int nx, double eps, std::string &err) {
+    if (n <= 0 || !H || !(eps > 0.0)) { err = "lmpc_setup: bad dimensions or eps_prox <= 0"; return LMPC_ERR_BADARG; }
+    if (!h_is_symmetric(H, n)) {
+        err = "lmpc_setup: proximal iterations (eps_prox > 0) need a symmetric H";
+        return LMPC_ERR_UNSUPPORTED;
+    }
+    std::vector<double> Ht((size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Ht[i + (size_t)n * j] = 0.5 * (H[i + (size_t)n * j] + H[j + (size_t)n * i]) + (i == j ? eps : 0.0);
+    // the subproblems' pack: the AVI transform of H + eps I, WITHOUT the feedback in its output map (the outer iteration
+    // works on x itself; the feedback is added to the outputs at the very end, Kth)
+    int rc = qp_to_avi(P, n, m, ms, nth, nout, Ht.data(), f, f_theta, A, bu, bl, W, sense, nullptr, 0, err);
+    if (rc != LMPC_OK) return rc;                       // (H + eps I not positive definite: H is indefinite -> -5)
+    P.prox = true; P.eps_prox = eps;
+    // Hinv again (qp_to_avi keeps it to itself), by the same elimination
+    std::vector<double> Aw((size_t)n * n);
+    P.Hinv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) Aw[(size_t)i * n + j] = Ht[i + (size_t)n * j];
+        P.Hinv[(size_t)i * n + i] = 1.0;
+    }
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        for (int r = c + 1; r < n; r++)
+            if (std::fabs(Aw[(size_t)r * n + c]) > std::fabs(Aw[(size_t)piv * n + c])) piv = r;
+        if (piv != c)
+            for (int k = 0; k < n; k++) {
+                std::swap(Aw[(size_t)piv * n + k], Aw[(size_t)c * n + k]);
+                std::swap(P.Hinv[(size_t)piv * n + k], P.Hinv[(size_t)c * n + k]);
+            }
+        const double d = 1.0 / Aw[(size_t)c * n + c];
+        for (int k = 0; k < n; k++) { Aw[(size_t)c * n + k] *= d; P.Hinv[(size_t)c * n + k] *= d; }
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            const double fct = Aw[(size_t)r * n + c];
+            if (fct == 0.0) continue;
+            for (int k = 0; k < n; k++) {
+                Aw[(size_t)r * n + k] -= fct * Aw[(size_t)c * n + k];
+                P.Hinv[(size_t)r * n + k] -= fct * P.Hinv[(size_t)c * n + k];
+            }
+        }
+    }
+    P.x0f.assign(n, 0.0);
+    P.Xthf.assign((size_t)n * nth, 0.0);
+    for (int k = 0; k < n; k++) {
+        double s = 0.0;
+        for (int c = 0; c < n; c++) s += P.Hinv[(size_t)k * n + c] * (f ? f[c] : 0.0);
+        P.x0f[k] = -s;
+        for (int t = 0; t < nth; t++) {
+            double q = 0.0;
+            for (int c = 0; c < n; c++) q += P.Hinv[(size_t)k * n + c] * (f_theta ? f_theta[c + (size_t)n * t] : 0.0);
+            P.Xthf[(size_t)k * nth + t] = -q;
+        }
+    }
+    P.Kth.assign((size_t)nout * nth, 0.0);
+    for (int k = 0; k < nout; k++)
+        for (int t = 0; t < nth && t < nx; t++)
+            if (Kfb) P.Kth[(size_t)k * nth + t] = -Kfb[k + (size_t)nout * t];
+    return LMPC_OK;
+}
+
 int qp_to_ldp(HostPack &P, int n, int m, int ms, int nth, int nout,
               const double *H, const double *f, const double *f_theta, const double *A,
               const double *bu, const double *bl, const double *W, const int32_t *sense,

@@ -84,6 +84,9 @@ struct AviLayout {
     int oML, oMR, oG, odu, odl, oDth, oRout, ox0, oXth, nC;
     double primal_tol, dual_tol, zero_tol, rho_soft;
     int iter_limit;
+    // proximal-point mode (eps_prox > 0): (H + eps I)^-1, the full-length affine map, the outputs' feedback term
+    int oHinv, ox0f, oXthf, oKth;
+    double eps_prox, eta_prox;
 };
 
 }  // namespace lmpc

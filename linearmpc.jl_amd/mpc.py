@@ -79,6 +79,7 @@ class MPC:
         self._opt_mpqp = None
         self._ctrl_mpqp = None
         self._pushed_settings = None
+        self.opt_model_eps_prox = 0.0
 
     # setup.jl:7-29
     def setup(self):
@@ -99,6 +100,7 @@ class MPC:
         self._ctrl_model = None
         self._opt_mpqp = q
         self._pushed_settings = self._settings_key()
+        self.opt_model_eps_prox = self.settings.eps_prox
         self.mpqp_issetup = True
         return self
 
@@ -116,6 +118,8 @@ class MPC:
         if not self.mpqp_issetup or self.opt_model is None or self._opt_mpqp is not self.mpQP:
             self.setup()
         key = self._settings_key()
+        if key != self._pushed_settings and self.settings.eps_prox != self.opt_model_eps_prox:
+            self.setup()                      # eps_prox is part of the factorisation: a new handle, like DAQP's own setup
         if key != self._pushed_settings:
             for model in (self.opt_model, self._ctrl_model):
                 if model is not None:
@@ -231,11 +235,12 @@ class MPC:
             if not hasattr(self.settings, k):
                 raise KeyError(f"unknown solver setting {k}")
             setattr(self.settings, k, type(getattr(self.settings, k))(v))
-        if changes:
+        if changes and "eps_prox" not in changes:
             for model in (self.opt_model, self._ctrl_model):
                 if model is not None:
                     model.set_settings(self.settings)
             self._pushed_settings = self._settings_key()
+        # (eps_prox: the next solve sets the handles up again, _model_for)
         return {k: getattr(self.settings, k) for k, _ in self.settings._fields_}
 
     # utils.jl:268-283

@@ -214,6 +214,16 @@ class BatchedQP:
         check(lib().lmpc_get_avi(self._h, _ptr(out["MR"]), _ptr(out["G"])), self._h)
         return out
 
+    def prox_pack(self):
+        """The extra arrays of a proximal-point handle (eps_prox > 0): (H + eps I)^-1, the full-length affine map of
+        the unconstrained optimum, the outputs' feedback term -- what tests hand to the oracle next to avi_pack()."""
+        out = dict(Hinv=np.empty((self.n, self.n)), x0f=np.empty(self.n), Xthf=np.empty((self.n, self.nth)),
+                   Kth=np.empty((self.nout, self.nth)))
+        lib().lmpc_get_prox.argtypes = [_vp] * 5
+        lib().lmpc_get_prox.restype = ctypes.c_int
+        check(lib().lmpc_get_prox(self._h, *[_ptr(out[k]) for k in ("Hinv", "x0f", "Xthf", "Kth")]), self._h)
+        return out
+
     def set_settings(self, settings: Settings):
         check(lib().lmpc_set_settings(self._h, ctypes.byref(settings)), self._h)
 

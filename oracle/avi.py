@@ -91,13 +91,16 @@ def qp2avi(H, f, f_theta, A, bu, bl, W, sense, nout, K=None) -> AVI:
 class _CAvi(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("m", ctypes.c_int32), ("ms", ctypes.c_int32), ("nth", ctypes.c_int32),
                 ("nout", ctypes.c_int32)] + [(k, ctypes.c_void_p) for k in
-                                              ("ML", "MR", "G", "du0", "dl0", "Dth", "Rout", "x0", "Xth", "sense")]
+                                              ("ML", "MR", "G", "du0", "dl0", "Dth", "Rout", "x0", "Xth", "sense",
+                                               "Hinv", "x0f", "Xthf", "Kth")]
 
 
-def _cavi(p: AVI):
+def _cavi(p: AVI, prox=None):
     p.contiguous()
+    extra = (None, None, None, None) if prox is None else tuple(np.ascontiguousarray(prox[k], dtype=np.float64).ctypes.data
+                                                                  for k in ("Hinv", "x0f", "Xthf", "Kth"))
     return _CAvi(p.n, p.m, p.ms, p.nth, p.nout, *(getattr(p, k).ctypes.data for k in
-                                                   ("ML", "MR", "G", "du0", "dl0", "Dth", "Rout", "x0", "Xth", "sense")))
+                                                   ("ML", "MR", "G", "du0", "dl0", "Dth", "Rout", "x0", "Xth", "sense")), *extra)
 
 
 def solve_batch(p: AVI, theta, settings: Settings | None = None, warm=None):
@@ -118,6 +121,45 @@ def solve_batch(p: AVI, theta, settings: Settings | None = None, warm=None):
     vp = ctypes.c_void_p
     L.oracle_avi_solve_batch(ctypes.byref(c), ctypes.byref(s), ctypes.c_int64(N), vp(theta.ctypes.data), wptr,
                              vp(X.ctypes.data), vp(ef.ctypes.data), vp(it.ctypes.data), vp(act.ctypes.data))
+    return X, ef, it, act
+
+
+def qp2prox(H, f, f_theta, A, bu, bl, W, sense, nout, eps, K=None):
+    """The pack of the proximal-point mode (eps_prox > 0, H symmetric positive SEMIdefinite): the AVI pack of the
+    regularised Hessian H + eps I plus what the outer iteration needs -- (H + eps I)^-1, the full-length affine map
+    of the unconstrained optimum, and the feedback term of the outputs.  Returns (AVI, dict of the extra arrays)."""
+    H = np.asarray(H, float)
+    n = H.shape[0]
+    if not np.allclose(H, H.T, rtol=1e-9, atol=0):
+        raise ValueError("proximal iterations need a symmetric H")
+    Ht = H + eps * np.eye(n)
+    f = np.asarray(f, float).reshape(n)
+    f_theta = np.asarray(f_theta, float).reshape(n, -1)
+    P = qp2avi(Ht, f, f_theta, A, bu, bl, W, sense, nout=nout, K=K)
+    Hinv = np.linalg.inv(Ht)
+    Kth = np.zeros((nout, f_theta.shape[1]))
+    if K is not None:
+        K = np.atleast_2d(np.asarray(K, float))
+        Kth[:K.shape[0], :K.shape[1]] -= K
+    return P, {"Hinv": Hinv, "x0f": -(Hinv @ f), "Xthf": -(Hinv @ f_theta), "Kth": Kth}
+
+
+def prox_solve_batch(p: AVI, prox, theta, eps, eta=1e-6, settings: Settings | None = None):
+    """oracle_avi_prox_solve_batch: X (N x nout), exitflag, summed iterations, active masks of the last subproblem."""
+    L = _ldp.lib()
+    theta = np.ascontiguousarray(np.asarray(theta, np.float64).reshape(-1, p.nth))
+    N = theta.shape[0]
+    nw = active_words(p.m)
+    X = np.empty((N, p.nout)); ef = np.empty(N, np.int32); it = np.empty(N, np.int32)
+    act = np.zeros((N, nw), np.uint64)
+    s = settings if settings is not None else default_settings()
+    keep = {k: np.ascontiguousarray(prox[k], dtype=np.float64) for k in ("Hinv", "x0f", "Xthf", "Kth")}
+    c = _cavi(p, keep)
+    vp = ctypes.c_void_p
+    L.oracle_avi_prox_solve_batch.restype = None
+    L.oracle_avi_prox_solve_batch(ctypes.byref(c), ctypes.byref(s), ctypes.c_double(eps), ctypes.c_double(eta),
+                                  ctypes.c_int64(N), vp(theta.ctypes.data), vp(X.ctypes.data), vp(ef.ctypes.data),
+                                  vp(it.ctypes.data), vp(act.ctypes.data))
     return X, ef, it, act
 
 

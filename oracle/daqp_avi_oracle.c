@@ -72,6 +72,11 @@ typedef struct {
     const double *G;     /* m x m row-major: G[i*m+j] = ML_i . MR_j                            */
     const double *du0, *dl0, *Dth, *Rout, *x0, *Xth;
     const int32_t *sense;
+    /* proximal-point mode only (oracle_avi_prox_solve_batch), NULL otherwise */
+    const double *Hinv;  /* n x n row-major: (H + eps I)^-1                                  */
+    const double *x0f;   /* n: -(H + eps I)^-1 f                                              */
+    const double *Xthf;  /* n x nth: -(H + eps I)^-1 f_theta                                  */
+    const double *Kth;   /* nout x nth: what the outputs get on top of x (the -K x feedback)  */
 } oracle_avi;
 
 /* same layout as daqp_ldp_oracle.c's oracle_settings_abi */
@@ -196,8 +201,8 @@ static void ldu_remove(awork *w, const avi_settings *s, int r) {
     if (r < w->reuse) w->reuse = r;
 }
 
-static int avi_solve(awork *w, const oracle_avi *p, const avi_settings *s, const double *theta,
-                     const uint64_t *warm, int32_t *iters) {
+static int avi_solve_shift(awork *w, const oracle_avi *p, const avi_settings *s, const double *theta,
+                           const uint64_t *warm, int32_t *iters, const double *xk, double eps) {
     const int n = p->n, m = p->m, nth = p->nth;
     int flag = EXIT_ITERLIMIT, iter = 1;
     for (int j = 0; j < m; j++) {                               /* mpc_update_qp.c:1-10 */
@@ -205,6 +210,12 @@ static int avi_solve(awork *w, const oracle_avi *p, const avi_settings *s, const
         for (int t = 0; t < nth; t++) sh = fma(p->Dth[(size_t)j * nth + t], theta[t], sh);
         w->dup[j] = p->du0[j] + sh;
         w->dlo[j] = p->dl0[j] + sh;
+        if (xk) {                                               /* proximal term: the linear term moved by -eps x_k */
+            double acc = 0.0;
+            for (int c = 0; c < n; c++) acc = fma(p->MR[(size_t)j * n + c], xk[c], acc);
+            w->dup[j] = w->dup[j] - eps * acc;
+            w->dlo[j] = w->dlo[j] - eps * acc;
+        }
     }
     w->na = 0; w->sing = -1; w->reuse = 0; w->nsoft_act = 0; w->soft_slack = 0.0;
     for (int k = 0; k < n; k++) w->u[k] = 0.0;
@@ -351,6 +362,11 @@ done:
     return flag;
 }
 
+static int avi_solve(awork *w, const oracle_avi *p, const avi_settings *s, const double *theta,
+                     const uint64_t *warm, int32_t *iters) {
+    return avi_solve_shift(w, p, s, theta, warm, iters, NULL, 0.0);
+}
+
 static void avi_outputs(const awork *w, const oracle_avi *p, const double *theta, double *xout, uint64_t *active, int nwords) {
     const int n = p->n, nth = p->nth;
     for (int k = 0; k < p->nout; k++) {                          /* mpc_update_qp.c:14-22 */
@@ -425,5 +441,67 @@ void oracle_avi_simulate(const oracle_avi *p, const avi_settings *s, int64_t N, 
         if (flag_min) flag_min[q] = fmin;
     }
     free(th); free(xn); free(uo); free(act);
+    awork_free(w);
+}
+
+/* Proximal-point iterations for a merely positive SEMIDEFINITE H -- DAQP's eps_prox setting (settings named at
+ * /root/reference/docs/src/manual/solver.md:46 "full documentation of all DAQP settings"; without it DAQP.setup answers
+ * -5, /root/reference/src/setup.jl:18-19).  libdaqp's own prox loop is not available to restate; this is the textbook
+ * method it is named after:  x_{k+1} = argmin 1/2 x'Hx + f'x + eps/2 |x - x_k|^2  over the constraint set, x_0 = 0,
+ * every subproblem strictly convex with Hessian H + eps I (its pack: p->ML/MR/G/du0/...), solved by avi_solve from the
+ * previous subproblem's final working set (mask start), until |x_{k+1} - x_k|_inf < eta_prox.  The iteration counts
+ * of the subproblems add up against iter_limit.  Any limit point satisfies the KKT conditions of the ORIGINAL problem
+ * (stationarity residual eps |x_{k+1} - x_k|), which is what the tests certify.
+ *   subproblem k:  linear term f(theta) - eps x_k  =>  x_unc = x_unc0 + eps (H + eps I)^-1 x_k,
+ *                  bounds d = d0 - eps MR x_k  (MR_j = s_j ((H + eps I)^-1 a_j')', symmetric Hessian)          */
+void oracle_avi_prox_solve_batch(const oracle_avi *p, const avi_settings *s, double eps, double eta, int64_t N,
+                                 const double *theta, double *x, int32_t *exitflag, int32_t *iters, uint64_t *active) {
+    int nsoft = 0;
+    for (int j = 0; j < p->m; j++) nsoft += (p->sense[j] & SENSE_SOFT) ? 1 : 0;
+    awork *w = awork_new(p->n, p->m, p->n + 1 + nsoft);
+    const int n = p->n, nth = p->nth, nwords = (2 * p->m + 63) / 64;
+    double *xk = (double *)calloc(n, sizeof(double)), *xn = (double *)calloc(n, sizeof(double));
+    uint64_t *act = (uint64_t *)calloc(nwords, sizeof(uint64_t));
+    for (int64_t q = 0; q < N; q++) {
+        const double *th = theta + q * nth;
+        int total = 0, flag = EXIT_ITERLIMIT, outer = 0;
+        for (int k = 0; k < n; k++) xk[k] = 0.0;
+        for (;;) {
+            int32_t it = 0;
+            avi_settings si = *s;
+            si.iter_limit = s->iter_limit - total;               /* what is left of the budget (the solve counts from 1) */
+            const int ef = avi_solve_shift(w, p, &si, th, outer > 0 ? act : NULL, &it, xk, eps);
+            total += it;
+            if (ef < 1) { flag = ef; break; }
+            for (int k2 = 0; k2 < nwords; k2++) act[k2] = 0;
+            for (int i = 0; i < w->na; i++) {
+                const int j = w->WS[i];
+                const int bit = (w->sense[j] & SENSE_LOWER) ? p->m + j : j;
+                act[bit >> 6] |= (uint64_t)1 << (bit & 63);
+            }
+            double diff = 0.0;
+            for (int k = 0; k < n; k++) {
+                double a = p->x0f[k], b = 0.0;
+                for (int t = 0; t < nth; t++) a = fma(p->Xthf[(size_t)k * nth + t], th[t], a);
+                for (int c = 0; c < n; c++) b = fma(p->Hinv[(size_t)k * n + c], xk[c], b);
+                xn[k] = (w->u[k] + a) + eps * b;
+                const double d = fabs(xn[k] - xk[k]);
+                if (d > diff) diff = d;
+            }
+            for (int k = 0; k < n; k++) xk[k] = xn[k];
+            outer++;
+            if (diff < eta) { flag = ef; break; }
+            if (total >= s->iter_limit) { flag = EXIT_ITERLIMIT; break; }
+        }
+        for (int k = 0; k < p->nout; k++) {
+            double sh = 0.0;
+            for (int t = 0; t < nth; t++) sh = fma(p->Kth[(size_t)k * nth + t], th[t], sh);
+            x[q * p->nout + k] = xk[k] + sh;
+        }
+        if (active) for (int k2 = 0; k2 < nwords; k2++) active[q * nwords + k2] = (flag >= 1) ? act[k2] : 0;
+        exitflag[q] = flag;
+        if (iters) iters[q] = total;
+    }
+    free(xk); free(xn); free(act);
     awork_free(w);
 }

@@ -2147,7 +2147,7 @@ def test_solve_mpc_theta_drop_in_and_user_settings(lmpc):
     u = mpc.compute_control([5.0, 5, 0, 0])
     assert abs(u[0] - 1.7612519326) < 1e-6
     with pytest.raises(KeyError):
-        mpc.solver_settings(eps_prox=1e-3)                        # proximal iterations: not in this backend
+        mpc.solver_settings(pivot_tol=1e-3)                       # a DAQP setting without a counterpart here
 
 
 def test_glue_cache_follows_the_mpqp_object_and_the_model_settings(lmpc):
@@ -2398,6 +2398,51 @@ def test_generated_controller_call_on_a_variational_handle(lmpc):
     out = lmpc.explicit.discover_regions_device(mpc.control_model(), None, None, 0, theta=torch.from_numpy(theta).to("cuda:0"))
     _, _, _, act = mpc.control_model().solve(theta)
     assert len(out["masks"]) == len(np.unique(act, axis=0)) and out["n_solved"] == N
+
+
+def test_proximal_point_mode_for_a_semidefinite_hessian(lmpc):
+    """eps_prox > 0 (DAQP's proximal-point setting; a semidefinite H is -5 without it): the kernel's outer iteration
+    against the oracle's on the same pack -- x, exit flags, summed iteration counts, final active sets bit for bit --
+    on rank-deficient problems with bounded variables and general rows; eps_prox reaches the handle through the settings
+    struct, changing it on the MPC rebuilds the handle, changing it on a live handle is refused."""
+    from oracle import avi as oavi
+    rng = np.random.default_rng(17)
+    for trial in range(8):
+        n = int(rng.integers(3, 10)); r = int(rng.integers(1, n)); mg = int(rng.integers(0, 9)); nth = int(rng.integers(1, 5))
+        B = rng.normal(size=(n, r)); H = B @ B.T
+        f, fth = rng.normal(size=n), rng.normal(size=(n, nth))
+        A = rng.normal(size=(mg, n)); m = n + mg
+        bu, bl = rng.uniform(0.5, 2, m), -rng.uniform(0.5, 2, m)
+        W = rng.normal(size=(m, nth)) * 0.2; W[:n] = 0
+        sense = np.zeros(m, np.int32)
+        s = lmpc.default_settings(); s.eps_prox = 1e-4; s.eta_prox = 1e-9
+        nout = min(n, 3)
+        qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense, nout=nout, settings=s)
+        assert qp.kernel_name == "avi+prox"
+        th = rng.normal(size=(1500, nth))
+        x, ef, it, act = qp.solve(th)
+        pk = qp.avi_pack()
+        P = oavi.AVI(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["ML"], pk["MR"], pk["G"], pk["du"], pk["dl"],
+                     pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"])).contiguous()
+        _, px = oavi.qp2prox(H, f, fth, A, bu, bl, W, sense, nout=nout, eps=1e-4)
+        px = {k: (pk[k] if k in pk else v) for k, v in px.items()}
+        xo, efo, ito, acto = oavi.prox_solve_batch(P, qp.prox_pack(), th, 1e-4, 1e-9)
+        assert np.all(efo == 1)
+        assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto) and np.array_equal(x, xo), trial
+        bad = lmpc.default_settings(); bad.eps_prox = 1e-3
+        with pytest.raises(lmpc.LmpcError):
+            qp.set_settings(bad)
+        qp.close()
+    # through the MPC mirror: eps_prox set on the model's settings -> the next solve sets the handle up again
+    q = lmpc.MPQP(H, f, fth, A, bu, bl, W, sense)
+    mpc = lmpc.MPC(q, nx=1, nu=1, nr=nth - 1 if nth > 1 else 0)
+    mpc.nx, mpc.nr = 1, nth - 1
+    with pytest.raises(lmpc.LmpcError) as e:
+        mpc.solve(th[0])
+    assert e.value.code == -5
+    mpc.solver_settings(eps_prox=1e-4, eta_prox=1e-9)
+    xs, fval, flag, info = mpc.solve(th[0])
+    assert flag == 1 and mpc.opt_model.kernel_name == "avi+prox"
 
 
 def test_variational_problems_with_general_and_soft_rows(lmpc):

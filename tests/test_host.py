@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(lmpc):
     L = lmpc.lib()
     for s in declared:
         assert hasattr(L, s), s
-    assert L.lmpc_abi_version() == 1
+    assert L.lmpc_abi_version() == 2          # 2: lmpc_settings grew eps_prox / eta_prox (round 4)
 
 
 def test_public_header_is_self_contained_c(tmp_path):
@@ -48,6 +48,8 @@ def test_default_settings_match_reference_docs(lmpc):
         (1e-6, 1e-12, 1e-6, 10, 10000, 1e-6)
     so = oldp.default_settings()
     for name, _ in lmpc.Settings._fields_:
+        if name in ("eps_prox", "eta_prox"):          # (the oracle takes the proximal settings as arguments)
+            continue
         assert getattr(s, name) == getattr(so, name), name
 
 
@@ -255,6 +257,30 @@ def test_setup_keywords_of_the_reference(lmpc, has_gpu):
         with pytest.raises(lmpc.LmpcError) as e:                # lmpc_setup decides is_avi from H by itself
             lmpc.BatchedQP.from_mpqp(H, *args)
         assert e.value.code == -101
+
+
+def test_semidefinite_hessian_needs_eps_prox(lmpc, has_gpu):
+    """A merely positive semidefinite H: DAQP.setup answers -5 ("Nonconvex objective", /root/reference/src/setup.jl:18-19)
+    unless the eps_prox setting is positive; lmpc_setup the same -- with eps_prox > 0 the host-side checks pass and the
+    answer without a GPU is NOGPU.  The settings struct carries eps_prox / eta_prox behind DAQP's documented six
+    (ABI version 2); an indefinite H is refused either way."""
+    assert lmpc.lib().lmpc_abi_version() >= 2
+    s = lmpc.default_settings()
+    assert s.eps_prox == 0.0 and s.eta_prox == 1e-6
+    B = np.array([[1.0], [1.0], [0.5]])
+    H = B @ B.T                                                   # rank 1 of 3
+    args = (np.zeros(3), np.zeros((3, 1)), np.zeros((0, 3)), np.ones(3), -np.ones(3), np.zeros((3, 1)))
+    with pytest.raises(lmpc.LmpcError) as e:
+        lmpc.BatchedQP.from_mpqp(H, *args)
+    assert e.value.code == -5
+    s.eps_prox = 1e-4
+    if not has_gpu:
+        with pytest.raises(lmpc.LmpcError) as e:
+            lmpc.BatchedQP.from_mpqp(H, *args, settings=s)
+        assert e.value.code == -101
+    with pytest.raises(lmpc.LmpcError) as e:                      # indefinite: still non-convex
+        lmpc.BatchedQP.from_mpqp(H - 0.5 * np.eye(3), *args, settings=s)
+    assert e.value.code == -5
 
 
 def test_host_transform_of_a_variational_problem_matches_the_oracle(lmpc):

@@ -842,3 +842,53 @@ def test_avi_oracle_kkt_and_infeasibility_on_random_problems():
                 assert r.status == 2, (trial, i, r.status)
                 ninf += 1
     assert nsolved > 1000 and ninf > 20
+
+
+def test_proximal_point_iterations_reach_a_kkt_point_of_the_semidefinite_problem():
+    """DAQP's eps_prox mode (a symmetric positive SEMIdefinite H; without it setup! answers -5,
+    /root/reference/src/setup.jl:18-19) as the oracle states it: x_{k+1} = argmin 1/2 x'Hx + f'x + eps/2 |x - x_k|^2
+    over the rows, until |x_{k+1} - x_k| < eta.  Rank-deficient H, every variable bounded (so the QP is bounded),
+    general rows: the limit must satisfy the KKT conditions of the ORIGINAL problem -- stationarity with multipliers of
+    the right sign recovered by least squares on the final active set, primal feasibility -- which certifies optimality
+    of a convex QP without reference to any solver; on top, no feasible point near it has a smaller objective.
+    (A strictly convex problem with a vanishing regularisation is no usable reference: the Cholesky factor of
+    H + 1e-7 I is so ill-conditioned that the QP oracle's normalised-row tolerance lets its answers violate the rows
+    by 1e-2.)"""
+    from oracle import avi as oavi
+    rng = np.random.default_rng(3)
+    eps, eta = 1e-4, 1e-9
+    nsolved = 0
+    for trial in range(40):
+        n = int(rng.integers(3, 9)); r = int(rng.integers(1, n)); mg = int(rng.integers(0, 8)); nth = int(rng.integers(1, 4))
+        B = rng.normal(size=(n, r)); H = B @ B.T                      # rank r < n
+        f, fth = rng.normal(size=n), rng.normal(size=(n, nth))
+        A = rng.normal(size=(mg, n)); m = n + mg
+        bu, bl = rng.uniform(0.5, 2, m), -rng.uniform(0.5, 2, m)
+        W = rng.normal(size=(m, nth)) * 0.2; W[:n] = 0
+        sense = np.zeros(m, np.int32)
+        P, px = oavi.qp2prox(H, f, fth, A, bu, bl, W, sense, nout=n, eps=eps)
+        th = rng.normal(size=(16, nth))
+        X, ef, it, act = oavi.prox_solve_batch(P, px, th, eps, eta)
+        assert np.all(ef == 1) and it.max() < 2000
+        Aext = np.vstack([np.eye(n), A])
+        for i in range(16):
+            g = H @ X[i] + f + fth @ th[i]
+            up = np.array([(int(act[i][j >> 6]) >> (j & 63)) & 1 for j in range(m)], bool)
+            lo = np.array([(int(act[i][(m + j) >> 6]) >> ((m + j) & 63)) & 1 for j in range(m)], bool)
+            rows = np.nonzero(up | lo)[0]
+            if len(rows):
+                mu = np.linalg.lstsq(Aext[rows].T, -g, rcond=None)[0]
+                res = np.abs(g + Aext[rows].T @ mu).max()
+                assert np.max(np.where(up[rows], -mu, mu)) < 1e-7, (trial, i)
+            else:
+                res = np.abs(g).max()
+            ax = Aext @ X[i]
+            assert res < 1e-7 and np.maximum(ax - (bu + W @ th[i]), (bl + W @ th[i]) - ax).max() < 2e-6, (trial, i, res)
+            obj = lambda z: 0.5 * z @ H @ z + (f + fth @ th[i]) @ z
+            for _ in range(8):
+                z = X[i] + 0.05 * rng.normal(size=n)
+                az = Aext @ z
+                if np.maximum(az - (bu + W @ th[i]), (bl + W @ th[i]) - az).max() <= 0:
+                    assert obj(z) >= obj(X[i]) - 1e-9, (trial, i)
+            nsolved += 1
+    assert nsolved == 640
