@@ -1590,7 +1590,7 @@ int lmpc_wave_stats(lmpc_handle *h, unsigned long long out[5]) {
 
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
-    if (h->avi) return "avi";
+    if (h->avi) return h->kname.c_str();          // "avi" / "avi+prox"
     if (h->useWave) return "wave";
     // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm
     // starts, closed loop, generated-controller call) the two-kernel form
