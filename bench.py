@@ -407,6 +407,19 @@ def multi_abi_check(torch, lmpc, g, nout, n_per_dev, seed):
     reported as config.multi_abi.  With one visible device there is nothing to gather: says so."""
     nd = torch.cuda.device_count()
     out = {"n_devices": nd}
+    if nd < 2 and os.environ.get("LMPC_MULTI_TRANSPORT") == "rccl_self":
+        # one GPU: the RCCL calls of the gather with the device itself as the peer (csrc/lmpc_multi.hip, test hook)
+        try:
+            mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout, devices=[0])
+            qp1 = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+            td = torch.from_numpy(make_theta("pendulum", n_per_dev, seed)).to("cuda:0")
+            xs, fs, xr, fr = mq.solve_device([td], gather=True)
+            x1, f1 = qp1.solve_device(td)
+            torch.cuda.synchronize()
+            out["rccl_self_identical"] = bool(torch.equal(xr, x1) and torch.equal(fr, f1))
+        except Exception as e:
+            out["error"] = f"{type(e).__name__}: {e}"[:300]
+        return out
     if nd < 2:
         out["skipped"] = "one visible GPU: the nd > 1 branch (ncclCommInitAll, ncclSend/ncclRecv) cannot run here"
         return out
@@ -701,6 +714,17 @@ def multi_abi_isolated(torch, n_per_dev, timeout_s=180):
             mq.close(); qp1.close()
         except Exception as e:
             out["error"] = f"{type(e).__name__}: {e}"[:300]
+        # ... and the RCCL calls themselves (library load, ncclCommInitAll, a grouped send / receive pair of the gather's
+        # data types) with the device as its own peer, in a child process with a time limit
+        try:
+            env = dict(os.environ, LMPC_MULTI_TRANSPORT="rccl_self", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-abi-only", "100000"],
+                               capture_output=True, text=True, timeout=90, env=env)
+            last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            out["rccl_self_identical"] = bool(last and json.loads(last[-1]).get("rccl_self_identical"))
+        except Exception as e:
+            out["rccl_self_identical"] = False
+            out["rccl_self_error"] = f"{type(e).__name__}: {e}"[:200]
         return out
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-abi-only", str(int(n_per_dev))],
@@ -847,7 +871,7 @@ def compact_line(out):
     if isinstance(cfg.get("multi_abi"), dict):
         ma = cfg["multi_abi"]
         line["config"]["multi_abi"] = {k: _r(ma[k]) for k in ("n_devices", "identical", "oracle_sample_identical",
-                                                               "loopback_identical", "transport") if k in ma}
+                                                               "loopback_identical", "rccl_self_identical", "transport") if k in ma}
     line["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
                                                        "algorithmic_bytes_per_solve")}
     if isinstance(roof.get("pipelined"), dict):

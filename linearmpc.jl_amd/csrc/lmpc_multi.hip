@@ -362,6 +362,8 @@ struct lmpc_multi {
     std::vector<ncclComm_t> comm;      // created on the first gather
     std::vector<hipEvent_t> done;      // transport 1: "shard d is solved", recorded on stream d, awaited by stream 0
     int transport = 0;                 // 0: RCCL send / receive pairs; 1: event-ordered peer copies issued by device 0
+    bool rcclSelf = false;             // test hook (LMPC_MULTI_TRANSPORT=rccl_self, one device): the local copy of shard 0
+                                       // goes through RCCL too -- ncclCommInitAll, a send / receive pair to itself
     bool repeats = false;              // the device list names a device more than once (transport 1 only)
     std::string err;
 };
@@ -442,6 +444,7 @@ int lmpc_setup_multi(lmpc_multi **out, int n, int m, int ms, int nth, int nout, 
     // and host threads on ONE GPU: how the n_devices > 1 control flow is exercised on a one-GPU machine
     const char *tenv = std::getenv("LMPC_MULTI_TRANSPORT");
     if (tenv && std::strcmp(tenv, "copy") == 0) hm->transport = 1;
+    if (tenv && std::strcmp(tenv, "rccl_self") == 0) hm->rcclSelf = true;
     for (int d = 0; d < n_devices; d++) {
         const int dev = devices ? devices[d] : d;
         const bool seen = std::find(hm->dev.begin(), hm->dev.end(), dev) != hm->dev.end();
@@ -530,7 +533,7 @@ int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const do
             }
         }
     }
-    if (gather && nd > 1 && hm->transport == 0 && hm->comm.empty()) {
+    if (gather && ((nd > 1 && hm->transport == 0) || (nd == 1 && hm->rcclSelf)) && hm->comm.empty()) {
         if (!g_rccl.load(hm->err)) return LMPC_ERR_UNSUPPORTED;
         hm->comm.assign((size_t)nd, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(hm->comm.data(), nd, hm->dev.data());
@@ -557,12 +560,29 @@ int lmpc_solve_batch_multi_device(lmpc_multi *hm, const int64_t *N_dev, const do
         {
             DeviceScope sc;
             if (sc.enter(hm->dev[0]) != hipSuccess) return mfail(hm, LMPC_ERR_HIP, "lmpc: hipSetDevice");
+            if (nd == 1 && hm->rcclSelf && N_dev[0] > 0) {
+                // one device, test hook: shard 0 reaches its place in the gathered arrays through RCCL -- the same calls,
+                // data types and group structure the several-device branch below makes, with itself as the peer
+                ncclResult_t r = g_rccl.GroupStart();
+                if (x_root && x_root != x[0] && r == ncclSuccess) {
+                    r = g_rccl.Send(x[0], (size_t)N_dev[0] * nout, ncclFloat64, 0, hm->comm[0], hm->stream[0]);
+                    if (r == ncclSuccess) r = g_rccl.Recv(x_root, (size_t)N_dev[0] * nout, ncclFloat64, 0, hm->comm[0], hm->stream[0]);
+                }
+                if (exitflag_root && exitflag_root != exitflag[0] && r == ncclSuccess) {
+                    r = g_rccl.Send(exitflag[0], (size_t)N_dev[0], ncclInt32, 0, hm->comm[0], hm->stream[0]);
+                    if (r == ncclSuccess) r = g_rccl.Recv(exitflag_root, (size_t)N_dev[0], ncclInt32, 0, hm->comm[0], hm->stream[0]);
+                }
+                const ncclResult_t re = g_rccl.GroupEnd();
+                if (r == ncclSuccess) r = re;
+                if (r != ncclSuccess) rc = mfail(hm, LMPC_ERR_HIP, std::string("RCCL self gather: ") + g_rccl.GetErrorString(r));
+            } else {
             if (x_root && N_dev[0] > 0 && x_root != x[0] &&
                 hipMemcpyAsync(x_root, x[0], sizeof(double) * N_dev[0] * nout, hipMemcpyDeviceToDevice, hm->stream[0]) != hipSuccess)
                 rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: local copy of shard 0");
             if (exitflag_root && N_dev[0] > 0 && exitflag_root != exitflag[0] &&
                 hipMemcpyAsync(exitflag_root, exitflag[0], sizeof(int32_t) * N_dev[0], hipMemcpyDeviceToDevice, hm->stream[0]) != hipSuccess)
                 rc = mfail(hm, LMPC_ERR_HIP, "lmpc: gather: local copy of shard 0");
+            }
         }
         if (rc == LMPC_OK && nd > 1 && hm->transport == 1) {
             // peer copies: shard d's solve is marked by an event on its stream; device 0's stream waits for it and pulls

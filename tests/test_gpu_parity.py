@@ -13,6 +13,7 @@ from conftest import load_golden, oracle_ldp_from
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
+ROOT_DIR = __import__("os").path.abspath(__import__("os").path.join(__import__("os").path.dirname(__file__), ".."))
 
 
 @pytest.fixture(scope="module")
@@ -2112,6 +2113,38 @@ def test_multi_device_control_flow_on_one_gpu(lmpc, monkeypatch):
     xs, fs, xr, fr = mq.solve_device(shards, gather=False)
     assert xr is None and np.array_equal(fs[2].cpu().numpy(), ef1[off[2]:])
     mq.close()
+
+
+def test_rccl_calls_of_the_gather_on_one_gpu():
+    """The RCCL half of the multi-device gather has never met a machine with several GPUs.  What one GPU can check: the
+    library loads librccl, resolves every symbol it calls, ncclCommInitAll succeeds, and a grouped ncclSend / ncclRecv
+    pair with the data types and counts of the gather moves a shard correctly -- to itself (LMPC_MULTI_TRANSPORT=rccl_self:
+    shard 0's local copy goes through RCCL).  In a child process with a time limit: a first-ever call into a
+    communication library must not be able to take the test run with it."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        os.environ["LMPC_MULTI_TRANSPORT"] = "rccl_self"
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, torch
+        import linearmpc_jl_amd as lmpc
+        from conftest import load_golden
+        g = load_golden("pendulum")
+        mq = lmpc.MultiQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1, devices=[0])
+        qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
+        rng = np.random.default_rng(3)
+        N = 100003
+        th = np.hstack([rng.uniform(-6, 6, (N, 4)), rng.uniform(-5, 5, (N, 1)), np.zeros((N, 1)), rng.uniform(-2, 2, (N, 1))])
+        td = torch.from_numpy(th).to("cuda:0")
+        xs, fs, xr, fr = mq.solve_device([td], gather=True)
+        x1, f1 = qp.solve_device(td)
+        torch.cuda.synchronize()
+        assert torch.equal(xr, x1) and torch.equal(fr, f1) and torch.equal(xs[0], x1)
+        print("RCCL_SELF_OK")
+    """) % (ROOT_DIR, ROOT_DIR)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RCCL_SELF_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_solve_mpc_theta_drop_in_and_user_settings(lmpc):
