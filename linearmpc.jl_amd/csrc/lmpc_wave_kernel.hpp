@@ -210,7 +210,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,
-    int32_t *__restrict__ queue, int qchunk, long long nprob,
+    int32_t *__restrict__ queue, int qchunk_arg, long long nprob,
     const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *__restrict__ count_next,
     long long seg_cap, int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, const WaveSim sim,
     R *__restrict__ bnb_r, int32_t *__restrict__ bnb_i, int bnb_depth,
@@ -363,6 +363,16 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
         }
         seg_end = incl; seg_beg = incl - c;
         ntotal = (long long)__builtin_amdgcn_readlane(incl, 63);
+    }
+    // problems per ticket.  Work-list mode: the host cannot know the list's length, the kernel does -- about 64 tickets per
+    // resident wavefront over the whole list, at most 8 problems each (round 4: with ONE problem per ticket a list of
+    // 10^6 entries drew 10^6 atomics on one word, 11 ms at ~90 per microsecond -- the reference's mass_spring example ran
+    // 1.75x SLOWER behind the screening pass than without it; 16 tickets per wavefront, up to 32 problems each, cost the
+    // 3-input masses 5 % in the tail: its problems run 32 iterations)
+    int qchunk = qchunk_arg;
+    if (list != nullptr && queue != nullptr) {
+        const long long q = ntotal / (64 * gwaves);
+        qchunk = q < 1 ? 1 : (q > 8 ? 8 : (int)q);
     }
     long long chunk = (long long)blockIdx.x * nwv + wv;
     long long idx = chunk * qchunk;
