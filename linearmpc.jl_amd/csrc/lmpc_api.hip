@@ -287,6 +287,13 @@ int launch_screen(lmpc_handle *h, int64_t nprob, const double *theta, double *x,
 template <typename R>
 int launch_wave_t(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                   int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
+    if constexpr (sizeof(R) == 8) {
+        // plain batched solve (no plant step to fuse, no kept factorisation, no run-ahead): the instantiations built
+        // without the closed-loop machinery
+        if (!h->bnb && h->waveSim.FG == nullptr && !h->keepOn)
+            return h->waveGram ? launch_wave_inst<R, false, true, false>(h, dC, nprob, theta, x, flag, iters, active, warm, st)
+                               : launch_wave_inst<R, false, false, false>(h, dC, nprob, theta, x, flag, iters, active, warm, st);
+    }
     if (h->waveGram)
         return h->bnb ? launch_wave_inst<R, true, true>(h, dC, nprob, theta, x, flag, iters, active, warm, st)
                       : launch_wave_inst<R, false, true>(h, dC, nprob, theta, x, flag, iters, active, warm, st);

@@ -229,16 +229,20 @@ int wave_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)
-template <typename R, bool BNB, bool GRAM>
+template <typename R, bool BNB, bool GRAM, bool SIM = true>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st);
-#define LMPC_WAVE_EXTERN(R, B, G)                                                                                  \
-    extern template int launch_wave_inst<R, B, G>(lmpc_handle *, const R *, int64_t, const R *, R *, int32_t *, \
-                                                  int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+#define LMPC_WAVE_EXTERN4(R, B, G, S)                                                                              \
+    extern template int launch_wave_inst<R, B, G, S>(lmpc_handle *, const R *, int64_t, const R *, R *, int32_t *, \
+                                                     int32_t *, uint64_t *, const uint64_t *, hipStream_t);
+#define LMPC_WAVE_EXTERN(R, B, G) LMPC_WAVE_EXTERN4(R, B, G, true)
 LMPC_WAVE_EXTERN(double, false, false) LMPC_WAVE_EXTERN(double, true, false)
 LMPC_WAVE_EXTERN(float, false, false) LMPC_WAVE_EXTERN(float, true, false)
 LMPC_WAVE_EXTERN(double, false, true) LMPC_WAVE_EXTERN(double, true, true)
 LMPC_WAVE_EXTERN(float, false, true) LMPC_WAVE_EXTERN(float, true, true)
+// (binary64 without branch and bound also WITHOUT the closed-loop machinery: the plain batched solve, its own units)
+LMPC_WAVE_EXTERN4(double, false, false, false) LMPC_WAVE_EXTERN4(double, false, true, false)
 #undef LMPC_WAVE_EXTERN
+#undef LMPC_WAVE_EXTERN4
 
 }  // namespace lmpc

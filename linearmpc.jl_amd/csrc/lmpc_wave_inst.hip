@@ -4,7 +4,10 @@
 #include "lmpc_wave_launch.hpp"
 
 namespace lmpc {
-template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM != 0)>(lmpc_handle *, const LMPC_WV_REAL *, int64_t,
+#ifndef LMPC_WV_SIM
+#define LMPC_WV_SIM 1
+#endif
+template int launch_wave_inst<LMPC_WV_REAL, (LMPC_WV_BNB != 0), (LMPC_WV_GRAM != 0), (LMPC_WV_SIM != 0)>(lmpc_handle *, const LMPC_WV_REAL *, int64_t,
                                                                 const LMPC_WV_REAL *, LMPC_WV_REAL *, int32_t *,
                                                                 int32_t *, uint64_t *, const uint64_t *, hipStream_t);
 #ifdef LMPC_WV_HELPERS

@@ -219,15 +219,12 @@ inline int bnb_first_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     return t.nwv * t.blocksPerCU > full.nwv * full.blocksPerCU ? c1 : 0;
 }
 
-template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false>
+template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false, bool SIM = true>
 int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t nprob, const R *theta, R *x,
                     int32_t *flag, int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     const WaveLayout &Wl = h->W;                         // (work-list mode, screening pass in front: h->waveList, see launch())
-    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, true>;
-    if constexpr (!BNB && sizeof(R) == 8) {
-        // plain batched solve (no plant step to fuse, no kept factorisation): the instantiation without the closed loop
-        if (h->waveSim.FG == nullptr && !h->keepOn) kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, false>;
-    }
+    // (SIM false: the instantiation without the closed-loop machinery -- the caller chose it for a plain batched solve)
+    auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, SIM>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
     int blocksPerCU = cfg.blocksPerCU;
@@ -361,7 +358,7 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     return LMPC_OK;
 }
 
-template <typename R, bool BNB, bool GRAM>
+template <typename R, bool BNB, bool GRAM, bool SIM>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
@@ -400,8 +397,8 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
         if constexpr (BNB) {
             rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: branch and bound covers n <= 64");
         } else {
-#define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
-                                  : launch_wave_cfg<R, MRR, 0, false, false, 2, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
+#define LMPC_WVU(MRR) (cfg.packed ? launch_wave_cfg<R, MRR, 0, false, true, 2, GRAM, SIM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st) \
+                                  : launch_wave_cfg<R, MRR, 0, false, false, 2, GRAM, SIM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st))
             if (mr <= 2) rc = LMPC_WVU(2);
             else if (mr == 3) rc = LMPC_WVU(3);
             else if (mr == 4) rc = LMPC_WVU(4);
@@ -413,7 +410,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
         }
         return rc;
     }
-#define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK, 1, GRAM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
+#define LMPC_WV4(MRR, LV, PK) launch_wave_cfg<R, MRR, LV, BNB, PK, 1, GRAM, SIM>(h, cfg, dC, nprob, theta, x, flag, iters, active, warm, st)
 #define LMPC_WV3(MRR, LV) LMPC_WV4(MRR, LV, false)
 #define LMPC_WV(MRR) (cfg.packed ? (cfg.level >= 1 ? LMPC_WV4(MRR, 1, true) : LMPC_WV4(MRR, 0, true)) \
                                  : (cfg.level >= 3 ? LMPC_WV3(MRR, 3) : (cfg.level == 2 ? LMPC_WV3(MRR, 2) : (cfg.level == 1 ? LMPC_WV3(MRR, 1) : LMPC_WV3(MRR, 0)))))
