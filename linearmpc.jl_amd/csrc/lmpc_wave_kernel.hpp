@@ -190,6 +190,11 @@ template <> struct wv_lim<float> { static __device__ __forceinline__ float inf()
 #ifndef LMPC_WAVE_LB4G
 #define LMPC_WAVE_LB4G 768     // Gram-scan form at 4 / 5 slots: built for three wavefronts per SIMD (168 registers)
 #endif
+// resident wavefronts per SIMD the 1-2 slot binary64 instantiations (no branch and bound) are built for: 4 = what the
+// 1024-thread launch bound gives (128 VGPRs); 5 / 6 tell the compiler to stay within 96 / 80 registers (A/B builds)
+#ifndef LMPC_WAVE_WPE
+#define LMPC_WAVE_WPE 4
+#endif
 __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB, bool GRAM = false) {
     if (GRAM && !BNB && (MR == 4 || MR == 5)) return LMPC_WAVE_LB4G;
     return MR >= 7 ? 256 : (MR >= 5 || BNB) ? 512 : (MR == 4 ? LMPC_WAVE_LB4 : (MR == 3 ? LMPC_WAVE_LB3 : LMPC_WAVE_LB));
@@ -206,7 +211,7 @@ __host__ __device__ constexpr int wave_launch_bound(int MR, bool BNB, bool GRAM 
 // runs the instantiation without it (round 4: the hot loop of the plain solve carried that state through its spills).
 template <typename R, int MR, int LDSC, bool BNB, bool PACKED, int NU = 1, bool GRAM = false, bool SIM = true>
 __global__ __launch_bounds__(wave_launch_bound(MR, BNB, GRAM))
-__attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : 1))) void wave_kernel(
+__attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : ((!BNB && MR <= 2 && sizeof(R) == 8 && LMPC_WAVE_WPE > 4) ? LMPC_WAVE_WPE : 1)))) void wave_kernel(
     const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ S,
     const R *__restrict__ theta, R *__restrict__ X, int32_t *__restrict__ exitflag,
     int32_t *__restrict__ iters, uint64_t *__restrict__ active, const uint64_t *__restrict__ warm,

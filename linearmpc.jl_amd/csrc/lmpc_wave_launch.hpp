@@ -37,7 +37,7 @@ inline int wave_max_resident(int slots, bool bnb, size_t rs, int level, int nu, 
     // 3 and 4 slots, <= 256 up to 8 slots
     if (gram && !bnb) return slots <= 2 ? 16 : (slots <= 5 ? (LMPC_WAVE_LB4G >= 768 || slots == 3 ? 12 : 8) : (slots <= 8 ? 8 : 4));
     if (bnb) return slots <= 2 ? ((rs == 4 && slots == 1) ? 16 : 12) : (slots <= 4 ? 8 : 4);
-    if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? 16 : 12;
+    if (slots <= 2) return LMPC_WAVE_LB >= 1024 ? ((rs == 8 && LMPC_WAVE_WPE > 4) ? 4 * LMPC_WAVE_WPE : 16) : 12;
     if (slots == 3) return LMPC_WAVE_LB3 >= 768 ? 12 : 8;
     if (slots == 4) return LMPC_WAVE_LB4 >= 768 ? 12 : 8;
     if (slots <= 6) return 8;
