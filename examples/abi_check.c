@@ -43,6 +43,22 @@ int main(void) {
     /* the unconstrained optimum as an affine map of theta: x = x0 + Xth*theta = theta */
     CHECK(fabs(Xth[0] - 1.0) < 1e-15 && fabs(Xth[1] - 1.0) < 1e-15 && x0[0] == 0.0, "output map");
 
+    /* the two keywords of the reference's DAQP.setup call (src/setup.jl:11-13) are part of the ABI: host-side answers */
+    CHECK(lmpc_abi_version() >= 2 && s.eps_prox == 0.0 && s.eta_prox == 1e-6, "settings v2");
+    {
+        const double Hn[4] = {2.0, 0.0, 0.5, 2.0};            /* column-major [[2, .5], [0, 2]]: not symmetric */
+        const int32_t bp[2] = {1, 2};
+        lmpc_handle *hx = NULL;
+        CHECK(lmpc_setup_ex(&hx, n, m, ms, nth, nout, H, f, f_theta, NULL, bu, bl, W, sense, NULL, 0, &s, bp, 2, 0, 0)
+                  == LMPC_ERR_UNSUPPORTED && hx == NULL, "prioritised constraints are refused");
+        CHECK(lmpc_setup_ex(&hx, n, m, ms, nth, nout, Hn, f, f_theta, NULL, bu, bl, W, sense, NULL, 0, &s, NULL, 0, 0, 0)
+                  == LMPC_ERR_BADARG, "is_avi = 0 with a non-symmetric H");
+        double ML[4], MR[4], G[4];
+        CHECK(lmpc_transform_avi(n, m, ms, nth, nout, Hn, f, f_theta, NULL, bu, bl, W, sense, NULL, 0, ML, MR, G,
+                                 NULL, NULL, NULL, NULL, NULL, NULL) == LMPC_OK, "lmpc_transform_avi");
+        CHECK(fabs(G[0] - 1.0) < 1e-14 && fabs(G[3] - 1.0) < 1e-14 && fabs(G[1] - G[2]) > 1e-3, "Gram matrix of the AVI pack");
+    }
+
     lmpc_handle *h = NULL;
     rc = lmpc_setup(&h, n, m, ms, nth, nout, H, f, f_theta, NULL, bu, bl, W, sense, NULL, 0, &s, 0);
     if (rc == LMPC_ERR_NOGPU) {
