@@ -21,17 +21,18 @@ sends on its own link) -- is timed behind the timed region and reported as confi
 By default three batches are kept in flight on three HIP streams (each with its own solver
 handle): the streaming pass of one batch overlaps the latency-bound iterating pass of another.
 
-Rank 0 prints ONE JSON line:
+Rank 0 prints a COMPACT JSON line (< 4 KB; compact_line(); the driver keeps only a tail of stdout) -- once as soon as
+the headline is measured, and again, with the per-config summaries, as the LAST line of stdout; the full report
+(every histogram, verification block and note) goes to bench_full.json and to stderr:
   value / ms_per_step   whole-job throughput of the timed region (cold HBM, batches in flight)
   roofline              ONE call at a time on one stream, cold HBM: algorithmic bytes of a call /
-                        the HIP-event duration of that call (screening kernel + iterating kernel);
-                        .pipelined = the same bytes / ms_per_step of the timed region;
-                        .cache_resident = both figures with one theta buffer reused
+                        the HIP-event duration of that call; pipelined_frac = the same bytes / ms_per_step
   cpu_baseline          the C oracle on the host cores (kind "port": libdaqp is not available)
-  configs               the other single-GPU BASELINE.json configurations, measured in the same
-                        process: mass_spring_3in@1e6 (f64), hybrid (f32), pendulum_hard@1e6 --
-                        each with its own roofline (VALU flop based for the wavefront kernel)
-                        and cpu_baseline sample.
+  configs               the other single-GPU BASELINE.json configurations, measured in the same process, one summary
+                        each {value, unit, frac, bound, verified[, gram_value, gram_frac, gram_frac_executed], cpu_1core
+                        [, first_run_value]}: pendulum_hard, mass_spring (the reference's example), mass_spring_3in
+                        (config 3) and its feasible-dominated companion, game_avi (is_avi), hybrid_f32 (config 5),
+                        pendulum_N50..125 (the reference's benchmark class), two closed loops, region_discovery (config 4)
 """
 import argparse
 import json
