@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "lmpc_avi_kernel.hpp"
@@ -81,23 +82,101 @@ int finalize_avi(lmpc_handle *h) {
     }
     HIP_TRY(h, hipMalloc(&h->dCa, sizeof(double) * buf.size()));
     HIP_TRY(h, hipMemcpy(h->dCa, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
+    // small box-constrained problem: the register-resident kernels in front of the generic one
+    // (lmpc_avi_tiers_kernel.hpp: bounds only, rows of ML = s_j e_j', no row flags, no proximal-point iterations)
+    h->aviTiersN = 0;
+    if (!P.prox && P.m == P.n && P.ms == P.m && P.n >= 2 && P.n <= 8 && P.nth >= 1 && P.words() == 1) {
+        bool ok = true;
+        for (int j = 0; j < P.m && ok; j++) {
+            if (P.sense[j] != 0) ok = false;
+            for (int c = 0; c < P.n && ok; c++)
+                if (c != j && P.M[(size_t)j * P.n + c] != 0.0) ok = false;
+        }
+        if (ok) { h->aviTiersN = P.n; h->kname = "avi_tiers<" + std::to_string(P.n) + ">|avi"; }
+    }
     HIP_TRY(h, hipMalloc(&h->dSa, sizeof(int32_t) * P.m));
     HIP_TRY(h, hipMemcpy(h->dSa, P.sense.data(), sizeof(int32_t) * P.m, hipMemcpyHostToDevice));
     return LMPC_OK;
 }
 
+// one segment of a work list of the tiers chain: wavefront w of a pass queues into segment w % kShards and takes the
+// tiles w, w + #wavefronts, ... (#wavefronts a multiple of kShards) -- an even share of the tiles, rounded up
+static long long avi_seg_cap(long long nprob) {
+    const long long tiles = (nprob + 63) / 64;
+    return ((tiles + kShards - 1) / kShards) * 64 + 64;
+}
+
+static bool avi_use_tiers(const lmpc_handle *h, int64_t nprob, const uint64_t *warm) {
+    return h->aviTiers && h->aviTiersN > 0 && warm == nullptr && h->S.iter_limit > h->aviTiersN + 1 &&
+           nprob < (int64_t)0x7fffffff;
+}
+
+static int avi_ensure_lists(lmpc_handle *h, int64_t nprob, hipStream_t st) {
+    if (nprob <= h->aviListCap) return LMPC_OK;
+    if (h->dAviCnt) (void)hipStreamSynchronize(st);
+    hipFree(h->dAviList[0]); hipFree(h->dAviList[1]); hipFree(h->dAviCnt);
+    h->dAviList[0] = h->dAviList[1] = h->dAviCnt = nullptr; h->aviListCap = 0;
+    const size_t seg = (size_t)avi_seg_cap(nprob);
+    HIP_TRY(h, hipMalloc(&h->dAviList[0], sizeof(int32_t) * seg * kShards));
+    HIP_TRY(h, hipMalloc(&h->dAviList[1], sizeof(int32_t) * seg * kShards));
+    HIP_TRY(h, hipMalloc(&h->dAviCnt, sizeof(int32_t) * 2 * kShards * kCountStride));
+    HIP_TRY(h, hipMemsetAsync(h->dAviCnt, 0, sizeof(int32_t) * 2 * kShards * kCountStride, st));
+    h->aviListCap = nprob;
+    return LMPC_OK;
+}
+
+static int avi_generic(lmpc_handle *h, int64_t nprob, long long max_tiles, const double *theta, double *x, int32_t *flag,
+                       int32_t *iters, uint64_t *active, const uint64_t *warm, const int32_t *list, const int32_t *count,
+                       long long seg_cap, int32_t *count_clear, hipStream_t st);
+
 int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                uint64_t *active, const uint64_t *warm, hipStream_t st) {
-    const AviLayout &A = h->A;
     if (!x || !flag) return fail(h, LMPC_ERR_BADARG, "lmpc: the variational-inequality kernel needs x and exitflag arrays");
+    const long long tiles = (nprob + 63) / 64;
+    if (!avi_use_tiers(h, nprob, warm))
+        return avi_generic(h, nprob, tiles, theta, x, flag, iters, active, warm, nullptr, nullptr, 0, nullptr, st);
+    // chain: tiers over the whole batch -> all n tiers on its list -> the generic kernel on that one's list
+    const int rc0 = avi_ensure_lists(h, nprob, st);
+    if (rc0 != LMPC_OK) return rc0;
+    for (int s = 0; s < 2; s++)
+        if (h->aviTiersOcc[s] == 0) {
+            const int rco = launch_avi_tiers(h, s == 0, h->aviTiersFirst, 0, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                             nullptr, nullptr, nullptr, nullptr, 0, 0, &h->aviTiersOcc[s]);
+            if (rco != LMPC_OK) return rco;
+        }
+    const long long seg = avi_seg_cap(h->aviListCap);
+    int32_t *cnt0 = h->dAviCnt, *cnt1 = h->dAviCnt + (size_t)kShards * kCountStride;
+    // workgroups of four wavefronts, a multiple of 16 (wavefronts a multiple of kShards), one resident round at most
+    auto grid_for = [&](int occ) {
+        long long g = (long long)h->numCU * occ;
+        const long long need = (tiles + 3) / 4;
+        if (g > need) g = need;
+        g = ((g + 15) / 16) * 16;
+        return (unsigned)g;
+    };
+    int rc = launch_avi_tiers(h, true, h->aviTiersFirst, grid_for(h->aviTiersOcc[0]), st, theta, x, flag, iters, active, nullptr,
+                              nullptr, h->dAviList[0], cnt0, cnt1, seg, (long long)nprob, nullptr);
+    if (rc != LMPC_OK) return rc;
+    rc = launch_avi_tiers(h, false, 0, grid_for(h->aviTiersOcc[1]), st, theta, x, flag, iters, active, h->dAviList[0], cnt0,
+                          h->dAviList[1], cnt1, nullptr, seg, (long long)nprob, nullptr);
+    if (rc != LMPC_OK) return rc;
+    return avi_generic(h, nprob, std::min<long long>(tiles, (long long)h->numCU * 4), theta, x, flag, iters, active, nullptr,
+                       h->dAviList[1], cnt1, seg, cnt0, st);
+}
+
+// the generic kernel over the whole batch (list == nullptr) or over a work list of the tiers chain
+static int avi_generic(lmpc_handle *h, int64_t nprob, long long tiles, const double *theta, double *x, int32_t *flag,
+                       int32_t *iters, uint64_t *active, const uint64_t *warm, const int32_t *list, const int32_t *count,
+                       long long seg_cap, int32_t *count_clear, hipStream_t st) {
+    const AviLayout &A = h->A;
     // one wavefront per workgroup, 64 problems per wavefront and round; resident wavefronts bounded by the scratch a
     // slab takes (at most 1 GiB in all)
     const size_t slabR = (size_t)avi_scratch_reals(A.n, A.m, A.cap) * 64, slabI = (size_t)avi_scratch_ints(A.m, A.cap) * 64;
-    const long long tiles = (nprob + 63) / 64;
     long long grid = (long long)h->numCU * (h->aviWaves > 0 ? h->aviWaves : 16);
     const long long fit = (long long)(((size_t)1 << 30) / (sizeof(double) * slabR + sizeof(int32_t) * slabI));
     grid = std::min(grid, std::max(1ll, fit));
     grid = std::min(grid, tiles);
+    if (list) grid = std::max<long long>(kShards, (grid / kShards) * kShards);      // (fit >= kShards: slabs of small problems)
     if (grid > h->aviSlabs) {
         // (grows with the largest batch seen; stream-ordered work of earlier calls on this handle finishes first)
         if (h->dAviR || h->dAviI) { (void)hipStreamSynchronize(st); hipFree(h->dAviR); hipFree(h->dAviI); }
@@ -112,7 +191,7 @@ int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, in
         if ((LDSB) > 48 * 1024)                                                                                           \
             HIP_TRY(h, hipFuncSetAttribute((const void *)avi_kernel<PK, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
         hipLaunchKernelGGL((avi_kernel<PK, PX>), dim3((unsigned)grid), dim3(64), (LDSB), st, A, h->dCa, h->dSa, theta, x, flag, \
-                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob);                                     \
+                           iters, active, warm, h->dAviR, h->dAviI, (long long)nprob, list, count, seg_cap, count_clear);    \
     } while (0)
     if (packBytes <= kAviLdsPack) {
         if (h->P.prox) LMPC_AVI_GO(true, true, packBytes); else LMPC_AVI_GO(true, false, packBytes);
@@ -128,6 +207,10 @@ void avi_release(lmpc_handle *h, bool pack_too) {
     if (h->dAviR) { (void)hipFree(h->dAviR); h->dAviR = nullptr; }
     if (h->dAviI) { (void)hipFree(h->dAviI); h->dAviI = nullptr; }
     h->aviSlabs = 0;
+    if (h->dAviList[0]) { (void)hipFree(h->dAviList[0]); h->dAviList[0] = nullptr; }
+    if (h->dAviList[1]) { (void)hipFree(h->dAviList[1]); h->dAviList[1] = nullptr; }
+    if (h->dAviCnt) { (void)hipFree(h->dAviCnt); h->dAviCnt = nullptr; }
+    h->aviListCap = 0;
     if (pack_too) {
         if (h->dCa) { (void)hipFree(h->dCa); h->dCa = nullptr; }
         if (h->dSa) { (void)hipFree(h->dSa); h->dSa = nullptr; }

@@ -49,10 +49,25 @@ template <bool LDSC, bool PROX = false>
 __global__ __launch_bounds__(64) void avi_kernel(
     const AviLayout P, const double *__restrict__ C, const int32_t *__restrict__ S, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
-    const uint64_t *__restrict__ warm, double *__restrict__ scratch_r, int32_t *__restrict__ scratch_i, long long nprob) {
+    const uint64_t *__restrict__ warm, double *__restrict__ scratch_r, int32_t *__restrict__ scratch_i, long long nprob,
+    const int32_t *__restrict__ list = nullptr, const int32_t *__restrict__ count = nullptr, long long seg_cap = 0,
+    int32_t *__restrict__ count_clear = nullptr) {
     extern __shared__ double lds_pack[];
     const int n = P.n, m = P.m, nth = P.nth, cap = P.cap;
     const int lane = threadIdx.x;
+    // work-list mode (behind avi_tiers_kernel, lmpc_avi_tiers_kernel.hpp): the problems to solve are the entries of
+    // kShards segments of `list` (segment s: count[s * kCountStride] entries from list[s * seg_cap]); workgroup b walks
+    // segment b % kShards (the grid is a multiple of kShards).  The counters of the chain's FIRST list are cleared here
+    // for the next call (the kernel that read them has finished: stream order).
+    if (count_clear && blockIdx.x == 0 && lane < kShards) count_clear[lane * kCountStride] = 0;
+    long long first = (long long)blockIdx.x * 64, stride = (long long)gridDim.x * 64, cnt = nprob;
+    if (list) {
+        const int shard = (int)(blockIdx.x % kShards);
+        first = (long long)(blockIdx.x / kShards) * 64;
+        stride = (long long)(gridDim.x / kShards) * 64;
+        cnt = (long long)count[shard * kCountStride];
+        list += (long long)shard * seg_cap;
+    }
     if constexpr (LDSC) {
         for (int e = lane; e < P.nC; e += 64) lds_pack[e] = C[e];
         __syncthreads();
@@ -86,9 +101,9 @@ __global__ __launch_bounds__(64) void avi_kernel(
 #define SEN(j) si[((long long)(cap + 1) + (j)) * 64]
     const double primal_tol = P.primal_tol, dual_tol = P.dual_tol, zero_tol = P.zero_tol, rho_soft = P.rho_soft;
 
-    for (long long base = (long long)blockIdx.x * 64; base < nprob; base += (long long)gridDim.x * 64) {
-        const long long pid = base + lane;
-        if (pid >= nprob) continue;               // (no barrier below: lanes of the last tile may leave)
+    for (long long base = first; base < cnt; base += stride) {
+        if (base + lane >= cnt) continue;         // (no barrier below: lanes of the last tile may leave)
+        const long long pid = list ? (long long)list[base + lane] : base + lane;
         const double *th = theta + pid * nth;
         int na = 0, sing = -1, reuse = 0, nsoft_act = 0;
         int flag = EXIT_ITERLIMIT, iter = 1;

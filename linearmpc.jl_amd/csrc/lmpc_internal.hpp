@@ -132,6 +132,14 @@ struct lmpc_handle {
     int32_t *dAviI = nullptr;
     int aviSlabs = 0;           // wavefront slabs of scratch allocated
     int aviWaves = 0;           // tuning: wavefronts per CU of its grid ("avi_waves", 0 = 16)
+    // ... small box-constrained problems: register-resident straight-line kernels in front of it (lmpc_avi_tiers_kernel.hpp)
+    int aviTiersN = 0;          // n if the problem qualifies (2 .. 8), else 0
+    int aviTiers = 1;           // tuning: 0 = the generic kernel alone ("avi_tiers"; results identical either way)
+    int aviTiersFirst = 2;      // tuning: tiers of the pass over the whole batch, 1 .. 3 ("avi_tiers_first")
+    int aviTiersOcc[2] = {0, 0};   // workgroups per CU the two instantiations keep resident (0 = not asked yet)
+    int32_t *dAviList[2] = {nullptr, nullptr};   // the two work lists of the chain, kShards segments each
+    int32_t *dAviCnt = nullptr;                  // ... their counters (two sets of kShards, kCountStride apart)
+    int64_t aviListCap = 0;
     lmpc::WaveLayout W{};
     double *dCw = nullptr;
     float *dCwf = nullptr;      // binary32 copy of the wave kernel's pack, built on the first f32 solve
@@ -215,6 +223,9 @@ void avi_fill_settings(lmpc_handle *h);
 int launch_avi(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                uint64_t *active, const uint64_t *warm, hipStream_t st);
 void avi_release(lmpc_handle *h, bool pack_too);
+int launch_avi_tiers(lmpc_handle *h, bool first, int kfirst, unsigned grid, hipStream_t st, const double *theta, double *x,
+                     int32_t *flag, int32_t *iters, uint64_t *active, const int32_t *list_in, const int32_t *count_in,
+                     int32_t *list_out, int32_t *count_out, int32_t *count_clear, long long seg_cap, long long nprob, int *occ);
 
 // one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
 bool fast_covers(const lmpc_handle *h);

@@ -133,6 +133,7 @@ __device__ __forceinline__ int fast_tiers(const PackLayout &P, const double *sM,
         int ofs = 0;
         asm volatile("" : "+s"(ofs));
         const double *sMk = sM + ofs, *sduk = sdu + ofs, *sdlk = sdl + ofs;
+        (void)sduk; (void)sdlk;
         const int na = k + 1;
         double xl[KMAX];
 #pragma unroll

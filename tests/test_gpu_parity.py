@@ -2345,7 +2345,7 @@ def test_game_theoretic_mpc_golden_vectors_and_same_pack_parity(lmpc):
     from oracle import avi as oavi
     g = load_golden("game_kat")
     qp = _qp_from_golden(lmpc, g)
-    assert qp.is_avi and qp.kernel_name == "avi"
+    assert qp.is_avi and qp.kernel_name == "avi_tiers<6>|avi"
     x, ef, it, act = qp.solve(g["theta"])
     assert np.array_equal(ef, g["exitflag"]) and np.array_equal(act, g["active"])
     assert np.abs(x - g["X"]).max() <= TOL
@@ -2501,3 +2501,57 @@ def test_variational_problems_with_general_and_soft_rows(lmpc):
         ok = efo >= 1
         assert np.array_equal(x[ok], xo[ok]), trial
         qp.close()
+
+
+def test_register_resident_variational_kernels_against_generic_kernel_and_oracle(lmpc):
+    """Small box-constrained variational problems (n = 2 .. 8, bounds only: the shape of the reference's game-theoretic
+    MPC, test/runtests.jl:1337-1358) run a chain of register-resident kernels in front of the generic one
+    (avi_tiers -> avi_lane -> avi).  Every depth of the first pass (0 = the complete lane kernel over the whole batch),
+    the generic kernel alone and the oracle agree bit for bit on x, flags, iteration counts and active sets --
+    on samplings with few and with many active bounds (removals), ragged batch sizes, several calls in a row (the
+    work lists' counters are handed over between calls), and with an iteration limit the chain must hand down."""
+    import torch
+    from oracle import avi as oavi, ldp as oldp
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda", 0)
+    for trial in range(14):
+        n = 2 + trial % 7
+        nth = int(rng.integers(1, 8)); nout = int(rng.integers(1, n + 1))
+        B = rng.normal(size=(n, n)); K = rng.normal(size=(n, n)) * rng.uniform(0.2, 2)
+        H = B @ B.T + 0.3 * np.eye(n) + (K - K.T)
+        bu, bl = rng.uniform(0.1, 2, n), -rng.uniform(0.1, 2, n)
+        qp = lmpc.BatchedQP.from_mpqp(H, rng.normal(size=n), rng.normal(size=(n, nth)), np.zeros((0, n)), bu, bl,
+                                      rng.normal(size=(n, nth)) * 0.3, np.zeros(n, np.int32), nout=nout)
+        assert qp.is_avi and qp.kernel_name.startswith("avi_tiers<%d>" % n), qp.kernel_name
+        P = _avi_oracle_pack(qp)
+        for N, scale in ((5000, 1.0), (4097, 6.0), (63, 3.0), (1, 2.0)):
+            th = np.ascontiguousarray(rng.normal(size=(N, nth)) * scale)
+            xo, efo, ito, acto = oavi.solve_batch(P, th)
+            assert (efo >= 1).all()
+            t = torch.from_numpy(th).to(dev)
+            for first in (2, 0, 1, 3, -1):
+                qp.set_option("avi_tiers", 0 if first < 0 else 1)
+                if first >= 0:
+                    qp.set_option("avi_tiers_first", first)
+                it = torch.full((N,), -77, dtype=torch.int32, device=dev)
+                act = torch.full((N, qp.words), -1, dtype=torch.int64, device=dev)
+                x, ef = qp.solve_device(t, iters=it, active=act)
+                torch.cuda.synchronize()
+                assert np.array_equal(ef.cpu().numpy(), efo), (trial, N, first)
+                assert np.array_equal(it.cpu().numpy(), ito), (trial, N, first)
+                assert np.array_equal(act.cpu().numpy().view(np.uint64), acto.view(np.uint64)), (trial, N, first)
+                assert np.array_equal(x.cpu().numpy(), xo), (trial, N, first)
+        # an iteration limit inside the chain's reach: what it cannot finish goes down to the generic kernel, which
+        # reports the limit exactly as it does alone
+        th = np.ascontiguousarray(rng.normal(size=(3000, nth)) * 6.0)
+        qp.set_option("avi_tiers", 1); qp.set_option("avi_tiers_first", 2)
+        for limit in (n + 2, 3):         # (3 <= n + 1: the chain is not used at all)
+            s = lmpc.default_settings(); s.iter_limit = limit; qp.set_settings(s)
+            so = oldp.default_settings(); so.iter_limit = limit
+            xo, efo, ito, acto = oavi.solve_batch(P, th, settings=so)
+            x, ef, it, act = qp.solve(th)
+            assert np.array_equal(ef, efo) and np.array_equal(it, ito), (trial, limit)
+            ok = efo >= 1
+            assert np.array_equal(x[ok], xo[ok]) and np.array_equal(act[ok], acto[ok]), (trial, limit)
+        qp.close()
+

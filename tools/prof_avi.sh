@@ -21,20 +21,25 @@ for f in glob.glob(out + "/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if float(r['Percentage']) >= 0.05:
             lines.append(f"| `{r['Name'][:120]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.1f} |")
-agg = collections.defaultdict(list); res = None
+agg = collections.defaultdict(lambda: collections.defaultdict(list)); res = {}
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "avi_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            res = (r["Kernel_Name"][:120], r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Workgroup_Size"), r.get("Grid_Size"))
-lines += ["", "## PMC (average per dispatch of avi_kernel)", ""]
-if res:
-    lines += [f"`{res[0]}`: VGPR {res[1]} SGPR {res[2]} LDS {res[3]} B, workgroup {res[4]}, grid {res[5]}", "", "| counter | value |", "|---|---|"]
-    lines += [f"| {c} | {sum(v) / len(v):.1f} |" for c, v in sorted(agg.items())]
-    if "FETCH_SIZE" in agg and "WRITE_SIZE" in agg:
-        fk, wk = sum(agg["FETCH_SIZE"]) / len(agg["FETCH_SIZE"]), sum(agg["WRITE_SIZE"]) / len(agg["WRITE_SIZE"])
-        lines += ["", f"HBM traffic per dispatch (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md): {(2 * fk + wk) * 1024 / 1e6:.1f} MB "
-                      f"against 68 MB algorithmic"]
+        k = r["Kernel_Name"]
+        if "lmpc::avi" in k:
+            k = k.split("(")[0].replace("void ", "")
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Workgroup_Size"), r.get("Grid_Size"))
+lines += ["", "## PMC (average per dispatch)", ""]
+tot_f = tot_w = 0.0
+for k in sorted(agg):
+    lines += [f"`{k}`: VGPR {res[k][0]} AGPR {res[k][1]} SGPR {res[k][2]} LDS {res[k][3]} B, workgroup {res[k][4]}, grid {res[k][5]}", "", "| counter | value |", "|---|---|"]
+    lines += [f"| {c} | {sum(v) / len(v):.1f} |" for c, v in sorted(agg[k].items())]
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        fk, wk = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"]), sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"])
+        tot_f += fk; tot_w += wk
+        lines += ["", f"HBM traffic per dispatch (FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md): {(2 * fk + wk) * 1024 / 1e6:.1f} MB"]
+    lines += [""]
+lines += [f"HBM traffic of the chain per call: {(2 * tot_f + tot_w) * 1024 / 1e6:.1f} MB against 68 MB algorithmic"]
 open(out + "/summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
