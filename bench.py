@@ -618,6 +618,9 @@ def avi_config(torch, lmpc, dev, local_rank, batch, steps, warmup, want_cpu, cpu
     nout = int(g["nu"])
     qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout,
                                   device=local_rank)
+    for kv in os.environ.get("LMPC_BENCH_AVI_OPTIONS", "").split(","):      # (tools/: "avi_tiers=0,avi_tiers_first=3")
+        if "=" in kv:
+            qp.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     rng = np.random.default_rng(1234)
     th_h = np.ascontiguousarray(np.hstack([rng.uniform(-30, 30, (batch, 4)), rng.uniform(-1, 1, (batch, 2))]))
     bytes_per = algorithmic_bytes(qp.nth, nout)
@@ -664,9 +667,10 @@ def avi_config(torch, lmpc, dev, local_rank, batch, steps, warmup, want_cpu, cpu
                                                                  "and iteration count bit-identical"},
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": None, "duration_used_ms": call_ms, "algorithmic_bytes_per_solve": bytes_per,
-                        "note": "algorithmic bytes (theta in, u0 and flag out) over the HIP-event duration of one call; the "
-                                "kernel itself is bound by the latency of its own per-lane scratch (L D U factor, "
-                                "multipliers), not by these bytes"}}
+                        "note": "algorithmic bytes (theta in, u0 and flag out) over the HIP-event duration of one call (a chain of "
+                                "three launches: register-resident tiers, lane kernel on its list, generic kernel on that "
+                                "one's); the chain is VALU-issue bound (f64 chains, selects), HBM traffic ~1.5x these bytes "
+                                "(profiles/r04_avi_chain.md)"}}
     if want_cpu:
         ns = min(batch, 200000)
         t1 = time.perf_counter()

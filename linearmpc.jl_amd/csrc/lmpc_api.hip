@@ -1711,7 +1711,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers") == 0) { h->aviTiers = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers_first") == 0) {
-        h->aviTiersFirst = value < 0 ? 0 : (value > 3 ? 3 : value); h->aviTiersOcc[0] = 0; return LMPC_OK;
+        h->aviTiersFirst = value < 0 ? -1 : (value > 3 ? 3 : value); h->aviTiersOcc[0] = 0; return LMPC_OK;
     }
     if (std::strcmp(name, "wave") == 0) {
         if (h->avi) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: a variational-inequality handle has one kernel");

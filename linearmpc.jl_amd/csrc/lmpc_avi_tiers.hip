@@ -13,7 +13,8 @@ int go(lmpc_handle *h, unsigned grid, hipStream_t st, const double *theta, doubl
        uint64_t *active, const int32_t *list_in, const int32_t *count_in, int32_t *list_out, int32_t *count_out,
        int32_t *count_clear, long long seg_cap, long long nprob, int *occ) {
     auto kern = avi_tiers_kernel<N, KMAX, LIST>;
-    const size_t lds = sizeof(double) * (size_t)AviSmallLds<N>::reals(h->A.nth, h->A.nout);
+    // the constants, then the four wavefronts' parked outputs (nout reals a lane)
+    const size_t lds = sizeof(double) * ((size_t)AviSmallLds<N>::reals + 4 * (size_t)h->A.nout * 64);
     if (occ) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, lds) != hipSuccess || nb < 1) nb = 1;
@@ -29,7 +30,11 @@ template <int N>
 int go_lane(lmpc_handle *h, unsigned grid, hipStream_t st, const double *theta, double *x, int32_t *flag, int32_t *iters,
             uint64_t *active, const int32_t *list_in, const int32_t *count_in, int32_t *list_out, int32_t *count_out,
             int32_t *count_clear, long long seg_cap, long long nprob, int *occ) {
-    const size_t lds = sizeof(double) * (size_t)AviSmallLds<N>::reals(h->A.nth, h->A.nout);
+    const size_t lds = sizeof(double) * (size_t)avi_lane_lds_reals<N>();
+    if (lds > 48 * 1024) {
+        HIP_TRY(h, hipFuncSetAttribute((const void *)avi_lane_kernel<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(h, hipFuncSetAttribute((const void *)avi_lane_kernel<N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     const bool listed = list_in != nullptr || occ != nullptr;
     const void *kern = listed ? (const void *)avi_lane_kernel<N, true> : (const void *)avi_lane_kernel<N, false>;
     if (occ) {

@@ -23,8 +23,8 @@
 //   What it does not finish -- a singular pivot, a row violated inside its own working set at the end, the iteration
 //   limit -- is queued for avi_kernel (never seen on the reference's problem; the list is there for completeness).
 //
-// The chain of a batch: avi_tiers_kernel<N, 2> over the whole batch (two tiers: what 4 of 5 problems need, at 4
-// wavefronts per SIMD) -> avi_lane_kernel<N> on its list -> avi_kernel on that one's list.
+// The chain of a batch: avi_tiers_kernel<N, 3> over the whole batch (three tiers: what 93 % of the reference's game
+// problem needs, at 3 wavefronts per SIMD) -> avi_lane_kernel<N> on its list -> avi_kernel on that one's list.
 //
 // Each chain is the fma chain of avi_kernel / the CPU checker in the same order, so a problem finished here has the
 // bits the generic kernel gives it.
@@ -46,69 +46,80 @@
 
 namespace lmpc {
 
-// LDS copy of the constants, at compile-time offsets (immediate offsets in the ds_read instructions):
-// s (diagonal of ML), MR, G, du0, dl0, then Dth TRANSPOSED (column t of all rows contiguous), Rout, x0, Xth
-// (rows read as a whole -- MR, the columns of Dth -- start on 16-byte boundaries: stride NP = N rounded up to even)
+// Constants: what every lane reads at the same index (Dth, bounds, the diagonal of ML, output maps) comes straight from
+// the pack by SCALAR loads (uniform addresses: s_load into SGPRs, operands of the fma -- as LDS broadcasts the same
+// reads kept the LDS pipe of a CU busy for half of the kernel's time); what a lane reads at its OWN index (rows of MR,
+// entries of G, by working-set row) is copied to LDS at compile-time offsets (rows of MR start on 16-byte boundaries:
+// stride NP = N rounded up to even).
 template <int N> struct AviSmallLds {
     static constexpr int NP = N + (N & 1);
-    static constexpr int oS = 0, oMR = NP, oG = oMR + N * NP, oDU = oG + ((N * N + 1) & ~1), oDL = oDU + NP, oDthT = oDL + NP;
-    __host__ __device__ static constexpr int reals(int nth, int nout) { return oDthT + nth * NP + nout * N + nout + nout * nth; }
+    static constexpr int oMR = 0, oG = N * NP, oSd = oG + ((N * N + 1) & ~1);
+    static constexpr int reals = oSd + NP;
 };
 
 template <int N>
 __device__ __forceinline__ void avi_small_stage(const AviLayout &P, const double *__restrict__ C, double *lds, int tid, int nthreads) {
     typedef AviSmallLds<N> Ly;
-    const int nth = P.nth, nout = P.nout;
-    for (int e = tid; e < N; e += nthreads) {
-        lds[Ly::oS + e] = C[P.oML + e * N + e];
-        lds[Ly::oDU + e] = C[P.odu + e];
-        lds[Ly::oDL + e] = C[P.odl + e];
-    }
     for (int e = tid; e < N * N; e += nthreads) {
         const int j = e / N, c = e - j * N;
         lds[Ly::oMR + j * Ly::NP + c] = C[P.oMR + e];
         lds[Ly::oG + e] = C[P.oG + e];
     }
-    for (int e = tid; e < N * nth; e += nthreads) { const int j = e / nth, t = e - j * nth; lds[Ly::oDthT + t * Ly::NP + j] = C[P.oDth + e]; }
-    const int oR = Ly::oDthT + nth * Ly::NP;
-    for (int e = tid; e < nout * N; e += nthreads) lds[oR + e] = C[P.oRout + e];
-    for (int e = tid; e < nout; e += nthreads) lds[oR + nout * N + e] = C[P.ox0 + e];
-    for (int e = tid; e < nout * nth; e += nthreads) lds[oR + nout * N + nout + e] = C[P.oXth + e];
+    for (int e = tid; e < N; e += nthreads) lds[Ly::oSd + e] = C[P.oSd + e];
 }
 
-// bounds of a parameter point (mpc_update_qp.c:1-10): d = du0 / dl0 + Dth theta, sums in index order
+// bounds of a parameter point (mpc_update_qp.c:1-10): d = du0 / dl0 + Dth theta, sums in index order; in the same pass
+// over theta the parameter's part of the outputs, x0 + Xth theta (mpc_update_qp.c:14-22), parked in LDS (element kk of
+// lane l at shx[kk * 64]) until the problem is finished.  Per column of theta ONE batch of scalar loads (AviLayout::oTh2).
 template <int N>
-__device__ __forceinline__ void avi_small_bounds(const double *lds, const double *th, int nth, double (&dup)[N], double (&dlo)[N]) {
-    typedef AviSmallLds<N> Ly;
-    double sh[N];
+__device__ __forceinline__ void avi_small_bounds(const AviLayout &P, const double *__restrict__ C, const double *th, int nth, int nout,
+                                                 double (&dup)[N], double (&dlo)[N], double *shx) {
+    double sh[N], so[N];
+    {
+        const double *b3 = C + P.oBnd3;
+        double x0v[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) sh[j] = 0.0;
-    const double *col = lds + Ly::oDthT;
-    for (int t = 0; t < nth; t++, col += Ly::NP) {
+        for (int j = 0; j < N; j++) x0v[j] = b3[2 * N + j];
+#pragma unroll
+        for (int j = 0; j < N; j++) { sh[j] = 0.0; so[j] = x0v[j]; }
+    }
+    const double *col = C + P.oTh2;
+    for (int t = 0; t < nth; t++, col += 2 * N) {
         const double tv = th[t];
-        double dv[N];
-        lmpc_lds_run<N>(col, 0, dv);
+        double cv[2 * N];
 #pragma unroll
-        for (int j = 0; j < N; j++) sh[j] = __builtin_fma(dv[j], tv, sh[j]);
+        for (int j = 0; j < 2 * N; j++) cv[j] = col[j];
+#pragma unroll
+        for (int j = 0; j < N; j++) sh[j] = __builtin_fma(cv[j], tv, sh[j]);
+#pragma unroll
+        for (int kk = 0; kk < N; kk++) so[kk] = __builtin_fma(cv[N + kk], tv, so[kk]);      // (rows >= nout: zeros, not stored)
+    }
+    {
+        const double *b3 = C + P.oBnd3;
+        double bv[2 * N];
+#pragma unroll
+        for (int j = 0; j < 2 * N; j++) bv[j] = b3[j];
+#pragma unroll
+        for (int j = 0; j < N; j++) { dup[j] = bv[j] + sh[j]; dlo[j] = bv[N + j] + sh[j]; }
     }
 #pragma unroll
-    for (int j = 0; j < N; j++) { dup[j] = lds[Ly::oDU + j] + sh[j]; dlo[j] = lds[Ly::oDL + j] + sh[j]; }
+    for (int kk = 0; kk < N; kk++)
+        if (kk < nout) shx[kk * 64] = so[kk];
 }
 
-// x = Rout u + x0 + Xth theta (mpc_update_qp.c:14-22), flag, iteration count, working set of a finished problem
+// x = Rout u + (x0 + Xth theta), flag, iteration count, working set of a finished problem
 template <int N>
-__device__ __forceinline__ void avi_small_output(const double *lds, const double *th, int nth, int nout, int words, long long pid,
-                                                 const double (&u)[N], int iter, unsigned act, unsigned low, double *__restrict__ X,
-                                                 int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
-                                                 uint64_t *__restrict__ active) {
-    typedef AviSmallLds<N> Ly;
-    const double *sRout = lds + Ly::oDthT + nth * Ly::NP, *sx0 = sRout + nout * N, *sXth = sx0 + nout;
+__device__ __forceinline__ void avi_small_output(const AviLayout &P, const double *__restrict__ C, const double *shx, int nout,
+                                                 long long pid, const double (&u)[N], int iter, unsigned act, unsigned low,
+                                                 double *__restrict__ X, int32_t *__restrict__ exitflag,
+                                                 int32_t *__restrict__ iters, uint64_t *__restrict__ active) {
+    const int words = P.words;
     for (int kk = 0; kk < nout; kk++) {
-        double xs = 0.0, sh = sx0[kk];
+        const double *ro = C + P.oRout + kk * N;
+        double xs = 0.0;
 #pragma unroll
-        for (int c = 0; c < N; c++) xs = __builtin_fma(sRout[kk * N + c], u[c], xs);
-        for (int t = 0; t < nth; t++) sh = __builtin_fma(sXth[kk * nth + t], th[t], sh);
-        X[pid * nout + kk] = xs + sh;
+        for (int c = 0; c < N; c++) xs = __builtin_fma(ro[c], u[c], xs);
+        X[pid * nout + kk] = xs + shx[kk * 64];
     }
     exitflag[pid] = EXIT_OPTIMAL;
     if (iters) iters[pid] = iter;
@@ -119,22 +130,36 @@ __device__ __forceinline__ void avi_small_output(const double *lds, const double
     }
 }
 
-// the lanes flagged `queue` append their problem index to segment `shard` of a work list
+// the lanes flagged `queue` append their problem index to segment `shard` of a work list -- in two halves, so that the
+// round trip of the counter's atomic is not waited for: avi_push_reserve at the end of a tile, avi_push_write at the end
+// of the NEXT one (and after the last)
+struct AviPush { unsigned long long mask = 0ull; int base = 0; int pid = 0; };
+__device__ __forceinline__ void avi_push_reserve(AviPush &q, bool queue, long long pid, int lane, int shard,
+                                                 int32_t *__restrict__ count_out) {
+    q.mask = __ballot(queue);
+    q.pid = (int)pid;
+    q.base = 0;
+    if (q.mask != 0ull && lane == 0) q.base = atomicAdd(&count_out[shard * kCountStride], __popcll(q.mask));
+}
+__device__ __forceinline__ void avi_push_write(AviPush &q, int lane, int shard, long long seg_cap, int32_t *__restrict__ list_out) {
+    if (q.mask != 0ull) {
+        const int qbase = __shfl(q.base, 0);
+        if ((q.mask >> lane) & 1ull)
+            list_out[(long long)shard * seg_cap + qbase + __popcll(q.mask & ((1ull << lane) - 1ull))] = q.pid;
+    }
+    q.mask = 0ull;
+}
 __device__ __forceinline__ void avi_small_push(bool queue, long long pid, int lane, int shard, long long seg_cap,
                                                int32_t *__restrict__ list_out, int32_t *__restrict__ count_out) {
-    const unsigned long long qmask = __ballot(queue);
-    if (qmask != 0ull) {
-        int qbase = 0;
-        if (lane == 0) qbase = atomicAdd(&count_out[shard * kCountStride], __popcll(qmask));
-        qbase = __shfl(qbase, 0);
-        if (queue) list_out[(long long)shard * seg_cap + qbase + __popcll(qmask & ((1ull << lane) - 1ull))] = (int32_t)pid;
-    }
+    AviPush q;
+    avi_push_reserve(q, queue, pid, lane, shard, count_out);
+    avi_push_write(q, lane, shard, seg_cap, list_out);
 }
 
 // one scanned row: most violated inactive row at the target (ties: the first), first satisfied row the step breaks
 #define LMPC_AVI_SCAN_ROW(jj, ACTIVE_LANES)                                                                    \
     {                                                                                                          \
-        const double s_ = lds[Ly::oS + (jj)];                                                                 \
+        const double s_ = sd[jj];                                                                              \
         const double Mc = __builtin_fma(s_, uc[jj], 0.0), Mt = __builtin_fma(s_, ut[jj], 0.0);                 \
         const double dj = dup[jj], ej = dlo[jj];                                                               \
         const double vu = dj - Mt, vl = -(ej - Mt);                                                            \
@@ -185,6 +210,12 @@ __global__ __launch_bounds__(256) void avi_tiers_kernel(
         first = gw * 64; stride = nw * 64; cnt = nprob;
     }
 
+    double *shx = lds + Ly::reals + (tid >> 6) * (nout * 64) + lane;   // this lane's parked outputs
+    // the diagonal of ML in vector registers for the whole kernel (through LDS: the compiler keeps what it read from
+    // there in VGPRs; as scalar loads inside the scan each row waited for its own)
+    double sd[N];
+    lmpc_lds_run<N>(lds + Ly::oSd, 0, sd);
+    AviPush pend;
     for (long long base = first; base < cnt; base += stride) {
         const long long idx = base + lane;
         const bool mine = idx < cnt;
@@ -193,7 +224,19 @@ __global__ __launch_bounds__(256) void avi_tiers_kernel(
         else pid = mine ? idx : 0;
         const double *th = theta + pid * nth;
         double dup[N], dlo[N];
-        avi_small_bounds<N>(lds, th, nth, dup, dlo);
+        // (the scalar loads of the constants stay where they are used: hoisted out of this loop they would sit in more
+        // scalar registers than there are -- the empty asm hides that the addresses repeat)
+        int zofs = 0;
+        asm volatile("" : "+s"(zofs));
+        const double *Cz = C + zofs;
+        avi_small_bounds<N>(P, Cz, th, nth, nout, dup, dlo, shx);
+        // the next tile's records on their way into the caches while this one is solved: one dummy load per 128-byte line
+        double touch = 0.0;
+        if constexpr (!LIST) {
+            const long long nb = base + stride;
+            const long long off = (long long)lane * 16;
+            if (nb < cnt && off < 64ll * nth && nb * nth + off < nprob * nth) touch = theta[nb * nth + off];
+        }
         // ---- iteration 1: empty working set, both iterates 0
         double min_val = -ptol;
         int add = -1;
@@ -330,34 +373,80 @@ __global__ __launch_bounds__(256) void avi_tiers_kernel(
         }
 
         if (finished)
-            avi_small_output<N>(lds, th, nth, nout, P.words, pid, ufin, iter_fin, act_fin, low_fin, X, exitflag, iters, active);
-        avi_small_push(mine && !finished, pid, lane, shard, seg_cap, list_out, count_out);
+            avi_small_output<N>(P, C + zofs, shx, nout, pid, ufin, iter_fin, act_fin, low_fin, X, exitflag, iters, active);
+        avi_push_write(pend, lane, shard, seg_cap, list_out);          // (the tile before's)
+        avi_push_reserve(pend, mine && !finished, pid, lane, shard, count_out);
+        asm volatile("" ::"v"(touch));
     }
+    avi_push_write(pend, lane, shard, seg_cap, list_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // avi_lane_kernel: the complete iteration in registers, one code block per working-set size.
+// Per lane in registers: the two triangles, reciprocal pivots, multipliers, working set.  What an iteration reads once or
+// rarely -- the bounds of all rows (the scan), the pivots themselves (a removal), the bound each position sits at, the
+// finished iterate -- is PARKED in LDS, element major (element e of lane l at park[e * 64 + l]: conflict-free, immediate
+// offsets): 6 N reals a lane, so that the kernel fits 2 wavefronts per SIMD up to n = 6.
 template <int N> struct AviLaneState {
     static constexpr int NS = N * (N - 1) / 2 > 0 ? N * (N - 1) / 2 : 1;
+    static constexpr int kPark = 6 * N;                 // dup, dlo, D, rhs, ufin, the outputs' parameter part (nout <= n)
     double Ls[NS], Us[NS];           // strict lower triangles of L and of U' (row i > column t)
-    double D[N], Di[N], lam[N], rhs[N];   // pivots, reciprocals, multipliers, the bound each position sits at
-    double dup[N], dlo[N], ufin[N];
+    double Di[N], lam[N];            // reciprocal pivots, multipliers
+    double *park;                    // this lane's column of the wavefront's parking area
     int wrow[N];
     unsigned lowpos, actrow, lowrow;
     int level, iter, iter_fin;
     unsigned act_fin, low_fin;
     bool running, finished;
+    __device__ __forceinline__ double &dup(int j) { return park[j * 64]; }
+    __device__ __forceinline__ double &dlo(int j) { return park[(N + j) * 64]; }
+    __device__ __forceinline__ double &D(int i) { return park[(2 * N + i) * 64]; }
+    __device__ __forceinline__ double &rhs(int i) { return park[(3 * N + i) * 64]; }
+    __device__ __forceinline__ double &ufin(int c) { return park[(4 * N + c) * 64]; }
 };
+
+// one scanned row of the lane kernel (bounds from the parking area)
+#define LMPC_AVI_LANE_SCAN_ROW(jj)                                                                             \
+    {                                                                                                          \
+        const double s_ = sd[jj];                                                                              \
+        const double Mc = __builtin_fma(s_, uc[jj], 0.0), Mt = __builtin_fma(s_, ut[jj], 0.0);                 \
+        const double dj = s.dup(jj), ej = s.dlo(jj);                                                           \
+        const double vu = dj - Mt, vl = -(ej - Mt);                                                            \
+        const bool inact = !((actrow >> (jj)) & 1u);                                                           \
+        broken = broken || (!inact && (vu < -ptol || vl < -ptol));                                             \
+        const bool tu = inact && (vu < min_val);                                                               \
+        const bool tl = inact && !tu && (vl < min_val);                                                        \
+        add = (tu || tl) ? (jj) : add;                                                                         \
+        addlow = tu ? false : (tl ? true : addlow);                                                            \
+        min_val = tu ? vu : (tl ? vl : min_val);                                                               \
+        const double cu = dj - Mc, cl = -(ej - Mc);                                                            \
+        const bool bu_ = inact && (vu < -ptol) && (cu >= -ptol);                                               \
+        const bool bl_ = inact && !bu_ && (vl < -ptol) && (cl >= -ptol);                                       \
+        if (__any(bu_ || bl_)) {                                                                               \
+            const double cv = bu_ ? cu : cl, vv = bu_ ? vu : vl;                                               \
+            const double t = cv > 0.0 ? cv / (cv - vv) : 0.0;                                                  \
+            const bool take = (bu_ || bl_) && (t < tblk);                                                      \
+            tblk = take ? t : tblk;                                                                            \
+            pblk = take ? (jj) : pblk;                                                                         \
+            pup = take ? bu_ : pup;                                                                            \
+        }                                                                                                      \
+    }
 
 // one iteration of the lanes at level NA (`part`: this lane takes part).  Statement for statement avi_kernel's loop body
 // for sing < 0 with na == NA a constant.
 template <int N, int NA>
-__device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool part, const double *lds, const double ptol,
-                                               const double dtol, const double ztol, const int ilimit) {
+__device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool part, const double *lds, const double *__restrict__ sdp,
+                                               const double ptol, const double dtol, const double ztol, const int ilimit) {
     typedef AviSmallLds<N> Ly;
     if (!part) return;
     if (s.iter >= ilimit) { s.running = false; return; }      // iteration limit: the generic kernel reports it
-    double (&dup)[N] = s.dup, (&dlo)[N] = s.dlo;
+    double sd[N];                                              // the diagonal of ML: one batch of scalar loads per level
+    {
+        int zofs = 0;
+        asm volatile("" : "+s"(zofs));
+#pragma unroll
+        for (int j = 0; j < N; j++) sd[j] = sdp[zofs + j];
+    }
     const unsigned actrow = s.actrow;
     // ---- (L D U) lam* = -d_W
     double ls[NA > 0 ? NA : 1];
@@ -365,7 +454,7 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
         double xl[NA > 0 ? NA : 1];
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            double acc = -s.rhs[i];
+            double acc = -s.rhs(i);
 #pragma unroll
             for (int t = 0; t < i; t++) acc = __builtin_fma(-s.Ls[lmpc_sl(i, t)], xl[t], acc);
             xl[i] = acc;
@@ -414,7 +503,7 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
     int add = -1, pblk = -1;
     bool addlow = false, pup = false, broken = false;
 #pragma unroll
-    for (int jj = 0; jj < N; jj++) LMPC_AVI_SCAN_ROW(jj, true)
+    for (int jj = 0; jj < N; jj++) LMPC_AVI_LANE_SCAN_ROW(jj)
     const bool stepblk = pblk >= 0;
     const bool do_remove = !stepblk && nblock > 0;
     if (!stepblk && !do_remove && add < 0) {
@@ -426,7 +515,7 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
             s.iter_fin = s.iter;
             s.act_fin = s.actrow; s.low_fin = s.lowrow;
 #pragma unroll
-            for (int c = 0; c < N; c++) s.ufin[c] = ut[c];
+            for (int c = 0; c < N; c++) s.ufin(c) = ut[c];
         }
         return;
     }
@@ -464,12 +553,9 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
             if (dnew < ztol) { s.running = false; return; }    // singular working set: the generic kernel
 #pragma unroll
             for (int t = 0; t < NA; t++) { s.Ls[lmpc_sl(NA, t)] = rl[t]; s.Us[lmpc_sl(NA, t)] = ru[t]; }
-            s.D[NA] = dnew; s.Di[NA] = 1.0 / dnew;
+            s.D(NA) = dnew; s.Di[NA] = 1.0 / dnew;
             s.wrow[NA] = j; s.lam[NA] = 0.0;
-            double dsel = 0.0;
-#pragma unroll
-            for (int q = 0; q < N; q++) dsel = (q == j) ? (lower ? dlo[q] : dup[q]) : dsel;
-            s.rhs[NA] = dsel;
+            s.rhs(NA) = s.park[((lower ? N : 0) + j) * 64];    // (the bound it sits at: dlo / dup of row j)
             s.lowpos = lower ? (s.lowpos | (1u << NA)) : (s.lowpos & ~(1u << NA));
             s.lowrow = lower ? (s.lowrow | (1u << j)) : (s.lowrow & ~(1u << j));
             s.actrow |= 1u << j;
@@ -482,11 +568,12 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
 #pragma unroll
         for (int i = 0; i < NA; i++) s.lam[i] = __builtin_fma(alpha, ls[i] - s.lam[i], s.lam[i]);
         const int r = rm;
+        double Dv[NA], Rv[NA];                                 // pivots and bounds by position, back from the parking area
+#pragma unroll
+        for (int i = 0; i < NA; i++) { Dv[i] = s.D(i); Rv[i] = s.rhs(i); }
         // old column r below the diagonal, by NEW position i = r .. NA-2 (old row i + 1); the pivot removed
         double pv[NA > 1 ? NA - 1 : 1], qv[NA > 1 ? NA - 1 : 1];
-        double al = 0.0;
-#pragma unroll
-        for (int q = 0; q < NA; q++) al = (q == r) ? s.D[q] : al;
+        double al = s.park[(2 * N + r) * 64];
 #pragma unroll
         for (int i = 0; i < NA - 1; i++) {
             double p = 0.0, qq = 0.0;
@@ -508,10 +595,10 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
                 s.Ls[lmpc_sl(i, c)] = mv ? (c < r ? l1 : l2) : l0;
                 s.Us[lmpc_sl(i, c)] = mv ? (c < r ? u1 : u2) : u0;
             }
-            s.D[i] = mv ? s.D[i + 1] : s.D[i];
+            Dv[i] = mv ? Dv[i + 1] : Dv[i];
+            Rv[i] = mv ? Rv[i + 1] : Rv[i];
             s.Di[i] = mv ? s.Di[i + 1] : s.Di[i];
             s.lam[i] = mv ? s.lam[i + 1] : s.lam[i];
-            s.rhs[i] = mv ? s.rhs[i + 1] : s.rhs[i];
         }
         int jr = 0;
 #pragma unroll
@@ -530,7 +617,7 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
         for (int i = 0; i < NA - 1; i++) {
             const bool on = i >= r && !stop;
             const double pt = pv[i], qt = qv[i];
-            const double dold = s.D[i];                        // (already shifted: old D[i + 1])
+            const double dold = Dv[i];                         // (already shifted: old D[i + 1])
             const double dbar = __builtin_fma(al * pt, qt, dold);
             const bool sg = on && (dbar < ztol);
             stop = stop || sg;
@@ -539,7 +626,7 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
             const double betaL = (qt * al) * rinv;
             const double betaU = (pt * al) * rinv;
             al = upd ? (dold * al) * rinv : al;
-            s.D[i] = upd ? dbar : s.D[i];
+            Dv[i] = upd ? dbar : Dv[i];
             s.Di[i] = upd ? rinv : s.Di[i];
 #pragma unroll
             for (int p = i + 1; p < NA - 1; p++) {
@@ -553,21 +640,28 @@ __device__ __forceinline__ void avi_lane_level(AviLaneState<N> &s, const bool pa
             }
         }
         if (stop) { s.running = false; return; }               // a singular pivot: the generic kernel
+#pragma unroll
+        for (int i = 0; i < NA - 1; i++) { s.D(i) = Dv[i]; s.rhs(i) = Rv[i]; }
         s.level = NA - 1;
     }
 }
 
 template <int N, int L>
-__device__ __forceinline__ void avi_lane_sweep(AviLaneState<N> &s, const double *lds, const double ptol, const double dtol,
-                                               const double ztol, const int ilimit) {
+__device__ __forceinline__ void avi_lane_sweep(AviLaneState<N> &s, const double *lds, const double *__restrict__ sd, const double ptol,
+                                               const double dtol, const double ztol, const int ilimit) {
     if constexpr (L <= N) {
-        avi_lane_level<N, L>(s, s.running && s.level == L, lds, ptol, dtol, ztol, ilimit);
-        avi_lane_sweep<N, L + 1>(s, lds, ptol, dtol, ztol, ilimit);
+        avi_lane_level<N, L>(s, s.running && s.level == L, lds, sd, ptol, dtol, ztol, ilimit);
+        avi_lane_sweep<N, L + 1>(s, lds, sd, ptol, dtol, ztol, ilimit);
     }
 }
 
+// LDS of a workgroup of avi_lane_kernel: the constants, then the four wavefronts' parking areas
+template <int N> __host__ __device__ constexpr int avi_lane_lds_reals() {
+    return AviSmallLds<N>::reals + 4 * AviLaneState<N>::kPark * 64;
+}
+
 template <int N, bool LIST>
-__global__ __launch_bounds__(256) void avi_lane_kernel(
+__global__ __launch_bounds__(256, (N <= 6 ? 2 : 1)) void avi_lane_kernel(
     const AviLayout P, const double *__restrict__ C, const double *__restrict__ theta, double *__restrict__ X,
     int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
     const int32_t *__restrict__ list_in, const int32_t *__restrict__ count_in, int32_t *__restrict__ list_out,
@@ -589,6 +683,9 @@ __global__ __launch_bounds__(256) void avi_lane_kernel(
     } else {
         first = gw * 64; stride = nw * 64; cnt = nprob;
     }
+    AviLaneState<N> s;
+    s.park = lds + AviSmallLds<N>::reals + (tid >> 6) * (AviLaneState<N>::kPark * 64) + lane;
+    const double *sd = C + P.oSd;
     for (long long base = first; base < cnt; base += stride) {
         const long long idx = base + lane;
         const bool mine = idx < cnt;
@@ -596,24 +693,35 @@ __global__ __launch_bounds__(256) void avi_lane_kernel(
         if constexpr (LIST) pid = mine ? (long long)list_in[idx] : 0;
         else pid = mine ? idx : 0;
         const double *th = theta + pid * nth;
-        AviLaneState<N> s;
-        avi_small_bounds<N>(lds, th, nth, s.dup, s.dlo);
+        {
+            double dup[N], dlo[N];
+            int zofs = 0;
+            asm volatile("" : "+s"(zofs));
+            avi_small_bounds<N>(P, C + zofs, th, nth, nout, dup, dlo, s.park + 5 * N * 64);
+#pragma unroll
+            for (int j = 0; j < N; j++) { s.dup(j) = dup[j]; s.dlo(j) = dlo[j]; }
+        }
 #pragma unroll
         for (int i = 0; i < AviLaneState<N>::NS; i++) { s.Ls[i] = 0.0; s.Us[i] = 0.0; }
 #pragma unroll
-        for (int i = 0; i < N; i++) { s.D[i] = 0.0; s.Di[i] = 0.0; s.lam[i] = 0.0; s.rhs[i] = 0.0; s.ufin[i] = 0.0; s.wrow[i] = 0; }
+        for (int i = 0; i < N; i++) { s.Di[i] = 0.0; s.lam[i] = 0.0; s.wrow[i] = 0; }
         s.lowpos = s.actrow = s.lowrow = 0u;
         s.level = 0; s.iter = 1; s.iter_fin = 1; s.act_fin = s.low_fin = 0u;
         s.running = mine; s.finished = false;
         // sweeps over the levels until no lane of the wavefront is running (each pass of the loop advances every
         // running lane by at least one iteration, and a lane stops at the iteration limit at the latest)
-        while (__any(s.running)) avi_lane_sweep<N, 0>(s, lds, ptol, dtol, ztol, P.iter_limit);
-        if (s.finished)
-            avi_small_output<N>(lds, th, nth, nout, P.words, pid, s.ufin, s.iter_fin, s.act_fin, s.low_fin, X, exitflag, iters, active);
+        while (__any(s.running)) avi_lane_sweep<N, 0>(s, lds, sd, ptol, dtol, ztol, P.iter_limit);
+        if (s.finished) {
+            double uf[N];
+#pragma unroll
+            for (int c = 0; c < N; c++) uf[c] = s.ufin(c);
+            avi_small_output<N>(P, C, s.park + 5 * N * 64, nout, pid, uf, s.iter_fin, s.act_fin, s.low_fin, X, exitflag, iters, active);
+        }
         avi_small_push(mine && !s.finished, pid, lane, shard, seg_cap, list_out, count_out);
     }
 }
 
+#undef LMPC_AVI_LANE_SCAN_ROW
 #undef LMPC_AVI_SCAN_ROW
 
 }  // namespace lmpc

@@ -135,7 +135,8 @@ struct lmpc_handle {
     // ... small box-constrained problems: register-resident straight-line kernels in front of it (lmpc_avi_tiers_kernel.hpp)
     int aviTiersN = 0;          // n if the problem qualifies (2 .. 8), else 0
     int aviTiers = 1;           // tuning: 0 = the generic kernel alone ("avi_tiers"; results identical either way)
-    int aviTiersFirst = 2;      // tuning: tiers of the pass over the whole batch, 1 .. 3 ("avi_tiers_first")
+    int aviTiersFirst = -1;     // tuning: tiers of the pass over the whole batch, 0 .. 3 ("avi_tiers_first"; -1: 3 up to n = 6, else 2;
+                                // 0: the lane kernel over the whole batch)
     int aviTiersOcc[2] = {0, 0};   // workgroups per CU the two instantiations keep resident (0 = not asked yet)
     int32_t *dAviList[2] = {nullptr, nullptr};   // the two work lists of the chain, kShards segments each
     int32_t *dAviCnt = nullptr;                  // ... their counters (two sets of kShards, kCountStride apart)

@@ -87,6 +87,10 @@ struct AviLayout {
     // proximal-point mode (eps_prox > 0): (H + eps I)^-1, the full-length affine map, the outputs' feedback term
     int oHinv, ox0f, oXthf, oKth;
     double eps_prox, eta_prox;
+    // register-resident kernels (lmpc_avi_tiers_kernel.hpp, m == n <= 8), laid out for batched scalar loads:
+    // oTh2: per column t of theta 2 n reals -- column t of Dth, then column t of Xth (rows >= nout zero);
+    // oBnd3: du0, dl0, x0 (padded to n); oSd: the diagonal of ML
+    int oTh2, oBnd3, oSd;
 };
 
 }  // namespace lmpc
