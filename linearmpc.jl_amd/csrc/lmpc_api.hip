@@ -671,6 +671,27 @@ void lmpc_default_settings_f32(lmpc_settings *s) {
     s->eps_prox = 0.0; s->eta_prox = 1e-6;
 }
 
+// The code objects of the kernels this handle's plain solves will launch are brought onto the device at SETUP: HIP
+// loads a translation unit's code lazily with the first launch of one of its kernels -- 5 to 15 ms for the wavefront
+// kernel's units -- which otherwise lands in the caller's first solve (once per process and unit).
+static void preload_code(lmpc_handle *h) {
+    lmpc::DeviceScope scope;
+    if (scope.enter(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)form_theta_kernel<double>);     // this unit: screening, lane, closed loop
+    if (h->avi) avi_preload(h);
+    else {
+        if (fast_covers(h)) fast_preload();
+        if (h->dCw && h->useWave) {
+            h->preloadOnly = true;
+            (void)launch_wave(h, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            h->preloadOnly = false;
+        }
+    }
+    (void)hipGetLastError();
+    h->err.clear();
+}
+
 static int setup_common(lmpc_handle **out, int n, int m, int ms, int nth, int nout, const double *H,
                         const double *f, const double *f_theta, const double *A, const double *bu,
                         const double *bl, const double *W, const int32_t *sense, const double *Kfb, int nx,
@@ -709,6 +730,7 @@ static int setup_common(lmpc_handle **out, int n, int m, int ms, int nth, int no
         if (rc == LMPC_OK) rc = finalize_handle(h);
     }
     if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
+    preload_code(h);
     *out = h;
     return LMPC_OK;
 }
@@ -763,6 +785,7 @@ int lmpc_setup_ldp(lmpc_handle **out, int n, int m, int ms, int nth, int nout, c
     int rc = finish_pack(P, h->err);
     if (rc == LMPC_OK) rc = finalize_handle(h);
     if (rc != LMPC_OK) { g_setup_err = h->err; lmpc_free(h); return rc; }
+    preload_code(h);
     *out = h;
     return LMPC_OK;
 }
@@ -1732,7 +1755,28 @@ int lmpc_reserve(lmpc_handle *h, int64_t N, void *stream) {
     if (h->avi) return LMPC_OK;                          // (its slabs depend on the launch shape only: first launch)
     if (h->useWave) {
         if (wave_screens(h, N)) { const int rc = ensure_lists(h, N, st); if (rc != LMPC_OK) return rc; }
-        return wave_reserve(h, N, st);
+        const int rcw = wave_reserve(h, N, st);
+        if (rcw != LMPC_OK || h->bnb || h->waveWarmed) return rcw;
+        // ONE dummy problem (theta = 0) through the wavefront kernel on the caller's stream, into scratch outputs: what a
+        // kernel's first dispatch on a queue still costs after the code is loaded (4 ms measured on pendulum N = 50:
+        // the queue's scratch memory for the kernel's spills) is paid here and not in the first solve
+        h->waveWarmed = true;
+        double *pt = nullptr;
+        int32_t *pf = nullptr;
+        const size_t nr = (size_t)h->P.nth + (size_t)h->P.nout + 2;
+        if (hipMalloc(&pt, sizeof(double) * nr) != hipSuccess) { (void)hipGetLastError(); return LMPC_OK; }
+        if (hipMalloc(&pf, sizeof(int32_t) * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pt); return LMPC_OK; }
+        int rc = LMPC_OK;
+        if (hipMemsetAsync(pt, 0, sizeof(double) * nr, st) == hipSuccess) {
+            const bool prof = h->prof, probe = h->waveProbe;
+            h->prof = false; h->waveProbe = false;             // (not a batch: no events, no probe)
+            rc = launch_wave(h, 1, pt, pt + h->P.nth, pf, nullptr, nullptr, nullptr, st);
+            h->prof = prof; h->waveProbe = probe;
+            (void)hipStreamSynchronize(st);
+        }
+        (void)hipGetLastError();
+        (void)hipFree(pt); (void)hipFree(pf);
+        return rc;
     }
     if (will_screen(h, N)) return ensure_lists(h, N, st);
     return LMPC_OK;

@@ -228,6 +228,21 @@ static int avi_generic(lmpc_handle *h, int64_t nprob, long long tiles, const dou
     return LMPC_OK;
 }
 
+// the code objects of this handle's kernels onto the device without a launch (setup; preload_code in lmpc_api.hip):
+// the generic kernel's unit, and through the occupancy queries the register-resident kernels'
+void avi_preload(lmpc_handle *h) {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)avi_kernel<true, false>);
+    if (h->aviTiers && h->aviTiersN > 0) {
+        const int kfirst = h->aviTiersFirst >= 0 ? h->aviTiersFirst : (h->aviTiersN <= 6 ? 3 : 2);
+        for (int s = 0; s < 2; s++)
+            if (h->aviTiersOcc[s] == 0)
+                (void)launch_avi_tiers(h, s == 0, kfirst, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                       nullptr, nullptr, 0, 0, &h->aviTiersOcc[s]);
+    }
+    (void)hipGetLastError();
+}
+
 void avi_release(lmpc_handle *h, bool pack_too) {
     if (h->dAviR) { (void)hipFree(h->dAviR); h->dAviR = nullptr; }
     if (h->dAviI) { (void)hipFree(h->dAviI); h->dAviI = nullptr; }

@@ -119,6 +119,13 @@ int check_fast_err(lmpc_handle *h) {
                                  "(LMPC_EXIT_UNFINISHED), their x is not a solution");
 }
 
+// this unit's code object onto the device without a launch (setup; see preload_code in lmpc_api.hip)
+void fast_preload() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)fast_kernel<8, 7, 5, false>);
+    (void)hipGetLastError();
+}
+
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st) {
     const bool gather = h->L.gat.state != nullptr;        // generated-controller call: theta from the five arrays

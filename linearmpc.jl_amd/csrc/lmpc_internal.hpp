@@ -180,6 +180,8 @@ struct lmpc_handle {
     int64_t ccStageCap = 0;
     size_t ccStagePer = 0;
     int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
+    bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
+    bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling
     bool prof = false;
     std::vector<lmpc::EventTriple> events;
@@ -230,6 +232,8 @@ int launch_avi_tiers(lmpc_handle *h, bool first, int kfirst, unsigned grid, hipS
 
 // one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
 bool fast_covers(const lmpc_handle *h);
+void fast_preload();
+void avi_preload(lmpc_handle *h);
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st);
 

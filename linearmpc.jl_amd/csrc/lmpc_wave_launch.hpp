@@ -227,6 +227,11 @@ int launch_wave_cfg(lmpc_handle *h, const WaveConfig &cfg, const R *dC, int64_t 
     auto kern = wave_kernel<R, MR, LDSC, BNB, PACKED, NU, GRAM, SIM>;
     if (cfg.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds));
+    if (h->preloadOnly) {                              // setup: the translation unit's code object on the device, no launch
+        hipFuncAttributes fa;
+        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void *)kern));
+        return LMPC_OK;
+    }
     int blocksPerCU = cfg.blocksPerCU;
     if (h->waveCap > 0) {                              // tuning: wavefronts per CU of the persistent grid
         blocksPerCU = h->waveCap / cfg.nwv;
@@ -362,7 +367,7 @@ template <typename R, bool BNB, bool GRAM, bool SIM>
 int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, const uint64_t *warm, hipStream_t st) {
     EventTriple ev{};
-    const bool prof = h->prof && h->waveList.list == nullptr;     // (behind the screening pass: launch_wave_screened's events)
+    const bool prof = h->prof && h->waveList.list == nullptr && !h->preloadOnly;     // (behind the screening pass: launch_wave_screened's events)
     if (prof) {
         HIP_TRY(h, pool_event(h, &ev.a));
         HIP_TRY(h, pool_event(h, &ev.mid));
@@ -444,6 +449,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
 #undef LMPC_WV4
     return rc;
     };   // dispatch
+    if (h->preloadOnly) return dispatch();
     if (c1 > 0) {
         h->W.cap = c1; h->W.ldc = c1 | 1; h->wavePass = 1;
         cfg = wave_config(h, sizeof(R));
