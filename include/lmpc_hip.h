@@ -506,6 +506,10 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * (more wavefronts resident) and hand the points that outgrow it to a second launch at the full capacity;
  * "wave_cap" c (8 .. 64, 0 = the problem's own) = the full capacity itself, points beyond it go to the slow path.
  * Neither changes a result.
+ * Variational handles (is_avi) with n <= 8 simple bounds run a chain of register-resident kernels in front of the
+ * generic one: "avi_tiers" (default 1; 0 = the generic kernel alone), "avi_tiers_first" (-1 = default: 3 up to n = 6,
+ * else 2; 1 .. 3 = straight-line tiers of the pass over the whole batch; 0 = the complete lane kernel over the whole
+ * batch), "avi_waves" (generic kernel: wavefronts per CU, default 16).  Results identical either way.
  * hipGraph capture of calls on one handle: the work-list and ticket counters alternate between two sets, each call
  * clearing the set of the next one -- capture an EVEN number of calls per handle. */
 int lmpc_set_option(lmpc_handle *h, const char *name, int value);
@@ -555,7 +559,9 @@ int lmpc_check(lmpc_handle *h);
 
 /* lmpc_reserve: allocate NOW what the *_device entry points would allocate lazily inside their first call on a batch of
  * N problems (work lists, overflow lists, counters, the slow path's scratch), so that the first call enqueues kernels
- * and nothing else.  Optional; asynchronous on `stream` (a few memsets).  What a first call on a fresh
+ * and nothing else.  Optional; on a wavefront-kernel handle it also sends ONE dummy problem through the kernel on
+ * `stream` and waits for it (the queue's first dispatch of that kernel costs ~4 ms), otherwise asynchronous (a few
+ * memsets).  (The kernels' code objects are loaded by lmpc_setup*, not by the first solve.)  What a first call on a fresh
  * wavefront-kernel handle still does by itself, once: it solves the leading 16 384 points of its own batch in front
  * into scratch outputs, waits for that launch and reads the working-set sizes it saw, so that the batch runs in the
  * launch shape a warmed-up handle would choose (lmpc_set_option "wave_probe" 0: never; such a handle's first calls run
