@@ -1730,6 +1730,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         return LMPC_OK;
     }
     if (std::strcmp(name, "wave_probe") == 0) { h->waveProbe = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "region_lockfree") == 0) { h->regW1 = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers") == 0) { h->aviTiers = value != 0; return LMPC_OK; }
@@ -1819,7 +1820,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dFastCtr);
+    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dRegW1); hipFree(h->dFastCtr);
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);

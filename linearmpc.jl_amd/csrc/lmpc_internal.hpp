@@ -82,6 +82,9 @@ struct lmpc_handle {
     int waveCtrSet = 0;         // which of the two (ticket, overflow) counter pairs the next wavefront-kernel launch uses
     int32_t *dRegTable = nullptr;  // hash table of lmpc_distinct_active_sets_device (lmpc_regions.hip): 16 control words + slots
     int regCap = 0;
+    unsigned long long *dRegW1 = nullptr;   // one-word masks: key / count / first-index tables of regW1Cap slots each (clean
+    int regW1Cap = 0;                       // between calls: the publishing kernel resets what it read)
+    int regW1 = 1;                          // tuning: 0 = the ballot-loop kernels also for one-word masks ("region_lockfree")
     int regBlocks = 0;          // tuning: workgroups per CU of the two-level distinct-mask reduction ("region_blocks", 0 = 1)
     long long *hRegOut = nullptr;   // lmpc_discover_regions_device: result block in mapped host memory ...
     long long *dRegOut = nullptr;   // ... and its device address; regOutWords = its size in 64-bit words

@@ -197,6 +197,101 @@ __global__ __launch_bounds__(256) void distinct_masks_kernel(
     }
 }
 
+// ONE-WORD masks (2 m <= 64 bits: every problem the lane kernels cover): the mask is its own key, so no slot is ever
+// "being filled" and nobody waits for anybody -- EVERY lane inserts its own sample: one 64-bit compare-and-swap on the
+// key table (empty -> mask; linear probing), then an atomic add on the slot's count and an atomic min on its first
+// index.  First into a table in the workgroup's LDS, then the workgroup's distinct masks (all its lanes at once) into
+// the global tables; the dense outputs are made by publish_w1_kernel.  The ballot loop of the kernels above spends
+// ~400 cycles per distinct mask and wavefront on its leader's round trips: 150 us per 10^6 samples against 12 here.
+constexpr unsigned long long kW1Empty = ~0ull;       // (no mask: a row is never active at both of its bounds)
+constexpr int kW1Tab = 1024;
+__global__ __launch_bounds__(256) void distinct_masks_w1_kernel(
+    long long N, const uint64_t *__restrict__ active, const int32_t *__restrict__ exitflag, int tcap_mask,
+    unsigned long long *__restrict__ gkey, unsigned long long *__restrict__ gcnt, long long *__restrict__ gfirst,
+    int32_t *__restrict__ overflow, int tiles) {
+    __shared__ unsigned long long lkey[kW1Tab];
+    __shared__ unsigned int lcnt[kW1Tab];
+    __shared__ long long lfirst[kW1Tab];
+    for (int i = threadIdx.x; i < kW1Tab; i += blockDim.x) { lkey[i] = kW1Empty; lcnt[i] = 0u; lfirst[i] = 0x7fffffffffffffffll; }
+    __syncthreads();
+    auto to_global = [&](unsigned long long key, unsigned long long cnt, long long first) {
+        int slot = (int)(mix64(key ^ 0x9e3779b97f4a7c15ull) & (unsigned long long)tcap_mask);
+        for (int probes = 0; probes <= tcap_mask; probes++) {
+            const unsigned long long old = atomicCAS(&gkey[slot], kW1Empty, key);
+            if (old == kW1Empty || old == key) {
+                atomicAdd(&gcnt[slot], cnt);
+                atomicMin(&gfirst[slot], first);
+                return;
+            }
+            slot = (slot + 1) & tcap_mask;
+        }
+        atomicExch(overflow, 1);                             // more distinct masks than slots (4 x capacity)
+    };
+    for (int tl = 0; tl < tiles; tl++) {
+        const long long idx = ((long long)blockIdx.x * tiles + tl) * blockDim.x + threadIdx.x;
+        if (idx >= N) break;
+        if (exitflag != nullptr && exitflag[idx] < 1) continue;
+        const unsigned long long key = active[idx];
+        int slot = (int)(mix64(key ^ 0x9e3779b97f4a7c15ull) & (unsigned long long)(kW1Tab - 1));
+        bool placed = false;
+        for (int probes = 0; probes < kW1Tab; probes++) {
+            const unsigned long long old = atomicCAS(&lkey[slot], kW1Empty, key);
+            if (old == kW1Empty || old == key) {
+                atomicAdd(&lcnt[slot], 1u);
+                atomicMin(&lfirst[slot], idx);
+                placed = true;
+                break;
+            }
+            slot = (slot + 1) & (kW1Tab - 1);
+        }
+        if (!placed) to_global(key, 1ull, idx);              // (more than 1024 distinct masks in one workgroup's share)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kW1Tab; i += blockDim.x)
+        if (lkey[i] != kW1Empty) to_global(lkey[i], (unsigned long long)lcnt[i], lfirst[i]);
+}
+
+// The global tables of distinct_masks_w1_kernel made dense: set_masks / set_count / set_first / n_sets (device), the
+// overflow word, and -- `out` non-null -- the block in mapped host memory publish_sets_kernel writes (same layout).
+// Every slot read is reset: the tables are clean for the next call without a memset.  One workgroup.
+__global__ __launch_bounds__(1024) void publish_w1_kernel(
+    int tcap, int capacity, unsigned long long *__restrict__ gkey, unsigned long long *__restrict__ gcnt,
+    long long *__restrict__ gfirst, uint64_t *__restrict__ set_masks, unsigned long long *__restrict__ set_count,
+    long long *__restrict__ set_first, int32_t *__restrict__ n_sets, int32_t *__restrict__ overflow, long long *__restrict__ out) {
+    __shared__ int found;
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0) { found = 0; total = 0ull; }
+    __syncthreads();
+    unsigned long long mine = 0ull;
+    for (int s = threadIdx.x; s < tcap; s += blockDim.x) {
+        const unsigned long long key = gkey[s];
+        if (key == kW1Empty) continue;
+        const unsigned long long cnt = gcnt[s];
+        const long long first = gfirst[s];
+        gkey[s] = kW1Empty; gcnt[s] = 0ull; gfirst[s] = 0x7fffffffffffffffll;
+        const int k = atomicAdd(&found, 1);
+        if (k < capacity) {
+            set_masks[k] = key; set_count[k] = cnt; set_first[k] = first;
+            if (out) { long long *row = out + 4 + (long long)k * 3; row[0] = (long long)key; row[1] = (long long)cnt; row[2] = first; }
+            mine += cnt;
+        }
+    }
+    atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ov = (found > capacity || *overflow != 0) ? 1 : 0;
+        *n_sets = found;
+        overflow[8] = ov;                                    // (what lmpc_distinct_active_sets_overflowed reads)
+        *overflow = 0;
+        if (out) {
+            out[1] = (long long)ov;
+            out[2] = (long long)total;
+            __threadfence_system();
+            out[0] = (long long)found;
+        }
+    }
+}
+
 // The distinct sets of one call, written by the device straight into mapped host memory: word 0 = sets found (claims,
 // if more than `capacity`), word 1 = overflow word, word 2 = problems counted, then per set its mask, count and first
 // index.  One block; the host reads the block after ONE synchronisation of the stream -- no copy calls.
@@ -231,6 +326,46 @@ __global__ __launch_bounds__(256) void publish_sets_kernel(
 
 extern "C" {
 
+// words == 1 and a large batch: the lock-free per-lane reduction, then the dense outputs (and, `out` non-null, the block
+// in mapped host memory) by one more launch; the tables are handle-owned and clean between calls
+static int distinct_w1(lmpc_handle *h, int64_t N, const uint64_t *active, const int32_t *exitflag, int32_t capacity,
+                       uint64_t *set_masks, int64_t *set_count, int64_t *set_first, int32_t *n_sets, long long *out, hipStream_t st) {
+    using namespace lmpc;
+    int tcap = 64;
+    while (tcap < 4 * (long long)capacity && tcap < (1 << 24)) tcap <<= 1;
+    if (!h->dRegTable) {
+        HIP_TRY(h, hipMalloc(&h->dRegTable, sizeof(int32_t) * ((size_t)64 + 16)));
+        h->regCap = 64;
+        HIP_TRY(h, hipMemsetAsync(h->dRegTable, 0, sizeof(int32_t) * 16, st));
+    }
+    if (tcap != h->regW1Cap) {
+        if (h->dRegW1) { (void)hipStreamSynchronize(st); hipFree(h->dRegW1); }
+        h->dRegW1 = nullptr; h->regW1Cap = 0;
+        HIP_TRY(h, hipMalloc(&h->dRegW1, sizeof(unsigned long long) * 3 * (size_t)tcap));
+        HIP_TRY(h, hipMemsetAsync(h->dRegW1, 0xff, sizeof(unsigned long long) * (size_t)tcap, st));                 // keys: empty
+        HIP_TRY(h, hipMemsetAsync(h->dRegW1 + tcap, 0, sizeof(unsigned long long) * (size_t)tcap, st));             // counts
+        HIP_TRY(h, hipMemsetAsync(h->dRegW1 + 2 * (size_t)tcap, 0x7f, sizeof(unsigned long long) * (size_t)tcap, st));   // first indices: large
+        HIP_TRY(h, hipMemsetAsync(h->dRegTable, 0, sizeof(int32_t) * 16, st));
+        h->regW1Cap = tcap;
+    }
+    unsigned long long *gkey = h->dRegW1, *gcnt = h->dRegW1 + tcap;
+    long long *gfirst = reinterpret_cast<long long *>(h->dRegW1 + 2 * (size_t)tcap);
+    const long long tilesAll = (N + 255) / 256;
+    const long long wantBlocks = (long long)h->numCU * (h->regBlocks > 0 ? h->regBlocks : 2);
+    const int tiles = (int)((tilesAll + wantBlocks - 1) / wantBlocks);
+    const unsigned grid = (unsigned)((tilesAll + tiles - 1) / tiles);
+    hipLaunchKernelGGL(distinct_masks_w1_kernel, dim3(grid), dim3(256), 0, st, (long long)N, active, exitflag, tcap - 1, gkey, gcnt,
+                       gfirst, h->dRegTable, tiles);
+    HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(publish_w1_kernel, dim3(1), dim3(1024), 0, st, tcap, (int)capacity, gkey, gcnt, gfirst, set_masks,
+                       reinterpret_cast<unsigned long long *>(set_count), reinterpret_cast<long long *>(set_first), n_sets,
+                       h->dRegTable, out);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+static bool use_w1(const lmpc_handle *h, int64_t N) { return h->regW1 && h->P.words() == 1 && N >= 65536; }
+
 int lmpc_distinct_active_sets_device(lmpc_handle *h, int64_t N, const uint64_t *active, const int32_t *exitflag,
                                      int32_t capacity, uint64_t *set_masks, int64_t *set_count, int64_t *set_first,
                                      int32_t *n_sets, void *stream) {
@@ -240,6 +375,7 @@ int lmpc_distinct_active_sets_device(lmpc_handle *h, int64_t N, const uint64_t *
         return fail(h, LMPC_ERR_BADARG, "lmpc_distinct_active_sets_device: NULL array, negative N or capacity < 1");
     LMPC_ENTER_DEVICE(h);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (use_w1(h, N)) return distinct_w1(h, N, active, exitflag, capacity, set_masks, set_count, set_first, n_sets, nullptr, st);
     int tcap = 64;
     while (tcap < 4 * (long long)capacity && tcap < (1 << 28)) tcap <<= 1;
     if (tcap > h->regCap) {
@@ -292,6 +428,11 @@ int lmpc_discover_regions_device(lmpc_handle *h, int64_t N, const double *theta,
     h->hRegOut[0] = -1;                                   // "not published yet" until the kernel's last store
     int rc = N > 0 ? lmpc_solve_batch_device(h, N, theta, x, exitflag, nullptr, active, nullptr, stream) : LMPC_OK;
     if (rc != LMPC_OK) return rc;
+    if (use_w1(h, N)) {                                   // (one-word masks: the dense outputs and the host block by one kernel)
+        rc = distinct_w1(h, N, active, exitflag, capacity, set_masks, set_count, set_first, n_sets, h->dRegOut, st);
+        if (rc == LMPC_OK) *result_host = h->hRegOut;
+        return rc;
+    }
     rc = lmpc_distinct_active_sets_device(h, N, active, exitflag, capacity, set_masks, set_count, set_first, n_sets, stream);
     if (rc != LMPC_OK) return rc;
     hipLaunchKernelGGL(publish_sets_kernel, dim3(1), dim3(256), 0, st, h->P.words(), (int)capacity, set_masks,
@@ -307,10 +448,10 @@ int lmpc_distinct_active_sets_overflowed(lmpc_handle *h, void *stream) {
     if (!h) return LMPC_ERR_BADARG;
     if (!h->dRegTable) return 0;
     LMPC_ENTER_DEVICE(h);
-    int32_t o = 0;
-    HIP_TRY(h, hipMemcpyAsync(&o, h->dRegTable, sizeof(o), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    int32_t o[9] = {0};                                   // word 0: this call's flag; word 8: the last publish_w1_kernel's
+    HIP_TRY(h, hipMemcpyAsync(o, h->dRegTable, sizeof(o), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     HIP_TRY(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return o;
+    return o[0] != 0 ? o[0] : o[8];
 }
 
 }  // extern "C"

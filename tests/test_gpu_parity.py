@@ -2247,6 +2247,23 @@ def test_region_discovery_device_pipeline(lmpc):
     m2, c2, f2 = qp.distinct_active_sets_device(torch.from_numpy(np.ascontiguousarray(ref_act(qp, theta[:50000]))).to("cuda:0"),
                                                 capacity=8)
     assert len(m2) == len(np.unique(ref_act(qp, theta[:50000]), axis=0)) and c2.sum() == 50000
+    # one-word masks of a large batch take the lock-free per-lane reduction (round 4): both forms give the same sets, with
+    # a capacity that overflows and is retried, and with problems excluded by their exit flag
+    act_all = torch.from_numpy(np.ascontiguousarray(ref_act(qp, theta))).to("cuda:0")
+    flags = torch.ones(len(theta), dtype=torch.int32, device="cuda:0")
+    flags[::3] = -1
+    keep = np.ones(len(theta), bool); keep[::3] = False
+    want_all = key(ref)
+    um, ui, uc = np.unique(ref_act(qp, theta)[keep], axis=0, return_index=True, return_counts=True)
+    want_kept = sorted((tuple(int(w) for w in m), int(c), int(np.flatnonzero(keep)[i])) for m, c, i in zip(um.view(np.uint64), uc, ui))
+    for lockfree in (1, 0):
+        qp.set_option("region_lockfree", lockfree)
+        for rep in range(2):             # (twice: the tables are handed over clean between calls)
+            m3, c3, f3 = qp.distinct_active_sets_device(act_all, capacity=8)
+            assert sorted((tuple(int(w) for w in m), int(c), int(f)) for m, c, f in zip(m3, c3, f3)) == want_all, (lockfree, rep)
+        m4, c4, f4 = qp.distinct_active_sets_device(act_all, exitflag=flags, capacity=4096)
+        assert sorted((tuple(int(w) for w in m), int(c), int(f)) for m, c, f in zip(m4, c4, f4)) == want_kept, lockfree
+    qp.set_option("region_lockfree", 1)
     # multi-word masks (m = 84 rows: three words) with infeasible points in the batch
     g3 = load_golden("mass_spring_3in")
     q3 = _qp_from_golden(lmpc, g3)
