@@ -32,7 +32,7 @@ the headline is measured, and again, with the per-config summaries, as the LAST 
                         each {value, unit, frac, bound, verified[, gram_value, gram_frac, gram_frac_executed], cpu_1core
                         [, first_run_value]}: pendulum_hard, mass_spring (the reference's example), mass_spring_3in
                         (config 3) and its feasible-dominated companion, game_avi (is_avi), hybrid_f32 (config 5),
-                        pendulum_N50..125 (the reference's benchmark class), two closed loops, region_discovery (config 4)
+                        pendulum_N50..125 (the reference's benchmark class), three closed loops, region_discovery (config 4)
 """
 import argparse
 import json
@@ -608,6 +608,63 @@ def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, g
     return res
 
 
+def avi_closed_loop_config(torch, lmpc, dev, local_rank, nscen, T, want_cpu, ncheck=512, reps=2):
+    """The reference's game-theoretic test as it runs there -- a closed loop (test/runtests.jl:1345-1354:
+    Simulation(mpc; x0 = 10*ones(2), r = [10, 0], N = 500)) -- batched: `nscen` scenarios around that start, `T` steps on
+    the device (lmpc_simulate_device, cold starts: every step runs the register-resident chain), scenario-steps per
+    second.  Verified: the first `ncheck` scenarios against the CPU checker's closed loop bit for bit, and every
+    checked scenario on its way to the reference's end values."""
+    import ctypes
+    from linearmpc_jl_amd._cabi import lib as _lib, check as _check
+    from oracle import avi as oavi
+    g = make_problem("game_kat")
+    nu = int(g["nu"])
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nu,
+                                  device=local_rank)
+    F, G = np.ascontiguousarray(g["F"], np.float64), np.ascontiguousarray(g["G"], np.float64)
+    nx = F.shape[0]
+    rng = np.random.default_rng(0)
+    x0 = np.array([10.0, 10.0]) + rng.uniform(-5, 5, (nscen, 2)); x0[0] = [10.0, 10.0]
+    r0 = np.tile([10.0, 0.0], (nscen, 1))
+    vp = lambda a: ctypes.c_void_p(a)
+    xd0 = torch.from_numpy(x0).to(dev); rd = torch.from_numpy(r0).to(dev)
+    fm = torch.empty(nscen, dtype=torch.int32, device=dev)
+    L_ = _lib()
+    def run():
+        xd = xd0.clone(); up = torch.zeros((nscen, nu), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _check(L_.lmpc_simulate_device(qp._h, nscen, T, nx, 2, nu, vp(F.ctypes.data), vp(G.ctypes.data), vp(xd.data_ptr()),
+                                       vp(rd.data_ptr()), vp(up.data_ptr()), None, None, vp(fm.data_ptr()), 0, None), qp._h)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, xd, up
+    first = run()[0]
+    best, xd, up = min((run() for _ in range(reps)), key=lambda t: t[0])
+    res = {"value": nscen * T / best, "unit": "scenario-steps/s", "ms_per_step": 1e3 * best / T, "scenarios": nscen, "steps": T,
+           "first_run_value": nscen * T / first, "kernel": qp.kernel_name, "dtype": "f64", "warm": False,
+           "min_flag": int(fm.min().item()),
+           "workload": "game_kat: closed loop of the two-player game (non-symmetric H, is_avi), states and references resident "
+                       "on the device, cold start every step, no trajectories recorded"}
+    pk = qp.avi_pack()
+    P = oavi.AVI(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["ML"], pk["MR"], pk["G"], pk["du"], pk["dl"],
+                 pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"])).contiguous()
+    t1 = time.perf_counter()
+    ref = oavi.simulate(P, x0[:ncheck], T, F, G, r=r0[:ncheck], uprev=np.zeros((ncheck, nu)), warm=False)
+    dtc = time.perf_counter() - t1
+    xg = xd[:ncheck].cpu().numpy(); ug = up[:ncheck].cpu().numpy()
+    res["verified"] = bool(np.array_equal(xg, ref["x"]) and np.array_equal(ug, ref["uprev"])
+                           and np.array_equal(fm[:ncheck].cpu().numpy(), ref["flag_min"]) and int(fm.min().item()) >= 1)
+    res["verification"] = {"scenarios": ncheck, "against": "oracle_avi_simulate (cold)",
+                           "final_states_and_inputs_bit_identical": res["verified"],
+                           "max_distance_to_reference_end_values": float(np.abs(xg - [10.0, 0.0]).max())}
+    if want_cpu:
+        res["cpu_baseline"] = {"value": ncheck * T / dtc, "unit": "scenario-steps/s", "cores": 1, "kind": "port",
+                               "sample": f"the same {ncheck} scenarios x {T} steps: oracle/daqp_avi_oracle.c oracle_avi_simulate, "
+                                         f"1 thread ({_cpu_model()})"}
+    qp.close()
+    return res
+
+
 def avi_config(torch, lmpc, dev, local_rank, batch, steps, warmup, want_cpu, cpu_seconds=3.0):
     """The reference's game-theoretic MPC (test/runtests.jl:1337-1358: two players, non-symmetric H, DAQP's is_avi
     mode, /root/reference/src/setup.jl:11-13) as a measured workload: `batch` parameter points (the fixture's
@@ -868,7 +925,7 @@ def compact_line(out):
                                           "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["value_one_call_at_a_time"] = _r(out.get("value_one_call_at_a_time"))
     line["verified"] = out.get("verified")
-    line["config"] = {"workload": str(cfg.get("workload", ""))[:400], "batch_per_gpu": cfg.get("batch_per_gpu"),
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:300], "batch_per_gpu": cfg.get("batch_per_gpu"),
                       "kernel": cfg.get("kernel"), "batches_in_flight": cfg.get("batches_in_flight"),
                       "options": {k: v for k, v in (cfg.get("options") or {}).items() if not k.startswith("_")}}
     if "exchange" in cfg:
@@ -884,7 +941,7 @@ def compact_line(out):
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
-                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:200]}
+                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:140]}
         if "all_cores" in cb:
             line["cpu_baseline"]["all_cores"] = {"value": _r(cb["all_cores"].get("value")), "cores": cb["all_cores"].get("cores")}
     if "configs" in out:
@@ -1311,6 +1368,8 @@ def main():
                 c_["gram_scan"] = closed_loop_config(torch, lmpc, "pendulum_N50", 200_000, 100, dev, local_rank, False, gram=1)
             except Exception as e:
                 c_["gram_scan"] = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
+            _phase("config closed_loop_game_avi")
+            cfg("closed_loop_game_avi", avi_closed_loop_config, torch, lmpc, dev, local_rank, 200_000, 100, want_cpu)
             _phase("config region_discovery")
             cfg("region_discovery", region_discovery_config, torch, lmpc, dev, local_rank, BATCH, want_cpu)
             out["configs"] = cfgs
