@@ -29,7 +29,7 @@ the headline is measured, and again, with the per-config summaries, as the LAST 
                         the HIP-event duration of that call; pipelined_frac = the same bytes / ms_per_step
   cpu_baseline          the C oracle on the host cores (kind "port": libdaqp is not available)
   configs               the other single-GPU BASELINE.json configurations, measured in the same process, one summary
-                        each {value, unit, frac, bound, verified[, gram_value, gram_frac, gram_frac_executed], cpu_1core
+                        each {value, verified[, unit unless solves/s][, frac[, bound unless valu]][, gram_value, gram_frac, gram_frac_executed], cpu_1core
                         [, first_run_value]}: pendulum_hard, mass_spring (the reference's example), mass_spring_3in
                         (config 3) and its feasible-dominated companion, game_avi (is_avi), hybrid_f32 (config 5),
                         pendulum_N50..125 (the reference's benchmark class), three closed loops, region_discovery (config 4)
@@ -917,7 +917,8 @@ def _r(v, sig=6):
 
 def compact_line(out):
     """The ONE bench line of the driver contract, cut down to what the contract names (a few KB): headline fields,
-    roofline, cpu_baseline, and per-config summaries {value, unit, frac, verified[, gram_value, gram_frac]}.  The full
+    roofline, cpu_baseline, and per-config summaries {value, verified[, unit if not solves/s][, frac[, bound if not valu]]
+    [, gram_value, gram_frac]}.  The full
     report (every histogram, verification block and note) goes to bench_full.json and to stderr."""
     cfg = out.get("config", {})
     roof = out.get("roofline", {})
@@ -947,11 +948,14 @@ def compact_line(out):
     if "configs" in out:
         cs = {}
         for name, c in out["configs"].items():
-            e = {"value": _r(c.get("value")), "unit": c.get("unit"), "verified": c.get("verified")}
+            e = {"value": _r(c.get("value")), "verified": c.get("verified")}
+            if c.get("unit") != "solves/s":
+                e["unit"] = c.get("unit")          # (solves/s unless stated)
             r_ = c.get("roofline") or {}
             if "frac" in r_:
                 e["frac"] = _r(r_.get("frac"), 4)
-                e["bound"] = r_.get("bound")
+                if r_.get("bound") != "valu":
+                    e["bound"] = r_.get("bound")   # (valu unless stated)
             if "error" in c:
                 e["error"] = str(c["error"])[:120]
             gs = c.get("gram_scan")
