@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64) void avi_kernel(
         stride = (long long)(gridDim.x / kShards) * 64;
         cnt = (long long)count[shard * kCountStride];
         list += (long long)shard * seg_cap;
+        if (first >= cnt) return;                 // (nothing listed for this wavefront: the usual case behind the lane kernel)
     }
     if constexpr (LDSC) {
         for (int e = lane; e < P.nC; e += 64) lds_pack[e] = C[e];
