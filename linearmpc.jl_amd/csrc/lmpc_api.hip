@@ -1753,7 +1753,7 @@ int lmpc_reserve(lmpc_handle *h, int64_t N, void *stream) {
     if (N == 0) return LMPC_OK;
     LMPC_ENTER_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
-    if (h->avi) return LMPC_OK;                          // (its slabs depend on the launch shape only: first launch)
+    if (h->avi) return avi_reserve(h, N, st);
     if (h->useWave) {
         if (wave_screens(h, N)) { const int rc = ensure_lists(h, N, st); if (rc != LMPC_OK) return rc; }
         const int rcw = wave_reserve(h, N, st);

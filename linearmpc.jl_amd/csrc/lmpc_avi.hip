@@ -148,6 +148,40 @@ static int avi_ensure_lists(lmpc_handle *h, int64_t nprob, hipStream_t st) {
     return LMPC_OK;
 }
 
+// the generic kernel's grid for `tiles` tiles of 64 problems -- one wavefront per workgroup, resident wavefronts bounded
+// by the scratch a slab takes (at most 1 GiB in all), a multiple of kShards behind a work list -- and its slabs
+static int avi_ensure_slabs(lmpc_handle *h, long long tiles, bool listed, hipStream_t st, long long *grid_out) {
+    const AviLayout &A = h->A;
+    const size_t slabR = (size_t)avi_scratch_reals(A.n, A.m, A.cap) * 64, slabI = (size_t)avi_scratch_ints(A.m, A.cap) * 64;
+    long long grid = (long long)h->numCU * (h->aviWaves > 0 ? h->aviWaves : 16);
+    const long long fit = (long long)(((size_t)1 << 30) / (sizeof(double) * slabR + sizeof(int32_t) * slabI));
+    grid = std::min(grid, std::max(1ll, fit));
+    grid = std::min(grid, tiles);
+    if (listed) grid = std::max<long long>(kShards, (grid / kShards) * kShards);      // (fit >= kShards: slabs of small problems)
+    if (grid > h->aviSlabs) {
+        // (grows with the largest batch seen; stream-ordered work of earlier calls on this handle finishes first)
+        if (h->dAviR || h->dAviI) { (void)hipStreamSynchronize(st); hipFree(h->dAviR); hipFree(h->dAviI); }
+        h->dAviR = nullptr; h->dAviI = nullptr; h->aviSlabs = 0;
+        HIP_TRY(h, hipMalloc(&h->dAviR, sizeof(double) * slabR * (size_t)grid));
+        HIP_TRY(h, hipMalloc(&h->dAviI, sizeof(int32_t) * slabI * (size_t)grid));
+        h->aviSlabs = (int)grid;
+    }
+    *grid_out = grid;
+    return LMPC_OK;
+}
+
+// lmpc_reserve on a variational handle: what the first call on a batch of nprob problems would allocate
+int avi_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st) {
+    const long long tiles = (nprob + 63) / 64;
+    long long grid = 0;
+    if (avi_use_tiers(h, nprob, nullptr)) {
+        const int rc = avi_ensure_lists(h, nprob, st);
+        if (rc != LMPC_OK) return rc;
+        return avi_ensure_slabs(h, std::min<long long>(tiles, (long long)h->numCU * 4), true, st, &grid);
+    }
+    return avi_ensure_slabs(h, tiles, false, st, &grid);
+}
+
 static int avi_generic(lmpc_handle *h, int64_t nprob, long long max_tiles, const double *theta, double *x, int32_t *flag,
                        int32_t *iters, uint64_t *active, const uint64_t *warm, const int32_t *list, const int32_t *count,
                        long long seg_cap, int32_t *count_clear, hipStream_t st);
@@ -194,22 +228,8 @@ static int avi_generic(lmpc_handle *h, int64_t nprob, long long tiles, const dou
                        int32_t *iters, uint64_t *active, const uint64_t *warm, const int32_t *list, const int32_t *count,
                        long long seg_cap, int32_t *count_clear, hipStream_t st) {
     const AviLayout &A = h->A;
-    // one wavefront per workgroup, 64 problems per wavefront and round; resident wavefronts bounded by the scratch a
-    // slab takes (at most 1 GiB in all)
-    const size_t slabR = (size_t)avi_scratch_reals(A.n, A.m, A.cap) * 64, slabI = (size_t)avi_scratch_ints(A.m, A.cap) * 64;
-    long long grid = (long long)h->numCU * (h->aviWaves > 0 ? h->aviWaves : 16);
-    const long long fit = (long long)(((size_t)1 << 30) / (sizeof(double) * slabR + sizeof(int32_t) * slabI));
-    grid = std::min(grid, std::max(1ll, fit));
-    grid = std::min(grid, tiles);
-    if (list) grid = std::max<long long>(kShards, (grid / kShards) * kShards);      // (fit >= kShards: slabs of small problems)
-    if (grid > h->aviSlabs) {
-        // (grows with the largest batch seen; stream-ordered work of earlier calls on this handle finishes first)
-        if (h->dAviR || h->dAviI) { (void)hipStreamSynchronize(st); hipFree(h->dAviR); hipFree(h->dAviI); }
-        h->dAviR = nullptr; h->dAviI = nullptr; h->aviSlabs = 0;
-        HIP_TRY(h, hipMalloc(&h->dAviR, sizeof(double) * slabR * (size_t)grid));
-        HIP_TRY(h, hipMalloc(&h->dAviI, sizeof(int32_t) * slabI * (size_t)grid));
-        h->aviSlabs = (int)grid;
-    }
+    long long grid = 0;
+    { const int rcs = avi_ensure_slabs(h, tiles, list != nullptr, st, &grid); if (rcs != LMPC_OK) return rcs; }
     const size_t packBytes = sizeof(double) * (size_t)A.nC;
 #define LMPC_AVI_GO(PK, PX, LDSB)                                                                                          \
     do {                                                                                                                  \

@@ -237,6 +237,7 @@ int launch_avi_tiers(lmpc_handle *h, bool first, int kfirst, unsigned grid, hipS
 bool fast_covers(const lmpc_handle *h);
 void fast_preload();
 void avi_preload(lmpc_handle *h);
+int avi_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st);
 
