@@ -888,10 +888,44 @@ int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, f
     return launch_wave_t<float>(h, h->dCwf, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
 }
 
+// ONE theta, as the reference's online call has it (utils.jl:268-283; compute_control in a Simulation loop): no staging
+// copies and no pipeline -- theta is written into a record of MAPPED host memory the kernels read directly, x and the
+// exit flag are written back into it by the kernels, the host waits for the handle's own stream once.  (Through
+// lmpc_solve_batch a single problem paid three pageable copies on three streams: 70 us against ~20 here.)
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x) {
-    int32_t flag = 0;
-    int rc = lmpc_solve_batch(h, 1, theta, x, &flag, nullptr, nullptr, nullptr);
-    return rc == LMPC_OK ? flag : rc;
+    if (!h) return LMPC_ERR_BADARG;
+    const size_t nth = (size_t)h->P.nth, nout = (size_t)h->P.nout;
+    if (!x || (nth > 0 && !theta)) return fail(h, LMPC_ERR_BADARG, "lmpc_solve_one: NULL array");
+    const size_t oX = (sizeof(double) * nth + 63) & ~(size_t)63, oF = oX + ((sizeof(double) * nout + 63) & ~(size_t)63);
+    if (!h->oneHost) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            return fail(h, LMPC_ERR_NOGPU, "lmpc: no HIP device available (this library has no CPU path)");
+    }
+    LMPC_ENTER_DEVICE(h);
+    if (!h->oneHost) {
+        char *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), oF + 4096, hipHostMallocMapped));
+        std::memset(hp, 0, oF + 4096);
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->oneDev), hp, 0) != hipSuccess ||
+            hipStreamCreateWithFlags(&h->oneStream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipHostFree(hp); h->oneDev = nullptr; h->oneStream = nullptr;
+            return fail(h, LMPC_ERR_HIP, "lmpc_solve_one: mapped record / stream");
+        }
+        h->oneHost = hp;
+    }
+    if (nth) std::memcpy(h->oneHost, theta, sizeof(double) * nth);
+    int32_t *hflag = reinterpret_cast<int32_t *>(h->oneHost + oF);
+    *hflag = LMPC_EXIT_UNFINISHED;
+    const int rc = launch(h, 1, reinterpret_cast<const double *>(h->oneDev), reinterpret_cast<double *>(h->oneDev + oX),
+                          reinterpret_cast<int32_t *>(h->oneDev + oF), nullptr, nullptr, nullptr, h->oneStream);
+    const hipError_t es = hipStreamSynchronize(h->oneStream);      // (also after a failed launch: nothing may still run)
+    if (rc != LMPC_OK) return rc;
+    if (es != hipSuccess) return fail(h, LMPC_ERR_HIP, std::string("lmpc_solve_one: ") + hipGetErrorString(es));
+    const int rcf = check_fast_err(h);
+    if (rcf != LMPC_OK) return rcf;
+    std::memcpy(x, h->oneHost + oX, sizeof(double) * nout);
+    return *hflag;
 }
 
 // per-scenario kept closed-loop state of the wavefront path (working set + factorisation, lmpc_wave_kernel.hpp): makes
@@ -1824,6 +1858,8 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);
+    if (h->oneHost) hipHostFree(h->oneHost);
+    if (h->oneStream) hipStreamDestroy(h->oneStream);
     hipFree(h->dStat);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);
     hipFree(h->ccT2S); hipFree(h->ccTheta); hipFree(h->ccAct); hipFree(h->ccFlag); hipFree(h->obsC);

@@ -183,6 +183,9 @@ struct lmpc_handle {
     int64_t ccStageCap = 0;
     size_t ccStagePer = 0;
     int64_t ccCap = 0, ccWarmN = -1;    // ccWarmN: batch size whose final working sets ccAct holds
+    // lmpc_solve_one: ONE record in mapped host memory (theta in, x and flag out), its device address, its own stream
+    char *oneHost = nullptr, *oneDev = nullptr;
+    hipStream_t oneStream = nullptr;
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
     bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling
