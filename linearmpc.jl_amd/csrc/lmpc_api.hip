@@ -1435,6 +1435,47 @@ int lmpc_compute_control(lmpc_handle *h, int64_t N, double *control, const doubl
     // one staging block per handle, kept between calls (a closed loop calls this once per time step):
     // [control | state | reference | disturbance | parameter] doubles, then the flags
     const size_t per = (size_t)nu + h->ccNx + wr + h->ccNd + h->ccNp;
+    if ((size_t)N * per * sizeof(double) <= (size_t)64 * 1024) {
+        // a handful of problems -- the generated controller's call, one state per time step (mpc_update_qp.c:29-54): the
+        // block lives in MAPPED host memory, the kernels read the arguments and write control and flags straight
+        // through it, the host waits once for the handle's own stream (seven blocking copies before: ~100 us a call)
+        const size_t need = ((size_t)N * per * sizeof(double) + 63 & ~(size_t)63) + sizeof(int32_t) * (size_t)N + 4096;
+        if (need > h->ccMapBytes) {
+            if (h->ccMapHost) { (void)hipDeviceSynchronize(); (void)hipHostFree(h->ccMapHost); }
+            h->ccMapHost = h->ccMapDev = nullptr; h->ccMapBytes = 0;
+            char *hp = nullptr;
+            HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), need, hipHostMallocMapped));
+            if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ccMapDev), hp, 0) != hipSuccess) {
+                (void)hipHostFree(hp); h->ccMapDev = nullptr;
+                return fail(h, LMPC_ERR_HIP, "lmpc_compute_control: mapped block");
+            }
+            h->ccMapHost = hp; h->ccMapBytes = need;
+        }
+        if (!h->oneStream) HIP_TRY(h, hipStreamCreateWithFlags(&h->oneStream, hipStreamNonBlocking));
+        size_t off = 0;
+        auto put = [&](const double *src, size_t w) -> double * {
+            if (!src || w == 0) return nullptr;
+            std::memcpy(h->ccMapHost + off, src, sizeof(double) * (size_t)N * w);
+            double *d = reinterpret_cast<double *>(h->ccMapDev + off);
+            off += sizeof(double) * (size_t)N * w;
+            return d;
+        };
+        double *dc = put(control, (size_t)nu), *ds = put(state, (size_t)h->ccNx), *dr = put(reference, wr),
+               *dd = put(disturbance, (size_t)h->ccNd), *dp = put(affine_parameter, (size_t)h->ccNp);
+        const size_t oF = (off + 63) & ~(size_t)63;
+        int32_t *hf = reinterpret_cast<int32_t *>(h->ccMapHost + oF);
+        for (int64_t i = 0; i < N; i++) hf[i] = LMPC_EXIT_UNFINISHED;
+        const int rc = lmpc_compute_control_device(h, N, dc, ds, dr, dd, dp, reinterpret_cast<int32_t *>(h->ccMapDev + oF), warm,
+                                                   h->oneStream);
+        const hipError_t es = hipStreamSynchronize(h->oneStream);
+        if (rc != LMPC_OK) return rc;
+        if (es != hipSuccess) return fail(h, LMPC_ERR_HIP, std::string("lmpc_compute_control: ") + hipGetErrorString(es));
+        const int rcf = check_fast_err(h);
+        if (rcf != LMPC_OK) return rcf;
+        std::memcpy(control, h->ccMapHost, sizeof(double) * (size_t)N * nu);
+        if (exitflag) std::memcpy(exitflag, hf, sizeof(int32_t) * (size_t)N);
+        return LMPC_OK;
+    }
     if (N > h->ccStageCap || per > h->ccStagePer) {
         hipFree(h->ccStage); hipFree(h->ccStageFlag);       // (ccObsScratch is another entry point's buffer)
         h->ccStage = nullptr; h->ccStageFlag = nullptr; h->ccStageCap = 0; h->ccStagePer = 0;
@@ -1859,6 +1900,7 @@ void lmpc_free(lmpc_handle *h) {
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);
     if (h->oneHost) hipHostFree(h->oneHost);
+    if (h->ccMapHost) hipHostFree(h->ccMapHost);
     if (h->oneStream) hipStreamDestroy(h->oneStream);
     hipFree(h->dStat);
     hipFree(h->simTheta); hipFree(h->simTheta2); hipFree(h->simU); hipFree(h->simFG); hipFree(h->simFlag); hipFree(h->simAct); hipFree(h->simK);

@@ -186,6 +186,10 @@ struct lmpc_handle {
     // lmpc_solve_one: ONE record in mapped host memory (theta in, x and flag out), its device address, its own stream
     char *oneHost = nullptr, *oneDev = nullptr;
     hipStream_t oneStream = nullptr;
+    // lmpc_compute_control with a handful of problems (the generated controller's one call per time step): its five
+    // argument arrays and the flags in mapped host memory likewise
+    char *ccMapHost = nullptr, *ccMapDev = nullptr;
+    size_t ccMapBytes = 0;
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
     bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling
