@@ -230,13 +230,6 @@ __global__ __launch_bounds__(256) void avi_tiers_kernel(
         asm volatile("" : "+s"(zofs));
         const double *Cz = C + zofs;
         avi_small_bounds<N>(P, Cz, th, nth, nout, dup, dlo, shx);
-        // the next tile's records on their way into the caches while this one is solved: one dummy load per 128-byte line
-        double touch = 0.0;
-        if constexpr (!LIST) {
-            const long long nb = base + stride;
-            const long long off = (long long)lane * 16;
-            if (nb < cnt && off < 64ll * nth && nb * nth + off < nprob * nth) touch = theta[nb * nth + off];
-        }
         // ---- iteration 1: empty working set, both iterates 0
         double min_val = -ptol;
         int add = -1;
@@ -376,7 +369,6 @@ __global__ __launch_bounds__(256) void avi_tiers_kernel(
             avi_small_output<N>(P, C + zofs, shx, nout, pid, ufin, iter_fin, act_fin, low_fin, X, exitflag, iters, active);
         avi_push_write(pend, lane, shard, seg_cap, list_out);          // (the tile before's)
         avi_push_reserve(pend, mine && !finished, pid, lane, shard, count_out);
-        asm volatile("" ::"v"(touch));
     }
     avi_push_write(pend, lane, shard, seg_cap, list_out);
 }
