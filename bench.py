@@ -546,7 +546,7 @@ def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, g
     g = make_problem(name)
     qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1,
                                   device=local_rank)
-    if qp.kernel_name == "wave":
+    if qp.kernel_name.endswith("wave"):
         qp.set_option("gram_scan", gram)
     rng = np.random.default_rng(0)
     if "n_closed_loop" in g:
@@ -579,7 +579,7 @@ def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, g
     res = {"value": nscen * T / best, "unit": "scenario-steps/s", "ms_per_step": 1e3 * best / T, "scenarios": nscen, "steps": T,
            "first_run_value": nscen * T / first,
            "kernel": qp.kernel_name, "dtype": "f64", "warm": True, "min_flag": int(fm.min().item()),
-           "options": ({"gram_scan": gram} if qp.kernel_name == "wave" else {}),
+           "options": ({"gram_scan": gram} if qp.kernel_name.endswith("wave") else {}),
            "workload": f"{name}: closed loop, states and references resident on the device, no trajectories recorded"}
     # verification against the checker's closed loop on the first scenarios
     from oracle import ldp as oldp
@@ -589,8 +589,8 @@ def closed_loop_config(torch, lmpc, name, nscen, T, dev, local_rank, want_cpu, g
     pk = qp.ldp()                      # the handle's own LDP (what the tests compare on): same pack, same bits
     Lq = oldp.LDP(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["M"], pk["du"], pk["dl"], pk["Dth"],
                   pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"]))
-    so = oldp.default_settings(); so.mode = 1 if (gram and qp.kernel_name == "wave") else 0
-    owarm = 2 if qp.kernel_name == "wave" else True
+    so = oldp.default_settings(); so.mode = 1 if (gram and qp.kernel_name.endswith("wave")) else 0
+    owarm = 2 if qp.kernel_name.endswith("wave") else True
     t1 = time.perf_counter()
     ref = oldp.simulate(Lq, x0[:ncheck], T, F, G, r=r0[:ncheck], uprev=np.zeros((ncheck, 1)), settings=so, warm=owarm)
     dtc = time.perf_counter() - t1
@@ -840,7 +840,7 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
     verification = w.verify_steps([steps - 1], per_step=2048)
     solo = w.single_launch(max(3, min(steps, 20)))
     value = batch * steps / el
-    wave = w.kernel == "wave"
+    wave = w.kernel.endswith("wave")
     dtype = "f32" if f32 else "f64"
     call_ms = solo[1]
     if wave:     # VALU-bound kernel: flop roofline against the dense vector peak
@@ -862,7 +862,7 @@ def side_config(torch, lmpc, workload, batch, dev, local_rank, steps, warmup, f3
            "workload": describe(w), **dist_info, "roofline": roof, "verified": verification["verified"],
            "verification": verification, "options": dict(w.options),
            "first_run_value": batch / first_call_s, "first_call_ms": 1e3 * first_call_s}
-    if w.kernel == "wave" and hasattr(w.qp, "wave_stats"):
+    if w.kernel.endswith("wave") and hasattr(w.qp, "wave_stats"):
         out["wave_stats"] = w.qp.wave_stats()       # working-set sizes seen; first_pass_rows > 0: two passes
     if want_cpu:
         _phase(f"config {workload}: cpu baseline")
@@ -1241,7 +1241,7 @@ def main():
         bytes_call = W.bytes_per * n_local
         gbs = lambda ms: bytes_call / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         dist_info, flop_est = W.work_distribution()
-        wave = W.kernel == "wave"
+        wave = W.kernel.endswith("wave")
         dtype = "f32" if args.f32 else "f64"
         roof = {"bound": "hbm", "achieved": gbs(step_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs(step_ms) / HBM_PEAK_GBS, "traffic": None,

@@ -113,6 +113,15 @@ int finalize_handle(lmpc_handle *h) {
     // 1.69e8 vs 1.60e8).  lmpc_set_option("wave", 0 | 1) overrides.
     const bool manyGeneralRows = P.ms < P.m && (long long)P.m * P.n >= 600;
     h->useWave = !laneOk || (waveOk && manyGeneralRows);
+    // ... and in front of the wavefront kernel, for exactly that class (small n, many rows, nothing but plain hard rows):
+    // straight-line tiers with one problem per lane (lmpc_qp_tiers_kernel.hpp)
+    h->qpTiersOk = false;
+    if (laneOk && waveOk && P.n >= 2 && P.n <= 12 && P.m <= 64 && P.nth >= 1 && P.nth <= 16 &&
+        qp_tiers_lds_bytes(P.n, P.m) <= (size_t)160 * 1024) {
+        bool plain = true;
+        for (int j = 0; j < P.m; j++) plain = plain && P.sense[j] == 0;
+        h->qpTiersOk = plain;
+    }
     LMPC_ENTER_DEVICE(h);                              // the caller's current device comes back when setup returns
     {
         hipDeviceProp_t prop;
@@ -418,6 +427,44 @@ int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, dou
     return rc;
 }
 
+// Small problems with many rows (lmpc_qp_tiers_kernel.hpp): the tiers pass over the whole batch -- it finishes what the
+// screening pass would and every problem on an append-only path, optimal or infeasible -- then the wavefront kernel on
+// its work list.  Cold plain binary64 solves in the n-chain form only.
+bool qp_tiers_applies(const lmpc_handle *h, int64_t nprob, const double *x, const int32_t *flag, const uint64_t *warm) {
+    return h->qpTiersOk && h->qpTiers && h->useWave && !h->waveGram && !h->bnb && warm == nullptr && x != nullptr &&
+           flag != nullptr && h->asyncPhase == 0 && h->L.sim.FG == nullptr && h->waveSim.FG == nullptr && !h->keepOn &&
+           h->L.gat.state == nullptr && h->S.iter_limit > h->P.n + 2 && nprob < (int64_t)0x7fffffff && h->screen;
+}
+
+int launch_wave_tiered(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+                       uint64_t *active, hipStream_t st) {
+    const int rc0 = ensure_lists(h, nprob, st);
+    if (rc0 != LMPC_OK) return rc0;
+    EventTriple ev{};
+    if (h->prof) {
+        HIP_TRY(h, pool_event(h, &ev.a));
+        HIP_TRY(h, pool_event(h, &ev.mid));
+        HIP_TRY(h, pool_event(h, &ev.b));
+        HIP_TRY(h, hipEventRecord(ev.a, st));
+    }
+    int32_t *cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+    int32_t *cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+    h->countSet ^= 1;
+    int rc = launch_qp_tiers(h, nprob, theta, x, flag, iters, active, h->dList, cnt_now, lane_seg_cap(nprob), st, false);
+    if (h->prof) HIP_TRY(h, hipEventRecord(ev.mid, st));
+    if (rc == LMPC_OK) {
+        h->waveList.list = h->dList; h->waveList.count = cnt_now; h->waveList.count_next = cnt_next;
+        h->waveList.seg_cap = lane_seg_cap(nprob);
+        rc = launch_wave(h, nprob, theta, x, flag, iters, active, nullptr, st);
+        h->waveList = WaveList{};
+    }
+    if (h->prof) {
+        if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+        else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+    }
+    return rc;
+}
+
 // First large batch of a FRESH wavefront-kernel handle: whether a batch first runs at a smaller working-set capacity (two
 // passes, lmpc_wave_launch.hpp) is decided from the working-set sizes the handle has seen -- and a fresh handle has
 // seen none, so its first calls ran in one pass (pendulum N = 50: 7.2e7 against 1.3e8 solves/s) until a launch or two
@@ -541,6 +588,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             const int rcp = wave_probe(h, theta, nprob, st);
             if (rcp != LMPC_OK) return rcp;
         }
+        if (qp_tiers_applies(h, nprob, x, flag, warm)) return launch_wave_tiered(h, nprob, theta, x, flag, iters, active, st);
         return wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
                                       : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
     }
@@ -682,6 +730,8 @@ static void preload_code(lmpc_handle *h) {
     if (h->avi) avi_preload(h);
     else {
         if (fast_covers(h)) fast_preload();
+        if (h->qpTiersOk && h->useWave)
+            (void)launch_qp_tiers(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
         if (h->dCw && h->useWave) {
             h->preloadOnly = true;
             (void)launch_wave(h, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1696,7 +1746,15 @@ int lmpc_wave_stats(lmpc_handle *h, unsigned long long out[5]) {
 const char *lmpc_kernel_name(const lmpc_handle *h) {
     if (!h) return "";
     if (h->avi) return h->kname.c_str();          // "avi" / "avi+prox"
-    if (h->useWave) return "wave";
+    if (h->useWave) {
+        // (small problems with many rows: cold plain binary64 batches pass through the tiers kernel first)
+        if (h->qpTiersOk && h->qpTiers && !h->waveGram && !h->bnb) {
+            thread_local std::string wname;
+            wname = "qp_tiers<" + std::to_string(h->P.n) + ">|wave";
+            return wname.c_str();
+        }
+        return "wave";
+    }
     // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm
     // starts, closed loop, generated-controller call) the two-kernel form
     if (fast_covers(h)) {
@@ -1808,6 +1866,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "region_lockfree") == 0) { h->regW1 = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
+    if (std::strcmp(name, "qp_tiers") == 0) { h->qpTiers = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers") == 0) { h->aviTiers = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers_first") == 0) {
         h->aviTiersFirst = value < 0 ? -1 : (value > 3 ? 3 : value); h->aviTiersOcc[0] = 0; return LMPC_OK;
@@ -1895,7 +1954,7 @@ void lmpc_free(lmpc_handle *h) {
     for (auto &e : h->eventPool) hipEventDestroy(e);
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
-    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dRegW1); hipFree(h->dFastCtr);
+    hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dRegW1); hipFree(h->dQpScan); hipFree(h->dFastCtr);
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);

@@ -190,6 +190,11 @@ struct lmpc_handle {
     // argument arrays and the flags in mapped host memory likewise
     char *ccMapHost = nullptr, *ccMapDev = nullptr;
     size_t ccMapBytes = 0;
+    // small problems with many rows on the wavefront path: straight-line tiers, one problem per lane, in front of it
+    // (lmpc_qp_tiers_kernel.hpp)
+    bool qpTiersOk = false;     // the problem qualifies (n = 2 .. 12, m <= 64 hard rows without flags, nth <= 16)
+    double *dQpScan = nullptr;  // ... its scan pack (rows of M with their bounds), built with the first launch
+    int qpTiers = 1;            // tuning: 0 = screening pass + wavefront kernel as before ("qp_tiers"; same results)
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
     bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling
@@ -243,6 +248,9 @@ int launch_avi_tiers(lmpc_handle *h, bool first, int kfirst, unsigned grid, hipS
 // one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
 bool fast_covers(const lmpc_handle *h);
 void fast_preload();
+size_t qp_tiers_lds_bytes(int n, int m);
+int launch_qp_tiers(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
+                    uint64_t *active, int32_t *list, int32_t *count, long long seg_cap, hipStream_t st, bool preload);
 void avi_preload(lmpc_handle *h);
 int avi_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,

@@ -65,7 +65,7 @@ def test_gram_form_hard_rows(lmpc, name):
     g = load_golden(name)
     qp = _qp_from_golden(lmpc, g)
     qp.set_option("wave", 1)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     x, ef, it, act = _compare_gram(qp, g["theta"])
     _against_chain_form(qp, g["theta"], x, ef, it, act, 1e-6 if name == "x0unc_kat" else TOL)
     ok = ef >= 1
@@ -106,7 +106,7 @@ def test_gram_form_reference_benchmark_class(lmpc, N):
     g = load_golden(f"pendulum_N{N}")
     theta = g["theta"]
     qp = _qp_from_golden(lmpc, g, 1)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     for scr in (1, 0):
         qp.set_option("screen_wave", scr)
         x, ef, it, act = _compare_gram(qp, theta)
@@ -132,7 +132,7 @@ def test_gram_form_random_problems(lmpc, n, mg, nth, nsoft, seed):
     big = mg > 128
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, (2 if big else 1) * bu, (2 if big else 1) * bl,
                                   (0.3 if big else 1.0) * W, sense, nout=min(n, 4))
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     theta = rng.uniform(-2, 2, (400, nth))
     x, ef, it, act = _compare_gram(qp, theta)
     assert (ef >= 1).mean() > 0.05
@@ -311,7 +311,7 @@ def test_wave_path_closed_loop_random_shapes_keep_and_mask_start(lmpc, gram):
         f_theta *= 0.6
         qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
         qp.set_option("wave", 1)
-        assert qp.kernel_name == "wave"
+        assert qp.kernel_name.endswith("wave")
         qp.set_option("gram_scan", gram)
         Fm = rng.standard_normal((nx, nx))
         Fm *= 0.9 / np.abs(np.linalg.eigvals(Fm)).max()
@@ -349,7 +349,7 @@ def test_wave_path_closed_loop_kept_factor_through_the_64_row_limit(lmpc, gram):
     W[n:, 0] = np.abs(W[n:, 0]) + 0.5                    # theta_0 >> 0 pushes every soft row over its bound
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=2)
     qp.set_option("gram_scan", gram)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     N, T = 150, 30
     x0 = np.vstack([rng.uniform(-1, 1, (60, 2)), np.hstack([rng.uniform(20, 60, (N - 60, 1)), rng.uniform(-1, 1, (N - 60, 1))])])
     Fm = np.array([[0.8, 0.05], [0.0, 0.7]])
@@ -454,7 +454,7 @@ def test_closed_loop_run_ahead_is_exact_after_the_handle_has_statistics(lmpc):
     f_theta *= 0.6
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nu)
     qp.set_option("gram_scan", 1)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     Fm = np.diag([0.9, 0.8, 0.7, 0.6]) + 0.02 * rng.standard_normal((4, 4))
     Gm = 0.3 * rng.standard_normal((4, 1))
     N, T = 6000, 15

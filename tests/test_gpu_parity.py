@@ -267,7 +267,7 @@ def test_wave_kernel_matches_oracle_and_lane_kernel(lmpc, name):
     xl, efl, itl, actl = qp.solve(g["theta"])
     assert "lane" in qp.kernel_name
     qp.set_option("wave", 1)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     xw, efw, itw, actw = _compare(qp, g["theta"])
     assert np.array_equal(xw, xl) and np.array_equal(efw, efl) and np.array_equal(itw, itl)
     assert np.array_equal(actw, actl)
@@ -320,7 +320,7 @@ def test_K8_soft_constraints_through_c_abi(lmpc):
                    nx=2, nu=1, nr=2, nuprev=1)
     u = mpc.compute_control([0.5, 1.0], r=[0.0, 0.0])
     assert abs(u[0] + 1.0) < 1e-6
-    assert mpc.opt_model.kernel_name == "wave"
+    assert mpc.opt_model.kernel_name.endswith("wave")
     x, ef, it, act = _compare(mpc.opt_model, g["theta"])
     assert (ef == 2).any() and (ef == 1).any() and (ef == -1).any()
     ok = g["exitflag"] >= 1
@@ -341,7 +341,7 @@ def test_wave_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
     rng = np.random.default_rng(seed)
     H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=min(n, 4))
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     theta = rng.uniform(-2, 2, (600, nth))
     x, ef, it, act = _compare(qp, theta)
     assert (ef >= 1).mean() > 0.05
@@ -359,7 +359,7 @@ def test_wave_kernel_many_rows(lmpc, n, mg, nth, nsoft, seed):
     rng = np.random.default_rng(seed)
     H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 2 * bu, 2 * bl, 0.3 * W, sense, nout=min(n, 4))
-    assert qp.kernel_name == "wave" and qp.m == n + mg
+    assert qp.kernel_name.endswith("wave") and qp.m == n + mg
     theta = rng.uniform(-2, 2, (300, nth))
     x, ef, it, act = _compare(qp, theta)
     assert (ef >= 1).mean() > 0.05 and (ef != -7).all()
@@ -584,7 +584,7 @@ def test_K2_prestabilising_feedback_through_c_abi(lmpc):
     unom = nominal.compute_control([0.0, 0.0], r=[1.0, 0.0])
     upre = prestab.compute_control([0.0, 0.0], r=[1.0, 0.0])
     assert np.linalg.norm(unom - upre) < 1e-10
-    assert prestab.opt_model.kernel_name == "wave" and prestab.opt_model.ms == 0      # bounds are general rows
+    assert prestab.opt_model.kernel_name.endswith("wave") and prestab.opt_model.ms == 0      # bounds are general rows
     # batched path with K folded into the output map, against the oracle on the same pack
     cm = prestab.control_model()
     x, ef, it, act = _compare(cm, g["theta"])
@@ -694,7 +694,7 @@ def test_broken_working_set_is_never_reported_optimal(lmpc):
     # hard rows to primal_tol in the normalised constraint space)
     g = load_golden("mass_spring_3in")
     qp = _qp_from_golden(lmpc, g)
-    assert qp.kernel_name == "wave" and (qp.n, qp.m) == (30, 84)
+    assert qp.kernel_name.endswith("wave") and (qp.n, qp.m) == (30, 84)
     rng = np.random.default_rng(1234)
     theta = rng.uniform(-3, 3, (3000, 12))
     x, ef, it, act = _compare(qp, theta)
@@ -715,7 +715,7 @@ def test_hybrid_branch_and_bound_matches_oracle(lmpc, name):
     # /root/reference/test/runtests.jl:820-834; binaries of mpc_examples.jl:533-546
     g = load_golden(name)
     qp = _qp_from_golden(lmpc, g)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     x, ef, it, act = _compare(qp, g["theta"])
     assert np.all(ef == 1)
     bins = np.flatnonzero(g["senses"] & 16)
@@ -765,7 +765,7 @@ def test_hybrid_random_problems_with_general_rows(lmpc):
         sense = sense.copy()
         sense[:3] |= 16                                                    # first three bounds binary
         qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense)
-        assert qp.kernel_name == "wave"
+        assert qp.kernel_name.endswith("wave")
         theta = rng.uniform(-1, 1, (200, nth))
         x, ef, it, act = _compare(qp, theta)
         ok = ef >= 1                                                       # trial 1 is infeasible throughout
@@ -967,7 +967,7 @@ def test_K5_closed_loops_on_the_gpu(lmpc):
     # (a) runtests.jl:1067-1074: x1 -> 0.4 (soft, tightened output bound), many scenarios at once
     g = load_golden("x0unc_kat")
     qp = _qp_from_golden(lmpc, g, 1)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     N = 16
     out = qp.simulate(np.zeros((N, 2)), 400, g["F"], g["G"], r=np.full((N, 1), 0.5), warm=False, want_x=False)
     assert np.all(out["flag_min"] >= 1) and np.abs(out["x"][:, 0] - 0.4).max() < 1e-6
@@ -1238,7 +1238,7 @@ def test_randomized_differential_against_the_oracle(lmpc):
         except lmpc.LmpcError as e:
             assert e.code in (-1, -6), e                     # setup flags of DAQP (infeasible bounds / dependent equalities)
             continue
-        kinds["wave" if qp.kernel_name == "wave" else "lane"] += 1
+        kinds["wave" if qp.kernel_name.endswith("wave") else "lane"] += 1
         theta = rng.uniform(-2, 2, (257, max(nth, 0))) if nth else np.zeros((257, 0))
         x, ef, it, act = _compare(qp, theta)
         seen_flags |= set(np.unique(ef).tolist())
@@ -1848,7 +1848,7 @@ def test_reference_benchmark_class_long_horizons(lmpc, N):
     g = load_golden(f"pendulum_N{N}")
     theta = g["theta"]
     qp = _qp_from_golden(lmpc, g, 1)
-    assert qp.kernel_name == "wave" and qp.n == N and qp.m == 3 * N - 2
+    assert qp.kernel_name.endswith("wave") and qp.n == N and qp.m == 3 * N - 2
     x, ef, it, act = _compare(qp, theta)                         # bit-level against the oracle on the library's pack
     assert np.all(ef >= 1)
     # against the committed answers (oracle on the numpy pack: 1/rho = 1e6 amplifies the 1e-16 between the packs)
@@ -1877,7 +1877,7 @@ def test_wave_kernel_two_variable_slots_random_problems(lmpc, n, mg, nsoft):
     sense = sense.copy()
     sense[n:n + nsoft] |= 8
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, 2 * bu, 2 * bl, 0.3 * W, sense, nout=min(n, 70))
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     theta = rng.uniform(-1.5, 1.5, (160, 5))
     x, ef, it, act = _compare(qp, theta)
     ok = ef >= 1
@@ -2010,7 +2010,7 @@ def test_screening_pass_in_front_of_wave_kernel(lmpc, n, mg, nth, nsoft, nout, i
     if imm:
         sense[[3, n + 70, n + mg - 1]] |= 4        # IMMUTABLE: never enters the working set, may be violated
     qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=nout)
-    assert qp.kernel_name == "wave"
+    assert qp.kernel_name.endswith("wave")
     for N in (1, 63, 257, 3000):
         # a mix: most points close to the origin (nothing violated), some far out (iterations needed)
         theta = rng.standard_normal((N, nth)) * np.where(rng.random(N) < 0.6, 0.05, 1.5)[:, None]
@@ -2570,5 +2570,51 @@ def test_register_resident_variational_kernels_against_generic_kernel_and_oracle
             assert np.array_equal(ef, efo) and np.array_equal(it, ito), (trial, limit)
             ok = efo >= 1
             assert np.array_equal(x[ok], xo[ok]) and np.array_equal(act[ok], acto[ok]), (trial, limit)
+        qp.close()
+
+
+def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
+    """Small problems with many plain hard rows on the wavefront path (the reference's mass_spring example is the model:
+    n = 10, m = 63) first go through straight-line tiers, one problem per lane (lmpc_qp_tiers_kernel.hpp), which finish
+    every problem on an append-only path -- optimal (1) or infeasible (-1) -- and queue the rest for the wavefront
+    kernel.  n = 2 .. 12 (forced onto the wavefront path where the lane kernels would be the default), m up to 64,
+    wide and narrow theta ranges, ragged batches: the same bits as the path without the pass and as the oracle --
+    x also on the failed points, flags, iteration counts, active sets; settings that rule the pass out (an iteration
+    limit inside its reach, a warm start) fall back by themselves."""
+    import torch
+    from oracle import ldp as oldp
+    rng = np.random.default_rng(404)
+    dev = torch.device("cuda", 0)
+    for trial in range(22):
+        n = 2 + trial % 11
+        mg = int(rng.integers(1, 64 - n + 1)); nth = int(rng.integers(1, 17))
+        H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth)
+        scale = rng.choice([0.5, 1.0, 3.0])
+        qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, scale * bu, scale * bl, W, sense, nout=int(rng.integers(1, n + 1)))
+        qp.set_option("wave", 1)
+        assert qp.kernel_name == "qp_tiers<%d>|wave" % n, qp.kernel_name
+        L = oracle_ldp_from(qp.ldp())
+        for N, amp in ((3000, 2.0), (4097, 8.0), (65, 1.0), (1, 4.0)):
+            th = np.ascontiguousarray(rng.uniform(-amp, amp, (N, nth)))
+            xo, efo, ito, acto = oldp.solve_batch(L, th)
+            t = torch.from_numpy(th).to(dev)
+            for tiers in (1, 0):
+                qp.set_option("qp_tiers", tiers)
+                it = torch.full((N,), -77, dtype=torch.int32, device=dev)
+                act = torch.full((N, qp.words), -1, dtype=torch.int64, device=dev)
+                x, ef = qp.solve_device(t, iters=it, active=act)
+                torch.cuda.synchronize()
+                assert np.array_equal(ef.cpu().numpy(), efo), (trial, N, tiers)
+                assert np.array_equal(it.cpu().numpy(), ito), (trial, N, tiers)
+                assert np.array_equal(act.cpu().numpy().view(np.uint64), acto.view(np.uint64)), (trial, N, tiers)
+                assert np.array_equal(x.cpu().numpy(), xo), (trial, N, tiers)
+        qp.set_option("qp_tiers", 1)
+        th = np.ascontiguousarray(rng.uniform(-6, 6, (2000, nth)))
+        s = lmpc.default_settings(); s.iter_limit = n + 2; qp.set_settings(s)          # the pass needs iter_limit > n + 2
+        so = oldp.default_settings(); so.iter_limit = n + 2
+        _compare(qp, th, settings=so)
+        s.iter_limit = 10000; qp.set_settings(s)
+        x, ef, it, act = _compare(qp, th)
+        _compare(qp, th, warm=act)                                                       # warm: wavefront kernel alone
         qp.close()
 

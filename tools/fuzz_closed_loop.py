@@ -41,7 +41,7 @@ for trial in range(trials):
     except lmpc.LmpcError:
         continue
     qp.set_option("wave", 1)
-    if qp.kernel_name != "wave":
+    if not qp.kernel_name.endswith("wave"):
         continue
     qp.set_option("gram_scan", gram)
     Fm = rng.standard_normal((nx, nx)); Fm *= rng.uniform(0.5, 0.97) / np.abs(np.linalg.eigvals(Fm)).max()

@@ -83,7 +83,7 @@ for trial in range(trials):
     theta = rng.uniform(-2, 2, (193, nth))
     L = oracle_ldp_from(qp.ldp())
     so = copy_settings(st) if f32 else oldp.default_settings()
-    if gram and (f32 or qp.kernel_name == "wave"):     # (the lane kernels have one form)
+    if gram and (f32 or qp.kernel_name.endswith("wave")):     # (the lane kernels have one form)
         qp.set_option("gram_scan", 1)
         so.mode = 1
     try:
@@ -96,7 +96,7 @@ for trial in range(trials):
             x, ef, it, act = qp.solve(theta)
             xo, efo, ito, acto = oldp.solve_batch(L, theta, so)
             tol = 1e-10
-            stats["wave" if qp.kernel_name == "wave" else "lane"] += 1
+            stats["wave" if qp.kernel_name.endswith("wave") else "lane"] += 1
     except lmpc.LmpcError as e:
         assert e.code == -103 and f32, e          # binary32 needs the wavefront kernel
         continue
@@ -108,7 +108,7 @@ for trial in range(trials):
         xw, efw, itw, actw = qp.solve(theta[sel][:64], warm=act[sel][:64])
         xq, efq, itq, actq = oldp.solve_batch(L, theta[sel][:64], so, warm=act[sel][:64])
         ok = np.array_equal(efw, efq) and np.array_equal(itw, itq) and np.array_equal(actw, actq) and np.abs(xw - xq).max() <= tol
-    if ok and not bnb and (f32 or qp.kernel_name == "wave"):
+    if ok and not bnb and (f32 or qp.kernel_name.endswith("wave")):
         # the wavefront kernel in two passes, forced at a random first-pass capacity, alternating with one pass on the same
         # handle: never visible in a result
         for tp, c1 in ((1, int(rng.choice([8, 12, 16, 24, 32, 48]))), (0, 0), (1, int(rng.choice([8, 16, 24, 40]))), (1, 24), (0, 0)):
@@ -124,7 +124,7 @@ for trial in range(trials):
         stats["two_pass_legs"] = stats.get("two_pass_legs", 0) + 5
     for k, c in zip(*np.unique(ef, return_counts=True)):
         flags_seen[int(k)] = flags_seen.get(int(k), 0) + int(c)
-    if gram and not f32 and qp.kernel_name == "wave":
+    if gram and not f32 and qp.kernel_name.endswith("wave"):
         qp.set_option("gram_scan", 0)
         x0, ef0, it0, act0 = qp.solve(theta)
         s0 = ef0 >= 1

@@ -42,7 +42,7 @@ else:
     prob = omm.pendulum()
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=1)
 print("kernel:", qp.kernel_name)
-if qp.kernel_name == "wave":
+if qp.kernel_name.endswith("wave"):
     qp.set_option("screen_wave", a.screen_wave)
     qp.set_option("gram_scan", a.gram)
     qp.set_option("sim_keep_factor", a.keep)
@@ -87,7 +87,7 @@ for rep in range(a.reps):
     t2 = time.perf_counter()
     print(f"N={N} T={T} warm={a.warm}: {N*T/(t2-t0):.3e} scenario-steps/s, {1e6*(t2-t0)/T:.1f} us/step "
           f"(host enqueue {1e6*(t1-t0)/T:.1f} us/step), min flag {int(fm.min())}"
-          + (f", wave stats {qp.wave_stats()}" if qp.kernel_name == "wave" else ""))
+          + (f", wave stats {qp.wave_stats()}" if qp.kernel_name.endswith("wave") else ""))
 
 
 if a.groups > 1:
