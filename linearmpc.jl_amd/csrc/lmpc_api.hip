@@ -649,6 +649,14 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             else { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
         }
         return rc;
+    } else if (screened && !sim && !gather && warm == nullptr && x != nullptr && flag != nullptr && h->qpTiersOk &&
+               h->qpTiers && h->P.ms < h->P.m && h->dCw != nullptr && h->S.iter_limit > h->P.n + 2 && h->asyncPhase == 0) {
+        // general rows on the lane path: the tiers pass (lmpc_qp_tiers_kernel.hpp) instead of the screening pass -- it
+        // finishes every append-only path, the lane kernel walks the rest
+        cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
+        cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
+        h->countSet ^= 1;
+        rc = launch_qp_tiers(h, nprob, theta, x, flag, iters, active, h->dList, cnt_now, lane_seg_cap(nprob), st, false);
     } else if (screened) {
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;

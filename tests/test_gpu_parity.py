@@ -2580,7 +2580,8 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
     kernel.  n = 2 .. 12 (forced onto the wavefront path where the lane kernels would be the default), m up to 64,
     wide and narrow theta ranges, ragged batches: the same bits as the path without the pass and as the oracle --
     x also on the failed points, flags, iteration counts, active sets; settings that rule the pass out (an iteration
-    limit inside its reach, a warm start) fall back by themselves."""
+    limit inside its reach, a warm start) fall back by themselves.  The same pass runs in front of the LANE kernel where
+    that one is the default for general rows ("wave" 0)."""
     import torch
     from oracle import ldp as oldp
     rng = np.random.default_rng(404)
@@ -2598,8 +2599,9 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
             th = np.ascontiguousarray(rng.uniform(-amp, amp, (N, nth)))
             xo, efo, ito, acto = oldp.solve_batch(L, th)
             t = torch.from_numpy(th).to(dev)
-            for tiers in (1, 0):
+            for tiers, wave in ((1, 1), (0, 1), (1, 0), (0, 0)):          # (in front of the wavefront kernel / the lane kernel)
                 qp.set_option("qp_tiers", tiers)
+                qp.set_option("wave", wave)
                 it = torch.full((N,), -77, dtype=torch.int32, device=dev)
                 act = torch.full((N, qp.words), -1, dtype=torch.int64, device=dev)
                 x, ef = qp.solve_device(t, iters=it, active=act)
@@ -2609,6 +2611,7 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
                 assert np.array_equal(act.cpu().numpy().view(np.uint64), acto.view(np.uint64)), (trial, N, tiers)
                 assert np.array_equal(x.cpu().numpy(), xo), (trial, N, tiers)
         qp.set_option("qp_tiers", 1)
+        qp.set_option("wave", 1)
         th = np.ascontiguousarray(rng.uniform(-6, 6, (2000, nth)))
         s = lmpc.default_settings(); s.iter_limit = n + 2; qp.set_settings(s)          # the pass needs iter_limit > n + 2
         so = oldp.default_settings(); so.iter_limit = n + 2
