@@ -25,7 +25,8 @@
 // problems, 9 of 10 instructions of the kernel -- takes its rows by scalar loads, one batch per row issued a row ahead
 // through inline assembly (QpRow): with a single wavefront per SIMD nothing else hides the scalar cache's latency, and
 // the compiler waits for a load it knows about right in front of its first use.  (Rows as LDS broadcast reads instead:
-// 2.36 against 1.98 ms per 10^6 problems.)  No MFMA (n <= 12).
+// 2.36 against 1.98 ms per 10^6 problems; as broadcast vector loads two rows ahead, three register sets: 2.50 -- a
+// broadcast costs the vector cache its full 64 lanes x 16 bytes.)  No MFMA (n <= 12).
 #pragma once
 
 #include <hip/hip_runtime.h>
