@@ -26,8 +26,8 @@ res = {}
 for f in glob.glob(out + "/pmc_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "wave_kernel" in k or "screen_kernel" in k:
-            kk = "wave_kernel" if "wave_kernel" in k else "screen_kernel"
+        if "wave_kernel" in k or "screen_kernel" in k or "qp_tiers_kernel" in k:
+            kk = "wave_kernel" if "wave_kernel" in k else ("qp_tiers_kernel" if "qp_tiers_kernel" in k else "screen_kernel")
             agg[kk][r["Counter_Name"]].append(float(r["Counter_Value"]))
             res[kk] = (k[:140], r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Workgroup_Size"), r.get("Grid_Size"))
 lines += ["", "## PMC (average per dispatch)", ""]
