@@ -738,7 +738,7 @@ static void preload_code(lmpc_handle *h) {
     if (h->avi) avi_preload(h);
     else {
         if (fast_covers(h)) fast_preload();
-        if (h->qpTiersOk && h->useWave)
+        if (h->qpTiersOk && (h->useWave || h->P.ms < h->P.m))
             (void)launch_qp_tiers(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
         if (h->dCw && h->useWave) {
             h->preloadOnly = true;

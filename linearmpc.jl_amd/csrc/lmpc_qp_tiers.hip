@@ -17,15 +17,6 @@ int go(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *f
     const size_t lds = sizeof(double) * (size_t)QpTiersLds<N>::reals(h->P.m);
     if (lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (preload) {
-        hipFuncAttributes fa;
-        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void *)kern));
-        return LMPC_OK;
-    }
-    // one workgroup of four wavefronts per CU (its LDS), a multiple of 16 workgroups (wavefronts a multiple of kShards)
-    const long long tiles = (nprob + 63) / 64;
-    long long grid = std::min<long long>((long long)h->numCU, (tiles + 3) / 4);
-    grid = ((grid + 15) / 16) * 16;
     if (!h->dQpScan) {
         // the scan pack: per row M_j, du0_j, dl0_j (padded to an even count), laid out for one batch of scalar loads
         constexpr int NR = qp_scan_row_reals(N);
@@ -38,6 +29,15 @@ int go(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *f
         HIP_TRY(h, hipMalloc(&h->dQpScan, sizeof(double) * sp.size()));
         HIP_TRY(h, hipMemcpy(h->dQpScan, sp.data(), sizeof(double) * sp.size(), hipMemcpyHostToDevice));
     }
+    if (preload) {
+        hipFuncAttributes fa;
+        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void *)kern));
+        return LMPC_OK;
+    }
+    // one workgroup of four wavefronts per CU (its LDS), a multiple of 16 workgroups (wavefronts a multiple of kShards)
+    const long long tiles = (nprob + 63) / 64;
+    long long grid = std::min<long long>((long long)h->numCU, (tiles + 3) / 4);
+    grid = ((grid + 15) / 16) * 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, h->W, h->dCw, theta, x, flag, iters, active, list, count,
                        seg_cap, (long long)nprob, h->dQpScan);
     HIP_TRY(h, hipGetLastError());
