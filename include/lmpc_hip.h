@@ -506,7 +506,7 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * (more wavefronts resident) and hand the points that outgrow it to a second launch at the full capacity;
  * "wave_cap" c (8 .. 64, 0 = the problem's own) = the full capacity itself, points beyond it go to the slow path.
  * Neither changes a result.
- * "qp_tiers" (default 1): problems with n = 2 .. 12 variables and up to 64 plain hard rows (no flags) send cold plain
+ * "qp_tiers" (default 1): problems with n = 2 .. 12 variables and up to 64 hard or SOFT rows (no other flags) send cold plain
  * binary64 batches through a tiers pass (one problem per lane, append-only paths finished in registers) in front of the
  * wavefront / lane kernel; 0 = the screening pass as before.  Results identical either way.
  * Variational handles (is_avi) with n <= 8 simple bounds run a chain of register-resident kernels in front of the

@@ -116,10 +116,10 @@ int finalize_handle(lmpc_handle *h) {
     // ... and in front of the wavefront kernel, for exactly that class (small n, many rows, nothing but plain hard rows):
     // straight-line tiers with one problem per lane (lmpc_qp_tiers_kernel.hpp)
     h->qpTiersOk = false;
-    if (laneOk && waveOk && P.n >= 2 && P.n <= 12 && P.m <= 64 && P.nth >= 1 && P.nth <= 16 &&
+    if (waveOk && !anyBinary && P.n >= 2 && P.n <= 12 && P.m <= 64 && P.nth >= 1 && P.nth <= 16 &&
         qp_tiers_lds_bytes(P.n, P.m) <= (size_t)160 * 1024) {
-        bool plain = true;
-        for (int j = 0; j < P.m; j++) plain = plain && P.sense[j] == 0;
+        bool plain = true;                                 // (hard or SOFT rows, no other flag)
+        for (int j = 0; j < P.m; j++) plain = plain && (P.sense[j] & ~SENSE_SOFT) == 0;
         h->qpTiersOk = plain;
     }
     LMPC_ENTER_DEVICE(h);                              // the caller's current device comes back when setup returns

@@ -192,7 +192,7 @@ struct lmpc_handle {
     size_t ccMapBytes = 0;
     // small problems with many rows on the wavefront path: straight-line tiers, one problem per lane, in front of it
     // (lmpc_qp_tiers_kernel.hpp)
-    bool qpTiersOk = false;     // the problem qualifies (n = 2 .. 12, m <= 64 hard rows without flags, nth <= 16)
+    bool qpTiersOk = false;     // the problem qualifies (n = 2 .. 12, m <= 64 hard or SOFT rows without other flags, nth <= 16)
     double *dQpScan = nullptr;  // ... its scan pack (rows of M with their bounds), built with the first launch
     int qpTiers = 1;            // tuning: 0 = screening pass + wavefront kernel as before ("qp_tiers"; same results)
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel

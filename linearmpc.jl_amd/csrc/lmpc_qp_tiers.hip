@@ -34,12 +34,14 @@ int go(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *f
         HIP_TRY(h, hipFuncGetAttributes(&fa, (const void *)kern));
         return LMPC_OK;
     }
+    unsigned long long soft = 0ull;
+    for (int j = 0; j < h->P.m; j++) soft |= (h->P.sense[j] & SENSE_SOFT) ? (1ull << j) : 0ull;
     // one workgroup of four wavefronts per CU (its LDS), a multiple of 16 workgroups (wavefronts a multiple of kShards)
     const long long tiles = (nprob + 63) / 64;
     long long grid = std::min<long long>((long long)h->numCU, (tiles + 3) / 4);
     grid = ((grid + 15) / 16) * 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, h->W, h->dCw, theta, x, flag, iters, active, list, count,
-                       seg_cap, (long long)nprob, h->dQpScan);
+                       seg_cap, (long long)nprob, h->dQpScan, soft);
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
 }

@@ -1,5 +1,5 @@
 // Straight-line tiers, one problem per LANE, in front of the wavefront kernel -- for small problems with MANY rows
-// (n <= 12 variables, up to 64 hard rows: the reference's own mass_spring example, n = 10, m = 63,
+// (n <= 12 variables, up to 64 hard or SOFT rows: the reference's own mass_spring example, n = 10, m = 63,
 // /root/reference/src/mpc_examples.jl:241-286).
 //
 // The wavefront kernel gives such a problem a whole wavefront: ~800 instructions per iteration whatever the size of
@@ -14,7 +14,7 @@
 //   solve, dual feasibility, u = -M_W' lam*, |u|^2 against fval_bound, the scan of all m rows.
 //
 // Each chain is the wavefront kernel's / the CPU checker's (oracle mode 0) in the same order, so a problem finished
-// here -- flag 1 or -1 -- has their bits (x, flag, iteration count, active set).  Anything else -- a blocking multiplier
+// here -- flag 1, 2 (a SOFT row violated at the optimum) or -1 -- has their bits (x, flag, iteration count, active set).  Anything else -- a blocking multiplier
 // (a removal), a row violated inside its own working set at the end, no progress of the dual objective -- is queued
 // (work list: kShards segments, one counter each, the screening pass's format) and the wavefront kernel solves it from
 // scratch.  The pass also does what the screening pass does (iteration 1), so it replaces it.
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
     const WaveLayout P, const double *__restrict__ C, const double *__restrict__ theta, double *__restrict__ X,
     int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
     int32_t *__restrict__ list, int32_t *__restrict__ count, const long long seg_cap, const long long nprob,
-    const double *__restrict__ SP) {
+    const double *__restrict__ SP, const unsigned long long soft_mask) {
     typedef QpTiersLds<N> Ly;
     constexpr int KMAX = N + 1;
     constexpr int NR = Ly::NR;                                    // reals a row of the scan pack
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
     double *sB = lds + Ly::oB(m) + wv * (m * 64) + lane;          // b_j of this lane at sB[j * 64]
     const double ptol = P.primal_tol, dtol = P.dual_tol, ztol = P.zero_tol, fbound = P.fval_bound, prog = P.progress_tol;
     const int cyc_tol = P.cycle_tol;
+    const double rho = P.rho_soft;                 // SOFT rows (bit j of soft_mask): slack weighted 1 / rho_soft (utils.jl:329-364)
 
     const long long gw = (long long)blockIdx.x * 4 + wv, nw = (long long)gridDim.x * 4;     // (nw % kShards == 0)
     const int shard = (int)(gw % kShards);
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
                 min_val = hit ? cand : min_val;
                 add = hit ? j : add;
                 addlow = hit ? !tu : addlow;
-                worst = __builtin_fmin(worst, __builtin_fmin(vu, vl));
+                // (an ACTIVE SOFT row may be violated: that is its slack)
+                const bool slack_row = ((soft_mask >> j) & 1ull) != 0ull && !inact;
+                worst = __builtin_fmin(worst, slack_row ? 0.0 : __builtin_fmin(vu, vl));
             };
             int j = 0;
             for (; j + 1 < m; j += 2) {
@@ -215,7 +218,8 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
         for (int i = 0; i < KMAX; i++) { Dinv[i] = 0.0; xl[i] = 0.0; wrow[i] = 0; }
         bool running = mine && add >= 0;
         bool finished = mine && add < 0;            // the unconstrained optimum is feasible
-        int flag_fin = EXIT_OPTIMAL, iter_fin = 1, cyc = 0;
+        int flag_fin = EXIT_OPTIMAL, iter_fin = 1, cyc = 0, nsoft_act = 0;
+        unsigned softpos = 0u;                      // bit i: working-set position i holds a SOFT row
         double best = -1.0, fval = 0.0;
 
         // (one generic lambda instantiated per tier: a `for` over the tiers is too large for the unroller from n = 8 on,
@@ -232,7 +236,8 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
                 const int a = wrow[t];
                 row[t] = sG[a >= j ? lmpc_tri(a) + j : lmpc_tri(j) + a];
             }
-            double dnew = sG[lmpc_tri(j) + j];
+            const bool jsoft = ((soft_mask >> j) & 1ull) != 0ull;
+            double dnew = sG[lmpc_tri(j) + j] + (jsoft ? rho : 0.0);
 #pragma unroll
             for (int i = 1; i < k; i++) {
                 double acc = row[i];
@@ -247,7 +252,8 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
                 row[i] = l;
                 dnew = __builtin_fma(-l, q, dnew);
             }
-            const bool singular = (dnew < ztol) || (k >= P.n);
+            // (n + 1 HARD rows in R^n are always dependent, whatever rounding says)
+            const bool singular = (dnew < ztol) || (!jsoft && k - nsoft_act >= P.n);
             const double bj = sB[j * 64];
             const double rk = addlow ? -(sSP[j * NR + N + 1] + bj) : -(sSP[j * NR + N] + bj);
 #pragma unroll
@@ -256,6 +262,8 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
             wrow[k] = j;
             act |= running ? (1ull << j) : 0ull;
             low |= (running && addlow) ? (1ull << j) : 0ull;
+            nsoft_act += (running && jsoft) ? 1 : 0;
+            softpos |= (running && jsoft) ? (1u << k) : 0u;
             {
                 const bool stall = fval - best < prog;
                 cyc = stall ? cyc + 1 : 0;
@@ -321,9 +329,12 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
 #pragma unroll
                 for (int c = 0; c < N; c++) un[c] = __builtin_fma(-mi[c], l, un[c]);
             }
-            double fv = 0.0;
+            double fv = 0.0, soft = 0.0;
+#pragma unroll
+            for (int i = 0; i <= k; i++) soft = ((softpos >> i) & 1u) ? __builtin_fma(ls[i] * ls[i], rho, soft) : soft;
 #pragma unroll
             for (int c = 0; c < N; c++) fv = __builtin_fma(un[c], un[c], fv);
+            fv = fv + soft;
 #pragma unroll
             for (int c = 0; c < N; c++) u[c] = running ? un[c] : u[c];
             fval = running ? fv : fval;
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void qp_tiers_kernel(
             running = running && add >= 0;                               // (add < 0 and broken: EXIT_CYCLE, next kernel)
             const bool fin = fin_inf || fin_bound || fin_opt;
             finished = finished || fin;
-            flag_fin = fin ? (fin_opt ? (int)EXIT_OPTIMAL : (int)EXIT_INFEASIBLE) : flag_fin;
+            flag_fin = fin ? (fin_opt ? (soft > ptol ? (int)EXIT_SOFT_OPTIMAL : (int)EXIT_OPTIMAL) : (int)EXIT_INFEASIBLE) : flag_fin;
             iter_fin = fin ? k + 2 : iter_fin;
             running = running && (k + 1 < KMAX);
         };

@@ -2620,4 +2620,35 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
         x, ef, it, act = _compare(qp, th)
         _compare(qp, th, warm=act)                                                       # warm: wavefront kernel alone
         qp.close()
+    # SOFT rows (the reference's default for output bounds, setup.jl:94): slack weighted 1 / rho_soft, exit flag 2 when a
+    # soft row is violated at the optimum -- the pass finishes those too; the reference's soft-constraint document example
+    cases = []
+    for trial in range(10):
+        n = 3 + trial % 10
+        mg = int(rng.integers(4, 64 - n + 1)); nth = int(rng.integers(1, 9)); nsoft = int(rng.integers(1, mg + 1))
+        H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=nsoft)
+        sc = rng.choice([0.3, 1.0])
+        cases.append((lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, sc * bu, sc * bl, W, sense, nout=min(n, 2)), nth, 3.0))
+    seen_soft_optimal = False
+    gs = load_golden("soft_doc")
+    cases.append((_qp_from_golden(lmpc, gs), gs["theta"].shape[1], None))
+    for qp, nth, amp in cases:
+        assert qp.kernel_name.startswith("qp_tiers<") and qp.kernel_name.endswith("wave"), qp.kernel_name
+        L = oracle_ldp_from(qp.ldp())
+        th = np.ascontiguousarray(rng.uniform(-amp, amp, (5000, nth))) if amp else np.ascontiguousarray(gs["theta"])
+        xo, efo, ito, acto = oldp.solve_batch(L, th)
+        t = torch.from_numpy(th).to(dev)
+        N = len(th)
+        for tiers in (1, 0):
+            qp.set_option("qp_tiers", tiers)
+            it = torch.full((N,), -77, dtype=torch.int32, device=dev)
+            act = torch.full((N, qp.words), -1, dtype=torch.int64, device=dev)
+            x, ef = qp.solve_device(t, iters=it, active=act)
+            torch.cuda.synchronize()
+            assert np.array_equal(ef.cpu().numpy(), efo) and np.array_equal(it.cpu().numpy(), ito), tiers
+            assert np.array_equal(act.cpu().numpy().view(np.uint64), acto.view(np.uint64)), tiers
+            assert np.array_equal(x.cpu().numpy(), xo), tiers
+        seen_soft_optimal = seen_soft_optimal or bool((efo == 2).any())
+        qp.close()
+    assert seen_soft_optimal
 
