@@ -588,7 +588,42 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             const int rcp = wave_probe(h, theta, nprob, st);
             if (rcp != LMPC_OK) return rcp;
         }
-        if (qp_tiers_applies(h, nprob, x, flag, warm)) return launch_wave_tiered(h, nprob, theta, x, flag, iters, active, st);
+        if (qp_tiers_applies(h, nprob, x, flag, warm)) {
+            // with or without the pass?  Small batches and "qp_tiers" 2: with.  Large batches: the handle times one call
+            // each way (events, read back without waiting by later calls) and goes with the faster; again every 512 calls.
+            // (The pass costs ~2 ms per 10^6 problems whatever it finishes: a sample of mostly hard points -- every
+            // second one with removals, soft_doc -- is 3 % faster without it, the reference's mass_spring 1.9x with it.)
+            int variant = 0, measure = -1;
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+            if (capturing) (void)hipGetLastError();
+            if (h->qpTiers == 1 && nprob >= 65536 && !capturing) {
+                for (int v = 0; v < 2; v++)
+                    if (h->qpAbPending[v] && hipEventQuery(h->qpAbEv[v][1]) == hipSuccess) {
+                        float ms = 0.f;
+                        if (hipEventElapsedTime(&ms, h->qpAbEv[v][0], h->qpAbEv[v][1]) == hipSuccess && h->qpAbN[v] > 0)
+                            h->qpAbNsPer[v] = 1e6 * (double)ms / (double)h->qpAbN[v];
+                        h->qpAbPending[v] = false;
+                    }
+                (void)hipGetLastError();
+                const long long phase = h->qpAbCalls++ % 512;
+                if (phase < 2 && !h->qpAbPending[phase]) { variant = (int)phase; measure = variant; }
+                else variant = (h->qpAbNsPer[0] >= 0.0 && h->qpAbNsPer[1] >= 0.0 && h->qpAbNsPer[1] < h->qpAbNsPer[0]) ? 1 : 0;
+            }
+            if (measure >= 0) {
+                for (int e = 0; e < 2; e++)
+                    if (!h->qpAbEv[measure][e] && hipEventCreate(&h->qpAbEv[measure][e]) != hipSuccess) { measure = -1; (void)hipGetLastError(); break; }
+            }
+            if (measure >= 0) HIP_TRY(h, hipEventRecord(h->qpAbEv[measure][0], st));
+            const int rct = variant == 0 ? launch_wave_tiered(h, nprob, theta, x, flag, iters, active, st)
+                          : (wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
+                                                    : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st));
+            if (measure >= 0 && rct == LMPC_OK) {
+                HIP_TRY(h, hipEventRecord(h->qpAbEv[measure][1], st));
+                h->qpAbN[measure] = nprob; h->qpAbPending[measure] = true;
+            }
+            return rct;
+        }
         return wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
                                       : launch_wave(h, nprob, theta, x, flag, iters, active, warm, st);
     }
@@ -1874,7 +1909,11 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "region_lockfree") == 0) { h->regW1 = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
-    if (std::strcmp(name, "qp_tiers") == 0) { h->qpTiers = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "qp_tiers") == 0) {
+        h->qpTiers = value < 0 ? 0 : (value > 2 ? 2 : value);
+        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0;       // (measure again)
+        return LMPC_OK;
+    }
     if (std::strcmp(name, "avi_tiers") == 0) { h->aviTiers = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "avi_tiers_first") == 0) {
         h->aviTiersFirst = value < 0 ? -1 : (value > 3 ? 3 : value); h->aviTiersOcc[0] = 0; return LMPC_OK;
@@ -1966,6 +2005,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);
+    for (int v = 0; v < 2; v++) for (int e = 0; e < 2; e++) if (h->qpAbEv[v][e]) hipEventDestroy(h->qpAbEv[v][e]);
     if (h->oneHost) hipHostFree(h->oneHost);
     if (h->ccMapHost) hipHostFree(h->ccMapHost);
     if (h->oneStream) hipStreamDestroy(h->oneStream);

@@ -194,7 +194,15 @@ struct lmpc_handle {
     // (lmpc_qp_tiers_kernel.hpp)
     bool qpTiersOk = false;     // the problem qualifies (n = 2 .. 12, m <= 64 hard or SOFT rows without other flags, nth <= 16)
     double *dQpScan = nullptr;  // ... its scan pack (rows of M with their bounds), built with the first launch
-    int qpTiers = 1;            // tuning: 0 = screening pass + wavefront kernel as before ("qp_tiers"; same results)
+    int qpTiers = 1;            // "qp_tiers": 0 = screening pass + wavefront kernel as before, 2 = always the tiers pass, 1 (default) =
+                                // the tiers pass, and for large batches whichever of the two the handle has MEASURED faster
+    // ... that measurement: one large call each way, timed by events that are read (without waiting) by later calls;
+    // taken again every 512 calls.  Variant 0 = with the pass, 1 = without.
+    hipEvent_t qpAbEv[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool qpAbPending[2] = {false, false};
+    int64_t qpAbN[2] = {0, 0};
+    double qpAbNsPer[2] = {-1.0, -1.0};      // measured nanoseconds per problem (-1: not measured yet)
+    long long qpAbCalls = 0;
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
     bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling

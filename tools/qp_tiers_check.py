@@ -28,7 +28,7 @@ for name, th in (("bench", bench.make_theta("mass_spring", 100_000, 1234, False)
     th = np.ascontiguousarray(th)
     xo, efo, ito, acto = oldp.solve_batch(L, th)
     t = torch.from_numpy(th).to(dev)
-    for tiers in (1, 0, 1):
+    for tiers in (2, 0, 1):
         qp.set_option("qp_tiers", tiers)
         it = torch.full((len(th),), -77, dtype=torch.int32, device=dev)
         act = torch.full((len(th), qp.words), -1, dtype=torch.int64, device=dev)
@@ -50,7 +50,7 @@ th = bench.make_theta("mass_spring", 1_000_000, 1234, False)
 ts = [torch.from_numpy(np.roll(th, r, axis=0).copy()).to(dev) for r in range(4)]
 xb = torch.empty((1_000_000, 1), dtype=torch.float64, device=dev)
 fb = torch.empty(1_000_000, dtype=torch.int32, device=dev)
-for tiers in (0, 1):
+for tiers in (0, 2, 1):          # (0: never, 2: always, 1: the handle measures one call each way and goes with the faster)
     qp.set_option("qp_tiers", tiers)
     for k in range(3):
         qp.solve_device(ts[k % 4], x=xb, exitflag=fb)
