@@ -427,6 +427,37 @@ int launch_wave_screened(lmpc_handle *h, int64_t nprob, const double *theta, dou
     return rc;
 }
 
+// With or without the tiers pass?  Returns the variant for this call (0 = with, 1 = without) and, in *measure, the
+// variant this call is to be TIMED as (-1: none).  Small batches and "qp_tiers" 2: with.  Large batches: the handle times
+// one call each way (events, read back without waiting by later calls) and goes with the faster; again every 512
+// calls.  (The pass costs ~2 ms per 10^6 problems whatever it finishes: a sample of mostly hard points -- every second
+// one with removals, soft_doc -- is 3 % faster without it, the reference's mass_spring 1.9x with it.)
+int qp_ab_choose(lmpc_handle *h, int64_t nprob, hipStream_t st, int *measure) {
+    *measure = -1;
+    if (h->qpTiers != 1 || nprob < 65536) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    for (int v = 0; v < 2; v++)
+        if (h->qpAbPending[v] && hipEventQuery(h->qpAbEv[v][1]) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->qpAbEv[v][0], h->qpAbEv[v][1]) == hipSuccess && h->qpAbN[v] > 0)
+                h->qpAbNsPer[v] = 1e6 * (double)ms / (double)h->qpAbN[v];
+            h->qpAbPending[v] = false;
+        }
+    (void)hipGetLastError();
+    const long long phase = h->qpAbCalls++ % 512;
+    int variant;
+    if (phase < 2 && !h->qpAbPending[phase]) {
+        variant = (int)phase;
+        *measure = variant;
+        for (int e = 0; e < 2; e++)
+            if (!h->qpAbEv[variant][e] && hipEventCreate(&h->qpAbEv[variant][e]) != hipSuccess) { *measure = -1; (void)hipGetLastError(); break; }
+    } else {
+        variant = (h->qpAbNsPer[0] >= 0.0 && h->qpAbNsPer[1] >= 0.0 && h->qpAbNsPer[1] < h->qpAbNsPer[0]) ? 1 : 0;
+    }
+    return variant;
+}
+
 // Small problems with many rows (lmpc_qp_tiers_kernel.hpp): the tiers pass over the whole batch -- it finishes what the
 // screening pass would and every problem on an append-only path, optimal or infeasible -- then the wavefront kernel on
 // its work list.  Cold plain binary64 solves in the n-chain form only.
@@ -589,31 +620,8 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
             if (rcp != LMPC_OK) return rcp;
         }
         if (qp_tiers_applies(h, nprob, x, flag, warm)) {
-            // with or without the pass?  Small batches and "qp_tiers" 2: with.  Large batches: the handle times one call
-            // each way (events, read back without waiting by later calls) and goes with the faster; again every 512 calls.
-            // (The pass costs ~2 ms per 10^6 problems whatever it finishes: a sample of mostly hard points -- every
-            // second one with removals, soft_doc -- is 3 % faster without it, the reference's mass_spring 1.9x with it.)
-            int variant = 0, measure = -1;
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
-            if (capturing) (void)hipGetLastError();
-            if (h->qpTiers == 1 && nprob >= 65536 && !capturing) {
-                for (int v = 0; v < 2; v++)
-                    if (h->qpAbPending[v] && hipEventQuery(h->qpAbEv[v][1]) == hipSuccess) {
-                        float ms = 0.f;
-                        if (hipEventElapsedTime(&ms, h->qpAbEv[v][0], h->qpAbEv[v][1]) == hipSuccess && h->qpAbN[v] > 0)
-                            h->qpAbNsPer[v] = 1e6 * (double)ms / (double)h->qpAbN[v];
-                        h->qpAbPending[v] = false;
-                    }
-                (void)hipGetLastError();
-                const long long phase = h->qpAbCalls++ % 512;
-                if (phase < 2 && !h->qpAbPending[phase]) { variant = (int)phase; measure = variant; }
-                else variant = (h->qpAbNsPer[0] >= 0.0 && h->qpAbNsPer[1] >= 0.0 && h->qpAbNsPer[1] < h->qpAbNsPer[0]) ? 1 : 0;
-            }
-            if (measure >= 0) {
-                for (int e = 0; e < 2; e++)
-                    if (!h->qpAbEv[measure][e] && hipEventCreate(&h->qpAbEv[measure][e]) != hipSuccess) { measure = -1; (void)hipGetLastError(); break; }
-            }
+            int measure = -1;
+            const int variant = qp_ab_choose(h, nprob, st, &measure);
             if (measure >= 0) HIP_TRY(h, hipEventRecord(h->qpAbEv[measure][0], st));
             const int rct = variant == 0 ? launch_wave_tiered(h, nprob, theta, x, flag, iters, active, st)
                           : (wave_screens(h, nprob) ? launch_wave_screened(h, nprob, theta, x, flag, iters, active, warm, st)
@@ -660,6 +668,7 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         HIP_TRY(h, hipEventRecord(ev.a, st));
     }
     int rc = LMPC_OK;
+    int ab_variant = 0, ab_measure = -1;          // (tiers pass on this path: measured like on the wavefront path)
     const bool sim = h->L.sim.FG != nullptr;      // closed-loop instantiations (SimFuse), lmpc_simulate* only
     const bool gather = !sim && h->L.gat.state != nullptr;   // generated-controller screening (GatherArgs)
     const bool wide = !sim && !gather && h->P.nout > 1 && h->P.nout <= 16;   // several outputs: transposed stores
@@ -685,14 +694,17 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
         }
         return rc;
     } else if (screened && !sim && !gather && warm == nullptr && x != nullptr && flag != nullptr && h->qpTiersOk &&
-               h->qpTiers && h->P.ms < h->P.m && h->dCw != nullptr && h->S.iter_limit > h->P.n + 2 && h->asyncPhase == 0) {
+               h->qpTiers && h->P.ms < h->P.m && h->dCw != nullptr && h->S.iter_limit > h->P.n + 2 && h->asyncPhase == 0 &&
+               (ab_variant = qp_ab_choose(h, nprob, st, &ab_measure)) == 0) {
         // general rows on the lane path: the tiers pass (lmpc_qp_tiers_kernel.hpp) instead of the screening pass -- it
         // finishes every append-only path, the lane kernel walks the rest
+        if (ab_measure >= 0) HIP_TRY(h, hipEventRecord(h->qpAbEv[ab_measure][0], st));
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
         rc = launch_qp_tiers(h, nprob, theta, x, flag, iters, active, h->dList, cnt_now, lane_seg_cap(nprob), st, false);
     } else if (screened) {
+        if (ab_measure >= 0) HIP_TRY(h, hipEventRecord(h->qpAbEv[ab_measure][0], st));
         cnt_now = h->dCount + (size_t)h->countSet * kShards * kCountStride;
         cnt_next = h->dCount + (size_t)(h->countSet ^ 1) * kShards * kCountStride;
         h->countSet ^= 1;
@@ -718,6 +730,10 @@ int launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_
 #undef LMPC_CASE
 #undef LMPC_LN
         default: rc = fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no kernel instantiation"); break;
+    }
+    if (ab_measure >= 0 && rc == LMPC_OK) {
+        HIP_TRY(h, hipEventRecord(h->qpAbEv[ab_measure][1], st));
+        h->qpAbN[ab_measure] = nprob; h->qpAbPending[ab_measure] = true;
     }
     if (h->prof) {
         if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
