@@ -1940,6 +1940,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         if (!value && (h->laneN == 0 || h->bnb))
             return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
         h->useWave = value != 0;
+        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0;       // (another path: the tiers pass is measured again)
         return LMPC_OK;
     }
     return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
