@@ -1927,7 +1927,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }
     if (std::strcmp(name, "qp_tiers") == 0) {
         h->qpTiers = value < 0 ? 0 : (value > 2 ? 2 : value);
-        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0;       // (measure again)
+        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0; h->qpAbPending[0] = h->qpAbPending[1] = false;   // (measure again)
         return LMPC_OK;
     }
     if (std::strcmp(name, "avi_tiers") == 0) { h->aviTiers = value != 0; return LMPC_OK; }
@@ -1940,7 +1940,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         if (!value && (h->laneN == 0 || h->bnb))
             return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: lane kernel does not cover this problem");
         h->useWave = value != 0;
-        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0;       // (another path: the tiers pass is measured again)
+        h->qpAbCalls = 0; h->qpAbNsPer[0] = h->qpAbNsPer[1] = -1.0; h->qpAbPending[0] = h->qpAbPending[1] = false;   // (another path: measured again)
         return LMPC_OK;
     }
     return fail(h, LMPC_ERR_BADARG, std::string("lmpc_set_option: unknown option ") + name);
