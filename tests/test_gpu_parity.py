@@ -2620,6 +2620,23 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
         x, ef, it, act = _compare(qp, th)
         _compare(qp, th, warm=act)                                                       # warm: wavefront kernel alone
         qp.close()
+    # large batches in the default mode: the handle times one call with the pass and one without, then keeps the faster
+    # -- whichever call it is, the arrays are the same
+    gm = load_golden("mass_spring")
+    qm = _qp_from_golden(lmpc, gm)
+    thm = np.ascontiguousarray(rng.uniform(-4, 4, (70_000, 12)))
+    tm = torch.from_numpy(thm).to(dev)
+    ref = None
+    for call in range(6):
+        x, ef = qm.solve_device(tm)
+        torch.cuda.synchronize()
+        cur = (x.cpu().numpy(), ef.cpu().numpy())
+        assert ref is None or (np.array_equal(cur[0], ref[0]) and np.array_equal(cur[1], ref[1])), call
+        ref = cur
+    sel = rng.integers(0, len(thm), 4000)
+    xo, efo, _, _ = oldp.solve_batch(oracle_ldp_from(qm.ldp()), thm[sel])
+    assert np.array_equal(ref[1][sel], efo) and np.array_equal(ref[0][sel], xo)
+    qm.close()
     # SOFT rows (the reference's default for output bounds, setup.jl:94): slack weighted 1 / rho_soft, exit flag 2 when a
     # soft row is violated at the optimum -- the pass finishes those too; the reference's soft-constraint document example
     cases = []
