@@ -794,6 +794,9 @@ static void preload_code(lmpc_handle *h) {
         if (h->dCw && h->useWave) {
             h->preloadOnly = true;
             (void)launch_wave(h, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            // (hybrid problems are the ones solved in binary32 too -- lmpc_solve_batch_f32*: that unit and its pack as well)
+            if (h->bnb && ensure_f32(h) == LMPC_OK)
+                (void)launch_wave_t<float>(h, h->dCwf, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
             h->preloadOnly = false;
         }
     }
