@@ -788,7 +788,7 @@ static void preload_code(lmpc_handle *h) {
     (void)hipFuncGetAttributes(&fa, (const void *)form_theta_kernel<double>);     // this unit: screening, lane, closed loop
     if (h->avi) avi_preload(h);
     else {
-        if (fast_covers(h)) fast_preload();
+        if (fast_covers(h)) fast_preload(h);
         if (h->qpTiersOk && (h->useWave || h->P.ms < h->P.m))
             (void)launch_qp_tiers(h, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, true);
         if (h->dCw && h->useWave) {

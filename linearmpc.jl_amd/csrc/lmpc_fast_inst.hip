@@ -120,9 +120,22 @@ int check_fast_err(lmpc_handle *h) {
 }
 
 // this unit's code object onto the device without a launch (setup; see preload_code in lmpc_api.hip)
-void fast_preload() {
+void fast_preload(lmpc_handle *h) {
     hipFuncAttributes fa;
     (void)hipFuncGetAttributes(&fa, (const void *)fast_kernel<8, 7, 5, false>);
+    // ... and what the kernel's first launch on this handle would allocate: its ticket counters, its error word
+    if (h && !h->dFastCtr && hipMalloc(&h->dFastCtr, sizeof(int32_t) * 2 * kFastCtrs * 32) == hipSuccess)
+        (void)hipMemset(h->dFastCtr, 0, sizeof(int32_t) * 2 * kFastCtrs * 32);
+#ifndef LMPC_FAST_TRACE
+    if (h && !h->dFastErr) {
+        int32_t *hp = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped) == hipSuccess) {
+            *hp = 0;
+            if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dFastErr), hp, 0) == hipSuccess) h->hFastErr = hp;
+            else { (void)hipHostFree(hp); h->dFastErr = nullptr; }
+        }
+    }
+#endif
     (void)hipGetLastError();
 }
 

@@ -255,7 +255,7 @@ int launch_avi_tiers(lmpc_handle *h, bool first, int kfirst, unsigned grid, hipS
 
 // one-launch solver for small box-constrained problems (lmpc_fast_inst.hip)
 bool fast_covers(const lmpc_handle *h);
-void fast_preload();
+void fast_preload(lmpc_handle *h);
 size_t qp_tiers_lds_bytes(int n, int m);
 int launch_qp_tiers(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                     uint64_t *active, int32_t *list, int32_t *count, long long seg_cap, hipStream_t st, bool preload);
