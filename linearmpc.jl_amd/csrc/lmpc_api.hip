@@ -1925,6 +1925,8 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
         return LMPC_OK;
     }
     if (std::strcmp(name, "wave_probe") == 0) { h->waveProbe = value != 0; return LMPC_OK; }
+    if (std::strcmp(name, "row_kernel") == 0) { h->rowKernel = value < 0 ? -1 : (value != 0); return LMPC_OK; }
+    if (std::strcmp(name, "row_blocks") == 0) { h->rowBlocks = value < 0 ? 0 : (value > 8 ? 8 : value); return LMPC_OK; }
     if (std::strcmp(name, "region_lockfree") == 0) { h->regW1 = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "region_blocks") == 0) { h->regBlocks = value < 0 ? 0 : (value > 16 ? 16 : value); return LMPC_OK; }
     if (std::strcmp(name, "avi_waves") == 0) { h->aviWaves = value < 0 ? 0 : (value > 32 ? 32 : value); return LMPC_OK; }

@@ -203,6 +203,9 @@ struct lmpc_handle {
     int64_t qpAbN[2] = {0, 0};
     double qpAbNsPer[2] = {-1.0, -1.0};      // measured nanoseconds per problem (-1: not measured yet)
     long long qpAbCalls = 0;
+    // four problems per wavefront (lmpc_row_kernel.hpp) in front of / instead of the wavefront kernel
+    int rowKernel = -1;         // "row_kernel": -1 = where it applies (large cold batches), 0 = never, 1 = whenever an instantiation covers
+    int rowBlocks = 0;          // tuning: workgroups per CU of its grid ("row_blocks", 0 = what LDS and registers allow)
     bool waveWarmed = false;    // lmpc_reserve has sent its one dummy problem through the wavefront kernel
     bool preloadOnly = false;   // launch_wave in "load the code, launch nothing" mode (preload_code)
     // profiling
@@ -269,6 +272,15 @@ int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, i
 int wave_first_pass_cap(lmpc_handle *h, int64_t nprob);
 void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]);
 int wave_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
+
+// four problems per wavefront (lmpc_row_inst.hip): capacity the batch would run at on that kernel (0: it does not take
+// the batch), and its launch as the only pass (pass 0) or the first of two (pass 1) of a wavefront-kernel call
+int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram, bool bnb);
+template <typename R>
+int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag, int32_t *iters,
+               uint64_t *active, hipStream_t st, int cap, int pass);
+extern template int launch_row<double>(lmpc_handle *, const double *, int64_t, const double *, double *, int32_t *, int32_t *,
+                                       uint64_t *, hipStream_t, int, int);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

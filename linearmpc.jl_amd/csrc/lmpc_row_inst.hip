@@ -1,0 +1,168 @@
+// Launch of the four-problems-per-wavefront kernel (lmpc_row_kernel.hpp): which instantiation covers a problem, its
+// launch shape, and the counter protocol it shares with the wavefront kernel's launches (lmpc_wave_launch.hpp) -- it
+// runs as the only pass of a batch (capacity = the problem's) or as the FIRST of two (a smaller capacity; what outgrows
+// it is listed for the wavefront kernel's second pass).
+#include "lmpc_internal.hpp"
+#include "lmpc_row_kernel.hpp"
+
+namespace lmpc {
+
+namespace {
+
+struct RowShape { int S, NS, MS, LDC; };
+
+// the instantiations built (LMPC_ROW_REAL per translation unit): position / variable / constraint slots, leading dimension
+constexpr RowShape kRowShapes[] = {
+    {1, 1, 4, 17},      // n <= 16, m <= 64, working sets <= 16 rows (the reference's mass_spring example: n = 10, m = 63)
+    {2, 2, 6, 31},      // n <= 32, m <= 96, <= 31 rows (BASELINE config 3: n = 30, m = 84)
+    {2, 2, 6, 33},      // ... <= 32 rows
+    {2, 4, 10, 33},     // n <= 64, m <= 160, <= 32 rows (the reference's benchmark class at N = 50: first of two passes)
+};
+
+bool shape_covers(const RowShape &sh, int n, int m, int cap) {
+    const int capp = 16 * sh.S < sh.LDC ? 16 * sh.S : sh.LDC;
+    return n <= 16 * sh.NS && m <= 16 * sh.MS && cap <= capp && m <= 256 /* mask words on 16 lanes */;
+}
+
+struct RowLaunch { int shape, nwv, blocks; size_t lds; };
+
+bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
+    const int n = h->P.n, m = h->P.m;
+    for (int q = 0; q < (int)(sizeof(kRowShapes) / sizeof(kRowShapes[0])); q++) {
+        const RowShape &sh = kRowShapes[q];
+        if (!shape_covers(sh, n, m, cap)) continue;
+        const int capp = 16 * sh.S < sh.LDC ? 16 * sh.S : sh.LDC;
+        const size_t ps = (size_t)row_problem_stride(capp, sh.LDC);
+        // most wavefronts per CU (each carries four problems); the staged M' is shared by a workgroup's wavefronts
+        RowLaunch best{-1, 0, 0, 0};
+        int bestWaves = 0;
+        const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS);
+        for (int nwv : {4, 3, 2, 1}) {
+            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps) + sizeof(int32_t) * (size_t)m + 16;
+            if (lds > kLdsMax) continue;
+            int blocks = (int)(kLdsMax / lds);
+            if (blocks * nwv > 8) blocks = 8 / nwv;                  // (256 registers: two wavefronts per SIMD at most)
+            if (blocks < 1) continue;
+            const int waves = blocks * nwv;
+            if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, lds}; }
+        }
+        if (best.shape < 0) return false;
+        *out = best;
+        return true;
+    }
+    return false;
+}
+
+template <typename R, int S, int NS, int MS, int LDC>
+int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
+                     int32_t *iters, uint64_t *active, hipStream_t st, int cap, int pass) {
+    auto kern = row_kernel<R, S, NS, MS, LDC>;
+    if (rl.lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl.lds));
+    if (h->preloadOnly) {
+        hipFuncAttributes fa;
+        HIP_TRY(h, hipFuncGetAttributes(&fa, (const void *)kern));
+        return LMPC_OK;
+    }
+    WaveLayout Wl = h->W;
+    Wl.cap = cap; Wl.ldc = LDC;
+    int blocks = rl.blocks;
+    if (h->rowBlocks > 0) blocks = h->rowBlocks;
+    long long grid = (long long)h->numCU * blocks;
+    const long long need = (nprob + 4 * rl.nwv - 1) / (4 * rl.nwv);
+    if (grid > need) grid = need;
+    // counters: the protocol of launch_wave_cfg (two alternating sets, each launch clears the next one's)
+    constexpr int kP1 = kShards * kCountStride;
+    if (!h->dQueue) {
+        if (!h->dOvfCount) HIP_TRY(h, hipMalloc(&h->dOvfCount, sizeof(int32_t) * (2 * kP1 + 64)));
+        HIP_TRY(h, hipMemsetAsync(h->dOvfCount, 0, sizeof(int32_t) * (2 * kP1 + 64), st));
+        HIP_TRY(h, hipMalloc(&h->dQueue, 64));
+        HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
+        h->waveCtrSet = 0; h->waveOvfSet = 0;
+    }
+    const int os = h->waveOvfSet;
+    int32_t *const p1Count = h->dOvfCount + os * kP1, *const p1Next = h->dOvfCount + (os ^ 1) * kP1;
+    int32_t *const p2Next = h->dOvfCount + 2 * kP1 + 8 * (os ^ 1);
+    int32_t *const queueNext = h->dQueue + 8 * (h->waveCtrSet ^ 1);
+    int32_t *queue = nullptr;
+    int qchunk = 1;
+    const long long nrows = grid * rl.nwv * 4;
+    if (h->waveList.list != nullptr) {
+        queue = h->dQueue + 8 * h->waveCtrSet;
+    } else if (nprob > 2 * nrows && h->waveQueue) {
+        const long long q = nprob / (32 * nrows);
+        qchunk = q < 1 ? 1 : (q > 16 ? 16 : (int)q);
+        queue = h->dQueue + 8 * h->waveCtrSet;
+    }
+    if (pass == 1 && nprob > h->ovfCap1) {
+        hipFree(h->dOvfList1); h->dOvfList1 = nullptr; h->ovfCap1 = 0;
+        HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
+        h->ovfCap1 = nprob;
+    }
+    if (!h->hStat) {
+        unsigned long long *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
+        for (int q = 0; q < 8; q++) hp[q] = 0ull;
+        h->hStat = hp;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dStatHost), hp, 0));
+        HIP_TRY(h, hipMalloc(&h->dStat, sizeof(unsigned long long) * 64 * 16));
+        HIP_TRY(h, hipMemsetAsync(h->dStat, 0, sizeof(unsigned long long) * 64 * 16, st));
+    }
+    const WaveList &wl = h->waveList;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * rl.nwv), rl.lds, st, Wl, dC, h->dSw, theta, x, flag, iters, active,
+                       queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
+                       pass == 1 ? h->dOvfList1 : nullptr, pass == 1 ? p1Count : nullptr, queueNext, p2Next, p1Next, h->dStat,
+                       h->dStatHost);
+    h->waveCtrSet ^= 1;
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+}  // namespace
+
+#ifdef LMPC_ROW_HELPERS
+// Working-set capacity at which a batch of this handle would first run on the row kernel: the problem's own capacity
+// (one pass), a smaller one (first of two passes; the statistics of the handle's earlier launches must say that nearly
+// all working sets stay within it), or 0 = the row kernel does not take this batch.
+int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram, bool bnb) {
+    if (h->rowKernel == 0 || bnb || gram || warm || h->avi) return 0;
+    if (h->waveSim.FG != nullptr || h->keepOn || nprob >= (int64_t)0x3fffffff) return 0;
+    if (h->rowKernel < 0 && nprob < 8192) return 0;              // (a handful of problems: one per wavefront has the shorter latency)
+    for (int j = 0; j < h->P.m; j++)
+        if (h->P.sense[j] & (SENSE_ACTIVE | SENSE_BINARY)) return 0;
+    if (h->S.iter_limit < 2) return 0;
+    const int full = h->W.cap;
+    RowLaunch rl;
+    int cap = 0;
+    if (full <= 32 && row_launch_for(h, full, rs, &rl)) cap = full;
+    else if (full > 32 && h->bigPath && h->waveTwoPass != 0) {
+        // first of two passes at 32 rows: when at most 1 in 20 of the working sets seen lately went beyond
+        unsigned long long sum[4] = {0, 0, 0, 0};
+        wave_stat_read(h, sum);
+        const bool known = sum[0] >= 1000ull;
+        const bool fits = known && (sum[0] - sum[2]) * 20ull <= sum[0];
+        if ((h->rowKernel > 0 || fits) && row_launch_for(h, 32, rs, &rl)) cap = 32;
+    }
+    return cap;
+}
+#endif
+
+template <typename R>
+int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag, int32_t *iters,
+               uint64_t *active, hipStream_t st, int cap, int pass) {
+    RowLaunch rl;
+    if (!row_launch_for(h, cap, sizeof(R), &rl)) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no row-kernel instantiation");
+#define LMPC_ROW(S_, NS_, MS_, LDC_) launch_row_shape<R, S_, NS_, MS_, LDC_>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass)
+    switch (rl.shape) {
+        case 0: return LMPC_ROW(1, 1, 4, 17);
+        case 1: return LMPC_ROW(2, 2, 6, 31);
+        case 2: return LMPC_ROW(2, 2, 6, 33);
+        default: return LMPC_ROW(2, 4, 10, 33);
+    }
+#undef LMPC_ROW
+}
+
+template int launch_row<LMPC_ROW_REAL>(lmpc_handle *, const LMPC_ROW_REAL *, int64_t, const LMPC_ROW_REAL *, LMPC_ROW_REAL *, int32_t *,
+                                       int32_t *, uint64_t *, hipStream_t, int, int);
+
+}  // namespace lmpc

@@ -450,6 +450,29 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     return rc;
     };   // dispatch
     if (h->preloadOnly) return dispatch();
+    // Four problems per wavefront (lmpc_row_kernel.hpp) where it applies: as the only pass when its capacity holds every
+    // working set of the problem, else as the first of two passes in place of this kernel's own first pass.
+    if constexpr (!BNB && !GRAM && sizeof(R) == 8) {
+        const int rcap = row_pass_cap(h, nprob, sizeof(R), warm != nullptr, GRAM, BNB);
+        if (rcap > 0) {
+            if (rcap >= capW) {
+                rc = launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
+            } else {
+                h->wavePass = 1;
+                rc = launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 1);
+                h->wavePass = 2;
+                cfg = wave_config(h, sizeof(R));
+                if (rc == LMPC_OK) rc = dispatch();
+                h->wavePass = 0;
+            }
+            h->waveOvfSet ^= 1;
+            if (prof) {
+                if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+                else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+            }
+            return rc;
+        }
+    }
     if (c1 > 0) {
         h->W.cap = c1; h->W.ldc = c1 | 1; h->wavePass = 1;
         cfg = wave_config(h, sizeof(R));
