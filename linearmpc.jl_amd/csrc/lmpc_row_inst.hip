@@ -109,10 +109,14 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
         HIP_TRY(h, hipMemsetAsync(h->dStat, 0, sizeof(unsigned long long) * 64 * 16, st));
     }
     const WaveList &wl = h->waveList;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * rl.nwv), rl.lds, st, Wl, dC, h->dSw, theta, x, flag, iters, active,
-                       queue, qchunk, (long long)nprob, wl.list, wl.count, wl.count_next, wl.seg_cap,
-                       pass == 1 ? h->dOvfList1 : nullptr, pass == 1 ? p1Count : nullptr, queueNext, p2Next, p1Next, h->dStat,
-                       h->dStatHost);
+    RowParams<R> prm{};
+    prm.P = Wl; prm.C = dC; prm.Sg = h->dSw; prm.theta = theta; prm.X = x; prm.exitflag = flag; prm.iters = iters;
+    prm.active = active; prm.queue = queue; prm.qchunk = qchunk; prm.nprob = (long long)nprob;
+    prm.list = wl.list; prm.count = wl.count; prm.count_next = wl.count_next; prm.seg_cap = wl.seg_cap;
+    prm.ovf_list = pass == 1 ? h->dOvfList1 : nullptr; prm.ovf_count = pass == 1 ? p1Count : nullptr;
+    prm.queue_next = queueNext; prm.ovf_next = p2Next; prm.ovf_next1 = p1Next;
+    prm.stat = h->dStat; prm.stat_host = h->dStatHost;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * rl.nwv), rl.lds, st, prm);
     h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());
     return LMPC_OK;
@@ -166,3 +170,15 @@ template int launch_row<LMPC_ROW_REAL>(lmpc_handle *, const LMPC_ROW_REAL *, int
                                        int32_t *, uint64_t *, hipStream_t, int, int);
 
 }  // namespace lmpc
+
+#if defined(LMPC_ROW_TRACE) && defined(LMPC_ROW_HELPERS)
+// diagnostic build only: per-phase shader-clock sums of the row kernel (see lmpc_row_kernel.hpp)
+extern "C" int lmpc_debug_row_trace(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lmpc::g_row_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lmpc::g_row_trace), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -46,6 +46,21 @@
 
 namespace lmpc {
 
+// Diagnostic build (-DLMPC_ROW_TRACE, tools/row_trace.py): shader-clock stamps at the phase boundaries of a trip, summed
+// per phase over all wavefronts into g_row_trace (read back by lmpc_debug_row_trace).  Shares, not absolutes.
+#ifdef LMPC_ROW_TRACE
+__device__ unsigned long long g_row_trace[16];
+#define RWT_DECL long long rwt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long rwt_prev = (long long)clock64()
+#define RWT(k) do { const long long t__ = (long long)clock64(); rwt_acc[k] += t__ - rwt_prev; rwt_prev = t__; } while (0)
+#define RWT_COUNT(k, n) do { rwt_acc[k] += (n); } while (0)
+#define RWT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 16; q__++) atomicAdd(&g_row_trace[q__], (unsigned long long)rwt_acc[q__]); } } while (0)
+#else
+#define RWT_DECL do { } while (0)
+#define RWT(k) do { } while (0)
+#define RWT_COUNT(k, n) do { } while (0)
+#define RWT_FLUSH do { } while (0)
+#endif
+
 // ---- row-level helpers ---------------------------------------------------------------------------------------------
 // lane T of each 16-lane row to all lanes of that row (DPP row_newbcast:T)
 template <int T, typename V> __device__ __forceinline__ V rw_bc(V v) {
@@ -113,9 +128,12 @@ __device__ __forceinline__ bool rw_any(bool p) { return __ballot(p) != 0ull; }
 
 constexpr int kRowPosFlagSoft = 1 << 16, kRowPosFlagImm = 1 << 17, kRowPosFlagLow = 1 << 18;
 constexpr int kRowBig = 0x7fffffff;
+// resident wavefronts per SIMD an instantiation is register-budgeted for: two where one slot of positions keeps the
+// factors small (LDS then allows them), else one (the factors of 16 problems fill the LDS of a CU: 256 + 256 registers)
 #ifndef LMPC_ROW_WPE
-#define LMPC_ROW_WPE 2      // resident wavefronts per SIMD the instantiations are register-budgeted for
+#define LMPC_ROW_WPE 0
 #endif
+__host__ __device__ constexpr int row_wpe(int s, int ns, int ms) { return LMPC_ROW_WPE > 0 ? LMPC_ROW_WPE : (s >= 2 ? 1 : 2); }
 
 // reals of LDS one problem's factor takes: (cap - 1) columns of LDC rows, rounded up to 16 (mod 32)
 // reals per row of the staged M' (odd)
@@ -127,26 +145,44 @@ __host__ __device__ constexpr int row_problem_stride(int cap, int ldc) {
     return ps;
 }
 
+// Everything a launch passes, in ONE block: the kernel copies the few scalars its iterations need into registers and
+// reads the rest -- the pointers of the outputs, the work list, the counters -- from the kernel-argument segment where
+// it uses them (a row takes or ends a problem once in ~8 trips), through a pointer the compiler cannot see through.
+// (As ~25 separate arguments they all stayed live in scalar registers across the whole loop: 230 scalar spills, reloaded
+// by v_readlane in the middle of every phase.)
+template <typename R> struct RowParams {
+    WaveLayout P;
+    const R *C; const int32_t *Sg; const R *theta;
+    R *X; int32_t *exitflag, *iters; uint64_t *active;
+    int32_t *queue; int qchunk; long long nprob;
+    const int32_t *list, *count; int32_t *count_next; long long seg_cap;
+    int32_t *ovf_list, *ovf_count, *queue_next, *ovf_next, *ovf_next1;
+    unsigned long long *stat; volatile unsigned long long *stat_host;
+};
+
 // R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  LDC: leading
 // dimension of the factor (odd; the launch's capacity P.cap <= min(LDC, 16 S)).
 template <typename R, int S, int NS, int MS, int LDC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WPE))) void row_kernel(
-    const WaveLayout P, const R *__restrict__ C, const int32_t *__restrict__ Sg, const R *__restrict__ theta,
-    R *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters, uint64_t *__restrict__ active,
-    int32_t *__restrict__ queue, int qchunk_arg, long long nprob, const int32_t *__restrict__ list,
-    const int32_t *__restrict__ count, int32_t *__restrict__ count_next, long long seg_cap,
-    int32_t *__restrict__ ovf_list, int32_t *__restrict__ ovf_count, int32_t *__restrict__ queue_next,
-    int32_t *__restrict__ ovf_next, int32_t *__restrict__ ovf_next1, unsigned long long *__restrict__ stat,
-    volatile unsigned long long *__restrict__ stat_host) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, NS, MS)))) void row_kernel(const RowParams<R> prm) {
     static_assert((LDC & 1) == 1, "odd leading dimension");
     static_assert(LDC <= 16 * S + 1, "rows of the factor live on S slots");
+    // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const RowParams<R> *kparg = (const RowParams<R> *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const RowParams<R> *kparg = &prm;
+#endif
+#define RW_ARGS() ([&]() { const RowParams<R> *a__ = kparg; asm volatile("" : "+s"(a__)); return a__; }())
     // the counters of the next launch / call on this handle, and the working-set statistics' host copy: the duties of
     // every wavefront-kernel launch (lmpc_wave_kernel.hpp, lmpc_wave_launch.hpp)
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *queue_next = 0; *ovf_next = 0; *ovf_next1 = 0; }
-    if (stat != nullptr && stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
-        unsigned long long sum = 0ull;
-        for (int sidx = 0; sidx < 64; sidx++) sum += stat[sidx * 16 + threadIdx.x];
-        stat_host[threadIdx.x] = sum;
+    {
+        const RowParams<R> *a = RW_ARGS();
+        if (blockIdx.x == 0 && threadIdx.x == 0) { *a->queue_next = 0; *a->ovf_next = 0; *a->ovf_next1 = 0; }
+        if (a->stat != nullptr && a->stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+            unsigned long long sum = 0ull;
+            for (int sidx = 0; sidx < 64; sidx++) sum += a->stat[sidx * 16 + threadIdx.x];
+            a->stat_host[threadIdx.x] = sum;
+        }
     }
 
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -154,7 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
     const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, rowbase = lane & 48, g = lane >> 4;
-    const int n = P.n, m = P.m, nth = P.nth, cap = P.cap, nout = P.nout;
+    // (scalars of the iterations: each in a register of its own -- as fields of the by-value block they are sub-registers
+    // of 16-wide loads that get spilled and reloaded whole)
+    int n = prm.P.n, m = prm.P.m, nth = prm.P.nth, cap = prm.P.cap, nout = prm.P.nout, oG = prm.P.oG;
+    int iter_limit = prm.P.iter_limit, cycle_tol = prm.P.cycle_tol;
+    asm volatile("" : "+s"(n), "+s"(m), "+s"(nth), "+s"(cap), "+s"(nout), "+s"(oG), "+s"(iter_limit), "+s"(cycle_tol));
     constexpr int CAPP = 16 * S < LDC ? 16 * S : LDC;            // positions the instantiation has code for
     constexpr int PS = row_problem_stride(CAPP, LDC);          // (sized for the instantiation: a sweep block may read columns up to CAPP - 2)
     // LDS: [32 zeros][M': ceil4(n) rows of MPAD reals, zero padded][factors: nwv * 4 problems, PS reals each][sense flags: m ints]
@@ -167,26 +207,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
     const int nP = (n + 3) & ~3;
     const int oZ = 0, oMt = 32, oL = oMt + nP * MPAD;
     int32_t *sens = reinterpret_cast<int32_t *>(lds + oL + nwv * 4 * PS);
+    const R *__restrict__ C = prm.C;
     for (int i = threadIdx.x; i < 32; i += blockDim.x) lds[oZ + i] = (R)0;
     for (int i = threadIdx.x; i < nP * MPAD; i += blockDim.x) {
         const int k = i / MPAD, j = i - k * MPAD;
-        lds[oMt + i] = (k < n && j < m) ? C[P.oMt + k * m + j] : (R)0;
+        lds[oMt + i] = (k < n && j < m) ? C[prm.P.oMt + k * m + j] : (R)0;
     }
     for (int i = threadIdx.x; i < nwv * 4 * PS; i += blockDim.x) lds[oL + i] = (R)0;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = Sg[i];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = prm.Sg[i];
     __syncthreads();
 
-    const R primal_tol = (R)P.primal_tol, dual_tol = (R)P.dual_tol, zero_tol = (R)P.zero_tol,
-            progress_tol = (R)P.progress_tol, rho_soft = (R)P.rho_soft, fbound = (R)P.fval_bound;
+    const R primal_tol = (R)prm.P.primal_tol, dual_tol = (R)prm.P.dual_tol, zero_tol = (R)prm.P.zero_tol,
+            progress_tol = (R)prm.P.progress_tol, rho_soft = (R)prm.P.rho_soft, fbound = (R)prm.P.fval_bound;
     const R kInf = wv_lim<R>::inf();
-    // constant pack and parameter records through buffer resources: scalar base + this lane's 32-bit index, no 64-bit
-    // per-lane pointers (lmpc_wave_kernel.hpp)
+    // constant pack through a buffer resource: scalar base + this lane's 32-bit index, no 64-bit per-lane pointers
+    // (lmpc_wave_kernel.hpp)
     const __amdgpu_buffer_rsrc_t crs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(C), 0, P.nC * (int)sizeof(R), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(C), 0, prm.P.nC * (int)sizeof(R), 0x00020000);
     auto ldc = [&](int soff, int voff) -> R { return wv_bufld(crs, (unsigned)voff, (unsigned)soff, R()); };   // C[soff + voff]
-    const __amdgpu_buffer_rsrc_t trs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(theta), 0, (int)(nprob * nth * (long long)sizeof(R)), 0x00020000);
-    auto ldth = [&](int voff) -> R { return wv_bufld(trs, (unsigned)voff, 0u, R()); };                       // theta[voff]
     // The unrolled chains below run in BLOCKS of a few steps behind one wave-uniform test each; inside a block every step
     // runs (steps beyond a row's sizes multiply by the zeros the padding guarantees).  The empty statement keeps the
     // compiler from folding a block's test into selects -- which turns the whole unrolled chain into one basic block
@@ -203,14 +241,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
         bo[s] = pos[s] < cap - 1 ? Lg + pos[s] * LDC : oZ;              // (beyond the last column: the block of zeros)
     }
     int jc[MS], mcol[NS];
+    unsigned okb = 0u, hardb = 0u;     // bit r: this lane's row of slot r can enter a working set / ... and is a hard row
 #pragma unroll
-    for (int r = 0; r < MS; r++) jc[r] = li + 16 * r < m ? li + 16 * r : m - 1;
+    for (int r = 0; r < MS; r++) {
+        const int j = li + 16 * r;
+        jc[r] = j < m ? j : m - 1;
+        const int sj = sens[jc[r]];
+        if (j < m && !(sj & SENSE_IMMUTABLE)) { okb |= 1u << r; if (!(sj & SENSE_SOFT)) hardb |= 1u << r; }
+    }
 #pragma unroll
     for (int s = 0; s < NS; s++) mcol[s] = oMt + (li + 16 * s < n ? li + 16 * s : n - 1) * MPAD;   // this lane's variables: their rows of M'
     const int mrow = oMt + li;                                  // this lane's constraints: column li + 16 r of M'
 
-    // ---- the state of this row's problem
-    int live = 0, dead = 0;                        // row-uniform: a problem is running / the batch is exhausted
+    // ---- the state of this row's problem (what is one number per problem is a row-uniform vector register; predicates
+    // are 0 / 1 integers -- as lane masks they would each hold a pair of scalar registers across the phases)
+    int live = 0, dead = 0;                        // a problem is running / the batch is exhausted
     int pid = 0, na = 0, sing = -1, iter = 1, cyc = 0, nsoft = 0, napk = 0, ydirty = 0;
     R best = (R)-1, fval = (R)0, soft_slack = (R)0;
     int ws[S];                                     // per position: row index | kRowPosFlag*
@@ -229,49 +274,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
     // Work-list mode (list != nullptr): a pass in front (screening, lmpc_screen_kernel.hpp) has finished what needs no
     // iterations and left the others in the kShards segments of `list` (segment s: count[s * kCountStride] entries from
     // list[s * seg_cap]); lane s of every wavefront holds segment s's range of positions in the concatenated list.
-    const long long nrows = (long long)gridDim.x * nwv * 4;
-    const long long myrow = ((long long)blockIdx.x * nwv + wv) * 4 + g;
-    long long ntotal = nprob;
-    int seg_end = 0, seg_beg = 0;
-    int qchunk = qchunk_arg;
-    if (list != nullptr) {
-        static_assert(kShards == 64, "one work-list segment per lane");
-        if (count_next != nullptr && blockIdx.x == 0 && threadIdx.x < 64) count_next[threadIdx.x * kCountStride] = 0;
-        const int c = count[lane * kCountStride];
-        int incl = c;
+    const int nrows = (int)gridDim.x * nwv * 4;
+    const int myrow = ((int)blockIdx.x * nwv + wv) * 4 + g;
+    int ntotal, qchunk, seg_end = 0, seg_beg = 0, ticket = 0;
+    {
+        const RowParams<R> *a = RW_ARGS();
+        ntotal = (int)a->nprob;
+        qchunk = a->qchunk;
+        if (a->list != nullptr) {
+            static_assert(kShards == 64, "one work-list segment per lane");
+            if (a->count_next != nullptr && blockIdx.x == 0 && threadIdx.x < 64) a->count_next[threadIdx.x * kCountStride] = 0;
+            const int c = a->count[lane * kCountStride];
+            int incl = c;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            seg_end = incl; seg_beg = incl - c;
+            ntotal = __builtin_amdgcn_readlane(incl, 63);
+            const int q = ntotal / (32 * nrows);                     // (the host cannot know the list's length)
+            qchunk = q < 1 ? 1 : (q > 16 ? 16 : q);
         }
-        seg_end = incl; seg_beg = incl - c;
-        ntotal = (long long)__builtin_amdgcn_readlane(incl, 63);
-        const long long q = ntotal / (32 * nrows);               // (the host cannot know the list's length)
-        qchunk = q < 1 ? 1 : (q > 16 ? 16 : (int)q);
+        if (a->queue != nullptr && li == 0) ticket = atomicAdd(a->queue, 1);
     }
-    long long cur = myrow * qchunk, endc = cur + qchunk < ntotal ? cur + qchunk : ntotal;
-    long long chunk_static = myrow;
-    int ticket = 0;
-    if (queue != nullptr && li == 0) ticket = atomicAdd(queue, 1);
-
+    int cur = myrow * qchunk, endc = cur + qchunk < ntotal ? cur + qchunk : ntotal;
+    int chunk_static = myrow;
     // ---- sweeps over the factor.  forward: v_p -= L(p,t) v_t for t = 0 .. top-1 in order; backward: v_i -= L(t,i) v_t
     // for t = top .. 1 descending.  `top` is wave-uniform (the largest of the four rows); a row whose working set is
     // smaller reads zeros (its factor's rows beyond na are zeros).
+    // The factor's entries of a block of CHS steps are fetched while the block before it runs (issued at its head, waited
+    // for at their first use): with one wavefront per SIMD nothing else hides the LDS round trip.
+    constexpr int CHS = S == 1 ? 8 : 4;
     auto sweep_fwd = [&](R (&v)[S], int nmax) {
-        constexpr int CH = 8;
-        rw_static_for<0, (CAPP + CH - 1) / CH>([&](auto B) {
-            constexpr int t0 = decltype(B)::value * CH;
+        constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;               // steps t = 0 .. CAPP-2
+        R Ln[CHS][S];
+        auto fetch = [&](auto B) {
+            constexpr int t0 = decltype(B)::value * CHS;
+#pragma unroll
+            for (int q = 0; q < CHS; q++)
+#pragma unroll
+                for (int s = 0; s < S; s++) Ln[q][s] = lds[fo[s] + (t0 + q < CAPP - 1 ? t0 + q : CAPP - 2) * LDC];
+        };
+        if (1 < nmax) fetch(std::integral_constant<int, 0>{});
+        rw_static_for<0, NB>([&](auto B) {
+            constexpr int b = decltype(B)::value, t0 = b * CHS;
             if (t0 + 1 < nmax) {
                 RW_BLOCK();
-                R Lr[CH][S];
+                R Lr[CHS][S];
 #pragma unroll
-                for (int q = 0; q < CH; q++)
+                for (int q = 0; q < CHS; q++)
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        const int t = t0 + q < CAPP - 1 ? t0 + q : CAPP - 2;
-                        Lr[q][s] = lds[fo[s] + t * LDC];
-                    }
-                rw_static_for<0, CH>([&](auto Q) {
+                    for (int s = 0; s < S; s++) Lr[q][s] = Ln[q][s];
+                if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
+                rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int t = t0 + decltype(Q)::value;
                     if constexpr (t + 1 < CAPP) {
                         const R vt = rw_bc<t>(v[t >> 4]);
@@ -284,22 +340,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
         });
     };
     auto sweep_bwd = [&](R (&v)[S], int top) {
-        constexpr int CH = 8;
-        constexpr int NB = (CAPP - 1 + CH - 1) / CH;              // steps t = CAPP-1 .. 1 in blocks from the top
+        constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;              // steps t = CAPP-1 .. 1 in blocks from the top
+        R Ln[CHS][S];
+        auto fetch = [&](auto B) {
+            constexpr int thi = CAPP - 1 - decltype(B)::value * CHS;
+#pragma unroll
+            for (int q = 0; q < CHS; q++)
+#pragma unroll
+                for (int s = 0; s < S; s++) Ln[q][s] = lds[bo[s] + (thi - q > 1 ? thi - q : 1)];
+        };
+        // (the first block that runs fetches for itself: which one that is depends on `top`)
+        bool primed = false;
         rw_static_for<0, NB>([&](auto B) {
-            constexpr int thi = CAPP - 1 - decltype(B)::value * CH;   // this block: t = thi .. thi-CH+1
-            constexpr int tlo = thi - CH + 1 > 1 ? thi - CH + 1 : 1;
+            constexpr int b = decltype(B)::value;
+            constexpr int thi = CAPP - 1 - b * CHS;                  // this block: t = thi .. thi-CHS+1
+            constexpr int tlo = thi - CHS + 1 > 1 ? thi - CHS + 1 : 1;
             if (top >= tlo) {
                 RW_BLOCK();
-                R Lc[CH][S];
+                if (!primed) { fetch(B); primed = true; }
+                R Lc[CHS][S];
 #pragma unroll
-                for (int q = 0; q < CH; q++)
+                for (int q = 0; q < CHS; q++)
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        const int t = thi - q > 1 ? thi - q : 1;
-                        Lc[q][s] = lds[bo[s] + t];
-                    }
-                rw_static_for<0, CH>([&](auto Q) {
+                    for (int s = 0; s < S; s++) Lc[q][s] = Ln[q][s];
+                if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
+                rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int t = thi - decltype(Q)::value;
                     if constexpr (t >= 1) {
                         const R vt = rw_bc<t>(v[t >> 4]);
@@ -312,80 +377,105 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
         });
     };
 
+    RWT_DECL;
     for (;;) {
+        RWT(15);
+        // (what the loop does not change, made opaque once per trip: otherwise every comparison against it is formed in
+        // front of the loop and kept -- as lane masks in scalar registers -- across all of it)
+        asm volatile("" : "+s"(n), "+s"(cap), "+s"(iter_limit));
         // =============================================================== a row without a problem takes the next one
         {
             const bool want = !live && !dead;
             if (rw_any(want)) {
+                const RowParams<R> *a = RW_ARGS();
                 const bool newchunk = want && cur >= endc;
                 if (rw_any(newchunk)) {
-                    long long ch;
-                    if (queue != nullptr) {
-                        const int tk = rw_bc<0>(ticket);
-                        ch = nrows + (long long)tk;
-                        if (newchunk && li == 0) ticket = atomicAdd(queue, 1);
+                    int ch;
+                    if (a->queue != nullptr) {
+                        ch = nrows + rw_bc<0>(ticket);
+                        if (newchunk && li == 0) ticket = atomicAdd(a->queue, 1);
                     } else {
                         ch = chunk_static + nrows;
                     }
-                    if (newchunk) {
-                        chunk_static = ch;
-                        cur = ch * qchunk;
-                        endc = cur + qchunk < ntotal ? cur + qchunk : ntotal;
-                    }
+                    const long long c64 = (long long)ch * qchunk;
+                    const int cn = c64 < (long long)ntotal ? (int)c64 : ntotal;
+                    chunk_static = newchunk ? ch : chunk_static;
+                    cur = newchunk ? cn : cur;
+                    endc = newchunk ? (cn + qchunk < ntotal ? cn + qchunk : ntotal) : endc;
                 }
-                const bool got = want && cur < ntotal && cur < endc;
+                const bool got = want && cur < endc;
                 dead = (want && !got) ? 1 : dead;
                 if (rw_any(got)) {
-                    int npid = got ? (int)cur : 0;
-                    if (list != nullptr) {
+                    int npid = got ? cur : 0;
+                    if (a->list != nullptr) {
                         // position in the concatenated list -> (segment, offset) -> problem, row by row (scalar)
 #pragma unroll
                         for (int gg = 0; gg < 4; gg++) {
                             if (__builtin_amdgcn_readlane(got ? 1 : 0, 16 * gg)) {
-                                const int ix = __builtin_amdgcn_readlane((int)cur, 16 * gg);
+                                const int ix = __builtin_amdgcn_readlane(cur, 16 * gg);
                                 int sgm = (int)__popcll(__ballot(seg_end <= ix));
                                 sgm = sgm < 63 ? sgm : 63;
                                 const int off = ix - __builtin_amdgcn_readlane(seg_beg, sgm);
-                                const int p = list[(long long)sgm * seg_cap + off];
+                                const int p = a->list[(long long)sgm * a->seg_cap + off];
                                 npid = g == gg ? p : npid;
                             }
                         }
                     }
                     cur = got ? cur + 1 : cur;
-                    const int tho = npid * nth;
+                    // b_j = Dth_j . theta (mpc_update_qp.c:5-6), four columns of Dth per round trip
+                    const R *th = a->theta + (long long)npid * nth;
                     R b[MS];
 #pragma unroll
                     for (int r = 0; r < MS; r++) b[r] = (R)0;
-                    for (int t = 0; t < nth; t++) {
-                        const R tv = ldth(tho + t);
+                    for (int t0 = 0; t0 < nth; t0 += 4) {
+                        R tv[4], dv[4][MS];
 #pragma unroll
-                        for (int r = 0; r < MS; r++) b[r] = wv_fma(ldc(P.oDth + t, jc[r] * nth), tv, b[r]);
+                        for (int q = 0; q < 4; q++) {
+                            const int t = t0 + q < nth ? t0 + q : nth - 1;
+                            tv[q] = th[t];
+#pragma unroll
+                            for (int r = 0; r < MS; r++) dv[q][r] = ldc(prm.P.oDth + t, jc[r] * nth);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (t0 + q < nth) {
+#pragma unroll
+                                for (int r = 0; r < MS; r++) b[r] = wv_fma(dv[q][r], tv[q], b[r]);
+                            }
                     }
 #pragma unroll
                     for (int r = 0; r < MS; r++) {
-                        const R du = ldc(P.odu, jc[r]) + b[r], dl = ldc(P.odl, jc[r]) + b[r];
+                        const R du = ldc(prm.P.odu, jc[r]) + b[r], dl = ldc(prm.P.odl, jc[r]) + b[r];
                         dub[r] = got ? du : dub[r];
                         dlb[r] = got ? dl : dlb[r];
                     }
-                    if (got) {
-                        pid = npid; live = 1; na = 0; sing = -1; iter = 1; cyc = 0; nsoft = 0; napk = 0; ydirty = 0;
-                        best = (R)-1; fval = (R)0; soft_slack = (R)0; actb = 0u; lowb = 0u;
+                    pid = got ? npid : pid; live = got ? 1 : live; na = got ? 0 : na; sing = got ? -1 : sing;
+                    iter = got ? 1 : iter; cyc = got ? 0 : cyc; nsoft = got ? 0 : nsoft; napk = got ? 0 : napk;
+                    ydirty = got ? 0 : ydirty; best = got ? (R)-1 : best; fval = got ? (R)0 : fval;
+                    soft_slack = got ? (R)0 : soft_slack; actb = got ? 0u : actb; lowb = got ? 0u : lowb;
 #pragma unroll
-                        for (int s = 0; s < S; s++) { ws[s] = 0; D[s] = Dinv[s] = lam[s] = ls[s] = rhs[s] = y[s] = (R)0; }
-#pragma unroll
-                        for (int s = 0; s < NS; s++) u[s] = (R)0;
+                    for (int s = 0; s < S; s++) {
+                        ws[s] = got ? 0 : ws[s]; D[s] = got ? (R)0 : D[s]; Dinv[s] = got ? (R)0 : Dinv[s];
+                        lam[s] = got ? (R)0 : lam[s]; ls[s] = got ? (R)0 : ls[s]; rhs[s] = got ? (R)0 : rhs[s];
+                        y[s] = got ? (R)0 : y[s];
                     }
+#pragma unroll
+                    for (int s = 0; s < NS; s++) u[s] = got ? (R)0 : u[s];
                 }
             }
             if (!rw_any(live != 0)) break;                       // every row of the wavefront has run out of problems
         }
 
-        int flag = 0;                                            // != 0: this row's problem ends in this trip
-        bool fin = false;
-        const bool act = live != 0;
-        if (act && iter >= P.iter_limit) { flag = EXIT_ITERLIMIT; fin = true; }
-        const bool run = act && !fin;
-        const bool sgl = sing >= 0;
+        RWT(0);
+        RWT_COUNT(10, 1);
+        int flag = 0, fin = 0;                                   // fin: this row's problem ends in this trip, with `flag`
+        {
+            const bool lim = live != 0 && iter >= iter_limit;
+            flag = lim ? EXIT_ITERLIMIT : 0;
+            fin = lim ? 1 : 0;
+        }
+        const int run = (live != 0 && !fin) ? 1 : 0;
+        const int sgl = sing >= 0 ? 1 : 0;
         const int namax = rw_max4(run ? na : 0);
 
         // =============================================================== stationary point / singular direction
@@ -409,7 +499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     const R lv = lds[bo[s] + (sgc > 1 ? sgc : 1)];       // L(sing, pos)
-                    if (sgl) v[s] = (run && pos[s] < sing) ? -lv : (R)0;
+                    v[s] = sgl ? ((run && pos[s] < sing) ? -lv : (R)0) : v[s];
                 }
                 int wsel = ws[0];
 #pragma unroll
@@ -419,17 +509,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
             sweep_bwd(v, namax - 1);
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                R acc = v[s];
-                if (sgl) {
-                    acc = pos[s] == sing ? (R)1 : (pos[s] > sing ? (R)0 : acc);
-                    acc = lowsg ? -acc : acc;
-                } else {
-                    acc = pos[s] < na ? acc : (R)0;
-                }
+                const R a1 = pos[s] == sing ? (R)1 : (pos[s] > sing ? (R)0 : v[s]);
+                const R asg = lowsg ? -a1 : a1;
+                const R ans = pos[s] < na ? v[s] : (R)0;
+                const R acc = sgl ? asg : ans;
                 ls[s] = run ? acc : ls[s];
             }
         }
 
+        RWT(1);
         // =============================================================== blocking multipliers: (alpha, rm) = first minimum
         int rm = -1;
         R alpha = (R)0;
@@ -446,22 +534,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                 R cand[S], cm = kInf;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    cand[s] = sgl ? (-lam[s] / ls[s]) : (-lam[s] / (ls[s] - lam[s]));
+                    const R den = sgl ? ls[s] : (ls[s] - lam[s]);
+                    cand[s] = -lam[s] / den;
                     cm = wv_min2(cm, blk[s] ? cand[s] : kInf);
                 }
                 const R gmin = rw_min(cm);
                 int tp = kRowBig, bp = kRowBig;
 #pragma unroll
                 for (int s = S - 1; s >= 0; s--) {
-                    if (blk[s] && cand[s] == gmin) tp = pos[s];
-                    if (blk[s]) bp = pos[s];
+                    tp = (blk[s] && cand[s] == gmin) ? pos[s] : tp;
+                    bp = blk[s] ? pos[s] : bp;
                 }
                 tp = rw_min(tp);
                 bp = rw_min(bp);
                 const int r0 = tp != kRowBig ? tp : bp;              // (no position equals the minimum: NaNs -- the first blocked one)
-                if (r0 != kRowBig) {
-                    rm = r0;
-                }
+                rm = r0 != kRowBig ? r0 : -1;
                 R csel = cand[0];
 #pragma unroll
                 for (int s = 1; s < S; s++) csel = ((r0 & 0xffff) >> 4) == s ? cand[s] : csel;
@@ -469,41 +556,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                 alpha = rm >= 0 ? a0 : (R)0;
             }
         }
-        if (run && sgl && rm < 0) { flag = EXIT_INFEASIBLE; fin = true; }
-        const bool doRem = run && rm >= 0;
-        const bool doAdd = run && !sgl && rm < 0;
+        RWT(2);
+        {
+            const bool infx = run && sgl && rm < 0;
+            flag = infx ? EXIT_INFEASIBLE : flag;
+            fin = infx ? 1 : fin;
+        }
+        const int doRem = (run && rm >= 0) ? 1 : 0;
+        const int doAdd = (run && !sgl && rm < 0) ? 1 : 0;
 
         // =============================================================== no blocking multiplier: primal iterate, scan, append
-        if (rw_any(doAdd)) {
+        if (rw_any(doAdd != 0)) {
             const int namaxA = rw_max4(doAdd ? na : 0);
             R un[NS];
 #pragma unroll
             for (int s = 0; s < NS; s++) un[s] = (R)0;
             // u = -M_W' lam*  (rows beyond a working set: lam* = 0 there, row 0 of M)
-            constexpr int CHP = 4;
-            rw_static_for<0, (CAPP + CHP - 1) / CHP>([&](auto B) {
-                constexpr int i0 = decltype(B)::value * CHP;
-                if (i0 < namaxA) {
-                    RW_BLOCK();
-                    R mv[CHP][NS];
+            constexpr int CHP = 4, NBP = (CAPP + CHP - 1) / CHP;
+            {
+                R mn[CHP][NS];
+                auto fetch = [&](auto B) {
+                    constexpr int i0 = decltype(B)::value * CHP;
                     rw_static_for<0, CHP>([&](auto Q) {
                         constexpr int i = i0 + decltype(Q)::value < CAPP ? i0 + decltype(Q)::value : CAPP - 1;
                         const int w = rw_bc<i>(ws[i >> 4]) & 0xffff;
 #pragma unroll
-                        for (int s = 0; s < NS; s++) mv[decltype(Q)::value][s] = lds[mcol[s] + w];
+                        for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[mcol[s] + w];
                     });
-                    rw_static_for<0, CHP>([&](auto Q) {
-                        constexpr int i = i0 + decltype(Q)::value;
-                        if constexpr (i < CAPP) {
-                            const R l = rw_bc<i>(ls[i >> 4]);
+                };
+                if (0 < namaxA) fetch(std::integral_constant<int, 0>{});
+                rw_static_for<0, NBP>([&](auto B) {
+                    constexpr int b = decltype(B)::value, i0 = b * CHP;
+                    if (i0 < namaxA) {
+                        RW_BLOCK();
+                        R mv[CHP][NS];
 #pragma unroll
-                            for (int s = 0; s < NS; s++) un[s] = wv_fma(-mv[decltype(Q)::value][s], l, un[s]);
-                        }
-                    });
-                }
-            });
+                        for (int q = 0; q < CHP; q++)
+#pragma unroll
+                            for (int s = 0; s < NS; s++) mv[q][s] = mn[q][s];
+                        if constexpr (b + 1 < NBP) fetch(std::integral_constant<int, b + 1>{});
+                        rw_static_for<0, CHP>([&](auto Q) {
+                            constexpr int i = i0 + decltype(Q)::value;
+                            if constexpr (i < CAPP) {
+                                const R l = rw_bc<i>(ls[i >> 4]);
+#pragma unroll
+                                for (int s = 0; s < NS; s++) un[s] = wv_fma(-mv[decltype(Q)::value][s], l, un[s]);
+                            }
+                        });
+                    }
+                });
+            }
 #pragma unroll
             for (int s = 0; s < NS; s++) un[s] = li + 16 * s < n ? un[s] : (R)0;
+            RWT(3);
+            RWT_COUNT(11, 1);
             R soft = (R)0;
             if (rw_any(doAdd && nsoft > 0)) {
                 rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
@@ -526,90 +632,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
             R fv = (R)0, Mu[MS];
 #pragma unroll
             for (int r = 0; r < MS; r++) Mu[r] = (R)0;
-            constexpr int CHK = MS <= 4 ? 4 : 2;                   // (divides 4: the staged M' has ceil4(n) rows)
-            rw_static_for<0, 16 * NS / CHK>([&](auto B) {
-                constexpr int k0 = decltype(B)::value * CHK;
-                if (k0 < n) {
-                    RW_BLOCK();
-                    R mt[CHK][MS];
+            constexpr int CHK = 4, NBK = 16 * NS / CHK;            // (the staged M' has ceil4(n) rows)
+            {
+                R mn[CHK][MS];
+                auto fetch = [&](auto B) {
+                    constexpr int k0 = decltype(B)::value * CHK;
 #pragma unroll
                     for (int q = 0; q < CHK; q++)                              // (rows beyond n, columns beyond m: zeros)
 #pragma unroll
-                        for (int r = 0; r < MS; r++) mt[q][r] = lds[mrow + (k0 + q) * MPAD + 16 * r];
-                    rw_static_for<0, CHK>([&](auto Q) {
-                        constexpr int k = k0 + decltype(Q)::value;
-                        const R v = rw_bc<k>(un[k >> 4]);
-                        fv = wv_fma(v, v, fv);
+                        for (int r = 0; r < MS; r++) mn[q][r] = lds[mrow + (k0 + q) * MPAD + 16 * r];
+                };
+                fetch(std::integral_constant<int, 0>{});
+                rw_static_for<0, NBK>([&](auto B) {
+                    constexpr int b = decltype(B)::value, k0 = b * CHK;
+                    if (k0 < n) {
+                        RW_BLOCK();
+                        R mt[CHK][MS];
 #pragma unroll
-                        for (int r = 0; r < MS; r++) Mu[r] = wv_fma(mt[decltype(Q)::value][r], v, Mu[r]);
-                    });
-                }
-            });
-            const R fvalN = fv + soft;
-            bool addp = doAdd;
-            if (doAdd) {                                         // (this trip's iterate is the row's iterate from here on)
+                        for (int q = 0; q < CHK; q++)
 #pragma unroll
-                for (int s = 0; s < NS; s++) u[s] = un[s];
-                fval = fvalN; soft_slack = soft;
+                            for (int r = 0; r < MS; r++) mt[q][r] = mn[q][r];
+                        if constexpr (b + 1 < NBK) {
+                            if (k0 + CHK < n) fetch(std::integral_constant<int, b + 1>{});
+                        }
+                        rw_static_for<0, CHK>([&](auto Q) {
+                            constexpr int k = k0 + decltype(Q)::value;
+                            const R v = rw_bc<k>(un[k >> 4]);
+                            fv = wv_fma(v, v, fv);
+#pragma unroll
+                            for (int r = 0; r < MS; r++) Mu[r] = wv_fma(mt[decltype(Q)::value][r], v, Mu[r]);
+                        });
+                    }
+                });
             }
-            if (addp && fvalN > fbound) { flag = EXIT_INFEASIBLE; fin = true; addp = false; }
+            RWT(4);
+            const R fvalN = fv + soft;
+            {                                                    // (this trip's iterate is the row's iterate from here on)
+                const bool c = doAdd != 0;
+#pragma unroll
+                for (int s = 0; s < NS; s++) u[s] = c ? un[s] : u[s];
+                fval = c ? fvalN : fval;
+                soft_slack = c ? soft : soft_slack;
+            }
+            int addp = doAdd;
+            {
+                const bool dom = addp && fvalN > fbound;
+                flag = dom ? EXIT_INFEASIBLE : flag; fin = dom ? 1 : fin; addp = dom ? 0 : addp;
+            }
             // most violated row: smallest value, ties to the lowest (row, side) index
             R mval = -primal_tol;
-            int midx = -1;
-            bool broken = false;
+            int midx = -1, broken = 0;
 #pragma unroll
             for (int r = 0; r < MS; r++) {
                 const int j = li + 16 * r;
-                if (j < m && !(sens[jc[r]] & SENSE_IMMUTABLE)) {
-                    const R vu = dub[r] - Mu[r];
-                    const R vl = -(dlb[r] - Mu[r]);
-                    if (!((actb >> r) & 1u)) {
-                        if (vu < mval) { mval = vu; midx = 2 * j; }
-                        else if (vl < mval) { mval = vl; midx = 2 * j + 1; }
-                    } else if (!(sens[jc[r]] & SENSE_SOFT) && (vu < -primal_tol || vl < -primal_tol)) {
-                        broken = true;
-                    }
-                }
+                const R vu = dub[r] - Mu[r];
+                const R vl = Mu[r] - dlb[r];                     // = -(dlower_j - M_j u), exactly
+                const bool ok = (okb >> r) & 1u, inw = (actb >> r) & 1u;
+                const bool bu = ok && !inw && vu < mval;
+                mval = bu ? vu : mval; midx = bu ? 2 * j : midx;
+                const bool bl = ok && !inw && !bu && vl < mval;
+                mval = bl ? vl : mval; midx = bl ? 2 * j + 1 : midx;
+                const bool br = inw && ((hardb >> r) & 1u) && (vu < -primal_tol || vl < -primal_tol);
+                broken = br ? 1 : broken;                        // the iterate violates a hard row of its own working set
             }
-            const int anyv = rw_or(midx >= 0 ? 1 : 0), anybr = rw_or(broken ? 1 : 0);
+            const int anyv = rw_or(midx >= 0 ? 1 : 0), anybr = rw_or(broken);
             const R gsel = rw_min(midx >= 0 ? mval : kInf);
             int mt = rw_min((midx >= 0 && mval == gsel) ? midx : kRowBig);
-            if (mt == kRowBig) mt = rw_min(midx >= 0 ? midx : kRowBig);
-            if (addp && !anyv) {
-                flag = anybr ? EXIT_CYCLE : (soft > primal_tol ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL);
-                fin = true; addp = false;
+            const int mt2 = rw_min(midx >= 0 ? midx : kRowBig);
+            mt = mt == kRowBig ? mt2 : mt;
+            {
+                const bool opt = addp && !anyv;
+                const int fl = anybr ? EXIT_CYCLE : (soft > primal_tol ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL);
+                flag = opt ? fl : flag; fin = opt ? 1 : fin; addp = opt ? 0 : addp;
+                const bool full = addp && na >= cap;
+                flag = full ? EXIT_WSCAP : flag; fin = full ? 1 : fin; addp = full ? 0 : addp;
             }
-            if (addp && na >= cap) { flag = EXIT_WSCAP; fin = true; addp = false; }
-
+            RWT(5);
             // ---- append row jadd to the working sets of the rows with addp
-            if (rw_any(addp)) {
-                const int jadd = addp ? (mt >> 1) : 0;
-                const bool lower = addp && (mt & 1);
+            if (rw_any(addp != 0)) {
+                const bool ap = addp != 0;
+                const int jadd = ap ? (mt >> 1) : 0;
+                const bool lower = ap && (mt & 1);
                 const int sj = sens[jadd];
                 const bool is_soft = (sj & SENSE_SOFT) != 0;
                 R q[S];
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    const int a = (addp && pos[s] < na) ? (ws[s] & 0xffff) : jadd;
-                    const int gi = a >= jadd ? a * (a + 1) / 2 + jadd : jadd * (jadd + 1) / 2 + a;
-                    const R gv = ldc(P.oG, gi);
-                    q[s] = (addp && pos[s] < na) ? gv : (R)0;
+                    const bool in = ap && pos[s] < na;
+                    const int a = in ? (ws[s] & 0xffff) : jadd;
+                    const int hi = a >= jadd ? a : jadd, lo = a >= jadd ? jadd : a;
+                    const R gv = ldc(oG, hi * (hi + 1) / 2 + lo);
+                    q[s] = in ? gv : (R)0;
                 }
-                const R gjj = ldc(P.oG, jadd * (jadd + 1) / 2 + jadd);
+                const R gjj = ldc(oG, jadd * (jadd + 1) / 2 + jadd);
 #pragma unroll
-                for (int s = 0; s < S; s++) lam[s] = addp ? ls[s] : lam[s];
-                const int namaxQ = rw_max4(addp ? na : 0);
-                sweep_fwd(q, namaxQ);
-                R l[S];
-#pragma unroll
-                for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
-                R dnew = gjj;
-                if (is_soft) dnew += rho_soft;
+                for (int s = 0; s < S; s++) lam[s] = ap ? ls[s] : lam[s];
+                const int namaxQ = rw_max4(ap ? na : 0);
                 // the bound of row jadd that enters: from the lane and slot that own the row
                 R bsel = lower ? dlb[0] : dub[0];
 #pragma unroll
                 for (int r = 1; r < MS; r++) bsel = (jadd >> 4) == r ? (lower ? dlb[r] : dub[r]) : bsel;
                 const R rj = -rw_pick(bsel, jadd & 15, rowbase);
+                sweep_fwd(q, namaxQ);
+                R l[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
+                R dnew = is_soft ? gjj + rho_soft : gjj;
                 R ynew = rj;
                 rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
                     constexpr int i0 = decltype(B)::value * 4;
@@ -627,47 +755,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                 });
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
+                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
+                                (lower ? kRowPosFlagLow : 0);
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    if (addp && pos[s] < na) lds[bo[s] + na] = l[s];         // new row: L(na, t) written by lane t
-                    if (addp && pos[s] == na) {
-                        ws[s] = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
-                                (lower ? kRowPosFlagLow : 0);
-                        rhs[s] = rj; lam[s] = (R)0; ls[s] = (R)0; y[s] = ynew;
-                        D[s] = singular ? (R)0 : dnew;
-                        Dinv[s] = singular ? (R)0 : dinv;
-                    }
+                    if (ap && pos[s] < na) lds[bo[s] + na] = l[s];           // new row: L(na, t) written by lane t
+                    const bool here = ap && pos[s] == na;
+                    ws[s] = here ? wsn : ws[s];
+                    rhs[s] = here ? rj : rhs[s]; lam[s] = here ? (R)0 : lam[s]; ls[s] = here ? (R)0 : ls[s];
+                    y[s] = here ? ynew : y[s];
+                    D[s] = here ? (singular ? (R)0 : dnew) : D[s];
+                    Dinv[s] = here ? (singular ? (R)0 : dinv) : Dinv[s];
                 }
-                if (addp && li == (jadd & 15)) {
-                    actb |= 1u << (jadd >> 4);
-                    if (lower) lowb |= 1u << (jadd >> 4);
+                {
+                    const bool mine = ap && li == (jadd & 15);
+                    const unsigned bit = 1u << (jadd >> 4);
+                    actb = mine ? (actb | bit) : actb;
+                    lowb = (mine && lower) ? (lowb | bit) : lowb;
                 }
-                if (addp) {
-                    if (singular) sing = na;
-                    nsoft += is_soft ? 1 : 0;
-                    na++;
-                    napk = na > napk ? na : napk;
-                    if (fvalN - best < progress_tol) {
-                        if (++cyc > P.cycle_tol) { flag = EXIT_CYCLE; fin = true; }
-                    } else { best = fvalN; cyc = 0; }
+                sing = (ap && singular) ? na : sing;
+                nsoft = (ap && is_soft) ? nsoft + 1 : nsoft;
+                na = ap ? na + 1 : na;
+                napk = na > napk ? na : napk;
+                {
+                    const bool slow = ap && (fvalN - best < progress_tol);
+                    const int cy = slow ? cyc + 1 : 0;
+                    const bool cyx = slow && cy > cycle_tol;
+                    cyc = ap ? cy : cyc;
+                    best = (ap && !slow) ? fvalN : best;
+                    flag = cyx ? EXIT_CYCLE : flag; fin = cyx ? 1 : fin;
                 }
             }
         }
 
+        RWT(6);
         // =============================================================== a blocking multiplier: step, drop its row
-        if (rw_any(doRem)) {
+        if (rw_any(doRem != 0)) {
+            RWT_COUNT(12, 1);
+            const bool dr = doRem != 0;
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                const R ln = sgl ? wv_fma(alpha, ls[s], lam[s]) : wv_fma(alpha, ls[s] - lam[s], lam[s]);
-                lam[s] = doRem ? ln : lam[s];
+                const R ln = wv_fma(alpha, sgl ? ls[s] : (ls[s] - lam[s]), lam[s]);
+                lam[s] = dr ? ln : lam[s];
             }
-            const int r = doRem ? rm : 0;
+            const int r = dr ? rm : 0;
             const int nao = na;
             R w[S];
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 const R lv = lds[fo[s] + (r < cap - 1 ? r : 0) * LDC];          // L(pos, r), old row index = pos
-                w[s] = (doRem && pos[s] > r && pos[s] < nao) ? lv : (R)0;
+                w[s] = (dr && pos[s] > r && pos[s] < nao) ? lv : (R)0;
             }
             R dsel = D[0];
             int wsel = ws[0];
@@ -677,7 +814,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
             const int wsr = rw_pick(wsel, r & 15, rowbase);
             const int jrem = wsr & 0xffff, softrem = (wsr & kRowPosFlagSoft) ? 1 : 0;
             // new row i = old row i + 1 without column r (i >= r): lane c moves entry (i + 1, c') to (i, c)
-            const int rlo = rw_min4(doRem ? r : kRowBig), nhi = rw_max4(doRem ? nao : 0);
+            const int rlo = rw_min4(dr ? r : kRowBig), nhi = rw_max4(dr ? nao : 0);
             {
                 int so[S];
 #pragma unroll
@@ -686,16 +823,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                     cp = cp < cap - 1 ? cp : 0;
                     so[s] = Lg + cp * LDC;
                 }
-                for (int i = rlo; i < nhi - 1; i++) {
+                // (four rows read before they are written: the reads of a row do not wait for the row above it)
+                for (int i0 = rlo; i0 < nhi - 1; i0 += 4) {
+                    R tv[4][S];
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        const R v = lds[so[s] + i + 1];
-                        if (doRem && i >= r && i < nao - 1 && pos[s] < i) lds[bo[s] + i] = v;
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int s = 0; s < S; s++) tv[q][s] = lds[so[s] + (i0 + q + 1 < CAPP ? i0 + q + 1 : CAPP - 1)];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = i0 + q;
+#pragma unroll
+                        for (int s = 0; s < S; s++)
+                            if (dr && i >= r && i < nao - 1 && pos[s] < i) lds[bo[s] + i] = tv[q][s];
                     }
                 }
 #pragma unroll
                 for (int s = 0; s < S; s++)
-                    if (doRem && pos[s] < nao - 1) lds[bo[s] + nao - 1] = (R)0;       // the row that left: back to zeros
+                    if (dr && pos[s] < nao - 1) lds[bo[s] + nao - 1] = (R)0;          // the row that left: back to zeros
             }
             // the per-position registers move down by one from position r on
             {
@@ -711,65 +856,85 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                     }
 #pragma unroll
                     for (int s = 0; s < S; s++) {
-                        if (doRem) {
-                            if (pos[s] >= r && pos[s] < nao - 1) a[s] = nx[s];
-                            else if (pos[s] == nao - 1 || clear_outside) a[s] = (V)0;
-                        }
+                        const bool mv = dr && pos[s] >= r && pos[s] < nao - 1;
+                        const bool zr = dr && !mv && (pos[s] == nao - 1 || clear_outside);
+                        a[s] = mv ? nx[s] : (zr ? (V)0 : a[s]);
                     }
                 };
                 shift(ws, false); shift(lam, false); shift(rhs, false); shift(D, false); shift(Dinv, false);
                 shift(w, true);
             }
-            if (doRem) { na = nao - 1; sing = -1; ydirty = 1; }
+            na = dr ? nao - 1 : na; sing = dr ? -1 : sing; ydirty = dr ? 1 : ydirty;
+            RWT(7);
             // rank-one update of the trailing block, column by column
             {
-                bool stop = false;
-                const int nhi2 = rw_max4(doRem ? na : 0);
-                rw_static_for<0, CAPP - 1>([&](auto T) {
-                    constexpr int t = decltype(T)::value;
-                    if (t >= rlo && t < nhi2) {
-                        const bool actv = doRem && t >= r && t < na && !stop;
-                        if (rw_any(actv)) {
-                            const R pt = rw_bc<t>(w[t >> 4]);
-                            const R dold = rw_bc<t>(D[t >> 4]);
-                            const R dbar = wv_fma(al * pt, pt, dold);
-                            const bool sng = actv && dbar < zero_tol;
-                            const bool upd = actv && !sng;
-                            const R rinv = (R)1 / dbar;
-                            const R beta = (pt * al) * rinv;
-                            const R aln = (dold * al) * rinv;
-                            if (pos[t >> 4] == t) {
-                                if (sng) { D[t >> 4] = (R)0; Dinv[t >> 4] = (R)0; }
-                                else if (upd) { D[t >> 4] = dbar; Dinv[t >> 4] = rinv; }
-                            }
-                            if (sng) { sing = t; stop = true; }
-                            al = upd ? aln : al;
+                int stop = 0;
+                const int nhi2 = rw_max4(dr ? na : 0);
+                // (the columns of a block of four steps are read at its head: a step changes its own column only)
+                constexpr int CHR = 4;
+                rw_static_for<0, (CAPP - 1 + CHR - 1) / CHR>([&](auto B) {
+                    constexpr int t0 = decltype(B)::value * CHR;
+                    if (t0 + CHR > rlo && t0 < nhi2) {
+                        RW_BLOCK();
+                        R lqb[CHR][S];
 #pragma unroll
-                            for (int s = 0; s < S; s++) {
-                                if (16 * s + 15 > t) {
-                                    const R lq = lds[fo[s] + t * LDC];
-                                    const bool m2 = upd && pos[s] > t && pos[s] < na;
-                                    const R wn = wv_fma(-pt, lq, w[s]);
-                                    w[s] = m2 ? wn : w[s];
-                                    if (m2) lds[fo[s] + t * LDC] = wv_fma(beta, wn, lq);
+                        for (int q = 0; q < CHR; q++)
+#pragma unroll
+                            for (int s = 0; s < S; s++) lqb[q][s] = lds[fo[s] + (t0 + q < CAPP - 1 ? t0 + q : CAPP - 2) * LDC];
+                        rw_static_for<0, CHR>([&](auto Q) {
+                            constexpr int t = t0 + decltype(Q)::value;
+                            if constexpr (t < CAPP - 1) {
+                                const bool actv = dr && t >= r && t < na && !stop;
+                                if (rw_any(actv)) {
+                                    const R pt = rw_bc<t>(w[t >> 4]);
+                                    const R dold = rw_bc<t>(D[t >> 4]);
+                                    const R dbar = wv_fma(al * pt, pt, dold);
+                                    const bool sng = actv && dbar < zero_tol;
+                                    const bool upd = actv && !sng;
+                                    const R rinv = (R)1 / dbar;
+                                    const R beta = (pt * al) * rinv;
+                                    const R aln = (dold * al) * rinv;
+                                    {
+                                        const bool hs = sng && pos[t >> 4] == t, hu = upd && pos[t >> 4] == t;
+                                        D[t >> 4] = hs ? (R)0 : (hu ? dbar : D[t >> 4]);
+                                        Dinv[t >> 4] = hs ? (R)0 : (hu ? rinv : Dinv[t >> 4]);
+                                    }
+                                    sing = sng ? t : sing;
+                                    stop = sng ? 1 : stop;
+                                    al = upd ? aln : al;
+#pragma unroll
+                                    for (int s = 0; s < S; s++) {
+                                        if (16 * s + 15 > t) {
+                                            const R lq = lqb[decltype(Q)::value][s];
+                                            const bool m2 = upd && pos[s] > t && pos[s] < na;
+                                            const R wn = wv_fma(-pt, lq, w[s]);
+                                            w[s] = m2 ? wn : w[s];
+                                            if (m2) lds[fo[s] + t * LDC] = wv_fma(beta, wn, lq);
+                                        }
+                                    }
                                 }
                             }
-                        }
+                        });
                     }
                 });
             }
-            if (doRem && li == (jrem & 15)) {
-                actb &= ~(1u << (jrem >> 4));
-                lowb &= ~(1u << (jrem >> 4));
+            {
+                const bool mine = dr && li == (jrem & 15);
+                const unsigned bit = 1u << (jrem >> 4);
+                actb = mine ? (actb & ~bit) : actb;
+                lowb = mine ? (lowb & ~bit) : lowb;
             }
-            if (doRem) nsoft -= softrem;
+            nsoft = dr ? nsoft - softrem : nsoft;
         }
-        if (run && !fin) iter++;
+        RWT(8);
+        iter = (run && !fin) ? iter + 1 : iter;
 
         // =============================================================== rows whose problem has ended: outputs, clean-up
-        if (rw_any(fin)) {
-            const bool listed = fin && flag == EXIT_WSCAP && ovf_list != nullptr;
-            const int tho = (fin ? pid : 0) * nth;
+        if (rw_any(fin != 0)) {
+            const RowParams<R> *a = RW_ARGS();
+            const bool fn = fin != 0;
+            const bool listed = fn && flag == EXIT_WSCAP && a->ovf_list != nullptr;
+            const R *th = a->theta + (long long)(fn ? pid : 0) * nth;
             // x = R^-1 u + x0 + Xth theta   (mpc_update_qp.c:14-22); lane k of slot s writes output k + 16 s
 #pragma unroll
             for (int s = 0; s < NS; s++) {
@@ -783,25 +948,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                             RW_BLOCK();
                             R rv[4];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) rv[q] = ldc(P.oRout, lo * n + (c0 + q < n ? c0 + q : n - 1));   // (beyond n: u_c = 0)
+                            for (int q = 0; q < 4; q++) rv[q] = ldc(prm.P.oRout, lo * n + (c0 + q < n ? c0 + q : n - 1));   // (beyond n: u_c = 0)
                             rw_static_for<0, 4>([&](auto Q) {
                                 constexpr int c = c0 + decltype(Q)::value;
                                 xs = wv_fma(rv[decltype(Q)::value], rw_bc<c>(u[c >> 4]), xs);
                             });
                         }
                     });
-                    R sh = ldc(P.ox0, lo);
-                    for (int t = 0; t < nth; t++) sh = wv_fma(ldc(P.oXth + t, lo * nth), ldth(tho + t), sh);
+                    R sh = ldc(prm.P.ox0, lo);
+                    for (int t = 0; t < nth; t++) sh = wv_fma(ldc(prm.P.oXth + t, lo * nth), th[t], sh);
                     const R xo = xs + sh;
-                    if (fin && ko < nout && X != nullptr) X[(long long)pid * nout + ko] = xo;
+                    if (fn && ko < nout && a->X != nullptr) a->X[(long long)pid * nout + ko] = xo;
                 }
             }
-            if (active != nullptr) {
+            if (a->active != nullptr) {
                 unsigned long long acc = 0ull;
+                const int words = prm.P.words;
 #pragma unroll
                 for (int r = 0; r < MS; r++) {
-                    const bool a = fin && ((actb >> r) & 1u), lo = (lowb >> r) & 1u;
-                    const unsigned long long bu = __ballot(a && !lo), bl = __ballot(a && lo);
+                    const bool ab = fn && ((actb >> r) & 1u), lo = (lowb >> r) & 1u;
+                    const unsigned long long bu = __ballot(ab && !lo), bl = __ballot(ab && lo);
                     const unsigned long long mu = (bu >> (16 * g)) & 0xffffull, ml = (bl >> (16 * g)) & 0xffffull;
                     const int pu = 16 * r, pl = m + 16 * r;
                     if ((pu >> 6) == li) acc |= mu << (pu & 63);
@@ -809,25 +975,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LMPC_ROW_WP
                     if ((pl >> 6) == li) acc |= ml << (pl & 63);
                     if ((pl >> 6) + 1 == li && (pl & 63) > 48) acc |= ml >> (64 - (pl & 63));
                 }
-                if (fin && !listed && li < P.words) active[(long long)pid * P.words + li] = acc;
+                if (fn && !listed && li < words) a->active[(long long)pid * words + li] = acc;
             }
-            if (fin && li == 0) {
-                if (exitflag != nullptr) exitflag[pid] = flag;
-                if (iters != nullptr) iters[pid] = iter;
-                if (listed) ovf_list[atomicAdd(ovf_count, 1)] = (int32_t)pid;
-                if (stat != nullptr && !listed)
-                    atomicAdd(&stat[(((int)myrow) & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
+            if (fn && li == 0) {
+                if (a->exitflag != nullptr) a->exitflag[pid] = flag;
+                if (a->iters != nullptr) a->iters[pid] = iter;
+                if (listed) a->ovf_list[atomicAdd(a->ovf_count, 1)] = (int32_t)pid;
+                if (a->stat != nullptr && !listed)
+                    atomicAdd(&a->stat[(myrow & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
             }
             // the factor's rows back to zeros: the next problem of this row starts on a factor of zeros
-            const int nclr = rw_max4(fin ? na : 0);
+            const int nclr = rw_max4(fn ? na : 0);
             for (int i = 1; i < nclr; i++) {
 #pragma unroll
                 for (int s = 0; s < S; s++)
-                    if (fin && i < na && pos[s] < i) lds[bo[s] + i] = (R)0;
+                    if (fn && i < na && pos[s] < i) lds[bo[s] + i] = (R)0;
             }
-            if (fin) live = 0;
+            live = fn ? 0 : live;
+            RWT(9);
+            RWT_COUNT(13, (int)__popcll(__ballot(fn && li == 0)));
         }
     }
+    RWT_FLUSH;
 }
 
 }  // namespace lmpc
