@@ -9,42 +9,41 @@ namespace lmpc {
 
 namespace {
 
-struct RowShape { int S, NS, MS, LDC; };
+struct RowShape { int S, NS, MS, CAPP; };
 
 // the instantiations built (LMPC_ROW_REAL per translation unit): position / variable / constraint slots, leading dimension
 constexpr RowShape kRowShapes[] = {
-    {1, 1, 4, 17},      // n <= 16, m <= 64, working sets <= 16 rows (the reference's mass_spring example: n = 10, m = 63)
+    {1, 1, 4, 16},      // n <= 16, m <= 64, working sets <= 16 rows (the reference's mass_spring example: n = 10, m = 63)
     {2, 2, 6, 31},      // n <= 32, m <= 96, <= 31 rows (BASELINE config 3: n = 30, m = 84)
-    {2, 2, 6, 33},      // ... <= 32 rows
-    {2, 4, 10, 33},     // n <= 64, m <= 160, <= 32 rows (the reference's benchmark class at N = 50: first of two passes)
+    {2, 2, 6, 32},      // ... <= 32 rows
+    {2, 4, 10, 32},     // n <= 64, m <= 160, <= 32 rows (the reference's benchmark class at N = 50: first of two passes)
 };
 
 bool shape_covers(const RowShape &sh, int n, int m, int cap) {
-    const int capp = 16 * sh.S < sh.LDC ? 16 * sh.S : sh.LDC;
-    return n <= 16 * sh.NS && m <= 16 * sh.MS && cap <= capp && m <= 256 /* mask words on 16 lanes */;
+    return n <= 16 * sh.NS && m <= 16 * sh.MS && cap <= sh.CAPP && m <= 256 /* mask words on 16 lanes */;
 }
 
-struct RowLaunch { int shape, nwv, blocks; size_t lds; };
+struct RowLaunch { int shape, nwv, blocks, ps; size_t lds; };
 
 bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
     const int n = h->P.n, m = h->P.m;
     for (int q = 0; q < (int)(sizeof(kRowShapes) / sizeof(kRowShapes[0])); q++) {
         const RowShape &sh = kRowShapes[q];
         if (!shape_covers(sh, n, m, cap)) continue;
-        const int capp = 16 * sh.S < sh.LDC ? 16 * sh.S : sh.LDC;
-        const size_t ps = (size_t)row_problem_stride(capp, sh.LDC);
-        // most wavefronts per CU (each carries four problems); the staged M' is shared by a workgroup's wavefronts
-        RowLaunch best{-1, 0, 0, 0};
+        // most wavefronts per CU (each carries four problems; two per SIMD is what the registers allow); the staged M' is
+        // shared by a workgroup's wavefronts
+        RowLaunch best{-1, 0, 0, 0, 0};
         int bestWaves = 0;
         const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS);
-        for (int nwv : {4, 3, 2, 1}) {
-            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps) + sizeof(int32_t) * (size_t)m + 16;
+        for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
+            const int ps = row_ps(sh.CAPP, nwv);
+            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * (size_t)m + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
-            if (blocks * nwv > 8) blocks = 8 / nwv;                  // (256 registers: two wavefronts per SIMD at most)
+            if (blocks * nwv > 8) blocks = 8 / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
-            if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, lds}; }
+            if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, ps, lds}; }
         }
         if (best.shape < 0) return false;
         *out = best;
@@ -53,10 +52,10 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
     return false;
 }
 
-template <typename R, int S, int NS, int MS, int LDC>
+template <typename R, int S, int NS, int MS, int CAPP>
 int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, hipStream_t st, int cap, int pass) {
-    auto kern = row_kernel<R, S, NS, MS, LDC>;
+    auto kern = row_kernel<R, S, NS, MS, CAPP>;
     if (rl.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl.lds));
     if (h->preloadOnly) {
@@ -65,7 +64,7 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
         return LMPC_OK;
     }
     WaveLayout Wl = h->W;
-    Wl.cap = cap; Wl.ldc = LDC;
+    Wl.cap = cap; Wl.ldc = 0;
     int blocks = rl.blocks;
     if (h->rowBlocks > 0) blocks = h->rowBlocks;
     long long grid = (long long)h->numCU * blocks;
@@ -111,7 +110,7 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
     const WaveList &wl = h->waveList;
     RowParams<R> prm{};
     prm.P = Wl; prm.C = dC; prm.Sg = h->dSw; prm.theta = theta; prm.X = x; prm.exitflag = flag; prm.iters = iters;
-    prm.active = active; prm.queue = queue; prm.qchunk = qchunk; prm.nprob = (long long)nprob;
+    prm.active = active; prm.queue = queue; prm.qchunk = qchunk; prm.ps = rl.ps; prm.nprob = (long long)nprob;
     prm.list = wl.list; prm.count = wl.count; prm.count_next = wl.count_next; prm.seg_cap = wl.seg_cap;
     prm.ovf_list = pass == 1 ? h->dOvfList1 : nullptr; prm.ovf_count = pass == 1 ? p1Count : nullptr;
     prm.queue_next = queueNext; prm.ovf_next = p2Next; prm.ovf_next1 = p1Next;
@@ -156,12 +155,12 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
                uint64_t *active, hipStream_t st, int cap, int pass) {
     RowLaunch rl;
     if (!row_launch_for(h, cap, sizeof(R), &rl)) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no row-kernel instantiation");
-#define LMPC_ROW(S_, NS_, MS_, LDC_) launch_row_shape<R, S_, NS_, MS_, LDC_>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass)
+#define LMPC_ROW(S_, NS_, MS_, CAPP_) launch_row_shape<R, S_, NS_, MS_, CAPP_>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass)
     switch (rl.shape) {
-        case 0: return LMPC_ROW(1, 1, 4, 17);
+        case 0: return LMPC_ROW(1, 1, 4, 16);
         case 1: return LMPC_ROW(2, 2, 6, 31);
-        case 2: return LMPC_ROW(2, 2, 6, 33);
-        default: return LMPC_ROW(2, 4, 10, 33);
+        case 2: return LMPC_ROW(2, 2, 6, 32);
+        default: return LMPC_ROW(2, 4, 10, 32);
     }
 #undef LMPC_ROW
 }

@@ -18,9 +18,11 @@
 //    register; the four problems of a wavefront take different decisions, so the phases of an iteration (stationary
 //    point, blocking test, then row append OR row removal) run under per-row predicates -- selects, never EXEC masks
 //    around DPP instructions;
-//  * the factor L of each problem sits in LDS, square and zero padded exactly as in the wavefront kernel (a sweep step
-//    is one fma on all lanes: fma(-0, v_t, v) = v), column major with an odd leading dimension LDC; the four problems of
-//    a wavefront are 16 (mod 32) reals apart, so that the two rows a 32-lane LDS phase serves never share a bank;
+//  * the factor L of each problem sits in LDS as its strict lower triangle, column after column, every column padded
+//    upwards to a multiple of four rows (rowp_p0 below): a sweep step is ONE v_fmac_f64_dpp per slot of positions --
+//    the broadcast is the instruction's own DPP control, the lanes outside the column are its bank mask or read
+//    padding zeros -- and 32 problems' factors fit a CU's LDS (two wavefronts per SIMD); the two rows a 32-lane LDS
+//    phase serves sit 16 (mod 32) reals apart, so they never share a bank;
 //  * a row that finishes a problem writes its outputs and takes the next problem from the batch by itself (tickets of
 //    a few problems each from one global counter), the other three rows keep iterating.
 //
@@ -28,7 +30,7 @@
 // results are bit-identical to the oracle's and to the wavefront kernel's (x, exit flag, iteration count, active set).
 //
 // Covers: cold plain solves, binary64 / binary32, n <= 16 NS, m <= 16 MS, hard / SOFT / IMMUTABLE rows, no rows
-// flagged ACTIVE or BINARY, working sets up to min(16 S, LDC) rows; a point that outgrows that is listed for the
+// flagged ACTIVE or BINARY, working sets up to CAPP <= 16 S rows; a point that outgrows that is listed for the
 // wavefront kernel (exit flag -7 inside this pass), exactly like the first of that kernel's two passes.
 //
 // Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp incl. soft constraints
@@ -128,23 +130,26 @@ __device__ __forceinline__ bool rw_any(bool p) { return __ballot(p) != 0ull; }
 
 constexpr int kRowPosFlagSoft = 1 << 16, kRowPosFlagImm = 1 << 17, kRowPosFlagLow = 1 << 18;
 constexpr int kRowBig = 0x7fffffff;
-// resident wavefronts per SIMD an instantiation is register-budgeted for: two where one slot of positions keeps the
-// factors small (LDS then allows them), else one (the factors of 16 problems fill the LDS of a CU: 256 + 256 registers)
-#ifndef LMPC_ROW_WPE
-#define LMPC_ROW_WPE 0
-#endif
-__host__ __device__ constexpr int row_wpe(int s, int ns, int ms) { return LMPC_ROW_WPE > 0 ? LMPC_ROW_WPE : (s >= 2 ? 1 : 2); }
-
-// reals of LDS one problem's factor takes: (cap - 1) columns of LDC rows, rounded up to 16 (mod 32)
-// reals per row of the staged M' (odd)
-__host__ __device__ constexpr int row_mpad(int ms) { return 16 * ms + 1; }
-__host__ __device__ constexpr int row_problem_stride(int cap, int ldc) {
-    const int need = (cap - 1) * ldc;
-    int ps = (need + 31) / 32 * 32 + 16;
-    if (ps - 32 >= need) ps -= 32;
+// The factor of a problem in LDS: the strict lower triangle column after column, each column padded UPWARDS to a row
+// index that is a multiple of four: column t holds rows p0(t) = 4 floor(t / 4) .. capp-1, of which p0(t) .. t are zeros
+// that are never written.  Entry (p, t) sits at cbm(t) + p.  A sweep step then needs no lane mask and no select: the
+// lanes of the 4-lane DPP banks entirely outside a column are switched off by the instruction's bank_mask (a literal),
+// the at most three lanes left in the bank of the diagonal read the padding.  538 reals for 31 rows (the square,
+// zero padded layout of the wavefront kernel: 930) -- which is what lets a CU hold the factors of 32 problems instead
+// of 16, i.e. two wavefronts per SIMD.
+__host__ __device__ constexpr int rowp_p0(int t) { return t & ~3; }
+__host__ __device__ constexpr int rowp_cb(int capp, int t) { return 4 * (t >> 2) * capp - 8 * (t >> 2) * ((t >> 2) - 1) + (t & 3) * (capp - 4 * (t >> 2)); }
+__host__ __device__ constexpr int rowp_cbm(int capp, int t) { return rowp_cb(capp, t) - rowp_p0(t); }
+__host__ __device__ constexpr int rowp_size(int capp) { return rowp_cb(capp, capp - 1); }      // columns 0 .. capp-2
+// reals between the factors of two problems, for nwv wavefronts per workgroup: the two DPP rows a 32-lane LDS phase
+// serves (problems nwv slots apart) must sit 16 reals apart modulo 32
+__host__ __device__ constexpr int row_ps(int capp, int nwv) {
+    int ps = rowp_size(capp);
+    while ((nwv * ps) % 32 != 16) ps++;
     return ps;
 }
-
+// reals per row of the staged M' (odd)
+__host__ __device__ constexpr int row_mpad(int ms) { return 16 * ms + 1; }
 // Everything a launch passes, in ONE block: the kernel copies the few scalars its iterations need into registers and
 // reads the rest -- the pointers of the outputs, the work list, the counters -- from the kernel-argument segment where
 // it uses them (a row takes or ends a problem once in ~8 trips), through a pointer the compiler cannot see through.
@@ -154,18 +159,56 @@ template <typename R> struct RowParams {
     WaveLayout P;
     const R *C; const int32_t *Sg; const R *theta;
     R *X; int32_t *exitflag, *iters; uint64_t *active;
-    int32_t *queue; int qchunk; long long nprob;
+    int32_t *queue; int qchunk; int ps; long long nprob;
     const int32_t *list, *count; int32_t *count_next; long long seg_cap;
     int32_t *ovf_list, *ovf_count, *queue_next, *ovf_next, *ovf_next1;
     unsigned long long *stat; volatile unsigned long long *stat_host;
 };
 
-// R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  LDC: leading
-// dimension of the factor (odd; the launch's capacity P.cap <= min(LDC, 16 S)).
-template <typename R, int S, int NS, int MS, int LDC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, NS, MS)))) void row_kernel(const RowParams<R> prm) {
-    static_assert((LDC & 1) == 1, "odd leading dimension");
-    static_assert(LDC <= 16 * S + 1, "rows of the factor live on S slots");
+// fused multiply-add with a row broadcast as its first factor and a DPP bank mask: acc += lane T of src's row * (-mul),
+// in the lanes of the banks set in BM (the others keep acc).  The 64-bit form is inline assembly (no builtin reaches
+// v_fmac_f64_dpp); the statements that use it carry their own wait states (see the sweeps).
+#define RW_FMAC_DPP64 "v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
+#define RW_FMAC_DPP32 "v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
+
+// one sweep step as ONE statement: NOP + 1 wait states (2 behind a vector instruction that wrote `src`, 5 behind a scalar
+// write of EXEC: the compiler knows neither hazard inside inline assembly), then
+//   rw_step1: acc += lane T of acc's row * (-l)            in the banks BM
+//   rw_step2: oth += lane T of src's row * (-loth)          in all lanes, then src += lane T of src's row * (-lsrc) in the banks BM
+template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step1(double &acc, double l) {
+    asm volatile("s_nop %2\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(l), "n"(NOP), "n"(T), "n"(BM));
+}
+template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step1(float &acc, float l) {
+    asm volatile("s_nop %2\n\tv_fmac_f32_dpp %0, %0, -%1 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(l), "n"(NOP), "n"(T), "n"(BM));
+}
+template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(double &src, double &oth, double lsrc, double loth) {
+    asm volatile("s_nop %4\n\tv_fmac_f64_dpp %1, %0, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"
+                 : "+v"(src), "+v"(oth) : "v"(lsrc), "v"(loth), "n"(NOP), "n"(T), "n"(BM));
+}
+template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(float &src, float &oth, float lsrc, float loth) {
+    asm volatile("s_nop %4\n\tv_fmac_f32_dpp %1, %0, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"
+                 : "+v"(src), "+v"(oth) : "v"(lsrc), "v"(loth), "n"(NOP), "n"(T), "n"(BM));
+}
+// banks (of four lanes) of slot s that hold rows >= p0(t) / columns <= t
+__host__ __device__ constexpr int rw_bm_rows(int s, int t) {
+    int bm = 0;
+    for (int b = 0; b < 4; b++) bm |= (16 * s + 4 * b >= rowp_p0(t)) ? (1 << b) : 0;
+    return bm;
+}
+__host__ __device__ constexpr int rw_bm_cols(int s, int t) {
+    int bm = 0;
+    for (int b = 0; b < 4; b++) bm |= (16 * s + 4 * b <= t) ? (1 << b) : 0;
+    return bm;
+}
+
+// R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  CAPP: rows the
+// factor is laid out for (the launch's capacity P.cap <= CAPP <= 16 S).
+template <typename R, int S, int NS, int MS, int CAPP>
+__global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
+    static_assert(S == 1 || S == 2, "one or two slots of working-set positions");
+    static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
 #if defined(__HIP_DEVICE_COMPILE__)
     const RowParams<R> *kparg = (const RowParams<R> *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -195,9 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
     int n = prm.P.n, m = prm.P.m, nth = prm.P.nth, cap = prm.P.cap, nout = prm.P.nout, oG = prm.P.oG;
     int iter_limit = prm.P.iter_limit, cycle_tol = prm.P.cycle_tol;
     asm volatile("" : "+s"(n), "+s"(m), "+s"(nth), "+s"(cap), "+s"(nout), "+s"(oG), "+s"(iter_limit), "+s"(cycle_tol));
-    constexpr int CAPP = 16 * S < LDC ? 16 * S : LDC;            // positions the instantiation has code for
-    constexpr int PS = row_problem_stride(CAPP, LDC);          // (sized for the instantiation: a sweep block may read columns up to CAPP - 2)
-    // LDS: [32 zeros][M': ceil4(n) rows of MPAD reals, zero padded][factors: nwv * 4 problems, PS reals each][sense flags: m ints]
+    const int PS = prm.ps;                                     // reals between two problems' factors (row_ps)
+    // LDS: [32 zeros][M': ceil4(n) rows of MPAD reals, zero padded][factors: nwv * 4 problems, PS reals each][2 zeros][sense flags: m ints]
     // ONE copy of the problem matrix serves both passes over it: the constraint scan reads ROW k of M' (lane = constraint,
     // consecutive addresses), the primal step reads COLUMN w of it (lane = variable, stride MPAD -- odd, so the 16 lanes
     // of a row hit 16 different banks).  MPAD is a compile-time constant: every address of the scan is one per-lane
@@ -206,14 +248,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
     constexpr int MPAD = row_mpad(MS);
     const int nP = (n + 3) & ~3;
     const int oZ = 0, oMt = 32, oL = oMt + nP * MPAD;
-    int32_t *sens = reinterpret_cast<int32_t *>(lds + oL + nwv * 4 * PS);
+    int32_t *sens = reinterpret_cast<int32_t *>(lds + oL + nwv * 4 * PS + 2);
     const R *__restrict__ C = prm.C;
     for (int i = threadIdx.x; i < 32; i += blockDim.x) lds[oZ + i] = (R)0;
     for (int i = threadIdx.x; i < nP * MPAD; i += blockDim.x) {
         const int k = i / MPAD, j = i - k * MPAD;
         lds[oMt + i] = (k < n && j < m) ? C[prm.P.oMt + k * m + j] : (R)0;
     }
-    for (int i = threadIdx.x; i < nwv * 4 * PS; i += blockDim.x) lds[oL + i] = (R)0;
+    for (int i = threadIdx.x; i < nwv * 4 * PS + 2; i += blockDim.x) lds[oL + i] = (R)0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = prm.Sg[i];
     __syncthreads();
 
@@ -231,14 +273,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
     // whose loads are all hoisted to its head (first build: 390 registers).
 #define RW_BLOCK() asm volatile("" ::: "memory")
 
-    // element (row p, column t) of this row's factor: lds[Lg + t * LDC + p]
-    const int Lg = oL + (wv * 4 + g) * PS;
+    // element (row p, column t) of this row's factor: lds[Lg + cbm(t) + p]
+    auto cbm = [](int t) -> int { return rowp_cbm(CAPP, t); };
+    const int Lg = oL + (wv + nwv * g) * PS;
     int pos[S], fo[S], bo[S];          // this lane's positions; offsets of its ROW (forward sweeps) and of its COLUMN
 #pragma unroll
     for (int s = 0; s < S; s++) {
         pos[s] = li + 16 * s;
-        fo[s] = Lg + (pos[s] < cap ? pos[s] : 0);                       // (row 0 has no entries: zeros in every column)
-        bo[s] = pos[s] < cap - 1 ? Lg + pos[s] * LDC : oZ;              // (beyond the last column: the block of zeros)
+        fo[s] = Lg + pos[s];                                            // (a lane beyond the last row reads the next column's padding)
+        bo[s] = pos[s] < CAPP - 1 ? Lg + cbm(pos[s]) : oZ;              // (beyond the last column: the block of zeros)
     }
     int jc[MS], mcol[NS];
     unsigned okb = 0u, hardb = 0u;     // bit r: this lane's row of slot r can enter a working set / ... and is a hard row
@@ -302,10 +345,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
     int chunk_static = myrow;
     // ---- sweeps over the factor.  forward: v_p -= L(p,t) v_t for t = 0 .. top-1 in order; backward: v_i -= L(t,i) v_t
     // for t = top .. 1 descending.  `top` is wave-uniform (the largest of the four rows); a row whose working set is
-    // smaller reads zeros (its factor's rows beyond na are zeros).
+    // smaller reads zeros (its factor's rows beyond na are zeros).  A step is one v_fmac_f64_dpp per slot of target
+    // positions: the multiplier v_t arrives as the instruction's row broadcast, the lanes outside the column are switched
+    // off by its bank mask or read the column's padding (see rowp_p0).
     // The factor's entries of a block of CHS steps are fetched while the block before it runs (issued at its head, waited
-    // for at their first use): with one wavefront per SIMD nothing else hides the LDS round trip.
-    constexpr int CHS = S == 1 ? 8 : 4;
+    // for at their first use).
+    constexpr int CHS = 4;
     auto sweep_fwd = [&](R (&v)[S], int nmax) {
         constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;               // steps t = 0 .. CAPP-2
         R Ln[CHS][S];
@@ -314,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
 #pragma unroll
             for (int q = 0; q < CHS; q++)
 #pragma unroll
-                for (int s = 0; s < S; s++) Ln[q][s] = lds[fo[s] + (t0 + q < CAPP - 1 ? t0 + q : CAPP - 2) * LDC];
+                for (int s = 0; s < S; s++) Ln[q][s] = lds[fo[s] + rowp_cbm(CAPP, t0 + q < CAPP - 1 ? t0 + q : CAPP - 2)];
         };
         if (1 < nmax) fetch(std::integral_constant<int, 0>{});
         rw_static_for<0, NB>([&](auto B) {
@@ -328,14 +373,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
                     for (int s = 0; s < S; s++) Lr[q][s] = Ln[q][s];
                 if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
                 rw_static_for<0, CHS>([&](auto Q) {
-                    constexpr int t = t0 + decltype(Q)::value;
+                    constexpr int q = decltype(Q)::value, t = t0 + q;
+                    constexpr int NOP = q == 0 ? 4 : 1;
                     if constexpr (t + 1 < CAPP) {
-                        const R vt = rw_bc<t>(v[t >> 4]);
-#pragma unroll
-                        for (int s = S - 1; s >= 0; s--)
-                            if (16 * s + 15 > t) v[s] = wv_fma(-Lr[decltype(Q)::value][s], vt, v[s]);
+                        if constexpr (S == 1) rw_step1<t, rw_bm_rows(0, t), NOP>(v[0], Lr[q][0]);
+                        else if constexpr (t < 16) rw_step2<t, rw_bm_rows(0, t), NOP>(v[0], v[S - 1], Lr[q][0], Lr[q][S - 1]);
+                        else rw_step1<t - 16, rw_bm_rows(1, t), NOP>(v[S - 1], Lr[q][S - 1]);
                     }
                 });
+#pragma unroll
+                for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));   // (a DPP read of v may follow)
             }
         });
     };
@@ -365,14 +412,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
                     for (int s = 0; s < S; s++) Lc[q][s] = Ln[q][s];
                 if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
                 rw_static_for<0, CHS>([&](auto Q) {
-                    constexpr int t = thi - decltype(Q)::value;
+                    constexpr int q = decltype(Q)::value, t = thi - q;
+                    constexpr int NOP = q == 0 ? 4 : 1;
                     if constexpr (t >= 1) {
-                        const R vt = rw_bc<t>(v[t >> 4]);
-#pragma unroll
-                        for (int s = 0; s < S; s++)
-                            if (16 * s < t) v[s] = wv_fma(-Lc[decltype(Q)::value][s], vt, v[s]);
+                        if constexpr (S == 1) rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
+                        else if constexpr (t >= 16) rw_step2<t - 16, rw_bm_cols(1, t), NOP>(v[S - 1], v[0], Lc[q][S - 1], Lc[q][0]);
+                        else rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
                     }
                 });
+#pragma unroll
+                for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));
             }
         });
     };
@@ -632,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
             R fv = (R)0, Mu[MS];
 #pragma unroll
             for (int r = 0; r < MS; r++) Mu[r] = (R)0;
-            constexpr int CHK = 4, NBK = 16 * NS / CHK;            // (the staged M' has ceil4(n) rows)
+            constexpr int CHK = MS <= 4 ? 4 : 2, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
                 auto fetch = [&](auto B) {
@@ -803,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
             R w[S];
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                const R lv = lds[fo[s] + (r < cap - 1 ? r : 0) * LDC];          // L(pos, r), old row index = pos
+                const R lv = lds[fo[s] + cbm(r < CAPP - 1 ? r : 0)];                // L(pos, r), old row index = pos
                 w[s] = (dr && pos[s] > r && pos[s] < nao) ? lv : (R)0;
             }
             R dsel = D[0];
@@ -820,8 +869,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     int cp = pos[s] + (pos[s] >= r ? 1 : 0);
-                    cp = cp < cap - 1 ? cp : 0;
-                    so[s] = Lg + cp * LDC;
+                    cp = cp < CAPP - 1 ? cp : 0;
+                    so[s] = Lg + cbm(cp);
                 }
                 // (four rows read before they are written: the reads of a row do not wait for the row above it)
                 for (int i0 = rlo; i0 < nhi - 1; i0 += 4) {
@@ -880,7 +929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
 #pragma unroll
                         for (int q = 0; q < CHR; q++)
 #pragma unroll
-                            for (int s = 0; s < S; s++) lqb[q][s] = lds[fo[s] + (t0 + q < CAPP - 1 ? t0 + q : CAPP - 2) * LDC];
+                            for (int s = 0; s < S; s++) lqb[q][s] = lds[fo[s] + rowp_cbm(CAPP, t0 + q < CAPP - 1 ? t0 + q : CAPP - 2)];
                         rw_static_for<0, CHR>([&](auto Q) {
                             constexpr int t = t0 + decltype(Q)::value;
                             if constexpr (t < CAPP - 1) {
@@ -909,7 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(row_wpe(S, 
                                             const bool m2 = upd && pos[s] > t && pos[s] < na;
                                             const R wn = wv_fma(-pt, lq, w[s]);
                                             w[s] = m2 ? wn : w[s];
-                                            if (m2) lds[fo[s] + t * LDC] = wv_fma(beta, wn, lq);
+                                            if (m2) lds[fo[s] + rowp_cbm(CAPP, t)] = wv_fma(beta, wn, lq);
                                         }
                                     }
                                 }
