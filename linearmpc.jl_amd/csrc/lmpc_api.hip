@@ -1815,6 +1815,8 @@ const char *lmpc_kernel_name(const lmpc_handle *h) {
             wname = "qp_tiers<" + std::to_string(h->P.n) + ">|wave";
             return wname.c_str();
         }
+        // (large cold plain binary64 batches: four problems per wavefront where that kernel is the default)
+        if (row_pass_cap(const_cast<lmpc_handle *>(h), (int64_t)1 << 20, sizeof(double), false, h->waveGram != 0, h->bnb) > 0) return "row|wave";
         return "wave";
     }
     // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm

@@ -36,11 +36,12 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
         int bestWaves = 0;
         const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS);
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
+            if (64 * nwv > row_launch_bound(sh.MS)) continue;
             const int ps = row_ps(sh.CAPP, nwv);
             const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * (size_t)m + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
-            if (blocks * nwv > 8) blocks = 8 / nwv;
+            if (blocks * nwv > row_launch_bound(sh.MS) / 64) blocks = row_launch_bound(sh.MS) / 64 / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
             if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, ps, lds}; }
@@ -137,6 +138,10 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     const int full = h->W.cap;
     RowLaunch rl;
     int cap = 0;
+    // where it is the default (measured, tools/row_check.py): the two-slot shapes with up to six constraint slots -- config 3
+    // runs 1.6x the wavefront kernel there; the one-slot shape (behind the tiers pass) and the ten-slot one (one wavefront
+    // per SIMD) run level with it or behind and are taken only on request ("row_kernel" 1)
+    if (h->rowKernel < 0 && !(h->P.n > 16 && h->P.n <= 32 && h->P.m <= 96)) return 0;
     if (full <= 32 && row_launch_for(h, full, rs, &rl)) cap = full;
     else if (full > 32 && h->bigPath && h->waveTwoPass != 0) {
         // first of two passes at 32 rows: when at most 1 in 20 of the working sets seen lately went beyond

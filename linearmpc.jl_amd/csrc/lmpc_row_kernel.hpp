@@ -129,6 +129,7 @@ __device__ __forceinline__ int rw_min4(int v) {
 __device__ __forceinline__ bool rw_any(bool p) { return __ballot(p) != 0ull; }
 
 constexpr int kRowPosFlagSoft = 1 << 16, kRowPosFlagImm = 1 << 17, kRowPosFlagLow = 1 << 18;
+constexpr int kRowPosOffShift = 20;      // bits 20 ..: where the row sits inside a row of the staged M' (lane * MS + slot)
 constexpr int kRowBig = 0x7fffffff;
 // The factor of a problem in LDS: the strict lower triangle column after column, each column padded UPWARDS to a row
 // index that is a multiple of four: column t holds rows p0(t) = 4 floor(t / 4) .. capp-1, of which p0(t) .. t are zeros
@@ -148,8 +149,9 @@ __host__ __device__ constexpr int row_ps(int capp, int nwv) {
     while ((nwv * ps) % 32 != 16) ps++;
     return ps;
 }
-// reals per row of the staged M' (odd)
-__host__ __device__ constexpr int row_mpad(int ms) { return 16 * ms + 1; }
+// reals per row of the staged M' (even, half of it odd): row k holds, for lane i = 0 .. 15, the MS entries M'(k, i + 16 r)
+// side by side
+__host__ __device__ constexpr int row_mpad(int ms) { return 16 * ms + 2; }
 // Everything a launch passes, in ONE block: the kernel copies the few scalars its iterations need into registers and
 // reads the rest -- the pointers of the outputs, the work list, the counters -- from the kernel-argument segment where
 // it uses them (a row takes or ends a problem once in ~8 trips), through a pointer the compiler cannot see through.
@@ -164,6 +166,11 @@ template <typename R> struct RowParams {
     int32_t *ovf_list, *ovf_count, *queue_next, *ovf_next, *ovf_next1;
     unsigned long long *stat; volatile unsigned long long *stat_host;
 };
+
+// threads per workgroup an instantiation is built for: 512 (two wavefronts per SIMD, 256 registers) up to six constraint
+// slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
+// LDS for five wavefronts' factors anyway)
+__host__ __device__ constexpr int row_launch_bound(int ms) { return ms <= 6 ? 512 : 256; }
 
 // fused multiply-add with a row broadcast as its first factor and a DPP bank mask: acc += lane T of src's row * (-mul),
 // in the lanes of the banks set in BM (the others keep acc).  The 64-bit form is inline assembly (no builtin reaches
@@ -206,7 +213,7 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 // R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  CAPP: rows the
 // factor is laid out for (the launch's capacity P.cap <= CAPP <= 16 S).
 template <typename R, int S, int NS, int MS, int CAPP>
-__global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
+__global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowParams<R> prm) {
     static_assert(S == 1 || S == 2, "one or two slots of working-set positions");
     static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
@@ -232,7 +239,8 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
     R *lds = reinterpret_cast<R *>(lds_raw);
     const int lane = threadIdx.x & 63, nwv = blockDim.x >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 15, rowbase = lane & 48, g = lane >> 4;
+    int li = lane & 15;
+    const int rowbase = lane & 48, g = lane >> 4;
     // (scalars of the iterations: each in a register of its own -- as fields of the by-value block they are sub-registers
     // of 16-wide loads that get spilled and reloaded whole)
     int n = prm.P.n, m = prm.P.m, nth = prm.P.nth, cap = prm.P.cap, nout = prm.P.nout, oG = prm.P.oG;
@@ -240,11 +248,13 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
     asm volatile("" : "+s"(n), "+s"(m), "+s"(nth), "+s"(cap), "+s"(nout), "+s"(oG), "+s"(iter_limit), "+s"(cycle_tol));
     const int PS = prm.ps;                                     // reals between two problems' factors (row_ps)
     // LDS: [32 zeros][M': ceil4(n) rows of MPAD reals, zero padded][factors: nwv * 4 problems, PS reals each][2 zeros][sense flags: m ints]
-    // ONE copy of the problem matrix serves both passes over it: the constraint scan reads ROW k of M' (lane = constraint,
-    // consecutive addresses), the primal step reads COLUMN w of it (lane = variable, stride MPAD -- odd, so the 16 lanes
-    // of a row hit 16 different banks).  MPAD is a compile-time constant: every address of the scan is one per-lane
-    // base register plus an immediate (with a run-time stride the compiler keeps one address register per (k, slot)
-    // alive across the whole kernel: 64 to 320 registers).
+    // ONE copy of the problem matrix serves both passes over it: the constraint scan reads ROW k of M' -- a lane's MS
+    // constraints side by side, 16-byte loads (ds_read_b128 moves 256 bytes a clock, the ds_read2_b64 the compiler makes
+    // of strided 8-byte loads 128) -- the primal step reads COLUMN w of it (lane = variable, stride MPAD: even with an
+    // odd half, so the 16 lanes of a row hit 16 different bank pairs).  MPAD is a compile-time constant: every address
+    // of the scan is one per-lane base register plus an immediate (with a run-time stride the compiler keeps one
+    // address register per (k, slot) alive across the whole kernel: 64 to 320 registers).
+    static_assert(MS % 2 == 0, "constraint slots in pairs (16-byte loads)");
     constexpr int MPAD = row_mpad(MS);
     const int nP = (n + 3) & ~3;
     const int oZ = 0, oMt = 32, oL = oMt + nP * MPAD;
@@ -252,8 +262,8 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
     const R *__restrict__ C = prm.C;
     for (int i = threadIdx.x; i < 32; i += blockDim.x) lds[oZ + i] = (R)0;
     for (int i = threadIdx.x; i < nP * MPAD; i += blockDim.x) {
-        const int k = i / MPAD, j = i - k * MPAD;
-        lds[oMt + i] = (k < n && j < m) ? C[prm.P.oMt + k * m + j] : (R)0;
+        const int k = i / MPAD, e = i - k * MPAD, j = (e / MS) + 16 * (e % MS);      // e = lane * MS + slot
+        lds[oMt + i] = (k < n && e < 16 * MS && j < m) ? C[prm.P.oMt + k * m + j] : (R)0;
     }
     for (int i = threadIdx.x; i < nwv * 4 * PS + 2; i += blockDim.x) lds[oL + i] = (R)0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = prm.Sg[i];
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
     }
 #pragma unroll
     for (int s = 0; s < NS; s++) mcol[s] = oMt + (li + 16 * s < n ? li + 16 * s : n - 1) * MPAD;   // this lane's variables: their rows of M'
-    const int mrow = oMt + li;                                  // this lane's constraints: column li + 16 r of M'
+    const int mrow = oMt + li * MS;                             // this lane's constraints: MS consecutive entries of a row of M'
 
     // ---- the state of this row's problem (what is one number per problem is a row-uniform vector register; predicates
     // are 0 / 1 integers -- as lane masks they would each hold a pair of scalar registers across the phases)
@@ -432,6 +442,12 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
         // (what the loop does not change, made opaque once per trip: otherwise every comparison against it is formed in
         // front of the loop and kept -- as lane masks in scalar registers -- across all of it)
         asm volatile("" : "+s"(n), "+s"(cap), "+s"(iter_limit));
+        // (likewise this lane's index: every lane-constant comparison -- "is this the lane of position t" for 31 values
+        // of t -- would otherwise be formed once, kept as a 64-bit lane mask and, there being 100 scalar registers,
+        // spilled and reloaded by two v_readlane where one v_cmp forms it again)
+        asm volatile("" : "+v"(li));
+#pragma unroll
+        for (int s = 0; s < S; s++) pos[s] = li + 16 * s;
         // =============================================================== a row without a problem takes the next one
         {
             const bool want = !live && !dead;
@@ -471,26 +487,37 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
                         }
                     }
                     cur = got ? cur + 1 : cur;
-                    // b_j = Dth_j . theta (mpc_update_qp.c:5-6), four columns of Dth per round trip
+                    // b_j = Dth_j . theta (mpc_update_qp.c:5-6): the record first, in one batch (a miss all the way to HBM), then
+                    // four columns of Dth per round trip (L2)
                     const R *th = a->theta + (long long)npid * nth;
                     R b[MS];
 #pragma unroll
                     for (int r = 0; r < MS; r++) b[r] = (R)0;
-                    for (int t0 = 0; t0 < nth; t0 += 4) {
-                        R tv[4], dv[4][MS];
+                    constexpr int NTHB = 16;
+                    R tb[NTHB];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int t = t0 + q < nth ? t0 + q : nth - 1;
-                            tv[q] = th[t];
+                    for (int t = 0; t < NTHB; t++) tb[t] = th[t < nth ? t : nth - 1];
+                    rw_static_for<0, NTHB / 4>([&](auto B) {
+                        constexpr int t0 = decltype(B)::value * 4;
+                        if (t0 < nth) {
+                            RW_BLOCK();
+                            R dv[4][MS];
 #pragma unroll
-                            for (int r = 0; r < MS; r++) dv[q][r] = ldc(prm.P.oDth + t, jc[r] * nth);
+                            for (int q = 0; q < 4; q++)
+#pragma unroll
+                                for (int r = 0; r < MS; r++) dv[q][r] = ldc(prm.P.oDth + (t0 + q < nth ? t0 + q : nth - 1), jc[r] * nth);
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                if (t0 + q < nth) {
+#pragma unroll
+                                    for (int r = 0; r < MS; r++) b[r] = wv_fma(dv[q][r], tb[t0 + q], b[r]);
+                                }
                         }
+                    });
+                    for (int t = NTHB; t < nth; t++) {              // (records longer than the batch: one column per round trip)
+                        const R tv = th[t];
 #pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (t0 + q < nth) {
-#pragma unroll
-                                for (int r = 0; r < MS; r++) b[r] = wv_fma(dv[q][r], tv[q], b[r]);
-                            }
+                        for (int r = 0; r < MS; r++) b[r] = wv_fma(ldc(prm.P.oDth + t, jc[r] * nth), tv, b[r]);
                     }
 #pragma unroll
                     for (int r = 0; r < MS; r++) {
@@ -628,7 +655,7 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
                     constexpr int i0 = decltype(B)::value * CHP;
                     rw_static_for<0, CHP>([&](auto Q) {
                         constexpr int i = i0 + decltype(Q)::value < CAPP ? i0 + decltype(Q)::value : CAPP - 1;
-                        const int w = rw_bc<i>(ws[i >> 4]) & 0xffff;
+                        const int w = (int)((unsigned)rw_bc<i>(ws[i >> 4]) >> kRowPosOffShift);
 #pragma unroll
                         for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[mcol[s] + w];
                     });
@@ -681,15 +708,19 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
             R fv = (R)0, Mu[MS];
 #pragma unroll
             for (int r = 0; r < MS; r++) Mu[r] = (R)0;
-            constexpr int CHK = MS <= 4 ? 4 : 2, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
+            constexpr int CHK = MS <= 4 ? 4 : (MS <= 6 ? 2 : 1), NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
+                typedef R rw_pair __attribute__((ext_vector_type(2)));
                 auto fetch = [&](auto B) {
                     constexpr int k0 = decltype(B)::value * CHK;
 #pragma unroll
                     for (int q = 0; q < CHK; q++)                              // (rows beyond n, columns beyond m: zeros)
 #pragma unroll
-                        for (int r = 0; r < MS; r++) mn[q][r] = lds[mrow + (k0 + q) * MPAD + 16 * r];
+                        for (int r = 0; r < MS; r += 2) {
+                            const rw_pair pr = *reinterpret_cast<const rw_pair *>(&lds[mrow + (k0 + q) * MPAD + r]);
+                            mn[q][r] = pr.x; mn[q][r + 1] = pr.y;
+                        }
                 };
                 fetch(std::integral_constant<int, 0>{});
                 rw_static_for<0, NBK>([&](auto B) {
@@ -728,29 +759,41 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
                 const bool dom = addp && fvalN > fbound;
                 flag = dom ? EXIT_INFEASIBLE : flag; fin = dom ? 1 : fin; addp = dom ? 0 : addp;
             }
-            // most violated row: smallest value, ties to the lowest (row, side) index
-            R mval = -primal_tol;
-            int midx = -1, broken = 0;
+            // most violated row: smallest value below -primal_tol, ties to the lowest (row, side) index.  Per row the side is
+            // the upper one if that is violated, else the lower one (both at once would need dupper < dlower).
+            R cval[MS], cm = kInf;
+            const R ntol = -primal_tol;
 #pragma unroll
             for (int r = 0; r < MS; r++) {
-                const int j = li + 16 * r;
                 const R vu = dub[r] - Mu[r];
                 const R vl = Mu[r] - dlb[r];                     // = -(dlower_j - M_j u), exactly
-                const bool ok = (okb >> r) & 1u, inw = (actb >> r) & 1u;
-                const bool bu = ok && !inw && vu < mval;
-                mval = bu ? vu : mval; midx = bu ? 2 * j : midx;
-                const bool bl = ok && !inw && !bu && vl < mval;
-                mval = bl ? vl : mval; midx = bl ? 2 * j + 1 : midx;
-                const bool br = inw && ((hardb >> r) & 1u) && (vu < -primal_tol || vl < -primal_tol);
-                broken = br ? 1 : broken;                        // the iterate violates a hard row of its own working set
+                const bool fre = ((okb & ~actb) >> r) & 1u;
+                const R c = vu < ntol ? vu : vl;
+                cval[r] = fre ? c : kInf;
+                cm = wv_min2(cm, cval[r]);
             }
-            const int anyv = rw_or(midx >= 0 ? 1 : 0), anybr = rw_or(broken);
-            const R gsel = rw_min(midx >= 0 ? mval : kInf);
-            int mt = rw_min((midx >= 0 && mval == gsel) ? midx : kRowBig);
-            const int mt2 = rw_min(midx >= 0 ? midx : kRowBig);
-            mt = mt == kRowBig ? mt2 : mt;
+            const R gsel = rw_min(cm);
+            const bool viol = gsel < ntol;
+            int mt = kRowBig;
+#pragma unroll
+            for (int r = MS - 1; r >= 0; r--) {
+                const int side = (dub[r] - Mu[r]) < ntol ? 0 : 1;
+                mt = cval[r] == gsel ? 2 * (li + 16 * r) + side : mt;
+            }
+            mt = rw_min(mt);
             {
-                const bool opt = addp && !anyv;
+                const bool opt = addp && !viol;
+                int anybr = 0;
+                if (rw_any(opt)) {                               // does the iterate violate a hard row of its own working set?
+                    int broken = 0;
+#pragma unroll
+                    for (int r = 0; r < MS; r++) {
+                        const bool hw = ((hardb & actb) >> r) & 1u;
+                        const bool br = hw && ((dub[r] - Mu[r]) < ntol || (Mu[r] - dlb[r]) < ntol);
+                        broken = br ? 1 : broken;
+                    }
+                    anybr = rw_or(broken);
+                }
                 const int fl = anybr ? EXIT_CYCLE : (soft > primal_tol ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL);
                 flag = opt ? fl : flag; fin = opt ? 1 : fin; addp = opt ? 0 : addp;
                 const bool full = addp && na >= cap;
@@ -805,7 +848,7 @@ __global__ __launch_bounds__(512) void row_kernel(const RowParams<R> prm) {
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
                 const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
-                                (lower ? kRowPosFlagLow : 0);
+                                (lower ? kRowPosFlagLow : 0) | (((jadd & 15) * MS + (jadd >> 4)) << kRowPosOffShift);
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     if (ap && pos[s] < na) lds[bo[s] + na] = l[s];           // new row: L(na, t) written by lane t

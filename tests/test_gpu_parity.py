@@ -2669,3 +2669,72 @@ def test_tiers_pass_in_front_of_the_wavefront_kernel(lmpc):
         qp.close()
     assert seen_soft_optimal
 
+
+
+# ------------------------------------------------------------------ four problems per wavefront (lmpc_row_kernel.hpp)
+def _row_vs_wave_vs_oracle(lmpc, qp, theta, settings=None):
+    """The row kernel (forced), the wavefront kernel (row kernel off) and the oracle on the same points: identical
+    x, exit flags, iteration counts and active sets."""
+    qp.set_option("row_kernel", 0)
+    ref = qp.solve(theta)
+    qp.set_option("row_kernel", 1)
+    got = _compare(qp, theta, settings=settings)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b, equal_nan=True)
+    return got
+
+
+@pytest.mark.parametrize("name", ["mass_spring_3in", "mass_spring", "soft_doc", "pendulum_N50"])
+def test_row_kernel_matches_the_wavefront_kernel_and_the_oracle(lmpc, name):
+    # BASELINE config 3 (n = 30, m = 84: two slots of positions), the reference's mass_spring example (one slot, behind
+    # the tiers pass: work-list mode), a problem with SOFT rows, the benchmark class at N = 50 (ten constraint slots; first
+    # of two passes at 32 rows, the wavefront kernel takes what outgrows it)
+    import bench
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g, nout=int(g["nu"]) if "nu" in g else None)
+    theta = bench.make_theta(name, 3001, 5)            # (ragged: 3001 = 46 wavefronts of 64 + 57)
+    x, ef, it, act = _row_vs_wave_vs_oracle(lmpc, qp, theta)
+    assert (ef != -7).all()
+    # trajectories: every output slot
+    qp2 = _qp_from_golden(lmpc, g)
+    _row_vs_wave_vs_oracle(lmpc, qp2, theta[:777])
+
+
+@pytest.mark.parametrize("n,mg,nth,nsoft,seed", [(6, 20, 3, 0, 31), (14, 40, 5, 6, 32), (16, 48, 16, 0, 33), (20, 30, 6, 0, 34),
+                                                 (30, 60, 8, 10, 35), (31, 65, 12, 0, 36), (32, 64, 7, 4, 37),
+                                                 (40, 100, 5, 0, 38), (60, 100, 17, 12, 39)])
+def test_row_kernel_random_problems(lmpc, n, mg, nth, nsoft, seed):
+    # every instantiation, full and partial slots, SOFT rows, records longer than the 16 parameters fetched in one batch;
+    # capacities beyond 32 rows run the row kernel as the first of two passes (what outgrows 32 rows goes to the
+    # wavefront kernel)
+    rng = np.random.default_rng(seed)
+    H, f, f_theta, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, f_theta, A, bu, bl, W, sense, nout=min(n, 4))
+    theta = rng.uniform(-2, 2, (1500, nth)) * (0.4 if nth >= 12 else 1.0)
+    x, ef, it, act = _row_vs_wave_vs_oracle(lmpc, qp, theta)
+    assert (ef >= 1).any() and (ef != -7).all()
+
+
+def test_row_kernel_guards_and_small_batches(lmpc):
+    # iteration limit, infeasible and singular paths, one to five problems (rows of a wavefront without a problem)
+    g = load_golden("mass_spring_3in")
+    qp = _qp_from_golden(lmpc, g, nout=3)
+    import bench
+    theta = bench.make_theta("mass_spring_3in", 700, 9)
+    for N in (1, 2, 3, 5, 63, 65, 700):
+        _row_vs_wave_vs_oracle(lmpc, qp, theta[:N])
+    s = lmpc.default_settings()
+    s.iter_limit = 12
+    qp.set_settings(s)
+    x, ef, it, act = _row_vs_wave_vs_oracle(lmpc, qp, theta, settings=_copy_settings(lmpc, s))
+    assert (ef == -4).any() and (it[ef == -4] == 12).all()
+    # the default: large cold batches take the row kernel, small ones the wavefront kernel; same answers either way
+    qp.set_settings(lmpc.default_settings())
+    qp.set_option("row_kernel", -1)
+    assert qp.kernel_name == "row|wave"
+    big = np.tile(theta, (13, 1))
+    xa = qp.solve(big)
+    qp.set_option("row_kernel", 0)
+    xb = qp.solve(big)
+    for a, b in zip(xa, xb):
+        assert np.array_equal(a, b, equal_nan=True)
