@@ -371,7 +371,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #pragma unroll
                 for (int s = 0; s < S; s++) Ln[q][s] = lds[fo[s] + rowp_cbm(CAPP, t0 + q < CAPP - 1 ? t0 + q : CAPP - 2)];
         };
-        if (1 < nmax) fetch(std::integral_constant<int, 0>{});
+        fetch(std::integral_constant<int, 0>{});
         rw_static_for<0, NB>([&](auto B) {
             constexpr int b = decltype(B)::value, t0 = b * CHS;
             if (t0 + 1 < nmax) {
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 });
 #pragma unroll
                 for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));   // (a DPP read of v may follow)
+                RW_BLOCK();
             }
         });
     };
@@ -406,15 +407,21 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #pragma unroll
                 for (int s = 0; s < S; s++) Ln[q][s] = lds[bo[s] + (thi - q > 1 ? thi - q : 1)];
         };
-        // (the first block that runs fetches for itself: which one that is depends on `top`)
-        bool primed = false;
+        // (the first block that runs -- which one depends on `top` -- is fetched here, with a run-time row index)
+        {
+            const int b0 = top >= 1 ? (CAPP - 1 - top) / CHS : 0;
+            const int thi0 = CAPP - 1 - b0 * CHS;
+#pragma unroll
+            for (int q = 0; q < CHS; q++)
+#pragma unroll
+                for (int s = 0; s < S; s++) Ln[q][s] = lds[bo[s] + (thi0 - q > 1 ? thi0 - q : 1)];
+        }
         rw_static_for<0, NB>([&](auto B) {
             constexpr int b = decltype(B)::value;
             constexpr int thi = CAPP - 1 - b * CHS;                  // this block: t = thi .. thi-CHS+1
             constexpr int tlo = thi - CHS + 1 > 1 ? thi - CHS + 1 : 1;
             if (top >= tlo) {
                 RW_BLOCK();
-                if (!primed) { fetch(B); primed = true; }
                 R Lc[CHS][S];
 #pragma unroll
                 for (int q = 0; q < CHS; q++)
@@ -432,6 +439,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 });
 #pragma unroll
                 for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));
+                RW_BLOCK();
             }
         });
     };
@@ -642,6 +650,10 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
         const int doAdd = (run && !sgl && rm < 0) ? 1 : 0;
 
         // =============================================================== no blocking multiplier: primal iterate, scan, append
+        int addpX = 0, jaddX = 0, lowerX = 0;                    // (the append's two halves: see below)
+        R qX[S], gjjX = (R)0, rjX = (R)0, fvalX = (R)0;
+#pragma unroll
+        for (int s = 0; s < S; s++) qX[s] = (R)0;
         if (rw_any(doAdd != 0)) {
             const int namaxA = rw_max4(doAdd ? na : 0);
             R un[NS];
@@ -660,7 +672,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                         for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[mcol[s] + w];
                     });
                 };
-                if (0 < namaxA) fetch(std::integral_constant<int, 0>{});
+                fetch(std::integral_constant<int, 0>{});
                 rw_static_for<0, NBP>([&](auto B) {
                     constexpr int b = decltype(B)::value, i0 = b * CHP;
                     if (i0 < namaxA) {
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                                 for (int s = 0; s < NS; s++) un[s] = wv_fma(-mv[decltype(Q)::value][s], l, un[s]);
                             }
                         });
+                        RW_BLOCK();
                     }
                 });
             }
@@ -732,9 +745,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                         for (int q = 0; q < CHK; q++)
 #pragma unroll
                             for (int r = 0; r < MS; r++) mt[q][r] = mn[q][r];
-                        if constexpr (b + 1 < NBK) {
-                            if (k0 + CHK < n) fetch(std::integral_constant<int, b + 1>{});
-                        }
+                        // (unconditionally: a test here makes the compiler wait for ALL loads in flight at the join, the ones just
+                        // issued included; rows beyond M' are the factors, finite, and meet u_k = 0)
+                        if constexpr (b + 1 < NBK) fetch(std::integral_constant<int, b + 1>{});
                         rw_static_for<0, CHK>([&](auto Q) {
                             constexpr int k = k0 + decltype(Q)::value;
                             const R v = rw_bc<k>(un[k >> 4]);
@@ -742,6 +755,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #pragma unroll
                             for (int r = 0; r < MS; r++) Mu[r] = wv_fma(mt[decltype(Q)::value][r], v, Mu[r]);
                         });
+                        RW_BLOCK();                                  // (keeps the next block's loads HERE: the compiler sinks them into that block otherwise)
                     }
                 });
             }
@@ -800,86 +814,28 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 flag = full ? EXIT_WSCAP : flag; fin = full ? 1 : fin; addp = full ? 0 : addp;
             }
             RWT(5);
-            // ---- append row jadd to the working sets of the rows with addp
+            // ---- append row jadd to the working sets of the rows with addp, first half: the Gram entries G(W_i, jadd) are
+            // requested here (L2: ~a microsecond), the factor is extended behind the removal phase of the other rows
+            addpX = addp; fvalX = fvalN;
             if (rw_any(addp != 0)) {
                 const bool ap = addp != 0;
-                const int jadd = ap ? (mt >> 1) : 0;
-                const bool lower = ap && (mt & 1);
-                const int sj = sens[jadd];
-                const bool is_soft = (sj & SENSE_SOFT) != 0;
-                R q[S];
+                jaddX = ap ? (mt >> 1) : 0;
+                lowerX = (ap && (mt & 1)) ? 1 : 0;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     const bool in = ap && pos[s] < na;
-                    const int a = in ? (ws[s] & 0xffff) : jadd;
-                    const int hi = a >= jadd ? a : jadd, lo = a >= jadd ? jadd : a;
-                    const R gv = ldc(oG, hi * (hi + 1) / 2 + lo);
-                    q[s] = in ? gv : (R)0;
+                    const int a = in ? (ws[s] & 0xffff) : jaddX;
+                    const int hi = a >= jaddX ? a : jaddX, lo = a >= jaddX ? jaddX : a;
+                    qX[s] = ldc(oG, hi * (hi + 1) / 2 + lo);
                 }
-                const R gjj = ldc(oG, jadd * (jadd + 1) / 2 + jadd);
-#pragma unroll
-                for (int s = 0; s < S; s++) lam[s] = ap ? ls[s] : lam[s];
-                const int namaxQ = rw_max4(ap ? na : 0);
+                gjjX = ldc(oG, jaddX * (jaddX + 1) / 2 + jaddX);
                 // the bound of row jadd that enters: from the lane and slot that own the row
-                R bsel = lower ? dlb[0] : dub[0];
+                R bsel = lowerX ? dlb[0] : dub[0];
 #pragma unroll
-                for (int r = 1; r < MS; r++) bsel = (jadd >> 4) == r ? (lower ? dlb[r] : dub[r]) : bsel;
-                const R rj = -rw_pick(bsel, jadd & 15, rowbase);
-                sweep_fwd(q, namaxQ);
-                R l[S];
-#pragma unroll
-                for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
-                R dnew = is_soft ? gjj + rho_soft : gjj;
-                R ynew = rj;
-                rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
-                    constexpr int i0 = decltype(B)::value * 4;
-                    if (i0 < namaxQ) {
-                        RW_BLOCK();
-                        rw_static_for<0, 4>([&](auto Q) {
-                            constexpr int i = i0 + decltype(Q)::value;
-                            if constexpr (i < CAPP) {                         // (beyond a working set: l_i = 0)
-                                const R lq = rw_bc<i>(l[i >> 4]);
-                                dnew = wv_fma(-lq, rw_bc<i>(q[i >> 4]), dnew);
-                                ynew = wv_fma(-lq, rw_bc<i>(y[i >> 4]), ynew);
-                            }
-                        });
-                    }
-                });
-                const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
-                const R dinv = (R)1 / dnew;
-                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
-                                (lower ? kRowPosFlagLow : 0) | (((jadd & 15) * MS + (jadd >> 4)) << kRowPosOffShift);
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    if (ap && pos[s] < na) lds[bo[s] + na] = l[s];           // new row: L(na, t) written by lane t
-                    const bool here = ap && pos[s] == na;
-                    ws[s] = here ? wsn : ws[s];
-                    rhs[s] = here ? rj : rhs[s]; lam[s] = here ? (R)0 : lam[s]; ls[s] = here ? (R)0 : ls[s];
-                    y[s] = here ? ynew : y[s];
-                    D[s] = here ? (singular ? (R)0 : dnew) : D[s];
-                    Dinv[s] = here ? (singular ? (R)0 : dinv) : Dinv[s];
-                }
-                {
-                    const bool mine = ap && li == (jadd & 15);
-                    const unsigned bit = 1u << (jadd >> 4);
-                    actb = mine ? (actb | bit) : actb;
-                    lowb = (mine && lower) ? (lowb | bit) : lowb;
-                }
-                sing = (ap && singular) ? na : sing;
-                nsoft = (ap && is_soft) ? nsoft + 1 : nsoft;
-                na = ap ? na + 1 : na;
-                napk = na > napk ? na : napk;
-                {
-                    const bool slow = ap && (fvalN - best < progress_tol);
-                    const int cy = slow ? cyc + 1 : 0;
-                    const bool cyx = slow && cy > cycle_tol;
-                    cyc = ap ? cy : cyc;
-                    best = (ap && !slow) ? fvalN : best;
-                    flag = cyx ? EXIT_CYCLE : flag; fin = cyx ? 1 : fin;
-                }
+                for (int r = 1; r < MS; r++) bsel = (jaddX >> 4) == r ? (lowerX ? dlb[r] : dub[r]) : bsel;
+                rjX = -rw_pick(bsel, jaddX & 15, rowbase);
             }
         }
-
         RWT(6);
         // =============================================================== a blocking multiplier: step, drop its row
         if (rw_any(doRem != 0)) {
@@ -1018,6 +974,74 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
             }
             nsoft = dr ? nsoft - softrem : nsoft;
         }
+        // =============================================================== ... second half of the append: extend the factor
+        if (rw_any(addpX != 0)) {
+                const bool ap = addpX != 0;
+                const int jadd = jaddX;
+                const bool lower = lowerX != 0;
+                const R fvalN = fvalX, gjj = gjjX, rj = rjX;
+                const int sj = sens[jadd];
+                const bool is_soft = (sj & SENSE_SOFT) != 0;
+                R q[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) q[s] = (ap && pos[s] < na) ? qX[s] : (R)0;
+#pragma unroll
+                for (int s = 0; s < S; s++) lam[s] = ap ? ls[s] : lam[s];
+                const int namaxQ = rw_max4(ap ? na : 0);
+                sweep_fwd(q, namaxQ);
+                R l[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
+                R dnew = is_soft ? gjj + rho_soft : gjj;
+                R ynew = rj;
+                rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
+                    constexpr int i0 = decltype(B)::value * 4;
+                    if (i0 < namaxQ) {
+                        RW_BLOCK();
+                        rw_static_for<0, 4>([&](auto Q) {
+                            constexpr int i = i0 + decltype(Q)::value;
+                            if constexpr (i < CAPP) {                         // (beyond a working set: l_i = 0)
+                                const R lq = rw_bc<i>(l[i >> 4]);
+                                dnew = wv_fma(-lq, rw_bc<i>(q[i >> 4]), dnew);
+                                ynew = wv_fma(-lq, rw_bc<i>(y[i >> 4]), ynew);
+                            }
+                        });
+                    }
+                });
+                const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
+                const R dinv = (R)1 / dnew;
+                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
+                                (lower ? kRowPosFlagLow : 0) | (((jadd & 15) * MS + (jadd >> 4)) << kRowPosOffShift);
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    if (ap && pos[s] < na) lds[bo[s] + na] = l[s];           // new row: L(na, t) written by lane t
+                    const bool here = ap && pos[s] == na;
+                    ws[s] = here ? wsn : ws[s];
+                    rhs[s] = here ? rj : rhs[s]; lam[s] = here ? (R)0 : lam[s]; ls[s] = here ? (R)0 : ls[s];
+                    y[s] = here ? ynew : y[s];
+                    D[s] = here ? (singular ? (R)0 : dnew) : D[s];
+                    Dinv[s] = here ? (singular ? (R)0 : dinv) : Dinv[s];
+                }
+                {
+                    const bool mine = ap && li == (jadd & 15);
+                    const unsigned bit = 1u << (jadd >> 4);
+                    actb = mine ? (actb | bit) : actb;
+                    lowb = (mine && lower) ? (lowb | bit) : lowb;
+                }
+                sing = (ap && singular) ? na : sing;
+                nsoft = (ap && is_soft) ? nsoft + 1 : nsoft;
+                na = ap ? na + 1 : na;
+                napk = na > napk ? na : napk;
+                {
+                    const bool slow = ap && (fvalN - best < progress_tol);
+                    const int cy = slow ? cyc + 1 : 0;
+                    const bool cyx = slow && cy > cycle_tol;
+                    cyc = ap ? cy : cyc;
+                    best = (ap && !slow) ? fvalN : best;
+                    flag = cyx ? EXIT_CYCLE : flag; fin = cyx ? 1 : fin;
+                }
+        }
+
         RWT(8);
         iter = (run && !fin) ? iter + 1 : iter;
 
@@ -1034,16 +1058,16 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                     const int ko = li + 16 * s;
                     const int lo = ko < nout ? ko : nout - 1;
                     R xs = (R)0;
+                    R rv[16 * NS];                                   // (this output's row of R^-1 in one batch: L2 round trips)
+#pragma unroll
+                    for (int c = 0; c < 16 * NS; c++) rv[c] = ldc(prm.P.oRout, lo * n + (c < n ? c : n - 1));   // (beyond n: u_c = 0)
                     rw_static_for<0, 16 * NS / 4>([&](auto B) {
                         constexpr int c0 = decltype(B)::value * 4;
                         if (c0 < n) {
                             RW_BLOCK();
-                            R rv[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) rv[q] = ldc(prm.P.oRout, lo * n + (c0 + q < n ? c0 + q : n - 1));   // (beyond n: u_c = 0)
                             rw_static_for<0, 4>([&](auto Q) {
                                 constexpr int c = c0 + decltype(Q)::value;
-                                xs = wv_fma(rv[decltype(Q)::value], rw_bc<c>(u[c >> 4]), xs);
+                                xs = wv_fma(rv[c], rw_bc<c>(u[c >> 4]), xs);
                             });
                         }
                     });
