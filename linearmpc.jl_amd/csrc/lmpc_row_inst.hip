@@ -38,7 +38,7 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
             if (64 * nwv > row_launch_bound(sh.MS)) continue;
             const int ps = row_ps(sh.CAPP, nwv);
-            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * (size_t)m + 16;
+            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
             if (blocks * nwv > row_launch_bound(sh.MS) / 64) blocks = row_launch_bound(sh.MS) / 64 / nwv;

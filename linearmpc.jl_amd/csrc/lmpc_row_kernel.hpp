@@ -107,11 +107,11 @@ __device__ __forceinline__ double rw_pick(double v, int src, int rowbase) {
     const int a = (rowbase + (src & 15)) << 2;
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(a, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(a, __double2loint(v)));
 }
-// lane i <- lane i + 1 inside a row (lane 15: unspecified; the callers overwrite it)
-__device__ __forceinline__ int rw_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xF, 0xF, false); }
-__device__ __forceinline__ float rw_shl1(float v) { return __int_as_float(rw_shl1(__float_as_int(v))); }
-__device__ __forceinline__ double rw_shl1(double v) {
-    return __hiloint2double(rw_shl1(__double2hiint(v)), rw_shl1(__double2loint(v)));
+// lane i <- lane i + 1 inside a row; lane 15 (whose source lies outside the row) keeps `edge`
+__device__ __forceinline__ int rw_shl1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x101, 0xF, 0xF, false); }
+__device__ __forceinline__ float rw_shl1(float v, float edge) { return __int_as_float(rw_shl1(__float_as_int(v), __float_as_int(edge))); }
+__device__ __forceinline__ double rw_shl1(double v, double edge) {
+    return __hiloint2double(rw_shl1(__double2hiint(v), __double2hiint(edge)), rw_shl1(__double2loint(v), __double2loint(edge)));
 }
 // maximum over the four rows of a row-uniform int, wave-uniform (scalar)
 __device__ __forceinline__ int rw_max4(int v) {
@@ -138,10 +138,20 @@ constexpr int kRowBig = 0x7fffffff;
 // the at most three lanes left in the bank of the diagonal read the padding.  538 reals for 31 rows (the square,
 // zero padded layout of the wavefront kernel: 930) -- which is what lets a CU hold the factors of 32 problems instead
 // of 16, i.e. two wavefronts per SIMD.
+//
+// The ORDER of the columns in memory is free, and for 31 rows it is chosen (by a backtracking search, tools/row_layout.py)
+// so that the 16 columns of a slot of positions start at 16 different offsets modulo 16: a lane that reads its own
+// COLUMN (backward sweep, row append, compaction) then never shares an LDS bank with another lane of its 32-lane phase.
+// In column order the starts collide four ways (8 LDS cycles an access instead of 2: rocprofv3 counted more bank-conflict
+// cycles than LDS instructions).  For 32 and 16 rows every column length is a multiple of four and no order helps.
 __host__ __device__ constexpr int rowp_p0(int t) { return t & ~3; }
 __host__ __device__ constexpr int rowp_cb(int capp, int t) { return 4 * (t >> 2) * capp - 8 * (t >> 2) * ((t >> 2) - 1) + (t & 3) * (capp - 4 * (t >> 2)); }
-__host__ __device__ constexpr int rowp_cbm(int capp, int t) { return rowp_cb(capp, t) - rowp_p0(t); }
 __host__ __device__ constexpr int rowp_size(int capp) { return rowp_cb(capp, capp - 1); }      // columns 0 .. capp-2
+__host__ __device__ constexpr int rowp_cbm(int capp, int t) {
+    constexpr int k31[30] = {379, 152, 183, 0, 237, 485, 458, 210, 318, 431, 102, 260, 121, 19, 348, 49,
+                             507, 79, 275, 64, 329, 390, 401, 30, 282, 292, 408, 492, 295, 285};
+    return capp == 31 ? k31[t < 30 ? t : 29] : rowp_cb(capp, t) - rowp_p0(t);
+}
 // reals between the factors of two problems, for nwv wavefronts per workgroup: the two DPP rows a 32-lane LDS phase
 // serves (problems nwv slots apart) must sit 16 reals apart modulo 32
 __host__ __device__ constexpr int row_ps(int capp, int nwv) {
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
     const int nP = (n + 3) & ~3;
     const int oZ = 0, oMt = 32, oL = oMt + nP * MPAD;
     int32_t *sens = reinterpret_cast<int32_t *>(lds + oL + nwv * 4 * PS + 2);
+    int32_t *cbt = sens + m;                                   // cbm(t), t = 0 .. CAPP-2, for run-time column indices
     const R *__restrict__ C = prm.C;
     for (int i = threadIdx.x; i < 32; i += blockDim.x) lds[oZ + i] = (R)0;
     for (int i = threadIdx.x; i < nP * MPAD; i += blockDim.x) {
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
     }
     for (int i = threadIdx.x; i < nwv * 4 * PS + 2; i += blockDim.x) lds[oL + i] = (R)0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = prm.Sg[i];
+    rw_static_for<0, CAPP - 1>([&](auto T) { if (threadIdx.x == 0) cbt[decltype(T)::value] = rowp_cbm(CAPP, decltype(T)::value); });
     __syncthreads();
 
     const R primal_tol = (R)prm.P.primal_tol, dual_tol = (R)prm.P.dual_tol, zero_tol = (R)prm.P.zero_tol,
@@ -284,14 +296,14 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #define RW_BLOCK() asm volatile("" ::: "memory")
 
     // element (row p, column t) of this row's factor: lds[Lg + cbm(t) + p]
-    auto cbm = [](int t) -> int { return rowp_cbm(CAPP, t); };
+    auto cbm = [&](int t) -> int { return cbt[t]; };            // (run-time t in [0, CAPP-2])
     const int Lg = oL + (wv + nwv * g) * PS;
     int pos[S], fo[S], bo[S];          // this lane's positions; offsets of its ROW (forward sweeps) and of its COLUMN
 #pragma unroll
     for (int s = 0; s < S; s++) {
         pos[s] = li + 16 * s;
         fo[s] = Lg + pos[s];                                            // (a lane beyond the last row reads the next column's padding)
-        bo[s] = pos[s] < CAPP - 1 ? Lg + cbm(pos[s]) : oZ;              // (beyond the last column: the block of zeros)
+        bo[s] = pos[s] < CAPP - 1 ? Lg + cbm(pos[s] < CAPP - 1 ? pos[s] : 0) : oZ;   // (beyond the last column: the block of zeros)
     }
     int jc[MS], mcol[NS];
     unsigned okb = 0u, hardb = 0u;     // bit r: this lane's row of slot r can enter a working set / ... and is a hard row
@@ -360,7 +372,10 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
     // off by its bank mask or read the column's padding (see rowp_p0).
     // The factor's entries of a block of CHS steps are fetched while the block before it runs (issued at its head, waited
     // for at their first use).
-    constexpr int CHS = 4;
+#ifndef LMPC_ROW_CHS
+#define LMPC_ROW_CHS 4
+#endif
+    constexpr int CHS = LMPC_ROW_CHS;
     auto sweep_fwd = [&](R (&v)[S], int nmax) {
         constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;               // steps t = 0 .. CAPP-2
         R Ln[CHS][S];
@@ -721,7 +736,10 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
             R fv = (R)0, Mu[MS];
 #pragma unroll
             for (int r = 0; r < MS; r++) Mu[r] = (R)0;
-            constexpr int CHK = MS <= 4 ? 4 : (MS <= 6 ? 2 : 1), NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
+#ifndef LMPC_ROW_CHK6
+#define LMPC_ROW_CHK6 2
+#endif
+            constexpr int CHK = MS <= 4 ? 4 : (MS <= 6 ? LMPC_ROW_CHK6 : 1), NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
                 typedef R rw_pair __attribute__((ext_vector_type(2)));
@@ -871,6 +889,10 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                     cp = cp < CAPP - 1 ? cp : 0;
                     so[s] = Lg + cbm(cp);
                 }
+                int clo[S];                                      // rows this lane's column takes part in: [clo, chi)
+                const int chi = dr ? nao - 1 : 0;
+#pragma unroll
+                for (int s = 0; s < S; s++) clo[s] = pos[s] + 1 > r ? pos[s] + 1 : r;
                 // (four rows read before they are written: the reads of a row do not wait for the row above it)
                 for (int i0 = rlo; i0 < nhi - 1; i0 += 4) {
                     R tv[4][S];
@@ -883,7 +905,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                         const int i = i0 + q;
 #pragma unroll
                         for (int s = 0; s < S; s++)
-                            if (dr && i >= r && i < nao - 1 && pos[s] < i) lds[bo[s] + i] = tv[q][s];
+                            if (i >= clo[s] && i < chi) lds[bo[s] + i] = tv[q][s];
                     }
                 }
 #pragma unroll
@@ -892,25 +914,21 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
             }
             // the per-position registers move down by one from position r on
             {
-                auto shift = [&](auto *a, bool clear_outside) {
+                // (positions beyond a working set hold zeros in every one of these arrays, so the position that falls free
+                // takes its zero from its neighbour like any other: one select per value)
+                auto shift = [&](auto *a) {
                     using V = std::remove_pointer_t<decltype(a)>;
                     V nx[S];
 #pragma unroll
                     for (int s = 0; s < S; s++) {
-                        const V sh = rw_shl1(a[s]);
                         V nb = (V)0;
                         if (s + 1 < S) nb = rw_bc<0>(a[s + 1 < S ? s + 1 : s]);
-                        nx[s] = li == 15 ? nb : sh;
+                        nx[s] = rw_shl1(a[s], nb);
                     }
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        const bool mv = dr && pos[s] >= r && pos[s] < nao - 1;
-                        const bool zr = dr && !mv && (pos[s] == nao - 1 || clear_outside);
-                        a[s] = mv ? nx[s] : (zr ? (V)0 : a[s]);
-                    }
+                    for (int s = 0; s < S; s++) a[s] = (dr && pos[s] >= r) ? nx[s] : a[s];
                 };
-                shift(ws, false); shift(lam, false); shift(rhs, false); shift(D, false); shift(Dinv, false);
-                shift(w, true);
+                shift(ws); shift(lam); shift(rhs); shift(D); shift(Dinv); shift(w);
             }
             na = dr ? nao - 1 : na; sing = dr ? -1 : sing; ydirty = dr ? 1 : ydirty;
             RWT(7);
