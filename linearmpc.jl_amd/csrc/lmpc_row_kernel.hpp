@@ -208,6 +208,14 @@ template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(float
                  "v_fmac_f32_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"
                  : "+v"(src), "+v"(oth) : "v"(lsrc), "v"(loth), "n"(NOP), "n"(T), "n"(BM));
 }
+// In front of and behind a sweep: five wait states with the sweep's vector as an operand.  In front: a scalar write of
+// EXEC (the end of a divergent region) must be five states away from the first DPP instruction, a vector write of the
+// vector two; behind: the compiler's own DPP reads of the vector must be two states behind the last step.  Inside a
+// sweep a step's own two states suffice: between two blocks there are only a scalar compare, a uniform branch and loads.
+template <typename V, int S> __device__ __forceinline__ void rw_sweep_fence(V (&v)[S]) {
+    if constexpr (S == 1) asm volatile("s_nop 4" : "+v"(v[0]));
+    else asm volatile("s_nop 4" : "+v"(v[0]), "+v"(v[S - 1]));
+}
 // banks (of four lanes) of slot s that hold rows >= p0(t) / columns <= t
 __host__ __device__ constexpr int rw_bm_rows(int s, int t) {
     int bm = 0;
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 for (int s = 0; s < S; s++) Ln[q][s] = lds[fo[s] + rowp_cbm(CAPP, t0 + q < CAPP - 1 ? t0 + q : CAPP - 2)];
         };
         fetch(std::integral_constant<int, 0>{});
+        rw_sweep_fence(v);
         rw_static_for<0, NB>([&](auto B) {
             constexpr int b = decltype(B)::value, t0 = b * CHS;
             if (t0 + 1 < nmax) {
@@ -399,18 +408,17 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
                 rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int q = decltype(Q)::value, t = t0 + q;
-                    constexpr int NOP = q == 0 ? 4 : 1;
+                    constexpr int NOP = 1;
                     if constexpr (t + 1 < CAPP) {
                         if constexpr (S == 1) rw_step1<t, rw_bm_rows(0, t), NOP>(v[0], Lr[q][0]);
                         else if constexpr (t < 16) rw_step2<t, rw_bm_rows(0, t), NOP>(v[0], v[S - 1], Lr[q][0], Lr[q][S - 1]);
                         else rw_step1<t - 16, rw_bm_rows(1, t), NOP>(v[S - 1], Lr[q][S - 1]);
                     }
                 });
-#pragma unroll
-                for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));   // (a DPP read of v may follow)
                 RW_BLOCK();
             }
         });
+        rw_sweep_fence(v);
     };
     auto sweep_bwd = [&](R (&v)[S], int top) {
         constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;              // steps t = CAPP-1 .. 1 in blocks from the top
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #pragma unroll
                 for (int s = 0; s < S; s++) Ln[q][s] = lds[bo[s] + (thi0 - q > 1 ? thi0 - q : 1)];
         }
+        rw_sweep_fence(v);
         rw_static_for<0, NB>([&](auto B) {
             constexpr int b = decltype(B)::value;
             constexpr int thi = CAPP - 1 - b * CHS;                  // this block: t = thi .. thi-CHS+1
@@ -445,18 +454,17 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
                 if constexpr (b + 1 < NB) fetch(std::integral_constant<int, b + 1>{});
                 rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int q = decltype(Q)::value, t = thi - q;
-                    constexpr int NOP = q == 0 ? 4 : 1;
+                    constexpr int NOP = 1;
                     if constexpr (t >= 1) {
                         if constexpr (S == 1) rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
                         else if constexpr (t >= 16) rw_step2<t - 16, rw_bm_cols(1, t), NOP>(v[S - 1], v[0], Lc[q][S - 1], Lc[q][0]);
                         else rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
                     }
                 });
-#pragma unroll
-                for (int s = 0; s < S; s++) asm volatile("s_nop 1" : "+v"(v[s]));
                 RW_BLOCK();
             }
         });
+        rw_sweep_fence(v);
     };
 
     RWT_DECL;
