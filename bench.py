@@ -915,6 +915,157 @@ PRIME_CALLS = 1      # untimed calls before a side configuration's timed region 
 LINE_LIMIT = 8192    # the bench line must stay far below what the driver keeps of stdout
 
 
+def single_call_config(lmpc, g, nout, cpu=True):
+    """BASELINE config 1 in this framework's terms: ONE parameter point per call -- lmpc_solve_one (theta in, x and flag out
+    through one record of mapped host memory) and the generated controller's mpc_compute_control with one state (host
+    arrays) -- wall time per call with the host in the loop, beside the CPU port's time for one solve of the same problem
+    (the reference's single compute_control on Julia + DAQP cannot run here)."""
+    import ctypes
+    from linearmpc_jl_amd._cabi import lib
+    vp = ctypes.c_void_p
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+    th = np.ascontiguousarray(g["theta"][0]); x = np.zeros(nout)
+    for _ in range(50):
+        lib().lmpc_solve_one(qp._h, vp(th.ctypes.data), vp(x.ctypes.data))
+    n = 500
+    t0 = time.perf_counter()
+    for _ in range(n):
+        lib().lmpc_solve_one(qp._h, vp(th.ctypes.data), vp(x.ctypes.data))
+    solve_one_us = 1e6 * (time.perf_counter() - t0) / n
+    out = {"solve_one_us": solve_one_us, "kernel": qp.kernel_name,
+           "note": "wall time per call, host in the loop, one GPU; the reference's counterpart is one compute_control on its "
+                   "CPU path (BASELINE config 1), quoted from its plots as ~11 us at N = 50 (a larger problem)"}
+    qp.close()
+    try:
+        q = lmpc.MPQP(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"])
+        mpc = lmpc.MPC(q, nx=4, nu=1, nr=2, nuprev=1)
+        gc = lmpc.GeneratedController(mpc)
+        control = np.zeros((1, 1)); state = np.array([[0.5, 0.1, 0.05, 0.0]]); ref = np.array([[1.0, 0.0]])
+        for _ in range(50):
+            gc.mpc_compute_control(control, state, ref)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gc.mpc_compute_control(control, state, ref)
+        out["compute_control_one_state_us"] = 1e6 * (time.perf_counter() - t0) / n
+    except Exception as e:                                    # never fatal for the line
+        out["compute_control_error"] = f"{type(e).__name__}: {e}"[:200]
+    if cpu:
+        from oracle import ldp as oldp
+        global _NATIVE_FLAGS
+        if _NATIVE_FLAGS is None:
+            _NATIVE_FLAGS = oldp.use_native()
+        L = oldp.qp2ldp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=nout)
+        th1 = np.ascontiguousarray(g["theta"][:1])
+        oldp.solve_batch(L, th1)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            oldp.solve_batch(L, th1)
+        out["cpu_port_single_solve_us"] = 1e6 * (time.perf_counter() - t0) / 2000     # (ctypes call overhead included)
+        th1k = np.ascontiguousarray(np.repeat(th1, 4096, 0))
+        t0 = time.perf_counter()
+        oldp.solve_batch(L, th1k)
+        out["cpu_port_solve_in_a_loop_us"] = 1e6 * (time.perf_counter() - t0) / 4096  # (the same point, C loop)
+    return out
+
+
+def traffic_stamp(workload):
+    """roofline.traffic for the headline: the PMC measurement committed under profiles/ -- with the kernel and the commit it
+    was taken on, and null when the kernel's source has changed since (the file would be stale)."""
+    pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    if not os.path.exists(pmc):
+        return None, {"note": "no PMC measurement committed for this workload"}
+    try:
+        d = json.load(open(pmc))
+    except (OSError, ValueError):
+        return None, {"note": "profiles/pmc_traffic file unreadable"}
+    info = {"source": d.get("source"), "kernels": d.get("kernels"), "measured_on_commit": d.get("measured_on_commit"),
+            "kernel_source_sha16": d.get("kernel_source_sha16")}
+    src = os.path.join(ROOT, "linearmpc.jl_amd", "csrc", d.get("kernel_source", "lmpc_fast_kernel.hpp"))
+    try:
+        import hashlib
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    except OSError:
+        sha = None
+    info["kernel_source_sha16_now"] = sha
+    if d.get("kernel_source_sha16") and sha and sha != d["kernel_source_sha16"]:
+        info["note"] = "STALE: the kernel's source has changed since the counters were collected; traffic withheld"
+        return None, info
+    return d.get("hbm_bytes_per_launch"), info
+
+
+def multi_rank_configs(torch, lmpc, dist, dev, local_rank, rank, world, batch):
+    """world > 1 (one process per GPU): BASELINE configs 3 and 4 as they shard -- every rank its own batch / its own
+    sample shard.  Config 3: independent shards, no exchange inside the solve; config 4: per-rank distinct-set tables
+    merged by ONE all_gather_into_tensor on the device tables (explicit.merge_region_tables).  Times are the maximum over
+    ranks between two barriers; values are whole-job aggregates.  Every rank calls this; rank 0 gets the report."""
+    from linearmpc_jl_amd import explicit
+    rep = {}
+
+    def allmax(v):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allvals(v):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        return [float(o.item()) for o in outl]
+
+    # ---- config 3: oscillating masses, 3 inputs; one 10^6-point batch per rank
+    try:
+        steps = 3
+        w = Workload(torch, lmpc, "mass_spring_3in", batch, dev, local_rank, rank, 1)
+        w.launch(0); torch.cuda.synchronize(dev)
+        dist.barrier()
+        el = w.timed(steps, 1)
+        el_max = allmax(el)
+        ver = w.verify_steps([steps - 1], per_step=1024)
+        ok = allvals(1.0 if ver["verified"] else 0.0)
+        per_rank = allvals(batch * steps / el)
+        rep["mass_spring_3in"] = {"value": world * batch * steps / el_max, "unit": "solves/s", "ms_per_step": 1e3 * el_max / steps,
+                                  "per_rank_value": per_rank, "batch_per_gpu": batch, "kernel": w.kernel, "verified": all(v > 0 for v in ok),
+                                  "scaling": "weak", "exchange": "none: independent shards, results stay on their GPU"}
+        w.close()
+    except Exception as e:
+        rep["mass_spring_3in"] = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
+    # ---- config 4: region discovery, the sample sharded over the ranks, tables exchanged as tensors
+    try:
+        g = make_problem("pendulum")
+        qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], device=local_rank)
+        lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
+        first = explicit.discover_regions_device(qp, lb, ub, batch, seed=4 + rank)
+        theta = first["theta"]
+        sampler = explicit.DeviceRegionSampler(qp, batch, capacity=1024)
+        sampler.run(theta)
+        reps = 10
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); t_ex = 0.0
+        for _ in range(reps):
+            m_, c_, f_, s_ = sampler.run(theta)
+            t1 = time.perf_counter()
+            gm, gc, gf, gs = explicit.merge_region_tables(sampler.masks[:len(c_)], sampler.counts[:len(c_)], sampler.first[:len(c_)],
+                                                          s_, dist.group.WORLD, capacity=1024, index_offset=rank * batch)
+            t_ex += time.perf_counter() - t1
+        dt = allmax((time.perf_counter() - t0) / reps)
+        ex_ms = allmax(1e3 * t_ex / reps)
+        # every rank must hold the same merged table, and its counts must add up to the solved samples of all ranks
+        chk = float(np.bitwise_xor.reduce(gm.view(np.uint64).reshape(-1)) % (1 << 52)) if len(gc) else 0.0
+        same = len(set(allvals(chk))) == 1 and len(set(allvals(float(len(gc))))) == 1
+        rep["region_discovery"] = {"value": world * batch / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt, "samples_per_gpu": batch,
+                                   "distinct_active_sets": int(len(gc)), "distinct_on_this_rank": int(len(c_)),
+                                   "n_solved": int(gs), "verified": bool(same and int(gc.sum()) == int(gs)),
+                                   "exchange": {"ms": ex_ms, "bytes_per_rank": 1025 * (qp.words + 2) * 8,
+                                                "how": "one all_gather_into_tensor of the per-rank tables of distinct masks "
+                                                       "(1024 rows of [mask, count, first index] + header) on the device buffers "
+                                                       "the pipeline leaves them in, merged on the device (torch.unique)"}}
+        qp.close()
+    except Exception as e:
+        rep["region_discovery"] = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
+    return rep
+
+
 def _r(v, sig=6):
     """Round floats to `sig` significant digits (line size), leave the rest alone."""
     if isinstance(v, float):
@@ -946,6 +1097,16 @@ def compact_line(out):
                                                        "algorithmic_bytes_per_solve")}
     if isinstance(roof.get("pipelined"), dict):
         line["roofline"]["pipelined_frac"] = _r(roof["pipelined"].get("frac"))
+    ti = roof.get("traffic_info")
+    if isinstance(ti, dict):
+        line["roofline"]["traffic_on"] = {"commit": ti.get("measured_on_commit"), "kernel": (ti.get("kernels") or [None])[0],
+                                          **({"note": ti["note"]} if "note" in ti else {})}
+    sc = out.get("single_call")
+    if isinstance(sc, dict):
+        line["single_call"] = {k: _r(sc[k], 4) for k in ("solve_one_us", "compute_control_one_state_us", "cpu_port_single_solve_us",
+                                                          "cpu_port_solve_in_a_loop_us") if k in sc}
+        if "error" in sc:
+            line["single_call"]["error"] = sc["error"][:120]
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
@@ -978,6 +1139,11 @@ def compact_line(out):
                 e["cpu_1core"] = _r(c["cpu_baseline"].get("value"), 4)
             if "first_run_value" in c:
                 e["first_run_value"] = _r(c.get("first_run_value"), 4)
+            if "per_rank_value" in c:
+                e["per_rank_value"] = [_r(v, 4) for v in c["per_rank_value"]]
+            if "exchange" in c:
+                e["exchange"] = ({"ms": _r(c["exchange"].get("ms"), 4), "bytes_per_rank": c["exchange"].get("bytes_per_rank")}
+                                 if isinstance(c["exchange"], dict) else str(c["exchange"])[:80])
             cs[name] = e
         line["configs"] = cs
     line["full_report"] = "bench_full.json"
@@ -1233,6 +1399,11 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # world > 1: BASELINE configs 3 and 4 sharded over the ranks (every rank takes part; reported by rank 0 below)
+    rank_cfgs = None
+    if world > 1 and args.workload == "pendulum" and not args.no_configs and not args.f32 and not args.wave:
+        _phase("multi-rank configs: mass_spring_3in and region discovery, one shard per rank")
+        rank_cfgs = multi_rank_configs(torch, lmpc, dist, dev, local_rank, rank, world, n_local)
 
     if rank == 0:
         total = world * n_local * args.steps
@@ -1287,12 +1458,7 @@ def main():
             ach = flop_est * n_local / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
             roof.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
                          "frac": ach / VALU_PEAK_TFLOPS[dtype]})
-        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
-        if os.path.exists(pmc):
-            try:
-                roof["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                pass
+        roof["traffic"], roof["traffic_info"] = traffic_stamp(args.workload)
         out = {
             "metric": "condensed-MPC QP solves/sec (batch 1e6 params), pendulum Nc=5"
                       if args.workload == "pendulum" else f"condensed-MPC QP solves/sec ({args.workload})",
@@ -1342,6 +1508,14 @@ def main():
         # the headline line goes out NOW (and again, with the per-config summaries, as the last line): a failure or a
         # timeout in a side configuration cannot lose it
         run_configs = world == 1 and args.workload == "pendulum" and not args.no_configs and not args.f32 and not args.wave
+        if rank_cfgs is not None:
+            out["configs"] = rank_cfgs
+        if args.workload == "pendulum" and not args.f32 and not args.wave and world == 1 and not args.no_configs:
+            _phase("single call: lmpc_solve_one / mpc_compute_control with one state")
+            try:
+                out["single_call"] = single_call_config(lmpc, W.g, nout, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                out["single_call"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         emit(out, final=not run_configs)
         # ---- the other single-GPU BASELINE configurations, same process (driver-timed as part of this run)
         if run_configs:

@@ -79,28 +79,82 @@ def affine_law(H, f, f_theta, A, bu, bl, W, mask, nout=None):
     return sol_th[:nout], sol_0[:nout]
 
 
-def discover_regions(solve_fn, theta, group=None):
+def merge_region_tables(masks, counts, first, n_solved, group, capacity=None, index_offset=0):
+    """Merge of the per-rank tables of distinct active sets across a torch.distributed group, as TENSORS: every rank
+    contributes one fixed-size table -- `capacity` rows of [mask words, count, first index] plus a header row [sets,
+    problems solved] -- in ONE all_gather_into_tensor on the device the tables live on (RCCL for the tables the device
+    pipeline leaves in HBM, gloo for CPU tensors), and the gathered rows are reduced on that device: equal masks are
+    found by torch.unique, their counts added, the smallest (global) first index kept.  What crosses the fabric is
+    (capacity + 1) x (words + 2) x 8 bytes per rank -- 24 kB for the pendulum's 45 sets at capacity 1024 -- against
+    the pickled object lists of round 4.
+
+    masks (R x words, int64 / uint64 tensor or array), counts (R), first (R) or None, n_solved (int); `index_offset` is
+    added to this rank's first indices (its shard's offset in the global sample).  Returns on every rank
+    (masks uint64 array, counts, first_index, n_solved), sets sorted by decreasing count, ties by first index.
+    A rank with more than `capacity` sets makes every rank repeat the exchange with four times the room."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    t_masks = torch.as_tensor(np.ascontiguousarray(np.asarray(masks).view(np.int64))) if not torch.is_tensor(masks) else masks
+    dev = t_masks.device
+    t_masks = t_masks.reshape(-1, t_masks.shape[-1] if t_masks.dim() > 1 else 1).to(torch.int64)
+    R, words = int(t_masks.shape[0]), int(t_masks.shape[1])
+    t_counts = torch.as_tensor(np.asarray(counts, np.int64)).to(dev) if not torch.is_tensor(counts) else counts.to(torch.int64)
+    if first is None:
+        t_first = torch.full((R,), -1, dtype=torch.int64, device=dev)
+    else:
+        t_first = (torch.as_tensor(np.asarray(first, np.int64)).to(dev) if not torch.is_tensor(first) else first.to(torch.int64)) + int(index_offset)
+    # room: agreed on by all ranks (the largest table, rounded up to a power of two, at least 64 rows)
+    need = torch.tensor([R], dtype=torch.int64, device=dev)
+    dist.all_reduce(need, op=dist.ReduceOp.MAX, group=group)
+    cap = int(capacity) if capacity else 64
+    while cap < int(need.item()):
+        cap *= 4
+    table = torch.zeros((cap + 1, words + 2), dtype=torch.int64, device=dev)
+    table[0, 0], table[0, 1] = R, int(n_solved)
+    if R:
+        table[1:R + 1, :words] = t_masks
+        table[1:R + 1, words] = t_counts[:R]
+        table[1:R + 1, words + 1] = t_first[:R]
+    gathered = torch.empty((world * (cap + 1), words + 2), dtype=torch.int64, device=dev)
+    try:
+        dist.all_gather_into_tensor(gathered, table, group=group)
+    except (RuntimeError, NotImplementedError):          # (a backend without the flat form: the list form, same bytes)
+        parts = [torch.empty_like(table) for _ in range(world)]
+        dist.all_gather(parts, table, group=group)
+        gathered = torch.cat(parts, 0)
+    gathered = gathered.reshape(world, cap + 1, words + 2)
+    nsets = gathered[:, 0, 0]
+    solved = int(gathered[:, 0, 1].sum().item())
+    rows = gathered[:, 1:, :]
+    valid = torch.arange(cap, device=dev)[None, :] < nsets[:, None]
+    rows = rows[valid]
+    if rows.shape[0] == 0:
+        return np.zeros((0, words), np.uint64), np.zeros(0, np.int64), np.zeros(0, np.int64), solved
+    um, inv = torch.unique(rows[:, :words], dim=0, return_inverse=True)
+    uc = torch.zeros(um.shape[0], dtype=torch.int64, device=dev).index_add_(0, inv, rows[:, words])
+    big = torch.iinfo(torch.int64).max
+    fi = rows[:, words + 1]
+    uf = torch.full((um.shape[0],), big, dtype=torch.int64, device=dev).scatter_reduce_(0, inv, torch.where(fi < 0, torch.full_like(fi, big), fi), reduce="amin")
+    um_h, uc_h, uf_h = um.cpu().numpy().view(np.uint64), uc.cpu().numpy(), uf.cpu().numpy()
+    uf_h = np.where(uf_h == big, -1, uf_h)
+    order = np.lexsort((uf_h, -uc_h))
+    return um_h[order], uc_h[order], uf_h[order], solved
+
+
+def discover_regions(solve_fn, theta, group=None, index_offset=0):
     """Distinct optimal active sets over a parameter sample, optionally merged across ranks.
 
     solve_fn(theta) -> (x, exitflag, iters, active) is `BatchedQP.solve` of a handle on this rank's
     GPU; with `group` given (torch.distributed) every rank passes ITS shard of the sample, the
-    per-rank unique masks are all-gathered (a few kB) and de-duplicated on every rank -- the sample
-    grid shards across the GPUs of a node exactly like any other batch."""
+    per-rank tables of distinct masks are exchanged as tensors (`merge_region_tables`: one all_gather_into_tensor) and
+    merged on every rank -- the sample grid shards across the GPUs of a node exactly like any other batch.
+    `index_offset`: this rank's offset in the global sample (first indices come back global)."""
     x, ef, it, act = solve_fn(theta)
     masks, counts, first = unique_active_sets(act, ef)
     solved = int(np.sum(np.asarray(ef) >= 1))
     if group is not None:
-        import torch.distributed as dist
-        gathered = [None] * dist.get_world_size(group)
-        dist.all_gather_object(gathered, (masks, counts, solved), group=group)
-        allm = np.concatenate([g[0] for g in gathered if len(g[0])], 0) if any(len(g[0]) for g in gathered) \
-            else masks
-        allc = np.concatenate([g[1] for g in gathered if len(g[0])]) if any(len(g[0]) for g in gathered) else counts
-        um, inv = np.unique(allm, axis=0, return_inverse=True)
-        uc = np.bincount(inv.reshape(-1), weights=allc, minlength=len(um)).astype(int)
-        order = np.argsort(-uc, kind="stable")
-        masks, counts, first = um[order], uc[order], None
-        solved = sum(g[2] for g in gathered)
+        masks, counts, first, solved = merge_region_tables(masks, counts, first, solved, group, index_offset=index_offset)
     return {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved}
 
 
@@ -184,12 +238,13 @@ class DeviceRegionSampler:
         return self.result()
 
 
-def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=65536, theta=None):
+def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=65536, theta=None, index_offset=0):
     """`discover_regions` with everything per-sample on the GPU: the sample of the box [lb, ub] is drawn on the device
     (torch generator, seeded), solved by `lmpc_solve_batch_device` with the active-set masks kept there, and reduced to
     its distinct masks by `lmpc_distinct_active_sets_device`; what crosses PCIe is one row per region that was hit.
     `theta`: a ready-made (N, nth) float64 CUDA tensor instead of the drawn sample.  With a torch.distributed `group`
-    every rank passes its own seed / shard and the per-rank sets (a few kB) are merged on every rank."""
+    every rank passes its own seed / shard; the per-rank tables of distinct sets stay ON THE DEVICE and are exchanged
+    by one all_gather_into_tensor (RCCL over xGMI) and merged there (`merge_region_tables`)."""
     import torch
     dev = torch.device("cuda", qp.device if hasattr(qp, "device") and qp.device is not None else torch.cuda.current_device())
     if theta is None:
@@ -202,18 +257,11 @@ def discover_regions_device(qp, lb, ub, nsamples, seed=0, group=None, capacity=6
     masks, counts, first, solved = sampler.run(theta)
     out = {"masks": masks, "counts": counts, "first_index": first, "n_solved": solved, "theta": theta}
     if group is not None:
-        import torch.distributed as dist
-        gathered = [None] * dist.get_world_size(group)
-        dist.all_gather_object(gathered, (masks, counts, solved), group=group)
-        nonempty = [g for g in gathered if len(g[0])]
-        if nonempty:
-            allm = np.concatenate([g[0] for g in nonempty], 0)
-            allc = np.concatenate([g[1] for g in nonempty])
-            um, inv = np.unique(allm, axis=0, return_inverse=True)
-            uc = np.bincount(inv.reshape(-1), weights=allc, minlength=len(um)).astype(np.int64)
-            order = np.argsort(-uc, kind="stable")
-            out.update({"masks": um[order], "counts": uc[order], "first_index": None})
-        out["n_solved"] = sum(g[2] for g in gathered)
+        # the device tables as the pipeline left them (sampler.masks / counts / first, `nfound` rows)
+        nfound = len(counts)
+        gm, gc, gf, gs = merge_region_tables(sampler.masks[:nfound], sampler.counts[:nfound], sampler.first[:nfound], solved,
+                                             group, index_offset=index_offset)
+        out.update({"masks": gm, "counts": gc, "first_index": gf, "n_solved": gs})
     return out
 
 

@@ -73,9 +73,26 @@ def _region_worker(rank, world, port, out_dir):
     lb = np.array([-20.0] * 4 + [-20.0, 0.0] + [-2.0]); ub = -lb; ub[5] = 0.0
     theta = lmpc.explicit.sample_range(lb, ub, 20000, seed=3)
     lo, hi = lmpc.shard_bounds(len(theta), world, rank)
-    out = lmpc.explicit.discover_regions(lambda th: oldp.solve_batch(L, th), theta[lo:hi], group=dist.group.WORLD)
+    out = lmpc.explicit.discover_regions(lambda th: oldp.solve_batch(L, th), theta[lo:hi], group=dist.group.WORLD, index_offset=lo)
     np.save(os.path.join(out_dir, f"masks{rank}.npy"), out["masks"])
     np.save(os.path.join(out_dir, f"counts{rank}.npy"), out["counts"])
+    np.save(os.path.join(out_dir, f"first{rank}.npy"), out["first_index"])
+    np.save(os.path.join(out_dir, f"solved{rank}.npy"), np.array([out["n_solved"]]))
+    # the exchange itself, on tensors as the device pipeline leaves them (int64 masks, unsorted, a small capacity that
+    # has to grow; an EMPTY table on rank 1)
+    import torch
+    x, ef, it, act = oldp.solve_batch(L, theta[lo:hi])
+    m, c, f = lmpc.explicit.unique_active_sets(act, ef)
+    perm = np.random.default_rng(rank).permutation(len(c))
+    tm = torch.from_numpy(np.ascontiguousarray(m[perm]).view(np.int64))
+    gm, gc, gf, gs = lmpc.explicit.merge_region_tables(tm, torch.from_numpy(c[perm].astype(np.int64)), torch.from_numpy(f[perm].astype(np.int64)),
+                                                       int((ef >= 1).sum()), dist.group.WORLD, capacity=4, index_offset=lo)
+    assert np.array_equal(gm, out["masks"]) and np.array_equal(gc, out["counts"]) and np.array_equal(gf, out["first_index"]) and gs == out["n_solved"]
+    keep = slice(0, 0) if rank == 1 else slice(None)
+    em, ec, ef_, es = lmpc.explicit.merge_region_tables(tm[keep], torch.from_numpy(c[perm].astype(np.int64))[keep],
+                                                        torch.from_numpy(f[perm].astype(np.int64))[keep], 0 if rank == 1 else 7,
+                                                        dist.group.WORLD, index_offset=lo)
+    np.save(os.path.join(out_dir, f"half{rank}.npy"), np.array([len(ec), int(ec.sum()), es]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,6 +112,18 @@ def test_sharded_region_discovery_equals_single_process(tmp_path):
     for r in range(world):
         assert key(np.load(tmp_path / f"masks{r}.npy"), np.load(tmp_path / f"counts{r}.npy")) == \
             key(ref["masks"], ref["counts"])
+        # tensor exchange: same order on every rank (decreasing count, ties by first index), GLOBAL first indices, the
+        # solved counts added up
+        o = np.lexsort((ref["first_index"], -ref["counts"]))
+        assert np.array_equal(np.load(tmp_path / f"masks{r}.npy"), ref["masks"][o])
+        assert np.array_equal(np.load(tmp_path / f"first{r}.npy"), ref["first_index"][o])
+        assert int(np.load(tmp_path / f"solved{r}.npy")[0]) == ref["n_solved"]
+    # an empty table on one rank: what comes back is rank 0's table
+    lo0, hi0 = lmpc.shard_bounds(len(theta), world, 0)
+    x0, ef0, _, act0 = oldp.solve_batch(L, theta[lo0:hi0])
+    m0, c0, _ = lmpc.explicit.unique_active_sets(act0, ef0)
+    for r in range(world):
+        assert np.load(tmp_path / f"half{r}.npy").tolist() == [len(c0), int(c0.sum()), 7]
 
 
 
