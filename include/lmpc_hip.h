@@ -65,6 +65,10 @@ typedef struct lmpc_settings {
     double eps_prox;     /* 0     */
     double eta_prox;     /* 1e-6  */
 } lmpc_settings;
+/* The layout every binding mirrors (integration/LmpcHipExt.jl::LmpcSettings, linearmpc.jl_amd/_cabi.py::Settings): ten
+ * fields, 72 bytes, the two 32-bit counters side by side at offset 48.  Checked here at compile time and against the
+ * Julia struct's text by tests/test_host.py::test_settings_layout_is_the_same_in_every_binding. */
+typedef char lmpc_settings_is_72_bytes[(sizeof(lmpc_settings) == 72) ? 1 : -1];
 
 /* status codes of the API itself (solver outcomes are the per-problem exit flags) */
 #define LMPC_OK 1
@@ -200,9 +204,9 @@ int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
  * D2H copy of chunk k-1 on three streams.  With arrays the caller pinned (lmpc_pin_host) every copy is
  * asynchronous and one thread drives the pipeline (1.17 ms per 10^6 pendulum problems, PCIe-bound: 56 MB in at
  * 52 GB/s); with pageable arrays, whose copy calls block, the upload and download sides run on two host threads
- * ("host_threads" 0: one chunk, one thread; 1.25 against 1.30 ms).  "host_register" 1 pins the caller's arrays
- * for the duration of each call instead -- not the default: registering ordinary heap memory call after call
- * ended in a GPU memory fault on this runtime after a few hundred calls in one process.
+ * ("host_threads" 0: one chunk, one thread; 1.25 against 1.30 ms).  (The option "host_register", which pinned the
+ * caller's arrays for the duration of each call, was removed in round 5 -- it ended in a GPU memory fault after a few
+ * hundred calls -- and lmpc_set_option answers LMPC_ERR_UNSUPPORTED for it.)
  * lmpc_solve_batch_device: DEVICE pointers on the handle's GPU; enqueues the kernels on
  * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns without
  * synchronising -- this is what bench.py times with inputs resident in HBM.

@@ -76,7 +76,7 @@ end
 # it was built from: every set_*! only clears mpc.mpqp_issetup (setup.jl:36-160) and the next setup! -- called by
 # solve (utils.jl:269), by us, or by the user -- builds a NEW mpQP of possibly the same dimensions (setup.jl:9), so
 # dimensions say nothing; object identity does.  The solver settings on mpc.opt_model are re-read on every solve
-# (a struct of eight numbers) and pushed with lmpc_set_settings when they differ from what the handle was last
+# (a struct of ten numbers: lmpc_settings) and pushed with lmpc_set_settings when they differ from what the handle was last
 # given, so DAQP.settings(mpc.opt_model, Dict(...)) after the first solve reaches the GPU path too.
 # (The Python mirror linearmpc.jl_amd/mpc.py::MPC._model_for is this logic line for line; the test-suite runs the
 # failing sequences on it: tests/test_gpu_parity.py::test_solve_mpc_theta_drop_in_and_user_settings.)

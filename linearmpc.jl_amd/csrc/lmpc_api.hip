@@ -509,6 +509,12 @@ int wave_probe(lmpc_handle *h, const double *theta, int64_t nprob, hipStream_t s
     if (h->waveProbed || !h->waveProbe || !h->useWave || h->avi || h->bnb || h->waveTwoPass >= 0 || !h->bigPath ||
         h->W.cap < 40 || nprob < 4 * kProbe || theta == nullptr)
         return LMPC_OK;
+    // (the probe allocates, copies and waits -- none of which a stream capture allows.  Inside a capture
+    // nothing is probed and nothing is marked: the first call outside one probes.)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return LMPC_OK; }
+    }
     h->waveProbed = true;
     double *px = nullptr;
     int32_t *pf = nullptr;
@@ -1867,7 +1873,13 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "big_path") == 0) { h->bigPath = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "lane_per") == 0) { h->lanePer = value; return LMPC_OK; }
     if (std::strcmp(name, "host_chunk") == 0) { h->hostChunk = value < 1024 ? 1024 : value; return LMPC_OK; }
-    if (std::strcmp(name, "host_register") == 0) { h->hostRegister = value ? 1 : 0; return LMPC_OK; }
+    if (std::strcmp(name, "host_register") == 0) {
+        // (removed in round 5: pinning ordinary heap memory call after call ended in a GPU memory fault on this runtime
+        // after a few hundred calls; lmpc_pin_host on long-lived arrays is the supported way)
+        if (value == 0) return LMPC_OK;
+        return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc_set_option: \"host_register\" 1 was removed (it faulted after a few hundred calls); "
+                                             "pin long-lived arrays with lmpc_pin_host instead");
+    }
     if (std::strcmp(name, "host_threads") == 0) { h->hostThreads = value ? 1 : 0; return LMPC_OK; }
     if (std::strcmp(name, "gram_scan") == 0) { h->waveGram = value != 0; return LMPC_OK; }
     if (std::strcmp(name, "wave_two_pass") == 0) { h->waveTwoPass = value < 0 ? -1 : (value != 0); return LMPC_OK; }

@@ -294,16 +294,9 @@ HostMode host_mode(PinScope &pin, const lmpc_handle *h, size_t rs, int64_t N, co
     if (caller_pinned(theta, bth) && caller_pinned(x, bx) && caller_pinned(flag, bf) && caller_pinned(iters, iters ? bf : 0) &&
         caller_pinned(active, active ? ba : 0) && caller_pinned(warm, warm ? ba : 0))
         return HostMode::ASYNC;
-    if (h->hostRegister) {
-        // Pin the caller's arrays for the duration of this call.  NOT the default: on this runtime (ROCm 7.2,
-        // MI355X) registering and unregistering ordinary heap memory call after call ended, after a few hundred
-        // calls in one process, in a GPU memory access fault on a host address (tests: the whole GPU suite in one
-        // process, two runs of eight).  Caller-pinned, page-aligned, long-lived arrays (lmpc_pin_host) are safe.
-        pin.pin(theta, bth); pin.pin(x, bx); pin.pin(flag, bf);
-        pin.pin(iters, iters ? bf : 0); pin.pin(active, active ? ba : 0); pin.pin(warm, warm ? ba : 0);
-        pin.commit();
-        return HostMode::ASYNC;
-    }
+    // (pinning the caller's arrays for the duration of a call -- "host_register" 1 of rounds 2-4 -- is gone: on this
+    // runtime registering and unregistering ordinary heap memory call after call ended, after a few hundred calls in one
+    // process, in a GPU memory access fault.  Caller-pinned, long-lived arrays (lmpc_pin_host) take the branch above.)
     return h->hostThreads ? HostMode::THREADED : HostMode::SINGLE;
 }
 

@@ -26,8 +26,15 @@ int go(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *f
             sp[(size_t)j * NR + N] = h->P.du0[j];
             sp[(size_t)j * NR + N + 1] = h->P.dl0[j];
         }
-        HIP_TRY(h, hipMalloc(&h->dQpScan, sizeof(double) * sp.size()));
-        HIP_TRY(h, hipMemcpy(h->dQpScan, sp.data(), sizeof(double) * sp.size(), hipMemcpyHostToDevice));
+        // (the handle gets the pointer only once the pack is in place: a failed copy must not leave a buffer of garbage
+        // that every later launch would take for the pack -- ADVICE round 4)
+        double *scan = nullptr;
+        HIP_TRY(h, hipMalloc(&scan, sizeof(double) * sp.size()));
+        if (hipMemcpy(scan, sp.data(), sizeof(double) * sp.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(scan);
+            return fail(h, LMPC_ERR_HIP, "lmpc: upload of the tiers pass's scan pack failed");
+        }
+        h->dQpScan = scan;
     }
     if (preload) {
         hipFuncAttributes fa;

@@ -26,7 +26,7 @@
 //  * a row that finishes a problem writes its outputs and takes the next problem from the batch by itself (tickets of
 //    a few problems each from one global counter), the other three rows keep iterating.
 //
-// Arithmetic: statement for statement the fma chains of oracle/daqp_ldp_oracle.c (mode 0, the n-chain form) -- the
+// Arithmetic: statement for statement the fma chains of the CPU checker (its mode 0, the n-chain form; the file the wavefront kernel is checked against) -- the
 // results are bit-identical to the oracle's and to the wavefront kernel's (x, exit flag, iteration count, active set).
 //
 // Covers: cold plain solves, binary64 / binary32, n <= 16 NS, m <= 16 MS, hard / SOFT / IMMUTABLE rows, no rows

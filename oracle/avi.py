@@ -210,7 +210,7 @@ def kkt_residual(H, f, f_theta, A, bu, bl, W, sense, theta, x, active, rho_soft=
     mu = np.zeros(m)
     # SOFT rows of the working set: the slack IS the multiplier, (row value - bound) * s_j^2 / rho_soft with the
     # row scale s_j = 1 / sqrt(a_j H^-1 a_j')  (rho_soft is measured in the scaled row's units, as in the QP mode)
-    Hinv = np.linalg.inv(H)
+    Hinv = np.linalg.inv(H) if any(soft[j] for j in rows) else None     # (a semidefinite H has none: only soft rows need it)
     for j in rows:
         if soft[j]:
             s2 = 1.0 / float(Aext[j] @ Hinv @ Aext[j])

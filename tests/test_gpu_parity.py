@@ -2474,9 +2474,24 @@ def test_proximal_point_mode_for_a_semidefinite_hessian(lmpc):
         pk = qp.avi_pack()
         P = oavi.AVI(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["ML"], pk["MR"], pk["G"], pk["du"], pk["dl"],
                      pk["Dth"], pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"])).contiguous()
-        _, px = oavi.qp2prox(H, f, fth, A, bu, bl, W, sense, nout=nout, eps=1e-4)
-        px = {k: (pk[k] if k in pk else v) for k, v in px.items()}
-        xo, efo, ito, acto = oavi.prox_solve_batch(P, qp.prox_pack(), th, 1e-4, 1e-9)
+        # the library's own transform (qp_to_prox: H + eps I, its inverse, the affine map, the outputs' feedback term)
+        # against the independent restatement in oracle/avi.py -- the kernel and the checker below share the handle's pack,
+        # so an error in the transform would cancel there
+        Pq, px = oavi.qp2prox(H, f, fth, A, bu, bl, W, sense, nout=nout, eps=1e-4)
+        hp = qp.prox_pack()
+        for k in ("Hinv", "x0f", "Xthf", "Kth"):
+            assert np.allclose(hp[k], px[k], rtol=1e-9, atol=1e-11), (trial, k)
+        for k, ref in (("ML", Pq.ML), ("MR", Pq.MR), ("du", Pq.du0), ("dl", Pq.dl0), ("Dth", Pq.Dth), ("Rout", Pq.Rout),
+                       ("x0", Pq.x0), ("Xth", Pq.Xth)):
+            assert np.allclose(np.asarray(pk[k]).reshape(-1), np.asarray(ref).reshape(-1), rtol=1e-8, atol=1e-10), (trial, k)
+        xo, efo, ito, acto = oavi.prox_solve_batch(P, hp, th, 1e-4, 1e-9)
+        # ... and the limit is a KKT point of the ORIGINAL (semidefinite) problem: full-length x from a second handle
+        qf = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense, nout=n, settings=s)
+        xf, eff, _, actf = qf.solve(th[:200])
+        for i in np.flatnonzero(eff == 1)[:40]:
+            r_st, r_pr, r_sg = oavi.kkt_residual(H, f, fth, A, bu, bl, W, sense, th[i], xf[i], actf[i])
+            assert r_st < 1e-6 and r_pr < 1e-6 and r_sg < 1e-6, (trial, i, r_st, r_pr, r_sg)
+        qf.close()
         assert set(np.unique(efo)) <= {1, -1} and (efo == 1).mean() > 0.5        # (some points' rows are infeasible)
         assert np.array_equal(ef, efo) and np.array_equal(it, ito) and np.array_equal(act, acto) and np.array_equal(x, xo), trial
         bad = lmpc.default_settings(); bad.eps_prox = 1e-3

@@ -451,3 +451,26 @@ def test_bench_line_is_compact_and_strict_json():
     full["configs"] = {f"c{i}": dict(full["configs"]["pendulum_N50"]) for i in range(200)}
     line2 = bench.compact_line(full)
     assert len(line2) < bench.LINE_LIMIT and "truncated" in json.loads(line2)
+
+
+def test_settings_layout_is_the_same_in_every_binding(lmpc):
+    """`lmpc_settings` as the C header declares it, as the ctypes mirror declares it and as the (never executed) Julia glue
+    declares it: same fields, same order, same types -- a drift in the Julia struct would be silent otherwise."""
+    import ctypes
+    import re
+    from linearmpc_jl_amd._cabi import Settings
+    hdr = open(os.path.join(ROOT, "include", "lmpc_hip.h")).read()
+    body = re.search(r"typedef struct lmpc_settings \{(.*?)\} lmpc_settings;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = [(m.group(2), m.group(1)) for m in re.finditer(r"\b(double|int32_t)\s+(\w+)\s*;", body)]
+    py_fields = [(n, {ctypes.c_double: "double", ctypes.c_int32: "int32_t"}[t]) for n, t in Settings._fields_]
+    assert c_fields == py_fields and len(c_fields) == 10
+    assert ctypes.sizeof(Settings) == 72 and Settings.cycle_tol.offset == 48 and Settings.iter_limit.offset == 52 \
+        and Settings.eps_prox.offset == 56
+    jl = open(os.path.join(ROOT, "integration", "LmpcHipExt.jl")).read()
+    sbody = re.search(r"struct LmpcSettings[^\n]*\n(.*?)\nend", jl, re.S).group(1)
+    jl_fields = [(m.group(1), {"Cdouble": "double", "Cint": "int32_t"}[m.group(2)]) for m in re.finditer(r"(\w+)::(Cdouble|Cint)", sbody)]
+    assert jl_fields == c_fields
+    # ... and the constructor passes the fields in that order
+    ctor = re.search(r"return LmpcSettings\((.*?)\)\nend", jl, re.S).group(1)
+    assert [a.strip().split(".")[-1] for a in ctor.replace("\n", " ").split(",")] == [n for n, _ in c_fields]
