@@ -727,6 +727,9 @@ def avi_config(torch, lmpc, dev, local_rank, batch, steps, warmup, want_cpu, cpu
            "solved_fraction": float((fb.cpu().numpy() >= 1).mean()), "mean_iterations": float(it_h.mean()),
            "max_iterations": int(it_h.max()),
            "first_run_value": batch / first_call_s, "first_call_ms": 1e3 * first_call_s,
+           "parity": "unpinned iteration: libdaqp's AVI mode is not restated (source unavailable); GPU == this build's own "
+                     "principal-pivoting oracle bit for bit; reference-held: the closed loop's end values [10, 0] "
+                     "(runtests.jl:1337-1358) and KKT certificates of the unique equilibrium",
            "verification": {"points": int(len(idx)), "against": "oracle/daqp_avi_oracle.c on the handle's pack: x, exit flag "
                                                                  "and iteration count bit-identical"},
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -1126,6 +1129,8 @@ def compact_line(out):
                     e["bound"] = r_.get("bound")   # (valu unless stated)
             if "error" in c:
                 e["error"] = str(c["error"])[:120]
+            if "parity" in c:
+                e["parity"] = str(c["parity"])[:28]
             gs = c.get("gram_scan")
             if isinstance(gs, dict):
                 e["gram_value"] = _r(gs.get("value"))

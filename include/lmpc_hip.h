@@ -55,7 +55,10 @@ typedef struct lmpc_settings {
     double rho_soft;     /* 1e-6  */
     int32_t cycle_tol;   /* 10    */
     int32_t iter_limit;  /* 10000 */
-    /* ABI version 2: DAQP's proximal-point settings.  eps_prox > 0 AT SETUP selects the proximal-point mode, the one
+    /* ABI version 2: DAQP's proximal-point settings.  (PARITY: UNPINNED -- libdaqp's own prox loop is not available to
+     * restate and no reference test holds a vector for it; this is the textbook method the setting is named after,
+     * checked against this build's own oracle twin and by KKT certificates of the original problem.)
+     * eps_prox > 0 AT SETUP selects the proximal-point mode, the one
      * that accepts a merely positive SEMIdefinite (symmetric) H -- without it such an H is answered with -5, as by
      * DAQP.setup (/root/reference/src/setup.jl:18-19):  x_{k+1} = argmin 1/2 x'Hx + f(theta)'x + eps_prox/2 |x - x_k|^2
      * over the constraint set, x_0 = 0, until |x_{k+1} - x_k|_inf < eta_prox; every subproblem is solved by the
@@ -120,7 +123,10 @@ int lmpc_setup(lmpc_handle **out, int n, int m, int ms, int nth, int nout,
  *          (H + H' must be positive definite: LMPC_ERR_NONCONVEX otherwise).  Solved by the library's AVI kernel
  *          (one problem per lane, recursive L D U factorisation; binary64; no BINARY rows); every entry point that
  *          takes a handle works on it except the binary32 ones and the Gram-scan option.  is_avi == 0 with a
- *          non-symmetric H is LMPC_ERR_BADARG.
+ *          non-symmetric H is LMPC_ERR_BADARG.  (PARITY OF THE ITERATION: UNPINNED -- libdaqp's AVI mode is not
+ *          restated; the solution of a strongly monotone AVI is unique, which is what the reference-held numbers
+ *          -- the game-theoretic closed loop's end values, test/runtests.jl:1337-1358 -- and the KKT certificates
+ *          pin; iteration counts and working-set sequences are this build's own.)
  * lmpc_setup itself decides is_avi from H exactly as the reference decides mpQP.is_symmetric
  * (isapprox(H, H', rtol = 1e-9), mpc2mpqp.jl:897) and has no priorities.
  * lmpc_is_avi: 1 / 0.  lmpc_get_avi: the AVI pack's second matrix MR[m*n] (row j = (H^-1 ML_j')', ML = what
