@@ -310,6 +310,60 @@ class Workload:
             self.qp.set_option(k_, v_)
         return solo
 
+    def several_batches_section(self, nb=8, ncalls=24):
+        """lmpc_solve_batches_device on ONE stream: calls of `nb` batches each, back to back, over a rotation of nb distinct
+        cold batches and nb output buffers; event-timed as a run (torch events on the launch stream).  On the headline's
+        handle one call is ONE kernel launch (fast_kernel_multi) in which the solving tail of a batch runs under the
+        stream of the next.  Returns the per-call / per-batch times and the oracle check of what the last call wrote."""
+        torch = self.torch
+        if self.f32 or not hasattr(self.qp, "bind_device_batches"):
+            return None
+        thetas = list(self.thetas)
+        while len(thetas) < nb:
+            thetas.append(torch.from_numpy(make_theta(self.name, self.n_local, 104729 * len(thetas) + 77, self.hard)).to(self.dev).to(self.tdt))
+        xs = [torch.empty((self.n_local, self.nout), dtype=self.tdt, device=self.dev) for _ in range(nb)]
+        fs = [torch.empty(self.n_local, dtype=torch.int32, device=self.dev) for _ in range(nb)]
+        st = self.streams[0]
+        call = self.qp.bind_device_batches(thetas[:nb], xs, fs, st.cuda_stream)
+        shaped = {k_: v_ for k_, v_ in self.options.items() if k_ in ("fast_nstr", "fast_tiles", "in_flight")}
+        for k_ in shaped:
+            self.qp.set_option(k_, 1 if k_ == "in_flight" else 0)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize(self.dev)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        for _ in range(ncalls):
+            call()
+        b.record(st)
+        torch.cuda.synchronize(self.dev)
+        call_ms = a.elapsed_time(b) / ncalls
+        for k_, v_ in shaped.items():
+            self.qp.set_option(k_, v_)
+        # the last call's outputs against the oracle (a sample of every batch)
+        from oracle import ldp as oldp
+        pk = self.qp.ldp()
+        L = oldp.LDP(pk["n"], pk["m"], pk["ms"], pk["nth"], pk["nout"], pk["M"], pk["du"], pk["dl"], pk["Dth"],
+                     pk["Rout"], pk["x0"], pk["Xth"], pk["sense"], np.ones(pk["m"]))
+        rng = np.random.default_rng(5)
+        nflag, worst, npts = 0, 0.0, 0
+        for q in range(nb):
+            idx = torch.from_numpy(np.sort(rng.choice(self.n_local, min(1024, self.n_local), replace=False))).to(self.dev)
+            xo, efo, _, _ = oldp.solve_batch(L, thetas[q][idx].cpu().numpy())
+            ef = fs[q][idx].cpu().numpy()
+            nflag += int((ef != efo).sum())
+            ok = efo >= 1
+            if ok.any():
+                worst = max(worst, float(np.abs(xs[q][idx].cpu().numpy()[ok] - xo[ok]).max()))
+            npts += len(idx)
+        by = self.bytes_per * self.n_local
+        return {"batches_per_call": nb, "calls_timed": ncalls, "call_ms": call_ms, "ms_per_batch": call_ms / nb,
+                "value": nb * self.n_local / (call_ms * 1e-3), "achieved": nb * by / (call_ms * 1e-3) / 1e9,
+                "frac": nb * by / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                "verified": bool(nflag == 0 and worst <= 1e-10), "points_checked": npts,
+                "how": f"lmpc_solve_batches_device, {nb} cold batches per call = ONE launch of fast_kernel_multi (gridDim.y = {nb}); "
+                       "calls back to back on ONE stream, event-timed as a run; algorithmic bytes of a call / its duration"}
+
     def verify_steps(self, ks, per_step=4096, seed=99):
         """Output check behind a timed region: for each step k in ks, a seeded sample of the buffers that step wrote
         against the CPU oracle on the same parameter points (the oracle is the checker here, nothing timed).  Returns
@@ -1100,6 +1154,11 @@ def compact_line(out):
                                                        "algorithmic_bytes_per_solve")}
     if isinstance(roof.get("pipelined"), dict):
         line["roofline"]["pipelined_frac"] = _r(roof["pipelined"].get("frac"))
+    sb = roof.get("several_batches_per_call")
+    if isinstance(sb, dict) and "frac" in sb:
+        line["roofline"]["calls_of_%d_batches" % sb.get("batches_per_call", 0)] = {"frac": _r(sb.get("frac"), 4), "value": _r(sb.get("value")),
+                                                                               "ms_per_batch": _r(sb.get("ms_per_batch"), 4),
+                                                                               "verified": sb.get("verified")}
     ti = roof.get("traffic_info")
     if isinstance(ti, dict):
         line["roofline"]["traffic_on"] = {"commit": ti.get("measured_on_commit"), "kernel": (ti.get("kernels") or [None])[0],
@@ -1438,6 +1497,11 @@ def main():
                              "launches_timed": cold[0], "kernel_ms": cold[1],
                              "screen_kernel_ms": cold[2], "iterate_kernel_ms": cold[3],
                              "screen_kernel_frac": gbs(cold[2]) / HBM_PEAK_GBS if cold[2] > 0 else None})
+            if args.workload == "pendulum" and not args.f32 and not args.wave:
+                try:
+                    roof["several_batches_per_call"] = W.several_batches_section(8, 24)
+                except Exception as e:                       # never fatal for the line
+                    roof["several_batches_per_call"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if not args.no_rotate:
                 # cache-resident counterparts (ONE theta buffer reused): what round 1 reported
                 res = W.single_launch(nsolo, resident=True)

@@ -220,6 +220,15 @@ int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
 int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x,
                      int32_t *exitflag, int32_t *iters, uint64_t *active,
                      const uint64_t *warm);
+/* lmpc_solve_batches_device: n_batches batches of N points each in ONE call -- theta / x / exitflag are HOST tables of
+ * n_batches DEVICE pointers (the tables are read during the call, the batches' buffers need not be adjacent).  Cold
+ * plain solves; results are those of n_batches calls of lmpc_solve_batch_device bit for bit.  On the handles the
+ * one-launch kernel covers (small box-constrained problems: the headline configuration) up to eight batches go into
+ * one kernel launch, in which the solving tail of a batch runs under the stream of the next: 10^6-point pendulum
+ * batches cost ~16 us each in a call of three against 22 us one call at a time.  Elsewhere it enqueues the batches one
+ * after the other.  Caller side: the same loop over parameter batches that calls solve (reference src/utils.jl:268-283). */
+int lmpc_solve_batches_device(lmpc_handle *h, int32_t n_batches, int64_t N, const double *const *theta, double *const *x,
+                              int32_t *const *exitflag, void *stream);
 int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, double *x,
                             int32_t *exitflag, int32_t *iters, uint64_t *active,
                             const uint64_t *warm, void *stream);

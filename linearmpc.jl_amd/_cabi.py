@@ -21,7 +21,7 @@ ERR_NAMES = {-1: "INFEASIBLE", -5: "NONCONVEX", -6: "OVERDETERMINED", -100: "BAD
 SYMBOLS = (
     "lmpc_abi_version", "lmpc_default_settings", "lmpc_setup", "lmpc_setup_ldp", "lmpc_transform",
     "lmpc_get_ldp", "lmpc_get_dims", "lmpc_active_words", "lmpc_set_settings",
-    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_one",
+    "lmpc_solve_batch", "lmpc_solve_batch_device", "lmpc_solve_batches_device", "lmpc_solve_one",
     "lmpc_default_settings_f32", "lmpc_solve_batch_f32", "lmpc_solve_batch_f32_device", "lmpc_simulate",
     "lmpc_simulate_device", "lmpc_simulate_f32", "lmpc_simulate_f32_device", "lmpc_form_parameter_device", "lmpc_simulate_ref_device", "lmpc_kernel_name",
     "lmpc_set_parameter_layout", "lmpc_compute_control", "lmpc_compute_control_device",
@@ -114,6 +114,9 @@ def lib():
     L.lmpc_solve_batch.restype = i32
     L.lmpc_solve_batch_device.argtypes = [vp, i64] + [vp] * 7
     L.lmpc_solve_batch_device.restype = i32
+    if hasattr(L, "lmpc_solve_batches_device"):
+        L.lmpc_solve_batches_device.argtypes = [vp, i32, i64, vp, vp, vp, vp]
+        L.lmpc_solve_batches_device.restype = i32
     L.lmpc_default_settings_f32.argtypes = [ctypes.POINTER(Settings)]
     L.lmpc_default_settings_f32.restype = None
     L.lmpc_solve_batch_f32.argtypes = [vp, i64] + [vp] * 6

@@ -990,6 +990,45 @@ int lmpc_solve_batch_device(lmpc_handle *h, int64_t N, const double *theta, doub
     return launch(h, N, theta, x, exitflag, iters, active, warm, (hipStream_t)stream);
 }
 
+// SEVERAL batches of N points each in one call (round 5): on the handles the one-launch kernel covers -- the headline's
+// class -- ONE kernel launch takes all of them (fast_kernel_multi: the solving tail of a batch runs under the stream of
+// the next); everywhere else the batches are enqueued one after the other on `stream`, exactly as n_batches calls of
+// lmpc_solve_batch_device would.  Results are those of the single-batch call bit for bit.
+int lmpc_solve_batches_device(lmpc_handle *h, int32_t n_batches, int64_t N, const double *const *theta, double *const *x,
+                              int32_t *const *exitflag, void *stream) {
+    if (!h) return LMPC_ERR_BADARG;
+    if (n_batches < 0 || N < 0 || (n_batches > 0 && (!theta || !x || !exitflag)))
+        return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batches_device: NULL table or negative count");
+    if (n_batches == 0 || N == 0) return LMPC_OK;
+    for (int b = 0; b < n_batches; b++)
+        if (!x[b] || !exitflag[b] || (h->P.nth > 0 && !theta[b]))
+            return fail(h, LMPC_ERR_BADARG, "lmpc_solve_batches_device: NULL array in the table");
+    if (N > (int64_t)0x7fffffff * 64) return fail(h, LMPC_ERR_BADARG, "lmpc: batch too large for one launch");
+    LMPC_ENTER_DEVICE(h);
+    hipStream_t st = (hipStream_t)stream;
+    const bool one_launch = !h->avi && !h->useWave && h->asyncPhase == 0 && h->L.sim.FG == nullptr && h->L.gat.state == nullptr &&
+                            will_screen(h, N) && fast_covers(h) && !h->prof;
+    int done = 0;
+    while (done < n_batches) {
+        const int nb = n_batches - done < 8 ? n_batches - done : 8;
+        int rc = LMPC_ERR_UNSUPPORTED;
+        if (one_launch && nb > 1) {
+            rc = check_fast_err(h);
+            if (rc == LMPC_OK) rc = launch_fast_multi(h, nb, N, theta + done, x + done, exitflag + done, st);
+        }
+        if (rc == LMPC_ERR_UNSUPPORTED) {
+            for (int b = 0; b < nb; b++) {
+                rc = launch(h, N, theta[done + b], x[done + b], exitflag[done + b], nullptr, nullptr, nullptr, st);
+                if (rc != LMPC_OK) return rc;
+            }
+        } else if (rc != LMPC_OK) {
+            return rc;
+        }
+        done += nb;
+    }
+    return LMPC_OK;
+}
+
 int lmpc_solve_batch_f32_device(lmpc_handle *h, int64_t N, const float *theta, float *x, int32_t *exitflag,
                                 int32_t *iters, uint64_t *active, const uint64_t *warm, void *stream) {
     if (!h) return LMPC_ERR_BADARG;

@@ -109,6 +109,78 @@ static int launch_fast_t(lmpc_handle *h, int64_t nprob, const double *theta, dou
     return LMPC_OK;
 }
 
+// Several equally sized batches in one launch (see fast_kernel_multi): the launch shape of a single batch, gridDim.y batches.
+template <int NTHMAX, int NT, int N>
+static int launch_fast_multi_t(lmpc_handle *h, int nb, int64_t nprob, const double *const *theta, double *const *x,
+                               int32_t *const *flag, hipStream_t st) {
+    const int nstr = h->fastNstr >= 1 && h->fastNstr <= 4 ? h->fastNstr : 3;
+    const long long ntiles = (nprob + 63) / 64;
+    long long slots = (long long)h->numCU * LMPC_FAST_WAVES;
+    long long Rl = (ntiles + slots - 1) / slots;
+    if (Rl < 8) Rl = 8;
+    if (h->fastTiles > 0) Rl = h->fastTiles;
+    if (Rl > kFastMaxTiles) Rl = kFastMaxTiles;
+    if (Rl > ntiles) Rl = ntiles > 0 ? ntiles : 1;
+    const int R = (int)Rl;
+    const unsigned grid = (unsigned)((ntiles + R - 1) / R);
+    int dk = h->fastDma >= 0 ? h->fastDma : (nstr <= 3 ? LMPC_FAST_DMA_DEPTH : 0);
+    if (dk == 1 || dk > 3) dk = dk == 1 ? 0 : 3;
+    if (nprob * (int64_t)NT * 8 < 16 || (fast_tile_bytes(NT) & 15u) != 0) dk = 0;
+    FastBatches B{};
+    for (int b = 0; b < nb; b++) {
+        B.theta[b] = theta[b]; B.x[b] = x[b]; B.flag[b] = flag[b];
+        if ((reinterpret_cast<uintptr_t>(theta[b]) & 15u) != 0) dk = 0;
+    }
+    const size_t lds = dk ? fast_lds_bytes_dma(N, R, NTHMAX, NT, nstr, dk) : fast_lds_bytes(N, R, NTHMAX);
+    auto kern = fast_kernel_multi<NTHMAX, NT, N>;
+    if (lds > 48 * 1024)
+        HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!h->dFastErr) {
+        int32_t *hp = nullptr;
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
+        *hp = 0;
+        h->hFastErr = hp;
+        HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dFastErr), hp, 0));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, (unsigned)nb), dim3(256), lds, st, h->L, h->dC, B, (long long)nprob, R, nstr, h->dFastErr,
+                       h->fastSpinLimit > 0 ? h->fastSpinLimit - 1 : kFastSpinLimit, dk);
+    HIP_TRY(h, hipGetLastError());
+    return LMPC_OK;
+}
+
+// nb <= kFastMaxBatches batches of nprob points each on a handle the one-launch kernel covers; LMPC_ERR_UNSUPPORTED where
+// no instantiation exists (the caller then falls back to one call per batch)
+int launch_fast_multi(lmpc_handle *h, int nb, int64_t nprob, const double *const *theta, double *const *x, int32_t *const *flag,
+                      hipStream_t st) {
+    if (nb < 1 || nb > kFastMaxBatches) return LMPC_ERR_UNSUPPORTED;
+#ifdef LMPC_FAST_TRACE
+    return LMPC_ERR_UNSUPPORTED;
+#else
+#define LMPC_FM(NM, NT)                                                                                     \
+    switch (h->laneN) {                                                                                     \
+        case 2: return launch_fast_multi_t<NM, NT, 2>(h, nb, nprob, theta, x, flag, st);                    \
+        case 3: return launch_fast_multi_t<NM, NT, 3>(h, nb, nprob, theta, x, flag, st);                    \
+        case 4: return launch_fast_multi_t<NM, NT, 4>(h, nb, nprob, theta, x, flag, st);                    \
+        case 5: if constexpr (NT <= 8) return launch_fast_multi_t<NM, NT, 5>(h, nb, nprob, theta, x, flag, st); break; \
+        default: break;                                                                                     \
+    }                                                                                                       \
+    break;
+    switch (h->P.nth) {
+#ifdef LMPC_FAST_ONLY_PENDULUM
+        case 7: if (h->laneN == 5) return launch_fast_multi_t<8, 7, 5>(h, nb, nprob, theta, x, flag, st); break;
+#else
+        case 1: LMPC_FM(8, 1)   case 2: LMPC_FM(8, 2)   case 3: LMPC_FM(8, 3)   case 4: LMPC_FM(8, 4)
+        case 5: LMPC_FM(8, 5)   case 6: LMPC_FM(8, 6)   case 7: LMPC_FM(8, 7)   case 8: LMPC_FM(8, 8)
+        case 9: LMPC_FM(16, 9)  case 10: LMPC_FM(16, 10) case 11: LMPC_FM(16, 11) case 12: LMPC_FM(16, 12)
+        case 13: LMPC_FM(16, 13) case 14: LMPC_FM(16, 14) case 15: LMPC_FM(16, 15) case 16: LMPC_FM(16, 16)
+#endif
+        default: break;
+    }
+#undef LMPC_FM
+    return LMPC_ERR_UNSUPPORTED;
+#endif
+}
+
 int check_fast_err(lmpc_handle *h) {
     if (!h->hFastErr) return LMPC_OK;
     const int32_t e = *h->hFastErr;

@@ -98,9 +98,10 @@ __host__ __device__ constexpr size_t fast_lds_bytes_dma(int N, int R, int NTHMAX
 // are read by the wavefront that streams it and, if it needs iterations, once more by the lane that solves it; they
 // are written once, by whichever of the two finishes the problem -- after its own reads, so the in/out array needs
 // no copy.
+// (the kernel's body: shared by the one-batch launch and the several-batches launch below)
 template <int NTHMAX, int NT, int N, bool GATHER = false>
-__global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
-    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
+__device__ __forceinline__ void fast_body(
+    const PackLayout &P, const double *__restrict__ C, const double *__restrict__ theta,
     double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
     uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit,
     int dk, int Rs, int Dcap, int32_t *__restrict__ tctr, int32_t *__restrict__ tctr_next) {
@@ -627,6 +628,36 @@ __global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
                             ((long long)((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xffu) << 48);
 #endif
 #undef LMPC_TRC
+}
+
+template <int NTHMAX, int NT, int N, bool GATHER = false>
+__global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel(
+    const PackLayout P, const double *__restrict__ C, const double *__restrict__ theta,
+    double *__restrict__ X, int32_t *__restrict__ exitflag, int32_t *__restrict__ iters,
+    uint64_t *__restrict__ active, long long nprob, int R, int nstr, int32_t *__restrict__ errflag, int spinLimit,
+    int dk, int Rs, int Dcap, int32_t *__restrict__ tctr, int32_t *__restrict__ tctr_next) {
+    fast_body<NTHMAX, NT, N, GATHER>(P, C, theta, X, exitflag, iters, active, nprob, R, nstr, errflag, spinLimit, dk, Rs, Dcap, tctr,
+                                     tctr_next);
+}
+
+// SEVERAL batches of the same size in ONE launch (lmpc_solve_batches_device): blockIdx.y picks the batch, its buffers
+// come from a table in the kernel arguments.  A launch of the one-batch kernel lives 22 us for a 13 us stream: the
+// solving tail, the spread of the streams' ends over the XCDs and the ramp are paid per launch.  Here the workgroups of
+// batch b + 1 are dispatched as those of batch b retire, so the tail of one batch runs under the stream of the next
+// -- what a caller gets from three streams, inside one launch on one stream.
+constexpr int kFastMaxBatches = 8;
+struct FastBatches {
+    const double *theta[kFastMaxBatches];
+    double *x[kFastMaxBatches];
+    int32_t *flag[kFastMaxBatches];
+};
+template <int NTHMAX, int NT, int N>
+__global__ __launch_bounds__(256, LMPC_FAST_WAVES) void fast_kernel_multi(
+    const PackLayout P, const double *__restrict__ C, const FastBatches B, long long nprob, int R, int nstr,
+    int32_t *__restrict__ errflag, int spinLimit, int dk) {
+    const int b = blockIdx.y;
+    fast_body<NTHMAX, NT, N, false>(P, C, B.theta[b], B.x[b], B.flag[b], nullptr, nullptr, nprob, R, nstr, errflag, spinLimit, dk, R, 0,
+                                    nullptr, nullptr);
 }
 
 }  // namespace lmpc

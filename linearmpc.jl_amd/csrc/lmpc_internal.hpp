@@ -266,6 +266,8 @@ void avi_preload(lmpc_handle *h);
 int avi_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
 int launch_fast(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters,
                 uint64_t *active, hipStream_t st);
+int launch_fast_multi(lmpc_handle *h, int nb, int64_t nprob, const double *const *theta, double *const *x, int32_t *const *flag,
+                      hipStream_t st);
 
 // capacity of the first of two passes the wavefront kernel would run a batch of nprob problems at (0: one pass;
 // lmpc_wave_launch.hpp, compiled into the binary64 translation unit)

@@ -336,6 +336,48 @@ class BatchedQP:
             return keep
         return call
 
+    def bind_device_batches(self, thetas, xs, exitflags, stream):
+        """`lmpc_solve_batches_device`: several resident batches of the same size in ONE call (on the handles the
+        one-launch kernel covers: one kernel launch for up to eight of them).  Arguments validated and marshalled once;
+        returns a callable that enqueues the same call again."""
+        import torch
+        nb = len(thetas)
+        if not (nb == len(xs) == len(exitflags) and nb >= 1):
+            raise ValueError("as many x and exitflag tensors as theta tensors")
+        N = int(thetas[0].shape[0])
+        for t in thetas:
+            if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.dim() == 2 and t.shape == (N, self.nth)
+                    and t.device.index == self.device):
+                raise ValueError("every theta must be a contiguous float64 CUDA tensor of shape (N, nth) on this handle's GPU")
+        P = ctypes.c_void_p * nb
+        tt = P(*[t.data_ptr() for t in thetas])
+        xx = P(*[_dev_arg(x, "x", torch.float64, N * self.nout, self.device, False).value for x in xs])
+        ff = P(*[_dev_arg(f, "exitflag", torch.int32, N, self.device, False).value for f in exitflags])
+        args = (self._h, ctypes.c_int32(nb), ctypes.c_int64(N), ctypes.cast(tt, ctypes.c_void_p), ctypes.cast(xx, ctypes.c_void_p),
+                ctypes.cast(ff, ctypes.c_void_p), _vp(stream))
+        fn = lib().lmpc_solve_batches_device
+        h = self._h
+        keep = (list(thetas), list(xs), list(exitflags), tt, xx, ff)
+
+        def call():
+            rc = fn(*args)
+            if rc != _cabi.LMPC_OK:
+                check(rc, h)
+            return keep
+        return call
+
+    def solve_batches_device(self, thetas, xs=None, exitflags=None, stream=None):
+        """Several resident batches in one call; returns (xs, exitflags).  Enqueued on `stream` (default: torch's current
+        stream), not synchronised."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        N = int(thetas[0].shape[0])
+        xs = xs or [torch.empty((N, self.nout), dtype=torch.float64, device=dev) for _ in thetas]
+        exitflags = exitflags or [torch.empty(N, dtype=torch.int32, device=dev) for _ in thetas]
+        st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+        self.bind_device_batches(thetas, xs, exitflags, st)()
+        return xs, exitflags
+
     def simulate(self, x0, T, F, G, r=None, uprev=None, warm=True, want_x=True):
         """Batched closed loop (`lmpc_simulate`): N scenarios, T steps of solve + x <- F x + G u.
 

@@ -2753,3 +2753,34 @@ def test_row_kernel_guards_and_small_batches(lmpc):
     xb = qp.solve(big)
     for a, b in zip(xa, xb):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,N", [("pendulum", 100_003), ("pendulum", 777), ("refcond_kat", 50_000), ("mass_spring_3in", 4000)])
+def test_several_batches_in_one_call(lmpc, name, N):
+    """lmpc_solve_batches_device: one to nine batches in one call (one kernel launch for up to eight of them on the
+    handles the one-launch kernel covers, a loop of single-batch launches elsewhere) against the single-batch call on the
+    same buffers: bit-identical x and exit flags; a sample against the oracle."""
+    import torch
+    import bench
+    from oracle import ldp as oldp
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g, nout=1)
+    rng = np.random.default_rng(3)
+    if name in ("pendulum", "mass_spring_3in"):
+        ths = [bench.make_theta(name, N, 100 + b, hard=(b % 2 == 1) if name == "pendulum" else False) for b in range(9)]
+    else:
+        base = g["theta"]
+        ths = [np.ascontiguousarray(base[rng.integers(0, len(base), N)] * rng.uniform(0.5, 1.5)) for _ in range(9)]
+    th_d = [torch.from_numpy(t).cuda() for t in ths]
+    singles = [qp.solve_device(t) for t in th_d]
+    torch.cuda.synchronize()
+    for nb in (1, 2, 3, 8, 9):
+        xs, fs = qp.solve_batches_device(th_d[:nb])
+        torch.cuda.synchronize()
+        qp.check()
+        for b in range(nb):
+            assert torch.equal(xs[b], singles[b][0]) and torch.equal(fs[b], singles[b][1]), (nb, b)
+    L = oracle_ldp_from(qp.ldp())
+    sel = np.arange(0, N, max(1, N // 500))
+    xo, efo, _, _ = oldp.solve_batch(L, ths[2][sel])
+    assert np.array_equal(singles[2][1].cpu().numpy()[sel], efo) and np.abs(singles[2][0].cpu().numpy()[sel] - xo).max() <= TOL
