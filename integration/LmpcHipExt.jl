@@ -110,6 +110,18 @@ function LinearMPC.solve(mpc::LinearMPC.MPC, θ::AbstractVector{<:Real})
     fval = 0.5*dot(x, q.H, x) + dot(q.f .+ q.f_theta*th, x)
     return x, fval, Int(flag), (status = flag >= 1 ? :Solved : :Failed, exitflag = Int(flag))
 end
+"several parameter batches already resident on the GPU (device pointers, e.g. from AMDGPU.jl arrays), ONE call: on the
+handles the one-launch kernel covers the batches share one kernel launch (include/lmpc_hip.h, lmpc_solve_batches_device)"
+function solve_batches_device!(bm::BatchedModel, N::Integer, thetas::Vector{Ptr{Cdouble}}, xs::Vector{Ptr{Cdouble}},
+                               flags::Vector{Ptr{Cint}}; stream::Ptr{Cvoid}=C_NULL)
+    length(thetas) == length(xs) == length(flags) || error("one x and one flag array per parameter batch")
+    rc = ccall((:lmpc_solve_batches_device, liblmpc), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cdouble}}, Ptr{Ptr{Cint}}, Ptr{Cvoid}),
+        bm.h, length(thetas), N, thetas, xs, flags, stream)
+    rc == 1 || error("lmpc_solve_batches_device failed ($rc)")
+    return nothing
+end
+
 "drop (and free) the handle of an MPC now; never needed for correctness -- _model_for notices a new mpQP by itself"
 reset_batched!(mpc::LinearMPC.MPC) = (bm = pop!(_models, mpc, nothing); bm === nothing || free!(bm); nothing)
 

@@ -16,7 +16,9 @@ constexpr RowShape kRowShapes[] = {
     {1, 1, 4, 16},      // n <= 16, m <= 64, working sets <= 16 rows (the reference's mass_spring example: n = 10, m = 63)
     {2, 2, 6, 31},      // n <= 32, m <= 96, <= 31 rows (BASELINE config 3: n = 30, m = 84)
     {2, 2, 6, 32},      // ... <= 32 rows
-    {2, 4, 10, 32},     // n <= 64, m <= 160, <= 32 rows (the reference's benchmark class at N = 50: first of two passes)
+    {2, 4, 10, 31},     // n <= 64, m <= 160, <= 31 rows (the reference's benchmark class at N = 50: first of two passes -- at 31
+                        // rows, the capacity whose column order is free of bank conflicts)
+    {2, 4, 10, 32},     // ... <= 32 rows
 };
 
 bool shape_covers(const RowShape &sh, int n, int m, int cap) {
@@ -41,7 +43,8 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
             const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
-            if (blocks * nwv > row_launch_bound(sh.MS) / 64) blocks = row_launch_bound(sh.MS) / 64 / nwv;
+            const int maxw = 4 * row_waves_per_simd(sh.S, sh.MS);
+            if (blocks * nwv > maxw) blocks = maxw / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
             if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, ps, lds}; }
@@ -138,18 +141,19 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     const int full = h->W.cap;
     RowLaunch rl;
     int cap = 0;
-    // where it is the default (measured, tools/row_check.py): the two-slot shapes with up to six constraint slots -- config 3
-    // runs 1.6x the wavefront kernel there; the one-slot shape (behind the tiers pass) and the ten-slot one (one wavefront
-    // per SIMD) run level with it or behind and are taken only on request ("row_kernel" 1)
-    if (h->rowKernel < 0 && !(h->P.n > 16 && h->P.n <= 32 && h->P.m <= 96)) return 0;
+    // where it is the default (measured, tools/row_check.py): up to two slots of variables and six of constraints -- config 3
+    // runs 1.9x the wavefront kernel there, soft_doc (n = 10, SOFT rows, 12 iterations) 1.8x, mass_spring behind the tiers
+    // pass level; the ten-slot shape (one wavefront per SIMD) is taken only on request ("row_kernel" 1)
+    if (h->rowKernel < 0 && !(h->P.n <= 32 && h->P.m <= 96)) return 0;
     if (full <= 32 && row_launch_for(h, full, rs, &rl)) cap = full;
     else if (full > 32 && h->bigPath && h->waveTwoPass != 0) {
-        // first of two passes at 32 rows: when at most 1 in 20 of the working sets seen lately went beyond
+        // first of two passes at 31 rows: when at most 1 in 20 of the working sets seen lately went beyond 24 (the
+        // statistics' bucket below; 31 is the capacity whose column order is free of bank conflicts)
         unsigned long long sum[4] = {0, 0, 0, 0};
         wave_stat_read(h, sum);
         const bool known = sum[0] >= 1000ull;
         const bool fits = known && (sum[0] - sum[2]) * 20ull <= sum[0];
-        if ((h->rowKernel > 0 || fits) && row_launch_for(h, 32, rs, &rl)) cap = 32;
+        if ((h->rowKernel > 0 || fits) && row_launch_for(h, 31, rs, &rl)) cap = 31;
     }
     return cap;
 }
@@ -165,6 +169,7 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
         case 0: return LMPC_ROW(1, 1, 4, 16);
         case 1: return LMPC_ROW(2, 2, 6, 31);
         case 2: return LMPC_ROW(2, 2, 6, 32);
+        case 3: return LMPC_ROW(2, 4, 10, 31);
         default: return LMPC_ROW(2, 4, 10, 32);
     }
 #undef LMPC_ROW

@@ -181,6 +181,12 @@ template <typename R> struct RowParams {
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
 // LDS for five wavefronts' factors anyway)
 __host__ __device__ constexpr int row_launch_bound(int ms) { return ms <= 6 ? 512 : 256; }
+// resident wavefronts per SIMD an instantiation is register-budgeted for: three for one slot of positions (small factors:
+// LDS allows them, 168 registers), two for two slots with up to six constraint slots, one beyond
+#ifndef LMPC_ROW_WPS1
+#define LMPC_ROW_WPS1 3
+#endif
+__host__ __device__ constexpr int row_waves_per_simd(int s, int ms) { return ms > 6 ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
 
 // fused multiply-add with a row broadcast as its first factor and a DPP bank mask: acc += lane T of src's row * (-mul),
 // in the lanes of the banks set in BM (the others keep acc).  The 64-bit form is inline assembly (no builtin reaches
@@ -231,7 +237,7 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 // R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  CAPP: rows the
 // factor is laid out for (the launch's capacity P.cap <= CAPP <= 16 S).
 template <typename R, int S, int NS, int MS, int CAPP>
-__global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowParams<R> prm) {
+__global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS)))) void row_kernel(const RowParams<R> prm) {
     static_assert(S == 1 || S == 2, "one or two slots of working-set positions");
     static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) void row_kernel(const RowPara
 #ifndef LMPC_ROW_CHK6
 #define LMPC_ROW_CHK6 2
 #endif
-            constexpr int CHK = MS <= 4 ? 4 : (MS <= 6 ? LMPC_ROW_CHK6 : 1), NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
+            constexpr int CHK = LMPC_ROW_CHK6, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
                 typedef R rw_pair __attribute__((ext_vector_type(2)));
