@@ -216,6 +216,10 @@ int lmpc_set_settings(lmpc_handle *h, const lmpc_settings *s);
  * lmpc_solve_batch_device: DEVICE pointers on the handle's GPU; enqueues the kernels on
  * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns without
  * synchronising -- this is what bench.py times with inputs resident in HBM.
+ * One exception, once per handle: the FIRST large batch (>= 65 536 points) of a fresh wavefront-kernel handle whose
+ * working sets can exceed 40 rows first solves its own leading 16 384 points into scratch and WAITS for that launch
+ * (the probe that decides the launch shape; lmpc_set_option "wave_probe" 0 switches it off).  Inside a stream capture
+ * (hipStreamBeginCapture) the probe is skipped and left for the first call outside a capture.
  */
 int lmpc_solve_batch(lmpc_handle *h, int64_t N, const double *theta, double *x,
                      int32_t *exitflag, int32_t *iters, uint64_t *active,
@@ -303,7 +307,12 @@ const char *lmpc_multi_last_error(const lmpc_multi *hm);
 void lmpc_free_multi(lmpc_multi *hm);
 
 /* N = 1 convenience with DAQP.solve's shape: returns the exit flag (or an LMPC_ERR_* <= -100),
- * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call. */
+ * x[nout] out.  What Simulation's per-step compute_control (simulation.jl:106) would call.
+ * Ordering: the call runs on a stream of the handle's own, NOT ordered with the caller's streams, and
+ * uses the handle's scratch (work lists, counters, warm-start state).  Everything enqueued earlier on this handle through
+ * a *_device entry point must have completed before lmpc_solve_one (or a host-array lmpc_compute_control with a handful
+ * of states, which takes the same route) is called; such a call also counts as one call for the "even number of calls
+ * per captured graph" rule of the *_device entry points.  One thread at a time per handle, as for a DAQP workspace. */
 int lmpc_solve_one(lmpc_handle *h, const double *theta, double *x);
 
 /*

@@ -2784,3 +2784,37 @@ def test_several_batches_in_one_call(lmpc, name, N):
     sel = np.arange(0, N, max(1, N // 500))
     xo, efo, _, _ = oldp.solve_batch(L, ths[2][sel])
     assert np.array_equal(singles[2][1].cpu().numpy()[sel], efo) and np.abs(singles[2][0].cpu().numpy()[sel] - xo).max() <= TOL
+
+
+def test_row_kernel_immutable_one_sided_and_duplicated_rows(lmpc):
+    """IMMUTABLE rows (both bounds infinite: never enter a working set), one-sided rows, duplicated and opposing general
+    rows (the singular-direction branch, infeasible points) on the row kernel; a problem with an equality row (flagged
+    ACTIVE) is left to the wavefront kernel even when the row kernel is asked for."""
+    rng = np.random.default_rng(41)
+    n, nth, mg = 14, 4, 30
+    Hh = rng.standard_normal((n, n)); H = Hh @ Hh.T + n * np.eye(n)
+    A = rng.standard_normal((mg, n))
+    A[5] = A[4]; A[7] = -A[6]                               # duplicated / opposing rows
+    m = n + mg
+    bu = rng.uniform(0.3, 1.5, m); bl = -rng.uniform(0.3, 1.5, m)
+    sense = np.zeros(m, np.int32)
+    for j in (1, 3, n + 2, n + 9):                          # both bounds infinite
+        bu[j], bl[j], sense[j] = 1e30, -1e30, 4
+    for j in (2, n + 1, n + 10):                            # one-sided
+        bl[j] = -1e30
+    bu[n + 7] = -bl[n + 6] - 0.4                            # opposing rows that cannot both hold for some theta
+    W = 0.4 * rng.standard_normal((m, nth)); W[:n] = 0
+    qp = lmpc.BatchedQP.from_mpqp(H, np.zeros(n), rng.standard_normal((n, nth)), A, bu, bl, W, sense, nout=3)
+    theta = rng.uniform(-2, 2, (2000, nth))
+    x, ef, it, act = _row_vs_wave_vs_oracle(lmpc, qp, theta)
+    assert (ef >= 1).any() and (ef < 0).any()
+    bits = act.view(np.uint64)
+    for j in (1, 3, n + 2, n + 9):                          # an IMMUTABLE row is in no final active set
+        assert not (((bits[:, j >> 6] >> np.uint64(j & 63)) & np.uint64(1)).any() or
+                    ((bits[:, (m + j) >> 6] >> np.uint64((m + j) & 63)) & np.uint64(1)).any())
+    # an equality row: flagged ACTIVE by the setup -> not the row kernel's (same answers through the option either way)
+    bu2, bl2, s2 = bu.copy(), bl.copy(), sense.copy()
+    bu2[n + 12] = bl2[n + 12] = 0.1; s2[n + 12] = 5
+    q2 = lmpc.BatchedQP.from_mpqp(H, np.zeros(n), rng.standard_normal((n, nth)), A, bu2, bl2, W, s2, nout=3)
+    assert q2.kernel_name == "wave"
+    _row_vs_wave_vs_oracle(lmpc, q2, theta[:500])

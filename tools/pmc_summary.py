@@ -18,13 +18,33 @@ def main():
     workload = sys.argv[3] if len(sys.argv) > 3 else "pendulum"
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     out = {"source": src, "workload": workload, "kernels": {}, "pmc": {}}
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    # (a bench run is several processes -- the multi-device check runs in a child -- and a directory may hold several
+    # runs: per pass, the file with the most library dispatches is the bench's own main process of the latest run)
+    def main_file(pattern, count):
+        best, bestn = None, -1
+        for f in sorted(glob.glob(pattern), key=os.path.getmtime):
+            n = count(f)
+            if n >= bestn:
+                best, bestn = f, n
+        return best
+
+    def stat_calls(f):
+        return sum(int(r["Calls"]) for r in csv.DictReader(open(f)) if "lmpc::" in r["Name"])
+
+    def pmc_calls(f):
+        return sum(1 for r in csv.DictReader(open(f)) if "lmpc::" in r["Kernel_Name"])
+
+    f = main_file(os.path.join(src, "trace", "*", "*_kernel_stats.csv"), stat_calls)
+    if f:
         for r in csv.DictReader(open(f)):
             out["kernels"][r["Name"].split("(")[0]] = {
                 "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                 "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]), "pct": float(r["Percentage"])}
     agg = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for d in glob.glob(os.path.join(src, "pmc_*")):
+        f = main_file(os.path.join(d, "*", "*_counter_collection.csv"), pmc_calls)
+        if not f:
+            continue
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
             if "lmpc::" in name:
