@@ -21,6 +21,7 @@ constexpr int kLaneMaxN = 12;
 constexpr int kLaneMaxM = 64;
 constexpr size_t kLdsMax = 160 * 1024;
 constexpr int kWaveMaxN = 127, kWaveMaxCap = 64, kWaveMaxM = 1024;
+constexpr int64_t kProbe = 16384;       // points a fresh wavefront-kernel handle solves in front of its first large batch (wave_probe)
 
 struct EventTriple { hipEvent_t a, mid, b; };
 // work-list mode of the wavefront kernel for one launch (list == nullptr: the whole batch)
@@ -274,6 +275,18 @@ int launch_fast_multi(lmpc_handle *h, int nb, int64_t nprob, const double *const
 int wave_first_pass_cap(lmpc_handle *h, int64_t nprob);
 void wave_stat_read(const lmpc_handle *h, unsigned long long out[4]);
 int wave_reserve(lmpc_handle *h, int64_t nprob, hipStream_t st);
+
+// lmpc_api.hip's launch policy and scratch for the second API unit (lmpc_api_loop.hip); that unit's code preload
+int api_launch(lmpc_handle *h, int64_t nprob, const double *theta, double *x, int32_t *flag, int32_t *iters, uint64_t *active,
+               const uint64_t *warm, hipStream_t st);
+int api_ensure_sim(lmpc_handle *h, int64_t N);
+int api_ensure_f32(lmpc_handle *h);
+bool api_will_screen(const lmpc_handle *h, int64_t nprob);
+bool api_wave_screens(const lmpc_handle *h, int64_t nprob);
+int api_wave_probe(lmpc_handle *h, const double *theta, int64_t nprob, hipStream_t st);
+int api_launch_wave_f32(lmpc_handle *h, const float *dC, int64_t nprob, const float *theta, float *x, int32_t *flag, int32_t *iters,
+                        uint64_t *active, const uint64_t *warm, hipStream_t st);
+void loop_preload();
 
 // four problems per wavefront (lmpc_row_inst.hip): capacity the batch would run at on that kernel (0: it does not take
 // the batch), and its launch as the only pass (pass 0) or the first of two (pass 1) of a wavefront-kernel call
