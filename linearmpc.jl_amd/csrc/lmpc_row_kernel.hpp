@@ -188,31 +188,47 @@ __host__ __device__ constexpr int row_launch_bound(int ms) { return ms <= 6 ? 51
 #endif
 __host__ __device__ constexpr int row_waves_per_simd(int s, int ms) { return ms > 6 ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
 
-// fused multiply-add with a row broadcast as its first factor and a DPP bank mask: acc += lane T of src's row * (-mul),
-// in the lanes of the banks set in BM (the others keep acc).  The 64-bit form is inline assembly (no builtin reaches
-// v_fmac_f64_dpp); the statements that use it carry their own wait states (see the sweeps).
-#define RW_FMAC_DPP64 "v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
-#define RW_FMAC_DPP32 "v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
-
-// one sweep step as ONE statement: NOP + 1 wait states (2 behind a vector instruction that wrote `src`, 5 behind a scalar
-// write of EXEC: the compiler knows neither hazard inside inline assembly), then
-//   rw_step1: acc += lane T of acc's row * (-l)            in the banks BM
-//   rw_step2: oth += lane T of src's row * (-loth)          in all lanes, then src += lane T of src's row * (-lsrc) in the banks BM
-template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step1(double &acc, double l) {
-    asm volatile("s_nop %2\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(l), "n"(NOP), "n"(T), "n"(BM));
-}
-template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step1(float &acc, float l) {
-    asm volatile("s_nop %2\n\tv_fmac_f32_dpp %0, %0, -%1 row_newbcast:%3 row_mask:0xf bank_mask:%4" : "+v"(acc) : "v"(l), "n"(NOP), "n"(T), "n"(BM));
-}
-template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(double &src, double &oth, double lsrc, double loth) {
-    asm volatile("s_nop %4\n\tv_fmac_f64_dpp %1, %0, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"
-                 : "+v"(src), "+v"(oth) : "v"(lsrc), "v"(loth), "n"(NOP), "n"(T), "n"(BM));
-}
-template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(float &src, float &oth, float lsrc, float loth) {
-    asm volatile("s_nop %4\n\tv_fmac_f32_dpp %1, %0, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"
-                 : "+v"(src), "+v"(oth) : "v"(lsrc), "v"(loth), "n"(NOP), "n"(T), "n"(BM));
+// One sweep step as ONE statement of inline assembly (no builtin reaches v_fmac_f64_dpp, and the wait states have to sit
+// right in front of the instruction): NOP + 1 wait states (2 behind a vector instruction that wrote `src`; the compiler
+// knows no DPP hazard inside inline assembly), then, with b = lane T of src's row,
+//   every "other" slot:  oth_k += b * (-loth_k)   in all lanes,
+//   the source's slot:   src   += b * (-lsrc)     in the lanes of the banks BM (the last instruction: it rewrites the register
+//                                                 the others read their broadcast from).
+#define RW_STEP_DEFS(RT, SUF)                                                                                                      \
+    template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step1(RT &src, RT lsrc) {                                 \
+        asm volatile("s_nop %2\n\tv_fmac_" SUF "_dpp %0, %0, -%1 row_newbcast:%3 row_mask:0xf bank_mask:%4"                        \
+                     : "+v"(src) : "v"(lsrc), "n"(NOP), "n"(T), "n"(BM));                                                          \
+    }                                                                                                                              \
+    template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(RT &src, RT &o1, RT lsrc, RT l1) {                  \
+        asm volatile("s_nop %4\n\tv_fmac_" SUF "_dpp %1, %0, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "v_fmac_" SUF "_dpp %0, %0, -%2 row_newbcast:%5 row_mask:0xf bank_mask:%6"                                    \
+                     : "+v"(src), "+v"(o1) : "v"(lsrc), "v"(l1), "n"(NOP), "n"(T), "n"(BM));                                       \
+    }                                                                                                                              \
+    template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step3(RT &src, RT &o1, RT &o2, RT lsrc, RT l1, RT l2) {   \
+        asm volatile("s_nop %6\n\tv_fmac_" SUF "_dpp %1, %0, -%4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "v_fmac_" SUF "_dpp %2, %0, -%5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_" SUF "_dpp %0, %0, -%3 row_newbcast:%7 row_mask:0xf bank_mask:%8"                                    \
+                     : "+v"(src), "+v"(o1), "+v"(o2) : "v"(lsrc), "v"(l1), "v"(l2), "n"(NOP), "n"(T), "n"(BM));                    \
+    }                                                                                                                              \
+    template <int T, int BM, int NOP>                                                                                              \
+    __device__ __forceinline__ void rw_step4(RT &src, RT &o1, RT &o2, RT &o3, RT lsrc, RT l1, RT l2, RT l3) {                      \
+        asm volatile("s_nop %8\n\tv_fmac_" SUF "_dpp %1, %0, -%5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "v_fmac_" SUF "_dpp %2, %0, -%6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_" SUF "_dpp %3, %0, -%7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                               \
+                     "v_fmac_" SUF "_dpp %0, %0, -%4 row_newbcast:%9 row_mask:0xf bank_mask:%10"                                   \
+                     : "+v"(src), "+v"(o1), "+v"(o2), "+v"(o3) : "v"(lsrc), "v"(l1), "v"(l2), "v"(l3), "n"(NOP), "n"(T), "n"(BM)); \
+    }
+RW_STEP_DEFS(double, "f64")
+RW_STEP_DEFS(float, "f32")
+#undef RW_STEP_DEFS
+// a step of a sweep over S slots: source position T0 (slot T0 / 16), the NO other slots OFF .. OFF + NO - 1
+template <int T0, int BM, int NOP, int NO, int OFF, typename RT, int S>
+__device__ __forceinline__ void rw_step(RT (&v)[S], const RT (&l)[S]) {
+    constexpr int st = T0 >> 4, T = T0 & 15;
+    if constexpr (NO == 0) rw_step1<T, BM, NOP>(v[st], l[st]);
+    else if constexpr (NO == 1) rw_step2<T, BM, NOP>(v[st], v[OFF], l[st], l[OFF]);
+    else if constexpr (NO == 2) rw_step3<T, BM, NOP>(v[st], v[OFF], v[OFF + 1], l[st], l[OFF], l[OFF + 1]);
+    else rw_step4<T, BM, NOP>(v[st], v[OFF], v[OFF + 1], v[OFF + 2], l[st], l[OFF], l[OFF + 1], l[OFF + 2]);
 }
 // In front of and behind a sweep: five wait states with the sweep's vector as an operand.  In front: a scalar write of
 // EXEC (the end of a divergent region) must be five states away from the first DPP instruction, a vector write of the
@@ -220,7 +236,9 @@ template <int T, int BM, int NOP> __device__ __forceinline__ void rw_step2(float
 // sweep a step's own two states suffice: between two blocks there are only a scalar compare, a uniform branch and loads.
 template <typename V, int S> __device__ __forceinline__ void rw_sweep_fence(V (&v)[S]) {
     if constexpr (S == 1) asm volatile("s_nop 4" : "+v"(v[0]));
-    else asm volatile("s_nop 4" : "+v"(v[0]), "+v"(v[S - 1]));
+    else if constexpr (S == 2) asm volatile("s_nop 4" : "+v"(v[0]), "+v"(v[1]));
+    else if constexpr (S == 3) asm volatile("s_nop 4" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    else asm volatile("s_nop 4" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 // banks (of four lanes) of slot s that hold rows >= p0(t) / columns <= t
 __host__ __device__ constexpr int rw_bm_rows(int s, int t) {
@@ -238,7 +256,7 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 // factor is laid out for (the launch's capacity P.cap <= CAPP <= 16 S).
 template <typename R, int S, int NS, int MS, int CAPP>
 __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS)))) void row_kernel(const RowParams<R> prm) {
-    static_assert(S == 1 || S == 2, "one or two slots of working-set positions");
+    static_assert(S >= 1 && S <= 4, "one to four slots of working-set positions");
     static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -415,10 +433,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int q = decltype(Q)::value, t = t0 + q;
                     constexpr int NOP = 1;
-                    if constexpr (t + 1 < CAPP) {
-                        if constexpr (S == 1) rw_step1<t, rw_bm_rows(0, t), NOP>(v[0], Lr[q][0]);
-                        else if constexpr (t < 16) rw_step2<t, rw_bm_rows(0, t), NOP>(v[0], v[S - 1], Lr[q][0], Lr[q][S - 1]);
-                        else rw_step1<t - 16, rw_bm_rows(1, t), NOP>(v[S - 1], Lr[q][S - 1]);
+                    if constexpr (t + 1 < CAPP) {                 // rows above the source's slot entirely, then its own slot
+                        constexpr int st = t >> 4;
+                        rw_step<t, rw_bm_rows(st, t), NOP, S - 1 - st, st + 1>(v, Lr[q]);
                     }
                 });
                 RW_BLOCK();
@@ -461,10 +478,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 rw_static_for<0, CHS>([&](auto Q) {
                     constexpr int q = decltype(Q)::value, t = thi - q;
                     constexpr int NOP = 1;
-                    if constexpr (t >= 1) {
-                        if constexpr (S == 1) rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
-                        else if constexpr (t >= 16) rw_step2<t - 16, rw_bm_cols(1, t), NOP>(v[S - 1], v[0], Lc[q][S - 1], Lc[q][0]);
-                        else rw_step1<t, rw_bm_cols(0, t), NOP>(v[0], Lc[q][0]);
+                    if constexpr (t >= 1) {                       // columns below the source's slot entirely, then its own slot
+                        constexpr int st = t >> 4;
+                        rw_step<t, rw_bm_cols(st, t), NOP, st, 0>(v, Lc[q]);
                     }
                 });
                 RW_BLOCK();
