@@ -1309,6 +1309,7 @@ int lmpc_release_scratch(lmpc_handle *h) {
     rel(h->ccObsScratch); h->ccObsCap = 0;
     rel(h->dOvfList); h->ovfCap = 0; rel(h->dOvfList1); h->ovfCap1 = 0; rel(h->dBigR); rel(h->dBigI);
     rel(h->dBnbR); rel(h->dBnbI); h->bnbBytesR = h->bnbBytesI = 0;
+    rel(h->dRowBnb); h->rowBnbBytes = 0;
     rel(h->dKeepR); rel(h->dKeepI); h->keepCap = 0;
     avi_release(h, false);
     return check_fast_err(h);
@@ -1333,6 +1334,7 @@ void lmpc_free(lmpc_handle *h) {
     hipFree(h->dC); hipFree(h->sTheta); hipFree(h->sX); hipFree(h->sFlag); hipFree(h->sIter);
     hipFree(h->sAct); hipFree(h->sWarm); hipFree(h->dList); hipFree(h->dList2); hipFree(h->dList3); hipFree(h->dCount); hipFree(h->dCw); hipFree(h->dCwf); hipFree(h->dSw); hipFree(h->dQueue);
     hipFree(h->dOvfList); hipFree(h->dOvfCount); hipFree(h->dBigR); hipFree(h->dBigI); hipFree(h->dRegTable); hipFree(h->dRegW1); hipFree(h->dQpScan); hipFree(h->dFastCtr);
+    hipFree(h->dRowBnb);
     hipFree(h->dBnbR); hipFree(h->dBnbI); hipFree(h->dKeepR); hipFree(h->dKeepI); hipFree(h->dOvfList1);
     if (h->hStat) hipHostFree(const_cast<unsigned long long *>(h->hStat));
     if (h->hRegOut) hipHostFree(h->hRegOut);

@@ -99,6 +99,8 @@ struct lmpc_handle {
     void *dBnbR = nullptr;
     int32_t *dBnbI = nullptr;
     size_t bnbBytesR = 0, bnbBytesI = 0;
+    void *dRowBnb = nullptr;    // ... of the row kernel's searches (lmpc_row_inst.hip)
+    size_t rowBnbBytes = 0;
     // closed loop on the wavefront path: per-scenario working set + factor kept between two steps ("sim_keep_factor")
     void *dKeepR = nullptr;
     int32_t *dKeepI = nullptr;
@@ -296,6 +298,13 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
                uint64_t *active, hipStream_t st, int cap, int pass);
 extern template int launch_row<double>(lmpc_handle *, const double *, int64_t, const double *, double *, int32_t *, int32_t *,
                                        uint64_t *, hipStream_t, int, int);
+// ... with branch and bound (binary32)
+int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs);
+template <typename R>
+int launch_row_bnb(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag, int32_t *iters,
+                   uint64_t *active, hipStream_t st, int cap, int pass);
+extern template int launch_row_bnb<float>(lmpc_handle *, const float *, int64_t, const float *, float *, int32_t *, int32_t *,
+                                          uint64_t *, hipStream_t, int, int);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

@@ -21,25 +21,34 @@ constexpr RowShape kRowShapes[] = {
     {2, 4, 10, 32},     // ... <= 32 rows
 };
 
+// ... with branch and bound (rows flagged BINARY; binary32)
+constexpr RowShape kRowShapesBnb[] = {
+    {1, 1, 2, 16},      // n <= 16, m <= 32, <= 16 rows (the satellite example at Np = 4: n = m = 12)
+    {3, 4, 4, 48},      // n <= 64, m <= 64, <= 48 rows (BASELINE config 5, satellite Np = 20: n = m = 60, 40 binaries -- first of two passes)
+};
+
 bool shape_covers(const RowShape &sh, int n, int m, int cap) {
     return n <= 16 * sh.NS && m <= 16 * sh.MS && cap <= sh.CAPP && m <= 256 /* mask words on 16 lanes */;
 }
 
 struct RowLaunch { int shape, nwv, blocks, ps; size_t lds; };
 
-bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
+bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bool bnb = false) {
     const int n = h->P.n, m = h->P.m;
-    for (int q = 0; q < (int)(sizeof(kRowShapes) / sizeof(kRowShapes[0])); q++) {
-        const RowShape &sh = kRowShapes[q];
+    const RowShape *shapes = bnb ? kRowShapesBnb : kRowShapes;
+    const int nshapes = bnb ? (int)(sizeof(kRowShapesBnb) / sizeof(kRowShapesBnb[0])) : (int)(sizeof(kRowShapes) / sizeof(kRowShapes[0]));
+    for (int q = 0; q < nshapes; q++) {
+        const RowShape &sh = shapes[q];
         if (!shape_covers(sh, n, m, cap)) continue;
         // most wavefronts per CU (each carries four problems; two per SIMD is what the registers allow); the staged M' is
         // shared by a workgroup's wavefronts
         RowLaunch best{-1, 0, 0, 0, 0};
         int bestWaves = 0;
-        const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS);
+        const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS, (int)rs);
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
             if (64 * nwv > row_launch_bound(sh.MS)) continue;
-            const int ps = row_ps(sh.CAPP, nwv);
+            const int ps = bnb ? row_ps4(sh.CAPP, nwv) : row_ps(sh.CAPP, nwv);
+            if (ps < 0) continue;
             const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
@@ -56,10 +65,10 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out) {
     return false;
 }
 
-template <typename R, int S, int NS, int MS, int CAPP>
+template <typename R, int S, int NS, int MS, int CAPP, bool BNB = false>
 int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag,
                      int32_t *iters, uint64_t *active, hipStream_t st, int cap, int pass) {
-    auto kern = row_kernel<R, S, NS, MS, CAPP>;
+    auto kern = row_kernel<R, S, NS, MS, CAPP, BNB>;
     if (rl.lds > 48 * 1024)
         HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rl.lds));
     if (h->preloadOnly) {
@@ -74,6 +83,31 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
     long long grid = (long long)h->numCU * blocks;
     const long long need = (nprob + 4 * rl.nwv - 1) / (4 * rl.nwv);
     if (grid > need) grid = need;
+    R *bnbR = nullptr;
+    int32_t *bnbI = nullptr;
+    const int bdepth = h->nBinary > 0 ? h->nBinary : 1;
+    if constexpr (BNB) {
+        // one snapshot slot per search depth and problem row of the grid, at most half of what the device has free (a
+        // smaller grid before an allocation that crowds out the caller: launch_wave_cfg's rule)
+        const size_t perRow = (size_t)bdepth * (sizeof(R) * (size_t)row_snap_reals(S, CAPP) + sizeof(int32_t) * (size_t)row_snap_ints(S));
+        auto bytes = [&](long long gr) { return perRow * (size_t)gr * (size_t)rl.nwv * 4; };
+        if (bytes(grid) > h->rowBnbBytes) {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { freeB = 0; (void)hipGetLastError(); }
+            const size_t budget = (freeB + h->rowBnbBytes) / 2;
+            while (grid > 1 && bytes(grid) > budget) grid = (grid + 1) / 2;
+            if (bytes(grid) > budget)
+                return fail(h, LMPC_ERR_HIP, "lmpc: not enough free device memory for the branch-and-bound snapshots");
+            if (bytes(grid) > h->rowBnbBytes) {
+                hipFree(h->dRowBnb); h->dRowBnb = nullptr; h->rowBnbBytes = 0;
+                HIP_TRY(h, hipMalloc(&h->dRowBnb, bytes(grid)));
+                h->rowBnbBytes = bytes(grid);
+            }
+        }
+        const size_t nrowsB = (size_t)grid * rl.nwv * 4;
+        bnbR = static_cast<R *>(h->dRowBnb);
+        bnbI = reinterpret_cast<int32_t *>(static_cast<char *>(h->dRowBnb) + sizeof(R) * nrowsB * bdepth * (size_t)row_snap_reals(S, CAPP));
+    }
     // counters: the protocol of launch_wave_cfg (two alternating sets, each launch clears the next one's)
     constexpr int kP1 = kShards * kCountStride;
     if (!h->dQueue) {
@@ -102,7 +136,7 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
         HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
         h->ovfCap1 = nprob;
     }
-    if (!h->hStat) {
+    if (!BNB && !h->hStat) {
         unsigned long long *hp = nullptr;
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void **>(&hp), 64, hipHostMallocMapped));
         for (int q = 0; q < 8; q++) hp[q] = 0ull;
@@ -118,7 +152,8 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
     prm.list = wl.list; prm.count = wl.count; prm.count_next = wl.count_next; prm.seg_cap = wl.seg_cap;
     prm.ovf_list = pass == 1 ? h->dOvfList1 : nullptr; prm.ovf_count = pass == 1 ? p1Count : nullptr;
     prm.queue_next = queueNext; prm.ovf_next = p2Next; prm.ovf_next1 = p1Next;
-    prm.stat = h->dStat; prm.stat_host = h->dStatHost;
+    prm.stat = BNB ? nullptr : h->dStat; prm.stat_host = BNB ? nullptr : h->dStatHost;
+    prm.bnb_r = bnbR; prm.bnb_i = bnbI; prm.bnb_depth = bdepth;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * rl.nwv), rl.lds, st, prm);
     h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());
@@ -157,6 +192,22 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     }
     return cap;
 }
+
+// ... for a handle with binary rows (binary32): the problem's own capacity if 16 rows hold it, else 48 rows as the first
+// of two passes when that leaves eight rows beyond the binaries (the wavefront kernel's rule, bnb_first_pass_cap)
+int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
+    if (h->rowKernel == 0 || !h->bnb || rs != 4 || h->avi || h->waveGram != 0) return 0;
+    if (h->waveSim.FG != nullptr || h->keepOn || nprob >= (int64_t)0x3fffffff) return 0;
+    if (h->rowKernel < 0 && nprob < 8192) return 0;
+    for (int j = 0; j < h->P.m; j++)
+        if (h->P.sense[j] & SENSE_ACTIVE) return 0;
+    if (h->S.iter_limit < 2 || h->nBinary > 63) return 0;
+    const int full = h->W.cap;
+    RowLaunch rl;
+    if (full <= 16) return row_launch_for(h, full, rs, &rl, true) ? full : 0;
+    if (h->waveTwoPass == 0 || h->nBinary + 8 > 48 || full <= 52) return 0;
+    return row_launch_for(h, 48, rs, &rl, true) ? 48 : 0;
+}
 #endif
 
 template <typename R>
@@ -175,17 +226,30 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
 #undef LMPC_ROW
 }
 
+#ifdef LMPC_ROW_BNB
+template <typename R>
+int launch_row_bnb(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag, int32_t *iters,
+                   uint64_t *active, hipStream_t st, int cap, int pass) {
+    RowLaunch rl;
+    if (!row_launch_for(h, cap, sizeof(R), &rl, true)) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no row-kernel instantiation");
+    if (rl.shape == 0) return launch_row_shape<R, 1, 1, 2, 16, true>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass);
+    return launch_row_shape<R, 3, 4, 4, 48, true>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass);
+}
+template int launch_row_bnb<LMPC_ROW_REAL>(lmpc_handle *, const LMPC_ROW_REAL *, int64_t, const LMPC_ROW_REAL *, LMPC_ROW_REAL *, int32_t *,
+                                           int32_t *, uint64_t *, hipStream_t, int, int);
+#else
 template int launch_row<LMPC_ROW_REAL>(lmpc_handle *, const LMPC_ROW_REAL *, int64_t, const LMPC_ROW_REAL *, LMPC_ROW_REAL *, int32_t *,
                                        int32_t *, uint64_t *, hipStream_t, int, int);
+#endif
 
 }  // namespace lmpc
 
-#if defined(LMPC_ROW_TRACE) && defined(LMPC_ROW_HELPERS)
+#if defined(LMPC_ROW_TRACE) && (defined(LMPC_ROW_HELPERS) || defined(LMPC_ROW_BNB))
 // diagnostic build only: per-phase shader-clock sums of the row kernel (see lmpc_row_kernel.hpp)
-extern "C" int lmpc_debug_row_trace(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(lmpc::g_row_trace), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+extern "C" int lmpc_debug_row_trace(unsigned long long *out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(lmpc::g_row_trace), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(lmpc::g_row_trace), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

@@ -51,15 +51,19 @@ namespace lmpc {
 // Diagnostic build (-DLMPC_ROW_TRACE, tools/row_trace.py): shader-clock stamps at the phase boundaries of a trip, summed
 // per phase over all wavefronts into g_row_trace (read back by lmpc_debug_row_trace).  Shares, not absolutes.
 #ifdef LMPC_ROW_TRACE
-__device__ unsigned long long g_row_trace[16];
-#define RWT_DECL long long rwt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long rwt_prev = (long long)clock64()
+__device__ unsigned long long g_row_trace[32];
+#define RWT_DECL long long rwt_acc[32] = {0}; long long rwt_prev = (long long)clock64()
 #define RWT(k) do { const long long t__ = (long long)clock64(); rwt_acc[k] += t__ - rwt_prev; rwt_prev = t__; } while (0)
 #define RWT_COUNT(k, n) do { rwt_acc[k] += (n); } while (0)
-#define RWT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 16; q__++) atomicAdd(&g_row_trace[q__], (unsigned long long)rwt_acc[q__]); } } while (0)
+#define RWS_BEGIN const long long rws_t0__ = (long long)clock64()
+#define RWS_END(k) do { rwt_acc[k] += (long long)clock64() - rws_t0__; } while (0)
+#define RWT_FLUSH do { if (lane == 0) { for (int q__ = 0; q__ < 32; q__++) atomicAdd(&g_row_trace[q__], (unsigned long long)rwt_acc[q__]); } } while (0)
 #else
 #define RWT_DECL do { } while (0)
 #define RWT(k) do { } while (0)
 #define RWT_COUNT(k, n) do { } while (0)
+#define RWS_BEGIN do { } while (0)
+#define RWS_END(k) do { } while (0)
 #define RWT_FLUSH do { } while (0)
 #endif
 
@@ -143,13 +147,20 @@ constexpr int kRowBig = 0x7fffffff;
 // so that the 16 columns of a slot of positions start at 16 different offsets modulo 16: a lane that reads its own
 // COLUMN (backward sweep, row append, compaction) then never shares an LDS bank with another lane of its 32-lane phase.
 // In column order the starts collide four ways (8 LDS cycles an access instead of 2: rocprofv3 counted more bank-conflict
-// cycles than LDS instructions).  For 32 and 16 rows every column length is a multiple of four and no order helps.
+// cycles than LDS instructions).  For 32 and 16 rows every column length is a multiple of four and no order helps; the
+// 48-row layout (binary32 branch and bound: 54 000 conflict cycles per search in column order) therefore pads every
+// column by one entry and orders them likewise (tools/row_layout.py 48).
 __host__ __device__ constexpr int rowp_p0(int t) { return t & ~3; }
 __host__ __device__ constexpr int rowp_cb(int capp, int t) { return 4 * (t >> 2) * capp - 8 * (t >> 2) * ((t >> 2) - 1) + (t & 3) * (capp - 4 * (t >> 2)); }
-__host__ __device__ constexpr int rowp_size(int capp) { return rowp_cb(capp, capp - 1); }      // columns 0 .. capp-2
+// (48 rows: every column one entry longer than its rows need -- odd lengths, without which no order separates the starts)
+__host__ __device__ constexpr int rowp_size(int capp) { return capp == 48 ? 1291 : rowp_cb(capp, capp - 1); }      // columns 0 .. capp-2
 __host__ __device__ constexpr int rowp_cbm(int capp, int t) {
     constexpr int k31[30] = {379, 152, 183, 0, 237, 485, 458, 210, 318, 431, 102, 260, 121, 19, 348, 49,
                              507, 79, 275, 64, 329, 390, 401, 30, 282, 292, 408, 492, 295, 285};
+    constexpr int k48[47] = {807, 0, 898, 687, 117, 264, 1001, 758, 605, 1164, 430, 1242, 356, 219, 467, 1201,
+                             638, 956, 389, 1063, 314, 543, 1030, 34, 160, 849, 923, 1123, 72, 505, 285, 564,
+                             177, 824, 51, 484, 713, 1085, 700, 1098, 135, 126, 514, 1072, 182, 319, 5};
+    if (capp == 48) return k48[t < 46 ? t : 46];
     return capp == 31 ? k31[t < 30 ? t : 29] : rowp_cb(capp, t) - rowp_p0(t);
 }
 // reals between the factors of two problems, for nwv wavefronts per workgroup: the two DPP rows a 32-lane LDS phase
@@ -159,9 +170,17 @@ __host__ __device__ constexpr int row_ps(int capp, int nwv) {
     while ((nwv * ps) % 32 != 16) ps++;
     return ps;
 }
+// ... and a multiple of four on top (branch and bound copies factors as 16-byte vectors); -1: no such spacing for this nwv
+__host__ __device__ constexpr int row_ps4(int capp, int nwv) {
+    int ps = (rowp_size(capp) + 3) & ~3;
+    for (int q = 0; q < 16; q++, ps += 4)
+        if ((nwv * ps) % 32 == 16) return ps;
+    return -1;
+}
 // reals per row of the staged M' (even, half of it odd): row k holds, for lane i = 0 .. 15, the MS entries M'(k, i + 16 r)
 // side by side
-__host__ __device__ constexpr int row_mpad(int ms) { return 16 * ms + 2; }
+// (binary32 with constraint slots in fours: a multiple of four, so that a lane's four entries are one 16-byte load)
+__host__ __device__ constexpr int row_mpad(int ms, int rs = 8) { return 16 * ms + ((rs == 4 && ms % 4 == 0) ? 4 : 2); }
 // Everything a launch passes, in ONE block: the kernel copies the few scalars its iterations need into registers and
 // reads the rest -- the pointers of the outputs, the work list, the counters -- from the kernel-argument segment where
 // it uses them (a row takes or ends a problem once in ~8 trips), through a pointer the compiler cannot see through.
@@ -175,7 +194,12 @@ template <typename R> struct RowParams {
     const int32_t *list, *count; int32_t *count_next; long long seg_cap;
     int32_t *ovf_list, *ovf_count, *queue_next, *ovf_next, *ovf_next1;
     unsigned long long *stat; volatile unsigned long long *stat_host;
+    R *bnb_r; int32_t *bnb_i; int bnb_depth;      // branch and bound: snapshot slots (row_snap_reals / row_snap_ints each), depths per row
 };
+// what one (lazy) snapshot of a branch-and-bound node takes, per problem row of the grid and search depth: reals = right-hand
+// side, D, 1/D, y per position and the padded triangle as it lies in LDS; ints = the positions' rows, one size
+__host__ __device__ constexpr int row_snap_reals(int s, int capp) { return 64 * s + ((rowp_size(capp) + 3) & ~3); }
+__host__ __device__ constexpr int row_snap_ints(int s) { return 16 * s + 16; }
 
 // threads per workgroup an instantiation is built for: 512 (two wavefronts per SIMD, 256 registers) up to six constraint
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
@@ -254,7 +278,9 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 
 // R: arithmetic type.  S / NS / MS: register slots of 16 working-set positions / variables / constraints.  CAPP: rows the
 // factor is laid out for (the launch's capacity P.cap <= CAPP <= 16 S).
-template <typename R, int S, int NS, int MS, int CAPP>
+// BNB: rows flagged BINARY end up active at one of their bounds -- the wavefront kernel's depth-first search (its header),
+// one search per row of the wavefront, every row at its own node.
+template <typename R, int S, int NS, int MS, int CAPP, bool BNB = false>
 __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS)))) void row_kernel(const RowParams<R> prm) {
     static_assert(S >= 1 && S <= 4, "one to four slots of working-set positions");
     static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
@@ -297,7 +323,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
     // of the scan is one per-lane base register plus an immediate (with a run-time stride the compiler keeps one
     // address register per (k, slot) alive across the whole kernel: 64 to 320 registers).
     static_assert(MS % 2 == 0, "constraint slots in pairs (16-byte loads)");
-    constexpr int MPAD = row_mpad(MS);
+    constexpr int MPAD = row_mpad(MS, (int)sizeof(R));
     const int nP = (n + 3) & ~3;
     const int oZ = 0, oMt = 32, oL = oMt + nP * MPAD;
     int32_t *sens = reinterpret_cast<int32_t *>(lds + oL + nwv * 4 * PS + 2);
@@ -338,6 +364,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         bo[s] = pos[s] < CAPP - 1 ? Lg + cbm(pos[s] < CAPP - 1 ? pos[s] : 0) : oZ;   // (beyond the last column: the block of zeros)
     }
     int jc[MS], mcol[NS];
+    unsigned binb = 0u;                // bit r: this lane's row of slot r is BINARY
     unsigned okb = 0u, hardb = 0u;     // bit r: this lane's row of slot r can enter a working set / ... and is a hard row
 #pragma unroll
     for (int r = 0; r < MS; r++) {
@@ -345,6 +372,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         jc[r] = j < m ? j : m - 1;
         const int sj = sens[jc[r]];
         if (j < m && !(sj & SENSE_IMMUTABLE)) { okb |= 1u << r; if (!(sj & SENSE_SOFT)) hardb |= 1u << r; }
+        if (BNB && j < m && (sj & SENSE_BINARY)) binb |= 1u << r;
     }
 #pragma unroll
     for (int s = 0; s < NS; s++) mcol[s] = oMt + (li + 16 * s < n ? li + 16 * s : n - 1) * MPAD;   // this lane's variables: their rows of M'
@@ -490,6 +518,169 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
     };
 
     RWT_DECL;
+    // ---- branch and bound (BNB): the search state of this row's problem, all of it in registers.  The stack entry of
+    // depth d sits on lane d % 16, slot d / 16: row branched on (bits 0-9), side being tried (10), the node's working-set
+    // size (13-19) and its count of soft rows (20-26); next to it the node's objective (stkf) and, in every lane, one byte
+    // per depth with the activity bits of the lane's rows at that node (abyte).  What an append changes about a node is
+    // thereby kept without memory traffic: its second child starts by cutting the working set back (and takes the
+    // node's multipliers from the next trip's backward sweep, which runs anyway).  The positions' registers and the
+    // factor go to global scratch only before the first removal that would disturb them (snap_clean / snap_saved, one
+    // bit per depth: the wavefront kernel's lazy snapshots); `tried2`: both sides of that depth's row have been tried.
+    static_assert(!BNB || MS <= 4, "a byte per depth holds the activity bits of up to four rows per lane");
+    constexpr int DS = BNB ? MS : 1;                             // (a search is at most m <= 16 MS levels deep)
+    int forced = -1, depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE, jbX = kRowBig, sideX = 0, rls = 0;
+    R bestval = fbound, ubest[NS], stkf[DS];
+    unsigned bestact = 0u, bestlow = 0u, abyte[4 * DS];
+    int stk[DS], fixd[MS];                                       // fixd[r]: the depth that fixed this lane's row of slot r (255: none)
+    unsigned long long snap_clean = 0ull, snap_saved = 0ull, tried2 = 0ull;
+#pragma unroll
+    for (int s = 0; s < NS; s++) ubest[s] = (R)0;
+#pragma unroll
+    for (int q = 0; q < DS; q++) { stk[q] = 0; stkf[q] = (R)0; }
+#pragma unroll
+    for (int q = 0; q < 4 * DS; q++) abyte[q] = 0u;
+#pragma unroll
+    for (int r = 0; r < MS; r++) fixd[r] = 255;
+    constexpr int kSnapR = row_snap_reals(S, CAPP), kSnapI = row_snap_ints(S);
+    auto stk_get = [&](int d) -> int {
+        int sel = stk[0];
+#pragma unroll
+        for (int q = 1; q < DS; q++) sel = (d >> 4) == q ? stk[q] : sel;
+        return rw_pick(sel, d & 15, rowbase);
+    };
+    auto stkf_get = [&](int d) -> R {
+        R sel = stkf[0];
+#pragma unroll
+        for (int q = 1; q < DS; q++) sel = (d >> 4) == q ? stkf[q] : sel;
+        return rw_pick(sel, d & 15, rowbase);
+    };
+    auto stk_set = [&](int d, int e, R f, bool pred) {
+#pragma unroll
+        for (int q = 0; q < DS; q++) {
+            const bool h = pred && (d >> 4) == q && li == (d & 15);
+            stk[q] = h ? e : stk[q]; stkf[q] = h ? f : stkf[q];
+        }
+    };
+    auto abyte_get = [&](int d) -> unsigned {
+        unsigned sel = abyte[0];
+#pragma unroll
+        for (int q = 1; q < 4 * DS; q++) sel = (d >> 2) == q ? abyte[q] : sel;
+        return (sel >> (8 * (d & 3))) & 0xffu;
+    };
+    auto abyte_set = [&](int d, unsigned v, bool pred) {
+        const int sh = 8 * (d & 3);
+#pragma unroll
+        for (int q = 0; q < 4 * DS; q++) abyte[q] = (pred && (d >> 2) == q) ? ((abyte[q] & ~(0xffu << sh)) | (v << sh)) : abyte[q];
+    };
+    auto snap_r = [&](int d) -> R * {
+        const RowParams<R> *a = RW_ARGS();
+        return a->bnb_r + ((long long)myrow * a->bnb_depth + d) * (long long)kSnapR;
+    };
+    auto snap_i = [&](int d) -> int32_t * {
+        const RowParams<R> *a = RW_ARGS();
+        return a->bnb_i + ((long long)myrow * a->bnb_depth + d) * (long long)kSnapI;
+    };
+    // the factor of this row's problem as 16-byte vectors (lane li moves vectors li, li + 16, ...): the whole padded
+    // triangle, whatever the node's size -- a copy of ~20 instructions a lane where a row-by-row one takes 120
+    constexpr int VW = 16 / (int)sizeof(R), FLV = (rowp_size(CAPP) + VW - 1) / VW, FLK = (FLV + 15) / 16, FLB = 10;
+    typedef R rw_vec __attribute__((ext_vector_type(VW)));
+    // the registers of the positions below nd and the factor as it stands -> slot d, for the rows with `sv`
+    auto save_tri = [&](bool sv, int d, int nd) {
+        R *sr = snap_r(d);
+        int32_t *si = snap_i(d);
+        if (sv) {
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const bool in = pos[s] < nd;
+                sr[16 * s + li] = in ? rhs[s] : (R)0; sr[16 * S + 16 * s + li] = in ? D[s] : (R)0;
+                sr[32 * S + 16 * s + li] = in ? Dinv[s] : (R)0; sr[48 * S + 16 * s + li] = in ? y[s] : (R)0;
+                si[16 * s + li] = in ? ws[s] : 0;
+            }
+            if (li == 0) si[16 * S] = na;                        // (rows nd .. na-1 of the copy belong to deeper nodes)
+        }
+        const rw_vec *lsrc = reinterpret_cast<const rw_vec *>(lds + Lg);
+        rw_vec *gdst = reinterpret_cast<rw_vec *>(sr + 64 * S);
+        for (int k0 = 0; k0 < FLK; k0 += FLB) {
+            rw_vec tv[FLB];
+#pragma unroll
+            for (int q = 0; q < FLB; q++) {
+                const int v = li + 16 * (k0 + q);
+                tv[q] = lsrc[v < FLV ? v : FLV - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < FLB; q++) {
+                const int v = li + 16 * (k0 + q);
+                if (sv && v < FLV) gdst[v] = tv[q];
+            }
+        }
+    };
+    // back to the optimal state of the node at depth d, entry e (rows with `rs`): its second child continues from there
+    auto restore = [&](bool rs, int d, int e) {
+        const R *sr = snap_r(d);
+        const int32_t *si = snap_i(d);
+        const int naold = na;
+        const bool clean = rs && ((snap_clean >> d) & 1ull) != 0ull;
+        const bool dirty = rs && !clean;
+        RWT_COUNT(17, rw_any(clean) ? 1 : 0);
+        RWT_COUNT(18, rw_any(dirty) ? 1 : 0);
+        {
+            const unsigned ab = abyte_get(d);
+            const R fv = stkf_get(d);
+            actb = rs ? (ab & 15u) : actb; lowb = rs ? (ab >> 4) : lowb;
+            fval = rs ? fv : fval; na = rs ? ((e >> 13) & 127) : na; nsoft = rs ? ((e >> 20) & 127) : nsoft;
+            rls = rs ? 1 : rls;                                  // (the node's multipliers: the next trip's backward sweep)
+        }
+        int nahi = naold;                                        // rows of the factor in LDS that lie behind the node's
+        if (rw_any(dirty)) {
+            int nsv = 0;
+            if (dirty) {
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    rhs[s] = sr[16 * s + li]; D[s] = sr[16 * S + 16 * s + li]; Dinv[s] = sr[32 * S + 16 * s + li];
+                    y[s] = sr[48 * S + 16 * s + li]; ws[s] = si[16 * s + li];
+                }
+                nsv = si[16 * S];
+            }
+            rw_vec *ldst = reinterpret_cast<rw_vec *>(lds + Lg);
+            const rw_vec *gsrc = reinterpret_cast<const rw_vec *>(sr + 64 * S);
+            for (int k0 = 0; k0 < FLK; k0 += FLB) {
+                rw_vec tv[FLB];
+#pragma unroll
+                for (int q = 0; q < FLB; q++) {
+                    const int v = li + 16 * (k0 + q);
+                    if (dirty && v < FLV) tv[q] = gsrc[v];
+                }
+#pragma unroll
+                for (int q = 0; q < FLB; q++) {
+                    const int v = li + 16 * (k0 + q);
+                    if (dirty && v < FLV) ldst[v] = tv[q];
+                }
+            }
+            nahi = dirty ? nsv : nahi;
+        }
+        {
+            // the node's factor and positions are the leading part of what is here: cut what lies behind them
+            const int a0 = na > 1 ? na : 1;
+            const int lo = rw_min4(rs ? a0 : kRowBig), hi = rw_max4(rs ? nahi : 0);
+            for (int i = lo; i < hi; i++) {
+#pragma unroll
+                for (int s = 0; s < S; s++)
+                    if (rs && i >= a0 && i < nahi && pos[s] < i) lds[bo[s] + i] = (R)0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const bool cut = clean && pos[s] >= na;
+            ws[s] = cut ? 0 : ws[s]; rhs[s] = cut ? (R)0 : rhs[s]; D[s] = cut ? (R)0 : D[s]; Dinv[s] = cut ? (R)0 : Dinv[s];
+            y[s] = cut ? (R)0 : y[s];
+        }
+        // (a node is restored once, for its second child: from here on nobody needs slot d's factor)
+        snap_clean = rs ? (snap_clean & ~(1ull << d)) : snap_clean;
+#pragma unroll
+        for (int s = 0; s < S; s++) { lam[s] = rs ? (R)0 : lam[s]; ls[s] = rs ? (R)0 : ls[s]; }
+        sing = rs ? -1 : sing; ydirty = rs ? 0 : ydirty;
+    };
+
     for (;;) {
         RWT(15);
         // (what the loop does not change, made opaque once per trip: otherwise every comparison against it is formed in
@@ -590,6 +781,17 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                     }
 #pragma unroll
                     for (int s = 0; s < NS; s++) u[s] = got ? (R)0 : u[s];
+                    if constexpr (BNB) {                         // the search starts at the root: nothing fixed, nothing found
+                        forced = got ? -1 : forced; depth = got ? 0 : depth; nodes = got ? 0 : nodes;
+                        total_it = got ? 0 : total_it; have = got ? 0 : have; bflag = got ? EXIT_INFEASIBLE : bflag;
+                        bestval = got ? fbound : bestval; bestact = got ? 0u : bestact; bestlow = got ? 0u : bestlow;
+                        snap_clean = got ? 0ull : snap_clean; snap_saved = got ? 0ull : snap_saved; tried2 = got ? 0ull : tried2;
+                        rls = got ? 0 : rls;
+#pragma unroll
+                        for (int s = 0; s < NS; s++) ubest[s] = got ? (R)0 : ubest[s];
+#pragma unroll
+                        for (int r = 0; r < MS; r++) fixd[r] = got ? 255 : fixd[r];
+                    }
                 }
             }
             if (!rw_any(live != 0)) break;                       // every row of the wavefront has run out of problems
@@ -603,9 +805,22 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             flag = lim ? EXIT_ITERLIMIT : 0;
             fin = lim ? 1 : 0;
         }
-        const int run = (live != 0 && !fin) ? 1 : 0;
+        // (branch and bound) a node that continues in place starts by taking the row just fixed into the working set: no
+        // stationary point, no scan in that trip
+        int addF = 0;
+        unsigned fixb = 0u;                                      // bit r: this lane's row of slot r is fixed on the path to this node
+        if constexpr (BNB) {
+            const bool frc = live != 0 && !fin && forced >= 0;
+            const bool fullF = frc && na >= cap;
+            flag = fullF ? EXIT_WSCAP : flag; fin = fullF ? 1 : fin;
+            addF = (frc && !fullF) ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < MS; r++) fixb |= fixd[r] < depth ? (1u << r) : 0u;
+        }
+        const int run = (live != 0 && !fin && !addF) ? 1 : 0;
         const int sgl = sing >= 0 ? 1 : 0;
-        const int namax = rw_max4(run ? na : 0);
+        const int stat = (run || (BNB && rls)) ? 1 : 0;          // rows that take part in the backward sweep
+        const int namax = rw_max4(stat ? na : 0);
 
         // =============================================================== stationary point / singular direction
         {
@@ -621,7 +836,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             }
             R v[S];
 #pragma unroll
-            for (int s = 0; s < S; s++) v[s] = run ? y[s] * Dinv[s] : (R)0;
+            for (int s = 0; s < S; s++) v[s] = stat ? y[s] * Dinv[s] : (R)0;
             int lowsg = 0;
             if (rw_any(run && sgl)) {
                 const int sgc = sgl ? sing : 1;
@@ -642,8 +857,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 const R asg = lowsg ? -a1 : a1;
                 const R ans = pos[s] < na ? v[s] : (R)0;
                 const R acc = sgl ? asg : ans;
-                ls[s] = run ? acc : ls[s];
+                ls[s] = stat ? acc : ls[s];
             }
+            rls = 0;
         }
 
         RWT(1);
@@ -695,10 +911,30 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         const int doAdd = (run && !sgl && rm < 0) ? 1 : 0;
 
         // =============================================================== no blocking multiplier: primal iterate, scan, append
-        int addpX = 0, jaddX = 0, lowerX = 0;                    // (the append's two halves: see below)
+        int addpX = 0, jaddX = 0, lowerX = 0, mtX = 0;           // (the append's two halves: see below)
         R qX[S], gjjX = (R)0, rjX = (R)0, fvalX = (R)0;
 #pragma unroll
         for (int s = 0; s < S; s++) qX[s] = (R)0;
+        auto gather = [&]() {
+            if (rw_any(addpX != 0)) {
+                const bool ap = addpX != 0;
+                jaddX = ap ? (mtX >> 1) : 0;
+                lowerX = (ap && (mtX & 1)) ? 1 : 0;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    const bool in = ap && pos[s] < na;
+                    const int a = in ? (ws[s] & 0xffff) : jaddX;
+                    const int hi = a >= jaddX ? a : jaddX, lo = a >= jaddX ? jaddX : a;
+                    qX[s] = ldc(oG, hi * (hi + 1) / 2 + lo);
+                }
+                gjjX = ldc(oG, jaddX * (jaddX + 1) / 2 + jaddX);
+                // the bound of row jadd that enters: from the lane and slot that own the row
+                R bsel = lowerX ? dlb[0] : dub[0];
+#pragma unroll
+                for (int r = 1; r < MS; r++) bsel = (jaddX >> 4) == r ? (lowerX ? dlb[r] : dub[r]) : bsel;
+                rjX = -rw_pick(bsel, jaddX & 15, rowbase);
+            }
+        };
         if (rw_any(doAdd != 0)) {
             const int namaxA = rw_max4(doAdd ? na : 0);
             R un[NS];
@@ -772,15 +1008,17 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             constexpr int CHK = LMPC_ROW_CHK6, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
-                typedef R rw_pair __attribute__((ext_vector_type(2)));
+                constexpr int PW = (sizeof(R) == 4 && MS % 4 == 0) ? 4 : 2;      // entries per load (16 bytes where they line up)
+                typedef R rw_pair __attribute__((ext_vector_type(PW)));
                 auto fetch = [&](auto B) {
                     constexpr int k0 = decltype(B)::value * CHK;
 #pragma unroll
                     for (int q = 0; q < CHK; q++)                              // (rows beyond n, columns beyond m: zeros)
 #pragma unroll
-                        for (int r = 0; r < MS; r += 2) {
+                        for (int r = 0; r < MS; r += PW) {
                             const rw_pair pr = *reinterpret_cast<const rw_pair *>(&lds[mrow + (k0 + q) * MPAD + r]);
-                            mn[q][r] = pr.x; mn[q][r + 1] = pr.y;
+#pragma unroll
+                            for (int e = 0; e < PW; e++) mn[q][r + e] = pr[e];
                         }
                 };
                 fetch(std::integral_constant<int, 0>{});
@@ -818,7 +1056,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             }
             int addp = doAdd;
             {
-                const bool dom = addp && fvalN > fbound;
+                const bool dom = addp && fvalN > (BNB ? bestval : fbound);     // (the search prunes against its incumbent)
                 flag = dom ? EXIT_INFEASIBLE : flag; fin = dom ? 1 : fin; addp = dom ? 0 : addp;
             }
             // most violated row: smallest value below -primal_tol, ties to the lowest (row, side) index.  Per row the side is
@@ -829,7 +1067,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             for (int r = 0; r < MS; r++) {
                 const R vu = dub[r] - Mu[r];
                 const R vl = Mu[r] - dlb[r];                     // = -(dlower_j - M_j u), exactly
-                const bool fre = ((okb & ~actb) >> r) & 1u;
+                const bool fre = ((okb & ~actb & ~fixb) >> r) & 1u;
                 const R c = vu < ntol ? vu : vl;
                 cval[r] = fre ? c : kInf;
                 cm = wv_min2(cm, cval[r]);
@@ -850,7 +1088,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                     int broken = 0;
 #pragma unroll
                     for (int r = 0; r < MS; r++) {
-                        const bool hw = ((hardb & actb) >> r) & 1u;
+                        const bool hw = ((hardb & actb & ~fixb) >> r) & 1u;
                         const bool br = hw && ((dub[r] - Mu[r]) < ntol || (Mu[r] - dlb[r]) < ntol);
                         broken = br ? 1 : broken;
                     }
@@ -858,31 +1096,39 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 }
                 const int fl = anybr ? EXIT_CYCLE : (soft > primal_tol ? EXIT_SOFT_OPTIMAL : EXIT_OPTIMAL);
                 flag = opt ? fl : flag; fin = opt ? 1 : fin; addp = opt ? 0 : addp;
+                if constexpr (BNB) {
+                    if (rw_any(opt)) {
+                        // the node's relaxation is solved: the lowest binary row outside its working set is branched on, the
+                        // side first whose bound the row's value is closer to
+                        int cand = kRowBig;
+#pragma unroll
+                        for (int r = MS - 1; r >= 0; r--) cand = (((binb & ~actb) >> r) & 1u) ? li + 16 * r : cand;
+                        const int jb = rw_min(cand);
+                        const int jq = jb != kRowBig ? jb : 0;
+                        R msel = Mu[0], lsel = dlb[0], usel = dub[0];
+#pragma unroll
+                        for (int r = 1; r < MS; r++) {
+                            const bool h = (jq >> 4) == r;
+                            msel = h ? Mu[r] : msel; lsel = h ? dlb[r] : lsel; usel = h ? dub[r] : usel;
+                        }
+                        const R mj = rw_pick(msel, jq & 15, rowbase), dlo = rw_pick(lsel, jq & 15, rowbase),
+                                dup = rw_pick(usel, jq & 15, rowbase);
+                        jbX = opt ? jb : jbX;
+                        sideX = opt ? (((mj - dlo) < (dup - mj)) ? 1 : 0) : sideX;
+                    }
+                }
                 const bool full = addp && na >= cap;
                 flag = full ? EXIT_WSCAP : flag; fin = full ? 1 : fin; addp = full ? 0 : addp;
             }
             RWT(5);
             // ---- append row jadd to the working sets of the rows with addp, first half: the Gram entries G(W_i, jadd) are
             // requested here (L2: ~a microsecond), the factor is extended behind the removal phase of the other rows
-            addpX = addp; fvalX = fvalN;
-            if (rw_any(addp != 0)) {
-                const bool ap = addp != 0;
-                jaddX = ap ? (mt >> 1) : 0;
-                lowerX = (ap && (mt & 1)) ? 1 : 0;
-#pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const bool in = ap && pos[s] < na;
-                    const int a = in ? (ws[s] & 0xffff) : jaddX;
-                    const int hi = a >= jaddX ? a : jaddX, lo = a >= jaddX ? jaddX : a;
-                    qX[s] = ldc(oG, hi * (hi + 1) / 2 + lo);
-                }
-                gjjX = ldc(oG, jaddX * (jaddX + 1) / 2 + jaddX);
-                // the bound of row jadd that enters: from the lane and slot that own the row
-                R bsel = lowerX ? dlb[0] : dub[0];
-#pragma unroll
-                for (int r = 1; r < MS; r++) bsel = (jaddX >> 4) == r ? (lowerX ? dlb[r] : dub[r]) : bsel;
-                rjX = -rw_pick(bsel, jaddX & 15, rowbase);
-            }
+            addpX = addp; fvalX = fvalN; mtX = mt;
+            if constexpr (!BNB) gather();
+        }
+        if constexpr (BNB) {
+            addpX = addF ? 1 : addpX; fvalX = addF ? fval : fvalX; mtX = addF ? forced : mtX;
+            gather();
         }
         RWT(6);
         // =============================================================== a blocking multiplier: step, drop its row
@@ -896,6 +1142,29 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             }
             const int r = dr ? rm : 0;
             const int nao = na;
+            if constexpr (BNB) {
+                // nodes on the path whose factor is still the leading block of this one and reaches beyond row r: their
+                // positions and factors go to their slots before the row leaves
+                unsigned long long hit = 0ull;
+#pragma unroll
+                for (int q = 0; q < DS; q++) {
+                    const unsigned long long bal = __ballot(dr && li + 16 * q < depth && ((stk[q] >> 13) & 127) > r);
+                    hit |= ((bal >> (16 * g)) & 0xffffull) << (16 * q);
+                }
+                hit &= snap_clean;
+                unsigned long long todo = hit & ~snap_saved;
+                while (rw_any(todo != 0ull)) {
+                    RWS_BEGIN;
+                    RWT_COUNT(19, 1);
+                    const bool sv = todo != 0ull;
+                    const int d = sv ? (int)__builtin_ctzll(todo) : 0;
+                    todo = sv ? (todo & (todo - 1ull)) : todo;
+                    save_tri(sv, d, (stk_get(d) >> 13) & 127);
+                    RWS_END(21);
+                }
+                snap_saved |= hit;
+                snap_clean &= ~hit;
+            }
             R w[S];
 #pragma unroll
             for (int s = 0; s < S; s++) {
@@ -1058,7 +1327,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 });
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
-                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | ((sj & SENSE_IMMUTABLE) ? kRowPosFlagImm : 0) |
+                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | (((sj & SENSE_IMMUTABLE) || (BNB && addF)) ? kRowPosFlagImm : 0) |
                                 (lower ? kRowPosFlagLow : 0) | (((jadd & 15) * MS + (jadd >> 4)) << kRowPosOffShift);
 #pragma unroll
                 for (int s = 0; s < S; s++) {
@@ -1091,7 +1360,85 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         }
 
         RWT(8);
-        iter = (run && !fin) ? iter + 1 : iter;
+        iter = ((run && !fin) || addF) ? iter + 1 : iter;
+        if constexpr (BNB) {
+            forced = addF ? -1 : forced;
+            // =========================================================== rows whose NODE has ended: the search's next move
+            if (rw_any(fin != 0)) {
+                const bool fn = fin != 0;
+                nodes = fn ? nodes + 1 : nodes;
+                total_it = fn ? total_it + iter : total_it;
+                const bool wsc = fn && flag == EXIT_WSCAP;       // (the working set outgrew this pass: the whole search is listed)
+                const bool okn = fn && !wsc && flag >= 1;
+                const bool leaf = okn && jbX == kRowBig;         // every binary row sits on a bound
+                const bool better = leaf && (!have || fval < bestval);
+                have = better ? 1 : have; bestval = better ? fval : bestval;
+                bestact = better ? actb : bestact; bestlow = better ? lowb : bestlow;
+#pragma unroll
+                for (int s = 0; s < NS; s++) ubest[s] = better ? u[s] : ubest[s];
+                const bool desc = okn && jbX != kRowBig;
+                if (rw_any(desc)) {
+                    RWS_BEGIN;
+                    RWT_COUNT(16, 1);
+                    // branch: the entry, what an append changes (the rest lazily, see the removal phase), the first child
+                    // continues in place
+                    stk_set(depth, jbX | (sideX << 10) | (na << 13) | (nsoft << 20), fval, desc);
+                    abyte_set(depth, actb | (lowb << 4), desc);
+                    const unsigned long long bit = 1ull << depth;
+                    snap_clean = desc ? (snap_clean | bit) : snap_clean;
+                    snap_saved = desc ? (snap_saved & ~bit) : snap_saved;
+                    tried2 = desc ? (tried2 & ~bit) : tried2;
+#pragma unroll
+                    for (int r = 0; r < MS; r++) {
+                        const bool mine = desc && li + 16 * r == jbX;
+                        fixd[r] = mine ? depth : ((desc && fixd[r] == depth) ? 255 : fixd[r]);
+                    }
+                    forced = desc ? 2 * jbX + sideX : forced;
+                    depth = desc ? depth + 1 : depth;
+                    RWS_END(22);
+                }
+                const bool back = fn && !wsc && !desc;           // backtrack to the next untried side
+                bool flip = false;
+                if (rw_any(back)) {
+                    RWS_BEGIN;
+                    {
+                        // the deepest level whose row still has an untried side
+                        const unsigned long long open = ~tried2 & ((1ull << depth) - 1ull);
+                        const int dn = open != 0ull ? 64 - (int)__builtin_clzll(open) : 0;
+                        depth = back ? dn : depth;
+                    }
+                    flip = back && depth > 0;
+                    RWS_END(23);
+                    if (rw_any(flip)) {
+                        RWS_BEGIN;
+                        const int d = flip ? depth - 1 : 0;
+                        const int e = stk_get(d);
+                        const int ne = e ^ (1 << 10);
+#pragma unroll
+                        for (int q = 0; q < DS; q++) stk[q] = (flip && (d >> 4) == q && li == (d & 15)) ? ne : stk[q];
+                        tried2 = flip ? (tried2 | (1ull << d)) : tried2;
+                        restore(flip, d, e);                     // that node's optimal state: its second child, in place
+                        forced = flip ? 2 * (ne & 1023) + ((ne >> 10) & 1) : forced;
+                        RWS_END(20);
+                    }
+                }
+                const bool limn = (desc || flip) && nodes >= 100000;
+                bflag = wsc ? EXIT_WSCAP : (limn ? EXIT_ITERLIMIT : bflag);
+                have = wsc ? 0 : have;
+                const bool pfin = wsc || (back && !flip) || limn;
+                const bool cont = fn && !pfin;
+                iter = cont ? 1 : iter; cyc = cont ? 0 : cyc; best = cont ? (R)-1 : best;
+                fin = pfin ? 1 : 0;
+                // the problem's result: the best leaf
+#pragma unroll
+                for (int s = 0; s < NS; s++) u[s] = pfin ? (have ? ubest[s] : (R)0) : u[s];
+                actb = pfin ? (have ? bestact : 0u) : actb;
+                lowb = pfin ? (have ? bestlow : 0u) : lowb;
+                flag = pfin ? (have ? (bflag == EXIT_ITERLIMIT ? EXIT_ITERLIMIT : EXIT_OPTIMAL) : bflag) : flag;
+                iter = pfin ? total_it : iter;
+            }
+            RWT(14);
+        }
 
         // =============================================================== rows whose problem has ended: outputs, clean-up
         if (rw_any(fin != 0)) {

@@ -454,6 +454,10 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             const int rcap = row_pass_cap(h, (int64_t)1 << 20, sizeof(R), false, GRAM, BNB);
             if (rcap > 0) (void)launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
         }
+        if constexpr (BNB && !GRAM && sizeof(R) == 4) {
+            const int rcap = row_bnb_pass_cap(h, (int64_t)1 << 20, sizeof(R));
+            if (rcap > 0) (void)launch_row_bnb<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
+        }
         return dispatch();
     }
     // Four problems per wavefront (lmpc_row_kernel.hpp) where it applies: as the only pass when its capacity holds every
@@ -466,6 +470,27 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             } else {
                 h->wavePass = 1;
                 rc = launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 1);
+                h->wavePass = 2;
+                cfg = wave_config(h, sizeof(R));
+                if (rc == LMPC_OK) rc = dispatch();
+                h->wavePass = 0;
+            }
+            h->waveOvfSet ^= 1;
+            if (prof) {
+                if (rc == LMPC_OK) { HIP_TRY(h, hipEventRecord(ev.b, st)); h->events.push_back(ev); }
+                else { hipEventDestroy(ev.a); hipEventDestroy(ev.mid); hipEventDestroy(ev.b); }
+            }
+            return rc;
+        }
+    }
+    if constexpr (BNB && !GRAM && sizeof(R) == 4) {           // ... four searches per wavefront
+        const int rcap = row_bnb_pass_cap(h, nprob, sizeof(R));
+        if (rcap > 0) {
+            if (rcap >= capW) {
+                rc = launch_row_bnb<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
+            } else {
+                h->wavePass = 1;
+                rc = launch_row_bnb<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 1);
                 h->wavePass = 2;
                 cfg = wave_config(h, sizeof(R));
                 if (rc == LMPC_OK) rc = dispatch();

@@ -1,13 +1,13 @@
 #!/bin/bash
-# PMC counters of the row kernel (four problems per wavefront): tools/profile_row.sh <name> <N> [row_kernel option, default 1]
+# PMC counters of the row kernel (four problems per wavefront): tools/profile_row.sh <name> <N> [row_kernel option, default 1] [f32]
 # Two counter passes (kernel trace only beside them) over tools/row_pmc_run.py; summary on stdout.
 export TMPDIR=/tmp
-NAME=${1:-mass_spring_3in}; N=${2:-1000000}; RK=${3:-1}
+NAME=${1:-mass_spring_3in}; N=${2:-1000000}; RK=${3:-1}; F32=${4:-f64}
 OUT=gpurun_out/prof_row_$RK
 rm -rf $OUT; mkdir -p $OUT
 for PASS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   T=$(echo $PASS | tr ' ' '_' | cut -c1-30)
-  rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d $OUT/pmc_$T -- python3 tools/row_pmc_run.py $NAME $N $RK > $OUT/log_$T.txt 2>&1
+  rocprofv3 --pmc $PASS --kernel-trace --output-format csv -d $OUT/pmc_$T -- python3 tools/row_pmc_run.py $NAME $N $RK $F32 > $OUT/log_$T.txt 2>&1
 done
 python3 - "$OUT" "$N" <<'PY'
 import csv, glob, collections, sys

@@ -8,7 +8,8 @@ sys.setrecursionlimit(10000)
 def solve(capp, seed=0, tlimit=30):
     ncol = capp - 1
     p0 = lambda t: t & ~3
-    L = [capp - p0(t) for t in range(ncol)]
+    lrow = capp if capp % 2 else capp + 1                # (even row counts: columns padded by one entry, odd lengths)
+    L = [lrow - p0(t) for t in range(ncol)]
     rnd = random.Random(seed)
     used = [set() for _ in range((ncol + 15) // 16)]
     c, remaining, t0 = {}, set(range(ncol)), time.time()
@@ -43,7 +44,7 @@ if __name__ == "__main__":
     for seed in range(5):
         c = solve(capp, seed)
         if c:
-            print("rows", capp, "cbm =", [c[t] - (t & ~3) for t in range(capp - 1)])
+            print("rows", capp, "size", max(c[t] + (capp if capp % 2 else capp + 1) - (t & ~3) for t in c), "cbm =", [c[t] - (t & ~3) for t in range(capp - 1)])
             break
     else:
         print("rows", capp, ": no conflict-free order (all column lengths a multiple of four?)")

@@ -16,7 +16,7 @@ g = load_golden(name)
 qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], nout=int(g["nu"]) if "nu" in g else None)
 qp.set_option("row_kernel", 1)
 th = torch.from_numpy(bench.make_theta(name, N, 77)).cuda()
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 qp.solve_device(th); torch.cuda.synchronize()
 L.lmpc_debug_row_trace(out, 1)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
