@@ -40,6 +40,7 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bo
     for (int q = 0; q < nshapes; q++) {
         const RowShape &sh = shapes[q];
         if (!shape_covers(sh, n, m, cap)) continue;
+        if (bnb && h->nBinary > row_bnb_depth_max(sh.MS)) continue;
         // most wavefronts per CU (each carries four problems; two per SIMD is what the registers allow); the staged M' is
         // shared by a workgroup's wavefronts
         RowLaunch best{-1, 0, 0, 0, 0};
@@ -201,7 +202,7 @@ int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     if (h->rowKernel < 0 && nprob < 8192) return 0;
     for (int j = 0; j < h->P.m; j++)
         if (h->P.sense[j] & SENSE_ACTIVE) return 0;
-    if (h->S.iter_limit < 2 || h->nBinary > 63) return 0;
+    if (h->S.iter_limit < 2 || h->nBinary > 47) return 0;
     const int full = h->W.cap;
     RowLaunch rl;
     if (full <= 16) return row_launch_for(h, full, rs, &rl, true) ? full : 0;

@@ -133,7 +133,6 @@ __device__ __forceinline__ int rw_min4(int v) {
 __device__ __forceinline__ bool rw_any(bool p) { return __ballot(p) != 0ull; }
 
 constexpr int kRowPosFlagSoft = 1 << 16, kRowPosFlagImm = 1 << 17, kRowPosFlagLow = 1 << 18;
-constexpr int kRowPosOffShift = 20;      // bits 20 ..: where the row sits inside a row of the staged M' (lane * MS + slot)
 constexpr int kRowBig = 0x7fffffff;
 // The factor of a problem in LDS: the strict lower triangle column after column, each column padded UPWARDS to a row
 // index that is a multiple of four: column t holds rows p0(t) = 4 floor(t / 4) .. capp-1, of which p0(t) .. t are zeros
@@ -200,6 +199,8 @@ template <typename R> struct RowParams {
 // side, D, 1/D, y per position and the padded triangle as it lies in LDS; ints = the positions' rows, one size
 __host__ __device__ constexpr int row_snap_reals(int s, int capp) { return 64 * s + ((rowp_size(capp) + 3) & ~3); }
 __host__ __device__ constexpr int row_snap_ints(int s) { return 16 * s + 16; }
+// binary rows a search on the row kernel can hold (its depth; the per-depth state lives in registers)
+__host__ __device__ constexpr int row_bnb_depth_max(int ms) { return (16 * ms < 48 ? 16 * ms : 48) - 1; }
 
 // threads per workgroup an instantiation is built for: 512 (two wavefronts per SIMD, 256 registers) up to six constraint
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         fo[s] = Lg + pos[s];                                            // (a lane beyond the last row reads the next column's padding)
         bo[s] = pos[s] < CAPP - 1 ? Lg + cbm(pos[s] < CAPP - 1 ? pos[s] : 0) : oZ;   // (beyond the last column: the block of zeros)
     }
-    int jc[MS], mcol[NS];
+    int jc[MS];
     unsigned binb = 0u;                // bit r: this lane's row of slot r is BINARY
     unsigned okb = 0u, hardb = 0u;     // bit r: this lane's row of slot r can enter a working set / ... and is a hard row
 #pragma unroll
@@ -374,8 +375,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         if (j < m && !(sj & SENSE_IMMUTABLE)) { okb |= 1u << r; if (!(sj & SENSE_SOFT)) hardb |= 1u << r; }
         if (BNB && j < m && (sj & SENSE_BINARY)) binb |= 1u << r;
     }
-#pragma unroll
-    for (int s = 0; s < NS; s++) mcol[s] = oMt + (li + 16 * s < n ? li + 16 * s : n - 1) * MPAD;   // this lane's variables: their rows of M'
+    // this lane's variables: rows li, li + 16, ... of M' (a lane beyond n reads on into the factors, or zeros beyond the
+    // allocation: values that its masked result never shows) -- one address register, the slots are immediates
+    const int mcol0 = oMt + li * MPAD;
     const int mrow = oMt + li * MS;                             // this lane's constraints: MS consecutive entries of a row of M'
 
     // ---- the state of this row's problem (what is one number per problem is a row-uniform vector register; predicates
@@ -383,12 +385,12 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
     int live = 0, dead = 0;                        // a problem is running / the batch is exhausted
     int pid = 0, na = 0, sing = -1, iter = 1, cyc = 0, nsoft = 0, napk = 0, ydirty = 0;
     R best = (R)-1, fval = (R)0, soft_slack = (R)0;
-    int ws[S];                                     // per position: row index | kRowPosFlag*
+    int ws[S], wof[S];                             // per position: row index | kRowPosFlag*; the row's offset inside a row of M'
     R D[S], Dinv[S], lam[S], ls[S], rhs[S], y[S];
     R u[NS], dub[MS], dlb[MS];
     unsigned actb = 0u, lowb = 0u;                 // bit r: this lane's row of slot r is active / active at its lower bound
 #pragma unroll
-    for (int s = 0; s < S; s++) { ws[s] = 0; D[s] = Dinv[s] = lam[s] = ls[s] = rhs[s] = y[s] = (R)0; }
+    for (int s = 0; s < S; s++) { ws[s] = 0; wof[s] = 0; D[s] = Dinv[s] = lam[s] = ls[s] = rhs[s] = y[s] = (R)0; }
 #pragma unroll
     for (int s = 0; s < NS; s++) u[s] = (R)0;
 #pragma unroll
@@ -527,10 +529,11 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
     // factor go to global scratch only before the first removal that would disturb them (snap_clean / snap_saved, one
     // bit per depth: the wavefront kernel's lazy snapshots); `tried2`: both sides of that depth's row have been tried.
     static_assert(!BNB || MS <= 4, "a byte per depth holds the activity bits of up to four rows per lane");
-    constexpr int DS = BNB ? MS : 1;                             // (a search is at most m <= 16 MS levels deep)
+    constexpr int DS = BNB ? MS : 1;                             // (a search is at most m <= 16 MS levels deep ...
+    constexpr int AW = BNB ? (4 * DS < 12 ? 4 * DS : 12) : 1;    //  ... and at most 4 AW <= 48: row_bnb_depth_max)
     int forced = -1, depth = 0, nodes = 0, total_it = 0, have = 0, bflag = EXIT_INFEASIBLE, jbX = kRowBig, sideX = 0, rls = 0;
     R bestval = fbound, ubest[NS], stkf[DS];
-    unsigned bestact = 0u, bestlow = 0u, abyte[4 * DS];
+    unsigned bestact = 0u, bestlow = 0u, abyte[AW];
     int stk[DS], fixd[MS];                                       // fixd[r]: the depth that fixed this lane's row of slot r (255: none)
     unsigned long long snap_clean = 0ull, snap_saved = 0ull, tried2 = 0ull;
 #pragma unroll
@@ -538,20 +541,30 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
 #pragma unroll
     for (int q = 0; q < DS; q++) { stk[q] = 0; stkf[q] = (R)0; }
 #pragma unroll
-    for (int q = 0; q < 4 * DS; q++) abyte[q] = 0u;
+    for (int q = 0; q < AW; q++) abyte[q] = 0u;
 #pragma unroll
     for (int r = 0; r < MS; r++) fixd[r] = 255;
     constexpr int kSnapR = row_snap_reals(S, CAPP), kSnapI = row_snap_ints(S);
+    // (the selects' operands pass through an empty statement: the compiler otherwise recognises an indexed array, keeps a
+    // copy of it in scratch memory and answers every look-up with a load from there)
     auto stk_get = [&](int d) -> int {
         int sel = stk[0];
 #pragma unroll
-        for (int q = 1; q < DS; q++) sel = (d >> 4) == q ? stk[q] : sel;
+        for (int q = 1; q < DS; q++) {
+            int t = stk[q];
+            asm volatile("" : "+v"(t));
+            sel = (d >> 4) == q ? t : sel;
+        }
         return rw_pick(sel, d & 15, rowbase);
     };
     auto stkf_get = [&](int d) -> R {
         R sel = stkf[0];
 #pragma unroll
-        for (int q = 1; q < DS; q++) sel = (d >> 4) == q ? stkf[q] : sel;
+        for (int q = 1; q < DS; q++) {
+            R t = stkf[q];
+            asm volatile("" : "+v"(t));
+            sel = (d >> 4) == q ? t : sel;
+        }
         return rw_pick(sel, d & 15, rowbase);
     };
     auto stk_set = [&](int d, int e, R f, bool pred) {
@@ -564,13 +577,17 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
     auto abyte_get = [&](int d) -> unsigned {
         unsigned sel = abyte[0];
 #pragma unroll
-        for (int q = 1; q < 4 * DS; q++) sel = (d >> 2) == q ? abyte[q] : sel;
+        for (int q = 1; q < AW; q++) {
+            unsigned t = abyte[q];
+            asm volatile("" : "+v"(t));
+            sel = (d >> 2) == q ? t : sel;
+        }
         return (sel >> (8 * (d & 3))) & 0xffu;
     };
     auto abyte_set = [&](int d, unsigned v, bool pred) {
         const int sh = 8 * (d & 3);
 #pragma unroll
-        for (int q = 0; q < 4 * DS; q++) abyte[q] = (pred && (d >> 2) == q) ? ((abyte[q] & ~(0xffu << sh)) | (v << sh)) : abyte[q];
+        for (int q = 0; q < AW; q++) abyte[q] = (pred && (d >> 2) == q) ? ((abyte[q] & ~(0xffu << sh)) | (v << sh)) : abyte[q];
     };
     auto snap_r = [&](int d) -> R * {
         const RowParams<R> *a = RW_ARGS();
@@ -580,10 +597,18 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         const RowParams<R> *a = RW_ARGS();
         return a->bnb_i + ((long long)myrow * a->bnb_depth + d) * (long long)kSnapI;
     };
-    // the factor of this row's problem as 16-byte vectors (lane li moves vectors li, li + 16, ...): the whole padded
-    // triangle, whatever the node's size -- a copy of ~20 instructions a lane where a row-by-row one takes 120
-    constexpr int VW = 16 / (int)sizeof(R), FLV = (rowp_size(CAPP) + VW - 1) / VW, FLK = (FLV + 15) / 16, FLB = 10;
+    // the factor of a problem as 16-byte vectors, the whole padded triangle whatever the node's size, moved by ALL 64
+    // lanes for one row of the wavefront after the other (seldom more than one row of a wavefront needs it at once): six
+    // instructions a copy where a row-by-row one by the row's own 16 lanes takes 120.  Memory -> LDS without registers
+    // (global_load_lds: wave-uniform LDS base + 16 bytes per lane), so that a restore waits for memory once.
+    constexpr int VW = 16 / (int)sizeof(R), FLV = (rowp_size(CAPP) + VW - 1) / VW, FLK = (FLV + 63) / 64;
     typedef R rw_vec __attribute__((ext_vector_type(VW)));
+    auto uni64 = [&](const void *ptr, int gg) -> unsigned long long {
+        const unsigned long long v = (unsigned long long)ptr;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * gg),
+                       hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * gg);
+        return (unsigned long long)lo | ((unsigned long long)hi << 32);
+    };
     // the registers of the positions below nd and the factor as it stands -> slot d, for the rows with `sv`
     auto save_tri = [&](bool sv, int d, int nd) {
         R *sr = snap_r(d);
@@ -598,19 +623,22 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             }
             if (li == 0) si[16 * S] = na;                        // (rows nd .. na-1 of the copy belong to deeper nodes)
         }
-        const rw_vec *lsrc = reinterpret_cast<const rw_vec *>(lds + Lg);
-        rw_vec *gdst = reinterpret_cast<rw_vec *>(sr + 64 * S);
-        for (int k0 = 0; k0 < FLK; k0 += FLB) {
-            rw_vec tv[FLB];
 #pragma unroll
-            for (int q = 0; q < FLB; q++) {
-                const int v = li + 16 * (k0 + q);
-                tv[q] = lsrc[v < FLV ? v : FLV - 1];
-            }
+        for (int gg = 0; gg < 4; gg++) {
+            if (__builtin_amdgcn_readlane(sv ? 1 : 0, 16 * gg)) {
+                const rw_vec *lsrc = reinterpret_cast<const rw_vec *>(lds + __builtin_amdgcn_readlane(Lg, 16 * gg));
+                rw_vec *gdst = reinterpret_cast<rw_vec *>(uni64(sr + 64 * S, gg));
+                rw_vec tv[FLK];
 #pragma unroll
-            for (int q = 0; q < FLB; q++) {
-                const int v = li + 16 * (k0 + q);
-                if (sv && v < FLV) gdst[v] = tv[q];
+                for (int q = 0; q < FLK; q++) {
+                    const int v = lane + 64 * q;
+                    tv[q] = lsrc[v < FLV ? v : FLV - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < FLK; q++) {
+                    const int v = lane + 64 * q;
+                    if (v < FLV) gdst[v] = tv[q];
+                }
             }
         }
     };
@@ -623,6 +651,8 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         const bool dirty = rs && !clean;
         RWT_COUNT(17, rw_any(clean) ? 1 : 0);
         RWT_COUNT(18, rw_any(dirty) ? 1 : 0);
+        RWT_COUNT(26, rw_any(dirty) ? 0 : 1);
+        RWS_BEGIN;
         {
             const unsigned ab = abyte_get(d);
             const R fv = stkf_get(d);
@@ -641,20 +671,28 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 }
                 nsv = si[16 * S];
             }
-            rw_vec *ldst = reinterpret_cast<rw_vec *>(lds + Lg);
-            const rw_vec *gsrc = reinterpret_cast<const rw_vec *>(sr + 64 * S);
-            for (int k0 = 0; k0 < FLK; k0 += FLB) {
-                rw_vec tv[FLB];
 #pragma unroll
-                for (int q = 0; q < FLB; q++) {
-                    const int v = li + 16 * (k0 + q);
-                    if (dirty && v < FLV) tv[q] = gsrc[v];
-                }
+            for (int gg = 0; gg < 4; gg++) {
+                if (__builtin_amdgcn_readlane(dirty ? 1 : 0, 16 * gg)) {
+                    const int lgg = __builtin_amdgcn_readlane(Lg, 16 * gg);
+                    const rw_vec *gsrc = reinterpret_cast<const rw_vec *>(uni64(sr + 64 * S, gg));
 #pragma unroll
-                for (int q = 0; q < FLB; q++) {
-                    const int v = li + 16 * (k0 + q);
-                    if (dirty && v < FLV) ldst[v] = tv[q];
+                    for (int q = 0; q < FLK; q++) {
+                        const int v = lane + 64 * q;
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass knows neither the instruction nor the address space)
+                        if (v < FLV)
+                            __builtin_amdgcn_global_load_lds(gsrc + v, (__attribute__((address_space(3))) void *)(lds + lgg + 64 * q * VW), 16, 0, 0);
+#else
+                        (void)gsrc; (void)lgg; (void)v;
+#endif
+                    }
                 }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the copies have landed; the registers' loads with them)
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const int j = ws[s] & 0xffff;
+                wof[s] = dirty ? (j & 15) * MS + (j >> 4) : wof[s];
             }
             nahi = dirty ? nsv : nahi;
         }
@@ -671,7 +709,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool cut = clean && pos[s] >= na;
-            ws[s] = cut ? 0 : ws[s]; rhs[s] = cut ? (R)0 : rhs[s]; D[s] = cut ? (R)0 : D[s]; Dinv[s] = cut ? (R)0 : Dinv[s];
+            ws[s] = cut ? 0 : ws[s]; wof[s] = cut ? 0 : wof[s]; rhs[s] = cut ? (R)0 : rhs[s]; D[s] = cut ? (R)0 : D[s]; Dinv[s] = cut ? (R)0 : Dinv[s];
             y[s] = cut ? (R)0 : y[s];
         }
         // (a node is restored once, for its second child: from here on nobody needs slot d's factor)
@@ -679,6 +717,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
 #pragma unroll
         for (int s = 0; s < S; s++) { lam[s] = rs ? (R)0 : lam[s]; ls[s] = rs ? (R)0 : ls[s]; }
         sing = rs ? -1 : sing; ydirty = rs ? 0 : ydirty;
+#ifdef LMPC_ROW_TRACE
+        if (rw_any(dirty)) RWS_END(24); else RWS_END(25);
+#endif
     };
 
     for (;;) {
@@ -775,7 +816,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                     soft_slack = got ? (R)0 : soft_slack; actb = got ? 0u : actb; lowb = got ? 0u : lowb;
 #pragma unroll
                     for (int s = 0; s < S; s++) {
-                        ws[s] = got ? 0 : ws[s]; D[s] = got ? (R)0 : D[s]; Dinv[s] = got ? (R)0 : Dinv[s];
+                        ws[s] = got ? 0 : ws[s]; wof[s] = got ? 0 : wof[s]; D[s] = got ? (R)0 : D[s]; Dinv[s] = got ? (R)0 : Dinv[s];
                         lam[s] = got ? (R)0 : lam[s]; ls[s] = got ? (R)0 : ls[s]; rhs[s] = got ? (R)0 : rhs[s];
                         y[s] = got ? (R)0 : y[s];
                     }
@@ -948,9 +989,9 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                     constexpr int i0 = decltype(B)::value * CHP;
                     rw_static_for<0, CHP>([&](auto Q) {
                         constexpr int i = i0 + decltype(Q)::value < CAPP ? i0 + decltype(Q)::value : CAPP - 1;
-                        const int w = (int)((unsigned)rw_bc<i>(ws[i >> 4]) >> kRowPosOffShift);
+                        const int w = mcol0 + rw_bc<i>(wof[i >> 4]);
 #pragma unroll
-                        for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[mcol[s] + w];
+                        for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[w + s * 16 * MPAD];
                     });
                 };
                 fetch(std::integral_constant<int, 0>{});
@@ -1227,7 +1268,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
 #pragma unroll
                     for (int s = 0; s < S; s++) a[s] = (dr && pos[s] >= r) ? nx[s] : a[s];
                 };
-                shift(ws); shift(lam); shift(rhs); shift(D); shift(Dinv); shift(w);
+                shift(ws); shift(wof); shift(lam); shift(rhs); shift(D); shift(Dinv); shift(w);
             }
             na = dr ? nao - 1 : na; sing = dr ? -1 : sing; ydirty = dr ? 1 : ydirty;
             RWT(7);
@@ -1328,12 +1369,13 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
                 const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | (((sj & SENSE_IMMUTABLE) || (BNB && addF)) ? kRowPosFlagImm : 0) |
-                                (lower ? kRowPosFlagLow : 0) | (((jadd & 15) * MS + (jadd >> 4)) << kRowPosOffShift);
+                                (lower ? kRowPosFlagLow : 0);
+                const int wofn = (jadd & 15) * MS + (jadd >> 4);      // where the row sits inside a row of the staged M'
 #pragma unroll
                 for (int s = 0; s < S; s++) {
                     if (ap && pos[s] < na) lds[bo[s] + na] = l[s];           // new row: L(na, t) written by lane t
                     const bool here = ap && pos[s] == na;
-                    ws[s] = here ? wsn : ws[s];
+                    ws[s] = here ? wsn : ws[s]; wof[s] = here ? wofn : wof[s];
                     rhs[s] = here ? rj : rhs[s]; lam[s] = here ? (R)0 : lam[s]; ls[s] = here ? (R)0 : ls[s];
                     y[s] = here ? ynew : y[s];
                     D[s] = here ? (singular ? (R)0 : dnew) : D[s];

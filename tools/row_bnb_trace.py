@@ -35,3 +35,4 @@ print(f"   {'loop overhead':42s} {100*v[15]/tot:5.1f} %   {v[15]/trips:8.0f} cyc
 print(f"   per trip: {v[16]/trips:.2f} branchings ({v[22]/max(v[16],1):.0f} cycles each), pop loops {v[23]/trips:.0f} cycles, "
       f"{v[17]/trips:.2f} clean / {v[18]/trips:.2f} dirty restores ({v[20]/max(v[17]+v[18],1):.0f} cycles each), "
       f"{v[19]/trips:.2f} lazy saves ({v[21]/max(v[19],1):.0f} cycles each)")
+print(f"   restores with a copy from memory: {v[24]/max(v[18],1):.0f} cycles each; without: {v[25]/max(v[26],1):.0f} cycles each ({v[26]/trips:.2f} per trip)")
