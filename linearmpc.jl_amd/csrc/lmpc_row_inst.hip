@@ -206,6 +206,9 @@ int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     const int full = h->W.cap;
     RowLaunch rl;
     if (full <= 16) return row_launch_for(h, full, rs, &rl, true) ? full : 0;
+    // ("wave_two_pass" 1 with "wave_cap1" c: first pass at min(c, 48) rows whatever the binaries leave -- tests of the listing)
+    if (h->waveTwoPass > 0 && h->waveCap1 > 0)
+        return row_launch_for(h, h->waveCap1 < 48 ? h->waveCap1 : 48, rs, &rl, true) ? (h->waveCap1 < 48 ? h->waveCap1 : 48) : 0;
     if (h->waveTwoPass == 0 || h->nBinary + 8 > 48 || full <= 52) return 0;
     return row_launch_for(h, 48, rs, &rl, true) ? 48 : 0;
 }

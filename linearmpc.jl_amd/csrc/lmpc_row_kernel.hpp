@@ -1274,6 +1274,8 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             RWT(7);
             // rank-one update of the trailing block, column by column
             {
+                RWS_BEGIN;
+                RWT_COUNT(28, nhi - rlo);
                 int stop = 0;
                 const int nhi2 = rw_max4(dr ? na : 0);
                 // (the columns of a block of four steps are read at its head: a step changes its own column only)
@@ -1323,6 +1325,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                         });
                     }
                 });
+                RWS_END(27);
             }
             {
                 const bool mine = dr && li == (jrem & 15);

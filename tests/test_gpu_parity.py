@@ -2818,3 +2818,89 @@ def test_row_kernel_immutable_one_sided_and_duplicated_rows(lmpc):
     q2 = lmpc.BatchedQP.from_mpqp(H, np.zeros(n), rng.standard_normal((n, nth)), A, bu2, bl2, W, s2, nout=3)
     assert q2.kernel_name == "wave"
     _row_vs_wave_vs_oracle(lmpc, q2, theta[:500])
+
+
+# ------------------------------------------------------------------ branch and bound on the row kernel (binary32)
+def _bnb_row_vs_wave_vs_oracle(lmpc, qp, s, theta, nsample=200):
+    """Binary32 search on the row kernel (four searches per wavefront, "row_kernel" 1) against the wavefront kernel (0) --
+    every output identical -- and a sample against the binary32 oracle."""
+    import torch
+    from oracle import ldp as oldp
+    N = len(theta)
+    th_d = torch.from_numpy(theta).cuda()
+    out = {}
+    for mode in (0, 1):
+        qp.set_option("row_kernel", mode)
+        it_d = torch.empty(N, dtype=torch.int32, device="cuda")
+        ac_d = torch.zeros((N, qp.words), dtype=torch.int64, device="cuda")
+        x_d, ef_d = qp.solve_device(th_d, iters=it_d, active=ac_d)
+        torch.cuda.synchronize()
+        qp.check()
+        out[mode] = (x_d.cpu().numpy(), ef_d.cpu().numpy(), it_d.cpu().numpy(), ac_d.cpu().numpy().view(np.uint64))
+    for q in range(4):
+        assert np.array_equal(out[0][q], out[1][q], equal_nan=(q == 0)), ("x", "exitflag", "iters", "active")[q]
+    sel = np.arange(0, N, max(1, N // nsample))
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], _copy_settings(lmpc, s), dtype=np.float32)
+    x, ef, it, act = out[1]
+    assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
+    assert np.abs(x[sel] - xo).max() == 0.0
+    return out[1]
+
+
+@pytest.mark.parametrize("name", ["satellite4", "satellite20"])
+def test_row_kernel_branch_and_bound_f32(lmpc, name):
+    # the hybrid example of /root/reference/test/runtests.jl:820-834 (binaries: mpc_examples.jl:533-546), single precision
+    # (codegen.jl:19 float_type="float"); satellite20 = BASELINE config 5: first pass of 48 rows on the row kernel, what
+    # outgrows it listed for the wavefront kernel
+    g = load_golden(name)
+    s = lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+    rng = np.random.default_rng(8)
+    base = g["theta"]
+    N = 3000 if name == "satellite20" else 6000
+    theta = base[rng.integers(0, len(base), N)] * rng.uniform(0.2, 1.6, (N, 1)) + rng.normal(0, 0.01, (N, base.shape[1]))
+    theta[: len(base)] = base[:N]
+    theta = theta.astype(np.float32)
+    x, ef, it, act = _bnb_row_vs_wave_vs_oracle(lmpc, qp, s, theta)
+    assert (ef == 1).mean() > 0.9
+    ok = ef == 1
+    bins = np.flatnonzero(g["senses"] & 16)                            # runtests.jl:831-834 (f32: +-1e-5)
+    assert np.all(np.minimum(np.abs(x[ok][:, bins] - g["bu"][bins]), np.abs(x[ok][:, bins] - g["bl"][bins])) < 1e-5)
+
+
+def test_row_kernel_branch_and_bound_overflow_is_listed(lmpc):
+    # a first pass too small for many of the searches ("wave_cap1" 42 rows for 40 binaries): those points are listed and
+    # searched again by the wavefront kernel at the full capacity -- same answers as without the split
+    g = load_golden("satellite20")
+    s = lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+    qp.set_option("wave_two_pass", 1)
+    qp.set_option("wave_cap1", 42)
+    rng = np.random.default_rng(9)
+    base = g["theta"]
+    theta = (base[rng.integers(0, len(base), 1500)] * rng.uniform(0.5, 1.6, (1500, 1))).astype(np.float32)
+    x, ef, it, act = _bnb_row_vs_wave_vs_oracle(lmpc, qp, s, theta, nsample=100)
+    assert (ef == 1).mean() > 0.9
+
+
+def test_row_kernel_branch_and_bound_random_problems(lmpc):
+    # binaries next to general rows and soft rows (n = 6, m = 11: the one-slot instantiation); infeasible assignments
+    # prune, an infeasible problem ends with the search's flag
+    rng = np.random.default_rng(2025)
+    s = lmpc.default_settings_f32()
+    nsolved = 0
+    for trial in range(6):
+        n, mg, nth = 6, 5, 3
+        H, f, fth, A, bu, bl, W, sense = _random_qp(rng, n, mg, nth, nsoft=(1 if trial % 2 else 0))
+        sense = sense.copy()
+        sense[:3] |= 16
+        qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense, settings=s)
+        theta = rng.uniform(-1, 1, (1200, nth)).astype(np.float32)
+        x, ef, it, act = _bnb_row_vs_wave_vs_oracle(lmpc, qp, s, theta)
+        ok = ef >= 1
+        nsolved += int(ok.sum())
+        xb = x[ok][:, :3]
+        lo = (bl[:3] + theta[ok] @ W[:3].T)
+        hi = (bu[:3] + theta[ok] @ W[:3].T)
+        assert np.all(np.minimum(np.abs(xb - lo), np.abs(xb - hi)) < 1e-4)
+    assert nsolved >= 3000

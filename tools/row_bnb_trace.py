@@ -36,3 +36,4 @@ print(f"   per trip: {v[16]/trips:.2f} branchings ({v[22]/max(v[16],1):.0f} cycl
       f"{v[17]/trips:.2f} clean / {v[18]/trips:.2f} dirty restores ({v[20]/max(v[17]+v[18],1):.0f} cycles each), "
       f"{v[19]/trips:.2f} lazy saves ({v[21]/max(v[19],1):.0f} cycles each)")
 print(f"   restores with a copy from memory: {v[24]/max(v[18],1):.0f} cycles each; without: {v[25]/max(v[26],1):.0f} cycles each ({v[26]/trips:.2f} per trip)")
+print(f"   rank-one updates: {v[27]/trips:.0f} cycles per trip, {v[27]/max(v[12],1):.0f} per removal phase ({v[28]/max(v[12],1):.1f} columns from the lowest removed row to the largest working set)")
