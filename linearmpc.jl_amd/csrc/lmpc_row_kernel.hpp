@@ -865,16 +865,8 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
 
         // =============================================================== stationary point / singular direction
         {
-            const bool dirty = run && !sgl && ydirty != 0;
-            if (rw_any(dirty)) {
-                R v[S];
-#pragma unroll
-                for (int s = 0; s < S; s++) v[s] = (dirty && pos[s] < na) ? rhs[s] : (R)0;
-                sweep_fwd(v, rw_max4(dirty ? na : 0));
-#pragma unroll
-                for (int s = 0; s < S; s++) y[s] = dirty ? v[s] : y[s];
-                ydirty = dirty ? 0 : ydirty;
-            }
+            // (y = L^-1 rhs is up to date here: an append extends it, a removal re-runs the forward sweep in its own trip --
+            // see the append's second half)
             R v[S];
 #pragma unroll
             for (int s = 0; s < S; s++) v[s] = stat ? y[s] * Dinv[s] : (R)0;
@@ -1336,8 +1328,11 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             nsoft = dr ? nsoft - softrem : nsoft;
         }
         // =============================================================== ... second half of the append: extend the factor
-        if (rw_any(addpX != 0)) {
+        // (the rows that dropped a row in this trip ride along in the forward sweep: their y = L^-1 rhs for the factor as the
+        // removal left it -- what the next stationary point needs -- instead of a sweep of their own at the next trip's head)
+        if (rw_any(addpX != 0 || doRem != 0)) {
                 const bool ap = addpX != 0;
+                const bool ry = doRem != 0;
                 const int jadd = jaddX;
                 const bool lower = lowerX != 0;
                 const R fvalN = fvalX, gjj = gjjX, rj = rjX;
@@ -1345,11 +1340,14 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 const bool is_soft = (sj & SENSE_SOFT) != 0;
                 R q[S];
 #pragma unroll
-                for (int s = 0; s < S; s++) q[s] = (ap && pos[s] < na) ? qX[s] : (R)0;
+                for (int s = 0; s < S; s++) q[s] = pos[s] < na ? (ap ? qX[s] : (ry ? rhs[s] : (R)0)) : (R)0;
 #pragma unroll
                 for (int s = 0; s < S; s++) lam[s] = ap ? ls[s] : lam[s];
-                const int namaxQ = rw_max4(ap ? na : 0);
+                const int namaxQ = rw_max4((ap || ry) ? na : 0);
                 sweep_fwd(q, namaxQ);
+#pragma unroll
+                for (int s = 0; s < S; s++) y[s] = ry ? q[s] : y[s];
+                ydirty = ry ? 0 : ydirty;
                 R l[S];
 #pragma unroll
                 for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
