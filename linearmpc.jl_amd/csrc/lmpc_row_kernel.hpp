@@ -30,8 +30,9 @@
 // results are bit-identical to the oracle's and to the wavefront kernel's (x, exit flag, iteration count, active set).
 //
 // Covers: cold plain solves, binary64 / binary32, n <= 16 NS, m <= 16 MS, hard / SOFT / IMMUTABLE rows, no rows
-// flagged ACTIVE or BINARY, working sets up to CAPP <= 16 S rows; a point that outgrows that is listed for the
-// wavefront kernel (exit flag -7 inside this pass), exactly like the first of that kernel's two passes.
+// flagged ACTIVE, working sets up to CAPP <= 16 S rows; a point that outgrows that is listed for the wavefront kernel
+// (exit flag -7 inside this pass), exactly like the first of that kernel's two passes.  Rows flagged BINARY: the BNB
+// instantiations (binary32), one depth-first search per row of the wavefront (see the search state below).
 //
 // Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp incl. soft constraints
 // ([EXT] libdaqp, called at mpc_update_qp.c:48 / utils.jl:282) and mpc_get_solution (mpc_update_qp.c:14-22).
