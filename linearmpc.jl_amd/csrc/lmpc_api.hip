@@ -97,8 +97,10 @@ int finalize_handle(lmpc_handle *h) {
     const bool laneOk = P.n <= kLaneMaxN && P.m <= kLaneMaxM && P.nsoft == 0 && !anyBinary;
     // working-set capacity: n hard rows + 1 (the row that makes it singular) + the soft rows, but never
     // more than the 64 lanes; a problem that wants more rows at once ends with exit flag -7
-    const int cap = std::min(P.n + 1 + P.nsoft, kWaveMaxCap);
-    h->capFull = P.n + 1 + P.nsoft;
+    // (branch and bound: one row more -- the row a node has just fixed enters on top of its parent's final working set,
+    // whatever that holds; the oracle's arrays have that row too)
+    const int cap = std::min(P.n + 1 + P.nsoft + (anyBinary ? 1 : 0), kWaveMaxCap);
+    h->capFull = P.n + 1 + P.nsoft + (anyBinary ? 1 : 0);
     const bool waveOk = P.n <= kWaveMaxN && P.m <= kWaveMaxM && P.m >= 1;
     if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,

@@ -177,10 +177,9 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     const int full = h->W.cap;
     RowLaunch rl;
     int cap = 0;
-    // where it is the default (measured, tools/row_check.py): up to two slots of variables and six of constraints -- config 3
-    // runs 1.9x the wavefront kernel there, soft_doc (n = 10, SOFT rows, 12 iterations) 1.8x, mass_spring behind the tiers
-    // pass level; the ten-slot shape (one wavefront per SIMD) is taken only on request ("row_kernel" 1)
-    if (h->rowKernel < 0 && !(h->P.n <= 32 && h->P.m <= 96)) return 0;
+    // where it is the default (measured, tools/row_check.py): every shape built -- config 3 runs 1.9x the wavefront kernel,
+    // soft_doc (n = 10, SOFT rows, 12 iterations) 1.7x, mass_spring behind the tiers pass level, the ten-slot shape (one
+    // wavefront per SIMD; pendulum_N50 behind the screening pass) 1.2x
     if (full <= 32 && row_launch_for(h, full, rs, &rl)) cap = full;
     else if (full > 32 && h->bigPath && h->waveTwoPass != 0) {
         // first of two passes at 31 rows: when at most 1 in 20 of the working sets seen lately went beyond 24 (the
@@ -206,6 +205,8 @@ int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     const int full = h->W.cap;
     RowLaunch rl;
     if (full <= 16) return row_launch_for(h, full, rs, &rl, true) ? full : 0;
+    // (on request also as the only pass of a problem whose capacity the 48-row shape holds: the randomized parity tests)
+    if (full <= 48 && h->rowKernel > 0) return row_launch_for(h, full, rs, &rl, true) ? full : 0;
     // ("wave_two_pass" 1 with "wave_cap1" c: first pass at min(c, 48) rows whatever the binaries leave -- tests of the listing)
     if (h->waveTwoPass > 0 && h->waveCap1 > 0)
         return row_launch_for(h, h->waveCap1 < 48 ? h->waveCap1 : 48, rs, &rl, true) ? (h->waveCap1 < 48 ? h->waveCap1 : 48) : 0;

@@ -720,6 +720,11 @@ static int solve_bnb(work_t *w, const oracle_ldp *p, const oracle_settings *s, c
     oracle_settings sn = *s;
     real best = s->fval_bound;
     int have = 0, depth = 0, nodes = 0, total_it = 0, flag = EXIT_INFEASIBLE, inplace = 0;
+    /* A search's working sets take one row more than a plain solve's: the row a node has just fixed enters on top of its
+     * parent's final working set whatever that holds (n hard rows, the soft rows, the row that made it singular), and the
+     * arrays are sized for it (work_new: cap + 1 rows).  The capacity-checked forms (Gram-scan; the kernels in both forms)
+     * stop one row later accordingly: binary32 searches on random dense problems do reach n + 2 + #soft rows. */
+    w->cap64 = w->cap + 1 < 64 ? w->cap + 1 : 64;
     shift_bounds(w, p, theta);
     for (;;) {
         if (nodes >= BNB_NODE_LIMIT) { flag = EXIT_ITERLIMIT; break; }

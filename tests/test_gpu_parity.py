@@ -6,6 +6,8 @@ identical final active sets.  Because the lane kernel and the oracle share one a
 (explicit fma chains in index order) the observed difference is 0; the tolerance asserted is the
 stated 1e-10.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -2904,3 +2906,20 @@ def test_row_kernel_branch_and_bound_random_problems(lmpc):
         hi = (bu[:3] + theta[ok] @ W[:3].T)
         assert np.all(np.minimum(np.abs(xb - lo), np.abs(xb - hi)) < 1e-4)
     assert nsolved >= 3000
+
+
+def test_row_kernel_branch_and_bound_fuzz(lmpc):
+    # random hybrid problems in both instantiations (tools/fuzz_row_bnb.py): the row kernel bit-identical to the
+    # wavefront kernel, a sample of every trial identical to the binary32 oracle.  Seed 3 holds the problem (trial 37:
+    # n = 24, 2 soft rows, 6 binaries) whose searches reach n + 2 + #soft rows in a working set -- one more than a plain
+    # solve can: the kernels used to give those points up with exit flag -7 where the oracle solves them
+    import importlib.util
+    from oracle import ldp as oldp
+    spec = importlib.util.spec_from_file_location("fuzz_row_bnb", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_row_bnb.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(3)
+    s = lmpc.default_settings_f32()
+    for t in range(40):
+        same, ok, n, m, nb, solved, its = fz.run_trial(rng, t % 2 == 1, 1500, s, oldp.Settings)
+        assert same and ok, (t, n, m, nb)
