@@ -298,6 +298,8 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
                uint64_t *active, hipStream_t st, int cap, int pass);
 extern template int launch_row<double>(lmpc_handle *, const double *, int64_t, const double *, double *, int32_t *, int32_t *,
                                        uint64_t *, hipStream_t, int, int);
+extern template int launch_row<float>(lmpc_handle *, const float *, int64_t, const float *, float *, int32_t *, int32_t *,
+                                      uint64_t *, hipStream_t, int, int);
 // ... with branch and bound (binary32)
 int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs);
 template <typename R>

@@ -177,6 +177,9 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     const int full = h->W.cap;
     RowLaunch rl;
     int cap = 0;
+    // binary32 by default only in the two-slot shape (config 3's class: 15.4 -> 9.4 ms per 4e5; soft_doc level, the one-slot
+    // and ten-slot shapes behind the wavefront kernel there: no tiers / screening pass in front of them in binary32)
+    if (rs == 4 && h->rowKernel < 0 && !(h->P.n > 16 && h->P.n <= 32 && h->P.m <= 96)) return 0;
     // where it is the default (measured, tools/row_check.py): every shape built -- config 3 runs 1.9x the wavefront kernel,
     // soft_doc (n = 10, SOFT rows, 12 iterations) 1.7x, mass_spring behind the tiers pass level, the ten-slot shape (one
     // wavefront per SIMD; pendulum_N50 behind the screening pass) 1.2x

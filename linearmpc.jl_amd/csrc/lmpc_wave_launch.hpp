@@ -450,7 +450,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     return rc;
     };   // dispatch
     if (h->preloadOnly) {
-        if constexpr (!BNB && !GRAM && sizeof(R) == 8) {      // (the row kernel's code object too, where a large batch would take it)
+        if constexpr (!BNB && !GRAM) {                        // (the row kernel's code object too, where a large batch would take it)
             const int rcap = row_pass_cap(h, (int64_t)1 << 20, sizeof(R), false, GRAM, BNB);
             if (rcap > 0) (void)launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
         }
@@ -462,7 +462,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     }
     // Four problems per wavefront (lmpc_row_kernel.hpp) where it applies: as the only pass when its capacity holds every
     // working set of the problem, else as the first of two passes in place of this kernel's own first pass.
-    if constexpr (!BNB && !GRAM && sizeof(R) == 8) {
+    if constexpr (!BNB && !GRAM) {
         const int rcap = row_pass_cap(h, nprob, sizeof(R), warm != nullptr, GRAM, BNB);
         if (rcap > 0) {
             if (rcap >= capW) {

@@ -2923,3 +2923,36 @@ def test_row_kernel_branch_and_bound_fuzz(lmpc):
     for t in range(40):
         same, ok, n, m, nb, solved, its = fz.run_trial(rng, t % 2 == 1, 1500, s, oldp.Settings)
         assert same and ok, (t, n, m, nb)
+
+
+@pytest.mark.parametrize("name", ["mass_spring_3in", "soft_doc", "mass_spring"])
+def test_row_kernel_binary32_plain_solves(lmpc, name):
+    # binary32 (codegen.jl:19 float_type="float") on the row kernel: identical to the wavefront kernel, a sample identical
+    # to the binary32 oracle
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden(name)
+    s = lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+    rng = np.random.default_rng(12)
+    base = g["theta"]
+    N = 20000
+    theta = (base[rng.integers(0, len(base), N)] * rng.uniform(0.3, 1.5, (N, 1))).astype(np.float32)
+    th_d = torch.from_numpy(theta).cuda()
+    out = {}
+    for mode in (0, 1):
+        qp.set_option("row_kernel", mode)
+        it_d = torch.empty(N, dtype=torch.int32, device="cuda")
+        ac_d = torch.zeros((N, qp.words), dtype=torch.int64, device="cuda")
+        x_d, ef_d = qp.solve_device(th_d, iters=it_d, active=ac_d)
+        torch.cuda.synchronize()
+        qp.check()
+        out[mode] = (x_d.cpu().numpy(), ef_d.cpu().numpy(), it_d.cpu().numpy(), ac_d.cpu().numpy().view(np.uint64))
+    for q in range(4):
+        assert np.array_equal(out[0][q], out[1][q], equal_nan=(q == 0))
+    sel = np.arange(0, N, 40)
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], _copy_settings(lmpc, s), dtype=np.float32)
+    x, ef, it, act = out[1]
+    assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
+    assert np.abs(x[sel] - xo).max() == 0.0
+    assert (ef >= 1).any()

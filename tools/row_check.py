@@ -1,5 +1,5 @@
 """Row kernel (four problems per wavefront, lmpc_row_kernel.hpp) against the wavefront kernel and the oracle, and its
-time per 10^6 problems.  Usage: python tools/row_check.py [name] [N] [--no-oracle] [--active]"""
+time per 10^6 problems.  Usage: python tools/row_check.py [name] [N] [--no-oracle] [--first] [--f32]"""
 import os
 import sys
 import time
@@ -33,9 +33,14 @@ def main():
     name = args[0] if args else "mass_spring_3in"
     N = int(args[1]) if len(args) > 1 else 40000
     g = load_golden(name)
+    f32 = "--f32" in sys.argv
+    st = lmpc.default_settings_f32() if f32 else None
     qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
-                                  nout=int(g["nu"]) if "--first" in sys.argv and "nu" in g else None)
+                                  nout=int(g["nu"]) if "--first" in sys.argv and "nu" in g else None,
+                                  **({"settings": st} if f32 else {}))
     theta = bench.make_theta(name, N, 77)
+    if f32:
+        theta = theta.astype(np.float32)
     th_d = torch.from_numpy(theta).cuda()
     out = {}
     for mode in (0, 1):
@@ -62,7 +67,13 @@ def main():
     if "--no-oracle" not in sys.argv:
         from oracle import ldp as oldp
         sel = np.arange(0, N, max(1, N // 2000))
-        xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
+        if f32:
+            so = oldp.Settings()
+            for fl, _ in so._fields_:
+                setattr(so, fl, getattr(st, fl, 0))
+            xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], so, dtype=np.float32)
+        else:
+            xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
         x, ef, it, ac = out[1]
         ok = (np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(ac[sel], acto)
               and np.abs(x[sel] - xo).max() == 0.0)
