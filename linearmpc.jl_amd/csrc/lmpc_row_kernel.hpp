@@ -1496,6 +1496,29 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 if (16 * s < nout) {
                     const int ko = li + 16 * s;
                     const int lo = ko < nout ? ko : nout - 1;
+                    // the shift x0 + Xth theta first: the parameter record and this output's row of Xth in ONE round trip (a loop
+                    // over the nth entries waits for memory once per entry: 12 round trips where one serves)
+                    constexpr int NTHF = 16;
+                    R sh = ldc(prm.P.ox0, lo);
+                    {
+                        R tf[NTHF], xf[NTHF];
+#pragma unroll
+                        for (int t = 0; t < NTHF; t++) {
+                            tf[t] = th[t < nth ? t : nth - 1];
+                            xf[t] = ldc(prm.P.oXth + (t < nth ? t : nth - 1), lo * nth);
+                        }
+                        rw_static_for<0, NTHF / 4>([&](auto B) {
+                            constexpr int t0 = decltype(B)::value * 4;
+                            if (t0 < nth) {
+                                RW_BLOCK();
+#pragma unroll
+                                for (int q = 0; q < 4; q++)
+                                    if (t0 + q < nth) sh = wv_fma(xf[t0 + q], tf[t0 + q], sh);
+                            }
+                        });
+                        for (int t = NTHF; t < nth; t++) sh = wv_fma(ldc(prm.P.oXth + t, lo * nth), th[t], sh);
+                        RW_BLOCK();
+                    }
                     R xs = (R)0;
                     R rv[16 * NS];                                   // (this output's row of R^-1 in one batch: L2 round trips)
 #pragma unroll
@@ -1510,8 +1533,6 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                             });
                         }
                     });
-                    R sh = ldc(prm.P.ox0, lo);
-                    for (int t = 0; t < nth; t++) sh = wv_fma(ldc(prm.P.oXth + t, lo * nth), th[t], sh);
                     const R xo = xs + sh;
                     if (fn && ko < nout && a->X != nullptr) a->X[(long long)pid * nout + ko] = xo;
                 }
