@@ -205,6 +205,8 @@ struct lmpc_handle {
     bool qpAbPending[2] = {false, false};
     int64_t qpAbN[2] = {0, 0};
     double qpAbNsPer[2] = {-1.0, -1.0};      // measured nanoseconds per problem (-1: not measured yet)
+    double qpAbAcc[2] = {-1.0, -1.0};   // ... best sample of the current round of measurements, and how many it holds
+    int qpAbCnt[2] = {0, 0};
     long long qpAbCalls = 0;
     // four problems per wavefront (lmpc_row_kernel.hpp) in front of / instead of the wavefront kernel
     int rowKernel = -1;         // "row_kernel": -1 = where it applies (large cold batches), 0 = never, 1 = whenever an instantiation covers
