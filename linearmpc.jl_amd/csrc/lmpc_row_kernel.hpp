@@ -849,13 +849,14 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
         }
         // (branch and bound) a node that continues in place starts by taking the row just fixed into the working set: no
         // stationary point, no scan in that trip
-        int addF = 0;
+        int addF = 0, immX = 0;                                  // immX: the row appended in this trip enters as a fixed (immutable) row
         unsigned fixb = 0u;                                      // bit r: this lane's row of slot r is fixed on the path to this node
         if constexpr (BNB) {
             const bool frc = live != 0 && !fin && forced >= 0;
             const bool fullF = frc && na >= cap;
             flag = fullF ? EXIT_WSCAP : flag; fin = fullF ? 1 : fin;
             addF = (frc && !fullF) ? 1 : 0;
+            immX = addF;
 #pragma unroll
             for (int r = 0; r < MS; r++) fixb |= fixd[r] < depth ? (1u << r) : 0u;
         }
@@ -1149,6 +1150,31 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                                 dup = rw_pick(usel, jq & 15, rowbase);
                         jbX = opt ? jb : jbX;
                         sideX = opt ? (((mj - dlo) < (dup - mj)) ? 1 : 0) : sideX;
+                        // A node that branches does so HERE: its first child continues in place, so the row just fixed joins this
+                        // very trip's append phase (decided behind the trip, as the other moves of the search are, the fixed row's
+                        // append would cost the row a trip of its own: one in ten).  Not at the node limit and not when
+                        // the working set is full: those cases go the long way, with the wavefront kernel's accounting.
+                        const bool early = opt && fl >= 1 && jb != kRowBig && na < cap && nodes + 1 < 100000;
+                        if (rw_any(early)) {
+                            nodes = early ? nodes + 1 : nodes;
+                            total_it = early ? total_it + iter : total_it;
+                            stk_set(depth, jb | (sideX << 10) | (na << 13) | (nsoft << 20), fvalN, early);
+                            abyte_set(depth, actb | (lowb << 4), early);
+                            const unsigned long long bit = 1ull << depth;
+                            snap_clean = early ? (snap_clean | bit) : snap_clean;
+                            snap_saved = early ? (snap_saved & ~bit) : snap_saved;
+                            tried2 = early ? (tried2 & ~bit) : tried2;
+#pragma unroll
+                            for (int r = 0; r < MS; r++) {
+                                const bool mine = early && li + 16 * r == jb;
+                                fixd[r] = mine ? depth : ((early && fixd[r] == depth) ? 255 : fixd[r]);
+                            }
+                            depth = early ? depth + 1 : depth;
+                            // the child's node starts: the fixed row is this trip's append
+                            fin = early ? 0 : fin; addp = early ? 1 : addp; mt = early ? 2 * jb + sideX : mt;
+                            immX = early ? 1 : immX;
+                            iter = early ? 1 : iter; cyc = early ? 0 : cyc; best = early ? (R)-1 : best;
+                        }
                     }
                 }
                 const bool full = addp && na >= cap;
@@ -1370,7 +1396,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 });
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
-                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | (((sj & SENSE_IMMUTABLE) || (BNB && addF)) ? kRowPosFlagImm : 0) |
+                const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | (((sj & SENSE_IMMUTABLE) || (BNB && immX)) ? kRowPosFlagImm : 0) |
                                 (lower ? kRowPosFlagLow : 0);
                 const int wofn = (jadd & 15) * MS + (jadd >> 4);      // where the row sits inside a row of the staged M'
 #pragma unroll
