@@ -978,12 +978,27 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
             // u = -M_W' lam*  (rows beyond a working set: lam* = 0 there, row 0 of M)
             constexpr int CHP = 4, NBP = (CAPP + CHP - 1) / CHP;
             {
-                R mn[CHP][NS];
+                R mn[CHP][NS], ln[CHP];
+                // binary32: a position's offset and its multiplier travel as ONE 64-bit broadcast (the multiplier is used a
+                // block later, with the rows of M' the offset fetched)
+                typedef int rw_i2 __attribute__((ext_vector_type(2)));
+                double wl[S];
+                if constexpr (sizeof(R) == 4) {
+#pragma unroll
+                    for (int s = 0; s < S; s++) { const rw_i2 t = {wof[s], __float_as_int((float)ls[s])}; wl[s] = __builtin_bit_cast(double, t); }
+                }
                 auto fetch = [&](auto B) {
                     constexpr int i0 = decltype(B)::value * CHP;
                     rw_static_for<0, CHP>([&](auto Q) {
                         constexpr int i = i0 + decltype(Q)::value < CAPP ? i0 + decltype(Q)::value : CAPP - 1;
-                        const int w = mcol0 + rw_bc<i>(wof[i >> 4]);
+                        int w;
+                        if constexpr (sizeof(R) == 4) {
+                            const rw_i2 t = __builtin_bit_cast(rw_i2, rw_bc<i>(wl[i >> 4]));
+                            w = mcol0 + t.x;
+                            ln[decltype(Q)::value] = (R)__int_as_float(t.y);
+                        } else {
+                            w = mcol0 + rw_bc<i>(wof[i >> 4]);
+                        }
 #pragma unroll
                         for (int s = 0; s < NS; s++) mn[decltype(Q)::value][s] = lds[w + s * 16 * MPAD];
                     });
@@ -993,16 +1008,20 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                     constexpr int b = decltype(B)::value, i0 = b * CHP;
                     if (i0 < namaxA) {
                         RW_BLOCK();
-                        R mv[CHP][NS];
+                        R mv[CHP][NS], lv[CHP];
 #pragma unroll
-                        for (int q = 0; q < CHP; q++)
+                        for (int q = 0; q < CHP; q++) {
+                            lv[q] = sizeof(R) == 4 ? ln[q] : (R)0;
 #pragma unroll
                             for (int s = 0; s < NS; s++) mv[q][s] = mn[q][s];
+                        }
                         if constexpr (b + 1 < NBP) fetch(std::integral_constant<int, b + 1>{});
                         rw_static_for<0, CHP>([&](auto Q) {
                             constexpr int i = i0 + decltype(Q)::value;
                             if constexpr (i < CAPP) {
-                                const R l = rw_bc<i>(ls[i >> 4]);
+                                R l;
+                                if constexpr (sizeof(R) == 4) l = lv[decltype(Q)::value];
+                                else l = rw_bc<i>(ls[i >> 4]);
 #pragma unroll
                                 for (int s = 0; s < NS; s++) un[s] = wv_fma(-mv[decltype(Q)::value][s], l, un[s]);
                             }
@@ -1380,6 +1399,30 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 for (int s = 0; s < S; s++) l[s] = q[s] * Dinv[s];
                 R dnew = is_soft ? gjj + rho_soft : gjj;
                 R ynew = rj;
+                if constexpr (sizeof(R) == 4) {
+                    // binary32: (q_i, y_i) travel as ONE 64-bit broadcast and the two chains advance in one packed fma
+                    typedef float rw_f2 __attribute__((ext_vector_type(2)));
+                    double qy[S];
+#pragma unroll
+                    for (int s = 0; s < S; s++) { const rw_f2 t = {(float)q[s], (float)y[s]}; qy[s] = __builtin_bit_cast(double, t); }
+                    rw_f2 acc = {(float)dnew, (float)ynew};
+                    rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
+                        constexpr int i0 = decltype(B)::value * 4;
+                        if (i0 < namaxQ) {
+                            RW_BLOCK();
+                            rw_static_for<0, 4>([&](auto Q) {
+                                constexpr int i = i0 + decltype(Q)::value;
+                                if constexpr (i < CAPP) {                     // (beyond a working set: l_i = 0)
+                                    const float lq = (float)rw_bc<i>(l[i >> 4]);
+                                    const rw_f2 b = __builtin_bit_cast(rw_f2, rw_bc<i>(qy[i >> 4]));
+                                    const rw_f2 nl = {-lq, -lq};
+                                    acc = __builtin_elementwise_fma(nl, b, acc);
+                                }
+                            });
+                        }
+                    });
+                    dnew = (R)acc.x; ynew = (R)acc.y;
+                } else {
                 rw_static_for<0, (CAPP + 3) / 4>([&](auto B) {
                     constexpr int i0 = decltype(B)::value * 4;
                     if (i0 < namaxQ) {
@@ -1394,6 +1437,7 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                         });
                     }
                 });
+                }
                 const bool singular = (dnew < zero_tol) || (!is_soft && (na - nsoft) >= n);
                 const R dinv = (R)1 / dnew;
                 const int wsn = jadd | (is_soft ? kRowPosFlagSoft : 0) | (((sj & SENSE_IMMUTABLE) || (BNB && immX)) ? kRowPosFlagImm : 0) |
