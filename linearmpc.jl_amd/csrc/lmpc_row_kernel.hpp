@@ -1199,10 +1199,54 @@ __global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_p
                 const bool full = addp && na >= cap;
                 flag = full ? EXIT_WSCAP : flag; fin = full ? 1 : fin; addp = full ? 0 : addp;
             }
+            // (branch and bound) ... and a node that ends here WITHOUT branching -- a leaf, a pruned node, a relaxation that
+            // failed -- backtracks here too: back to the deepest node with an untried side (restore), that node's
+            // multipliers by one more backward sweep, and its second child's fixed row joins this trip's append.  (Behind
+            // the trip, the search's other moves' place, the fixed row's append costs the row a trip of its own: one in
+            // seven.)  The search's last node, the node limit and a descent that the capacity blocks go the long way.
+            bool flipE = false;
+            if constexpr (BNB) {
+                const bool endE = doAdd != 0 && fin != 0 && flag != EXIT_WSCAP;
+                const bool leafE = endE && flag >= 1 && jbX == kRowBig;
+                const bool blockedE = endE && flag >= 1 && jbX != kRowBig;
+                const unsigned long long open = ~tried2 & ((1ull << depth) - 1ull);
+                flipE = endE && !blockedE && open != 0ull && nodes + 1 < 100000;
+                if (rw_any(flipE)) {
+                    RWS_BEGIN;
+                    nodes = flipE ? nodes + 1 : nodes;
+                    total_it = flipE ? total_it + iter : total_it;
+                    const bool better = flipE && leafE && (!have || fvalN < bestval);
+                    have = better ? 1 : have; bestval = better ? fvalN : bestval;
+                    bestact = better ? actb : bestact; bestlow = better ? lowb : bestlow;
+#pragma unroll
+                    for (int s = 0; s < NS; s++) ubest[s] = better ? un[s] : ubest[s];
+                    depth = flipE ? 64 - (int)__builtin_clzll(open | 1ull) : depth;     // (open != 0 for these rows)
+                    const int d = flipE ? depth - 1 : 0;
+                    const int e = stk_get(d);
+                    const int ne = e ^ (1 << 10);
+#pragma unroll
+                    for (int q = 0; q < DS; q++) stk[q] = (flipE && (d >> 4) == q && li == (d & 15)) ? ne : stk[q];
+                    tried2 = flipE ? (tried2 | (1ull << d)) : tried2;
+                    restore(flipE, d, e);
+                    {
+                        R v[S];
+#pragma unroll
+                        for (int s = 0; s < S; s++) v[s] = flipE ? y[s] * Dinv[s] : (R)0;
+                        sweep_bwd(v, rw_max4(flipE ? na : 0) - 1);
+#pragma unroll
+                        for (int s = 0; s < S; s++) ls[s] = flipE ? (pos[s] < na ? v[s] : (R)0) : ls[s];
+                        rls = flipE ? 0 : rls;
+                    }
+                    fin = flipE ? 0 : fin; addp = flipE ? 1 : addp; mt = flipE ? 2 * (ne & 1023) + ((ne >> 10) & 1) : mt;
+                    immX = flipE ? 1 : immX;
+                    iter = flipE ? 1 : iter; cyc = flipE ? 0 : cyc; best = flipE ? (R)-1 : best;
+                    RWS_END(20);
+                }
+            }
             RWT(5);
             // ---- append row jadd to the working sets of the rows with addp, first half: the Gram entries G(W_i, jadd) are
             // requested here (L2: ~a microsecond), the factor is extended behind the removal phase of the other rows
-            addpX = addp; fvalX = fvalN; mtX = mt;
+            addpX = addp; fvalX = flipE ? fval : fvalN; mtX = mt;
             if constexpr (!BNB) gather();
         }
         if constexpr (BNB) {
