@@ -474,3 +474,34 @@ def test_settings_layout_is_the_same_in_every_binding(lmpc):
     # ... and the constructor passes the fields in that order
     ctor = re.search(r"return LmpcSettings\((.*?)\)\nend", jl, re.S).group(1)
     assert [a.strip().split(".")[-1] for a in ctor.replace("\n", " ").split(",")] == [n for n, _ in c_fields]
+
+
+def test_row_kernel_column_order_tables_are_valid_layouts():
+    """The row kernel's factor layouts with a searched column order (lmpc_row_kernel.hpp rowp_cbm: 31 rows, and 48 rows
+    with every column padded by one entry): no two entries share an address, everything lies inside rowp_size, and the
+    16 columns of each slot of positions start at 16 different offsets modulo 16 (what makes column accesses free of LDS
+    bank conflicts)."""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "linearmpc.jl_amd", "csrc", "lmpc_row_kernel.hpp")).read()
+
+    def table(name):
+        m = re.search(r"constexpr int " + name + r"\[\d+\] = \{([^}]*)\}", src)
+        assert m, name
+        return [int(v) for v in m.group(1).replace("\n", " ").split(",")]
+
+    for name, rows, lrow, size in (("k31", 31, 31, None), ("k48", 48, 49, 1291)):
+        cbm = table(name)
+        assert len(cbm) == rows - 1
+        if size is None:                                    # rowp_cb(capp, capp - 1) of the unpadded layout
+            q, r = (rows - 1) >> 2, (rows - 1) & 3
+            size = 4 * q * rows - 8 * q * (q - 1) + r * (rows - 4 * q)
+        used = set()
+        for t, c in enumerate(cbm):
+            p0 = t & ~3
+            for p in range(p0, lrow):                        # column t holds rows p0(t) .. lrow-1 at cbm(t) + p
+                a = c + p
+                assert 0 <= a < size and a not in used, (name, t, p)
+                used.add(a)
+        for g in range((rows - 1 + 15) // 16):
+            starts = [cbm[t] % 16 for t in range(16 * g, min(16 * g + 16, rows - 1))]
+            assert len(set(starts)) == len(starts), (name, g)
