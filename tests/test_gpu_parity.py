@@ -2956,3 +2956,37 @@ def test_row_kernel_binary32_plain_solves(lmpc, name):
     assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
     assert np.abs(x[sel] - xo).max() == 0.0
     assert (ef >= 1).any()
+
+
+def test_row_kernel_branch_and_bound_scratch_and_streams(lmpc):
+    # the search's snapshot scratch is per handle and sized by the grid: released and allocated again between calls, and two
+    # handles searching at once on two streams, the answers stay the same
+    import torch
+    g = load_golden("satellite20")
+    s = lmpc.default_settings_f32()
+    rng = np.random.default_rng(21)
+    base = g["theta"]
+    N = 12000
+    theta = (base[rng.integers(0, len(base), N)] * rng.uniform(0.4, 1.5, (N, 1))).astype(np.float32)
+    th_d = torch.from_numpy(theta).cuda()
+    qps = [lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+           for _ in range(2)]
+    x0, ef0 = qps[0].solve_device(th_d)                      # (N >= 8192: the row kernel by default)
+    torch.cuda.synchronize()
+    ref = (x0.cpu().numpy(), ef0.cpu().numpy())
+    qps[0].release_scratch()
+    x1, ef1 = qps[0].solve_device(th_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(x1.cpu().numpy(), ref[0]) and np.array_equal(ef1.cpu().numpy(), ref[1])
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = []
+    for r in range(3):
+        for q, st in zip(qps, streams):
+            outs.append(q.solve_device(th_d, stream=st.cuda_stream))
+    torch.cuda.synchronize()
+    for x, ef in outs:
+        assert np.array_equal(x.cpu().numpy(), ref[0]) and np.array_equal(ef.cpu().numpy(), ref[1])
+    qps[0].set_option("row_kernel", 0)
+    xw, efw = qps[0].solve_device(th_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(xw.cpu().numpy(), ref[0]) and np.array_equal(efw.cpu().numpy(), ref[1])
