@@ -302,13 +302,15 @@ extern template int launch_row<double>(lmpc_handle *, const double *, int64_t, c
                                        uint64_t *, hipStream_t, int, int);
 extern template int launch_row<float>(lmpc_handle *, const float *, int64_t, const float *, float *, int32_t *, int32_t *,
                                       uint64_t *, hipStream_t, int, int);
-// ... with branch and bound (binary32)
+// ... with branch and bound
 int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs);
 template <typename R>
 int launch_row_bnb(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x, int32_t *flag, int32_t *iters,
                    uint64_t *active, hipStream_t st, int cap, int pass);
 extern template int launch_row_bnb<float>(lmpc_handle *, const float *, int64_t, const float *, float *, int32_t *, int32_t *,
                                           uint64_t *, hipStream_t, int, int);
+extern template int launch_row_bnb<double>(lmpc_handle *, const double *, int64_t, const double *, double *, int32_t *, int32_t *,
+                                           uint64_t *, hipStream_t, int, int);
 
 // launch of the wavefront kernel for one batch (defined in lmpc_wave_launch.hpp, instantiated once per
 // (R, BNB) in lmpc_wave_inst.hip)

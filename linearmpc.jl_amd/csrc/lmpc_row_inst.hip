@@ -21,7 +21,7 @@ constexpr RowShape kRowShapes[] = {
     {2, 4, 10, 32},     // ... <= 32 rows
 };
 
-// ... with branch and bound (rows flagged BINARY; binary32)
+// ... with branch and bound (rows flagged BINARY)
 constexpr RowShape kRowShapesBnb[] = {
     {1, 1, 2, 16},      // n <= 16, m <= 32, <= 16 rows (the satellite example at Np = 4: n = m = 12)
     {3, 4, 4, 48},      // n <= 64, m <= 64, <= 48 rows (BASELINE config 5, satellite Np = 20: n = m = 60, 40 binaries -- first of two passes)
@@ -47,13 +47,13 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bo
         int bestWaves = 0;
         const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS, (int)rs);
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
-            if (64 * nwv > row_launch_bound(sh.MS)) continue;
+            if (64 * nwv > row_launch_bound(sh.MS, sh.S, (int)rs)) continue;
             const int ps = bnb ? row_ps4(sh.CAPP, nwv) : row_ps(sh.CAPP, nwv);
             if (ps < 0) continue;
             const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
             int blocks = (int)(kLdsMax / lds);
-            const int maxw = 4 * row_waves_per_simd(sh.S, sh.MS);
+            const int maxw = 4 * row_waves_per_simd(sh.S, sh.MS, (int)rs);
             if (blocks * nwv > maxw) blocks = maxw / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
@@ -196,10 +196,10 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     return cap;
 }
 
-// ... for a handle with binary rows (binary32): the problem's own capacity if 16 rows hold it, else 48 rows as the first
+// ... for a handle with binary rows: the problem's own capacity if 16 rows hold it, else 48 rows as the first
 // of two passes when that leaves eight rows beyond the binaries (the wavefront kernel's rule, bnb_first_pass_cap)
 int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
-    if (h->rowKernel == 0 || !h->bnb || rs != 4 || h->avi || h->waveGram != 0) return 0;
+    if (h->rowKernel == 0 || !h->bnb || h->avi || h->waveGram != 0) return 0;
     if (h->waveSim.FG != nullptr || h->keepOn || nprob >= (int64_t)0x3fffffff) return 0;
     if (h->rowKernel < 0 && nprob < 8192) return 0;
     for (int j = 0; j < h->P.m; j++)

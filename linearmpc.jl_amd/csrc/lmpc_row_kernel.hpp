@@ -32,7 +32,7 @@
 // Covers: cold plain solves, binary64 / binary32, n <= 16 NS, m <= 16 MS, hard / SOFT / IMMUTABLE rows, no rows
 // flagged ACTIVE, working sets up to CAPP <= 16 S rows; a point that outgrows that is listed for the wavefront kernel
 // (exit flag -7 inside this pass), exactly like the first of that kernel's two passes.  Rows flagged BINARY: the BNB
-// instantiations (binary32), one depth-first search per row of the wavefront (see the search state below).
+// instantiations, one depth-first search per row of the wavefront (see the search state below).
 //
 // Replaces, per problem: mpc_update_qp (reference codegen/mpc_update_qp.c:1-10), daqp_ldp incl. soft constraints
 // ([EXT] libdaqp, called at mpc_update_qp.c:48 / utils.jl:282) and mpc_get_solution (mpc_update_qp.c:14-22).
@@ -206,13 +206,14 @@ __host__ __device__ constexpr int row_bnb_depth_max(int ms) { return (16 * ms < 
 // threads per workgroup an instantiation is built for: 512 (two wavefronts per SIMD, 256 registers) up to six constraint
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
 // LDS for five wavefronts' factors anyway)
-__host__ __device__ constexpr int row_launch_bound(int ms) { return ms <= 6 ? 512 : 256; }
+// ... and the three-slot shape in binary64 (branch and bound at 48 rows: 300 + registers)
+__host__ __device__ constexpr int row_launch_bound(int ms, int s = 2, int rs = 4) { return (ms > 6 || (s >= 3 && rs == 8)) ? 256 : 512; }
 // resident wavefronts per SIMD an instantiation is register-budgeted for: three for one slot of positions (small factors:
 // LDS allows them, 168 registers), two for two slots with up to six constraint slots, one beyond
 #ifndef LMPC_ROW_WPS1
 #define LMPC_ROW_WPS1 3
 #endif
-__host__ __device__ constexpr int row_waves_per_simd(int s, int ms) { return ms > 6 ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
+__host__ __device__ constexpr int row_waves_per_simd(int s, int ms, int rs = 4) { return (ms > 6 || (s >= 3 && rs == 8)) ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
 
 // One sweep step as ONE statement of inline assembly (no builtin reaches v_fmac_f64_dpp, and the wait states have to sit
 // right in front of the instruction): NOP + 1 wait states (2 behind a vector instruction that wrote `src`; the compiler
@@ -283,7 +284,7 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 // BNB: rows flagged BINARY end up active at one of their bounds -- the wavefront kernel's depth-first search (its header),
 // one search per row of the wavefront, every row at its own node.
 template <typename R, int S, int NS, int MS, int CAPP, bool BNB = false>
-__global__ __launch_bounds__(row_launch_bound(MS)) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS)))) void row_kernel(const RowParams<R> prm) {
+__global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS, (int)sizeof(R))))) void row_kernel(const RowParams<R> prm) {
     static_assert(S >= 1 && S <= 4, "one to four slots of working-set positions");
     static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)

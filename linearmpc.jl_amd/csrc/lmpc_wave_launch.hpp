@@ -454,7 +454,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             const int rcap = row_pass_cap(h, (int64_t)1 << 20, sizeof(R), false, GRAM, BNB);
             if (rcap > 0) (void)launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
         }
-        if constexpr (BNB && !GRAM && sizeof(R) == 4) {
+        if constexpr (BNB && !GRAM) {
             const int rcap = row_bnb_pass_cap(h, (int64_t)1 << 20, sizeof(R));
             if (rcap > 0) (void)launch_row_bnb<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
         }
@@ -483,7 +483,7 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
             return rc;
         }
     }
-    if constexpr (BNB && !GRAM && sizeof(R) == 4) {           // ... four searches per wavefront
+    if constexpr (BNB && !GRAM) {           // ... four searches per wavefront
         const int rcap = row_bnb_pass_cap(h, nprob, sizeof(R));
         if (rcap > 0) {
             if (rcap >= capW) {

@@ -2990,3 +2990,48 @@ def test_row_kernel_branch_and_bound_scratch_and_streams(lmpc):
     xw, efw = qps[0].solve_device(th_d)
     torch.cuda.synchronize()
     assert np.array_equal(xw.cpu().numpy(), ref[0]) and np.array_equal(efw.cpu().numpy(), ref[1])
+
+
+@pytest.mark.parametrize("name", ["satellite4", "satellite20"])
+def test_row_kernel_branch_and_bound_f64(lmpc, name):
+    # binary64 searches on the row kernel (one wavefront per SIMD: 336 registers): identical to the wavefront kernel and, on
+    # a sample, to the oracle
+    import torch
+    from oracle import ldp as oldp
+    g = load_golden(name)
+    qp = _qp_from_golden(lmpc, g)
+    rng = np.random.default_rng(18)
+    base = g["theta"]
+    N = 3000 if name == "satellite20" else 6000
+    theta = base[rng.integers(0, len(base), N)] * rng.uniform(0.2, 1.6, (N, 1)) + rng.normal(0, 0.01, (N, base.shape[1]))
+    theta[: len(base)] = base[:N]
+    th_d = torch.from_numpy(theta).cuda()
+    out = {}
+    for mode in (0, 1):
+        qp.set_option("row_kernel", mode)
+        it_d = torch.empty(N, dtype=torch.int32, device="cuda")
+        ac_d = torch.zeros((N, qp.words), dtype=torch.int64, device="cuda")
+        x_d, ef_d = qp.solve_device(th_d, iters=it_d, active=ac_d)
+        torch.cuda.synchronize()
+        qp.check()
+        out[mode] = (x_d.cpu().numpy(), ef_d.cpu().numpy(), it_d.cpu().numpy(), ac_d.cpu().numpy().view(np.uint64))
+    for q in range(4):
+        assert np.array_equal(out[0][q], out[1][q], equal_nan=(q == 0))
+    sel = np.arange(0, N, max(1, N // 150))
+    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
+    x, ef, it, act = out[1]
+    assert np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(act[sel], acto)
+    assert np.abs(x[sel] - xo).max() == 0.0
+    assert (ef == 1).mean() > 0.9
+
+
+def test_row_kernel_branch_and_bound_fuzz_f64(lmpc):
+    import importlib.util
+    from oracle import ldp as oldp
+    spec = importlib.util.spec_from_file_location("fuzz_row_bnb", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_row_bnb.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(14)
+    for t in range(24):
+        same, ok, n, m, nb, solved, its = fz.run_trial(rng, t % 2 == 1, 1500, None, oldp.Settings, True)
+        assert same and ok, (t, n, m, nb)

@@ -1,8 +1,8 @@
-"""Randomized parity of the row kernel's branch and bound (binary32) against the wavefront kernel: random hybrid problems
+"""Randomized parity of the row kernel's branch and bound (binary32; --f64 / --mixed: binary64) against the wavefront kernel: random hybrid problems
 (binaries among the simple bounds, general rows, soft rows; infeasible assignments and infeasible problems) in both
 instantiations -- up to 16 rows (n <= 15) and up to 48 rows (n <= 47, taken on request as the only pass) -- every output
 compared bit for bit; a sample of each trial against the binary32 oracle.
-Usage: python tools/fuzz_row_bnb.py [trials] [seed]"""
+Usage: python tools/fuzz_row_bnb.py [trials] [seed] [--f64 | --mixed]"""
 import os
 import sys
 
@@ -36,10 +36,10 @@ def random_hybrid(rng, big):
     return H, np.zeros(n), rng.standard_normal((n, nth)), A, bu, bl, W, sense
 
 
-def run_trial(rng, big, N, s, so_cls):
+def run_trial(rng, big, N, s, so_cls, f64=False):
     H, f, fth, A, bu, bl, W, sense = random_hybrid(rng, big)
-    qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense, settings=s)
-    theta = (rng.uniform(-1, 1, (N, W.shape[1])) * rng.choice([0.3, 1.0, 2.5])).astype(np.float32)
+    qp = lmpc.BatchedQP.from_mpqp(H, f, fth, A, bu, bl, W, sense, **({} if f64 else {"settings": s}))
+    theta = (rng.uniform(-1, 1, (N, W.shape[1])) * rng.choice([0.3, 1.0, 2.5])).astype(np.float64 if f64 else np.float32)
     th_d = torch.from_numpy(theta).cuda()
     out = {}
     for mode in (0, 1):
@@ -52,11 +52,14 @@ def run_trial(rng, big, N, s, so_cls):
         out[mode] = (x_d.cpu().numpy(), ef_d.cpu().numpy(), it_d.cpu().numpy(), ac_d.cpu().numpy())
     same = all(np.array_equal(out[0][q], out[1][q], equal_nan=(q == 0)) for q in range(4))
     from oracle import ldp as oldp
-    so = so_cls()
-    for fl, _ in so._fields_:
-        setattr(so, fl, getattr(s, fl, 0))
     sel = np.arange(0, N, max(1, N // 40))
-    xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], so, dtype=np.float32)
+    if f64:
+        xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
+    else:
+        so = so_cls()
+        for fl, _ in so._fields_:
+            setattr(so, fl, getattr(s, fl, 0))
+        xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], so, dtype=np.float32)
     x, ef, it, ac = out[1]
     ok = (np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(ac[sel].view(np.uint64), acto)
           and np.array_equal(x[sel], xo, equal_nan=True))
@@ -70,14 +73,16 @@ def main(trials=40, seed=1):
     bad = 0
     for t in range(trials):
         big = t % 2 == 1
-        same, ok, n, m, nb, solved, its = run_trial(rng, big, 1500, s, oldp.Settings)
+        f64 = "--f64" in sys.argv or ("--mixed" in sys.argv and t % 4 >= 2)
+        same, ok, n, m, nb, solved, its = run_trial(rng, big, 1500, s, oldp.Settings, f64)
         if not (same and ok):
             bad += 1
-        print(f"trial {t:3d} n={n:2d} m={m:2d} binaries={nb} solved {solved:.2f} iterations {its:7.1f}: "
+        print(f"trial {t:3d} {'f64' if f64 else 'f32'} n={n:2d} m={m:2d} binaries={nb} solved {solved:.2f} iterations {its:7.1f}: "
               f"{'identical' if same else 'DIFFERENT from the wavefront kernel'}, {'oracle ok' if ok else 'ORACLE MISMATCH'}", flush=True)
     print("OK" if not bad else f"FAILED ({bad} trials)")
     return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    _a = [a for a in sys.argv[1:] if not a.startswith("--")]
+    sys.exit(main(int(_a[0]) if len(_a) > 0 else 40, int(_a[1]) if len(_a) > 1 else 1))

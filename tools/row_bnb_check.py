@@ -1,5 +1,5 @@
 """Branch and bound on the row kernel (four searches per wavefront, binary32) against the wavefront kernel and the
-binary32 oracle, and its time.  Usage: python tools/row_bnb_check.py [name] [N] [--no-oracle]"""
+binary32 oracle, and its time.  Usage: python tools/row_bnb_check.py [name] [N] [--no-oracle] [--f64]"""
 import os
 import sys
 
@@ -19,15 +19,17 @@ def main():
     name = args[0] if args else "satellite4"
     N = int(args[1]) if len(args) > 1 else 4000
     g = load_golden(name)
-    s = lmpc.default_settings_f32()
-    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"], settings=s)
+    f64 = "--f64" in sys.argv
+    s = None if f64 else lmpc.default_settings_f32()
+    qp = lmpc.BatchedQP.from_mpqp(g["H"], g["f"], g["f_theta"], g["A"], g["bu"], g["bl"], g["W"], g["senses"],
+                                  **({} if f64 else {"settings": s}))
     rng = np.random.default_rng(5)
     base = g["theta"]
     theta = base[rng.integers(0, len(base), N)] * rng.uniform(0.2, 1.6, (N, 1)) + rng.normal(0, 0.01, (N, base.shape[1]))
     theta[: len(base)] = base[:N]
     if name == "satellite20" and N >= 50000:
         theta = bench.make_theta(name, N, 77)
-    theta = theta.astype(np.float32)
+    theta = theta.astype(np.float64 if f64 else np.float32)
     th_d = torch.from_numpy(theta).cuda()
     out = {}
     for mode in (0, 1):
@@ -53,11 +55,14 @@ def main():
           "| flags", dict(zip(*np.unique(out[1][1], return_counts=True))), "| mean iterations", out[1][2].mean())
     if "--no-oracle" not in sys.argv:
         from oracle import ldp as oldp
-        so = oldp.Settings()
-        for f, _ in so._fields_:
-            setattr(so, f, getattr(s, f, 0))
         sel = np.arange(0, N, max(1, N // 300))
-        xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], so, dtype=np.float32)
+        if f64:
+            xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
+        else:
+            so = oldp.Settings()
+            for f, _ in so._fields_:
+                setattr(so, f, getattr(s, f, 0))
+            xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel], so, dtype=np.float32)
         x, ef, it, ac = out[1]
         ok = (np.array_equal(ef[sel], efo) and np.array_equal(it[sel], ito) and np.array_equal(ac[sel], acto)
               and np.abs(x[sel] - xo).max() == 0.0)
