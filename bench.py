@@ -1606,6 +1606,7 @@ def main():
             _phase("config game_avi")
             cfg("game_avi", avi_config, torch, lmpc, dev, local_rank, BATCH, 10, 2, want_cpu)
             cfg("hybrid_f32", side_config, torch, lmpc, "hybrid", 100_000, dev, local_rank, 4, 1, True, want_cpu, 4.0)
+            cfg("hybrid_f64", side_config, torch, lmpc, "hybrid", 100_000, dev, local_rank, 3, 1, False, False, 0.0)   # (the same searches in binary64)
             # the reference's only published numbers (plots, unstated hardware, generated C, one solve at a time
             # in closed loop): quoted beside the batched rate as context, not as a baseline
             ref_us = {50: 11.0, 75: 16.0, 100: 22.0, 125: 31.0}
