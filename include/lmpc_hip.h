@@ -534,11 +534,18 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * (more wavefronts resident) and hand the points that outgrow it to a second launch at the full capacity;
  * "wave_cap" c (8 .. 64, 0 = the problem's own) = the full capacity itself, points beyond it go to the slow path.
  * Neither changes a result.
+ * "row_kernel" (default -1): cold plain batches and branch-and-bound searches of 8 192 problems and more with n <= 64
+ * variables, m <= 160 rows (searches: m <= 64, up to 47 binary rows) run on the four-problems-per-wavefront kernel
+ * (lmpc_row_kernel.hpp: one problem per 16-lane DPP row) where the handle's statistics let its working-set capacity --
+ * 16 / 31 / 32 rows, searches 16 / 48 -- hold nearly all points; what outgrows it is listed for the wavefront kernel
+ * (the two-pass protocol above).  -1 = where it measured faster (binary64 every shape, binary32 the two-slot shape and
+ * the searches), 1 = wherever an instantiation covers the problem, whatever the batch size, 0 = never.  "row_blocks" =
+ * its workgroups per CU (tuning).  Results identical either way (tools/fuzz_row.py, tools/fuzz_row_bnb.py).
  * "qp_tiers": problems with n = 2 .. 12 variables and up to 64 hard or SOFT rows (no other flags) can send cold plain
  * binary64 batches through a tiers pass (one problem per lane, append-only paths finished in registers) in front of the
  * wavefront / lane kernel.  2 = always, 0 = never (the screening pass as before), 1 (default) = yes -- and for batches of
- * 65 536 problems and more on the wavefront path whichever of the two the handle has measured faster (one call each way,
- * timed by events that later calls read without waiting; measured again every 512 calls).  Results identical either way.
+ * 65 536 problems and more on the wavefront path whichever of the two the handle has measured faster (the best of three
+ * calls each way, timed by events that later calls read without waiting; measured again every 512 calls).  Results identical either way.
  * Variational handles (is_avi) with n <= 8 simple bounds run a chain of register-resident kernels in front of the
  * generic one: "avi_tiers" (default 1; 0 = the generic kernel alone), "avi_tiers_first" (-1 = default: 3 up to n = 6,
  * else 2; 1 .. 3 = straight-line tiers of the pass over the whole batch; 0 = the complete lane kernel over the whole
