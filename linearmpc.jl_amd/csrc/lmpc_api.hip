@@ -100,7 +100,10 @@ int finalize_handle(lmpc_handle *h) {
     // (branch and bound: one row more -- the row a node has just fixed enters on top of its parent's final working set,
     // whatever that holds; the oracle's arrays have that row too)
     const int cap = std::min(P.n + 1 + P.nsoft + (anyBinary ? 1 : 0), kWaveMaxCap);
-    h->capFull = P.n + 1 + P.nsoft + (anyBinary ? 1 : 0);
+    // ... and what a working set can reach in floating point: one row more (a singular working set that the pivot test
+    // misses takes another row before it fails; the oracle's arrays have that spare row).  A plain solve that wants it
+    // is listed for the slow path, like one that outgrows the 64 rows; a search has it in the kernels (no slow path there).
+    h->capFull = P.n + 2 + P.nsoft;
     const bool waveOk = P.n <= kWaveMaxN && P.m <= kWaveMaxM && P.m >= 1;
     if (!laneOk && !waveOk)
         return fail(h, LMPC_ERR_UNSUPPORTED,
@@ -1192,7 +1195,7 @@ int lmpc_set_option(lmpc_handle *h, const char *name, int value) {
     if (std::strcmp(name, "wave_cap") == 0) {
         // working-set rows the wavefront kernel holds per problem (8 .. 64, at most n + 1 + #soft): a smaller factor in
         // LDS keeps more wavefronts resident; a point that wants more goes to the slow path
-        const int full = h->capFull < kWaveMaxCap ? h->capFull : kWaveMaxCap;
+        const int full = std::min(h->P.n + 1 + h->P.nsoft + (h->bnb ? 1 : 0), kWaveMaxCap);      // (the capacity of setup)
         int c = value <= 0 ? full : (value < 8 ? 8 : value);
         if (c > full) c = full;
         h->W.cap = c; h->W.ldc = c | 1;

@@ -91,7 +91,7 @@ struct lmpc_handle {
     long long *dRegOut = nullptr;   // ... and its device address; regOutWords = its size in 64-bit words
     size_t regOutWords = 0;
     // slow path for working sets beyond the 64 lanes (lmpc_big_kernel.hpp): overflow list + counter, per-thread scratch
-    int capFull = 0;            // n + 1 + #soft: the rows a working set of this problem can hold
+    int capFull = 0;            // n + 2 + #soft: the rows a working set of this problem can reach (one beyond the kernels' own n + 1 + #soft)
     int32_t *dOvfList = nullptr, *dOvfCount = nullptr, *dBigI = nullptr;
     void *dBigR = nullptr;
     int64_t ovfCap = 0;

@@ -465,7 +465,9 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
     if constexpr (!BNB && !GRAM) {
         const int rcap = row_pass_cap(h, nprob, sizeof(R), warm != nullptr, GRAM, BNB);
         if (rcap > 0) {
-            if (rcap >= capW) {
+            // (as the only pass where nothing lies behind its capacity; else what outgrows it is listed: for this kernel's
+            // second pass and, behind that, the slow path)
+            if (rcap >= capW && !(h->bigPath && h->capFull > capW)) {
                 rc = launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 0);
             } else {
                 h->wavePass = 1;

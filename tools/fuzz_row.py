@@ -66,9 +66,8 @@ def run_trial(rng, f32, N):
     else:
         xo, efo, ito, acto = oldp.solve_batch(oracle_ldp_from(qp.ldp()), theta[sel])
     x, ef, it, ac = out[1]
-    # (known limit, DESIGN section 6: a plain solve whose working set wants n + 2 + #soft rows ends with exit flag -7 on the
-    # kernels; the oracle's arrays have one spare row, it goes one iteration further and fails with -1 / -2.  Such points --
-    # failed on both sides -- are counted, not compared)
+    # (a working set that wants more than n + 2 + #soft rows ends with exit flag -7 on the kernels and has
+    # no room in the oracle's arrays either; such points -- none seen so far -- are counted, not compared)
     lim = (ef[sel] == -7) & (efo < 0)
     keep = ~lim
     ok = (np.array_equal(ef[sel][keep], efo[keep]) and np.array_equal(it[sel][keep], ito[keep])
