@@ -3035,3 +3035,18 @@ def test_row_kernel_branch_and_bound_fuzz_f64(lmpc):
     for t in range(24):
         same, ok, n, m, nb, solved, its = fz.run_trial(rng, t % 2 == 1, 1500, None, oldp.Settings, True)
         assert same and ok, (t, n, m, nb)
+
+
+def test_row_kernel_fuzz_plain_solves(lmpc):
+    # random plain problems over all instantiations, binary64 and binary32 alternating (tools/fuzz_row.py): the row kernel
+    # identical to the wavefront kernel, a sample of every trial identical to the oracle.  Seed 5 holds the problem (trial
+    # 297: binary32, n = 13, one soft row) whose working sets reach n + 2 + #soft rows: those points now go through the
+    # slow path and end with the oracle's flag (they used to keep exit flag -7)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_row", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_row.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(5)
+    for t in range(300):
+        same, ok, n, m, kn, solved, its, nlim = fz.run_trial(rng, t % 2 == 1, 3000)
+        assert same and ok and nlim == 0, (t, n, m, kn, nlim)
