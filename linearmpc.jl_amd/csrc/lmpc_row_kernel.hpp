@@ -207,13 +207,16 @@ __host__ __device__ constexpr int row_bnb_depth_max(int ms) { return (16 * ms < 
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
 // LDS for five wavefronts' factors anyway)
 // ... and the three-slot shape in binary64 (branch and bound at 48 rows: 300 + registers)
-__host__ __device__ constexpr int row_launch_bound(int ms, int s = 2, int rs = 4) { return (ms > 6 || (s >= 3 && rs == 8)) ? 256 : 512; }
+#ifndef LMPC_ROW_WIDE10
+#define LMPC_ROW_WIDE10 0        // (experiment: the ten-slot shape budgeted for two wavefronts per SIMD)
+#endif
+__host__ __device__ constexpr int row_launch_bound(int ms, int s = 2, int rs = 4) { return ((ms > 6 && !LMPC_ROW_WIDE10) || (s >= 3 && rs == 8)) ? 256 : 512; }
 // resident wavefronts per SIMD an instantiation is register-budgeted for: three for one slot of positions (small factors:
 // LDS allows them, 168 registers), two for two slots with up to six constraint slots, one beyond
 #ifndef LMPC_ROW_WPS1
 #define LMPC_ROW_WPS1 3
 #endif
-__host__ __device__ constexpr int row_waves_per_simd(int s, int ms, int rs = 4) { return (ms > 6 || (s >= 3 && rs == 8)) ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
+__host__ __device__ constexpr int row_waves_per_simd(int s, int ms, int rs = 4) { return ((ms > 6 && !LMPC_ROW_WIDE10) || (s >= 3 && rs == 8)) ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
 
 // One sweep step as ONE statement of inline assembly (no builtin reaches v_fmac_f64_dpp, and the wait states have to sit
 // right in front of the instruction): NOP + 1 wait states (2 behind a vector instruction that wrote `src`; the compiler
