@@ -442,7 +442,8 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
 #ifndef LMPC_ROW_CHS
 #define LMPC_ROW_CHS 4
 #endif
-    constexpr int CHS = LMPC_ROW_CHS;
+    // (the binary32 three-slot shape -- branch and bound at 48 rows -- measured 1 % faster with blocks of eight)
+    constexpr int CHS = (sizeof(R) == 4 && S >= 3) ? 8 : LMPC_ROW_CHS;
     auto sweep_fwd = [&](R (&v)[S], int nmax) {
         constexpr int NB = (CAPP - 1 + CHS - 1) / CHS;               // steps t = 0 .. CAPP-2
         R Ln[CHS][S];
@@ -1063,7 +1064,8 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
 #ifndef LMPC_ROW_CHK6
 #define LMPC_ROW_CHK6 2
 #endif
-            constexpr int CHK = LMPC_ROW_CHK6, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
+            // (binary32 with four constraint slots: rows of 16 bytes per lane, four of them in flight measured 3 % faster)
+            constexpr int CHK = (sizeof(R) == 4 && MS == 4) ? 4 : LMPC_ROW_CHK6, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
                 constexpr int PW = (sizeof(R) == 4 && MS % 4 == 0) ? 4 : 2;      // entries per load (16 bytes where they line up)
