@@ -981,7 +981,10 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
 #pragma unroll
             for (int s = 0; s < NS; s++) un[s] = (R)0;
             // u = -M_W' lam*  (rows beyond a working set: lam* = 0 there, row 0 of M)
-            constexpr int CHP = 4, NBP = (CAPP + CHP - 1) / CHP;
+#ifndef LMPC_ROW_CHP
+#define LMPC_ROW_CHP 4
+#endif
+            constexpr int CHP = LMPC_ROW_CHP, NBP = (CAPP + CHP - 1) / CHP;
             {
                 R mn[CHP][NS], ln[CHP];
                 // binary32: a position's offset and its multiplier travel as ONE 64-bit broadcast (the multiplier is used a
