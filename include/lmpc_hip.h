@@ -534,8 +534,9 @@ int lmpc_profile_read(lmpc_handle *h, double avg_ms[3]);
  * (more wavefronts resident) and hand the points that outgrow it to a second launch at the full capacity;
  * "wave_cap" c (8 .. 64, 0 = the problem's own) = the full capacity itself, points beyond it go to the slow path.
  * Neither changes a result.
- * "row_kernel" (default -1): cold plain batches and branch-and-bound searches of 8 192 problems and more with n <= 64
- * variables, m <= 160 rows (searches: m <= 64, up to 47 binary rows) run on the four-problems-per-wavefront kernel
+ * "row_kernel" (default -1): cold plain batches with n <= 64 variables, m <= 160 rows (from 8 192 problems on; 16 < n <= 32,
+ * m <= 96: whatever the batch size) and branch-and-bound searches (m <= 64, up to 47 binary rows; whatever the batch
+ * size: ONE search takes 1.0 ms there against 1.5 ms) run on the four-problems-per-wavefront kernel
  * (lmpc_row_kernel.hpp: one problem per 16-lane DPP row) where the handle's statistics let its working-set capacity --
  * 16 / 31 / 32 rows, searches 16 / 48 -- hold nearly all points; what outgrows it is listed for the wavefront kernel
  * (the two-pass protocol above).  -1 = where it measured faster (binary64 every shape, binary32 the two-slot shape and

@@ -1131,6 +1131,7 @@ const char *lmpc_kernel_name(const lmpc_handle *h) {
         }
         // (large cold plain binary64 batches: four problems per wavefront where that kernel is the default)
         if (row_pass_cap(const_cast<lmpc_handle *>(h), (int64_t)1 << 20, sizeof(double), false, h->waveGram != 0, h->bnb) > 0) return "row|wave";
+        if (h->bnb && row_bnb_pass_cap(const_cast<lmpc_handle *>(h), (int64_t)1 << 20, sizeof(double)) > 0) return "row|wave";
         return "wave";
     }
     // small boxed problems: cold plain batches take the one-launch kernel, everything else on the handle (warm

@@ -170,7 +170,10 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
 int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram, bool bnb) {
     if (h->rowKernel == 0 || bnb || gram || warm || h->avi) return 0;
     if (h->waveSim.FG != nullptr || h->keepOn || nprob >= (int64_t)0x3fffffff) return 0;
-    if (h->rowKernel < 0 && nprob < 8192) return 0;              // (a handful of problems: one per wavefront has the shorter latency)
+    // (small batches: the two-slot shape is ahead down to a single problem -- config 3's class 0.14 against 0.17 ms for one
+    // solve, 0.53 against 0.63 ms for 512 --, the one-slot and ten-slot shapes only from a few thousand problems on)
+    const bool twoSlot = h->P.n > 16 && h->P.n <= 32 && h->P.m <= 96;
+    if (h->rowKernel < 0 && nprob < 8192 && !twoSlot) return 0;
     for (int j = 0; j < h->P.m; j++)
         if (h->P.sense[j] & (SENSE_ACTIVE | SENSE_BINARY)) return 0;
     if (h->S.iter_limit < 2) return 0;
@@ -201,7 +204,8 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
 int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     if (h->rowKernel == 0 || !h->bnb || h->avi || h->waveGram != 0) return 0;
     if (h->waveSim.FG != nullptr || h->keepOn || nprob >= (int64_t)0x3fffffff) return 0;
-    if (h->rowKernel < 0 && nprob < 8192) return 0;
+    // (whatever the batch size: a search takes 110 trips here against 185 iterations + 41 node starts on the wavefront
+    // kernel -- ONE search 0.98 against 1.50 ms in binary32, 1.18 against 1.84 ms in binary64)
     for (int j = 0; j < h->P.m; j++)
         if (h->P.sense[j] & SENSE_ACTIVE) return 0;
     if (h->S.iter_limit < 2 || h->nBinary > 47) return 0;
