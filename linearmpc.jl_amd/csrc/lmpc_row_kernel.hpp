@@ -531,7 +531,8 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
     // size (13-19) and its count of soft rows (20-26); next to it the node's objective (stkf) and, in every lane, one byte
     // per depth with the activity bits of the lane's rows at that node (abyte).  What an append changes about a node is
     // thereby kept without memory traffic: its second child starts by cutting the working set back (and takes the
-    // node's multipliers from the next trip's backward sweep, which runs anyway).  The positions' registers and the
+    // node's multipliers from one backward sweep over the restored factor: in the trip that backtracks, see the add
+    // phase; a backtrack decided behind the trip -- the rare moves -- from the next trip's sweep, `rls`).  The positions' registers and the
     // factor go to global scratch only before the first removal that would disturb them (snap_clean / snap_saved, one
     // bit per depth: the wavefront kernel's lazy snapshots); `tried2`: both sides of that depth's row have been tried.
     static_assert(!BNB || MS <= 4, "a byte per depth holds the activity bits of up to four rows per lane");
