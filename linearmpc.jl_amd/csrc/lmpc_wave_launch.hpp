@@ -168,6 +168,13 @@ inline int wave_reserve_impl(lmpc_handle *h, int64_t nprob, hipStream_t st) {
         HIP_TRY(h, hipMemsetAsync(h->dQueue, 0, 64, st));
         h->waveCtrSet = 0; h->waveOvfSet = 0;
     }
+    // (the first-pass list: a first pass may run on any handle since the row kernel takes batches of every size -- plain
+    // solves as the first of two passes whenever the slow path lies behind its capacity, searches at 48 rows)
+    if (h->waveTwoPass != 0 && nprob < (int64_t)0x7fffffff && nprob > h->ovfCap1) {
+        hipFree(h->dOvfList1); h->dOvfList1 = nullptr; h->ovfCap1 = 0;
+        HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
+        h->ovfCap1 = nprob;
+    }
     if (h->bnb || nprob >= (int64_t)0x7fffffff) return LMPC_OK;
     if (!h->hStat) {
         unsigned long long *hp = nullptr;
@@ -177,11 +184,6 @@ inline int wave_reserve_impl(lmpc_handle *h, int64_t nprob, hipStream_t st) {
         HIP_TRY(h, hipHostGetDevicePointer(reinterpret_cast<void **>(&h->dStatHost), hp, 0));
         HIP_TRY(h, hipMalloc(&h->dStat, sizeof(unsigned long long) * 64 * 16));
         HIP_TRY(h, hipMemsetAsync(h->dStat, 0, sizeof(unsigned long long) * 64 * 16, st));
-    }
-    if (h->bigPath && h->W.cap >= 40 && h->waveTwoPass != 0 && nprob > h->ovfCap1) {      // a first pass may run
-        hipFree(h->dOvfList1); h->dOvfList1 = nullptr; h->ovfCap1 = 0;
-        HIP_TRY(h, hipMalloc(&h->dOvfList1, sizeof(int32_t) * (size_t)nprob));
-        h->ovfCap1 = nprob;
     }
     if (h->bigPath && h->capFull > h->W.cap) {                                            // the slow path may run
         if (nprob > h->ovfCap) {

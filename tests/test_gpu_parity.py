@@ -3050,3 +3050,37 @@ def test_row_kernel_fuzz_plain_solves(lmpc):
     for t in range(300):
         same, ok, n, m, kn, solved, its, nlim = fz.run_trial(rng, t % 2 == 1, 3000)
         assert same and ok and nlim == 0, (t, n, m, kn, nlim)
+
+
+def test_row_kernel_calls_captured_in_a_graph(lmpc):
+    # lmpc_reserve, then an even number of calls captured in a hipGraph and replayed: the row kernel (plain solves as the
+    # first of two passes, the second pass and the slow path behind it) allocates nothing inside the capture
+    import torch
+    g = load_golden("mass_spring_3in")
+    qp = _qp_from_golden(lmpc, g, 3)
+    assert qp.kernel_name == "row|wave"
+    rng = np.random.default_rng(31)
+    N = 4096
+    theta = g["theta"][rng.integers(0, len(g["theta"]), N)] * rng.uniform(0.3, 1.3, (N, 1))
+    th_d = torch.from_numpy(theta).cuda()
+    x_ref, ef_ref = qp.solve_device(th_d)
+    torch.cuda.synchronize()
+    x_ref, ef_ref = x_ref.clone(), ef_ref.clone()
+    qp = _qp_from_golden(lmpc, g, 3)                       # a fresh handle: its first calls are the captured ones
+    qp.reserve(N)
+    xs = [torch.zeros((N, qp.nout), dtype=torch.float64, device="cuda") for _ in range(2)]
+    fs = [torch.zeros(N, dtype=torch.int32, device="cuda") for _ in range(2)]
+    st = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(graph, stream=st):
+            for q in range(2):
+                qp.solve_device(th_d, x=xs[q], exitflag=fs[q], stream=st.cuda_stream)
+    for rep in range(3):
+        for q in range(2):
+            xs[q].zero_(); fs[q].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for q in range(2):
+            assert torch.equal(xs[q], x_ref) and torch.equal(fs[q], ef_ref)
+    qp.check()
