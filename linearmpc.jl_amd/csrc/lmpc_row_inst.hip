@@ -24,7 +24,9 @@ constexpr RowShape kRowShapes[] = {
 // ... with branch and bound (rows flagged BINARY)
 constexpr RowShape kRowShapesBnb[] = {
     {1, 1, 2, 16},      // n <= 16, m <= 32, <= 16 rows (the satellite example at Np = 4: n = m = 12)
-    {3, 4, 4, 48},      // n <= 64, m <= 64, <= 48 rows (BASELINE config 5, satellite Np = 20: n = m = 60, 40 binaries -- first of two passes)
+    {3, 4, 4, 44},      // n <= 64, m <= 64, <= 44 rows (BASELINE config 5, satellite Np = 20: n = m = 60, 40 binaries -- first of two
+                        // passes; eight wavefronts per CU in binary32)
+    {3, 4, 4, 48},      // ... <= 48 rows (seven)
 };
 
 bool shape_covers(const RowShape &sh, int n, int m, int cap) {
@@ -48,7 +50,7 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bo
         const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS, (int)rs);
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
             if (64 * nwv > row_launch_bound(sh.MS, sh.S, (int)rs)) continue;
-            const int ps = bnb ? row_ps4(sh.CAPP, nwv) : row_ps(sh.CAPP, nwv);
+            const int ps = (bnb && row_copy16(sh.CAPP, (int)rs)) ? row_ps4(sh.CAPP, nwv) : row_ps(sh.CAPP, nwv);
             if (ps < 0) continue;
             const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
@@ -217,8 +219,10 @@ int row_bnb_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs) {
     // ("wave_two_pass" 1 with "wave_cap1" c: first pass at min(c, 48) rows whatever the binaries leave -- tests of the listing)
     if (h->waveTwoPass > 0 && h->waveCap1 > 0)
         return row_launch_for(h, h->waveCap1 < 48 ? h->waveCap1 : 48, rs, &rl, true) ? (h->waveCap1 < 48 ? h->waveCap1 : 48) : 0;
-    if (h->waveTwoPass == 0 || h->nBinary + 8 > 48 || full <= 52) return 0;
-    return row_launch_for(h, 48, rs, &rl, true) ? 48 : 0;
+    if (h->waveTwoPass == 0 || full <= 52) return 0;
+    // 44 rows where that leaves four beyond the binaries (config 5: no search of 10^5 goes beyond 42), else 48
+    const int c1 = h->nBinary + 4 <= 44 ? 44 : 48;
+    return row_launch_for(h, c1, rs, &rl, true) ? c1 : 0;
 }
 #endif
 
@@ -245,6 +249,7 @@ int launch_row_bnb(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R
     RowLaunch rl;
     if (!row_launch_for(h, cap, sizeof(R), &rl, true)) return fail(h, LMPC_ERR_UNSUPPORTED, "lmpc: no row-kernel instantiation");
     if (rl.shape == 0) return launch_row_shape<R, 1, 1, 2, 16, true>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass);
+    if (rl.shape == 1) return launch_row_shape<R, 3, 4, 4, 44, true>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass);
     return launch_row_shape<R, 3, 4, 4, 48, true>(h, rl, dC, nprob, theta, x, flag, iters, active, st, cap, pass);
 }
 template int launch_row_bnb<LMPC_ROW_REAL>(lmpc_handle *, const LMPC_ROW_REAL *, int64_t, const LMPC_ROW_REAL *, LMPC_ROW_REAL *, int32_t *,

@@ -153,14 +153,20 @@ constexpr int kRowBig = 0x7fffffff;
 __host__ __device__ constexpr int rowp_p0(int t) { return t & ~3; }
 __host__ __device__ constexpr int rowp_cb(int capp, int t) { return 4 * (t >> 2) * capp - 8 * (t >> 2) * ((t >> 2) - 1) + (t & 3) * (capp - 4 * (t >> 2)); }
 // (48 rows: every column one entry longer than its rows need -- odd lengths, without which no order separates the starts)
-__host__ __device__ constexpr int rowp_size(int capp) { return capp == 48 ? 1291 : rowp_cb(capp, capp - 1); }      // columns 0 .. capp-2
+__host__ __device__ constexpr int rowp_size(int capp) { return capp == 48 ? 1291 : (capp == 44 ? 1095 : rowp_cb(capp, capp - 1)); }      // columns 0 .. capp-2
 __host__ __device__ constexpr int rowp_cbm(int capp, int t) {
     constexpr int k31[30] = {379, 152, 183, 0, 237, 485, 458, 210, 318, 431, 102, 260, 121, 19, 348, 49,
                              507, 79, 275, 64, 329, 390, 401, 30, 282, 292, 408, 492, 295, 285};
     constexpr int k48[47] = {807, 0, 898, 687, 117, 264, 1001, 758, 605, 1164, 430, 1242, 356, 219, 467, 1201,
                              638, 956, 389, 1063, 314, 543, 1030, 34, 160, 849, 923, 1123, 72, 505, 285, 564,
                              177, 824, 51, 484, 713, 1085, 700, 1098, 135, 126, 514, 1072, 182, 319, 5};
+    // (44 rows: the same, for searches whose working sets stay within the binaries + 4 rows -- small enough for EIGHT
+    // wavefronts' factors per CU next to M' in binary32)
+    constexpr int k44[43] = {322, 9, 776, 277, 525, 223, 1050, 363, 620, 867, 400, 983, 929, 182, 830, 484,
+                             554, 583, 896, 136, 713, 107, 645, 451, 68, 30, 797, 1004, 662, 946, 417, 47,
+                             675, 731, 688, 149, 232, 77, -36, 426, 82, 718, 1009};
     if (capp == 48) return k48[t < 46 ? t : 46];
+    if (capp == 44) return k44[t < 42 ? t : 42];
     return capp == 31 ? k31[t < 30 ? t : 29] : rowp_cb(capp, t) - rowp_p0(t);
 }
 // reals between the factors of two problems, for nwv wavefronts per workgroup: the two DPP rows a 32-lane LDS phase
@@ -170,6 +176,8 @@ __host__ __device__ constexpr int row_ps(int capp, int nwv) {
     while ((nwv * ps) % 32 != 16) ps++;
     return ps;
 }
+// factors copied as 16-byte vectors (branch and bound's snapshots)?  Not the binary32 44-row shape: see row_kernel
+__host__ __device__ constexpr bool row_copy16(int capp, int rs) { return !(capp == 44 && rs == 4); }
 // ... and a multiple of four on top (branch and bound copies factors as 16-byte vectors); -1: no such spacing for this nwv
 __host__ __device__ constexpr int row_ps4(int capp, int nwv) {
     int ps = (rowp_size(capp) + 3) & ~3;
@@ -289,7 +297,9 @@ __host__ __device__ constexpr int rw_bm_cols(int s, int t) {
 template <typename R, int S, int NS, int MS, int CAPP, bool BNB = false>
 __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribute__((amdgpu_waves_per_eu(row_waves_per_simd(S, MS, (int)sizeof(R))))) void row_kernel(const RowParams<R> prm) {
     static_assert(S >= 1 && S <= 4, "one to four slots of working-set positions");
-    static_assert(CAPP <= 16 * S && CAPP >= 16 * S - 1, "rows of the factor live on S slots; a lane beyond the last row must land on padding");
+    // (lanes beyond the last row -- one with 31 / 47 rows, four with 44 -- read whatever lies behind a column: finite values
+    // that stay in those lanes, see the masks where a sweep's result is kept)
+    static_assert(CAPP <= 16 * S && CAPP > 16 * (S - 1), "rows of the factor live on S slots");
     // the launch's parameter block as the rare phases read it (the same bytes as `prm`)
 #if defined(__HIP_DEVICE_COMPILE__)
     const RowParams<R> *kparg = (const RowParams<R> *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -608,7 +618,10 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
     // lanes for one row of the wavefront after the other (seldom more than one row of a wavefront needs it at once): six
     // instructions a copy where a row-by-row one by the row's own 16 lanes takes 120.  Memory -> LDS without registers
     // (global_load_lds: wave-uniform LDS base + 16 bytes per lane), so that a restore waits for memory once.
-    constexpr int VW = 16 / (int)sizeof(R), FLV = (rowp_size(CAPP) + VW - 1) / VW, FLK = (FLV + 63) / 64;
+    // (the binary32 44-row shape copies word by word: eight wavefronts per workgroup leave no spacing of the factors that is
+    // both a multiple of four and 16 banks apart, row_copy16)
+    constexpr int VB = row_copy16(CAPP, (int)sizeof(R)) ? 16 : 4;
+    constexpr int VW = VB / (int)sizeof(R), FLV = (rowp_size(CAPP) + VW - 1) / VW, FLK = (FLV + 63) / 64;
     typedef R rw_vec __attribute__((ext_vector_type(VW)));
     auto uni64 = [&](const void *ptr, int gg) -> unsigned long long {
         const unsigned long long v = (unsigned long long)ptr;
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                         const int v = lane + 64 * q;
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass knows neither the instruction nor the address space)
                         if (v < FLV)
-                            __builtin_amdgcn_global_load_lds(gsrc + v, (__attribute__((address_space(3))) void *)(lds + lgg + 64 * q * VW), 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds(gsrc + v, (__attribute__((address_space(3))) void *)(lds + lgg + 64 * q * VW), VB, 0, 0);
 #else
                         (void)gsrc; (void)lgg; (void)v;
 #endif
@@ -1446,7 +1459,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                 const int namaxQ = rw_max4((ap || ry) ? na : 0);
                 sweep_fwd(q, namaxQ);
 #pragma unroll
-                for (int s = 0; s < S; s++) y[s] = ry ? q[s] : y[s];
+                for (int s = 0; s < S; s++) y[s] = ry ? (pos[s] < CAPP ? q[s] : (R)0) : y[s];
                 ydirty = ry ? 0 : ydirty;
                 R l[S];
 #pragma unroll
