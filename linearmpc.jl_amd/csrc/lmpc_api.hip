@@ -544,7 +544,7 @@ int wave_probe(lmpc_handle *h, const double *theta, int64_t nprob, hipStream_t s
     if (rc == LMPC_OK && h->dStat && h->hStat) {
         unsigned long long raw[64 * 16];
         if (hipMemcpyAsync(raw, h->dStat, sizeof(raw), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < 5; q++) {
                 unsigned long long sum = 0ull;
                 for (int sh = 0; sh < 64; sh++) sum += raw[sh * 16 + q];
                 h->hStat[q] = sum;                    // what the next launch would have published by itself

@@ -16,6 +16,8 @@ constexpr RowShape kRowShapes[] = {
     {1, 1, 4, 16},      // n <= 16, m <= 64, working sets <= 16 rows (the reference's mass_spring example: n = 10, m = 63)
     {2, 2, 6, 31},      // n <= 32, m <= 96, <= 31 rows (BASELINE config 3: n = 30, m = 84)
     {2, 2, 6, 32},      // ... <= 32 rows
+    {1, 4, 10, 16},     // n <= 64, m <= 160, <= 16 rows: two wavefronts per SIMD (256 registers), eight per CU next to 67 KB of M'
+                        // (pendulum_N50: 99 % of the points that iterate stay within 16 rows)
     {2, 4, 10, 31},     // n <= 64, m <= 160, <= 31 rows (the reference's benchmark class at N = 50: first of two passes -- at 31
                         // rows, the capacity whose column order is free of bank conflicts)
     {2, 4, 10, 32},     // ... <= 32 rows
@@ -188,6 +190,9 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
     // where it is the default (measured, tools/row_check.py): every shape built -- config 3 runs 1.9x the wavefront kernel,
     // soft_doc (n = 10, SOFT rows, 12 iterations) 1.7x, mass_spring behind the tiers pass level, the ten-slot shape (one
     // wavefront per SIMD; pendulum_N50 behind the screening pass) 1.2x
+    if (h->waveTwoPass > 0 && h->waveCap1 > 0 && h->waveCap1 < full && h->bigPath) {      // (a first pass at the caller's capacity)
+        if (row_launch_for(h, h->waveCap1, rs, &rl)) cap = h->waveCap1;
+    } else
     if (full <= 32 && row_launch_for(h, full, rs, &rl)) cap = full;
     else if (full > 32 && h->bigPath && h->waveTwoPass != 0) {
         // first of two passes at 31 rows: when at most 1 in 20 of the working sets seen lately went beyond 24 (the
@@ -196,7 +201,13 @@ int row_pass_cap(lmpc_handle *h, int64_t nprob, size_t rs, bool warm, bool gram,
         wave_stat_read(h, sum);
         const bool known = sum[0] >= 1000ull;
         const bool fits = known && (sum[0] - sum[2]) * 20ull <= sum[0];
-        if ((h->rowKernel > 0 || fits) && row_launch_for(h, 31, rs, &rl)) cap = 31;
+        // ... at 16 rows for the ten-slot class when 98 of 100 problems of the handle's life stayed within them (the one-slot
+        // shape: eight wavefronts per CU instead of four -- pendulum_N50 1.33 -> 1.16 ms per 2e5)
+        unsigned long long tot = 0ull, le16 = 0ull;
+        if (h->hStat) { for (int q = 0; q < 4; q++) tot += h->hStat[q]; le16 = h->hStat[4]; }
+        const bool fits16 = tot >= 1000ull && le16 <= tot && (tot - le16) * 50ull <= tot && (h->P.n > 32 || h->P.m > 96);
+        if (fits16 && row_launch_for(h, 16, rs, &rl)) cap = 16;
+        else if ((h->rowKernel > 0 || fits) && row_launch_for(h, 31, rs, &rl)) cap = 31;
     }
     return cap;
 }
@@ -236,7 +247,8 @@ int launch_row(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta, R *x,
         case 0: return LMPC_ROW(1, 1, 4, 16);
         case 1: return LMPC_ROW(2, 2, 6, 31);
         case 2: return LMPC_ROW(2, 2, 6, 32);
-        case 3: return LMPC_ROW(2, 4, 10, 31);
+        case 3: return LMPC_ROW(1, 4, 10, 16);
+        case 4: return LMPC_ROW(2, 4, 10, 31);
         default: return LMPC_ROW(2, 4, 10, 32);
     }
 #undef LMPC_ROW

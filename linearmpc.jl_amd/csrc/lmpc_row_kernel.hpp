@@ -215,16 +215,14 @@ __host__ __device__ constexpr int row_bnb_depth_max(int ms) { return (16 * ms < 
 // slots; the ten-slot one takes 256 (one per SIMD: its bounds and row values alone are 60 registers, and its M' leaves
 // LDS for five wavefronts' factors anyway)
 // ... and the three-slot shape in binary64 (branch and bound at 48 rows: 300 + registers)
-#ifndef LMPC_ROW_WIDE10
-#define LMPC_ROW_WIDE10 0        // (experiment: the ten-slot shape budgeted for two wavefronts per SIMD)
-#endif
-__host__ __device__ constexpr int row_launch_bound(int ms, int s = 2, int rs = 4) { return ((ms > 6 && !LMPC_ROW_WIDE10) || (s >= 3 && rs == 8)) ? 256 : 512; }
+// (the ONE-slot shape with ten constraint slots -- a first pass of 16 rows -- fits 256 registers: two per SIMD)
+__host__ __device__ constexpr int row_launch_bound(int ms, int s = 2, int rs = 4) { return ((ms > 6 && s >= 2) || (s >= 3 && rs == 8)) ? 256 : 512; }
 // resident wavefronts per SIMD an instantiation is register-budgeted for: three for one slot of positions (small factors:
 // LDS allows them, 168 registers), two for two slots with up to six constraint slots, one beyond
 #ifndef LMPC_ROW_WPS1
 #define LMPC_ROW_WPS1 3
 #endif
-__host__ __device__ constexpr int row_waves_per_simd(int s, int ms, int rs = 4) { return ((ms > 6 && !LMPC_ROW_WIDE10) || (s >= 3 && rs == 8)) ? 1 : (s == 1 ? LMPC_ROW_WPS1 : 2); }
+__host__ __device__ constexpr int row_waves_per_simd(int s, int ms, int rs = 4) { return ((ms > 6 && s >= 2) || (s >= 3 && rs == 8)) ? 1 : ((s == 1 && ms <= 6) ? LMPC_ROW_WPS1 : 2); }
 
 // One sweep step as ONE statement of inline assembly (no builtin reaches v_fmac_f64_dpp, and the wait states have to sit
 // right in front of the instruction): NOP + 1 wait states (2 behind a vector instruction that wrote `src`; the compiler
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
     {
         const RowParams<R> *a = RW_ARGS();
         if (blockIdx.x == 0 && threadIdx.x == 0) { *a->queue_next = 0; *a->ovf_next = 0; *a->ovf_next1 = 0; }
-        if (a->stat != nullptr && a->stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+        if (a->stat != nullptr && a->stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 5) {
             unsigned long long sum = 0ull;
             for (int sidx = 0; sidx < 64; sidx++) sum += a->stat[sidx * 16 + threadIdx.x];
             a->stat_host[threadIdx.x] = sum;
@@ -802,17 +800,18 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                     R tb[NTHB];
 #pragma unroll
                     for (int t = 0; t < NTHB; t++) tb[t] = th[t < nth ? t : nth - 1];
-                    rw_static_for<0, NTHB / 4>([&](auto B) {
-                        constexpr int t0 = decltype(B)::value * 4;
+                    constexpr int DTB = (S == 1 && MS >= 10) ? 2 : 4;     // (columns per round trip: fewer where registers are short)
+                    rw_static_for<0, NTHB / DTB>([&](auto B) {
+                        constexpr int t0 = decltype(B)::value * DTB;
                         if (t0 < nth) {
                             RW_BLOCK();
-                            R dv[4][MS];
+                            R dv[DTB][MS];
 #pragma unroll
-                            for (int q = 0; q < 4; q++)
+                            for (int q = 0; q < DTB; q++)
 #pragma unroll
                                 for (int r = 0; r < MS; r++) dv[q][r] = ldc(prm.P.oDth + (t0 + q < nth ? t0 + q : nth - 1), jc[r] * nth);
 #pragma unroll
-                            for (int q = 0; q < 4; q++)
+                            for (int q = 0; q < DTB; q++)
                                 if (t0 + q < nth) {
 #pragma unroll
                                     for (int r = 0; r < MS; r++) b[r] = wv_fma(dv[q][r], tb[t0 + q], b[r]);
@@ -1082,7 +1081,9 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
 #define LMPC_ROW_CHK6 2
 #endif
             // (binary32 with four constraint slots: rows of 16 bytes per lane, four of them in flight measured 3 % faster)
-            constexpr int CHK = (sizeof(R) == 4 && MS == 4) ? 4 : LMPC_ROW_CHK6, NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
+            // (the one-slot shape with ten constraint slots -- two wavefronts per SIMD on 256 registers -- one row ahead: two
+            // spill into the loop)
+            constexpr int CHK = (sizeof(R) == 4 && MS == 4) ? 4 : ((S == 1 && MS >= 10) ? 1 : LMPC_ROW_CHK6), NBK = 16 * NS / CHK;   // (CHK divides 4: the staged M' has ceil4(n) rows)
             {
                 R mn[CHK][MS];
                 constexpr int PW = (sizeof(R) == 4 && MS % 4 == 0) ? 4 : 2;      // entries per load (16 bytes where they line up)
@@ -1657,17 +1658,25 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                         RW_BLOCK();
                     }
                     R xs = (R)0;
-                    R rv[16 * NS];                                   // (this output's row of R^-1 in one batch: L2 round trips)
+                    // (this output's row of R^-1 in batches of 32 entries: L2 round trips; beyond n: u_c = 0)
+                    constexpr int RVB = 16 * NS < 32 ? 16 * NS : 32;
+                    rw_static_for<0, 16 * NS / RVB>([&](auto H) {
+                        constexpr int h0 = decltype(H)::value * RVB;
+                        if (h0 < n) {
+                            R rv[RVB];
 #pragma unroll
-                    for (int c = 0; c < 16 * NS; c++) rv[c] = ldc(prm.P.oRout, lo * n + (c < n ? c : n - 1));   // (beyond n: u_c = 0)
-                    rw_static_for<0, 16 * NS / 4>([&](auto B) {
-                        constexpr int c0 = decltype(B)::value * 4;
-                        if (c0 < n) {
-                            RW_BLOCK();
-                            rw_static_for<0, 4>([&](auto Q) {
-                                constexpr int c = c0 + decltype(Q)::value;
-                                xs = wv_fma(rv[c], rw_bc<c>(u[c >> 4]), xs);
+                            for (int c = 0; c < RVB; c++) rv[c] = ldc(prm.P.oRout, lo * n + (h0 + c < n ? h0 + c : n - 1));
+                            rw_static_for<0, RVB / 4>([&](auto B) {
+                                constexpr int c0 = decltype(B)::value * 4;
+                                if (h0 + c0 < n) {
+                                    RW_BLOCK();
+                                    rw_static_for<0, 4>([&](auto Q) {
+                                        constexpr int c = h0 + c0 + decltype(Q)::value;
+                                        xs = wv_fma(rv[c - h0], rw_bc<c>(u[c >> 4]), xs);
+                                    });
+                                }
                             });
+                            RW_BLOCK();
                         }
                     });
                     const R xo = xs + sh;
@@ -1694,8 +1703,10 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                 if (a->exitflag != nullptr) a->exitflag[pid] = flag;
                 if (a->iters != nullptr) a->iters[pid] = iter;
                 if (listed) a->ovf_list[atomicAdd(a->ovf_count, 1)] = (int32_t)pid;
-                if (a->stat != nullptr && !listed)
+                if (a->stat != nullptr && !listed) {
                     atomicAdd(&a->stat[(myrow & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
+                    if (napk <= 16) atomicAdd(&a->stat[(myrow & 63) * 16 + 4], 1ull);      // (... and how many stayed within 16 rows)
+                }
             }
             // the factor's rows back to zeros: the next problem of this row starts on a factor of zeros
             const int nclr = rw_max4(fn ? na : 0);

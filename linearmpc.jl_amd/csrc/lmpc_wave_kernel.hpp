@@ -234,7 +234,7 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : ((!BNB && MR <= 2 && s
     // closed-loop step 45 us -- a word takes about 90 atomics per microsecond)
     // (the shards are summed here: four stores into host memory per launch -- 256 of them, one per shard counter, took a
     // launch 10 us to retire over PCIe)
-    if (stat != nullptr && stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+    if (stat != nullptr && stat_host != nullptr && blockIdx.x == 0 && threadIdx.x < 5) {
         unsigned long long sum = 0ull;
         for (int sidx = 0; sidx < 64; sidx++) sum += stat[sidx * 16 + threadIdx.x];
         stat_host[threadIdx.x] = sum;
@@ -1360,8 +1360,10 @@ __attribute__((amdgpu_waves_per_eu((BNB && MR <= 2) ? 3 : ((!BNB && MR <= 2 && s
         }
         // (one fire-and-forget atomic per finished problem, on the wavefront's shard: counters kept in registers across
         // the problems of a wavefront cost the kernel more -- spills -- than these)
-        if (stat != nullptr && lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr))
+        if (stat != nullptr && lane == 0 && !(flag == EXIT_WSCAP && ovf_list != nullptr)) {
             atomicAdd(&stat[((blockIdx.x * nwv + wv) & 63) * 16 + (napk <= 24 ? 0 : (napk <= 32 ? 1 : (napk <= 48 ? 2 : 3)))], 1ull);
+            if (napk <= 16) atomicAdd(&stat[((blockIdx.x * nwv + wv) & 63) * 16 + 4], 1ull);   // (... and how many within 16 rows: the row kernel's smallest first pass)
+        }
         WVT(14);                                 // (trace: masks, flags, kept state)
         cont = more && warm != nullptr;
         if (!cont) clear_rows(1, na);            // ZP: the next solve starts on a factor of zeros
