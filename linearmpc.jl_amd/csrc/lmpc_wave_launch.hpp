@@ -475,7 +475,18 @@ int launch_wave_inst(lmpc_handle *h, const R *dC, int64_t nprob, const R *theta,
                 h->wavePass = 1;
                 rc = launch_row<R>(h, dC, nprob, theta, x, flag, iters, active, st, rcap, 1);
                 h->wavePass = 2;
+                // (what the row kernel lists is a handful of long solves: the second pass is a latency chain, so it takes the
+                // highest staging level that fits with small workgroups instead of the most wavefronts per CU --
+                // pendulum_N50: 0.22 -> 0.12 ms for the 327 of 2e5 points beyond 16 rows)
                 cfg = wave_config(h, sizeof(R));
+                if (h->waveLevel < 0 && h->waveNwv <= 0) {
+                    for (int lv = 3; lv >= 1; lv--) {
+                        h->waveLevel = lv; h->waveNwv = 2;
+                        const WaveConfig c2 = wave_config(h, sizeof(R));
+                        if (c2.level >= 1) { cfg = c2; break; }
+                    }
+                    h->waveLevel = -1; h->waveNwv = 0;
+                }
                 if (rc == LMPC_OK) rc = dispatch();
                 h->wavePass = 0;
             }
