@@ -35,7 +35,7 @@ bool shape_covers(const RowShape &sh, int n, int m, int cap) {
     return n <= 16 * sh.NS && m <= 16 * sh.MS && cap <= sh.CAPP && m <= 256 /* mask words on 16 lanes */;
 }
 
-struct RowLaunch { int shape, nwv, blocks, ps; size_t lds; };
+struct RowLaunch { int shape, nwv, blocks, ps; size_t lds; int aux; };
 
 bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bool bnb = false) {
     const int n = h->P.n, m = h->P.m;
@@ -47,21 +47,29 @@ bool row_launch_for(const lmpc_handle *h, int cap, size_t rs, RowLaunch *out, bo
         if (bnb && h->nBinary > row_bnb_depth_max(sh.MS)) continue;
         // most wavefronts per CU (each carries four problems; two per SIMD is what the registers allow); the staged M' is
         // shared by a workgroup's wavefronts
-        RowLaunch best{-1, 0, 0, 0, 0};
+        RowLaunch best{-1, 0, 0, 0, 0, 0};
         int bestWaves = 0;
         const size_t mt = (size_t)((n + 3) & ~3) * row_mpad(sh.MS, (int)rs);
         for (int nwv : {8, 7, 6, 5, 4, 3, 2, 1}) {
             if (64 * nwv > row_launch_bound(sh.MS, sh.S, (int)rs)) continue;
             const int ps = (bnb && row_copy16(sh.CAPP, (int)rs)) ? row_ps4(sh.CAPP, nwv) : row_ps(sh.CAPP, nwv);
             if (ps < 0) continue;
-            const size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
+            size_t lds = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP) + 16;
             if (lds > kLdsMax) continue;
+            // ten-slot shapes: the per-problem constants in LDS too (row_kernel: AUXS) -- or a smaller workgroup
+            int aux = 0;
+            if (sh.MS >= 10) {
+                const size_t front = rs * (32 + mt + (size_t)nwv * 4 * ps + 2) + sizeof(int32_t) * ((size_t)m + sh.CAPP);
+                lds = row_aux_offset(front) + rs * (size_t)row_aux_reals(h->W) + 16;
+                if (lds > kLdsMax) continue;
+                aux = 1;
+            }
             int blocks = (int)(kLdsMax / lds);
             const int maxw = 4 * row_waves_per_simd(sh.S, sh.MS, (int)rs);
             if (blocks * nwv > maxw) blocks = maxw / nwv;
             if (blocks < 1) continue;
             const int waves = blocks * nwv;
-            if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, ps, lds}; }
+            if (waves > bestWaves) { bestWaves = waves; best = RowLaunch{q, nwv, blocks, ps, lds, aux}; }
         }
         if (best.shape < 0) return false;
         *out = best;
@@ -159,6 +167,7 @@ int launch_row_shape(lmpc_handle *h, const RowLaunch &rl, const R *dC, int64_t n
     prm.queue_next = queueNext; prm.ovf_next = p2Next; prm.ovf_next1 = p1Next;
     prm.stat = BNB ? nullptr : h->dStat; prm.stat_host = BNB ? nullptr : h->dStatHost;
     prm.bnb_r = bnbR; prm.bnb_i = bnbI; prm.bnb_depth = bdepth;
+    prm.aux = rl.aux;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * rl.nwv), rl.lds, st, prm);
     h->waveCtrSet ^= 1;
     HIP_TRY(h, hipGetLastError());

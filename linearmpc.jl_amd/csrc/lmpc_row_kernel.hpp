@@ -203,7 +203,12 @@ template <typename R> struct RowParams {
     int32_t *ovf_list, *ovf_count, *queue_next, *ovf_next, *ovf_next1;
     unsigned long long *stat; volatile unsigned long long *stat_host;
     R *bnb_r; int32_t *bnb_i; int bnb_depth;      // branch and bound: snapshot slots (row_snap_reals / row_snap_ints each), depths per row
+    int aux;                                      // (ten-slot shapes: the per-problem constants are staged in LDS; the host has sized for them)
 };
+// bytes of LDS in front of the staged constants (row_aux_offset) and their size in reals: everything between the bounds
+// and the full Gram matrix of the constant pack (lmpc_api.hip: odu, odl, oDth, oRout, ox0, oXth are contiguous)
+__host__ __device__ constexpr size_t row_aux_offset(size_t front) { return (front + 15) & ~(size_t)15; }
+__host__ __device__ inline int row_aux_reals(const WaveLayout &P) { return P.oGf - P.odu; }
 // what one (lazy) snapshot of a branch-and-bound node takes, per problem row of the grid and search depth: reals = right-hand
 // side, D, 1/D, y per position and the padded triangle as it lies in LDS; ints = the positions' rows, one size
 __host__ __device__ constexpr int row_snap_reals(int s, int capp) { return 64 * s + ((rowp_size(capp) + 3) & ~3); }
@@ -350,6 +355,17 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
     }
     for (int i = threadIdx.x; i < nwv * 4 * PS + 2; i += blockDim.x) lds[oL + i] = (R)0;
     for (int i = threadIdx.x; i < m; i += blockDim.x) sens[i] = prm.Sg[i];
+    // Ten constraint slots (the reference's benchmark class): a row takes or ends a problem every fifth trip there, and what
+    // that reads per problem -- 70 entries of Dth a lane, the bounds, a row of R^-1 -- came from L2 in four to six round
+    // trips with the other three rows of the wavefront waiting (a third of the kernel's time at N = 50).  Where LDS has
+    // The ten-slot shapes stage these constants as well (the host sizes the workgroup so that they fit, or leaves the
+    // problem to the wavefront kernel) and read them by a 32-bit LDS index like everything else.
+    constexpr bool AUXS = MS >= 10;
+    const int oAux = (int)(row_aux_offset((size_t)((const unsigned char *)(cbt + CAPP) - lds_raw)) / sizeof(R)) - prm.P.odu;
+    if constexpr (AUXS) {
+        const int na_ = row_aux_reals(prm.P);
+        for (int i = threadIdx.x; i < na_; i += blockDim.x) lds[oAux + prm.P.odu + i] = C[prm.P.odu + i];
+    }
     rw_static_for<0, CAPP - 1>([&](auto T) { if (threadIdx.x == 0) cbt[decltype(T)::value] = rowp_cbm(CAPP, decltype(T)::value); });
     __syncthreads();
 
@@ -361,6 +377,11 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
     const __amdgpu_buffer_rsrc_t crs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<R *>(C), 0, prm.P.nC * (int)sizeof(R), 0x00020000);
     auto ldc = [&](int soff, int voff) -> R { return wv_bufld(crs, (unsigned)voff, (unsigned)soff, R()); };   // C[soff + voff]
+    // ... the per-problem constants (bounds, Dth, R^-1 rows, x0, Xth): from LDS where they are staged (ten-slot shapes)
+    auto ldk = [&](int soff, int voff) -> R {
+        if constexpr (AUXS) return lds[oAux + soff + voff];
+        else return ldc(soff, voff);
+    };
     // The unrolled chains below run in BLOCKS of a few steps behind one wave-uniform test each; inside a block every step
     // runs (steps beyond a row's sizes multiply by the zeros the padding guarantees).  The empty statement keeps the
     // compiler from folding a block's test into selects -- which turns the whole unrolled chain into one basic block
@@ -796,11 +817,11 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                     R b[MS];
 #pragma unroll
                     for (int r = 0; r < MS; r++) b[r] = (R)0;
-                    constexpr int NTHB = 16;
+                    constexpr int NTHB = (MS >= 10) ? 8 : 16;        // (ten-slot shapes: registers are short; longer records take the tail loop)
                     R tb[NTHB];
 #pragma unroll
                     for (int t = 0; t < NTHB; t++) tb[t] = th[t < nth ? t : nth - 1];
-                    constexpr int DTB = (S == 1 && MS >= 10) ? 2 : 4;     // (columns per round trip: fewer where registers are short)
+                    constexpr int DTB = (MS >= 10) ? 1 : 4;               // (columns per batch: the ten-slot shapes read Dth from LDS, one at a time)
                     rw_static_for<0, NTHB / DTB>([&](auto B) {
                         constexpr int t0 = decltype(B)::value * DTB;
                         if (t0 < nth) {
@@ -809,7 +830,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
 #pragma unroll
                             for (int q = 0; q < DTB; q++)
 #pragma unroll
-                                for (int r = 0; r < MS; r++) dv[q][r] = ldc(prm.P.oDth + (t0 + q < nth ? t0 + q : nth - 1), jc[r] * nth);
+                                for (int r = 0; r < MS; r++) dv[q][r] = ldk(prm.P.oDth + (t0 + q < nth ? t0 + q : nth - 1), jc[r] * nth);
 #pragma unroll
                             for (int q = 0; q < DTB; q++)
                                 if (t0 + q < nth) {
@@ -821,11 +842,11 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                     for (int t = NTHB; t < nth; t++) {              // (records longer than the batch: one column per round trip)
                         const R tv = th[t];
 #pragma unroll
-                        for (int r = 0; r < MS; r++) b[r] = wv_fma(ldc(prm.P.oDth + t, jc[r] * nth), tv, b[r]);
+                        for (int r = 0; r < MS; r++) b[r] = wv_fma(ldk(prm.P.oDth + t, jc[r] * nth), tv, b[r]);
                     }
 #pragma unroll
                     for (int r = 0; r < MS; r++) {
-                        const R du = ldc(prm.P.odu, jc[r]) + b[r], dl = ldc(prm.P.odl, jc[r]) + b[r];
+                        const R du = ldk(prm.P.odu, jc[r]) + b[r], dl = ldk(prm.P.odl, jc[r]) + b[r];
                         dub[r] = got ? du : dub[r];
                         dlb[r] = got ? dl : dlb[r];
                     }
@@ -1637,13 +1658,13 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                     // the shift x0 + Xth theta first: the parameter record and this output's row of Xth in ONE round trip (a loop
                     // over the nth entries waits for memory once per entry: 12 round trips where one serves)
                     constexpr int NTHF = 16;
-                    R sh = ldc(prm.P.ox0, lo);
+                    R sh = ldk(prm.P.ox0, lo);
                     {
                         R tf[NTHF], xf[NTHF];
 #pragma unroll
                         for (int t = 0; t < NTHF; t++) {
                             tf[t] = th[t < nth ? t : nth - 1];
-                            xf[t] = ldc(prm.P.oXth + (t < nth ? t : nth - 1), lo * nth);
+                            xf[t] = ldk(prm.P.oXth + (t < nth ? t : nth - 1), lo * nth);
                         }
                         rw_static_for<0, NTHF / 4>([&](auto B) {
                             constexpr int t0 = decltype(B)::value * 4;
@@ -1654,7 +1675,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                                     if (t0 + q < nth) sh = wv_fma(xf[t0 + q], tf[t0 + q], sh);
                             }
                         });
-                        for (int t = NTHF; t < nth; t++) sh = wv_fma(ldc(prm.P.oXth + t, lo * nth), th[t], sh);
+                        for (int t = NTHF; t < nth; t++) sh = wv_fma(ldk(prm.P.oXth + t, lo * nth), th[t], sh);
                         RW_BLOCK();
                     }
                     R xs = (R)0;
@@ -1665,7 +1686,7 @@ __global__ __launch_bounds__(row_launch_bound(MS, S, (int)sizeof(R))) __attribut
                         if (h0 < n) {
                             R rv[RVB];
 #pragma unroll
-                            for (int c = 0; c < RVB; c++) rv[c] = ldc(prm.P.oRout, lo * n + (h0 + c < n ? h0 + c : n - 1));
+                            for (int c = 0; c < RVB; c++) rv[c] = ldk(prm.P.oRout, lo * n + (h0 + c < n ? h0 + c : n - 1));
                             rw_static_for<0, RVB / 4>([&](auto B) {
                                 constexpr int c0 = decltype(B)::value * 4;
                                 if (h0 + c0 < n) {
