@@ -3084,3 +3084,19 @@ def test_row_kernel_calls_captured_in_a_graph(lmpc):
         for q in range(2):
             assert torch.equal(xs[q], x_ref) and torch.equal(fs[q], ef_ref)
     qp.check()
+
+
+def test_row_kernel_sixteen_row_first_pass_of_the_benchmark_class(lmpc):
+    # pendulum_N50 (the reference's published benchmark class, docs/src/manual/benchmark.md:4-16): the one-slot shape with
+    # ten constraint slots as a first pass of 16 rows (forced here; by default the handle's statistics choose it), what
+    # outgrows it listed for the wavefront kernel -- identical to the wavefront kernel alone and to the oracle
+    g = load_golden("pendulum_N50")
+    qp = _qp_from_golden(lmpc, g, int(g["nu"]))
+    rng = np.random.default_rng(51)
+    base = g["theta"]
+    N = 6000
+    theta = base[rng.integers(0, len(base), N)] * rng.uniform(0.6, 1.8, (N, 1))
+    qp.set_option("wave_two_pass", 1)
+    qp.set_option("wave_cap1", 16)
+    x, ef, it, act = _row_vs_wave_vs_oracle(lmpc, qp, theta)
+    assert (ef >= 1).mean() > 0.9 and it.max() > 17          # (some points do outgrow 16 rows)
