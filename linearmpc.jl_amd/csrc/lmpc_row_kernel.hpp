@@ -147,13 +147,13 @@ constexpr int kRowBig = 0x7fffffff;
 // so that the 16 columns of a slot of positions start at 16 different offsets modulo 16: a lane that reads its own
 // COLUMN (backward sweep, row append, compaction) then never shares an LDS bank with another lane of its 32-lane phase.
 // In column order the starts collide four ways (8 LDS cycles an access instead of 2: rocprofv3 counted more bank-conflict
-// cycles than LDS instructions).  For 32 and 16 rows every column length is a multiple of four and no order helps; the
-// 48-row layout (binary32 branch and bound: 54 000 conflict cycles per search in column order) therefore pads every
+// cycles than LDS instructions).  For 32, 16, 48 and 44 rows every column length is a multiple of four and no order helps; the
+// 16-, 44- and 48-row layouts (binary32 branch and bound: 54 000 conflict cycles per search in column order) therefore pads every
 // column by one entry and orders them likewise (tools/row_layout.py 48).
 __host__ __device__ constexpr int rowp_p0(int t) { return t & ~3; }
 __host__ __device__ constexpr int rowp_cb(int capp, int t) { return 4 * (t >> 2) * capp - 8 * (t >> 2) * ((t >> 2) - 1) + (t & 3) * (capp - 4 * (t >> 2)); }
 // (48 rows: every column one entry longer than its rows need -- odd lengths, without which no order separates the starts)
-__host__ __device__ constexpr int rowp_size(int capp) { return capp == 48 ? 1291 : (capp == 44 ? 1095 : rowp_cb(capp, capp - 1)); }      // columns 0 .. capp-2
+__host__ __device__ constexpr int rowp_size(int capp) { return capp == 48 ? 1291 : (capp == 44 ? 1095 : (capp == 16 ? 171 : rowp_cb(capp, capp - 1))); }      // columns 0 .. capp-2
 __host__ __device__ constexpr int rowp_cbm(int capp, int t) {
     constexpr int k31[30] = {379, 152, 183, 0, 237, 485, 458, 210, 318, 431, 102, 260, 121, 19, 348, 49,
                              507, 79, 275, 64, 329, 390, 401, 30, 282, 292, 408, 492, 295, 285};
@@ -165,8 +165,11 @@ __host__ __device__ constexpr int rowp_cbm(int capp, int t) {
     constexpr int k44[43] = {322, 9, 776, 277, 525, 223, 1050, 363, 620, 867, 400, 983, 929, 182, 830, 484,
                              554, 583, 896, 136, 713, 107, 645, 451, 68, 30, 797, 1004, 662, 946, 417, 47,
                              675, 731, 688, 149, 232, 77, -36, 426, 82, 718, 1009};
+    // (16 rows likewise: the one-slot shapes counted 0.8 conflict cycles per LDS instruction in column order)
+    constexpr int k16[15] = {69, 0, 30, 52, 13, 82, 105, 118, 127, 136, 154, 145, 92, 35, 87};
     if (capp == 48) return k48[t < 46 ? t : 46];
     if (capp == 44) return k44[t < 42 ? t : 42];
+    if (capp == 16) return k16[t < 14 ? t : 14];
     return capp == 31 ? k31[t < 30 ? t : 29] : rowp_cb(capp, t) - rowp_p0(t);
 }
 // reals between the factors of two problems, for nwv wavefronts per workgroup: the two DPP rows a 32-lane LDS phase

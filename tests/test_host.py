@@ -489,7 +489,7 @@ def test_row_kernel_column_order_tables_are_valid_layouts():
         assert m, name
         return [int(v) for v in m.group(1).replace("\n", " ").split(",")]
 
-    for name, rows, lrow, size in (("k31", 31, 31, None), ("k48", 48, 49, 1291), ("k44", 44, 45, 1095)):
+    for name, rows, lrow, size in (("k31", 31, 31, None), ("k48", 48, 49, 1291), ("k44", 44, 45, 1095), ("k16", 16, 17, 171)):
         cbm = table(name)
         assert len(cbm) == rows - 1
         if size is None:                                    # rowp_cb(capp, capp - 1) of the unpadded layout
